@@ -1,0 +1,87 @@
+/* VP8 boolean entropy decoder (RFC 6386 section 7) -- host feeder, CPU only.
+ *
+ * Behavioural reference: vp8/decoder/dboolhuff.h:76-120 (vp8dx_decode_bool) and
+ * dboolhuff.c:16-60.  Same arithmetic (split = 1 + (((range-1)*prob) >> 8), MSB-first
+ * window, zero bytes past the end of the partition); own structure: a 64-bit window with
+ * `bits` counting the valid bits BELOW the active top byte.
+ */
+#ifndef VP8_BOOLREADER_H
+#define VP8_BOOLREADER_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+typedef struct vp8_boolreader {
+    const uint8_t *cur, *end;
+    uint64_t window;   /* active byte in bits 63..56 */
+    int      bits;     /* valid bits below the top byte; < 0 => refill before next read */
+    uint32_t range;    /* 128..255 after normalisation */
+    int      zero_fill; /* bytes synthesised past the end (stream over-read indicator) */
+} vp8_boolreader;
+
+static inline void vp8br_refill(vp8_boolreader *br)
+{
+    while (br->bits <= 48) {
+        uint64_t byte = 0;
+        if (br->cur < br->end)
+            byte = *br->cur++;
+        else
+            br->zero_fill++;
+        br->window |= byte << (48 - br->bits);
+        br->bits += 8;
+    }
+}
+
+static inline void vp8br_init(vp8_boolreader *br, const uint8_t *data, size_t size)
+{
+    br->cur = data;
+    br->end = data + size;
+    br->window = 0;
+    br->bits = -8;
+    br->range = 255;
+    br->zero_fill = 0;
+    vp8br_refill(br);
+}
+
+static inline int vp8br_get(vp8_boolreader *br, int prob)
+{
+    uint32_t split = 1 + (((br->range - 1) * (uint32_t)prob) >> 8);
+    uint64_t big;
+    int bit, shift;
+    if (br->bits < 0)
+        vp8br_refill(br);
+    big = (uint64_t)split << 56;
+    if (br->window >= big) {
+        br->window -= big;
+        br->range -= split;
+        bit = 1;
+    } else {
+        br->range = split;
+        bit = 0;
+    }
+    shift = __builtin_clz(br->range) - 24;   /* 0..7: renormalise range into 128..255 */
+    br->range <<= shift;
+    br->window <<= shift;
+    br->bits -= shift;
+    return bit;
+}
+
+static inline int vp8br_bit(vp8_boolreader *br) { return vp8br_get(br, 128); }
+
+static inline int vp8br_literal(vp8_boolreader *br, int nbits)
+{
+    int v = 0;
+    while (nbits-- > 0)
+        v = (v << 1) | vp8br_get(br, 128);
+    return v;
+}
+
+/* Bits consumed beyond the real end of the partition (with two bytes of slack for the
+ * decoder's look-ahead): the partition was truncated (cf. vp8dx_bool_error,
+ * dboolhuff.h:131-153). */
+static inline int vp8br_overrun(const vp8_boolreader *br)
+{
+    return br->zero_fill * 8 - (8 + br->bits) > 16;
+}
+
+#endif

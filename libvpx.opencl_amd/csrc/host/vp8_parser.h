@@ -1,0 +1,73 @@
+/* VP8 host feeder: compressed frame -> frame-batched IR (include/vp8_ir.h).
+ *
+ * Pure CPU, no pixel work.  Replaces, for the feeder side only, the reference's
+ *   vp8_decode_frame header part      vp8/decoder/decodframe.c:690-1077
+ *   vp8_decode_mode_mvs               vp8/decoder/decodemv.c:622-672
+ *   vp8_decode_mb_tokens              vp8/decoder/detokenize.c:183-405
+ * Everything a pixel kernel needs leaves through the IR; the pixel path itself lives behind
+ * include/vp8hip.h (HIP) -- this file never touches pixels.
+ */
+#ifndef VP8_PARSER_H
+#define VP8_PARSER_H
+
+#include <stddef.h>
+#include <stdint.h>
+#include "vp8_ir.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* error codes: numeric values of vpx_codec_err_t (vpx/vpx_codec.h:81-132) */
+enum {
+    VP8P_OK = 0,
+    VP8P_ERROR = 1,
+    VP8P_MEM_ERROR = 2,
+    VP8P_UNSUP_BITSTREAM = 5,
+    VP8P_CORRUPT_FRAME = 7,
+    VP8P_INVALID_PARAM = 8
+};
+
+typedef struct vp8_parser vp8_parser;
+
+vp8_parser *vp8_parser_create(void);
+void vp8_parser_destroy(vp8_parser *p);
+
+/* vp8_peek_si (vp8/vp8_dx_iface.c:245-285): key-frame start code + 14-bit dimensions. */
+int vp8_parser_peek(const uint8_t *data, size_t size, int *is_key, int *width, int *height);
+
+/* Step 1: frame tag + frame header (everything up to, not including, per-MB modes).
+ * Fills *hdr.  On a key frame with new dimensions the parser re-allocates its per-MB state.
+ * `data` must stay valid until vp8_parser_decode_mbs returns. */
+int vp8_parser_begin_frame(vp8_parser *p, const uint8_t *data, size_t size, vp8ir_frame_hdr *hdr);
+
+/* Step 2: per-MB modes / motion vectors (first partition) and coefficient tokens (token
+ * partitions) for the frame opened by begin_frame, written to caller-owned arrays sized for
+ * hdr->mb_cols * hdr->mb_rows macroblocks:
+ *   mbs  [n]        always
+ *   coef [n * 400]  int16, column-major 4x4 blocks; only non-skipped MBs are written
+ *   mvs  [n * 16]   inter frames only (may be NULL on key frames)
+ * Returns VP8P_OK, or an error; *corrupt (optional) reports a truncated partition. */
+int vp8_parser_decode_mbs(vp8_parser *p, vp8ir_mb *mbs, int16_t *coef, vp8ir_mv *mvs, int *corrupt);
+
+const char *vp8_parser_error(const vp8_parser *p);
+
+/* Reference-buffer index bookkeeping shared by every decoder built on the parser:
+ * swap_frame_buffers / get_free_fb / ref_cnt_fb (vp8/decoder/onyxd_if.c:238-316). */
+typedef struct vp8_refs {
+    int new_idx, lst_idx, gld_idx, alt_idx;
+    int ref_cnt[4];
+    int show_idx;        /* frame_to_show */
+} vp8_refs;
+
+/* Per frame: get_free -> begin_frame -> (dimensions changed? on_alloc) -> decode -> swap. */
+void vp8_refs_init(vp8_refs *r);                  /* at decoder creation */
+void vp8_refs_on_alloc(vp8_refs *r);              /* vp8_alloc_frame_buffers, alloccommon.c:87-95 */
+int  vp8_refs_get_free(vp8_refs *r);              /* -> new_idx, or -1 */
+void vp8_refs_release_new(vp8_refs *r);           /* frame failed: give new_idx back */
+int  vp8_refs_swap(vp8_refs *r, const vp8ir_frame_hdr *hdr);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

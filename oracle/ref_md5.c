@@ -1,0 +1,86 @@
+/* oracle/ref_md5.c -- TEST INFRASTRUCTURE.  Our harness around the REFERENCE's public
+ * decoder API (linked against oracle/_ref/libvpxref.so, built from /root/reference).
+ *
+ * Prints one line per shown frame in the format of the reference's generated
+ * `decode_to_md5` example (examples/decode_to_md5.txt:28-47):
+ *     "<32 hex>  img-<d_w>x<d_h>-<frame_cnt %04d>.i420"
+ * and, unlike that example (fixed 256 KiB frame buffer, decoder_tmpl.c:53,82), accepts
+ * frames of any size.  Options:
+ *     ref_md5 in.ivf out.md5            per-frame md5 listing
+ *     ref_md5 --time N in.ivf           decode the file N times, print
+ *                                       "frames pixels seconds" (timing brackets only
+ *                                       vpx_codec_decode, like vpxdec.c:1041-1055)
+ *     ref_md5 --dump K in.ivf out.i420  write shown frame K (1-based) as raw I420
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+#define VPX_CODEC_DISABLE_COMPAT 1
+#include "vpx/vpx_decoder.h"
+#include "vpx/vp8dx.h"
+#include "md5_utils.h"
+
+static unsigned rd32(const unsigned char *p) { return p[0] | (p[1] << 8) | (p[2] << 16) | ((unsigned)p[3] << 24); }
+static double now(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
+
+int main(int argc, char **argv) {
+    int reps = 1, timing = 0, dumpk = 0;
+    int ai = 1;
+    if (argc > 2 && !strcmp(argv[1], "--time")) { timing = 1; reps = atoi(argv[2]); ai = 3; }
+    else if (argc > 2 && !strcmp(argv[1], "--dump")) { dumpk = atoi(argv[2]); ai = 3; }
+    if (argc - ai < (timing ? 1 : 2)) { fprintf(stderr, "usage: see header comment\n"); return 2; }
+    FILE *f = fopen(argv[ai], "rb");
+    if (!f) { perror(argv[ai]); return 1; }
+    fseek(f, 0, SEEK_END); long n = ftell(f); fseek(f, 0, SEEK_SET);
+    unsigned char *buf = malloc(n);
+    if (fread(buf, 1, n, f) != (size_t)n) return 1;
+    fclose(f);
+    if (n < 32 || memcmp(buf, "DKIF", 4)) { fprintf(stderr, "not IVF\n"); return 1; }
+    FILE *out = timing ? NULL : fopen(argv[ai + 1], "wb");
+    double secs = 0; long frames = 0; double pixels = 0;
+    for (int r = 0; r < reps; r++) {
+        vpx_codec_ctx_t c;
+        if (vpx_codec_dec_init(&c, vpx_codec_vp8_dx(), NULL, 0)) { fprintf(stderr, "init failed\n"); return 1; }
+        long pos = 32; int cnt = 0;
+        while (pos + 12 <= n) {
+            unsigned sz = rd32(buf + pos); pos += 12;
+            if (pos + sz > n) break;
+            cnt++;
+            double t0 = now();
+            int err = vpx_codec_decode(&c, buf + pos, sz, NULL, 0);
+            secs += now() - t0;
+            if (err) { fprintf(stderr, "decode error frame %d: %s\n", cnt, vpx_codec_error(&c)); return 1; }
+            pos += sz;
+            vpx_codec_iter_t it = NULL; vpx_image_t *img;
+            while ((img = vpx_codec_get_frame(&c, &it))) {
+                frames++; pixels += (double)img->d_w * img->d_h;
+                if (timing) continue;
+                if (dumpk) {
+                    if (cnt != dumpk) continue;
+                    for (int pl = 0; pl < 3; pl++) {
+                        unsigned char *p = img->planes[pl];
+                        unsigned w = pl ? (img->d_w + 1) >> 1 : img->d_w, h = pl ? (img->d_h + 1) >> 1 : img->d_h;
+                        for (unsigned y = 0; y < h; y++, p += img->stride[pl]) fwrite(p, 1, w, out);
+                    }
+                    continue;
+                }
+                MD5Context m; unsigned char d[16];
+                MD5Init(&m);
+                for (int pl = 0; pl < 3; pl++) {
+                    unsigned char *p = img->planes[pl];
+                    unsigned w = pl ? (img->d_w + 1) >> 1 : img->d_w, h = pl ? (img->d_h + 1) >> 1 : img->d_h;
+                    for (unsigned y = 0; y < h; y++, p += img->stride[pl]) MD5Update(&m, p, w);
+                }
+                MD5Final(d, &m);
+                for (int i = 0; i < 16; i++) fprintf(out, "%02x", d[i]);
+                fprintf(out, "  img-%dx%d-%04d.i420\n", img->d_w, img->d_h, cnt);
+            }
+        }
+        vpx_codec_destroy(&c);
+    }
+    if (timing) printf("%ld %.0f %.6f\n", frames, pixels, secs);
+    if (out) fclose(out);
+    free(buf);
+    return 0;
+}

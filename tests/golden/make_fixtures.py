@@ -1,0 +1,155 @@
+#!/usr/bin/env python3
+"""Generate the golden IVF + per-frame MD5 fixtures with the REAL reference.
+
+Runs only in the dev container: needs oracle/_ref/{vpxenc_ref,ref_md5} (built by
+`make -C oracle ref` from /root/reference; see oracle/Makefile).  The outputs
+(tests/golden/*.ivf, *.md5) are data: compressed VP8 streams produced by the
+reference encoder from numpy-synthesised (seeded) I420 input, and the MD5 of every
+frame the reference *decoder* (generic-C path) shows for them, in the reference's
+`decode_to_md5` line format (examples/decode_to_md5.txt:28-47).
+
+Fixture matrix follows SURVEY.md §8c.  Everything is deterministic (single thread,
+fixed seeds); re-running reproduces the files byte for byte.
+
+    python tests/golden/make_fixtures.py [name ...]
+"""
+import hashlib
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REFDIR = os.path.join(ROOT, "oracle", "_ref")
+VPXENC = os.path.join(REFDIR, "vpxenc_ref")
+REFMD5 = os.path.join(REFDIR, "ref_md5")
+
+
+def synth_i420(w, h, frames, seed, noise=6, speed=(1.375, 0.625)):
+    """Moving smooth texture + 32-px checker + moving blocks + uniform noise.
+
+    Sub-pel global motion (so inter MVs hit all eight 1/8-pel chroma phases and
+    the odd and even quarter-pel luma phases), locally moving squares (SPLITMV /
+    intra-in-P candidates), flat regions (DC/V/H/TM) and texture (B_PRED).
+    """
+    rng = np.random.default_rng(seed)
+    pad = 64
+    tw, th = w + 2 * pad + int(abs(speed[0]) * frames) + 8, h + 2 * pad + int(abs(speed[1]) * frames) + 8
+    # smooth texture: sum of a few random sinusoids + coarse noise upsampled
+    yy, xx = np.mgrid[0:th, 0:tw].astype(np.float32)
+    tex = 128 + 40 * np.sin(xx / 37.0 + yy / 91.0) + 30 * np.cos(xx / 11.0 - yy / 23.0)
+    coarse = rng.uniform(-35, 35, size=(th // 8 + 2, tw // 8 + 2)).astype(np.float32)
+    tex += np.kron(coarse, np.ones((8, 8), np.float32))[:th, :tw]
+    tex += ((xx.astype(np.int32) // 32 + yy.astype(np.int32) // 32) % 2) * 24 - 12
+    cu = 128 + 50 * np.sin(xx / 53.0) * np.cos(yy / 41.0)
+    cv = 128 + 50 * np.cos(xx / 29.0 + yy / 67.0)
+    out = bytearray()
+    nsq = 6
+    sq = rng.uniform(0, 1, size=(nsq, 4))
+    for t in range(frames):
+        ox, oy = pad + speed[0] * t, pad + speed[1] * t
+        ix, iy = int(np.floor(ox)), int(np.floor(oy))
+        fx, fy = ox - ix, oy - iy
+
+        def samp(p, sx, sy, ww, hh, fx=fx, fy=fy):
+            a = p[sy:sy + hh + 1, sx:sx + ww + 1]
+            return ((1 - fy) * ((1 - fx) * a[:-1, :-1] + fx * a[:-1, 1:]) + fy * ((1 - fx) * a[1:, :-1] + fx * a[1:, 1:]))
+
+        y = samp(tex, ix, iy, w, h).copy()
+        u = samp(cu, ix, iy, w, h)[::2, ::2].copy()
+        v = samp(cv, ix, iy, w, h)[::2, ::2].copy()
+        # flat band (favours 16x16 DC/V/H prediction, low-activity loop-filter paths)
+        y[: h // 6, : w // 3] = 90 + 0.1 * np.arange(w // 3)[None, :]
+        for k in range(nsq):
+            s = 24 + int(sq[k, 2] * 40)
+            px = int((sq[k, 0] * (w - s) + (k - 2.5) * 3.25 * t) % max(1, w - s))
+            py = int((sq[k, 1] * (h - s) + (2.5 - k) * 1.75 * t) % max(1, h - s))
+            y[py:py + s, px:px + s] = 40 + 30 * k + 20 * np.sin(np.arange(s) / (2.0 + k))[None, :]
+        if noise:
+            y += rng.integers(-noise, noise + 1, size=y.shape)
+        out += np.clip(np.rint(y), 0, 255).astype(np.uint8).tobytes()
+        ch, cw = (h + 1) // 2, (w + 1) // 2
+        out += np.clip(np.rint(u[:ch, :cw]), 0, 255).astype(np.uint8).tobytes()
+        out += np.clip(np.rint(v[:ch, :cw]), 0, 255).astype(np.uint8).tobytes()
+    return bytes(out)
+
+
+COMMON = ["--ivf", "--i420", "-p", "1", "--lag-in-frames=0", "-t", "1"]
+ALLKEY = ["--kf-max-dist=0", "--kf-min-dist=0"]
+INTER = ["--kf-max-dist=9999", "--auto-alt-ref=0"]
+
+# name: (w, h, frames, seed, noise, encoder args)
+FIXTURES = {
+    # (1) config-1 plumbing stream: 640x360, 10 key frames, profile 0, normal loop filter
+    "kf_640x360": (640, 360, 10, 11, 10, ALLKEY + ["--good", "--cpu-used=4", "--end-usage=cq", "--cq-level=14",
+                                                    "--target-bitrate=6000"]),
+    # (2) headline stream: 1920x1080, 10 key frames, profile 0, loop filter on
+    "kf_1920x1080": (1920, 1080, 10, 7, 6, ALLKEY + ["--good", "--cpu-used=5", "--end-usage=cq", "--cq-level=20",
+                                                      "--target-bitrate=20000"]),
+    # (3) loop filter OFF (q=0 -> filter_level 0) and very dense coefficients
+    "kf_q0_176x144": (176, 144, 4, 3, 12, ALLKEY + ["--good", "--cpu-used=2", "--min-q=0", "--max-q=0",
+                                                     "--target-bitrate=40000"]),
+    # (4) 1080p key + 9 inter frames, 6-tap MC, normal LF
+    "p_1920x1080": (1920, 1080, 10, 7, 6, INTER + ["--good", "--cpu-used=5", "--end-usage=cq", "--cq-level=20",
+                                                    "--target-bitrate=8000"]),
+    # (5) profiles 1-3 (bilinear MC / simple LF / full-pixel), SPLITMV, 4 token partitions
+    "p_prof1_640x360": (640, 360, 10, 21, 8, INTER + ["--good", "--cpu-used=0", "--profile=1", "--token-parts=2",
+                                                       "--target-bitrate=1500"]),
+    "p_prof2_640x360": (640, 360, 10, 22, 8, INTER + ["--good", "--cpu-used=0", "--profile=2", "--token-parts=2",
+                                                       "--target-bitrate=1500"]),
+    "p_prof3_640x360": (640, 360, 10, 23, 8, INTER + ["--good", "--cpu-used=0", "--profile=3", "--token-parts=2",
+                                                       "--target-bitrate=1500"]),
+    # profile 0 with best-quality search: SPLITMV 16/8x8/4x4, intra MBs in P frames, 8 partitions
+    "p_split_352x288": (352, 288, 12, 31, 8, INTER + ["--best", "--cpu-used=0", "--token-parts=3",
+                                                       "--target-bitrate=900"]),
+    # (6) sizes that are not multiples of 16 (crop) incl. odd width/height
+    "p_odd_130x98": (130, 98, 8, 41, 8, INTER + ["--good", "--cpu-used=1", "--target-bitrate=300"]),
+    "kf_odd_67x45": (67, 45, 3, 42, 8, ALLKEY + ["--good", "--cpu-used=1", "--target-bitrate=300"]),
+    # (7) 4K key frames (config 5)
+    "kf_3840x2160": (3840, 2160, 3, 5, 4, ALLKEY + ["--good", "--cpu-used=6", "--end-usage=cq", "--cq-level=24",
+                                                     "--target-bitrate=30000"]),
+    # golden / alt-ref with hidden (show_frame=0) frames: lagged 2-pass-less ARF
+    "p_arf_176x144": (176, 144, 70, 51, 6, ["--ivf", "--i420", "-p", "2", "-t", "1", "--kf-max-dist=9999",
+                                           "--auto-alt-ref=1", "--lag-in-frames=16", "--good", "--cpu-used=1",
+                                           "--target-bitrate=120", "--arnr-maxframes=5", "--arnr-strength=3"]),
+    # sharpness != 0 (loop-filter limit tables), error-resilient stream
+    "p_sharp_320x240": (320, 240, 8, 61, 10, INTER + ["--good", "--cpu-used=1", "--sharpness=5",
+                                                       "--error-resilient=1", "--target-bitrate=500"]),
+    # low bitrate: high filter levels, many skipped MBs (mb_skip_coeff / skip_lf paths)
+    "p_lowrate_640x360": (640, 360, 10, 71, 4, INTER + ["--good", "--cpu-used=3", "--target-bitrate=150"]),
+}
+
+
+def run(cmd):
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode:
+        sys.stderr.write(r.stdout + r.stderr)
+        raise SystemExit("FAILED: " + " ".join(cmd))
+
+
+def main():
+    names = sys.argv[1:] or list(FIXTURES)
+    for exe in (VPXENC, REFMD5):
+        if not os.path.exists(exe):
+            raise SystemExit(f"{exe} missing: run `make -C oracle ref` (dev container only)")
+    for name in names:
+        w, h, frames, seed, noise, args = FIXTURES[name]
+        ivf = os.path.join(HERE, name + ".ivf")
+        md5 = os.path.join(HERE, name + ".md5")
+        with tempfile.TemporaryDirectory(dir="/tmp") as td:
+            yuv = os.path.join(td, "in.yuv")
+            with open(yuv, "wb") as f:
+                f.write(synth_i420(w, h, frames, seed, noise))
+            base = args if "-p" in args else COMMON + args
+            run([VPXENC, *base, "-w", str(w), "-h", str(h), "-o", ivf, yuv])
+        run([REFMD5, ivf, md5])
+        nshown = sum(1 for _ in open(md5))
+        print(f"{name:20s} {os.path.getsize(ivf):8d} B  {nshown:3d} shown frames  "
+              f"listing-md5 {hashlib.md5(open(md5,'rb').read()).hexdigest()[:12]}")
+
+
+if __name__ == "__main__":
+    main()
