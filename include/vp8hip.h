@@ -1,0 +1,105 @@
+/* include/vp8hip.h -- C ABI of the MI355X (gfx950) VP8 pixel path: libvp8hip.so.
+ *
+ * Plain C, opaque handle, int status returns (0 = OK, negative = error; text via
+ * vp8hip_last_error), no HIP / C++ / torch types in any signature.  This is the frame-granular
+ * boundary that sits where the reference's OpenCL offload branches sit (SURVEY.md 8b "B3"):
+ *
+ *   vp8hip_create / vp8hip_destroy      <- vp8dx_create_decompressor / vp8dx_remove_decompressor
+ *                                          (vp8/decoder/onyxd_if.c:73,136) + cl_init/cl_destroy
+ *                                          (vp8/common/opencl/vp8_opencl.c:40-84,155-260)
+ *   vp8hip_configure                    <- vp8_alloc_frame_buffers (vp8/common/alloccommon.c:59)
+ *                                          incl. the per-frame-buffer device memory the reference
+ *                                          attaches as YV12_BUFFER_CONFIG.buffer_mem
+ *                                          (vpx_scale/yv12config.h:63-65, yv12config.c:97-105)
+ *   vp8hip_ir_map / vp8hip_ir_upload    <- the per-MB submit points of the reference's CL path
+ *                                          (vp8/decoder/decodframe.c:149-156: qcoeff/eobs/MODE_INFO
+ *                                          handed to vp8_decode_macroblock_cl)
+ *   vp8hip_decode                       <- decode_mb_row x mb_rows (decodframe.c:1116-1129),
+ *                                          vp8_loop_filter_frame (vp8/common/loopfilter.c:203; its
+ *                                          CL diversion at :225-230) and
+ *                                          vp8_yv12_extend_frame_borders_ptr (onyxd_if.c:607)
+ *   vp8hip_frame_download               <- the read-back of loopfilter_cl.c:688-696 / the plane
+ *                                          pointers vp8dx_get_raw_frame exposes (onyxd_if.c:707)
+ *
+ * There is NO CPU fallback behind this interface: if the GPU or the code object is unavailable
+ * vp8hip_create fails and the decoder built on it reports VPX_CODEC_ERROR.
+ *
+ * Threading: one context per decoder / per GPU; a context is not thread-safe.
+ */
+#ifndef VP8HIP_H
+#define VP8HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+#include "vp8_ir.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct vp8hip_ctx vp8hip_ctx;
+
+#define VP8HIP_STAGE_RECON   1   /* dequant+IDCT/WHT, intra + inter prediction, add            */
+#define VP8HIP_STAGE_LF      2   /* in-loop deblocking (no-op for frames with filter_level 0) */
+#define VP8HIP_STAGE_EXTEND  4   /* 32/16-px border replication                               */
+#define VP8HIP_STAGE_ALL     7
+
+/* One frame of work.  Slots and frame buffers are indices into the pools sized by
+ * vp8hip_configure.  ref_fb[VP8IR_LAST_FRAME..VP8IR_ALTREF_FRAME] are read by inter MBs only
+ * (ref_fb[0] unused; -1 where a reference does not exist).  Jobs passed to ONE vp8hip_decode
+ * call must be mutually independent (no job's dst_fb is another's ref_fb): they run concurrently. */
+typedef struct vp8hip_job {
+    int32_t ir_slot;
+    int32_t dst_fb;
+    int32_t ref_fb[4];
+} vp8hip_job;
+
+typedef struct vp8hip_stats {      /* filled by vp8hip_get_stats; times from HIP events, ms */
+    float recon_ms, lf_ms, extend_ms;   /* last vp8hip_decode call */
+    int   recon_waves, lf_waves;        /* waves per workgroup chosen for the geometry */
+    int   workgroups;
+} vp8hip_stats;
+
+/* device < 0: use the current HIP device.  Returns 0 or a negative error. */
+int  vp8hip_create(int device, vp8hip_ctx **out);
+void vp8hip_destroy(vp8hip_ctx *ctx);
+const char *vp8hip_last_error(const vp8hip_ctx *ctx);   /* ctx may be NULL: creation error */
+
+/* (Re)allocate device state for frames of width x height: num_fb frame buffers
+ * (vp8ir_geom layout, borders included) and num_slots IR slots (hdr + mbs + coef + mvs, each
+ * with a pinned host staging mirror).  Existing contents are discarded. */
+int  vp8hip_configure(vp8hip_ctx *ctx, int width, int height, int num_fb, int num_slots);
+int  vp8hip_geometry(const vp8hip_ctx *ctx, vp8ir_geom *g);
+
+/* Pinned host staging of a slot, for the feeder to write the IR into directly. */
+int  vp8hip_ir_map(vp8hip_ctx *ctx, int slot, vp8ir_frame_hdr **hdr, vp8ir_mb **mbs,
+                   int16_t **coef, vp8ir_mv **mvs);
+/* Asynchronous H2D copy of one slot on the context's stream (mvs only for inter frames). */
+int  vp8hip_ir_upload(vp8hip_ctx *ctx, int slot);
+/* Device-to-device replication of an uploaded slot (synthetic looped streams: every key frame
+ * is independently decodable, decodframe.c:610-639). */
+int  vp8hip_ir_copy(vp8hip_ctx *ctx, int dst_slot, int src_slot);
+
+/* Enqueue the pixel path for njobs independent frames on the context's stream.  `stages` is a
+ * mask of VP8HIP_STAGE_*.  Asynchronous; see vp8hip_sync. */
+int  vp8hip_decode(vp8hip_ctx *ctx, const vp8hip_job *jobs, int njobs, int stages);
+
+/* Copy one frame buffer to the host.  full != 0: the whole buffer (frame_size bytes, borders
+ * included) into y (u, v ignored).  Otherwise the visible planes: rows of width x height (Y) and
+ * ((w+1)/2) x ((h+1)/2) (U, V) written with the given destination strides.  Synchronous. */
+int  vp8hip_frame_download(vp8hip_ctx *ctx, int fb, int full, uint8_t *y, uint8_t *u, uint8_t *v,
+                           int y_stride, int uv_stride);
+/* Upload a whole frame buffer (frame_size bytes) -- tests and VP8_SET_REFERENCE. */
+int  vp8hip_frame_upload(vp8hip_ctx *ctx, int fb, const uint8_t *buf);
+int  vp8hip_frame_copy(vp8hip_ctx *ctx, int dst_fb, int src_fb);
+
+int  vp8hip_sync(vp8hip_ctx *ctx);
+int  vp8hip_get_stats(vp8hip_ctx *ctx, vp8hip_stats *st);
+/* The HIP stream (hipStream_t, as void*) all work of this context is enqueued on, so callers
+ * can bracket it with their own events. */
+void *vp8hip_stream(vp8hip_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VP8HIP_H */

@@ -1,0 +1,377 @@
+"""libvpx.opencl_amd -- MI355X-native VP8 decode pixel path (host-side Python plumbing).
+
+The product is the two native libraries built from ``csrc/``:
+
+* ``lib/libvp8hip.so``  -- hand-written HIP kernels for gfx950 + the C-ABI shim (``include/vp8hip.h``)
+* ``lib/libvpx_hip.so`` -- the C host side: bitstream feeder (``vp8_parser``), decoder core and the
+  ``vpx_codec`` / ``vp8_dx`` interface (``include/vpx/*.h``), linked against ``libvp8hip.so``
+
+This module only binds them with ctypes for the tests and ``bench.py`` (the reference is C; the
+drop-in boundary is the C ABI, Python is plumbing).  It deliberately has NO CPU fallback:
+``Vp8Hip()`` raises if the HIP library or a gfx950 device is missing.
+
+The directory name contains a dot, so it is loaded by path (see ``__graft_entry__.load_package``).
+"""
+import ctypes
+import hashlib
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+LIBDIR = os.path.join(HERE, "lib")
+HIP_LIB = os.path.join(LIBDIR, "libvp8hip.so")
+HOST_LIB = os.path.join(LIBDIR, "libvpx_hip.so")
+
+c_void_p, c_int, c_size_t = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
+
+STAGE_RECON, STAGE_LF, STAGE_EXTEND, STAGE_ALL = 1, 2, 4, 7
+
+
+def build(verbose=False):
+    """Compile every native piece in-tree (hipcc cross-compiles gfx950 without a GPU)."""
+    out = subprocess.run(["make", "-C", os.path.join(HERE, "csrc"), "all"], capture_output=True, text=True)
+    if out.returncode:
+        raise RuntimeError("native build failed:\n" + out.stdout + out.stderr)
+    if verbose:
+        print(out.stdout)
+
+
+# ------------------------------------------------------------------------------------------
+# IR structures (include/vp8_ir.h)
+# ------------------------------------------------------------------------------------------
+class FrameHdr(ctypes.Structure):
+    _fields_ = [("width", ctypes.c_uint16), ("height", ctypes.c_uint16), ("mb_cols", ctypes.c_uint16),
+                ("mb_rows", ctypes.c_uint16), ("frame_type", ctypes.c_uint8), ("version", ctypes.c_uint8),
+                ("show_frame", ctypes.c_uint8), ("filter_type", ctypes.c_uint8), ("filter_level", ctypes.c_uint8),
+                ("sharpness_level", ctypes.c_uint8), ("segmentation_enabled", ctypes.c_uint8),
+                ("mb_segment_abs_delta", ctypes.c_uint8), ("segment_quant", ctypes.c_int8 * 4),
+                ("segment_lf", ctypes.c_int8 * 4), ("mode_ref_lf_delta_enabled", ctypes.c_uint8),
+                ("ref_lf_deltas", ctypes.c_int8 * 4), ("mode_lf_deltas", ctypes.c_int8 * 4),
+                ("base_qindex", ctypes.c_uint8), ("y1dc_delta_q", ctypes.c_int8), ("y2dc_delta_q", ctypes.c_int8),
+                ("y2ac_delta_q", ctypes.c_int8), ("uvdc_delta_q", ctypes.c_int8), ("uvac_delta_q", ctypes.c_int8),
+                ("refresh_last", ctypes.c_uint8), ("refresh_golden", ctypes.c_uint8), ("refresh_alt", ctypes.c_uint8),
+                ("copy_buffer_to_gf", ctypes.c_uint8), ("copy_buffer_to_arf", ctypes.c_uint8),
+                ("sign_bias_golden", ctypes.c_uint8), ("sign_bias_alt", ctypes.c_uint8),
+                ("color_space", ctypes.c_uint8), ("clamping_type", ctypes.c_uint8),
+                ("num_token_partitions", ctypes.c_uint8), ("rsv", ctypes.c_uint8 * 15)]
+
+
+assert ctypes.sizeof(FrameHdr) == 64
+
+
+class Geom(ctypes.Structure):
+    _fields_ = [(n, c_int) for n in ("aligned_w", "aligned_h", "y_stride", "uv_stride", "y_plane_size",
+                                     "uv_plane_size", "frame_size", "y_off", "u_off", "v_off")]
+
+
+def geom(width, height):
+    """vp8ir_geom_init (include/vp8_ir.h) restated for numpy-side indexing."""
+    g = Geom()
+    aw, ah = (width + 15) & ~15, (height + 15) & ~15
+    g.aligned_w, g.aligned_h = aw, ah
+    g.y_stride = (aw + 64 + 31) & ~31
+    g.uv_stride = g.y_stride >> 1
+    g.y_plane_size = (ah + 64) * g.y_stride
+    g.uv_plane_size = (ah // 2 + 32) * g.uv_stride
+    g.frame_size = g.y_plane_size + 2 * g.uv_plane_size
+    g.y_off = 32 * g.y_stride + 32
+    g.u_off = g.y_plane_size + 16 * g.uv_stride + 16
+    g.v_off = g.y_plane_size + g.uv_plane_size + 16 * g.uv_stride + 16
+    return g
+
+
+class Refs(ctypes.Structure):
+    _fields_ = [("new_idx", c_int), ("lst_idx", c_int), ("gld_idx", c_int), ("alt_idx", c_int),
+                ("ref_cnt", c_int * 4), ("show_idx", c_int)]
+
+
+class Job(ctypes.Structure):
+    _fields_ = [("ir_slot", ctypes.c_int32), ("dst_fb", ctypes.c_int32), ("ref_fb", ctypes.c_int32 * 4)]
+
+
+class Stats(ctypes.Structure):
+    _fields_ = [("recon_ms", ctypes.c_float), ("lf_ms", ctypes.c_float), ("extend_ms", ctypes.c_float),
+                ("recon_waves", c_int), ("lf_waves", c_int), ("workgroups", c_int)]
+
+
+# ------------------------------------------------------------------------------------------
+# IVF container + MD5 of a decoded frame (vpxdec.c:386-441 / examples/decode_to_md5.txt:28-47)
+# ------------------------------------------------------------------------------------------
+def read_ivf(path):
+    data = open(path, "rb").read()
+    if len(data) < 32 or data[:4] != b"DKIF":
+        raise ValueError(f"{path}: not an IVF file")
+    w, h = int.from_bytes(data[12:14], "little"), int.from_bytes(data[14:16], "little")
+    frames, pos = [], 32
+    while pos + 12 <= len(data):
+        sz = int.from_bytes(data[pos:pos + 4], "little")
+        pos += 12
+        if pos + sz > len(data):
+            break
+        frames.append(data[pos:pos + sz])
+        pos += sz
+    return w, h, frames
+
+
+def frame_md5(buf, g, width, height):
+    """MD5 over the visible Y, U, V rows of a whole frame buffer (numpy uint8, vp8ir_geom layout)."""
+    m = hashlib.md5()
+    cw, ch = (width + 1) // 2, (height + 1) // 2
+    for off, stride, w, h in ((g.y_off, g.y_stride, width, height), (g.u_off, g.uv_stride, cw, ch),
+                              (g.v_off, g.uv_stride, cw, ch)):
+        plane = np.lib.stride_tricks.as_strided(buf[off:], shape=(h, w), strides=(stride, 1))
+        m.update(np.ascontiguousarray(plane).tobytes())
+    return m.hexdigest()
+
+
+def planes_md5(y, u, v):
+    m = hashlib.md5()
+    for p in (y, u, v):
+        m.update(np.ascontiguousarray(p).tobytes())
+    return m.hexdigest()
+
+
+# ------------------------------------------------------------------------------------------
+# host feeder (vp8_parser.h), exported by libvpx_hip.so
+# ------------------------------------------------------------------------------------------
+_host = None
+
+
+def load_host():
+    global _host
+    if _host is None:
+        if not os.path.exists(HOST_LIB):
+            raise RuntimeError(f"{HOST_LIB} missing: run __graft_entry__.build()")
+        # libvpx_hip.so links libvp8hip.so (rpath $ORIGIN)
+        L = ctypes.CDLL(HOST_LIB)
+        L.vp8_parser_create.restype = c_void_p
+        L.vp8_parser_destroy.argtypes = [c_void_p]
+        L.vp8_parser_begin_frame.argtypes = [c_void_p, ctypes.c_char_p, c_size_t, c_void_p]
+        L.vp8_parser_decode_mbs.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
+        L.vp8_parser_error.argtypes = [c_void_p]
+        L.vp8_parser_error.restype = ctypes.c_char_p
+        for f in ("vp8_refs_init", "vp8_refs_on_alloc", "vp8_refs_release_new"):
+            getattr(L, f).argtypes = [c_void_p]
+        L.vp8_refs_get_free.argtypes = [c_void_p]
+        L.vp8_refs_swap.argtypes = [c_void_p, c_void_p]
+        _host = L
+    return _host
+
+
+class Parser:
+    """Bitstream -> IR.  Owns the reference-buffer bookkeeping too (vp8_refs)."""
+
+    def __init__(self):
+        self.L = load_host()
+        self.p = c_void_p(self.L.vp8_parser_create())
+        self.refs = Refs()
+        self.L.vp8_refs_init(ctypes.byref(self.refs))
+        self.dims = None
+
+    def close(self):
+        if self.p:
+            self.L.vp8_parser_destroy(self.p)
+            self.p = None
+
+    def begin(self, data):
+        """-> (hdr, dims_changed).  Acquires refs.new_idx like the reference's get_free_fb."""
+        hdr = FrameHdr()
+        if self.L.vp8_refs_get_free(ctypes.byref(self.refs)) < 0:
+            raise RuntimeError("no free frame buffer")
+        rc = self.L.vp8_parser_begin_frame(self.p, data, len(data), ctypes.byref(hdr))
+        if rc:
+            self.L.vp8_refs_release_new(ctypes.byref(self.refs))
+            raise ValueError(f"vp8 header error {rc}: {self.L.vp8_parser_error(self.p).decode()}")
+        changed = self.dims != (hdr.width, hdr.height)
+        if changed:
+            self.dims = (hdr.width, hdr.height)
+            self.L.vp8_refs_on_alloc(ctypes.byref(self.refs))
+        return hdr, changed
+
+    def decode_mbs(self, mbs_ptr, coef_ptr, mvs_ptr):
+        corrupt = c_int(0)
+        rc = self.L.vp8_parser_decode_mbs(self.p, mbs_ptr, coef_ptr, mvs_ptr, ctypes.byref(corrupt))
+        if rc:
+            self.L.vp8_refs_release_new(ctypes.byref(self.refs))
+            raise ValueError(f"vp8 macroblock data error {rc}: {self.L.vp8_parser_error(self.p).decode()}")
+        return corrupt.value
+
+    def swap(self, hdr):
+        self.L.vp8_refs_swap(ctypes.byref(self.refs), ctypes.byref(hdr))
+
+
+def parse_to_numpy(parser, data):
+    """One frame -> (hdr, mbs uint8[n,64], coef int16[n,400], mvs int16[n,16,2]) in numpy arrays."""
+    hdr, changed = parser.begin(data)
+    n = hdr.mb_cols * hdr.mb_rows
+    mbs = np.zeros((n, 64), np.uint8)
+    coef = np.zeros((n, 400), np.int16)
+    mvs = np.zeros((n, 16, 2), np.int16)
+    parser.decode_mbs(mbs.ctypes.data, coef.ctypes.data, mvs.ctypes.data)
+    return hdr, changed, mbs, coef, mvs
+
+
+# ------------------------------------------------------------------------------------------
+# HIP pixel path (vp8hip.h)
+# ------------------------------------------------------------------------------------------
+_hip = None
+
+
+def load_hip():
+    global _hip
+    if _hip is None:
+        if not os.path.exists(HIP_LIB):
+            raise RuntimeError(f"{HIP_LIB} missing: run __graft_entry__.build(); there is no CPU fallback")
+        L = ctypes.CDLL(HIP_LIB, mode=ctypes.RTLD_GLOBAL)
+        L.vp8hip_create.argtypes = [c_int, ctypes.POINTER(c_void_p)]
+        L.vp8hip_destroy.argtypes = [c_void_p]
+        L.vp8hip_last_error.argtypes = [c_void_p]
+        L.vp8hip_last_error.restype = ctypes.c_char_p
+        L.vp8hip_configure.argtypes = [c_void_p, c_int, c_int, c_int, c_int]
+        L.vp8hip_geometry.argtypes = [c_void_p, c_void_p]
+        L.vp8hip_ir_map.argtypes = [c_void_p, c_int] + [ctypes.POINTER(c_void_p)] * 4
+        L.vp8hip_ir_upload.argtypes = [c_void_p, c_int]
+        L.vp8hip_ir_copy.argtypes = [c_void_p, c_int, c_int]
+        L.vp8hip_decode.argtypes = [c_void_p, c_void_p, c_int, c_int]
+        L.vp8hip_frame_download.argtypes = [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int]
+        L.vp8hip_frame_upload.argtypes = [c_void_p, c_int, c_void_p]
+        L.vp8hip_frame_copy.argtypes = [c_void_p, c_int, c_int]
+        L.vp8hip_sync.argtypes = [c_void_p]
+        L.vp8hip_get_stats.argtypes = [c_void_p, c_void_p]
+        L.vp8hip_stream.argtypes = [c_void_p]
+        L.vp8hip_stream.restype = c_void_p
+        _hip = L
+    return _hip
+
+
+class Vp8Hip:
+    """One HIP context = one GPU's frame-buffer pool + IR slots + stream."""
+
+    def __init__(self, device=-1):
+        self.L = load_hip()
+        h = c_void_p()
+        if self.L.vp8hip_create(device, ctypes.byref(h)):
+            raise RuntimeError("vp8hip_create: " + self.L.vp8hip_last_error(None).decode())
+        self.h = h
+        self.width = self.height = 0
+        self.g = None
+
+    def _chk(self, rc, what):
+        if rc:
+            raise RuntimeError(f"{what}: {self.L.vp8hip_last_error(self.h).decode()}")
+
+    def close(self):
+        if self.h:
+            self.L.vp8hip_destroy(self.h)
+            self.h = None
+
+    def configure(self, width, height, num_fb, num_slots):
+        self._chk(self.L.vp8hip_configure(self.h, width, height, num_fb, num_slots), "vp8hip_configure")
+        self.width, self.height = width, height
+        self.g = geom(width, height)
+        self.nmb = (self.g.aligned_w // 16) * (self.g.aligned_h // 16)
+        self.num_fb, self.num_slots = num_fb, num_slots
+
+    def ir_map(self, slot):
+        ptrs = [c_void_p() for _ in range(4)]
+        self._chk(self.L.vp8hip_ir_map(self.h, slot, *[ctypes.byref(p) for p in ptrs]), "vp8hip_ir_map")
+        return [p.value for p in ptrs]   # hdr, mbs, coef, mvs (pinned host addresses)
+
+    def fill_slot(self, slot, hdr, mbs, coef, mvs):
+        """Copy numpy IR arrays into a slot's pinned staging and upload it."""
+        ph, pm, pc, pv = self.ir_map(slot)
+        ctypes.memmove(ph, ctypes.byref(hdr), 64)
+        ctypes.memmove(pm, mbs.ctypes.data, mbs.nbytes)
+        ctypes.memmove(pc, coef.ctypes.data, coef.nbytes)
+        if hdr.frame_type != 0:
+            ctypes.memmove(pv, mvs.ctypes.data, mvs.nbytes)
+        self.upload(slot)
+
+    def parse_into_slot(self, parser, data, slot):
+        """Feeder writes straight into the pinned staging of `slot`; returns hdr (not yet uploaded)."""
+        hdr, changed = parser.begin(data)
+        if changed or (hdr.width, hdr.height) != (self.width, self.height):
+            raise RuntimeError("dimension change: reconfigure the context first")
+        ph, pm, pc, pv = self.ir_map(slot)
+        parser.decode_mbs(pm, pc, pv)
+        ctypes.memmove(ph, ctypes.byref(hdr), 64)
+        return hdr
+
+    def upload(self, slot):
+        self._chk(self.L.vp8hip_ir_upload(self.h, slot), "vp8hip_ir_upload")
+
+    def ir_copy(self, dst, src):
+        self._chk(self.L.vp8hip_ir_copy(self.h, dst, src), "vp8hip_ir_copy")
+
+    def decode(self, jobs, stages=STAGE_ALL):
+        """jobs: list of (ir_slot, dst_fb, (last, golden, alt))"""
+        arr = (Job * len(jobs))()
+        for i, (slot, dst, refs) in enumerate(jobs):
+            arr[i].ir_slot, arr[i].dst_fb = slot, dst
+            arr[i].ref_fb[0] = -1
+            for k in range(3):
+                arr[i].ref_fb[k + 1] = refs[k] if refs is not None else -1
+        self._jobs_keepalive = arr
+        self._chk(self.L.vp8hip_decode(self.h, arr, len(jobs), stages), "vp8hip_decode")
+
+    def decode_array(self, job_array, n, stages=STAGE_ALL):
+        self._chk(self.L.vp8hip_decode(self.h, job_array, n, stages), "vp8hip_decode")
+
+    def sync(self):
+        self._chk(self.L.vp8hip_sync(self.h), "vp8hip_sync")
+
+    def stats(self):
+        s = Stats()
+        self._chk(self.L.vp8hip_get_stats(self.h, ctypes.byref(s)), "vp8hip_get_stats")
+        return s
+
+    def stream(self):
+        return self.L.vp8hip_stream(self.h)
+
+    def download_full(self, fb):
+        buf = np.empty(self.g.frame_size, np.uint8)
+        self._chk(self.L.vp8hip_frame_download(self.h, fb, 1, buf.ctypes.data, None, None, 0, 0), "download")
+        return buf
+
+    def download_planes(self, fb):
+        w, h = self.width, self.height
+        cw, ch = (w + 1) // 2, (h + 1) // 2
+        y, u, v = np.empty((h, w), np.uint8), np.empty((ch, cw), np.uint8), np.empty((ch, cw), np.uint8)
+        self._chk(self.L.vp8hip_frame_download(self.h, fb, 0, y.ctypes.data, u.ctypes.data, v.ctypes.data, w, cw),
+                  "download")
+        return y, u, v
+
+    def upload_frame(self, fb, buf):
+        assert buf.nbytes == self.g.frame_size
+        self._chk(self.L.vp8hip_frame_upload(self.h, fb, buf.ctypes.data), "upload")
+
+
+def decode_ivf_gpu(path, device=-1, stages=STAGE_ALL):
+    """Decode a whole IVF on the GPU, frame by frame (the latency path): list of per-shown-frame MD5s."""
+    w, h, frames = read_ivf(path)
+    parser, ctx = Parser(), Vp8Hip(device)
+    out = []
+    try:
+        for data in frames:
+            hdr, changed = parser.begin(data)
+            if changed:
+                ctx.configure(hdr.width, hdr.height, 4, 1)
+            _, pm, pc, pv = ctx.ir_map(0)
+            ph = ctx.ir_map(0)[0]
+            parser.decode_mbs(pm, pc, pv)
+            ctypes.memmove(ph, ctypes.byref(hdr), 64)
+            ctx.upload(0)
+            r = parser.refs
+            ctx.decode([(0, r.new_idx, (r.lst_idx, r.gld_idx, r.alt_idx))], stages)
+            parser.swap(hdr)
+            if hdr.show_frame:
+                out.append(planes_md5(*ctx.download_planes(parser.refs.show_idx)))
+            else:
+                ctx.sync()
+    finally:
+        ctx.close()
+        parser.close()
+    return out

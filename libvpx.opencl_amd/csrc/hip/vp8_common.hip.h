@@ -1,0 +1,81 @@
+// Shared device-side definitions for the gfx950 VP8 pixel-path kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "vp8_ir.h"
+
+// One frame of work as the kernels see it (device memory, one entry per job of a launch).
+struct DevJob {
+    vp8ir_frame_hdr hdr;          // 64 B
+    const vp8ir_mb *mbs;
+    const int16_t  *coef;
+    const vp8ir_mv *mvs;
+    uint8_t        *dst;
+    const uint8_t  *ref[4];
+    // 64 + 8*8 = 128 B
+};
+static_assert(sizeof(DevJob) == 128, "DevJob layout");
+
+// Frame geometry common to all jobs of a launch (vp8ir_geom, flattened for kernel args).
+struct DevGeom {
+    int mb_cols, mb_rows;
+    int aligned_w, aligned_h;
+    int y_stride, uv_stride;
+    int y_off, u_off, v_off;
+};
+
+#define WAVE 64
+
+// ---- intra-workgroup progress flags in LDS ------------------------------------------------
+// A wave publishes "(row sequence number << 16) | MBs finished in that row"; finishing a row
+// publishes (seq+1) << 16.  All waves of a workgroup live on one CU and share its L1, so
+// workgroup-scope release/acquire is sufficient for data handed over through LDS *and* through
+// global memory (LLVM AMDGPU memory model, non-tgsplit mode).
+__device__ __forceinline__ void wg_wait_ge(int *flag, int value)
+{
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < value)
+        __builtin_amdgcn_s_sleep(2);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+__device__ __forceinline__ void wg_publish(int *flag, int value, int lane)
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0)
+        __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// Lanes of one wave exchanging data through LDS: the hardware issues a wave's LDS operations in
+// order, but the COMPILER only promises per-thread ordering and may move one lane's load above
+// another lane's store.  This is the (instruction-free) fence that pins the order.
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ int clamp255(int v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }
+
+__device__ __forceinline__ int wave_sum(int v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+    return v;
+}
+
+// quantiser lookups (vp8/common/quant_common.c:14-37); VP8 format constants
+__constant__ static const unsigned short k_dc_q[128] = {
+    4, 5, 6, 7, 8, 9, 10, 10, 11, 12, 13, 14, 15, 16, 17, 17, 18, 19, 20, 20, 21, 21, 22, 22, 23, 23, 24, 25, 25, 26,
+    27, 28, 29, 30, 31, 32, 33, 34, 35, 36, 37, 37, 38, 39, 40, 41, 42, 43, 44, 45, 46, 46, 47, 48, 49, 50, 51, 52,
+    53, 54, 55, 56, 57, 58, 59, 60, 61, 62, 63, 64, 65, 66, 67, 68, 69, 70, 71, 72, 73, 74, 75, 76, 76, 77, 78, 79,
+    80, 81, 82, 83, 84, 85, 86, 87, 88, 89, 91, 93, 95, 96, 98, 100, 101, 102, 104, 106, 108, 110, 112, 114, 116,
+    118, 122, 124, 126, 128, 130, 132, 134, 136, 138, 140, 143, 145, 148, 151, 154, 157
+};
+__constant__ static const unsigned short k_ac_q[128] = {
+    4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33,
+    34, 35, 36, 37, 38, 39, 40, 41, 42, 43, 44, 45, 46, 47, 48, 49, 50, 51, 52, 53, 54, 55, 56, 57, 58, 60, 62, 64,
+    66, 68, 70, 72, 74, 76, 78, 80, 82, 84, 86, 88, 90, 92, 94, 96, 98, 100, 102, 104, 106, 108, 110, 112, 114, 116,
+    119, 122, 125, 128, 131, 134, 137, 140, 143, 146, 149, 152, 155, 158, 161, 164, 167, 170, 173, 177, 181, 185,
+    189, 193, 197, 201, 205, 209, 213, 217, 221, 225, 229, 234, 239, 245, 249, 254, 259, 264, 269, 274, 279, 284
+};

@@ -1,0 +1,390 @@
+// C-ABI shim of the gfx950 VP8 pixel path (include/vp8hip.h).  Owns the HIP stream, the device
+// frame-buffer pool (the decoder's yv12_fb[] lives in HBM), the IR slots with their pinned host
+// staging mirrors, and launches the three kernels.  No CPU fallback: every failure is reported.
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+
+#include "vp8hip.h"
+#include "vp8_common.hip.h"
+
+extern "C" __global__ void vp8_recon_kernel(const DevJob *jobs, int njobs, DevGeom g);
+extern "C" __global__ void vp8_loopfilter_kernel(const DevJob *jobs, int njobs, DevGeom g);
+extern "C" __global__ void vp8_extend_kernel(const DevJob *jobs, int njobs, DevGeom g);
+
+static char g_create_error[256] = "";
+
+struct Slot {
+    // device
+    vp8ir_frame_hdr *d_hdr; vp8ir_mb *d_mbs; int16_t *d_coef; vp8ir_mv *d_mvs;
+    // pinned host mirror
+    vp8ir_frame_hdr *h_hdr; vp8ir_mb *h_mbs; int16_t *h_coef; vp8ir_mv *h_mvs;
+    vp8ir_frame_hdr hdr_copy;      // header as of the last upload / copy (host side, for job setup)
+};
+
+struct vp8hip_ctx {
+    int device;
+    hipStream_t stream;
+    hipEvent_t ev[4];
+    hipEvent_t ev_jobs;            // job table of the previous call has been copied
+    char err[256];
+    // geometry
+    int width, height;
+    vp8ir_geom geom;
+    DevGeom dg;
+    int nmb;
+    // pools
+    std::vector<uint8_t *> fb;
+    std::vector<Slot> slots;
+    uint8_t *fb_block; char *slot_block_dev; char *slot_block_host;
+    // job staging
+    DevJob *d_jobs; DevJob *h_jobs; int jobs_cap;
+    // launch configuration
+    int num_cu, max_lds;
+    int recon_nw, lf_nw;
+    size_t recon_lds, lf_lds;
+    bool have_times;
+    vp8hip_stats stats;
+};
+
+static int fail(vp8hip_ctx *c, int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(c ? c->err : g_create_error, 256, fmt, ap);
+    va_end(ap);
+    return code;
+}
+#define HIPCHK(ctx, call)                                                                          \
+    do {                                                                                           \
+        hipError_t e_ = (call);                                                                    \
+        if (e_ != hipSuccess) return fail(ctx, -1, "%s failed: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+
+extern "C" const char *vp8hip_last_error(const vp8hip_ctx *ctx) { return ctx ? ctx->err : g_create_error; }
+
+static void free_pools(vp8hip_ctx *c)
+{
+    if (c->fb_block) (void)hipFree(c->fb_block);
+    if (c->slot_block_dev) (void)hipFree(c->slot_block_dev);
+    if (c->slot_block_host) (void)hipHostFree(c->slot_block_host);
+    c->fb_block = nullptr; c->slot_block_dev = nullptr; c->slot_block_host = nullptr;
+    c->fb.clear(); c->slots.clear();
+}
+
+extern "C" int vp8hip_create(int device, vp8hip_ctx **out)
+{
+    if (!out) return fail(nullptr, -2, "vp8hip_create: null out pointer");
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0)
+        return fail(nullptr, -1, "no HIP device available (%s): the VP8 pixel path has no CPU fallback",
+                    hipGetErrorString(e));
+    if (device < 0) { if (hipGetDevice(&device) != hipSuccess) device = 0; }
+    if (device >= ndev) return fail(nullptr, -2, "device %d out of range (%d devices)", device, ndev);
+    if ((e = hipSetDevice(device)) != hipSuccess)
+        return fail(nullptr, -1, "hipSetDevice(%d): %s", device, hipGetErrorString(e));
+    hipDeviceProp_t prop;
+    if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess)
+        return fail(nullptr, -1, "hipGetDeviceProperties: %s", hipGetErrorString(e));
+    if (!strstr(prop.gcnArchName, "gfx950"))
+        return fail(nullptr, -1, "device %d is %s; this library carries gfx950 (MI355X) code only", device,
+                    prop.gcnArchName);
+    vp8hip_ctx *c = new vp8hip_ctx();
+    memset(c->err, 0, sizeof c->err);
+    c->device = device;
+    c->num_cu = prop.multiProcessorCount;
+    c->max_lds = 160 * 1024;
+    c->fb_block = nullptr; c->slot_block_dev = nullptr; c->slot_block_host = nullptr;
+    c->d_jobs = nullptr; c->h_jobs = nullptr; c->jobs_cap = 0;
+    c->width = c->height = 0;
+    c->have_times = false;
+    memset(&c->stats, 0, sizeof c->stats);
+    if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) {
+        fail(nullptr, -1, "hipStreamCreate: %s", hipGetErrorString(e));
+        delete c;
+        return -1;
+    }
+    for (int i = 0; i < 4; i++) (void)hipEventCreate(&c->ev[i]);
+    (void)hipEventCreateWithFlags(&c->ev_jobs, hipEventDisableTiming);
+    e = hipFuncSetAttribute((const void *)vp8_recon_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_lds);
+    if (e != hipSuccess) {
+        fail(nullptr, -1, "hipFuncSetAttribute(recon, %d B LDS): %s", c->max_lds, hipGetErrorString(e));
+        (void)hipStreamDestroy(c->stream);
+        delete c;
+        return -1;
+    }
+    *out = c;
+    return 0;
+}
+
+extern "C" void vp8hip_destroy(vp8hip_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    free_pools(c);
+    if (c->d_jobs) (void)hipFree(c->d_jobs);
+    if (c->h_jobs) (void)hipHostFree(c->h_jobs);
+    for (int i = 0; i < 4; i++) (void)hipEventDestroy(c->ev[i]);
+    (void)hipEventDestroy(c->ev_jobs);
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// per-wave LDS footprints; must match the kernels (WaveLds 2288 B + line slot, LfWaveLds 768 B)
+static size_t recon_lds_bytes(int nw, int aligned_w) { return 512 + (size_t)nw * (2288 + 2 * aligned_w + 96); }
+static size_t lf_lds_bytes(int nw) { return 256 + (size_t)nw * 768; }
+
+extern "C" int vp8hip_configure(vp8hip_ctx *c, int width, int height, int num_fb, int num_slots)
+{
+    if (!c) return -2;
+    if (width <= 0 || height <= 0 || width > 16383 || height > 16383 || num_fb < 1 || num_slots < 1)
+        return fail(c, -2, "vp8hip_configure: bad arguments %dx%d fb=%d slots=%d", width, height, num_fb, num_slots);
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    free_pools(c);
+    c->width = width; c->height = height;
+    vp8ir_geom_init(&c->geom, width, height);
+    const vp8ir_geom &g = c->geom;
+    c->dg.mb_cols = g.aligned_w / 16; c->dg.mb_rows = g.aligned_h / 16;
+    c->dg.aligned_w = g.aligned_w; c->dg.aligned_h = g.aligned_h;
+    c->dg.y_stride = g.y_stride; c->dg.uv_stride = g.uv_stride;
+    c->dg.y_off = g.y_off; c->dg.u_off = g.u_off; c->dg.v_off = g.v_off;
+    c->nmb = c->dg.mb_cols * c->dg.mb_rows;
+    if (c->dg.mb_cols > 65535) return fail(c, -2, "frame too wide");
+
+    // waves per workgroup: one wave per MB row in flight; as many as LDS allows, at most 16, and
+    // no more than the frame has rows (rounded up to 2, the minimum the line-buffer ring needs)
+    int nw = 16;
+    while (nw > 2 && (recon_lds_bytes(nw, g.aligned_w) > (size_t)c->max_lds)) nw -= 2;
+    if (recon_lds_bytes(nw, g.aligned_w) > (size_t)c->max_lds)
+        return fail(c, -2, "frame width %d needs more LDS than a CU has", width);
+    while (nw > 2 && nw / 2 >= c->dg.mb_rows) nw /= 2;
+    c->recon_nw = nw; c->recon_lds = recon_lds_bytes(nw, g.aligned_w);
+    int lnw = 16;
+    while (lnw > 2 && lnw / 2 >= c->dg.mb_rows) lnw /= 2;
+    c->lf_nw = lnw; c->lf_lds = lf_lds_bytes(lnw);
+
+    // frame buffers: one block, each buffer 256-B aligned
+    const size_t fbsz = align_up((size_t)g.frame_size, 256);
+    HIPCHK(c, hipMalloc((void **)&c->fb_block, fbsz * num_fb));
+    HIPCHK(c, hipMemsetAsync(c->fb_block, 0, fbsz * num_fb, c->stream));
+    for (int i = 0; i < num_fb; i++) c->fb.push_back(c->fb_block + fbsz * i);
+
+    // IR slots
+    const size_t o_mbs = 64, o_coef = o_mbs + align_up((size_t)c->nmb * sizeof(vp8ir_mb), 256);
+    const size_t o_mvs = o_coef + align_up((size_t)c->nmb * VP8IR_COEF_PER_MB * sizeof(int16_t), 256);
+    const size_t slotsz = align_up(o_mvs + (size_t)c->nmb * 16 * sizeof(vp8ir_mv), 256);
+    HIPCHK(c, hipMalloc((void **)&c->slot_block_dev, slotsz * num_slots));
+    HIPCHK(c, hipHostMalloc((void **)&c->slot_block_host, slotsz * num_slots, hipHostMallocDefault));
+    memset(c->slot_block_host, 0, slotsz * num_slots);
+    c->slots.resize(num_slots);
+    for (int i = 0; i < num_slots; i++) {
+        char *d = c->slot_block_dev + slotsz * i, *h = c->slot_block_host + slotsz * i;
+        Slot &s = c->slots[i];
+        s.d_hdr = (vp8ir_frame_hdr *)d; s.d_mbs = (vp8ir_mb *)(d + o_mbs);
+        s.d_coef = (int16_t *)(d + o_coef); s.d_mvs = (vp8ir_mv *)(d + o_mvs);
+        s.h_hdr = (vp8ir_frame_hdr *)h; s.h_mbs = (vp8ir_mb *)(h + o_mbs);
+        s.h_coef = (int16_t *)(h + o_coef); s.h_mvs = (vp8ir_mv *)(h + o_mvs);
+        memset(&s.hdr_copy, 0, sizeof s.hdr_copy);
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int vp8hip_geometry(const vp8hip_ctx *c, vp8ir_geom *g)
+{
+    if (!c || !g || !c->width) return -2;
+    *g = c->geom;
+    return 0;
+}
+
+extern "C" int vp8hip_ir_map(vp8hip_ctx *c, int slot, vp8ir_frame_hdr **hdr, vp8ir_mb **mbs, int16_t **coef,
+                             vp8ir_mv **mvs)
+{
+    if (!c || slot < 0 || slot >= (int)c->slots.size()) return fail(c, -2, "vp8hip_ir_map: bad slot %d", slot);
+    Slot &s = c->slots[slot];
+    if (hdr) *hdr = s.h_hdr;
+    if (mbs) *mbs = s.h_mbs;
+    if (coef) *coef = s.h_coef;
+    if (mvs) *mvs = s.h_mvs;
+    return 0;
+}
+
+extern "C" int vp8hip_ir_upload(vp8hip_ctx *c, int slot)
+{
+    if (!c || slot < 0 || slot >= (int)c->slots.size()) return fail(c, -2, "vp8hip_ir_upload: bad slot %d", slot);
+    Slot &s = c->slots[slot];
+    const vp8ir_frame_hdr &h = *s.h_hdr;
+    if (h.mb_cols != c->dg.mb_cols || h.mb_rows != c->dg.mb_rows)
+        return fail(c, -2, "vp8hip_ir_upload: header is %dx%d MBs, context configured for %dx%d", h.mb_cols,
+                    h.mb_rows, c->dg.mb_cols, c->dg.mb_rows);
+    HIPCHK(c, hipSetDevice(c->device));
+    s.hdr_copy = h;
+    HIPCHK(c, hipMemcpyAsync(s.d_mbs, s.h_mbs, (size_t)c->nmb * sizeof(vp8ir_mb), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(s.d_coef, s.h_coef, (size_t)c->nmb * VP8IR_COEF_PER_MB * sizeof(int16_t),
+                             hipMemcpyHostToDevice, c->stream));
+    if (h.frame_type != 0)
+        HIPCHK(c, hipMemcpyAsync(s.d_mvs, s.h_mvs, (size_t)c->nmb * 16 * sizeof(vp8ir_mv), hipMemcpyHostToDevice,
+                                 c->stream));
+    return 0;
+}
+
+extern "C" int vp8hip_ir_copy(vp8hip_ctx *c, int dst, int src)
+{
+    if (!c || dst < 0 || src < 0 || dst >= (int)c->slots.size() || src >= (int)c->slots.size())
+        return fail(c, -2, "vp8hip_ir_copy: bad slots %d <- %d", dst, src);
+    if (dst == src) return 0;
+    Slot &d = c->slots[dst], &s = c->slots[src];
+    HIPCHK(c, hipSetDevice(c->device));
+    d.hdr_copy = s.hdr_copy;
+    HIPCHK(c, hipMemcpyAsync(d.d_mbs, s.d_mbs, (size_t)c->nmb * sizeof(vp8ir_mb), hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d.d_coef, s.d_coef, (size_t)c->nmb * VP8IR_COEF_PER_MB * sizeof(int16_t),
+                             hipMemcpyDeviceToDevice, c->stream));
+    if (s.hdr_copy.frame_type != 0)
+        HIPCHK(c, hipMemcpyAsync(d.d_mvs, s.d_mvs, (size_t)c->nmb * 16 * sizeof(vp8ir_mv), hipMemcpyDeviceToDevice,
+                                 c->stream));
+    return 0;
+}
+
+extern "C" int vp8hip_decode(vp8hip_ctx *c, const vp8hip_job *jobs, int njobs, int stages)
+{
+    if (!c || !jobs || njobs <= 0) return fail(c, -2, "vp8hip_decode: bad arguments");
+    if (!c->width) return fail(c, -2, "vp8hip_decode: context not configured");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (njobs > c->jobs_cap) {
+        // the staging arrays are reused by in-flight launches: drain before growing
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (c->d_jobs) (void)hipFree(c->d_jobs);
+        if (c->h_jobs) (void)hipHostFree(c->h_jobs);
+        c->jobs_cap = njobs < 64 ? 64 : njobs;
+        HIPCHK(c, hipMalloc((void **)&c->d_jobs, sizeof(DevJob) * c->jobs_cap));
+        HIPCHK(c, hipHostMalloc((void **)&c->h_jobs, sizeof(DevJob) * c->jobs_cap, hipHostMallocDefault));
+    } else {
+        // h_jobs is read by an async copy of the previous call; wait for that copy only
+        HIPCHK(c, hipEventSynchronize(c->ev_jobs));
+    }
+    const int nfb = (int)c->fb.size(), nsl = (int)c->slots.size();
+    bool any_lf = false;
+    for (int i = 0; i < njobs; i++) {
+        const vp8hip_job &j = jobs[i];
+        if (j.ir_slot < 0 || j.ir_slot >= nsl || j.dst_fb < 0 || j.dst_fb >= nfb)
+            return fail(c, -2, "vp8hip_decode: job %d has slot %d / fb %d out of range", i, j.ir_slot, j.dst_fb);
+        const Slot &s = c->slots[j.ir_slot];
+        DevJob &d = c->h_jobs[i];
+        d.hdr = s.hdr_copy;
+        d.mbs = s.d_mbs; d.coef = s.d_coef; d.mvs = s.d_mvs;
+        d.dst = c->fb[j.dst_fb];
+        d.ref[0] = nullptr;
+        for (int k = 1; k < 4; k++) {
+            int f = j.ref_fb[k];
+            if (f >= nfb) return fail(c, -2, "vp8hip_decode: job %d ref %d out of range", i, f);
+            if (f < 0 && s.hdr_copy.frame_type != 0)
+                return fail(c, -2, "vp8hip_decode: inter frame job %d lacks reference %d", i, k);
+            d.ref[k] = f < 0 ? nullptr : c->fb[f];
+            if (f == j.dst_fb) return fail(c, -2, "vp8hip_decode: job %d decodes into its own reference", i);
+        }
+        any_lf |= s.hdr_copy.filter_level != 0;
+    }
+    HIPCHK(c, hipMemcpyAsync(c->d_jobs, c->h_jobs, sizeof(DevJob) * njobs, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipEventRecord(c->ev_jobs, c->stream));
+
+    const int grid = njobs < c->num_cu ? njobs : c->num_cu;
+    c->stats.workgroups = grid;
+    c->stats.recon_waves = c->recon_nw;
+    c->stats.lf_waves = c->lf_nw;
+    HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+    if (stages & VP8HIP_STAGE_RECON) {
+        hipLaunchKernelGGL(vp8_recon_kernel, dim3(grid), dim3(64 * c->recon_nw), c->recon_lds, c->stream,
+                           (const DevJob *)c->d_jobs, njobs, c->dg);
+        HIPCHK(c, hipGetLastError());
+    }
+    HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+    if ((stages & VP8HIP_STAGE_LF) && any_lf) {
+        hipLaunchKernelGGL(vp8_loopfilter_kernel, dim3(grid), dim3(64 * c->lf_nw), c->lf_lds, c->stream,
+                           (const DevJob *)c->d_jobs, njobs, c->dg);
+        HIPCHK(c, hipGetLastError());
+    }
+    HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
+    if (stages & VP8HIP_STAGE_EXTEND) {
+        int bx = (c->geom.aligned_h + 64) / 4;
+        if (bx < 1) bx = 1;
+        if (bx > 64) bx = 64;
+        hipLaunchKernelGGL(vp8_extend_kernel, dim3(bx, njobs), dim3(256), 0, c->stream, (const DevJob *)c->d_jobs,
+                           njobs, c->dg);
+        HIPCHK(c, hipGetLastError());
+    }
+    HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
+    c->have_times = true;
+    return 0;
+}
+
+extern "C" int vp8hip_sync(vp8hip_ctx *c)
+{
+    if (!c) return -2;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int vp8hip_get_stats(vp8hip_ctx *c, vp8hip_stats *st)
+{
+    if (!c || !st) return -2;
+    if (c->have_times) {
+        HIPCHK(c, hipEventSynchronize(c->ev[3]));
+        (void)hipEventElapsedTime(&c->stats.recon_ms, c->ev[0], c->ev[1]);
+        (void)hipEventElapsedTime(&c->stats.lf_ms, c->ev[1], c->ev[2]);
+        (void)hipEventElapsedTime(&c->stats.extend_ms, c->ev[2], c->ev[3]);
+    }
+    *st = c->stats;
+    return 0;
+}
+
+extern "C" void *vp8hip_stream(vp8hip_ctx *c) { return c ? (void *)c->stream : nullptr; }
+
+extern "C" int vp8hip_frame_download(vp8hip_ctx *c, int fb, int full, uint8_t *y, uint8_t *u, uint8_t *v,
+                                     int y_stride, int uv_stride)
+{
+    if (!c || fb < 0 || fb >= (int)c->fb.size() || !y) return fail(c, -2, "vp8hip_frame_download: bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    const vp8ir_geom &g = c->geom;
+    if (full) {
+        HIPCHK(c, hipMemcpyAsync(y, c->fb[fb], (size_t)g.frame_size, hipMemcpyDeviceToHost, c->stream));
+    } else {
+        if (!u || !v) return fail(c, -2, "vp8hip_frame_download: null chroma pointers");
+        const int cw = (c->width + 1) / 2, ch = (c->height + 1) / 2;
+        HIPCHK(c, hipMemcpy2DAsync(y, y_stride, c->fb[fb] + g.y_off, g.y_stride, c->width, c->height,
+                                   hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpy2DAsync(u, uv_stride, c->fb[fb] + g.u_off, g.uv_stride, cw, ch, hipMemcpyDeviceToHost,
+                                   c->stream));
+        HIPCHK(c, hipMemcpy2DAsync(v, uv_stride, c->fb[fb] + g.v_off, g.uv_stride, cw, ch, hipMemcpyDeviceToHost,
+                                   c->stream));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int vp8hip_frame_upload(vp8hip_ctx *c, int fb, const uint8_t *buf)
+{
+    if (!c || fb < 0 || fb >= (int)c->fb.size() || !buf) return fail(c, -2, "vp8hip_frame_upload: bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(c->fb[fb], buf, (size_t)c->geom.frame_size, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int vp8hip_frame_copy(vp8hip_ctx *c, int dst, int src)
+{
+    if (!c || dst < 0 || src < 0 || dst >= (int)c->fb.size() || src >= (int)c->fb.size())
+        return fail(c, -2, "vp8hip_frame_copy: bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(c->fb[dst], c->fb[src], (size_t)c->geom.frame_size, hipMemcpyDeviceToDevice, c->stream));
+    return 0;
+}
