@@ -1,0 +1,237 @@
+#!/usr/bin/env python3
+"""bench.py -- VP8 decode pixel path on MI355X: Mpix/s on a 1080p all-key-frame stream.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--frames F] [--workload 1080p|4k]
+
+One "step" = one pass of the whole pixel path (dequant+IDCT/WHT + intra reconstruction, in-loop
+deblocking filter, border extension: the three kernels behind include/vp8hip.h) over a batch of F
+independent key frames whose IR (modes, eobs, dense coefficients) is ALREADY RESIDENT IN HBM.  The
+batch is the committed fixture tests/golden/kf_1920x1080.ivf (10 key frames, entropy-decoded once
+on the host, outside the timed region) looped F/10 times -- legal because every key frame is
+independently decodable (reference: vp8/decoder/decodframe.c:610-639).  Before timing, decoded
+frames are checked bit-exactly against the reference decoder's per-frame MD5s
+(tests/golden/*.md5).
+
+N > 1: launched by torch.distributed.run, one rank per GPU, every rank decodes its own F frames
+(frames shard one-per-GPU, no pixel exchange: "scaling": "weak").  RCCL (backend "nccl") carries
+only the start/stop barriers, the max-over-ranks time and the per-rank verification flag.
+
+Prints ONE JSON line on rank 0 (see README / DESIGN.md for the field definitions):
+  value      whole-job Mpix/s (display pixels) = N * F * K * w * h / seconds
+  roofline   dominant kernel: algorithmic bytes per launch (SURVEY.md 8d byte model) / mean launch
+             time measured with HIP events on the launch stream, vs 8 TB/s HBM peak
+  cpu_baseline  the REAL reference decoder (oracle/_ref, generic-C build of /root/reference) timed on
+             this host on the same stream, 1 core; falls back to the repo's C restatement ("port")
+"""
+import argparse
+import ctypes
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+# SURVEY.md 8(d) algorithmic bytes per macroblock, dense-coefficient model
+B_RECON = 833 + 384      # coefficients+eobs+params read, pixels written (key frames)
+B_LF = 770               # pixels read + written, params
+B_EXTEND = 36
+HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+WORKLOADS = {
+    "1080p": ("kf_1920x1080", 1920, 1080),
+    "4k": ("kf_3840x2160", 3840, 2160),
+}
+
+
+def cpu_baseline(fixture, budget_s=12.0):
+    """Time the reference decoder (or the port) on this host, single thread."""
+    ivf = os.path.join(ROOT, "tests", "golden", fixture + ".ivf")
+    ref = os.path.join(ROOT, "oracle", "_ref", "ref_md5")
+    cores = 1
+    if os.path.exists(ref):
+        try:
+            t0 = time.time()
+            out = subprocess.run([ref, "--time", "1", ivf], capture_output=True, text=True, timeout=120)
+            one = max(time.time() - t0, 1e-3)
+            reps = max(1, min(400, int(budget_s / one)))
+            out = subprocess.run([ref, "--time", str(reps), ivf], capture_output=True, text=True, timeout=600)
+            frames, pixels, secs = out.stdout.split()
+            return {"value": round(float(pixels) / float(secs) / 1e6, 2), "unit": "Mpix/s", "cores": cores,
+                    "kind": "reference",
+                    "sample": f"{fixture}.ivf x{reps} passes ({frames} frames) through oracle/_ref (reference "
+                              f"generic-C decoder, gcc -O3, 1 thread), time inside vpx_codec_decode only"}
+        except Exception as e:  # noqa: BLE001 - fall through to the port
+            sys.stderr.write(f"[bench] reference baseline failed ({e}); using the port\n")
+    # port: host feeder + oracle pixel path (checker code, timed here only as a baseline)
+    from vp8_testlib import load_package, oracle_decode_ivf
+    t0 = time.time()
+    n = 0
+    P = load_package()
+    w, h, frames = P.read_ivf(ivf)
+    while time.time() - t0 < budget_s:
+        oracle_decode_ivf(fixture)
+        n += len(frames)
+    secs = time.time() - t0
+    return {"value": round(n * w * h / secs / 1e6, 2), "unit": "Mpix/s", "cores": cores, "kind": "port",
+            "sample": f"{fixture}.ivf, {n} frames through the host feeder + oracle/ C restatement, 1 thread, "
+                      f"whole-loop wall time (includes entropy decode and MD5)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--frames", type=int, default=1024, help="frames per GPU per step")
+    ap.add_argument("--workload", default="1080p", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+    dist = None
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the VP8 pixel path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    from vp8_testlib import load_package, golden_md5, ivf_path
+    P = load_package()
+    fixture, W, H = WORKLOADS[args.workload]
+    F = args.frames
+
+    # ---- host feeder once (outside the timed region): 10 key frames -> IR
+    w, h, frames = P.read_ivf(ivf_path(fixture))
+    assert (w, h) == (W, H)
+    nsrc = len(frames)
+    gold = golden_md5(fixture)
+    ctx = P.Vp8Hip(local_rank)
+    ctx.configure(W, H, F, F)
+    parser = P.Parser()
+    t_feed0 = time.time()
+    for i, data in enumerate(frames):
+        hdr = ctx.parse_into_slot(parser, data, i)
+        assert hdr.frame_type == 0, "bench stream must be all key frames"
+        parser.swap(hdr)
+        ctx.upload(i)
+    feed_s = time.time() - t_feed0
+    for i in range(nsrc, F):
+        ctx.ir_copy(i, i % nsrc)
+    ctx.sync()
+    parser.close()
+
+    jobs = (P.Job * F)()
+    for i in range(F):
+        jobs[i].ir_slot, jobs[i].dst_fb = i, i
+        for k in range(4):
+            jobs[i].ref_fb[k] = -1
+    nmb = ctx.nmb
+
+    # ---- correctness gate: one untimed pass, check a spread of frames against the reference MD5s
+    ctx.decode_array(jobs, F, P.STAGE_ALL)
+    ctx.sync()
+    ok = 1
+    for i in sorted(set([0, 1, nsrc - 1, F // 2, F - 1])):
+        if P.planes_md5(*ctx.download_planes(i)) != gold[i % nsrc]:
+            ok = 0
+            sys.stderr.write(f"[bench] rank {rank}: frame {i} MD5 mismatch\n")
+    if dist is not None:
+        t = torch.tensor([ok], device="cuda", dtype=torch.int32)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        ok = int(t.item())
+    if not ok:
+        raise SystemExit("decode_to_md5 precondition failed: GPU output differs from the reference")
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        ctx.sync()
+
+    for _ in range(args.warmup):
+        ctx.decode_array(jobs, F, P.STAGE_ALL)
+    barrier()
+    k_recon = k_lf = k_ext = 0.0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ctx.decode_array(jobs, F, P.STAGE_ALL)
+        st = ctx.stats()            # HIP-event times of this step's three launches (syncs the stream)
+        k_recon += st.recon_ms
+        k_lf += st.lf_ms
+        k_ext += st.extend_ms
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        K = args.steps
+        total_pix = world * F * K * W * H
+        ms = {"recon": k_recon / K, "loopfilter": k_lf / K, "extend": k_ext / K}
+        bytes_per_launch = {"recon": B_RECON * nmb * F, "loopfilter": B_LF * nmb * F, "extend": B_EXTEND * nmb * F}
+        dom = max(ms, key=lambda k: ms[k])
+        achieved = bytes_per_launch[dom] / (ms[dom] * 1e-3) / 1e9
+        out = {
+            "metric": "vp8_decode_pixel_path_mpix_per_s",
+            "value": round(total_pix / elapsed / 1e6, 1),
+            "unit": "Mpix/s",
+            "n_gpus": world,
+            "steps": K,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / K * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{W}x{H} all-key-frame VP8 stream (tests/golden/{fixture}.ivf looped), full pixel "
+                            f"path: dequant+IDCT/WHT + intra recon + loop filter + border extend "
+                            f"(BASELINE configs[1]+[3]); IR resident in HBM, MD5-checked vs the reference",
+                "frames_per_gpu_per_step": F,
+                "macroblocks_per_frame": nmb,
+                "parallelism": f"frame-parallel, {world} GPU(s), no pixel exchange",
+                "kernel_ms": {k: round(v, 4) for k, v in ms.items()},
+                "waves_per_workgroup": {"recon": st.recon_waves, "loopfilter": st.lf_waves},
+                "workgroups": st.workgroups,
+                "host_feeder_s_for_source_frames": round(feed_s, 4),
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": {"recon": "vp8_recon_kernel", "loopfilter": "vp8_loopfilter_kernel",
+                           "extend": "vp8_extend_kernel"}[dom],
+                "achieved": round(achieved, 2),
+                "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBPS, 5),
+                "traffic": None,
+                "algorithmic_bytes_per_launch": bytes_per_launch[dom],
+                "mean_launch_ms": round(ms[dom], 4),
+                "all_kernels_GBps": {k: round(bytes_per_launch[k] / (ms[k] * 1e-3) / 1e9, 2) if ms[k] > 0 else None
+                                     for k in ms},
+            },
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(fixture)
+        print(json.dumps(out))
+    ctx.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -293,7 +293,7 @@ class Vp8Hip:
     def parse_into_slot(self, parser, data, slot):
         """Feeder writes straight into the pinned staging of `slot`; returns hdr (not yet uploaded)."""
         hdr, changed = parser.begin(data)
-        if changed or (hdr.width, hdr.height) != (self.width, self.height):
+        if (hdr.width, hdr.height) != (self.width, self.height):
             raise RuntimeError("dimension change: reconfigure the context first")
         ph, pm, pc, pv = self.ir_map(slot)
         parser.decode_mbs(pm, pc, pv)

@@ -299,7 +299,7 @@ vp8_recon_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g)
     const int lU = 2 * LINE_PAD + g.aligned_w, lV = lU + 2 * LINE_PAD + g.aligned_w / 2;
 
     if (threadIdx.x < 64) prog[threadIdx.x] = 0;
-    if (threadIdx.x < 160) bptab[threadIdx.x] = k_bpred_tab[threadIdx.x];
+    for (int i = threadIdx.x; i < 160; i += blockDim.x) bptab[i] = k_bpred_tab[i];   // blockDim may be 128
     if (lane < 3) {   // x = -1 of every line is the constant 129 left border (setupintrarecon.c:23-30)
         const int off = lane == 0 ? 0 : (lane == 1 ? lU : lV);
         my_line[off + LINE_PAD - 1] = 129;

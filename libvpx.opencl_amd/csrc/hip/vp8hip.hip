@@ -23,6 +23,7 @@ struct Slot {
     // pinned host mirror
     vp8ir_frame_hdr *h_hdr; vp8ir_mb *h_mbs; int16_t *h_coef; vp8ir_mv *h_mvs;
     vp8ir_frame_hdr hdr_copy;      // header as of the last upload / copy (host side, for job setup)
+    char *h_block;                 // pinned mirror, allocated on first vp8hip_ir_map
 };
 
 struct vp8hip_ctx {
@@ -39,7 +40,8 @@ struct vp8hip_ctx {
     // pools
     std::vector<uint8_t *> fb;
     std::vector<Slot> slots;
-    uint8_t *fb_block; char *slot_block_dev; char *slot_block_host;
+    uint8_t *fb_block; char *slot_block_dev;
+    size_t slot_bytes, o_mbs, o_coef, o_mvs;
     // job staging
     DevJob *d_jobs; DevJob *h_jobs; int jobs_cap;
     // launch configuration
@@ -70,8 +72,9 @@ static void free_pools(vp8hip_ctx *c)
 {
     if (c->fb_block) (void)hipFree(c->fb_block);
     if (c->slot_block_dev) (void)hipFree(c->slot_block_dev);
-    if (c->slot_block_host) (void)hipHostFree(c->slot_block_host);
-    c->fb_block = nullptr; c->slot_block_dev = nullptr; c->slot_block_host = nullptr;
+    for (Slot &s : c->slots)
+        if (s.h_block) (void)hipHostFree(s.h_block);
+    c->fb_block = nullptr; c->slot_block_dev = nullptr;
     c->fb.clear(); c->slots.clear();
 }
 
@@ -99,7 +102,7 @@ extern "C" int vp8hip_create(int device, vp8hip_ctx **out)
     c->device = device;
     c->num_cu = prop.multiProcessorCount;
     c->max_lds = 160 * 1024;
-    c->fb_block = nullptr; c->slot_block_dev = nullptr; c->slot_block_host = nullptr;
+    c->fb_block = nullptr; c->slot_block_dev = nullptr;
     c->d_jobs = nullptr; c->h_jobs = nullptr; c->jobs_cap = 0;
     c->width = c->height = 0;
     c->have_times = false;
@@ -183,16 +186,14 @@ extern "C" int vp8hip_configure(vp8hip_ctx *c, int width, int height, int num_fb
     const size_t o_mvs = o_coef + align_up((size_t)c->nmb * VP8IR_COEF_PER_MB * sizeof(int16_t), 256);
     const size_t slotsz = align_up(o_mvs + (size_t)c->nmb * 16 * sizeof(vp8ir_mv), 256);
     HIPCHK(c, hipMalloc((void **)&c->slot_block_dev, slotsz * num_slots));
-    HIPCHK(c, hipHostMalloc((void **)&c->slot_block_host, slotsz * num_slots, hipHostMallocDefault));
-    memset(c->slot_block_host, 0, slotsz * num_slots);
+    c->slot_bytes = slotsz; c->o_mbs = o_mbs; c->o_coef = o_coef; c->o_mvs = o_mvs;
     c->slots.resize(num_slots);
     for (int i = 0; i < num_slots; i++) {
-        char *d = c->slot_block_dev + slotsz * i, *h = c->slot_block_host + slotsz * i;
+        char *d = c->slot_block_dev + slotsz * i;
         Slot &s = c->slots[i];
         s.d_hdr = (vp8ir_frame_hdr *)d; s.d_mbs = (vp8ir_mb *)(d + o_mbs);
         s.d_coef = (int16_t *)(d + o_coef); s.d_mvs = (vp8ir_mv *)(d + o_mvs);
-        s.h_hdr = (vp8ir_frame_hdr *)h; s.h_mbs = (vp8ir_mb *)(h + o_mbs);
-        s.h_coef = (int16_t *)(h + o_coef); s.h_mvs = (vp8ir_mv *)(h + o_mvs);
+        s.h_block = nullptr; s.h_hdr = nullptr; s.h_mbs = nullptr; s.h_coef = nullptr; s.h_mvs = nullptr;
         memset(&s.hdr_copy, 0, sizeof s.hdr_copy);
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -211,6 +212,13 @@ extern "C" int vp8hip_ir_map(vp8hip_ctx *c, int slot, vp8ir_frame_hdr **hdr, vp8
 {
     if (!c || slot < 0 || slot >= (int)c->slots.size()) return fail(c, -2, "vp8hip_ir_map: bad slot %d", slot);
     Slot &s = c->slots[slot];
+    if (!s.h_block) {   // pinned staging is created on first use: device-only slots cost no host memory
+        HIPCHK(c, hipSetDevice(c->device));
+        HIPCHK(c, hipHostMalloc((void **)&s.h_block, c->slot_bytes, hipHostMallocDefault));
+        memset(s.h_block, 0, c->slot_bytes);
+        s.h_hdr = (vp8ir_frame_hdr *)s.h_block; s.h_mbs = (vp8ir_mb *)(s.h_block + c->o_mbs);
+        s.h_coef = (int16_t *)(s.h_block + c->o_coef); s.h_mvs = (vp8ir_mv *)(s.h_block + c->o_mvs);
+    }
     if (hdr) *hdr = s.h_hdr;
     if (mbs) *mbs = s.h_mbs;
     if (coef) *coef = s.h_coef;
@@ -222,6 +230,7 @@ extern "C" int vp8hip_ir_upload(vp8hip_ctx *c, int slot)
 {
     if (!c || slot < 0 || slot >= (int)c->slots.size()) return fail(c, -2, "vp8hip_ir_upload: bad slot %d", slot);
     Slot &s = c->slots[slot];
+    if (!s.h_block) return fail(c, -2, "vp8hip_ir_upload: slot %d was never mapped", slot);
     const vp8ir_frame_hdr &h = *s.h_hdr;
     if (h.mb_cols != c->dg.mb_cols || h.mb_rows != c->dg.mb_rows)
         return fail(c, -2, "vp8hip_ir_upload: header is %dx%d MBs, context configured for %dx%d", h.mb_cols,

@@ -1,0 +1,144 @@
+"""GPU (-m gpu): the HIP pixel path, called through the C ABI (include/vp8hip.h), against
+ (1) the reference decoder's per-frame MD5s on every fixture,
+ (2) the oracle, stage by stage and whole-buffer (borders included), on fixtures and on seeded random IR,
+ (3) size-independent properties at the benchmark's full batch sizes."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from vp8_testlib import (FIXTURES, bordered_area_equal, coded_area_equal, golden_md5, ivf_path, oracle_decode,
+                         random_frame, synth_ir)
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx(pkg):
+    c = pkg.Vp8Hip(0)
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("name", FIXTURES)
+def test_fixture_md5_frame_by_frame(pkg, name):
+    """decode_to_md5 parity: every shown frame equals the reference decoder's MD5."""
+    assert pkg.decode_ivf_gpu(ivf_path(name), device=0) == golden_md5(name)
+
+
+@pytest.mark.parametrize("name", ["kf_640x360", "p_split_352x288", "p_prof1_640x360", "p_prof3_640x360",
+                                  "p_sharp_320x240", "p_odd_130x98", "kf_q0_176x144"])
+def test_stages_against_oracle(pkg, ctx, name):
+    """recon / recon+LF on the coded area, full pipeline on the whole buffer incl. borders.  References
+    are re-seeded from the oracle every frame so a mismatch is attributed to the frame it occurs in."""
+    w, h, frames = pkg.read_ivf(ivf_path(name))
+    parser = pkg.Parser()
+    obufs = None
+    for data in frames[:6]:
+        hdr, changed, mbs, coef, mvs = pkg.parse_to_numpy(parser, data)
+        if changed:
+            ctx.configure(hdr.width, hdr.height, 4, 1)
+            g = ctx.g
+            obufs = [np.zeros(g.frame_size, np.uint8) for _ in range(4)]
+        r = parser.refs
+        refs = (r.lst_idx, r.gld_idx, r.alt_idx)
+        for idx in set(refs) - {r.new_idx}:
+            ctx.upload_frame(idx, obufs[idx])
+        ctx.fill_slot(0, hdr, mbs, coef, mvs)
+        final = None
+        for stages in (1, 3, 7):
+            o = np.zeros(g.frame_size, np.uint8)
+            oracle_decode(hdr, mbs, coef, mvs, o, tuple(obufs[i] for i in refs), stages)
+            ctx.decode([(0, r.new_idx, refs)], stages)
+            got = ctx.download_full(r.new_idx)
+            d = coded_area_equal(got, o, g) if stages != 7 else bordered_area_equal(got, o, g)
+            assert not d, (name, stages, d)
+            final = o
+        obufs[r.new_idx][:] = final
+        parser.swap(hdr)
+    parser.close()
+
+
+@pytest.mark.parametrize("w,h", [(16, 16), (48, 32), (176, 144), (640, 368), (1000, 40), (33, 600)])
+@pytest.mark.parametrize("inter,version,ftype", [(False, 0, 0), (True, 0, 0), (True, 1, 1), (True, 2, 0), (True, 3, 1)])
+def test_random_ir_against_oracle(pkg, ctx, w, h, inter, version, ftype):
+    """Seeded random IR (random modes, dense and sparse coefficients up to +-2047, random MVs incl. ones
+    that need the UMV clamp, random segment / loop-filter parameters): whole buffer must match the oracle."""
+    ctx.configure(w, h, 4, 1)
+    g = ctx.g
+    for seed in range(4):
+        hdr, mbs, coef, mvs = synth_ir(w, h, seed * 7 + w + 3 * version, inter=inter, version=version,
+                                       filter_type=ftype, dense=(0.15, 0.5, 0.9, 0.3)[seed], big=seed == 2)
+        refs_np = [random_frame(g, 100 + seed * 3 + k) for k in range(3)]
+        for k in range(3):
+            ctx.upload_frame(1 + k, refs_np[k])
+        ctx.fill_slot(0, hdr, mbs, coef, mvs)
+        o = np.zeros(g.frame_size, np.uint8)
+        oracle_decode(hdr, mbs, coef, mvs, o, tuple(refs_np), 7)
+        ctx.decode([(0, 0, (1, 2, 3))], 7)
+        d = bordered_area_equal(ctx.download_full(0), o, g)
+        assert not d, (seed, d)
+
+
+def _batch(pkg, ctx, name, nframes):
+    w, h, frames = pkg.read_ivf(ivf_path(name))
+    gold = golden_md5(name)
+    nsrc = len(frames)
+    ctx.configure(w, h, nframes, nframes)
+    parser = pkg.Parser()
+    for i, data in enumerate(frames):
+        hdr = ctx.parse_into_slot(parser, data, i)
+        assert hdr.frame_type == 0
+        parser.swap(hdr)
+        ctx.upload(i)
+    parser.close()
+    for i in range(nsrc, nframes):
+        ctx.ir_copy(i, i % nsrc)
+    ctx.decode([(i, i, None) for i in range(nframes)], 7)
+    ctx.sync()
+    return gold, nsrc
+
+
+@pytest.mark.parametrize("name,nframes", [("kf_odd_67x45", 700), ("kf_q0_176x144", 300), ("kf_640x360", 530)])
+def test_batched_key_frames(pkg, ctx, name, nframes):
+    """Many independent key frames in ONE launch (more jobs than workgroups: persistent loop, line-slot
+    reuse across frames, frames with fewer MB rows than waves): every frame equals its reference MD5."""
+    gold, nsrc = _batch(pkg, ctx, name, nframes)
+    for i in list(range(0, nframes, 37)) + [nframes - 1, 255, 256, 257]:
+        assert pkg.planes_md5(*ctx.download_planes(i)) == gold[i % nsrc], i
+
+
+def test_full_size_1080p_batch_properties(pkg, ctx):
+    """At the benchmark's size (1920x1080 x 512 frames per launch): replication invariance -- frame i and
+    frame i+10 were decoded from copies of the same IR by different workgroups/waves and must be
+    bit-identical over the WHOLE buffer; a sample is also checked against the reference MD5s."""
+    n = 512
+    gold, nsrc = _batch(pkg, ctx, "kf_1920x1080", n)
+    for i in (0, 1, 9, 250, 256, 511):
+        assert pkg.planes_md5(*ctx.download_planes(i)) == gold[i % nsrc], i
+    a = ctx.download_full(3)
+    for j in (13, 263, 503):
+        assert np.array_equal(a, ctx.download_full(j)), j
+    # idempotence: decoding the same jobs again into the same buffers changes nothing
+    ctx.decode([(i, i, None) for i in range(n)], 7)
+    assert np.array_equal(a, ctx.download_full(3))
+
+
+def test_full_size_4k(pkg, ctx):
+    gold, nsrc = _batch(pkg, ctx, "kf_3840x2160", 96)
+    for i in (0, 1, 2, 47, 95):
+        assert pkg.planes_md5(*ctx.download_planes(i)) == gold[i % nsrc], i
+
+
+def test_abi_error_paths(pkg, ctx):
+    ctx.configure(64, 64, 2, 1)
+    with pytest.raises(RuntimeError):
+        ctx.decode([(5, 0, None)], 7)              # slot out of range
+    with pytest.raises(RuntimeError):
+        ctx.decode([(0, 9, None)], 7)              # frame buffer out of range
+    hdr, mbs, coef, mvs = synth_ir(64, 64, 1, inter=True)
+    ctx.fill_slot(0, hdr, mbs, coef, mvs)
+    with pytest.raises(RuntimeError):
+        ctx.decode([(0, 0, (-1, -1, -1))], 7)      # inter frame without references
+    with pytest.raises(RuntimeError):
+        ctx.decode([(0, 1, (1, 1, 1))], 7)         # decoding into its own reference

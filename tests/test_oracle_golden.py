@@ -1,0 +1,46 @@
+"""CPU: host feeder + oracle reproduce the REAL reference decoder's per-frame MD5s on every fixture.
+This is what pins the oracle (and the feeder) to the reference: tests/golden/*.md5 were printed by the
+reference's own decoder (oracle/_ref, built from /root/reference) -- see tests/golden/make_fixtures.py."""
+import pytest
+
+from vp8_testlib import FIXTURES, golden_md5, oracle_decode_ivf
+
+
+@pytest.mark.parametrize("name", FIXTURES)
+def test_fixture_md5(name):
+    assert oracle_decode_ivf(name) == golden_md5(name)
+
+
+def test_fixture_matrix_covers_the_paths(pkg):
+    """The fixture set exercises what SURVEY.md 8c asks for: key/inter, all 4 versions, both filter
+    types, filter off, SPLITMV, B_PRED, intra MBs in inter frames, golden/alt refs, odd sizes, 1/4/8 partitions."""
+    from vp8_testlib import ivf_path
+    seen = {"versions": set(), "filter_types": set(), "lf0": False, "split": False, "bpred": False,
+            "intra_in_inter": False, "refs": set(), "parts": set(), "odd": False, "sharp": False, "skip": False}
+    for name in FIXTURES:
+        w, h, frames = pkg.read_ivf(ivf_path(name))
+        if name in ("kf_3840x2160", "kf_1920x1080", "p_1920x1080"):
+            frames = frames[:2]
+        parser = pkg.Parser()
+        for data in frames:
+            hdr, _, mbs, coef, mvs = pkg.parse_to_numpy(parser, data)
+            parser.swap(hdr)
+            seen["versions"].add(hdr.version)
+            seen["filter_types"].add(hdr.filter_type)
+            seen["lf0"] |= hdr.filter_level == 0
+            seen["parts"].add(hdr.num_token_partitions)
+            seen["odd"] |= (hdr.width % 16 != 0)
+            seen["sharp"] |= hdr.sharpness_level != 0
+            seen["split"] |= bool((mbs[:, 0] == 9).any())
+            seen["bpred"] |= bool((mbs[:, 0] == 4).any())
+            seen["skip"] |= bool((mbs[:, 3] & 1).any())
+            if hdr.frame_type:
+                seen["intra_in_inter"] |= bool((mbs[:, 2] == 0).any())
+                seen["refs"] |= set(mbs[:, 2].tolist())
+        parser.close()
+    assert seen["versions"] == {0, 1, 2, 3}
+    assert seen["filter_types"] == {0, 1}
+    assert seen["lf0"] and seen["split"] and seen["bpred"] and seen["intra_in_inter"] and seen["odd"]
+    assert seen["sharp"] and seen["skip"]
+    assert {1, 2}.issubset(seen["refs"])
+    assert {1, 4, 8}.issubset(seen["parts"])

@@ -112,3 +112,119 @@ def bordered_area_equal(a, b, g):
             ys, xs = np.nonzero(d)
             diffs.append((name, int(d.sum()), int(ys[0]) - bd, int(xs[0]) - bd))
     return diffs
+
+
+# ------------------------------------------------------------------------------------------
+# synthetic, well-formed IR (no bitstream involved): random modes / coefficients / MVs
+# ------------------------------------------------------------------------------------------
+ZIGZAG_RASTER = [0, 1, 4, 8, 5, 2, 3, 6, 9, 12, 13, 10, 7, 11, 14, 15]
+ZIGZAG_COLMAJOR = [(z % 4) * 4 + z // 4 for z in ZIGZAG_RASTER]
+
+
+def synth_ir(width, height, seed, inter=False, version=0, filter_type=0, dense=0.3, big=False, segmented=True):
+    """One frame of random IR.  Coefficients and eobs are mutually consistent the way the feeder
+    produces them (eob = last coded zig-zag position + 1; Y blocks of an MB with a Y2 block start at 1)."""
+    P = load_package()
+    rng = np.random.default_rng(seed)
+    cols, rows = (width + 15) // 16, (height + 15) // 16
+    n = cols * rows
+    hdr = P.FrameHdr()
+    hdr.width, hdr.height, hdr.mb_cols, hdr.mb_rows = width, height, cols, rows
+    hdr.frame_type = 1 if inter else 0
+    hdr.version = version
+    hdr.show_frame = 1
+    hdr.filter_type = filter_type
+    hdr.filter_level = int(rng.integers(0, 64)) if seed % 5 else 0
+    hdr.sharpness_level = int(rng.integers(0, 8))
+    hdr.segmentation_enabled = 1 if segmented else 0
+    hdr.mb_segment_abs_delta = int(rng.integers(0, 2))
+    for i in range(4):
+        hdr.segment_quant[i] = int(rng.integers(0, 128)) if hdr.mb_segment_abs_delta else int(rng.integers(-40, 41))
+        hdr.segment_lf[i] = int(rng.integers(0, 64)) if hdr.mb_segment_abs_delta else int(rng.integers(-30, 31))
+        hdr.ref_lf_deltas[i] = int(rng.integers(-20, 21))
+        hdr.mode_lf_deltas[i] = int(rng.integers(-20, 21))
+    hdr.mode_ref_lf_delta_enabled = int(rng.integers(0, 2))
+    hdr.base_qindex = int(rng.integers(0, 128))
+    for f in ("y1dc_delta_q", "y2dc_delta_q", "y2ac_delta_q", "uvdc_delta_q", "uvac_delta_q"):
+        setattr(hdr, f, int(rng.integers(-15, 16)))
+    mbs = np.zeros((n, 64), np.uint8)
+    coef = np.zeros((n, 400), np.int16)
+    mvs = np.zeros((n, 16, 2), np.int16)
+    zz = np.array(ZIGZAG_COLMAJOR)
+    for i in range(n):
+        r, c = divmod(i, cols)
+        is_inter = inter and rng.random() < 0.8
+        if is_inter:
+            y_mode = int(rng.choice([5, 6, 7, 8, 9]))
+            mbs[i, 2] = int(rng.integers(1, 4))
+            mbs[i, 1] = 0
+        else:
+            y_mode = int(rng.choice([0, 1, 2, 3, 4], p=[0.15, 0.15, 0.15, 0.15, 0.4]))
+            mbs[i, 1] = int(rng.integers(0, 4))
+            mbs[i, 40:56] = rng.integers(0, 10, size=16)
+        mbs[i, 0] = y_mode
+        mbs[i, 4] = int(rng.integers(0, 4)) if segmented else 0
+        has_y2 = y_mode not in (4, 9)
+        skip = rng.random() < 0.15
+        if is_inter:
+            # MVs in 1/8 pel units (even for luma, as the bitstream stores quarter pel << 1), kept within
+            # the range the feeder's bounds logic allows without clamping, or flagged for clamping
+            clampflag = rng.random() < 0.3
+            lim_l, lim_r = -(c * 16 + 16) * 8, ((cols - 1 - c) * 16 + 16) * 8
+            lim_t, lim_b = -(r * 16 + 16) * 8, ((rows - 1 - r) * 16 + 16) * 8
+            if clampflag:
+                lim_l -= 400; lim_r += 400; lim_t -= 400; lim_b += 400
+                mbs[i, 3] |= 2
+            def rmv():
+                return (int(rng.integers(lim_t // 2, lim_b // 2 + 1)) * 2, int(rng.integers(lim_l // 2, lim_r // 2 + 1)) * 2)
+            if y_mode == 9:
+                part = int(rng.integers(0, 4))
+                mbs[i, 5] = part
+                groups = {0: lambda b: b >> 3, 1: lambda b: (b >> 1) & 1, 2: lambda b: ((b >> 3) << 1) | ((b >> 1) & 1),
+                          3: lambda b: b}[part]
+                table = {}
+                for b in range(16):
+                    gidx = groups(b)
+                    if gidx not in table:
+                        table[gidx] = rmv() if rng.random() < 0.8 else (0, 0)
+                    mvs[i, b] = table[gidx]
+            else:
+                mv = (0, 0) if y_mode == 7 else rmv()
+                mvs[i, :] = mv
+        if skip:
+            mbs[i, 3] |= 1
+            continue
+        mag = 2047 if big else 60
+        total = 0
+        for b in range(25):
+            if b == 24 and not has_y2:
+                continue
+            first = 1 if (has_y2 and b < 16) else 0
+            if rng.random() < dense:
+                last = int(rng.integers(first, 16))
+                vals = rng.integers(-mag, mag + 1, size=16).astype(np.int16)
+                vals[rng.random(16) < 0.5] = 0
+                vals[:first] = 0
+                vals[last + 1:] = 0
+                if vals[last] == 0:
+                    vals[last] = 1
+                coef[i, b * 16 + zz] = vals
+                eob = 15 if last == 15 else last + 1
+            else:
+                eob = first
+            mbs[i, 8 + b] = eob
+            total += eob
+        if has_y2:
+            total -= 16
+        if total == 0:
+            mbs[i, 3] |= 1
+            mbs[i, 8:33] = 0
+            coef[i] = 0
+    return hdr, mbs, coef, mvs
+
+
+def random_frame(g, seed):
+    """A fully defined random reference frame buffer (smooth + noise so filters do interesting things)."""
+    rng = np.random.default_rng(seed)
+    buf = rng.integers(0, 256, size=g.frame_size).astype(np.uint8)
+    return buf
