@@ -1,0 +1,289 @@
+/* The VP8 decoder algorithm interface `vpx_codec_vp8_dx`, backed by the MI355X HIP pixel path.
+ *
+ * Same entry points, argument meaning and error behaviour as the reference's
+ *   vp8/vp8_dx_iface.c        vp8_init :188, vp8_destroy :221, vp8_peek_si :245, vp8_get_si :287,
+ *                             vp8_decode :350, vp8_get_frame :485, controls :611-770, iface :776
+ *   vp8/decoder/onyxd_if.c    vp8dx_receive_compressed_data :318 (frame lifecycle, buffer swap)
+ * but the work is split differently: the host only entropy-decodes (vp8_parser) into pinned IR
+ * staging; prediction, residual, loop filter and border extension run on the GPU through the
+ * RTCD table (include/vp8_rtcd.h -> include/vp8hip.h); the reference-frame pool lives in HBM and
+ * only the frame to show is copied back.  No CPU pixel fallback exists: if the GPU is
+ * unavailable, decode() returns VPX_CODEC_ERROR with a detail string.
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "vp8_parser.h"
+#include "vp8_rtcd.h"
+#include "vpx/vp8dx.h"
+#include "vpx_codec_internal.h"
+
+#define VP8_CAP_POSTPROC 0          /* CONFIG_POSTPROC 0 in the decoder-only generic build */
+
+struct vpx_codec_alg_priv {
+    vpx_codec_priv_t        base;
+    vpx_codec_dec_cfg_t     cfg;
+    vpx_codec_stream_info_t si;
+    int                     decoder_init;
+    vp8_parser             *parser;
+    vp8hip_ctx             *hip;
+    vp8_refs                refs;
+    vp8ir_geom              geom;
+    int                     width, height;
+    uint8_t                *host_frame;       /* frame_to_show copied back, vp8ir_geom layout */
+    vpx_image_t             img;
+    int                     img_avail;
+    int                     fb_corrupted[4];
+    int                     show_corrupted;
+    int                     ref_updates, ref_used;
+    char                    detail[160];
+};
+
+static vpx_codec_err_t set_detail(vpx_codec_alg_priv_t *p, vpx_codec_err_t code, const char *msg)
+{
+    snprintf(p->detail, sizeof p->detail, "%s", msg ? msg : "");
+    p->base.err_detail = msg ? p->detail : NULL;
+    return code;
+}
+
+static vpx_codec_err_t vp8_init(vpx_codec_ctx_t *ctx, void *mr_cfg)
+{
+    (void)mr_cfg;
+    if (!ctx->priv) {
+        vpx_codec_alg_priv_t *p = (vpx_codec_alg_priv_t *)calloc(1, sizeof *p);
+        if (!p) return VPX_CODEC_MEM_ERROR;
+        ctx->priv = &p->base;
+        p->base.sz = sizeof *p;
+        p->base.iface = ctx->iface;
+        p->base.alg_priv = p;
+        p->base.init_flags = ctx->init_flags;
+        p->si.sz = sizeof p->si;
+        if (ctx->config.dec) {           /* keep our own copy: the caller's struct may go away */
+            p->cfg = *ctx->config.dec;
+            ctx->config.dec = &p->cfg;
+        }
+    }
+    return VPX_CODEC_OK;
+}
+
+static vpx_codec_err_t vp8_destroy(vpx_codec_alg_priv_t *p)
+{
+    if (p->hip) vp8hip_destroy(p->hip);
+    vp8_parser_destroy(p->parser);
+    free(p->host_frame);
+    free(p);
+    return VPX_CODEC_OK;
+}
+
+static vpx_codec_err_t vp8_peek_si(const uint8_t *data, unsigned int data_sz, vpx_codec_stream_info_t *si)
+{
+    int is_kf = 0, w = 0, h = 0, rc;
+    if (data + data_sz <= data) return VPX_CODEC_INVALID_PARAM;
+    rc = vp8_parser_peek(data, data_sz, &is_kf, &w, &h);
+    si->is_kf = (unsigned)is_kf;
+    if (is_kf) { si->w = (unsigned)w; si->h = (unsigned)h; }
+    return (vpx_codec_err_t)rc;
+}
+
+static vpx_codec_err_t vp8_get_si(vpx_codec_alg_priv_t *p, vpx_codec_stream_info_t *si)
+{
+    unsigned int sz = si->sz >= sizeof p->si ? sizeof p->si : sizeof(vpx_codec_stream_info_t);
+    memcpy(si, &p->si, sz);
+    si->sz = sz;
+    return VPX_CODEC_OK;
+}
+
+static vpx_codec_err_t gpu_error(vpx_codec_alg_priv_t *p, const char *what)
+{
+    char msg[160];
+    snprintf(msg, sizeof msg, "%s: %s", what, vp8hip_last_error(p->hip));
+    return set_detail(p, VPX_CODEC_ERROR, msg);
+}
+
+/* yuvconfig2image (vp8_dx_iface.c:319-347): the image aliases the decoder's own frame memory */
+static void publish_image(vpx_codec_alg_priv_t *p, void *user_priv)
+{
+    vpx_image_t *img = &p->img;
+    const vp8ir_geom *g = &p->geom;
+    memset(img, 0, sizeof *img);
+    img->fmt = VPX_IMG_FMT_I420;
+    img->w = (unsigned)g->y_stride;
+    img->h = (unsigned)((g->aligned_h + 2 * VP8IR_BORDER + 15) & ~15);
+    img->d_w = (unsigned)p->width;
+    img->d_h = (unsigned)p->height;
+    img->x_chroma_shift = img->y_chroma_shift = 1;
+    img->planes[VPX_PLANE_Y] = p->host_frame + g->y_off;
+    img->planes[VPX_PLANE_U] = p->host_frame + g->u_off;
+    img->planes[VPX_PLANE_V] = p->host_frame + g->v_off;
+    img->planes[VPX_PLANE_ALPHA] = NULL;
+    img->stride[VPX_PLANE_Y] = g->y_stride;
+    img->stride[VPX_PLANE_U] = img->stride[VPX_PLANE_V] = g->uv_stride;
+    img->stride[VPX_PLANE_ALPHA] = g->y_stride;
+    img->bps = 12;
+    img->user_priv = user_priv;
+    img->img_data = p->host_frame;
+}
+
+static vpx_codec_err_t vp8_decode(vpx_codec_alg_priv_t *p, const uint8_t *data, unsigned int data_sz, void *user_priv,
+                                  long deadline)
+{
+    vp8ir_frame_hdr hdr, *h_hdr;
+    vp8ir_mb *h_mbs;
+    int16_t *h_coef;
+    vp8ir_mv *h_mvs;
+    vp8hip_job job;
+    int rc, corrupt = 0, i, nmb;
+    (void)deadline;
+
+    p->img_avail = 0;
+    p->base.err_detail = NULL;
+
+    if (!p->si.h) {                                   /* first call: needs a key frame (vp8_dx_iface.c:364) */
+        vpx_codec_err_t res = vp8_peek_si(data, data_sz, &p->si);
+        if (res) return res;
+    }
+    if (!p->decoder_init) {                           /* vp8dx_create_decompressor equivalent */
+        int device = -1;
+        const char *env = getenv("VP8HIP_DEVICE");
+        if (env && *env) device = atoi(env);
+        vpx_rtcd();
+        p->parser = vp8_parser_create();
+        if (!p->parser) return VPX_CODEC_MEM_ERROR;
+        vp8_refs_init(&p->refs);
+        p->decoder_init = 1;
+        if (vp8hip_create(device, &p->hip)) {
+            p->hip = NULL;
+            return set_detail(p, VPX_CODEC_ERROR, vp8hip_last_error(NULL));
+        }
+    }
+    if (!p->hip) return set_detail(p, VPX_CODEC_ERROR, "HIP pixel path unavailable (no CPU fallback)");
+
+    if (data == NULL && data_sz == 0) {
+        /* missing frame (onyxd_if.c:375-407): mark the last reference corrupt, nothing to show */
+        p->fb_corrupted[p->refs.lst_idx] = 1;
+        return VPX_CODEC_OK;
+    }
+
+    if (vp8_refs_get_free(&p->refs) < 0) return set_detail(p, VPX_CODEC_ERROR, "no free frame buffer");
+    rc = vp8_parser_begin_frame(p->parser, data, data_sz, &hdr);
+    if (rc) {
+        vp8_refs_release_new(&p->refs);
+        return set_detail(p, (vpx_codec_err_t)rc, vp8_parser_error(p->parser));
+    }
+    if (hdr.width != p->width || hdr.height != p->height) {       /* vp8_alloc_frame_buffers */
+        if (vp8hip_configure(p->hip, hdr.width, hdr.height, 4, 1)) {
+            vp8_refs_release_new(&p->refs);
+            return gpu_error(p, "vp8hip_configure");
+        }
+        vp8hip_geometry(p->hip, &p->geom);
+        free(p->host_frame);
+        p->host_frame = (uint8_t *)malloc((size_t)p->geom.frame_size);
+        if (!p->host_frame) return VPX_CODEC_MEM_ERROR;
+        p->width = hdr.width;
+        p->height = hdr.height;
+        p->si.w = hdr.width;
+        p->si.h = hdr.height;
+        vp8_refs_on_alloc(&p->refs);
+        memset(p->fb_corrupted, 0, sizeof p->fb_corrupted);
+    }
+    if (vp8hip_ir_map(p->hip, 0, &h_hdr, &h_mbs, &h_coef, &h_mvs)) return gpu_error(p, "vp8hip_ir_map");
+    rc = vp8_parser_decode_mbs(p->parser, h_mbs, h_coef, h_mvs, &corrupt);
+    if (rc) {
+        vp8_refs_release_new(&p->refs);
+        return set_detail(p, (vpx_codec_err_t)rc, vp8_parser_error(p->parser));
+    }
+    *h_hdr = hdr;
+
+    /* which references does this frame read (vp8dx_references_buffer, onyxd_if.c:711-760) */
+    nmb = hdr.mb_cols * hdr.mb_rows;
+    p->ref_used = 0;
+    if (hdr.frame_type != 0)
+        for (i = 0; i < nmb; i++) {
+            int rf = h_mbs[i].ref_frame;
+            if (rf == VP8IR_LAST_FRAME) p->ref_used |= VP8_LAST_FRAME;
+            else if (rf == VP8IR_GOLDEN_FRAME) p->ref_used |= VP8_GOLD_FRAME;
+            else if (rf == VP8IR_ALTREF_FRAME) p->ref_used |= VP8_ALTR_FRAME;
+        }
+    p->ref_updates = (hdr.refresh_last ? VP8_LAST_FRAME : 0) | (hdr.refresh_golden ? VP8_GOLD_FRAME : 0)
+                   | (hdr.refresh_alt ? VP8_ALTR_FRAME : 0);
+    if (p->ref_used & VP8_LAST_FRAME) corrupt |= p->fb_corrupted[p->refs.lst_idx];
+    if (p->ref_used & VP8_GOLD_FRAME) corrupt |= p->fb_corrupted[p->refs.gld_idx];
+    if (p->ref_used & VP8_ALTR_FRAME) corrupt |= p->fb_corrupted[p->refs.alt_idx];
+    p->fb_corrupted[p->refs.new_idx] = corrupt;
+
+    if (vp8hip_ir_upload(p->hip, 0)) { vp8_refs_release_new(&p->refs); return gpu_error(p, "vp8hip_ir_upload"); }
+    job.ir_slot = 0;
+    job.dst_fb = p->refs.new_idx;
+    job.ref_fb[0] = -1;
+    job.ref_fb[VP8IR_LAST_FRAME] = p->refs.lst_idx;
+    job.ref_fb[VP8IR_GOLDEN_FRAME] = p->refs.gld_idx;
+    job.ref_fb[VP8IR_ALTREF_FRAME] = p->refs.alt_idx;
+    if (vp8_decode_frame_pixels(p->hip, &job, 1)) { vp8_refs_release_new(&p->refs); return gpu_error(p, "vp8hip_decode"); }
+
+    if (vp8_refs_swap(&p->refs, &hdr)) return set_detail(p, VPX_CODEC_ERROR, "invalid buffer copy flags");
+    p->show_corrupted = p->fb_corrupted[p->refs.show_idx];
+
+    if (hdr.show_frame) {
+        const vp8ir_geom *g = &p->geom;
+        if (vp8hip_frame_download(p->hip, p->refs.show_idx, 0, p->host_frame + g->y_off, p->host_frame + g->u_off,
+                                  p->host_frame + g->v_off, g->y_stride, g->uv_stride))
+            return gpu_error(p, "vp8hip_frame_download");
+        publish_image(p, user_priv);
+        p->img_avail = 1;
+    } else if (vp8hip_sync(p->hip))
+        return gpu_error(p, "vp8hip_sync");
+    return VPX_CODEC_OK;
+}
+
+static vpx_image_t *vp8_get_frame(vpx_codec_alg_priv_t *p, vpx_codec_iter_t *iter)
+{
+    if (p->img_avail && !*iter) {          /* flip-flop iterator (vp8_dx_iface.c:485-503) */
+        *iter = &p->img;
+        return &p->img;
+    }
+    return NULL;
+}
+
+static vpx_codec_err_t ctl_get_int(vpx_codec_alg_priv_t *p, int ctrl_id, va_list ap)
+{
+    int *out = va_arg(ap, int *);
+    if (!out) return VPX_CODEC_INVALID_PARAM;
+    if (!p->decoder_init) return VPX_CODEC_ERROR;
+    if (ctrl_id == VP8D_GET_FRAME_CORRUPTED) *out = p->show_corrupted;
+    else if (ctrl_id == VP8D_GET_LAST_REF_UPDATES) *out = p->ref_updates;
+    else *out = p->ref_used;
+    return VPX_CODEC_OK;
+}
+
+static vpx_codec_err_t ctl_incapable(vpx_codec_alg_priv_t *p, int ctrl_id, va_list ap)
+{
+    (void)ctrl_id; (void)ap;
+    /* VP8_SET_REFERENCE / VP8_COPY_REFERENCE / postproc: outside the hot path */
+    return set_detail(p, VPX_CODEC_INCAPABLE, "control not implemented by the HIP decoder");
+}
+
+static vpx_codec_ctrl_fn_map_t vp8_ctf_maps[] = {
+    { VP8_SET_REFERENCE, ctl_incapable },
+    { VP8_COPY_REFERENCE, ctl_incapable },
+    { VP8_SET_POSTPROC, ctl_incapable },
+    { VP8D_GET_LAST_REF_UPDATES, ctl_get_int },
+    { VP8D_GET_FRAME_CORRUPTED, ctl_get_int },
+    { VP8D_GET_LAST_REF_USED, ctl_get_int },
+    { -1, NULL },
+};
+
+const struct vpx_codec_iface vpx_codec_vp8_dx_algo = {
+    "MI355X HIP VP8 Decoder (gfx950) " "v1.0.0",
+    VPX_CODEC_INTERNAL_ABI_VERSION,
+    VPX_CODEC_CAP_DECODER | VP8_CAP_POSTPROC,
+    vp8_init,
+    vp8_destroy,
+    vp8_ctf_maps,
+    NULL,               /* get_mmap: XMA not supported */
+    NULL,               /* set_mmap */
+    { vp8_peek_si, vp8_get_si, vp8_decode, vp8_get_frame },
+    { NULL, NULL, NULL, NULL, NULL, NULL, NULL },
+};
+
+vpx_codec_iface_t *vpx_codec_vp8_dx(void) { return &vpx_codec_vp8_dx_algo; }

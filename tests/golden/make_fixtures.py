@@ -26,6 +26,7 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 REFDIR = os.path.join(ROOT, "oracle", "_ref")
 VPXENC = os.path.join(REFDIR, "vpxenc_ref")
 REFMD5 = os.path.join(REFDIR, "ref_md5")
+VPXDEC = os.path.join(REFDIR, "vpxdec_ref")
 
 
 def synth_i420(w, h, frames, seed, noise=6, speed=(1.375, 0.625)):
@@ -130,7 +131,19 @@ def run(cmd):
         raise SystemExit("FAILED: " + " ".join(cmd))
 
 
+def stream_md5(name):
+    """`vpxdec --md5 --i420` of the REFERENCE: one digest over all shown frames (vpxdec.c:322-383)."""
+    ivf = os.path.join(HERE, name + ".ivf")
+    r = subprocess.run([VPXDEC, "--md5", "--i420", ivf], capture_output=True, text=True, check=True)
+    with open(os.path.join(HERE, name + ".vpxdec_md5"), "w") as f:
+        f.write(r.stdout.split()[0] + "\n")
+
+
 def main():
+    if "--stream-md5-only" in sys.argv:
+        for name in FIXTURES:
+            stream_md5(name)
+        return
     names = sys.argv[1:] or list(FIXTURES)
     for exe in (VPXENC, REFMD5):
         if not os.path.exists(exe):
@@ -146,6 +159,7 @@ def main():
             base = args if "-p" in args else COMMON + args
             run([VPXENC, *base, "-w", str(w), "-h", str(h), "-o", ivf, yuv])
         run([REFMD5, ivf, md5])
+        stream_md5(name)
         nshown = sum(1 for _ in open(md5))
         print(f"{name:20s} {os.path.getsize(ivf):8d} B  {nshown:3d} shown frames  "
               f"listing-md5 {hashlib.md5(open(md5,'rb').read()).hexdigest()[:12]}")
