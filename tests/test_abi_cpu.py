@@ -12,6 +12,7 @@ from vp8_testlib import ROOT
 def declared(header, prefix):
     src = open(os.path.join(ROOT, "include", header)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    src = re.sub(r"^[ \t]*#[ \t]*define(?:.*\\\n)*.*$", "", src, flags=re.M)     # macros are not symbols
     return sorted(set(re.findall(r"\b(" + prefix + r"\w+)\s*\(", src)))
 
 
