@@ -28,19 +28,41 @@ struct DevGeom {
 
 // ---- intra-workgroup progress flags in LDS ------------------------------------------------
 // A wave publishes "(row sequence number << 16) | MBs finished in that row"; finishing a row
-// publishes (seq+1) << 16.  All waves of a workgroup live on one CU and share its L1, so
-// workgroup-scope release/acquire is sufficient for data handed over through LDS *and* through
-// global memory (LLVM AMDGPU memory model, non-tgsplit mode).
+// publishes (seq+1) << 16.  All waves of a workgroup live on one CU.
+//
+// Two flavours, chosen by where the handed-over DATA lives:
+//  * data in LDS (recon kernel's line buffers): a wave's LDS operations are executed in issue
+//    order, so "write data; write flag" / "read flag; read data" need NO s_waitcnt at all -- only
+//    the compiler must be kept from reordering.  In particular the publisher does not wait for its
+//    outstanding global stores (frame write-out) and the consumer does not drain its prefetches.
+//  * data in global memory (loop-filter kernel's context rows): the publisher must have its stores
+//    acknowledged (s_waitcnt vmcnt(0)) before the flag store; same CU => same L1/L2, so workgroup
+//    scope needs no cache maintenance (LLVM AMDGPU memory model, non-tgsplit mode).
+__device__ __forceinline__ void compiler_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 __device__ __forceinline__ void wg_wait_ge(int *flag, int value)
 {
     while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < value)
-        __builtin_amdgcn_s_sleep(2);
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        __builtin_amdgcn_s_sleep(1);
+    compiler_fence();
 }
 
-__device__ __forceinline__ void wg_publish(int *flag, int value, int lane)
+__device__ __forceinline__ void wg_publish_lds(int *flag, int value, int lane)
 {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    compiler_fence();
+    if (lane == 0)
+        __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+__device__ __forceinline__ void wg_publish_global(int *flag, int value, int lane)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    compiler_fence();
     if (lane == 0)
         __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }

@@ -205,7 +205,7 @@ vp8_loopfilter_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g)
         const vp8ir_frame_hdr &hdr = job.hdr;
         const int dep_seq = (R - 1) / NW;
         if (hdr.filter_level == 0) {             // frame not filtered at all (onyxd_if.c:576)
-            wg_publish(&prog[wave], (k + 1) << 16, lane);
+            wg_publish_global(&prog[wave], (k + 1) << 16, lane);
             continue;
         }
         build_levels(hdr, wl->lvl, lane);
@@ -346,7 +346,7 @@ vp8_loopfilter_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g)
                         *(const unsigned int *)((pl ? tV : tU) + LC_AT(yy, -4));
                 }
             }
-            wg_publish(&prog[wave], c + 1 == cols ? (k + 1) << 16 : (k << 16) + c + 1, lane);
+            wg_publish_global(&prog[wave], c + 1 == cols ? (k + 1) << 16 : (k << 16) + c + 1, lane);
         }
     }
 }

@@ -17,15 +17,23 @@
 //     row above must be two MBs ahead (above-right pixels of B_PRED); progress is exchanged
 //     through LDS flags, never through global memory, never across CUs.
 //   * unfiltered neighbour pixels travel through LDS: the bottom pixel line of every MB row sits in
-//     a per-wave LDS line buffer, the left column stays in the wave's LDS tile.  The frame in HBM
-//     is written exactly once per pixel and never read back by this kernel; coefficients are read
-//     exactly once (coalesced 8-byte-per-lane loads, lane = 4x4 block column).
+//     a per-wave LDS line buffer, the left column stays in the wave's LDS working set.  The frame in
+//     HBM is written exactly once per pixel and never read back by this kernel; coefficients are
+//     read exactly once (coalesced 8-byte-per-lane loads, lane = 4x4 block column).
+//   * the per-MB instruction stream is latency-bound (dependent steps), so dependent memory round
+//     trips are designed out: the 4x4 transposes of the IDCT/WHT are DPP quad permutes (no LDS), DC
+//     sums are v_sad_u8 over uniformly-read LDS dwords (no cross-lane reduction), MB descriptors are
+//     prefetched two MBs ahead with one vector load and read with v_readlane, and a B_PRED sub-block
+//     step costs exactly one LDS write->read turnaround (edge vector assembled and indexed in
+//     registers with v_perm / v_alignbyte, predictor table and residuals preloaded).
 //   * integer only (u8 pixels, i16 coefficients, i32 accumulators); no MFMA by design.
 #include "vp8_common.hip.h"
+#include <stddef.h>
 
-// ---- 4x4 intra predictor table (same encoding as the oracle's, derived from
-// vp8/common/reconintra4x4.c:16-303): edge vector P[15] = {L3,L3,L2,L1,L0,TL,A0..A7,A7};
-// entry = kind<<4 | k with kind 0 copy, 1 (P[k]+P[k+1]+1)>>1, 2 (P[k-1]+2P[k]+P[k+1]+2)>>2.
+// ---- 4x4 intra predictor table (derived from vp8/common/reconintra4x4.c:16-303, same as the
+// oracle's): edge vector P[0..14] = {L3,L3,L2,L1,L0,TL,A0..A7,A7}; entry = kind<<4 | k with kind
+// 0: P[k], 1: (P[k]+P[k+1]+1)>>1, 2: (P[k-1]+2P[k]+P[k+1]+2)>>2.  Rows = modes; B_DC / B_TM (rows
+// 0,1) are computed directly.
 #define C_(k) (0x00 | (k))
 #define A_(k) (0x10 | (k))
 #define F_(k) (0x20 | (k))
@@ -52,32 +60,57 @@ __constant__ static const short k_sixtap[8][6] = {
 };
 
 // ---- per-wave LDS working set ----------------------------------------------------------------
-// Tiles hold the MB being reconstructed plus its prediction edges:
-//   tY: 17 rows (y = -1..15) x 24 cols (x = -4..19); x = -1 is the left column, x = 16..19 of
-//       row -1 the above-right pixels.  tU/tV: 9 rows x 12 cols (x = -4..7).
-#define TY_STRIDE 24
-#define TC_STRIDE 12
-#define TY_AT(y, x) (((y) + 1) * TY_STRIDE + (x) + 4)
-#define TC_AT(y, x) (((y) + 1) * TC_STRIDE + (x) + 4)
+//   tY: 17 rows (y = -1..15), 40-byte rows: x = -4..-1 at 12..15, x = 0..15 at 16..31 (16-byte
+//       aligned), x = 16..19 at 32..35.  Row -1 holds the above line incl. top-left and above-right.
+//   tU/tV: 9 rows, 24-byte rows: x = -4..-1 at 4..7, x = 0..7 at 8..15.
+//   lcol: left column of the current MB, contiguous (Y 16, U 8, V 8) for v_sad_u8 sums.
+#define TY_STRIDE 40
+#define TC_STRIDE 24
+#define TY_AT(y, x) (((y) + 1) * TY_STRIDE + 16 + (x))
+#define TC_AT(y, x) (((y) + 1) * TC_STRIDE + 8 + (x))
 struct __attribute__((aligned(16))) WaveLds {
-    unsigned char tY[17 * TY_STRIDE];   // 408
-    unsigned char tU[9 * TC_STRIDE];    // 108
-    unsigned char tV[9 * TC_STRIDE];    // 108  -> 624
-    short res[384];                     // residual, pixel order: [blk][row][col]      -> 1392
-    short tr[400];                      // IDCT transpose scratch: [blk][row][col]      -> 2192
-    short wht_dc[16];                   // Y2 -> per-block DC                           -> 2224
-    short dq[4][6];                     // per segment: y1dc,y1ac,y2dc,y2ac,uvdc,uvac   -> 2272
-    unsigned char pad[16];              //                                              -> 2288
+    unsigned char lcol[32];             //    0
+    unsigned char tY[17 * TY_STRIDE];   //   32 .. 712
+    unsigned char padA[8];              //  712 .. 720
+    unsigned char tU[9 * TC_STRIDE];    //  720 .. 936
+    unsigned char tV[9 * TC_STRIDE];    //  936 .. 1152
+    short res[384];                     // 1152 .. 1920  residual, pixel order [blk][row][col] (B_PRED only)
+    short dq[4][8];                     // 1920 .. 1984  per segment: y1dc,y1ac,y2dc,y2ac,uvdc,uvac
+    unsigned int colbuf[16];            // 1984 .. 2048  right column of each finished 4x4 block
+    short wht_dc[16];                   // 2048 .. 2080  Y2 -> per-block DC
 };
-static_assert(sizeof(WaveLds) % 16 == 0, "WaveLds alignment");
+static_assert(sizeof(WaveLds) == 2080, "WaveLds layout");
+static_assert(offsetof(WaveLds, tY) % 16 == 0 && offsetof(WaveLds, tU) % 16 == 0 && offsetof(WaveLds, tV) % 8 == 0
+              && offsetof(WaveLds, res) % 16 == 0, "WaveLds alignment");
 
-#define LINE_PAD 16   // line[LINE_PAD + x]; x = -1 valid (left border), x up to W+3 valid
+#define LINE_PAD 16   // line[LINE_PAD + x]; x = -4..-1 readable (x = -1 is the 129 left border), x up to W+3 valid
 
-__device__ __forceinline__ int line_bytes(int aligned_w) { return 2 * aligned_w + 6 * LINE_PAD; }
+typedef unsigned int u32;
+
+__device__ __forceinline__ u32 dpp_xor1(u32 v) { return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, false); }
+__device__ __forceinline__ u32 dpp_xor2(u32 v) { return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, false); }
+__device__ __forceinline__ u32 perm(u32 hi, u32 lo, u32 sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
+__device__ __forceinline__ int sad4(u32 v) { return (int)__builtin_amdgcn_sad_u8(v, 0u, 0u); }
+__device__ __forceinline__ int sext16(u32 v) { return (int)(short)(v & 0xffff); }
+__device__ __forceinline__ int hi16(u32 v) { return (int)v >> 16; }
+
+// 4x4 transpose of 16-bit values across the four lanes of a quad.  In: lane j holds column j as
+// (o0,o1,o2,o3) = rows 0..3 (truncated to 16 bits here, as the reference's `short output[16]`).
+// Out: lane i holds row i as t[0..3] = columns 0..3.  Two DPP stages, no LDS.
+__device__ __forceinline__ void quad_transpose16(int o0, int o1, int o2, int o3, int lane, int t[4])
+{
+    u32 p01 = ((u32)o0 & 0xffff) | ((u32)o1 << 16), p23 = ((u32)o2 & 0xffff) | ((u32)o3 << 16);
+    const u32 selA = (lane & 1) ? 0x03020706u : 0x05040100u;
+    u32 a01 = perm(dpp_xor1(p01), p01, selA), a23 = perm(dpp_xor1(p23), p23, selA);
+    const bool up = lane & 2;
+    u32 recv = dpp_xor2(up ? a01 : a23);
+    u32 lo = up ? recv : a01, hi = up ? a23 : recv;
+    t[0] = sext16(lo); t[1] = hi16(lo); t[2] = sext16(hi); t[3] = hi16(hi);
+}
 
 // vp8cx_init_de_quantizer + mb_init_dequantizer (vp8/decoder/decodframe.c:50-109,
 // vp8/common/quant_common.c:39-132): six factors per segment.
-__device__ __forceinline__ void build_dequant(const vp8ir_frame_hdr &h, short (*dq)[6], int lane)
+__device__ __forceinline__ void build_dequant(const vp8ir_frame_hdr &h, short (*dq)[8], int lane)
 {
     if (lane < 24) {
         int seg = lane / 6, k = lane % 6;
@@ -102,23 +135,21 @@ __device__ __forceinline__ void build_dequant(const vp8ir_frame_hdr &h, short (*
     }
 }
 
-// One column (vertical) pass of vp8_short_idct4x4llm_c (idctllm.c:39-60); outputs truncated to i16.
-__device__ __forceinline__ void idct_col(int i0, int i1, int i2, int i3, short o[4])
+// Column (vertical) pass of vp8_short_idct4x4llm_c (idctllm.c:39-60); results are truncated to
+// i16 by the packing in quad_transpose16.
+__device__ __forceinline__ void idct_col(int i0, int i1, int i2, int i3, int o[4])
 {
     int a1 = i0 + i2, b1 = i0 - i2;
     int c1 = ((i1 * 35468) >> 16) - (i3 + ((i3 * 20091) >> 16));
     int d1 = (i1 + ((i1 * 20091) >> 16)) + ((i3 * 35468) >> 16);
-    o[0] = (short)(a1 + d1);
-    o[3] = (short)(a1 - d1);
-    o[1] = (short)(b1 + c1);
-    o[2] = (short)(b1 - c1);
+    o[0] = a1 + d1; o[3] = a1 - d1; o[1] = b1 + c1; o[2] = b1 - c1;
 }
-// Row (horizontal) pass with the (x+4)>>3 rounding (idctllm.c:65-88).
-__device__ __forceinline__ void idct_row(int t0, int t1, int t2, int t3, short o[4])
+// Row (horizontal) pass with the (x+4)>>3 rounding (idctllm.c:65-88); outputs are i16 values.
+__device__ __forceinline__ void idct_row(const int t[4], int o[4])
 {
-    int a1 = t0 + t2, b1 = t0 - t2;
-    int c1 = ((t1 * 35468) >> 16) - (t3 + ((t3 * 20091) >> 16));
-    int d1 = (t1 + ((t1 * 20091) >> 16)) + ((t3 * 35468) >> 16);
+    int a1 = t[0] + t[2], b1 = t[0] - t[2];
+    int c1 = ((t[1] * 35468) >> 16) - (t[3] + ((t[3] * 20091) >> 16));
+    int d1 = (t[1] + ((t[1] * 20091) >> 16)) + ((t[3] * 35468) >> 16);
     o[0] = (short)((a1 + d1 + 4) >> 3);
     o[3] = (short)((a1 - d1 + 4) >> 3);
     o[1] = (short)((b1 + c1 + 4) >> 3);
@@ -127,95 +158,32 @@ __device__ __forceinline__ void idct_row(int t0, int t1, int t2, int t3, short o
 
 struct short4v { short x, y, z, w; };
 
-// Residual of one MB -> wl->res (all 24 blocks, zero-filled for skipped MBs).
-// qY: lane = Y block*4 + column; qC: lanes 0..31 = U/V block*4 + column, lanes 32..35 = Y2 columns.
-__device__ __forceinline__ void compute_residual(WaveLds *wl, int lane, bool skip, bool has_y2, int seg,
-                                                 short4v qY, short4v qC)
+__device__ __forceinline__ u32 add_clamp_pack(u32 pred, const int r[4])
 {
-    short *res = wl->res, *tr = wl->tr;
-    if (skip) {
-        // 768 bytes of zeros: 64 lanes x 12 bytes
-        int *z = (int *)res;
-        z[lane] = 0; z[64 + lane] = 0; z[128 + lane] = 0;
-        wave_lds_sync();
-        return;
-    }
-    const short *dq = wl->dq[seg];
-    const int col = lane & 3;
-    // ---- chroma blocks + Y2: column pass
-    if (lane < 36) {
-        short o[4];
-        if (lane < 32) {
-            int f0 = col == 0 ? dq[4] : dq[5], fa = dq[5];
-            idct_col((short)(qC.x * f0), (short)(qC.y * fa), (short)(qC.z * fa), (short)(qC.w * fa), o);
-        } else {   // vp8_dequantize_b + first loop of vp8_short_inv_walsh4x4_c (idctllm.c:150-163)
-            int f0 = col == 0 ? dq[2] : dq[3], fa = dq[3];
-            int i0 = (short)(qC.x * f0), i1 = (short)(qC.y * fa), i2 = (short)(qC.z * fa), i3 = (short)(qC.w * fa);
-            int a1 = i0 + i3, b1 = i1 + i2, c1 = i1 - i2, d1 = i0 - i3;
-            o[0] = (short)(a1 + b1); o[1] = (short)(c1 + d1); o[2] = (short)(a1 - b1); o[3] = (short)(d1 - c1);
-        }
-        short *t = tr + 256 + (lane >> 2) * 16 + col;      // [blk][row][col]
-        t[0] = o[0]; t[4] = o[1]; t[8] = o[2]; t[12] = o[3];
-    }
-    wave_lds_sync();
-    if (lane < 36) {
-        const short *t = tr + 256 + lane * 4;               // row (lane&3) of block (lane>>2)
-        int t0 = t[0], t1 = t[1], t2 = t[2], t3 = t[3];
-        if (lane < 32) {
-            short o[4];
-            idct_row(t0, t1, t2, t3, o);
-            short *r = res + 256 + lane * 4;
-            r[0] = o[0]; r[1] = o[1]; r[2] = o[2]; r[3] = o[3];
-        } else {   // second loop of vp8_short_inv_walsh4x4_c (idctllm.c:168-186): row -> 4 block DCs
-            int a1 = t0 + t3, b1 = t1 + t2, c1 = t1 - t2, d1 = t0 - t3;
-            short *w = wl->wht_dc + (lane - 32) * 4;
-            w[0] = (short)((a1 + b1 + 3) >> 3);
-            w[1] = (short)((c1 + d1 + 3) >> 3);
-            w[2] = (short)((a1 - b1 + 3) >> 3);
-            w[3] = (short)((d1 - c1 + 3) >> 3);
-        }
-    }
-    wave_lds_sync();
-    // ---- luma blocks
-    {
-        short o[4];
-        int fa = dq[1];
-        int i0;
-        if (col == 0) i0 = has_y2 ? (int)wl->wht_dc[lane >> 2] : (int)(short)(qY.x * dq[0]);
-        else i0 = (short)(qY.x * fa);
-        idct_col(i0, (short)(qY.y * fa), (short)(qY.z * fa), (short)(qY.w * fa), o);
-        short *t = tr + (lane >> 2) * 16 + col;
-        t[0] = o[0]; t[4] = o[1]; t[8] = o[2]; t[12] = o[3];
-    }
-    wave_lds_sync();
-    {
-        const short *t = tr + lane * 4;
-        short o[4];
-        idct_row(t[0], t[1], t[2], t[3], o);
-        short *r = res + lane * 4;
-        r[0] = o[0]; r[1] = o[1]; r[2] = o[2]; r[3] = o[3];
-    }
-    wave_lds_sync();
+    u32 out = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) out |= (u32)clamp255((int)((pred >> (8 * i)) & 0xff) + r[i]) << (8 * i);
+    return out;
 }
 
-// 16x16 / 8x8 whole-block intra predictors (reconintra.c:139-241, 403-521): value of pixel (y, x)
-// from the tile edges.  `n` = 16 or 8, dc precomputed by the caller.
-__device__ __forceinline__ int intra_pixel(const unsigned char *tile, int stride, int mode, int y, int x, int dc)
+// Whole-block intra predictors (reconintra.c:139-241, 403-521) for a 4-pixel row segment:
+// above = the 4 pixels above the segment's columns, left = pixel left of the segment's row.
+__device__ __forceinline__ u32 intra_pred4(int mode, u32 above, int left, int tl, int dc)
 {
-    // tile index of (yy, xx) = (yy+1)*stride + xx + 4
-    if (mode == VP8IR_DC_PRED) return dc;
-    int above = tile[x + 4];
+    if (mode == VP8IR_DC_PRED) return (u32)dc * 0x01010101u;
     if (mode == VP8IR_V_PRED) return above;
-    int left = tile[(y + 1) * stride + 3];
-    if (mode == VP8IR_H_PRED) return left;
-    return clamp255(left + above - tile[3]);   // TM_PRED
+    if (mode == VP8IR_H_PRED) return (u32)left * 0x01010101u;
+    u32 out = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) out |= (u32)clamp255(left + (int)((above >> (8 * i)) & 0xff) - tl) << (8 * i);
+    return out;
 }
 
 // ---- inter prediction of a 4-pixel row segment (reconinter.c:161-227 + filter.c) --------------
 // ref points at pixel (0,0) of the plane; (px,py) = integer position of the first output pixel in
 // the current frame; mv in 1/8 pel.  border = 32 (luma) / 16 (chroma); plane w x h (coded size).
-__device__ __forceinline__ void inter_row4(const uint8_t *ref, int stride, int px, int py, int mvrow, int mvcol,
-                                           bool bilinear, int w, int h, int border, int out[4])
+__device__ __forceinline__ u32 inter_row4(const uint8_t *ref, int stride, int px, int py, int mvrow, int mvcol,
+                                          bool bilinear, int w, int h, int border)
 {
     int sx = px + (mvcol >> 3), sy = py + (mvrow >> 3);
     const int fx = mvcol & 7, fy = mvrow & 7;
@@ -224,12 +192,11 @@ __device__ __forceinline__ void inter_row4(const uint8_t *ref, int stride, int p
     sx = max(-border + 2, min(sx, w + border - 10));
     sy = max(-border + 2, min(sy, h + border - 4));
     const uint8_t *s = ref + (long)sy * stride + sx;
+    int out[4];
     if ((fx | fy) == 0) {
 #pragma unroll
         for (int i = 0; i < 4; i++) out[i] = s[i];
-        return;
-    }
-    if (bilinear) {   // filter_block2d_bil (filter.c:376-397): H pass on rows y, y+1; then V
+    } else if (bilinear) {   // filter_block2d_bil (filter.c:376-397): H pass on rows y, y+1; then V
         const int h0 = 128 - fx * 16, h1 = fx * 16, v0 = 128 - fy * 16, v1 = fy * 16;
         int a[5], b[5];
 #pragma unroll
@@ -240,26 +207,27 @@ __device__ __forceinline__ void inter_row4(const uint8_t *ref, int stride, int p
             int t1 = (b[i] * h0 + b[i + 1] * h1 + 64) >> 7;
             out[i] = (t0 * v0 + t1 * v1 + 64) >> 7;
         }
-        return;
-    }
-    // six-tap, both passes always (filter.c:41-128): H over rows -2..+3 with clamp, then V with clamp
-    int acc[4] = { 64, 64, 64, 64 };
+    } else {
+        // six-tap, both passes always (filter.c:41-128): H over rows -2..+3 with clamp, then V with clamp
+        int acc[4] = { 64, 64, 64, 64 };
 #pragma unroll
-    for (int r = 0; r < 6; r++) {
-        const uint8_t *row = s + (long)(r - 2) * stride;
-        int p[9];
+        for (int r = 0; r < 6; r++) {
+            const uint8_t *row = s + (long)(r - 2) * stride;
+            int p[9];
 #pragma unroll
-        for (int i = 0; i < 9; i++) p[i] = row[i - 2];
-        const int vt = k_sixtap[fy][r];
+            for (int i = 0; i < 9; i++) p[i] = row[i - 2];
+            const int vt = k_sixtap[fy][r];
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            int t = p[i] * k_sixtap[fx][0] + p[i + 1] * k_sixtap[fx][1] + p[i + 2] * k_sixtap[fx][2]
-                  + p[i + 3] * k_sixtap[fx][3] + p[i + 4] * k_sixtap[fx][4] + p[i + 5] * k_sixtap[fx][5] + 64;
-            acc[i] += clamp255(t >> 7) * vt;
+            for (int i = 0; i < 4; i++) {
+                int t = p[i] * k_sixtap[fx][0] + p[i + 1] * k_sixtap[fx][1] + p[i + 2] * k_sixtap[fx][2]
+                      + p[i + 3] * k_sixtap[fx][3] + p[i + 4] * k_sixtap[fx][4] + p[i + 5] * k_sixtap[fx][5] + 64;
+                acc[i] += clamp255(t >> 7) * vt;
+            }
         }
-    }
 #pragma unroll
-    for (int i = 0; i < 4; i++) out[i] = clamp255(acc[i] >> 7);
+        for (int i = 0; i < 4; i++) out[i] = clamp255(acc[i] >> 7);
+    }
+    return (u32)out[0] | ((u32)out[1] << 8) | ((u32)out[2] << 16) | ((u32)out[3] << 24);
 }
 
 // clamp_mv_to_umv_border (reconinter.c:348-368)
@@ -288,33 +256,47 @@ vp8_recon_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g)
     const int NW = blockDim.x >> 6;
     const int cols = g.mb_cols, rows = g.mb_rows;
 
-    // ---- LDS carve: [progress flags 256 B][bpred table 160 B][NW x WaveLds][NW x line slot]
+    // ---- LDS carve: [progress flags 256 B][NW x WaveLds][NW x line slot]
     int *prog = (int *)smem;
-    unsigned char *bptab = smem + 256;
-    WaveLds *wl = (WaveLds *)(smem + 512) + wave;
-    const int lbytes = line_bytes(g.aligned_w);
-    unsigned char *lines = smem + 512 + NW * sizeof(WaveLds);
+    WaveLds *wl = (WaveLds *)(smem + 256) + wave;
+    const int lbytes = 2 * g.aligned_w + 6 * LINE_PAD;
+    unsigned char *lines = smem + 256 + NW * sizeof(WaveLds);
     unsigned char *my_line = lines + wave * lbytes;
     // within a slot: Y at +0 (LINE_PAD + W + LINE_PAD), U, V each (LINE_PAD + W/2 + LINE_PAD)
     const int lU = 2 * LINE_PAD + g.aligned_w, lV = lU + 2 * LINE_PAD + g.aligned_w / 2;
 
     if (threadIdx.x < 64) prog[threadIdx.x] = 0;
-    for (int i = threadIdx.x; i < 160; i += blockDim.x) bptab[i] = k_bpred_tab[i];   // blockDim may be 128
-    if (lane < 3) {   // x = -1 of every line is the constant 129 left border (setupintrarecon.c:23-30)
+    if (lane < 3) {   // x = -4..-1 of every line: only x = -1 is ever used, the constant 129 left border
         const int off = lane == 0 ? 0 : (lane == 1 ? lU : lV);
-        my_line[off + LINE_PAD - 1] = 129;
+        *(u32 *)(my_line + off + LINE_PAD - 4) = 0x81818181u;
     }
     __syncthreads();
+
+    // ---- per-lane constants
+    // 4x4 predictor table column of this lane's pixel (lanes 0..15), modes 2..9 packed in two dwords
+    u32 tabLo = 0, tabHi = 0;
+    {
+        const int i = lane & 15;
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+            tabLo |= (u32)k_bpred_tab[(2 + m) * 16 + i] << (8 * m);
+            tabHi |= (u32)k_bpred_tab[(6 + m) * 16 + i] << (8 * m);
+        }
+    }
+    // pixel-stage lane roles.  Luma: lane = block*4 + row  ->  (y, x0).  Chroma (lanes 0..31):
+    // plane = lane>>4, block = (lane>>2)&3, row = lane&3.
+    const int ly = ((lane >> 4) << 2) + (lane & 3), lx0 = ((lane >> 2) & 3) << 2;
+    const int cpl = (lane >> 4) & 1, cy = (((lane >> 2) & 3) >> 1) * 4 + (lane & 3), cx0 = ((lane >> 2) & 1) << 2;
 
     const int myjobs = (njobs - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
     const int total_rows = myjobs * rows;
     const int dep_wave = (wave + NW - 1) % NW;
+    unsigned char *tY = wl->tY, *tU = wl->tU, *tV = wl->tV;
 
     for (int R = wave, k = 0; R < total_rows; R += NW, ++k) {
         const int jj = R / rows, r = R - jj * rows;
         const DevJob &job = jobs[blockIdx.x + jj * gridDim.x];
         const vp8ir_frame_hdr &hdr = job.hdr;
-        const bool key = hdr.frame_type == 0;
         const bool bilinear = hdr.version != 0;
         const bool fullpix = hdr.version == 3;
 
@@ -327,6 +309,8 @@ vp8_recon_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g)
             wg_wait_ge(&prog[rd], (kr + 1) << 16);
         }
         build_dequant(hdr, wl->dq, lane);
+        if (lane < 8) ((u32 *)wl->lcol)[lane] = 0x81818181u;      // column 0: the left border is 129
+        if (lane >= 16 && lane < 32) tY[TY_AT(lane - 16, -1)] = 129;
         wave_lds_sync();
 
         const unsigned char *dep_line = lines + dep_wave * lbytes;
@@ -337,187 +321,207 @@ vp8_recon_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g)
         uint8_t *dU = job.dst + g.u_off + (long)r * 8 * g.uv_stride;
         uint8_t *dV = job.dst + g.v_off + (long)r * 8 * g.uv_stride;
 
-        // software pipeline: coefficients of MB c+1 are in flight while MB c is processed
+        // ---- software pipeline: MB descriptors two ahead (lanes 0..15 hold the 16 dwords of a
+        // vp8ir_mb), coefficients one ahead
+        u32 mbw0 = 0, mbw1 = 0;
+        if (lane < 16) {
+            mbw0 = ((const u32 *)mbrow)[lane];
+            if (cols > 1) mbw1 = ((const u32 *)(mbrow + 1))[lane];
+        }
         short4v qY = { 0, 0, 0, 0 }, qC = { 0, 0, 0, 0 };
-        {
-            const bool sk = mbrow[0].flags & VP8IR_MB_SKIP;
-            if (!sk) {
-                qY = *(const short4v *)(coefrow + lane * 4);
-                if (lane < 36) qC = *(const short4v *)(coefrow + 256 + lane * 4);
-            }
+        if (!(((u32)__builtin_amdgcn_readlane((int)mbw0, 0) >> 24) & VP8IR_MB_SKIP)) {
+            qY = *(const short4v *)(coefrow + lane * 4);
+            if (lane < 36) qC = *(const short4v *)(coefrow + 256 + lane * 4);
         }
 
         for (int c = 0; c < cols; ++c) {
-            const vp8ir_mb &mb = mbrow[c];
-            const int y_mode = mb.y_mode, uv_mode = mb.uv_mode, ref_frame = mb.ref_frame;
-            const bool skip = mb.flags & VP8IR_MB_SKIP;
+            const u32 w0 = (u32)__builtin_amdgcn_readlane((int)mbw0, 0), w1 = (u32)__builtin_amdgcn_readlane((int)mbw0, 1);
+            const int y_mode = w0 & 0xff, uv_mode = (w0 >> 8) & 0xff, ref_frame = (w0 >> 16) & 0xff;
+            const u32 flags = w0 >> 24;
+            const bool skip = flags & VP8IR_MB_SKIP;
             const bool has_y2 = y_mode != VP8IR_B_PRED && y_mode != VP8IR_SPLITMV;
+            const int seg = w1 & 3;
+            const u32 bm0 = (u32)__builtin_amdgcn_readlane((int)mbw0, 10), bm1 = (u32)__builtin_amdgcn_readlane((int)mbw0, 11);
+            const u32 bm2 = (u32)__builtin_amdgcn_readlane((int)mbw0, 12), bm3 = (u32)__builtin_amdgcn_readlane((int)mbw0, 13);
             const short4v cY = qY, cC = qC;
-            if (c + 1 < cols) {
-                const bool sk = mbrow[c + 1].flags & VP8IR_MB_SKIP;
-                if (!sk) {
-                    const int16_t *q = coefrow + (long)(c + 1) * VP8IR_COEF_PER_MB;
-                    qY = *(const short4v *)(q + lane * 4);
-                    if (lane < 36) qC = *(const short4v *)(q + 256 + lane * 4);
+            // prefetch: coefficients of MB c+1 (its descriptor is already here), descriptor of MB c+2
+            const u32 nflags = (u32)__builtin_amdgcn_readlane((int)mbw1, 0) >> 24;
+            mbw0 = mbw1;
+            if (c + 1 < cols && !(nflags & VP8IR_MB_SKIP)) {
+                const int16_t *q = coefrow + (long)(c + 1) * VP8IR_COEF_PER_MB;
+                qY = *(const short4v *)(q + lane * 4);
+                if (lane < 36) qC = *(const short4v *)(q + 256 + lane * 4);
+            }
+            if (c + 2 < cols && lane < 16) mbw1 = ((const u32 *)(mbrow + c + 2))[lane];
+
+            // ---- residual (independent of every neighbour: done BEFORE waiting on the row above).
+            // rY[4]: lane = block*4+row, the row's 4 residuals.  rC[4]: lanes 0..31 chroma likewise.
+            int rY[4] = { 0, 0, 0, 0 }, rC[4] = { 0, 0, 0, 0 };
+            if (!skip) {
+                const short *dq = wl->dq[seg];
+                const int col = lane & 3;
+                const int dq_y1dc = dq[0], dq_y1ac = dq[1], dq_y2dc = dq[2], dq_y2ac = dq[3], dq_uvdc = dq[4], dq_uvac = dq[5];
+                {   // chroma blocks (lanes 0..31) and the Y2 block (lanes 32..35), column pass
+                    int o[4], t[4];
+                    const bool is_y2 = lane >= 32;
+                    const int f0 = col == 0 ? (is_y2 ? dq_y2dc : dq_uvdc) : (is_y2 ? dq_y2ac : dq_uvac);
+                    const int fa = is_y2 ? dq_y2ac : dq_uvac;
+                    const int i0 = (short)(cC.x * f0), i1 = (short)(cC.y * fa), i2 = (short)(cC.z * fa), i3 = (short)(cC.w * fa);
+                    int oi[4], ow[4];
+                    idct_col(i0, i1, i2, i3, oi);
+                    {   // vp8_dequantize_b + first loop of vp8_short_inv_walsh4x4_c (idctllm.c:150-163)
+                        int a1 = i0 + i3, b1 = i1 + i2, c1 = i1 - i2, d1 = i0 - i3;
+                        ow[0] = a1 + b1; ow[1] = c1 + d1; ow[2] = a1 - b1; ow[3] = d1 - c1;
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; i++) o[i] = is_y2 ? ow[i] : oi[i];
+                    quad_transpose16(o[0], o[1], o[2], o[3], lane, t);
+                    idct_row(t, rC);
+                    if (has_y2 && is_y2 && lane < 36) {   // second loop (idctllm.c:168-186): row -> 4 block DCs
+                        int a1 = t[0] + t[3], b1 = t[1] + t[2], c1 = t[1] - t[2], d1 = t[0] - t[3];
+                        short *w = wl->wht_dc + (lane - 32) * 4;
+                        w[0] = (short)((a1 + b1 + 3) >> 3);
+                        w[1] = (short)((c1 + d1 + 3) >> 3);
+                        w[2] = (short)((a1 - b1 + 3) >> 3);
+                        w[3] = (short)((d1 - c1 + 3) >> 3);
+                    }
+                }
+                if (has_y2) wave_lds_sync();
+                {   // luma blocks
+                    int o[4], t[4];
+                    int i0;
+                    if (col == 0) i0 = has_y2 ? (int)wl->wht_dc[lane >> 2] : (int)(short)(cY.x * dq_y1dc);
+                    else i0 = (short)(cY.x * dq_y1ac);
+                    idct_col(i0, (short)(cY.y * dq_y1ac), (short)(cY.z * dq_y1ac), (short)(cY.w * dq_y1ac), o);
+                    quad_transpose16(o[0], o[1], o[2], o[3], lane, t);
+                    idct_row(t, rY);
                 }
             }
-
-            // ---- residual: independent of every neighbour, done BEFORE waiting on the row above
-            compute_residual(wl, lane, skip, has_y2, mb.segment_id & 3, cY, cC);
 
             // ---- wait for the row above to be two MBs ahead (or finished)
-            if (r > 0) {
-                const int need = min(c + 2, cols);
-                wg_wait_ge(&prog[dep_wave], (dep_seq << 16) + need);
-            }
+            if (r > 0) wg_wait_ge(&prog[dep_wave], (dep_seq << 16) + min(c + 2, cols));
 
-            // ---- prediction edges into the tile
-            unsigned char *tY = wl->tY, *tU = wl->tU, *tV = wl->tV;
+            // ---- above line -> tile row -1 (dword copies: Y x=-4..19, U/V x=-4..7)
+            if (lane < 12) {
+                const int pl = lane < 6 ? 0 : (lane < 9 ? 1 : 2), i = lane - (pl == 0 ? 0 : (pl == 1 ? 6 : 9));
+                u32 v = 0x7f7f7f7fu;                 // frame row 0: everything above is 127
+                if (r > 0) {
+                    const unsigned char *src = dep_line + (pl == 0 ? 0 : (pl == 1 ? lU : lV)) + LINE_PAD
+                                             + (pl == 0 ? c * 16 : c * 8) - 4 + i * 4;
+                    v = *(const u32 *)src;
+                }
+                unsigned char *dst = (pl == 0 ? tY + TY_AT(-1, -4) : (pl == 1 ? tU : tV) + TC_AT(-1, -4)) + i * 4;
+                *(u32 *)dst = v;
+            }
             wave_lds_sync();
-            if (lane < 16) {         // left column := previous MB's right column, or the 129 border
-                tY[TY_AT(lane, -1)] = c == 0 ? 129 : tY[TY_AT(lane, 15)];
-            } else if (lane < 24) {
-                int y = lane - 16;
-                tU[TC_AT(y, -1)] = c == 0 ? 129 : tU[TC_AT(y, 7)];
-            } else if (lane < 32) {
-                int y = lane - 24;
-                tV[TC_AT(y, -1)] = c == 0 ? 129 : tV[TC_AT(y, 7)];
-            }
-            if (lane < 21) {         // above row x = -1..19 (row 0: the 127 border incl. top-left)
-                int x = lane - 1;
-                tY[TY_AT(-1, x)] = r == 0 ? 127 : dep_line[LINE_PAD + c * 16 + x];
-            } else if (lane >= 32 && lane < 41) {
-                int x = lane - 33;
-                tU[TC_AT(-1, x)] = r == 0 ? 127 : dep_line[lU + LINE_PAD + c * 8 + x];
-            } else if (lane >= 48 && lane < 57) {
-                int x = lane - 49;
-                tV[TC_AT(-1, x)] = r == 0 ? 127 : dep_line[lV + LINE_PAD + c * 8 + x];
-            }
 
-            wave_lds_sync();
-            const short *res = wl->res;
+            u32 outY = 0, outC = 0;
             if (ref_frame == VP8IR_INTRA_FRAME) {
-                // ---- chroma (lanes 0..31: plane = lane>>4, block = (lane>>2)&3, row = lane&3)
+                const int up = r > 0, lf = c > 0;
+                // ---- chroma: DC sums by v_sad_u8 over uniformly read dwords
                 {
-                    // DC needs sums over the above row and left column of each plane
-                    int v = 0;
-                    if (lane < 8) v = tU[TC_AT(-1, lane)];
-                    else if (lane < 16) v = tU[TC_AT(lane - 8, -1)];
-                    else if (lane < 24) v = tV[TC_AT(-1, lane - 16)];
-                    else if (lane < 32) v = tV[TC_AT(lane - 24, -1)];
-                    // sums per group of 8 lanes
-                    int s = v;
-                    s += __shfl_xor(s, 1, WAVE); s += __shfl_xor(s, 2, WAVE); s += __shfl_xor(s, 4, WAVE);
-                    const int up = r > 0, lf = c > 0;
-                    int sUa = __shfl(s, 0, WAVE), sUl = __shfl(s, 8, WAVE), sVa = __shfl(s, 16, WAVE), sVl = __shfl(s, 24, WAVE);
+                    const uint2 aU = *(const uint2 *)(tU + TC_AT(-1, 0)), aV = *(const uint2 *)(tV + TC_AT(-1, 0));
+                    const uint2 lU2 = *(const uint2 *)(wl->lcol + 16), lV2 = *(const uint2 *)(wl->lcol + 24);
                     int dcU = 128, dcV = 128;
                     if (up | lf) {
-                        int shift = 2 + up + lf;
-                        dcU = ((up ? sUa : 0) + (lf ? sUl : 0) + (1 << (shift - 1))) >> shift;
-                        dcV = ((up ? sVa : 0) + (lf ? sVl : 0) + (1 << (shift - 1))) >> shift;
+                        const int shift = 2 + up + lf;
+                        const int sU = (up ? sad4(aU.x) + sad4(aU.y) : 0) + (lf ? sad4(lU2.x) + sad4(lU2.y) : 0);
+                        const int sV = (up ? sad4(aV.x) + sad4(aV.y) : 0) + (lf ? sad4(lV2.x) + sad4(lV2.y) : 0);
+                        dcU = (sU + (1 << (shift - 1))) >> shift;
+                        dcV = (sV + (1 << (shift - 1))) >> shift;
                     }
                     if (lane < 32) {
-                        const int plane = lane >> 4, blk = (lane >> 2) & 3, row = lane & 3;
-                        const int y = (blk >> 1) * 4 + row, x0 = (blk & 1) * 4;
-                        unsigned char *t = plane ? tV : tU;
-                        const short *rr = res + 256 + lane * 4;
-                        int dc = plane ? dcV : dcU;
-                        unsigned int packed = 0;
-#pragma unroll
-                        for (int i = 0; i < 4; i++) {
-                            int p = intra_pixel(t, TC_STRIDE, uv_mode, y, x0 + i, dc);
-                            packed |= (unsigned)clamp255(p + rr[i]) << (8 * i);
-                        }
-                        *(unsigned int *)(t + TC_AT(y, x0)) = packed;
+                        const unsigned char *t = cpl ? tV : tU;
+                        const u32 above = *(const u32 *)(t + TC_AT(-1, cx0));
+                        const int left = wl->lcol[16 + cpl * 8 + cy];
+                        const int tl = t[TC_AT(-1, -1)];
+                        outC = add_clamp_pack(intra_pred4(uv_mode, above, left, tl, cpl ? dcV : dcU), rC);
                     }
                 }
-                // ---- luma
                 if (y_mode != VP8IR_B_PRED) {
-                    int v = 0;
-                    if (lane < 16) v = tY[TY_AT(-1, lane)];
-                    else if (lane < 32) v = tY[TY_AT(lane - 16, -1)];
-                    int s = v;
-                    s += __shfl_xor(s, 1, WAVE); s += __shfl_xor(s, 2, WAVE);
-                    s += __shfl_xor(s, 4, WAVE); s += __shfl_xor(s, 8, WAVE);
-                    const int up = r > 0, lf = c > 0;
-                    int sa = __shfl(s, 0, WAVE), sl = __shfl(s, 16, WAVE);
+                    const uint4 aY = *(const uint4 *)(tY + TY_AT(-1, 0));
+                    const uint4 lY = *(const uint4 *)(wl->lcol);
                     int dc = 128;
                     if (up | lf) {
-                        int shift = 3 + up + lf;
-                        dc = ((up ? sa : 0) + (lf ? sl : 0) + (1 << (shift - 1))) >> shift;
+                        const int shift = 3 + up + lf;
+                        const int s = (up ? sad4(aY.x) + sad4(aY.y) + sad4(aY.z) + sad4(aY.w) : 0)
+                                    + (lf ? sad4(lY.x) + sad4(lY.y) + sad4(lY.z) + sad4(lY.w) : 0);
+                        dc = (s + (1 << (shift - 1))) >> shift;
                     }
-                    const int blk = lane >> 2, row = lane & 3;
-                    const int y = (blk >> 2) * 4 + row, x0 = (blk & 3) * 4;
-                    const short *rr = res + lane * 4;
-                    unsigned int packed = 0;
-#pragma unroll
-                    for (int i = 0; i < 4; i++) {
-                        int p = intra_pixel(tY, TY_STRIDE, y_mode, y, x0 + i, dc);
-                        packed |= (unsigned)clamp255(p + rr[i]) << (8 * i);
-                    }
-                    *(unsigned int *)(tY + TY_AT(y, x0)) = packed;
+                    const u32 above = *(const u32 *)(tY + TY_AT(-1, lx0));
+                    const int left = wl->lcol[ly];
+                    const int tl = tY[TY_AT(-1, -1)];
+                    outY = add_clamp_pack(intra_pred4(y_mode, above, left, tl, dc), rY);
                 } else {
-                    // B_PRED: 16 sub-blocks in raster order, each predicted from already reconstructed
-                    // pixels (decodframe.c:200-236).  16 lanes, one pixel each.
+                    // ---- B_PRED (decodframe.c:200-236): 16 sub-blocks in raster order, each predicted
+                    // from already reconstructed pixels; lanes 0..15 = the block's 16 pixels.
+                    *(uint2 *)(wl->res + lane * 4) = make_uint2(((u32)rY[0] & 0xffff) | ((u32)rY[1] << 16),
+                                                                ((u32)rY[2] & 0xffff) | ((u32)rY[3] << 16));
+                    wave_lds_sync();
                     const int pr = (lane >> 2) & 3, pc = lane & 3;
-                    for (int b = 0; b < 16; ++b) {
-                        const int by = b >> 2, bx = b & 3;
-                        const int mode = mb.b_modes[b];
-                        if (lane < 16) {
-                            const int oy = by * 4, ox = bx * 4;
-                            int pred;
-                            // edge fetch: P[k], k = 0..14 (see table comment).  Above-right of the
-                            // right-hand block column is the MB's own above-right row for every block row.
-                            auto P = [&](int kk) -> int {
-                                if (kk <= 4) { int j = kk == 0 ? 3 : 4 - kk; return tY[TY_AT(oy + j, ox - 1)]; }
-                                if (kk == 5) return tY[TY_AT(oy - 1, ox - 1)];
-                                int a = kk == 14 ? 7 : kk - 6;
-                                if (a >= 4 && bx == 3) return tY[TY_AT(-1, 12 + a)];
-                                return tY[TY_AT(oy - 1, ox + a)];
-                            };
-                            if (mode == VP8IR_B_DC_PRED) {
-                                int s = 4;
+                    int resb[16];
 #pragma unroll
-                                for (int i = 0; i < 4; i++) s += P(6 + i) + P(1 + i);
-                                pred = s >> 3;
-                            } else if (mode == VP8IR_B_TM_PRED) {
-                                pred = clamp255(P(6 + pc) - P(5) + P(4 - pr));
-                            } else {
-                                int e = bptab[mode * 16 + lane], kk = e & 15, kind = e >> 4;
-                                if (kind == 2) pred = (P(kk - 1) + 2 * P(kk) + P(kk + 1) + 2) >> 2;
-                                else if (kind == 1) pred = (P(kk) + P(kk + 1) + 1) >> 1;
-                                else pred = P(kk);
-                            }
-                            int v = clamp255(pred + res[b * 16 + pr * 4 + pc]);
+                    for (int b = 0; b < 16; b++) resb[b] = wl->res[b * 16 + (lane & 15)];
+#pragma unroll
+                    for (int b = 0; b < 16; ++b) {
+                        const int by = b >> 2, bx = b & 3, oy = by * 4, ox = bx * 4;
+                        const u32 bmw = b < 4 ? bm0 : (b < 8 ? bm1 : (b < 12 ? bm2 : bm3));
+                        const int mode = (bmw >> (8 * (b & 3))) & 0xff;
+                        // edges: W0 = x-4..x-1 (top-left in byte 3), W1 = A0..A3, W2 = A4..A7 (the MB's own
+                        // above-right row for the right-hand block column), Ld = left column L0..L3
+                        const u32 W0 = *(const u32 *)(tY + TY_AT(oy - 1, ox - 4));
+                        const u32 W1 = *(const u32 *)(tY + TY_AT(oy - 1, ox));
+                        const u32 W2 = *(const u32 *)(tY + (bx == 3 ? TY_AT(-1, 16) : TY_AT(oy - 1, ox + 4)));
+                        const u32 Ld = bx == 0 ? ((const u32 *)wl->lcol)[by] : wl->colbuf[b - 1];
+                        int pred;
+                        if (mode == VP8IR_B_DC_PRED) {
+                            pred = (sad4(W1) + sad4(Ld) + 4) >> 3;
+                        } else if (mode == VP8IR_B_TM_PRED) {
+                            pred = clamp255((int)((W1 >> (8 * pc)) & 0xff) + (int)((Ld >> (8 * pr)) & 0xff) - (int)(W0 >> 24));
+                        } else {
+                            // V = P[0..15] as 4 dwords: {L3,L3,L2,L1} {L0,TL,A0,A1} {A2..A5} {A6,A7,A7,A7}
+                            const u32 V0 = perm(Ld, Ld, 0x01020303u);
+                            const u32 tt = perm(W0, Ld, 0x00000700u);          // {L0, TL, -, -}
+                            const u32 V1 = perm(W1, tt, 0x05040100u);
+                            const u32 V2 = __builtin_amdgcn_alignbyte(W2, W1, 2);
+                            const u32 V3 = perm(W2, W2, 0x03030302u);
+                            const u32 e = ((mode < 6 ? tabLo : tabHi) >> (8 * ((mode - 2) & 3))) & 0xff;
+                            const int kk = e & 15, kind = e >> 4;
+                            const int o = kk - 1 + (kind == 0);                // first byte of the 3-byte window
+                            const int j = o >> 2;
+                            const u32 lo = j == 0 ? V0 : (j == 1 ? V1 : (j == 2 ? V2 : V3));
+                            const u32 hi = j == 0 ? V1 : (j == 1 ? V2 : V3);
+                            const u32 win = __builtin_amdgcn_alignbyte(hi, lo, (u32)(o & 3));
+                            const int p0 = win & 0xff, p1 = (win >> 8) & 0xff, p2 = (win >> 16) & 0xff;
+                            // kinds 2 and 1: window = P[k-1],P[k],P[k+1]; kind 0: window starts at P[k]
+                            pred = kind == 2 ? (p0 + 2 * p1 + p2 + 2) >> 2 : (kind == 1 ? (p1 + p2 + 1) >> 1 : p0);
+                        }
+                        const int v = clamp255(pred + resb[b]);
+                        if (lane < 16) {
                             tY[TY_AT(oy + pr, ox + pc)] = (unsigned char)v;
+                            if (pc == 3) ((unsigned char *)(wl->colbuf + b))[pr] = (unsigned char)v;
                         }
                         wave_lds_sync();
                     }
+                    outY = *(const u32 *)(tY + TY_AT(ly, lx0));
                 }
             } else {
                 // ---- inter MB (vp8_build_inter_predictors_mb, reconinter.c:560-606)
                 const vp8ir_mv *mv = job.mvs + ((long)r * cols + c) * 16;
                 const uint8_t *rf = job.ref[ref_frame];
-                const bool clampmv = mb.flags & VP8IR_MB_CLAMP;
+                const bool clampmv = flags & VP8IR_MB_CLAMP;
                 const int e_left = -((c * 16) << 3), e_right = ((cols - 1 - c) * 16) << 3;
                 const int e_top = -((r * 16) << 3), e_bottom = ((rows - 1 - r) * 16) << 3;
                 {   // luma: lane = block*4 + row
-                    const int blk = lane >> 2, row = lane & 3;
-                    const int y = (blk >> 2) * 4 + row, x0 = (blk & 3) * 4;
+                    const int blk = lane >> 2;
                     int mrow = mv[blk].row, mcol = mv[blk].col;
                     if (clampmv) clamp_luma_mv(mrow, mcol, e_left, e_right, e_top, e_bottom);
-                    int o[4];
-                    inter_row4(rf + g.y_off, g.y_stride, c * 16 + x0, r * 16 + y, mrow, mcol, bilinear,
-                               g.aligned_w, g.aligned_h, 32, o);
-                    const short *rr = res + lane * 4;
-                    unsigned int packed = 0;
-#pragma unroll
-                    for (int i = 0; i < 4; i++) packed |= (unsigned)clamp255(o[i] + rr[i]) << (8 * i);
-                    *(unsigned int *)(tY + TY_AT(y, x0)) = packed;
+                    const u32 p = inter_row4(rf + g.y_off, g.y_stride, c * 16 + lx0, r * 16 + ly, mrow, mcol, bilinear,
+                                             g.aligned_w, g.aligned_h, 32);
+                    outY = add_clamp_pack(p, rY);
                 }
                 if (lane < 32) {   // chroma
-                    const int plane = lane >> 4, blk = (lane >> 2) & 3, row = lane & 3;
-                    const int y = (blk >> 1) * 4 + row, x0 = (blk & 1) * 4;
+                    const int blk = (lane >> 2) & 3;
                     int mrow, mcol;
                     if (y_mode != VP8IR_SPLITMV) {   // reconinter.c:419-424: from the CLAMPED luma MV
                         mrow = mv[0].row; mcol = mv[0].col;
@@ -536,44 +540,30 @@ vp8_recon_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g)
                         if (fullpix) { mrow &= ~7; mcol &= ~7; }
                         if (clampmv) clamp_chroma_mv(mrow, mcol, e_left, e_right, e_top, e_bottom);
                     }
-                    int o[4];
-                    inter_row4(rf + (plane ? g.v_off : g.u_off), g.uv_stride, c * 8 + x0, r * 8 + y, mrow, mcol,
-                               bilinear, g.aligned_w / 2, g.aligned_h / 2, 16, o);
-                    unsigned char *t = plane ? tV : tU;
-                    const short *rr = res + 256 + lane * 4;
-                    unsigned int packed = 0;
-#pragma unroll
-                    for (int i = 0; i < 4; i++) packed |= (unsigned)clamp255(o[i] + rr[i]) << (8 * i);
-                    *(unsigned int *)(t + TC_AT(y, x0)) = packed;
+                    const u32 p = inter_row4(rf + (cpl ? g.v_off : g.u_off), g.uv_stride, c * 8 + cx0, r * 8 + cy, mrow,
+                                             mcol, bilinear, g.aligned_w / 2, g.aligned_h / 2, 16);
+                    outC = add_clamp_pack(p, rC);
                 }
             }
 
-            // ---- write the finished MB: frame (HBM, once) + my line buffer (bottom rows)
-            wave_lds_sync();
-            {
-                const int y = lane >> 2, xd = (lane & 3) * 4;
-                unsigned int v = *(const unsigned int *)(tY + TY_AT(y, xd));
-                *(unsigned int *)(dY + (long)y * g.y_stride + c * 16 + xd) = v;
-                if (y == 15) *(unsigned int *)(my_line + LINE_PAD + c * 16 + xd) = v;
-                if (lane < 32) {
-                    const int plane = lane >> 4, yy = (lane >> 1) & 7, xx = (lane & 1) * 4;
-                    const unsigned char *t = plane ? tV : tU;
-                    unsigned int cv = *(const unsigned int *)(t + TC_AT(yy, xx));
-                    uint8_t *dp = (plane ? dV : dU) + (long)yy * g.uv_stride + c * 8 + xx;
-                    *(unsigned int *)dp = cv;
-                    if (yy == 7) *(unsigned int *)(my_line + (plane ? lV : lU) + LINE_PAD + c * 8 + xx) = cv;
-                }
-                if (c == cols - 1) {
-                    // vp8_extend_mb_row (extend.c:160-185): what the next row's last MB sees as
-                    // above-right is the last pixel of this line replicated.
-                    if (lane == 0) {
-                        unsigned int e = tY[TY_AT(15, 15)] * 0x01010101u;
-                        *(unsigned int *)(my_line + LINE_PAD + cols * 16) = e;
-                    }
-                }
+            // ---- finished MB: frame (HBM, once), my line buffer (bottom rows), left column for MB c+1
+            *(u32 *)(dY + (long)ly * g.y_stride + c * 16 + lx0) = outY;
+            if (ly == 15) *(u32 *)(my_line + LINE_PAD + c * 16 + lx0) = outY;
+            if (lx0 == 12) {
+                wl->lcol[ly] = (unsigned char)(outY >> 24);
+                tY[TY_AT(ly, -1)] = (unsigned char)(outY >> 24);
             }
-            wg_publish(&prog[wave], c + 1 == cols ? (k + 1) << 16 : (k << 16) + c + 1, lane);
+            if (lane < 32) {
+                *(u32 *)((cpl ? dV : dU) + (long)cy * g.uv_stride + c * 8 + cx0) = outC;
+                if (cy == 7) *(u32 *)(my_line + (cpl ? lV : lU) + LINE_PAD + c * 8 + cx0) = outC;
+                if (cx0 == 4) wl->lcol[16 + cpl * 8 + cy] = (unsigned char)(outC >> 24);
+            }
+            if (c == cols - 1 && lane == 63) {
+                // vp8_extend_mb_row (extend.c:160-185): what the next row's last MB sees as above-right
+                // is the last pixel of this line replicated (lane 63 holds pixel row 15, x = 12..15).
+                *(u32 *)(my_line + LINE_PAD + cols * 16) = (outY >> 24) * 0x01010101u;
+            }
+            wg_publish_lds(&prog[wave], c + 1 == cols ? (k + 1) << 16 : (k << 16) + c + 1, lane);
         }
-        (void)key;
     }
 }

@@ -141,8 +141,8 @@ extern "C" void vp8hip_destroy(vp8hip_ctx *c)
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-// per-wave LDS footprints; must match the kernels (WaveLds 2288 B + line slot, LfWaveLds 768 B)
-static size_t recon_lds_bytes(int nw, int aligned_w) { return 512 + (size_t)nw * (2288 + 2 * aligned_w + 96); }
+// per-wave LDS footprints; must match the kernels (WaveLds 2080 B + line slot, LfWaveLds 768 B)
+static size_t recon_lds_bytes(int nw, int aligned_w) { return 256 + (size_t)nw * (2080 + 2 * aligned_w + 96); }
 static size_t lf_lds_bytes(int nw) { return 256 + (size_t)nw * 768; }
 
 extern "C" int vp8hip_configure(vp8hip_ctx *c, int width, int height, int num_fb, int num_slots)
@@ -293,12 +293,13 @@ extern "C" int vp8hip_decode(vp8hip_ctx *c, const vp8hip_job *jobs, int njobs, i
         d.dst = c->fb[j.dst_fb];
         d.ref[0] = nullptr;
         for (int k = 1; k < 4; k++) {
+            d.ref[k] = nullptr;
+            if (s.hdr_copy.frame_type == 0) continue;          // key frames read no reference
             int f = j.ref_fb[k];
             if (f >= nfb) return fail(c, -2, "vp8hip_decode: job %d ref %d out of range", i, f);
-            if (f < 0 && s.hdr_copy.frame_type != 0)
-                return fail(c, -2, "vp8hip_decode: inter frame job %d lacks reference %d", i, k);
-            d.ref[k] = f < 0 ? nullptr : c->fb[f];
+            if (f < 0) return fail(c, -2, "vp8hip_decode: inter frame job %d lacks reference %d", i, k);
             if (f == j.dst_fb) return fail(c, -2, "vp8hip_decode: job %d decodes into its own reference", i);
+            d.ref[k] = c->fb[f];
         }
         any_lf |= s.hdr_copy.filter_level != 0;
     }
