@@ -26,6 +26,17 @@ struct DevGeom {
 
 #define WAVE 64
 
+// Pointers that come out of a DevJob (i.e. out of memory) are generic to the compiler, which then
+// emits FLAT loads/stores: those count on lgkmcnt as well as vmcnt, so every LDS wait would also
+// wait for the global prefetches and the frame write-out.  Casting to the global address space
+// makes them global_load/global_store (vmcnt only).
+#define GLOBAL_AS __attribute__((address_space(1)))
+typedef GLOBAL_AS unsigned char *g_u8p;
+typedef GLOBAL_AS const unsigned char *g_cu8p;
+typedef GLOBAL_AS unsigned int *g_u32p;
+typedef GLOBAL_AS const unsigned int *g_cu32p;
+typedef GLOBAL_AS const short *g_cs16p;
+
 // ---- intra-workgroup progress flags in LDS ------------------------------------------------
 // A wave publishes "(row sequence number << 16) | MBs finished in that row"; finishing a row
 // publishes (seq+1) << 16.  All waves of a workgroup live on one CU.

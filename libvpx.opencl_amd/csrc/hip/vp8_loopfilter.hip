@@ -15,19 +15,20 @@
 // row, horizontal edges one lane per pixel column; Y, U and V edges of the same kind share a step.
 #include "vp8_common.hip.h"
 
-#define LY_STRIDE 20
-#define LC_STRIDE 12
-#define LY_AT(y, x) (((y) + 4) * LY_STRIDE + (x) + 4)
-#define LC_AT(y, x) (((y) + 4) * LC_STRIDE + (x) + 4)
+// Per-wave LDS tile: luma 20 rows (y = -4..15) x 32 bytes (x = -4..-1 at 12..15, x = 0..15 at 16..31,
+// so a pixel row is one aligned 16-byte access); chroma 12 rows x 16 bytes (x = -4..-1 at 4..7,
+// x = 0..7 at 8..15).
+#define LY_STRIDE 32
+#define LC_STRIDE 16
+#define LY_AT(y, x) (((y) + 4) * LY_STRIDE + 16 + (x))
+#define LC_AT(y, x) (((y) + 4) * LC_STRIDE + 8 + (x))
 
 struct __attribute__((aligned(16))) LfWaveLds {
-    unsigned char tY[20 * LY_STRIDE];    // 400
-    unsigned char tU[12 * LC_STRIDE];    // 144
-    unsigned char tV[12 * LC_STRIDE];    // 144 -> 688
-    unsigned char lvl[64];               // [seg][ref][mode] filter levels -> 752
-    unsigned char pad[16];               // -> 768
+    unsigned char tY[20 * LY_STRIDE];    // 640
+    unsigned char tU[12 * LC_STRIDE];    // 192
+    unsigned char tV[12 * LC_STRIDE];    // 192 -> 1024
 };
-static_assert(sizeof(LfWaveLds) % 16 == 0, "LfWaveLds alignment");
+static_assert(sizeof(LfWaveLds) == 1024, "LfWaveLds layout");
 
 __device__ __forceinline__ int sc8(int v) { return v < -128 ? -128 : (v > 127 ? 127 : v); }
 __device__ __forceinline__ int iabs(int v) { return v < 0 ? -v : v; }
@@ -105,35 +106,49 @@ __device__ __forceinline__ void lf_simple(int p[8], int blimit)
 
 struct LfParams { int mblim, blim, lim, hev_thr; };
 
-// One edge, one position per lane.  `base` points at q0 of this lane's position inside the tile,
-// `across` is the byte step over the edge.  kind: 0 inner normal, 1 MB-edge normal, 2 simple.
-__device__ __forceinline__ void filter_position(unsigned char *base, int across, int kind, const LfParams &lp,
-                                                int edge_limit)
+// All edges of one pixel line held in registers: a[0..19] = positions -4..15 across the MB
+// (x for the vertical-edge pass, y for the horizontal-edge pass; chroma lines use a[0..11]).
+// Order and gating exactly as vp8_loop_filter_frame (loopfilter.c:265-299): MB edge at 0 (if there
+// is a neighbour), then inner edges at 4, 8, 12 (if !skip_lf); chroma has edges 0 and 4 only and
+// is not touched by the simple filter.
+__device__ __forceinline__ void filter_edge(int *q0, int kind, const LfParams &lp, int edge_limit)
 {
     int p[8];
 #pragma unroll
-    for (int i = 0; i < 8; i++) p[i] = base[(i - 4) * across];
+    for (int i = 0; i < 8; i++) p[i] = q0[i - 4];
     if (kind == 2) {
         lf_simple(p, edge_limit);
-        base[-across] = (unsigned char)p[3];
-        base[0] = (unsigned char)p[4];
+        q0[-1] = p[3]; q0[0] = p[4];
         return;
     }
     const bool m = lf_mask(lp.lim, edge_limit, p), hv = lf_hev(lp.hev_thr, p);
     if (kind == 1) {
         lf_mbedge(p, m, hv);
-        base[-3 * across] = (unsigned char)p[1];
-        base[2 * across] = (unsigned char)p[6];
+        q0[-3] = p[1]; q0[2] = p[6];
     } else
         lf_inner(p, m, hv);
-    base[-2 * across] = (unsigned char)p[2];
-    base[-across] = (unsigned char)p[3];
-    base[0] = (unsigned char)p[4];
-    base[across] = (unsigned char)p[5];
+    q0[-2] = p[2]; q0[-1] = p[3]; q0[0] = p[4]; q0[1] = p[5];
+}
+
+__device__ __forceinline__ void filter_line(int a[20], bool luma, bool simple, bool mb_edge, bool inner,
+                                            const LfParams &lp)
+{
+    if (simple) {
+        if (luma) {
+            if (mb_edge) filter_edge(a + 4, 2, lp, lp.mblim);
+            if (inner) { filter_edge(a + 8, 2, lp, lp.blim); filter_edge(a + 12, 2, lp, lp.blim); filter_edge(a + 16, 2, lp, lp.blim); }
+        }
+        return;
+    }
+    if (mb_edge) filter_edge(a + 4, 1, lp, lp.mblim);
+    if (inner) {
+        filter_edge(a + 8, 0, lp, lp.blim);
+        if (luma) { filter_edge(a + 12, 0, lp, lp.blim); filter_edge(a + 16, 0, lp, lp.blim); }
+    }
 }
 
 // vp8_loop_filter_frame_init (loopfilter.c:117-201): level per [segment][ref_frame][mode class]
-__device__ __forceinline__ void build_levels(const vp8ir_frame_hdr &h, unsigned char *lvl, int lane)
+__device__ __forceinline__ int build_level(const vp8ir_frame_hdr &h, int lane)
 {
     const int seg = lane >> 4, ref = (lane >> 2) & 3, mode = lane & 3;
     int base = h.filter_level;
@@ -155,7 +170,7 @@ __device__ __forceinline__ void build_levels(const vp8ir_frame_hdr &h, unsigned 
         }
         v = v < 0 ? 0 : (v > 63 ? 63 : v);
     }
-    lvl[lane] = (unsigned char)v;
+    return v;
 }
 
 // vp8_loop_filter_update_sharpness + hev threshold LUT (loopfilter.c:24-96)
@@ -176,6 +191,17 @@ __device__ __forceinline__ LfParams lf_params(int sharp, int level, int frame_ty
     return l;
 }
 
+typedef unsigned int u32;
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef GLOBAL_AS u32x4 *g_u32x4p;
+typedef GLOBAL_AS const u32x4 *g_cu32x4p;
+typedef GLOBAL_AS u32x2 *g_u32x2p;
+typedef GLOBAL_AS const u32x2 *g_cu32x2p;
+
+__device__ __forceinline__ void unpack4(u32 v, int *a) { a[0] = v & 0xff; a[1] = (v >> 8) & 0xff; a[2] = (v >> 16) & 0xff; a[3] = v >> 24; }
+__device__ __forceinline__ u32 pack4(const int *a) { return (u32)a[0] | ((u32)a[1] << 8) | ((u32)a[2] << 16) | ((u32)a[3] << 24); }
+
 extern "C" __global__ void __launch_bounds__(1024)
 vp8_loopfilter_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g)
 {
@@ -186,7 +212,6 @@ vp8_loopfilter_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g)
     const int cols = g.mb_cols, rows = g.mb_rows;
     int *prog = (int *)smem;
     LfWaveLds *wl = (LfWaveLds *)(smem + 256) + wave;
-    unsigned char *tY = wl->tY, *tU = wl->tU, *tV = wl->tV;
 
     if (threadIdx.x < 64) prog[threadIdx.x] = 0;
     __syncthreads();
@@ -199,157 +224,138 @@ vp8_loopfilter_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g)
     const unsigned mode_class = (1u) | (1u << 2) | (1u << 4) | (1u << 6) | (0u << 8) | (2u << 10) | (2u << 12)
                               | (1u << 14) | (2u << 16) | (3u << 18);
 
+    // ---- lane roles.  "Line" lanes 0..31 own one pixel line of the MB in both filter passes:
+    //   lanes 0..15 luma line (row y in the vertical-edge pass, column x in the horizontal-edge pass),
+    //   lanes 16..23 U, 24..31 V.  Lanes 32..43 carry the 4 context rows above (3 luma quads + U + V).
+    const bool is_line = lane < 32, luma = lane < 16;
+    const int li = luma ? lane : (lane & 7);                       // line index inside its plane
+    unsigned char *tile = luma ? wl->tY : ((lane & 8) ? wl->tV : wl->tU);   // lanes 16..23 U, 24..31 V
+    const int top_plane = lane < 36 ? 0 : (lane < 40 ? 1 : 2), top_row = (lane & 3) - 4;   // lanes 32..43
+    unsigned char *top_tile = top_plane == 0 ? wl->tY : (top_plane == 1 ? wl->tU : wl->tV);
+
     for (int R = wave, k = 0; R < total_rows; R += NW, ++k) {
         const int jj = R / rows, r = R - jj * rows;
         const DevJob &job = jobs[blockIdx.x + jj * gridDim.x];
         const vp8ir_frame_hdr &hdr = job.hdr;
         const int dep_seq = (R - 1) / NW;
         if (hdr.filter_level == 0) {             // frame not filtered at all (onyxd_if.c:576)
-            wg_publish_global(&prog[wave], (k + 1) << 16, lane);
+            wg_publish_lds(&prog[wave], (k + 1) << 16, lane);
             continue;
         }
-        build_levels(hdr, wl->lvl, lane);
-        wave_lds_sync();
+        const int lvlv = build_level(hdr, lane);  // lane l holds lvl[seg][ref][mode class], l = seg<<4|ref<<2|class
         const bool simple = hdr.filter_type != 0;
         const int sharp = hdr.sharpness_level, ftype = hdr.frame_type;
-        const vp8ir_mb *mbrow = job.mbs + (long)r * cols;
-        uint8_t *fY = job.dst + g.y_off + (long)r * 16 * g.y_stride;
-        uint8_t *fU = job.dst + g.u_off + (long)r * 8 * g.uv_stride;
-        uint8_t *fV = job.dst + g.v_off + (long)r * 8 * g.uv_stride;
+        g_cu32p mbrow = (g_cu32p)(job.mbs + (long)r * cols);          // 16 dwords per MB
+        g_u8p fY = (g_u8p)(job.dst + g.y_off + (long)r * 16 * g.y_stride);
+        g_u8p fU = (g_u8p)(job.dst + g.u_off + (long)r * 8 * g.uv_stride);
+        g_u8p fV = (g_u8p)(job.dst + g.v_off + (long)r * 8 * g.uv_stride);
+        // this lane's pixel row in the frame (line lanes), resp. its context row (lanes 32..43)
+        g_u8p frow = luma ? fY + (long)li * g.y_stride : ((lane & 8) ? fV : fU) + (long)li * g.uv_stride;
+        g_u8p trow = top_plane == 0 ? fY + (long)top_row * g.y_stride
+                                    : (top_plane == 1 ? fU : fV) + (long)top_row * g.uv_stride;
+        const int xstep = luma ? 16 : 8;          // bytes per MB in this lane's plane
+        const int tstep = top_plane == 0 ? 16 : 8;
 
-        // lane roles for loads/stores of the MB body: Y lane -> (row lane>>2, dword lane&3);
-        // chroma lanes 0..31 -> plane lane>>4, row (lane>>1)&7, dword lane&1
-        const int by = lane >> 2, bxd = (lane & 3) * 4;
-        const int cpl = lane >> 4, cy = (lane >> 1) & 7, cxd = (lane & 1) * 4;
-        unsigned int nY = *(const unsigned int *)(fY + (long)by * g.y_stride + bxd);
-        unsigned int nC = 0;
-        if (lane < 32) nC = *(const unsigned int *)((cpl ? fV : fU) + (long)cy * g.uv_stride + cxd);
+        // One MB.  `body` = this lane's 16 (8) unfiltered pixels, prefetched; `w0`,`w1` = the first two
+        // dwords of the MB descriptor.
+        auto process = [&](const int c, const u32x4 body, const u32 w0, const u32 w1) {
+            const int y_mode = w0 & 0xff, ref_frame = (w0 >> 16) & 3;
+            const bool skip_lf = y_mode != VP8IR_B_PRED && y_mode != VP8IR_SPLITMV && ((w0 >> 24) & VP8IR_MB_SKIP);
+            const int level = __builtin_amdgcn_readlane(lvlv, ((w1 & 3) << 4) | (ref_frame << 2) | ((mode_class >> (2 * y_mode)) & 3));
+            const LfParams lp = lf_params(sharp, level, ftype);
+            const bool on = level != 0;
 
-        for (int c = 0; c < cols; ++c) {
-            const vp8ir_mb &mb = mbrow[c];
-            const int y_mode = mb.y_mode;
-            const bool skip_lf = y_mode != VP8IR_B_PRED && y_mode != VP8IR_SPLITMV && (mb.flags & VP8IR_MB_SKIP);
-            const int level = wl->lvl[((mb.segment_id & 3) << 4) | ((mb.ref_frame & 3) << 2)
-                                      | ((mode_class >> (2 * y_mode)) & 3)];
-            const unsigned int curY = nY, curC = nC;
-            if (c + 1 < cols) {                  // prefetch the next MB's (still unfiltered) pixels
-                nY = *(const unsigned int *)(fY + (long)by * g.y_stride + (c + 1) * 16 + bxd);
-                if (lane < 32)
-                    nC = *(const unsigned int *)((cpl ? fV : fU) + (long)cy * g.uv_stride + (c + 1) * 8 + cxd);
-            }
-            // ---- slide the tile: previous MB's 4 right-hand columns become the left context
-            wave_lds_sync();
-            if (c > 0) {
-                if (lane < 16)
-                    *(unsigned int *)(tY + LY_AT(lane, -4)) = *(const unsigned int *)(tY + LY_AT(lane, 12));
-                else if (lane < 24)
-                    *(unsigned int *)(tU + LC_AT(lane - 16, -4)) = *(const unsigned int *)(tU + LC_AT(lane - 16, 4));
-                else if (lane < 32)
-                    *(unsigned int *)(tV + LC_AT(lane - 24, -4)) = *(const unsigned int *)(tV + LC_AT(lane - 24, 4));
-            }
-            wave_lds_sync();
-            *(unsigned int *)(tY + LY_AT(by, bxd)) = curY;
-            if (lane < 32) *(unsigned int *)((cpl ? tV : tU) + LC_AT(cy, cxd)) = curC;
-
-            // ---- top context: 4 rows above, final-so-far values written by the wave of row r-1
+            // ---- context rows above: written by the wave of row r-1 (final-so-far values); the loads are
+            // issued now and consumed after the vertical-edge pass
+            u32x4 topv = { 0, 0, 0, 0 };
             if (r > 0) {
                 wg_wait_ge(&prog[dep_wave], (dep_seq << 16) + min(c + 2, cols));
-                if (lane < 16) {
-                    const int ty = (lane >> 2) - 4, tx = (lane & 3) * 4;
-                    *(unsigned int *)(tY + LY_AT(ty, tx)) =
-                        *(const unsigned int *)(fY + (long)ty * g.y_stride + c * 16 + tx);
-                } else if (lane < 32) {
-                    const int pl = (lane >> 3) & 1, ty = ((lane >> 1) & 3) - 4, tx = (lane & 1) * 4;
-                    *(unsigned int *)((pl ? tV : tU) + LC_AT(ty, tx)) =
-                        *(const unsigned int *)((pl ? fV : fU) + (long)ty * g.uv_stride + c * 8 + tx);
-                }
+                if (lane >= 32 && lane < 36) topv = *(g_cu32x4p)(trow + c * 16);
+                else if (lane >= 36 && lane < 44) { const u32x2 t = *(g_cu32x2p)(trow + c * 8); topv.x = t.x; topv.y = t.y; }
             }
 
-            wave_lds_sync();
-            if (level) {
-                const LfParams lp = lf_params(sharp, level, ftype);
-                // position roles: lanes 0..15 luma position, 16..23 U, 24..31 V
-                unsigned char *tile = lane < 16 ? tY : (lane < 24 ? tU : tV);
-                const int stride = lane < 16 ? LY_STRIDE : LC_STRIDE;
-                const int pos = lane < 16 ? lane : (lane & 7);
-                const int origin = lane < 16 ? LY_AT(0, 0) : LC_AT(0, 0);
-                if (!simple) {
-                    if (lane < 32) {
-                        // vertical edges: position = pixel row, step across = 1
-                        unsigned char *rowp = tile + origin + pos * stride;
-                        if (c > 0) filter_position(rowp, 1, 1, lp, lp.mblim);
-                        if (!skip_lf) {
-                            filter_position(rowp + 4, 1, 0, lp, lp.blim);
-                            if (lane < 16) {
-                                filter_position(rowp + 8, 1, 0, lp, lp.blim);
-                                filter_position(rowp + 12, 1, 0, lp, lp.blim);
-                            }
-                        }
-                    }
-                    wave_lds_sync();
-                    if (lane < 32) {
-                        // horizontal edges: position = pixel column, step across = stride
-                        unsigned char *colp = tile + origin + pos;
-                        if (r > 0) filter_position(colp, stride, 1, lp, lp.mblim);
-                        if (!skip_lf) {
-                            filter_position(colp + 4 * stride, stride, 0, lp, lp.blim);
-                            if (lane < 16) {
-                                filter_position(colp + 8 * stride, stride, 0, lp, lp.blim);
-                                filter_position(colp + 12 * stride, stride, 0, lp, lp.blim);
-                            }
-                        }
-                    }
-                } else if (lane < 16) {          // simple filter: luma only (loopfilter.c:284-299)
-                    unsigned char *rowp = tY + LY_AT(lane, 0);
-                    if (c > 0) filter_position(rowp, 1, 2, lp, lp.mblim);
-                    if (!skip_lf) {
-                        filter_position(rowp + 4, 1, 2, lp, lp.blim);
-                        filter_position(rowp + 8, 1, 2, lp, lp.blim);
-                        filter_position(rowp + 12, 1, 2, lp, lp.blim);
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                    unsigned char *colp = tY + LY_AT(0, lane);
-                    if (r > 0) filter_position(colp, LY_STRIDE, 2, lp, lp.mblim);
-                    if (!skip_lf) {
-                        filter_position(colp + 4 * LY_STRIDE, LY_STRIDE, 2, lp, lp.blim);
-                        filter_position(colp + 8 * LY_STRIDE, LY_STRIDE, 2, lp, lp.blim);
-                        filter_position(colp + 12 * LY_STRIDE, LY_STRIDE, 2, lp, lp.blim);
-                    }
-                }
+            // ---- vertical edges: the whole pixel row in registers
+            int a[20];
+            if (is_line) {
+                const u32 left = luma ? *(const u32 *)(tile + LY_AT(li, 12)) : *(const u32 *)(tile + LC_AT(li, 4));
+                unpack4(left, a); unpack4(body.x, a + 4); unpack4(body.y, a + 8); unpack4(body.z, a + 12); unpack4(body.w, a + 16);
+                if (on) filter_line(a, luma, simple, c > 0, !skip_lf, lp);
             }
+            wave_lds_sync();       // everyone has read the previous tile's right-hand columns
+            if (is_line) {
+                if (luma) {
+                    *(u32 *)(tile + LY_AT(li, -4)) = pack4(a);
+                    *(u32x4 *)(tile + LY_AT(li, 0)) = (u32x4){ pack4(a + 4), pack4(a + 8), pack4(a + 12), pack4(a + 16) };
+                } else {
+                    *(u32 *)(tile + LC_AT(li, -4)) = pack4(a);
+                    *(u32x2 *)(tile + LC_AT(li, 0)) = (u32x2){ pack4(a + 4), pack4(a + 8) };
+                }
+            } else if (r > 0 && lane < 44) {
+                if (top_plane == 0) *(u32x4 *)(top_tile + LY_AT(top_row, 0)) = topv;
+                else *(u32x2 *)(top_tile + LC_AT(top_row, 0)) = (u32x2){ topv.x, topv.y };
+            }
+            wave_lds_sync();
 
-            // ---- write back: MB body, the 4 context rows above (cols 0..15) and the 4 context
-            // columns to the left (rows 0..15); the corner is never touched by this MB's filters.
+            // ---- horizontal edges: the whole pixel column in registers
+            if (is_line && on) {
+                const int stride = luma ? LY_STRIDE : LC_STRIDE;
+                unsigned char *colp = tile + (luma ? LY_AT(-4, li) : LC_AT(-4, li));
+                const int n = luma ? 20 : 12;
+#pragma unroll
+                for (int i = 0; i < 20; i++) a[i] = i < n ? colp[i * stride] : 0;
+                filter_line(a, luma, simple, r > 0, !skip_lf, lp);
+#pragma unroll
+                for (int i = 1; i < 19; i++) if (i < n - 1) colp[i * stride] = (unsigned char)a[i];
+            }
             wave_lds_sync();
-            *(unsigned int *)(fY + (long)by * g.y_stride + c * 16 + bxd) = *(const unsigned int *)(tY + LY_AT(by, bxd));
-            if (lane < 32)
-                *(unsigned int *)((cpl ? fV : fU) + (long)cy * g.uv_stride + c * 8 + cxd) =
-                    *(const unsigned int *)((cpl ? tV : tU) + LC_AT(cy, cxd));
-            if (r > 0) {
-                if (lane < 16) {
-                    const int ty = (lane >> 2) - 4, tx = (lane & 3) * 4;
-                    *(unsigned int *)(fY + (long)ty * g.y_stride + c * 16 + tx) = *(const unsigned int *)(tY + LY_AT(ty, tx));
-                } else if (lane < 32) {
-                    const int pl = (lane >> 3) & 1, ty = ((lane >> 1) & 3) - 4, tx = (lane & 1) * 4;
-                    *(unsigned int *)((pl ? fV : fU) + (long)ty * g.uv_stride + c * 8 + tx) =
-                        *(const unsigned int *)((pl ? tV : tU) + LC_AT(ty, tx));
+
+            // ---- publish the PREVIOUS MB (its stores were issued a whole MB ago), then write this one back:
+            // body rows, the 4 context columns to the left (c > 0) and the 3 context rows above (r > 0)
+            wg_publish_global(&prog[wave], (k << 16) + c, lane);
+            if (is_line) {
+                if (luma) {
+                    *(g_u32x4p)(frow + c * 16) = *(const u32x4 *)(tile + LY_AT(li, 0));
+                    if (c > 0) *(g_u32p)(frow + c * 16 - 4) = *(const u32 *)(tile + LY_AT(li, -4));
+                } else {
+                    *(g_u32x2p)(frow + c * 8) = *(const u32x2 *)(tile + LC_AT(li, 0));
+                    if (c > 0) *(g_u32p)(frow + c * 8 - 4) = *(const u32 *)(tile + LC_AT(li, -4));
                 }
+            } else if (r > 0 && lane < 44 && top_row > -4) {
+                if (top_plane == 0) *(g_u32x4p)(trow + c * 16) = *(const u32x4 *)(top_tile + LY_AT(top_row, 0));
+                else *(g_u32x2p)(trow + c * 8) = *(const u32x2 *)(top_tile + LC_AT(top_row, 0));
             }
-            if (c > 0) {
-                if (lane >= 32 && lane < 48) {
-                    const int yy = lane - 32;
-                    *(unsigned int *)(fY + (long)yy * g.y_stride + c * 16 - 4) = *(const unsigned int *)(tY + LY_AT(yy, -4));
-                } else if (lane >= 48) {
-                    const int pl = (lane >> 3) & 1, yy = lane & 7;
-                    *(unsigned int *)((pl ? fV : fU) + (long)yy * g.uv_stride + c * 8 - 4) =
-                        *(const unsigned int *)((pl ? tV : tU) + LC_AT(yy, -4));
-                }
+        };
+
+        auto load_body = [&](int c) -> u32x4 {
+            u32x4 v = { 0, 0, 0, 0 };
+            if (luma) v = *(g_cu32x4p)(frow + c * 16);
+            else if (is_line) { const u32x2 t = *(g_cu32x2p)(frow + c * 8); v.x = t.x; v.y = t.y; }
+            return v;
+        };
+        auto load_desc = [&](int c) -> u32 { return lane < 2 ? mbrow[c * 16 + lane] : 0u; };
+
+        // ---- software pipeline, unrolled by two so that no loaded register is ever copied
+        u32x4 bodyA = load_body(0), bodyB = { 0, 0, 0, 0 };
+        u32 dA = load_desc(0), dB = cols > 1 ? load_desc(1) : 0u;
+        for (int c = 0; c < cols; c += 2) {
+            {
+                const u32 w0 = (u32)__builtin_amdgcn_readlane((int)dA, 0), w1 = (u32)__builtin_amdgcn_readlane((int)dA, 1);
+                if (c + 1 < cols) bodyB = load_body(c + 1);
+                if (c + 2 < cols) dA = load_desc(c + 2);
+                process(c, bodyA, w0, w1);
             }
-            wg_publish_global(&prog[wave], c + 1 == cols ? (k + 1) << 16 : (k << 16) + c + 1, lane);
+            if (c + 1 < cols) {
+                const u32 w0 = (u32)__builtin_amdgcn_readlane((int)dB, 0), w1 = (u32)__builtin_amdgcn_readlane((int)dB, 1);
+                if (c + 2 < cols) bodyA = load_body(c + 2);
+                if (c + 3 < cols) dB = load_desc(c + 3);
+                process(c + 1, bodyB, w0, w1);
+            }
         }
+        wg_publish_global(&prog[wave], (k + 1) << 16, lane);
+        (void)xstep; (void)tstep;
     }
 }
+
 
 // ---- border extension ------------------------------------------------------------------------
 // vp8_yv12_extend_frame_borders (yv12extend.c:24-145): replicate the first/last pixel of every row
@@ -363,7 +369,7 @@ vp8_extend_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g)
     for (int plane = 0; plane < 3; ++plane) {
         const int w = plane ? g.aligned_w / 2 : g.aligned_w, h = plane ? g.aligned_h / 2 : g.aligned_h;
         const int stride = plane ? g.uv_stride : g.y_stride, border = plane ? 16 : 32;
-        uint8_t *p = job.dst + (plane == 0 ? g.y_off : plane == 1 ? g.u_off : g.v_off);
+        g_u8p p = (g_u8p)(job.dst + (plane == 0 ? g.y_off : plane == 1 ? g.u_off : g.v_off));
         const int full_w = w + 2 * border;               // bytes per widened row
         const int dw_per_row = full_w / 4;
         // phase A (left/right of every image row) and phase B (top/bottom rows) are fused: a thread
@@ -376,9 +382,9 @@ vp8_extend_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g)
             if (inside_x && inside_y) continue;
             const int sy = row < 0 ? 0 : (row >= h ? h - 1 : row);
             unsigned int v;
-            if (inside_x) v = *(const unsigned int *)(p + (long)sy * stride + xd);
+            if (inside_x) v = *(g_cu32p)(p + (long)sy * stride + xd);
             else v = p[(long)sy * stride + (xd < 0 ? 0 : w - 1)] * 0x01010101u;
-            *(unsigned int *)(p + (long)row * stride + xd) = v;
+            *(g_u32p)(p + (long)row * stride + xd) = v;
         }
     }
 }

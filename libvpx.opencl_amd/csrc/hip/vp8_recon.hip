@@ -156,7 +156,14 @@ __device__ __forceinline__ void idct_row(const int t[4], int o[4])
     o[2] = (short)((b1 - c1 + 4) >> 3);
 }
 
-struct short4v { short x, y, z, w; };
+// four int16 coefficients (one 4x4 block column) as loaded: two dwords
+typedef unsigned int coef4 __attribute__((ext_vector_type(2)));
+typedef GLOBAL_AS const coef4 *g_cs4p;
+typedef GLOBAL_AS const unsigned int *g_cmvp;       // vp8ir_mv {int16 row, col} read as one dword
+__device__ __forceinline__ int c4x(coef4 v) { return (int)(short)(v.x & 0xffff); }
+__device__ __forceinline__ int c4y(coef4 v) { return (int)v.x >> 16; }
+__device__ __forceinline__ int c4z(coef4 v) { return (int)(short)(v.y & 0xffff); }
+__device__ __forceinline__ int c4w(coef4 v) { return (int)v.y >> 16; }
 
 __device__ __forceinline__ u32 add_clamp_pack(u32 pred, const int r[4])
 {
@@ -182,7 +189,7 @@ __device__ __forceinline__ u32 intra_pred4(int mode, u32 above, int left, int tl
 // ---- inter prediction of a 4-pixel row segment (reconinter.c:161-227 + filter.c) --------------
 // ref points at pixel (0,0) of the plane; (px,py) = integer position of the first output pixel in
 // the current frame; mv in 1/8 pel.  border = 32 (luma) / 16 (chroma); plane w x h (coded size).
-__device__ __forceinline__ u32 inter_row4(const uint8_t *ref, int stride, int px, int py, int mvrow, int mvcol,
+__device__ __forceinline__ u32 inter_row4(g_cu8p ref, int stride, int px, int py, int mvrow, int mvcol,
                                           bool bilinear, int w, int h, int border)
 {
     int sx = px + (mvcol >> 3), sy = py + (mvrow >> 3);
@@ -191,7 +198,7 @@ __device__ __forceinline__ u32 inter_row4(const uint8_t *ref, int stride, int px
     // allocated plane incl. its border.
     sx = max(-border + 2, min(sx, w + border - 10));
     sy = max(-border + 2, min(sy, h + border - 4));
-    const uint8_t *s = ref + (long)sy * stride + sx;
+    g_cu8p s = ref + (long)sy * stride + sx;
     int out[4];
     if ((fx | fy) == 0) {
 #pragma unroll
@@ -212,7 +219,7 @@ __device__ __forceinline__ u32 inter_row4(const uint8_t *ref, int stride, int px
         int acc[4] = { 64, 64, 64, 64 };
 #pragma unroll
         for (int r = 0; r < 6; r++) {
-            const uint8_t *row = s + (long)(r - 2) * stride;
+            g_cu8p row = s + (long)(r - 2) * stride;
             int p[9];
 #pragma unroll
             for (int i = 0; i < 9; i++) p[i] = row[i - 2];
@@ -315,23 +322,23 @@ vp8_recon_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g)
 
         const unsigned char *dep_line = lines + dep_wave * lbytes;
         const int dep_seq = (R - 1) / NW;
-        const vp8ir_mb *mbrow = job.mbs + (long)r * cols;
-        const int16_t *coefrow = job.coef + (long)r * cols * VP8IR_COEF_PER_MB;
-        uint8_t *dY = job.dst + g.y_off + (long)r * 16 * g.y_stride;
-        uint8_t *dU = job.dst + g.u_off + (long)r * 8 * g.uv_stride;
-        uint8_t *dV = job.dst + g.v_off + (long)r * 8 * g.uv_stride;
+        g_cu32p mbrow = (g_cu32p)(job.mbs + (long)r * cols);          // 16 dwords per MB
+        g_cs16p coefrow = (g_cs16p)(job.coef + (long)r * cols * VP8IR_COEF_PER_MB);
+        g_u8p dY = (g_u8p)(job.dst + g.y_off + (long)r * 16 * g.y_stride);
+        g_u8p dU = (g_u8p)(job.dst + g.u_off + (long)r * 8 * g.uv_stride);
+        g_u8p dV = (g_u8p)(job.dst + g.v_off + (long)r * 8 * g.uv_stride);
 
         // ---- software pipeline: MB descriptors two ahead (lanes 0..15 hold the 16 dwords of a
         // vp8ir_mb), coefficients one ahead
         u32 mbw0 = 0, mbw1 = 0;
         if (lane < 16) {
-            mbw0 = ((const u32 *)mbrow)[lane];
-            if (cols > 1) mbw1 = ((const u32 *)(mbrow + 1))[lane];
+            mbw0 = mbrow[lane];
+            if (cols > 1) mbw1 = mbrow[16 + lane];
         }
-        short4v qY = { 0, 0, 0, 0 }, qC = { 0, 0, 0, 0 };
+        coef4 qY = { 0, 0 }, qC = { 0, 0 };
         if (!(((u32)__builtin_amdgcn_readlane((int)mbw0, 0) >> 24) & VP8IR_MB_SKIP)) {
-            qY = *(const short4v *)(coefrow + lane * 4);
-            if (lane < 36) qC = *(const short4v *)(coefrow + 256 + lane * 4);
+            qY = *(g_cs4p)(coefrow + lane * 4);
+            if (lane < 36) qC = *(g_cs4p)(coefrow + 256 + lane * 4);
         }
 
         for (int c = 0; c < cols; ++c) {
@@ -343,16 +350,16 @@ vp8_recon_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g)
             const int seg = w1 & 3;
             const u32 bm0 = (u32)__builtin_amdgcn_readlane((int)mbw0, 10), bm1 = (u32)__builtin_amdgcn_readlane((int)mbw0, 11);
             const u32 bm2 = (u32)__builtin_amdgcn_readlane((int)mbw0, 12), bm3 = (u32)__builtin_amdgcn_readlane((int)mbw0, 13);
-            const short4v cY = qY, cC = qC;
+            const coef4 cY = qY, cC = qC;
             // prefetch: coefficients of MB c+1 (its descriptor is already here), descriptor of MB c+2
             const u32 nflags = (u32)__builtin_amdgcn_readlane((int)mbw1, 0) >> 24;
             mbw0 = mbw1;
             if (c + 1 < cols && !(nflags & VP8IR_MB_SKIP)) {
-                const int16_t *q = coefrow + (long)(c + 1) * VP8IR_COEF_PER_MB;
-                qY = *(const short4v *)(q + lane * 4);
-                if (lane < 36) qC = *(const short4v *)(q + 256 + lane * 4);
+                g_cs16p q = coefrow + (long)(c + 1) * VP8IR_COEF_PER_MB;
+                qY = *(g_cs4p)(q + lane * 4);
+                if (lane < 36) qC = *(g_cs4p)(q + 256 + lane * 4);
             }
-            if (c + 2 < cols && lane < 16) mbw1 = ((const u32 *)(mbrow + c + 2))[lane];
+            if (c + 2 < cols && lane < 16) mbw1 = mbrow[(c + 2) * 16 + lane];
 
             // ---- residual (independent of every neighbour: done BEFORE waiting on the row above).
             // rY[4]: lane = block*4+row, the row's 4 residuals.  rC[4]: lanes 0..31 chroma likewise.
@@ -366,7 +373,7 @@ vp8_recon_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g)
                     const bool is_y2 = lane >= 32;
                     const int f0 = col == 0 ? (is_y2 ? dq_y2dc : dq_uvdc) : (is_y2 ? dq_y2ac : dq_uvac);
                     const int fa = is_y2 ? dq_y2ac : dq_uvac;
-                    const int i0 = (short)(cC.x * f0), i1 = (short)(cC.y * fa), i2 = (short)(cC.z * fa), i3 = (short)(cC.w * fa);
+                    const int i0 = (short)(c4x(cC) * f0), i1 = (short)(c4y(cC) * fa), i2 = (short)(c4z(cC) * fa), i3 = (short)(c4w(cC) * fa);
                     int oi[4], ow[4];
                     idct_col(i0, i1, i2, i3, oi);
                     {   // vp8_dequantize_b + first loop of vp8_short_inv_walsh4x4_c (idctllm.c:150-163)
@@ -390,9 +397,9 @@ vp8_recon_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g)
                 {   // luma blocks
                     int o[4], t[4];
                     int i0;
-                    if (col == 0) i0 = has_y2 ? (int)wl->wht_dc[lane >> 2] : (int)(short)(cY.x * dq_y1dc);
-                    else i0 = (short)(cY.x * dq_y1ac);
-                    idct_col(i0, (short)(cY.y * dq_y1ac), (short)(cY.z * dq_y1ac), (short)(cY.w * dq_y1ac), o);
+                    if (col == 0) i0 = has_y2 ? (int)wl->wht_dc[lane >> 2] : (int)(short)(c4x(cY) * dq_y1dc);
+                    else i0 = (short)(c4x(cY) * dq_y1ac);
+                    idct_col(i0, (short)(c4y(cY) * dq_y1ac), (short)(c4z(cY) * dq_y1ac), (short)(c4w(cY) * dq_y1ac), o);
                     quad_transpose16(o[0], o[1], o[2], o[3], lane, t);
                     idct_row(t, rY);
                 }
@@ -507,14 +514,15 @@ vp8_recon_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g)
                 }
             } else {
                 // ---- inter MB (vp8_build_inter_predictors_mb, reconinter.c:560-606)
-                const vp8ir_mv *mv = job.mvs + ((long)r * cols + c) * 16;
-                const uint8_t *rf = job.ref[ref_frame];
+                g_cmvp mv = (g_cmvp)(job.mvs + ((long)r * cols + c) * 16);
+                g_cu8p rf = (g_cu8p)job.ref[ref_frame];
                 const bool clampmv = flags & VP8IR_MB_CLAMP;
                 const int e_left = -((c * 16) << 3), e_right = ((cols - 1 - c) * 16) << 3;
                 const int e_top = -((r * 16) << 3), e_bottom = ((rows - 1 - r) * 16) << 3;
                 {   // luma: lane = block*4 + row
                     const int blk = lane >> 2;
-                    int mrow = mv[blk].row, mcol = mv[blk].col;
+                    const u32 mvw = mv[blk];
+                    int mrow = sext16(mvw), mcol = hi16(mvw);
                     if (clampmv) clamp_luma_mv(mrow, mcol, e_left, e_right, e_top, e_bottom);
                     const u32 p = inter_row4(rf + g.y_off, g.y_stride, c * 16 + lx0, r * 16 + ly, mrow, mcol, bilinear,
                                              g.aligned_w, g.aligned_h, 32);
@@ -524,7 +532,8 @@ vp8_recon_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g)
                     const int blk = (lane >> 2) & 3;
                     int mrow, mcol;
                     if (y_mode != VP8IR_SPLITMV) {   // reconinter.c:419-424: from the CLAMPED luma MV
-                        mrow = mv[0].row; mcol = mv[0].col;
+                        const u32 mvw = mv[0];
+                        mrow = sext16(mvw); mcol = hi16(mvw);
                         if (clampmv) clamp_luma_mv(mrow, mcol, e_left, e_right, e_top, e_bottom);
                         mrow = (short)(mrow + (1 | (mrow >> 31)));
                         mcol = (short)(mcol + (1 | (mcol >> 31)));
@@ -532,8 +541,9 @@ vp8_recon_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g)
                         if (fullpix) { mrow &= ~7; mcol &= ~7; }
                     } else {                          // build_4x4uvmvs (reconinter.c:520-558): UNclamped MVs
                         const int kq = (blk >> 1) * 8 + (blk & 1) * 2;
-                        mrow = mv[kq].row + mv[kq + 1].row + mv[kq + 4].row + mv[kq + 5].row;
-                        mcol = mv[kq].col + mv[kq + 1].col + mv[kq + 4].col + mv[kq + 5].col;
+                        const u32 m0 = mv[kq], m1 = mv[kq + 1], m4 = mv[kq + 4], m5 = mv[kq + 5];
+                        mrow = sext16(m0) + sext16(m1) + sext16(m4) + sext16(m5);
+                        mcol = hi16(m0) + hi16(m1) + hi16(m4) + hi16(m5);
                         mrow += 4 + ((mrow >> 31) << 3);
                         mcol += 4 + ((mcol >> 31) << 3);
                         mrow /= 8; mcol /= 8;
@@ -547,14 +557,14 @@ vp8_recon_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g)
             }
 
             // ---- finished MB: frame (HBM, once), my line buffer (bottom rows), left column for MB c+1
-            *(u32 *)(dY + (long)ly * g.y_stride + c * 16 + lx0) = outY;
+            *(g_u32p)(dY + (long)ly * g.y_stride + c * 16 + lx0) = outY;
             if (ly == 15) *(u32 *)(my_line + LINE_PAD + c * 16 + lx0) = outY;
             if (lx0 == 12) {
                 wl->lcol[ly] = (unsigned char)(outY >> 24);
                 tY[TY_AT(ly, -1)] = (unsigned char)(outY >> 24);
             }
             if (lane < 32) {
-                *(u32 *)((cpl ? dV : dU) + (long)cy * g.uv_stride + c * 8 + cx0) = outC;
+                *(g_u32p)((cpl ? dV : dU) + (long)cy * g.uv_stride + c * 8 + cx0) = outC;
                 if (cy == 7) *(u32 *)(my_line + (cpl ? lV : lU) + LINE_PAD + c * 8 + cx0) = outC;
                 if (cx0 == 4) wl->lcol[16 + cpl * 8 + cy] = (unsigned char)(outC >> 24);
             }

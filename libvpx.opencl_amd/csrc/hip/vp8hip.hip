@@ -143,7 +143,7 @@ static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // per-wave LDS footprints; must match the kernels (WaveLds 2080 B + line slot, LfWaveLds 768 B)
 static size_t recon_lds_bytes(int nw, int aligned_w) { return 256 + (size_t)nw * (2080 + 2 * aligned_w + 96); }
-static size_t lf_lds_bytes(int nw) { return 256 + (size_t)nw * 768; }
+static size_t lf_lds_bytes(int nw) { return 256 + (size_t)nw * 1024; }
 
 extern "C" int vp8hip_configure(vp8hip_ctx *c, int width, int height, int num_fb, int num_slots)
 {
@@ -170,9 +170,11 @@ extern "C" int vp8hip_configure(vp8hip_ctx *c, int width, int height, int num_fb
     if (recon_lds_bytes(nw, g.aligned_w) > (size_t)c->max_lds)
         return fail(c, -2, "frame width %d needs more LDS than a CU has", width);
     while (nw > 2 && nw / 2 >= c->dg.mb_rows) nw /= 2;
+    if (const char *e = getenv("VP8HIP_RECON_NW")) { int v = atoi(e); if (v >= 2 && v <= nw) nw = v; }   // tuning knob
     c->recon_nw = nw; c->recon_lds = recon_lds_bytes(nw, g.aligned_w);
     int lnw = 16;
     while (lnw > 2 && lnw / 2 >= c->dg.mb_rows) lnw /= 2;
+    if (const char *e = getenv("VP8HIP_LF_NW")) { int v = atoi(e); if (v >= 2 && v <= 16) lnw = v; }
     c->lf_nw = lnw; c->lf_lds = lf_lds_bytes(lnw);
 
     // frame buffers: one block, each buffer 256-B aligned
@@ -306,7 +308,9 @@ extern "C" int vp8hip_decode(vp8hip_ctx *c, const vp8hip_job *jobs, int njobs, i
     HIPCHK(c, hipMemcpyAsync(c->d_jobs, c->h_jobs, sizeof(DevJob) * njobs, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipEventRecord(c->ev_jobs, c->stream));
 
-    const int grid = njobs < c->num_cu ? njobs : c->num_cu;
+    int wg_per_cu = 1;
+    if (const char *e = getenv("VP8HIP_WG_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 8) wg_per_cu = v; }
+    const int grid = njobs < c->num_cu * wg_per_cu ? njobs : c->num_cu * wg_per_cu;
     c->stats.workgroups = grid;
     c->stats.recon_waves = c->recon_nw;
     c->stats.lf_waves = c->lf_nw;
