@@ -15,20 +15,22 @@
 // row, horizontal edges one lane per pixel column; Y, U and V edges of the same kind share a step.
 #include "vp8_common.hip.h"
 
-// Per-wave LDS tile: luma 20 rows (y = -4..15) x 32 bytes (x = -4..-1 at 12..15, x = 0..15 at 16..31,
-// so a pixel row is one aligned 16-byte access); chroma 12 rows x 16 bytes (x = -4..-1 at 4..7,
-// x = 0..7 at 8..15).
-#define LY_STRIDE 32
-#define LC_STRIDE 16
-#define LY_AT(y, x) (((y) + 4) * LY_STRIDE + 16 + (x))
-#define LC_AT(y, x) (((y) + 4) * LC_STRIDE + 8 + (x))
+// Per-wave LDS tile = a RING of 8 macroblock columns: luma 20 rows (y = -4..15) x 128 bytes, chroma
+// 12 rows (y = -4..7) x 64 bytes, addressed by the absolute x inside the MB row modulo the ring.
+// The filters work in place in the ring; finished columns are written to the frame four MBs at a
+// time as 64-byte-aligned 64-byte row segments (full memory sectors instead of 16-byte pieces).
+#define RING_MBS 8
+#define LY_STRIDE 128
+#define LC_STRIDE 64
+#define LY_AT(y, X) (((y) + 4) * LY_STRIDE + ((X) & 127))
+#define LC_AT(y, X) (((y) + 4) * LC_STRIDE + ((X) & 63))
 
 struct __attribute__((aligned(16))) LfWaveLds {
-    unsigned char tY[20 * LY_STRIDE];    // 640
-    unsigned char tU[12 * LC_STRIDE];    // 192
-    unsigned char tV[12 * LC_STRIDE];    // 192 -> 1024
+    unsigned char tY[20 * LY_STRIDE];    // 2560
+    unsigned char tU[12 * LC_STRIDE];    //  768
+    unsigned char tV[12 * LC_STRIDE];    //  768 -> 4096
 };
-static_assert(sizeof(LfWaveLds) == 1024, "LfWaveLds layout");
+static_assert(sizeof(LfWaveLds) == 4096, "LfWaveLds layout");
 
 __device__ __forceinline__ int sc8(int v) { return v < -128 ? -128 : (v > 127 ? 127 : v); }
 __device__ __forceinline__ int iabs(int v) { return v < 0 ? -v : v; }
@@ -264,12 +266,13 @@ vp8_loopfilter_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g)
             const int level = __builtin_amdgcn_readlane(lvlv, ((w1 & 3) << 4) | (ref_frame << 2) | ((mode_class >> (2 * y_mode)) & 3));
             const LfParams lp = lf_params(sharp, level, ftype);
             const bool on = level != 0;
+            const int X = luma ? c * 16 : c * 8;      // absolute x of this MB in the lane's plane
 
             // ---- context rows above: written by the wave of row r-1 (final-so-far values); the loads are
             // issued now and consumed after the vertical-edge pass
             u32x4 topv = { 0, 0, 0, 0 };
             if (r > 0) {
-                wg_wait_ge(&prog[dep_wave], (dep_seq << 16) + min(c + 2, cols));
+                wg_wait_ge(&prog[dep_wave], (dep_seq << 16) + c + 1);
                 if (lane >= 32 && lane < 36) topv = *(g_cu32x4p)(trow + c * 16);
                 else if (lane >= 36 && lane < 44) { const u32x2 t = *(g_cu32x2p)(trow + c * 8); topv.x = t.x; topv.y = t.y; }
             }
@@ -277,29 +280,26 @@ vp8_loopfilter_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g)
             // ---- vertical edges: the whole pixel row in registers
             int a[20];
             if (is_line) {
-                const u32 left = luma ? *(const u32 *)(tile + LY_AT(li, 12)) : *(const u32 *)(tile + LC_AT(li, 4));
+                const u32 left = luma ? *(const u32 *)(tile + LY_AT(li, X - 4)) : *(const u32 *)(tile + LC_AT(li, X - 4));
                 unpack4(left, a); unpack4(body.x, a + 4); unpack4(body.y, a + 8); unpack4(body.z, a + 12); unpack4(body.w, a + 16);
                 if (on) filter_line(a, luma, simple, c > 0, !skip_lf, lp);
-            }
-            wave_lds_sync();       // everyone has read the previous tile's right-hand columns
-            if (is_line) {
                 if (luma) {
-                    *(u32 *)(tile + LY_AT(li, -4)) = pack4(a);
-                    *(u32x4 *)(tile + LY_AT(li, 0)) = (u32x4){ pack4(a + 4), pack4(a + 8), pack4(a + 12), pack4(a + 16) };
+                    *(u32 *)(tile + LY_AT(li, X - 4)) = pack4(a);
+                    *(u32x4 *)(tile + LY_AT(li, X)) = (u32x4){ pack4(a + 4), pack4(a + 8), pack4(a + 12), pack4(a + 16) };
                 } else {
-                    *(u32 *)(tile + LC_AT(li, -4)) = pack4(a);
-                    *(u32x2 *)(tile + LC_AT(li, 0)) = (u32x2){ pack4(a + 4), pack4(a + 8) };
+                    *(u32 *)(tile + LC_AT(li, X - 4)) = pack4(a);
+                    *(u32x2 *)(tile + LC_AT(li, X)) = (u32x2){ pack4(a + 4), pack4(a + 8) };
                 }
             } else if (r > 0 && lane < 44) {
-                if (top_plane == 0) *(u32x4 *)(top_tile + LY_AT(top_row, 0)) = topv;
-                else *(u32x2 *)(top_tile + LC_AT(top_row, 0)) = (u32x2){ topv.x, topv.y };
+                if (top_plane == 0) *(u32x4 *)(top_tile + LY_AT(top_row, c * 16)) = topv;
+                else *(u32x2 *)(top_tile + LC_AT(top_row, c * 8)) = (u32x2){ topv.x, topv.y };
             }
             wave_lds_sync();
 
             // ---- horizontal edges: the whole pixel column in registers
             if (is_line && on) {
                 const int stride = luma ? LY_STRIDE : LC_STRIDE;
-                unsigned char *colp = tile + (luma ? LY_AT(-4, li) : LC_AT(-4, li));
+                unsigned char *colp = tile + (luma ? LY_AT(-4, X + li) : LC_AT(-4, X + li));
                 const int n = luma ? 20 : 12;
 #pragma unroll
                 for (int i = 0; i < 20; i++) a[i] = i < n ? colp[i * stride] : 0;
@@ -308,21 +308,22 @@ vp8_loopfilter_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g)
                 for (int i = 1; i < 19; i++) if (i < n - 1) colp[i * stride] = (unsigned char)a[i];
             }
             wave_lds_sync();
+        };
 
-            // ---- publish the PREVIOUS MB (its stores were issued a whole MB ago), then write this one back:
-            // body rows, the 4 context columns to the left (c > 0) and the 3 context rows above (r > 0)
-            wg_publish_global(&prog[wave], (k << 16) + c, lane);
-            if (is_line) {
-                if (luma) {
-                    *(g_u32x4p)(frow + c * 16) = *(const u32x4 *)(tile + LY_AT(li, 0));
-                    if (c > 0) *(g_u32p)(frow + c * 16 - 4) = *(const u32 *)(tile + LY_AT(li, -4));
-                } else {
-                    *(g_u32x2p)(frow + c * 8) = *(const u32x2 *)(tile + LC_AT(li, 0));
-                    if (c > 0) *(g_u32p)(frow + c * 8 - 4) = *(const u32 *)(tile + LC_AT(li, -4));
-                }
-            } else if (r > 0 && lane < 44 && top_row > -4) {
-                if (top_plane == 0) *(g_u32x4p)(trow + c * 16) = *(const u32x4 *)(top_tile + LY_AT(top_row, 0));
-                else *(g_u32x2p)(trow + c * 8) = *(const u32x2 *)(top_tile + LC_AT(top_row, 0));
+        // Write MBs [m0, m1) of the ring to the frame: luma rows -3..15 (0..15 on the first MB row), chroma
+        // rows -3..7; 16-byte (luma) / 8-byte (chroma) pieces, one per lane and pass.  Rows 12..15 are
+        // provisional (the wave below finishes them) but must be visible to it.
+        auto flush = [&](const int m0, const int m1) {
+            const int n = m1 - m0, y0 = r > 0 ? -3 : 0;
+            const int ny = 16 - y0, nc = 8 - y0;
+            for (int t = lane; t < ny * n; t += 64) {
+                const int y = y0 + t / n, m = m0 + t % n;
+                *(g_u32x4p)(fY + (long)y * g.y_stride + m * 16) = *(const u32x4 *)(wl->tY + LY_AT(y, m * 16));
+            }
+            for (int t = lane; t < 2 * nc * n; t += 64) {
+                const int pl = t >= nc * n, tt = pl ? t - nc * n : t;
+                const int y = y0 + tt / n, m = m0 + tt % n;
+                *(g_u32x2p)((pl ? fV : fU) + (long)y * g.uv_stride + m * 8) = *(const u32x2 *)((pl ? wl->tV : wl->tU) + LC_AT(y, m * 8));
             }
         };
 
@@ -334,6 +335,22 @@ vp8_loopfilter_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g)
         };
         auto load_desc = [&](int c) -> u32 { return lane < 2 ? mbrow[c * 16 + lane] : 0u; };
 
+        // After MB c: once MB c's vertical-edge pass has run, MBs < c are final as far as this wave is
+        // concerned.  Frame writes happen in groups that end on 64-byte sector boundaries of the frame
+        // rows (x = 32 mod 64, i.e. MB index = 2 mod 4).  Publishing is one group late: by the time the
+        // next group is written the previous group's stores have long been acknowledged, so the
+        // vmcnt(0) in wg_publish_global costs (almost) nothing.
+        int flushed = 0, published = 0;
+        auto after_mb = [&](const int c) {
+            const bool last = c == cols - 1;
+            if (last || (c & 3) == 2) {
+                wg_publish_global(&prog[wave], (k << 16) + flushed, lane);
+                published = flushed;
+                flush(flushed, last ? cols : c);
+                flushed = last ? cols : c;
+            }
+        };
+
         // ---- software pipeline, unrolled by two so that no loaded register is ever copied
         u32x4 bodyA = load_body(0), bodyB = { 0, 0, 0, 0 };
         u32 dA = load_desc(0), dB = cols > 1 ? load_desc(1) : 0u;
@@ -343,15 +360,18 @@ vp8_loopfilter_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g)
                 if (c + 1 < cols) bodyB = load_body(c + 1);
                 if (c + 2 < cols) dA = load_desc(c + 2);
                 process(c, bodyA, w0, w1);
+                after_mb(c);
             }
             if (c + 1 < cols) {
                 const u32 w0 = (u32)__builtin_amdgcn_readlane((int)dB, 0), w1 = (u32)__builtin_amdgcn_readlane((int)dB, 1);
                 if (c + 2 < cols) bodyA = load_body(c + 2);
                 if (c + 3 < cols) dB = load_desc(c + 3);
                 process(c + 1, bodyB, w0, w1);
+                after_mb(c + 1);
             }
         }
         wg_publish_global(&prog[wave], (k + 1) << 16, lane);
+        (void)published;
         (void)xstep; (void)tstep;
     }
 }
