@@ -204,6 +204,10 @@ typedef GLOBAL_AS const u32x2 *g_cu32x2p;
 __device__ __forceinline__ void unpack4(u32 v, int *a) { a[0] = v & 0xff; a[1] = (v >> 8) & 0xff; a[2] = (v >> 16) & 0xff; a[3] = v >> 24; }
 __device__ __forceinline__ u32 pack4(const int *a) { return (u32)a[0] | ((u32)a[1] << 8) | ((u32)a[2] << 16) | ((u32)a[3] << 24); }
 
+// Two frames per wave: lanes 0..31 filter frame A, lanes 32..63 frame B of a job pair, at the same
+// MB position.  One MB keeps only 32 lanes busy (16 luma + 8 U + 8 V pixel lines) and the kernel is
+// bound by VALU issue (one wave instruction = 4 SIMD cycles whatever the number of active lanes),
+// so sharing the instruction stream between two independent frames halves the cost per MB.
 extern "C" __global__ void __launch_bounds__(1024)
 vp8_loopfilter_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g)
 {
@@ -212,60 +216,69 @@ vp8_loopfilter_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int NW = blockDim.x >> 6;
     const int cols = g.mb_cols, rows = g.mb_rows;
+    const int half = lane >> 5, hl = lane & 31;
     int *prog = (int *)smem;
-    LfWaveLds *wl = (LfWaveLds *)(smem + 256) + wave;
+    LfWaveLds *wl = (LfWaveLds *)(smem + 256) + wave * 2 + half;
 
     if (threadIdx.x < 64) prog[threadIdx.x] = 0;
     __syncthreads();
 
-    const int myjobs = (njobs - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
-    const int total_rows = myjobs * rows;
+    const int npairs = (njobs + 1) >> 1;
+    const int mypairs = (npairs - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int total_rows = mypairs * rows;
     const int dep_wave = (wave + NW - 1) % NW;
     // mode_lf_lut (loopfilter.c:52-63) indexed by MB mode: DC,V,H,TM -> 1, B_PRED -> 0,
     // NEAREST,NEAR,NEW -> 2, ZERO -> 1, SPLIT -> 3; packed 2 bits each.
     const unsigned mode_class = (1u) | (1u << 2) | (1u << 4) | (1u << 6) | (0u << 8) | (2u << 10) | (2u << 12)
                               | (1u << 14) | (2u << 16) | (3u << 18);
 
-    // ---- lane roles.  "Line" lanes 0..31 own one pixel line of the MB in both filter passes:
-    //   lanes 0..15 luma line (row y in the vertical-edge pass, column x in the horizontal-edge pass),
-    //   lanes 16..23 U, 24..31 V.  Lanes 32..43 carry the 4 context rows above (3 luma quads + U + V).
-    const bool is_line = lane < 32, luma = lane < 16;
-    const int li = luma ? lane : (lane & 7);                       // line index inside its plane
-    unsigned char *tile = luma ? wl->tY : ((lane & 8) ? wl->tV : wl->tU);   // lanes 16..23 U, 24..31 V
-    const int top_plane = lane < 36 ? 0 : (lane < 40 ? 1 : 2), top_row = (lane & 3) - 4;   // lanes 32..43
-    unsigned char *top_tile = top_plane == 0 ? wl->tY : (top_plane == 1 ? wl->tU : wl->tV);
+    // ---- lane roles inside a half: every lane owns one pixel line of the MB in both filter passes --
+    // hl 0..15 a luma line (row y in the vertical-edge pass, column x in the horizontal-edge pass),
+    // hl 16..23 a U line, hl 24..31 a V line.  The first four lanes of each plane additionally fetch
+    // the four context rows above the MB.
+    const bool luma = hl < 16;
+    const int li = luma ? hl : (hl & 7);                          // line index inside its plane
+    unsigned char *tile = luma ? wl->tY : ((hl & 8) ? wl->tV : wl->tU);
+    const bool is_top = li < 4;
+    const int top_row = li - 4;
 
     for (int R = wave, k = 0; R < total_rows; R += NW, ++k) {
         const int jj = R / rows, r = R - jj * rows;
-        const DevJob &job = jobs[blockIdx.x + jj * gridDim.x];
-        const vp8ir_frame_hdr &hdr = job.hdr;
+        const int pair = blockIdx.x + jj * gridDim.x;
+        const bool haveB = 2 * pair + 1 < njobs;
+        const DevJob &jobA = jobs[2 * pair];
+        const DevJob &jobB = jobs[haveB ? 2 * pair + 1 : 2 * pair];
+        const vp8ir_frame_hdr &hA = jobA.hdr, &hB = jobB.hdr;
         const int dep_seq = (R - 1) / NW;
-        if (hdr.filter_level == 0) {             // frame not filtered at all (onyxd_if.c:576)
+        const bool onA = hA.filter_level != 0, onB = haveB && hB.filter_level != 0;
+        if (!onA && !onB) {                      // neither frame is filtered at all (onyxd_if.c:576)
             wg_publish_lds(&prog[wave], (k + 1) << 16, lane);
             continue;
         }
-        const int lvlv = build_level(hdr, lane);  // lane l holds lvl[seg][ref][mode class], l = seg<<4|ref<<2|class
-        const bool simple = hdr.filter_type != 0;
-        const int sharp = hdr.sharpness_level, ftype = hdr.frame_type;
-        g_cu32p mbrow = (g_cu32p)(job.mbs + (long)r * cols);          // 16 dwords per MB
-        g_u8p fY = (g_u8p)(job.dst + g.y_off + (long)r * 16 * g.y_stride);
-        g_u8p fU = (g_u8p)(job.dst + g.u_off + (long)r * 8 * g.uv_stride);
-        g_u8p fV = (g_u8p)(job.dst + g.v_off + (long)r * 8 * g.uv_stride);
-        // this lane's pixel row in the frame (line lanes), resp. its context row (lanes 32..43)
-        g_u8p frow = luma ? fY + (long)li * g.y_stride : ((lane & 8) ? fV : fU) + (long)li * g.uv_stride;
-        g_u8p trow = top_plane == 0 ? fY + (long)top_row * g.y_stride
-                                    : (top_plane == 1 ? fU : fV) + (long)top_row * g.uv_stride;
-        const int xstep = luma ? 16 : 8;          // bytes per MB in this lane's plane
-        const int tstep = top_plane == 0 ? 16 : 8;
+        const bool frame_on = half ? onB : onA;
+        // lane l holds lvl[seg][ref][mode class] of each frame, l = seg<<4 | ref<<2 | class
+        const int lvlA = build_level(hA, lane), lvlB = build_level(hB, lane);
+        const bool simple = (half ? hB.filter_type : hA.filter_type) != 0;
+        const int sharp = half ? hB.sharpness_level : hA.sharpness_level;
+        const int ftype = half ? hB.frame_type : hA.frame_type;
+        const vp8ir_mb *mbs = half ? jobB.mbs : jobA.mbs;
+        uint8_t *dst = half ? jobB.dst : jobA.dst;
+        g_cu32p mbrow = (g_cu32p)(mbs + (long)r * cols);              // 16 dwords per MB
+        g_u8p fY = (g_u8p)(dst + g.y_off + (long)r * 16 * g.y_stride);
+        g_u8p fU = (g_u8p)(dst + g.u_off + (long)r * 8 * g.uv_stride);
+        g_u8p fV = (g_u8p)(dst + g.v_off + (long)r * 8 * g.uv_stride);
+        const int pstride = luma ? g.y_stride : g.uv_stride;
+        g_u8p plane = luma ? fY : ((hl & 8) ? fV : fU);
+        g_u8p frow = plane + (long)li * pstride;       // this lane's pixel row in the frame
+        g_u8p trow = plane + (long)top_row * pstride;  // its context row (is_top lanes)
 
         // One MB.  `body` = this lane's 16 (8) unfiltered pixels, prefetched; `w0`,`w1` = the first two
-        // dwords of the MB descriptor.
-        auto process = [&](const int c, const u32x4 body, const u32 w0, const u32 w1) {
-            const int y_mode = w0 & 0xff, ref_frame = (w0 >> 16) & 3;
+        // dwords of the MB descriptor of this half's frame.
+        auto process = [&](const int c, const u32x4 body, const u32 w0, const u32 w1, const int level) {
+            const int y_mode = w0 & 0xff;
             const bool skip_lf = y_mode != VP8IR_B_PRED && y_mode != VP8IR_SPLITMV && ((w0 >> 24) & VP8IR_MB_SKIP);
-            const int level = __builtin_amdgcn_readlane(lvlv, ((w1 & 3) << 4) | (ref_frame << 2) | ((mode_class >> (2 * y_mode)) & 3));
             const LfParams lp = lf_params(sharp, level, ftype);
-            const bool on = level != 0;
+            const bool on = frame_on && level != 0;
             const int X = luma ? c * 16 : c * 8;      // absolute x of this MB in the lane's plane
 
             // ---- context rows above: written by the wave of row r-1 (final-so-far values); the loads are
@@ -273,13 +286,15 @@ vp8_loopfilter_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g)
             u32x4 topv = { 0, 0, 0, 0 };
             if (r > 0) {
                 wg_wait_ge(&prog[dep_wave], (dep_seq << 16) + c + 1);
-                if (lane >= 32 && lane < 36) topv = *(g_cu32x4p)(trow + c * 16);
-                else if (lane >= 36 && lane < 44) { const u32x2 t = *(g_cu32x2p)(trow + c * 8); topv.x = t.x; topv.y = t.y; }
+                if (is_top) {
+                    if (luma) topv = *(g_cu32x4p)(trow + c * 16);
+                    else { const u32x2 t = *(g_cu32x2p)(trow + c * 8); topv.x = t.x; topv.y = t.y; }
+                }
             }
 
             // ---- vertical edges: the whole pixel row in registers
             int a[20];
-            if (is_line) {
+            {
                 const u32 left = luma ? *(const u32 *)(tile + LY_AT(li, X - 4)) : *(const u32 *)(tile + LC_AT(li, X - 4));
                 unpack4(left, a); unpack4(body.x, a + 4); unpack4(body.y, a + 8); unpack4(body.z, a + 12); unpack4(body.w, a + 16);
                 if (on) filter_line(a, luma, simple, c > 0, !skip_lf, lp);
@@ -290,14 +305,15 @@ vp8_loopfilter_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g)
                     *(u32 *)(tile + LC_AT(li, X - 4)) = pack4(a);
                     *(u32x2 *)(tile + LC_AT(li, X)) = (u32x2){ pack4(a + 4), pack4(a + 8) };
                 }
-            } else if (r > 0 && lane < 44) {
-                if (top_plane == 0) *(u32x4 *)(top_tile + LY_AT(top_row, c * 16)) = topv;
-                else *(u32x2 *)(top_tile + LC_AT(top_row, c * 8)) = (u32x2){ topv.x, topv.y };
+            }
+            if (r > 0 && is_top) {
+                if (luma) *(u32x4 *)(tile + LY_AT(top_row, X)) = topv;
+                else *(u32x2 *)(tile + LC_AT(top_row, X)) = (u32x2){ topv.x, topv.y };
             }
             wave_lds_sync();
 
             // ---- horizontal edges: the whole pixel column in registers
-            if (is_line && on) {
+            if (on) {
                 const int stride = luma ? LY_STRIDE : LC_STRIDE;
                 unsigned char *colp = tile + (luma ? LY_AT(-4, X + li) : LC_AT(-4, X + li));
                 const int n = luma ? 20 : 12;
@@ -314,13 +330,14 @@ vp8_loopfilter_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g)
         // rows -3..7; 16-byte (luma) / 8-byte (chroma) pieces, one per lane and pass.  Rows 12..15 are
         // provisional (the wave below finishes them) but must be visible to it.
         auto flush = [&](const int m0, const int m1) {
+            if (!frame_on) return;
             const int n = m1 - m0, y0 = r > 0 ? -3 : 0;
             const int ny = 16 - y0, nc = 8 - y0;
-            for (int t = lane; t < ny * n; t += 64) {
+            for (int t = hl; t < ny * n; t += 32) {
                 const int y = y0 + t / n, m = m0 + t % n;
                 *(g_u32x4p)(fY + (long)y * g.y_stride + m * 16) = *(const u32x4 *)(wl->tY + LY_AT(y, m * 16));
             }
-            for (int t = lane; t < 2 * nc * n; t += 64) {
+            for (int t = hl; t < 2 * nc * n; t += 32) {
                 const int pl = t >= nc * n, tt = pl ? t - nc * n : t;
                 const int y = y0 + tt / n, m = m0 + tt % n;
                 *(g_u32x2p)((pl ? fV : fU) + (long)y * g.uv_stride + m * 8) = *(const u32x2 *)((pl ? wl->tV : wl->tU) + LC_AT(y, m * 8));
@@ -330,22 +347,29 @@ vp8_loopfilter_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g)
         auto load_body = [&](int c) -> u32x4 {
             u32x4 v = { 0, 0, 0, 0 };
             if (luma) v = *(g_cu32x4p)(frow + c * 16);
-            else if (is_line) { const u32x2 t = *(g_cu32x2p)(frow + c * 8); v.x = t.x; v.y = t.y; }
+            else { const u32x2 t = *(g_cu32x2p)(frow + c * 8); v.x = t.x; v.y = t.y; }
             return v;
         };
-        auto load_desc = [&](int c) -> u32 { return lane < 2 ? mbrow[c * 16 + lane] : 0u; };
+        auto load_desc = [&](int c) -> u32 { return hl < 2 ? mbrow[c * 16 + hl] : 0u; };
+        // descriptor fields and filter level of this half's MB (lanes 0,1 / 32,33 hold the dwords)
+        auto mb_fields = [&](const u32 d, u32 &w0, u32 &w1, int &level) {
+            const u32 a0 = (u32)__builtin_amdgcn_readlane((int)d, 0), a1 = (u32)__builtin_amdgcn_readlane((int)d, 1);
+            const u32 b0 = (u32)__builtin_amdgcn_readlane((int)d, 32), b1 = (u32)__builtin_amdgcn_readlane((int)d, 33);
+            const int la = __builtin_amdgcn_readlane(lvlA, ((a1 & 3) << 4) | (((a0 >> 16) & 3) << 2) | ((mode_class >> (2 * (a0 & 0xff))) & 3));
+            const int lb = __builtin_amdgcn_readlane(lvlB, ((b1 & 3) << 4) | (((b0 >> 16) & 3) << 2) | ((mode_class >> (2 * (b0 & 0xff))) & 3));
+            w0 = half ? b0 : a0; w1 = half ? b1 : a1; level = half ? lb : la;
+        };
 
         // After MB c: once MB c's vertical-edge pass has run, MBs < c are final as far as this wave is
         // concerned.  Frame writes happen in groups that end on 64-byte sector boundaries of the frame
         // rows (x = 32 mod 64, i.e. MB index = 2 mod 4).  Publishing is one group late: by the time the
         // next group is written the previous group's stores have long been acknowledged, so the
         // vmcnt(0) in wg_publish_global costs (almost) nothing.
-        int flushed = 0, published = 0;
+        int flushed = 0;
         auto after_mb = [&](const int c) {
             const bool last = c == cols - 1;
             if (last || (c & 3) == 2) {
                 wg_publish_global(&prog[wave], (k << 16) + flushed, lane);
-                published = flushed;
                 flush(flushed, last ? cols : c);
                 flushed = last ? cols : c;
             }
@@ -356,26 +380,25 @@ vp8_loopfilter_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g)
         u32 dA = load_desc(0), dB = cols > 1 ? load_desc(1) : 0u;
         for (int c = 0; c < cols; c += 2) {
             {
-                const u32 w0 = (u32)__builtin_amdgcn_readlane((int)dA, 0), w1 = (u32)__builtin_amdgcn_readlane((int)dA, 1);
+                u32 w0, w1; int level;
+                mb_fields(dA, w0, w1, level);
                 if (c + 1 < cols) bodyB = load_body(c + 1);
                 if (c + 2 < cols) dA = load_desc(c + 2);
-                process(c, bodyA, w0, w1);
+                process(c, bodyA, w0, w1, level);
                 after_mb(c);
             }
             if (c + 1 < cols) {
-                const u32 w0 = (u32)__builtin_amdgcn_readlane((int)dB, 0), w1 = (u32)__builtin_amdgcn_readlane((int)dB, 1);
+                u32 w0, w1; int level;
+                mb_fields(dB, w0, w1, level);
                 if (c + 2 < cols) bodyA = load_body(c + 2);
                 if (c + 3 < cols) dB = load_desc(c + 3);
-                process(c + 1, bodyB, w0, w1);
+                process(c + 1, bodyB, w0, w1, level);
                 after_mb(c + 1);
             }
         }
         wg_publish_global(&prog[wave], (k + 1) << 16, lane);
-        (void)published;
-        (void)xstep; (void)tstep;
     }
 }
-
 
 // ---- border extension ------------------------------------------------------------------------
 // vp8_yv12_extend_frame_borders (yv12extend.c:24-145): replicate the first/last pixel of every row

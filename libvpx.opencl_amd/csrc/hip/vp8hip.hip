@@ -121,6 +121,13 @@ extern "C" int vp8hip_create(int device, vp8hip_ctx **out)
         delete c;
         return -1;
     }
+    e = hipFuncSetAttribute((const void *)vp8_loopfilter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_lds);
+    if (e != hipSuccess) {
+        fail(nullptr, -1, "hipFuncSetAttribute(loopfilter, %d B LDS): %s", c->max_lds, hipGetErrorString(e));
+        (void)hipStreamDestroy(c->stream);
+        delete c;
+        return -1;
+    }
     *out = c;
     return 0;
 }
@@ -143,7 +150,7 @@ static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // per-wave LDS footprints; must match the kernels (WaveLds 2080 B + line slot, LfWaveLds 768 B)
 static size_t recon_lds_bytes(int nw, int aligned_w) { return 256 + (size_t)nw * (2080 + 2 * aligned_w + 96); }
-static size_t lf_lds_bytes(int nw) { return 256 + (size_t)nw * 4096; }
+static size_t lf_lds_bytes(int nw) { return 256 + (size_t)nw * 2 * 4096; }   // two frames per wave
 
 extern "C" int vp8hip_configure(vp8hip_ctx *c, int width, int height, int num_fb, int num_slots)
 {
@@ -322,7 +329,9 @@ extern "C" int vp8hip_decode(vp8hip_ctx *c, const vp8hip_job *jobs, int njobs, i
     }
     HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
     if ((stages & VP8HIP_STAGE_LF) && any_lf) {
-        hipLaunchKernelGGL(vp8_loopfilter_kernel, dim3(grid), dim3(64 * c->lf_nw), c->lf_lds, c->stream,
+        const int npairs = (njobs + 1) / 2;          // the loop filter works on two frames per wave
+        const int lfgrid = npairs < c->num_cu * wg_per_cu ? npairs : c->num_cu * wg_per_cu;
+        hipLaunchKernelGGL(vp8_loopfilter_kernel, dim3(lfgrid), dim3(64 * c->lf_nw), c->lf_lds, c->stream,
                            (const DevJob *)c->d_jobs, njobs, c->dg);
         HIPCHK(c, hipGetLastError());
     }
