@@ -263,11 +263,12 @@ vp8_recon_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g)
     const int NW = blockDim.x >> 6;
     const int cols = g.mb_cols, rows = g.mb_rows;
 
-    // ---- LDS carve: [progress flags 256 B][NW x WaveLds][NW x line slot]
+    // ---- LDS carve: [progress flags 256 B][B_PRED gather table 640 B, pad to 1024][NW x WaveLds][NW x line slot]
     int *prog = (int *)smem;
-    WaveLds *wl = (WaveLds *)(smem + 256) + wave;
+    u32 *gtab = (u32 *)(smem + 256);
+    WaveLds *wl = (WaveLds *)(smem + 1024) + wave;
     const int lbytes = 2 * g.aligned_w + 6 * LINE_PAD;
-    unsigned char *lines = smem + 256 + NW * sizeof(WaveLds);
+    unsigned char *lines = smem + 1024 + NW * sizeof(WaveLds);
     unsigned char *my_line = lines + wave * lbytes;
     // within a slot: Y at +0 (LINE_PAD + W + LINE_PAD), U, V each (LINE_PAD + W/2 + LINE_PAD)
     const int lU = 2 * LINE_PAD + g.aligned_w, lV = lU + 2 * LINE_PAD + g.aligned_w / 2;
@@ -280,16 +281,28 @@ vp8_recon_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g)
     __syncthreads();
 
     // ---- per-lane constants
-    // 4x4 predictor table column of this lane's pixel (lanes 0..15), modes 2..9 packed in two dwords
-    u32 tabLo = 0, tabHi = 0;
-    {
-        const int i = lane & 15;
-#pragma unroll
-        for (int m = 0; m < 4; m++) {
-            tabLo |= (u32)k_bpred_tab[(2 + m) * 16 + i] << (8 * m);
-            tabHi |= (u32)k_bpred_tab[(6 + m) * 16 + i] << (8 * m);
+    // B_PRED gather table gtab[mode][pixel] (LDS, built once per workgroup): one dword per entry,
+    //   byte0..2 = tile byte offsets (relative to the block's top-left pixel, biased by +64) of the three
+    //   edge pixels p0,p1,p2 the predictor reads, byte3 = kind:
+    //   0: p1   1: (p1+p2+1)>>1   2: (p0+2*p1+p2+2)>>2   3: clamp(p0+p1-p2) (B_TM_PRED)
+    // derived from k_bpred_tab with P[k] -> tile offset: L_j = j*stride-1, TL = -stride-1, A_i = -stride+i.
+    for (int t = threadIdx.x; t < 160; t += blockDim.x) {
+        const int m = t >> 4, i = t & 15, pr = i >> 2, pc = i & 3;
+        auto poff = [](int k) -> int {      // tile offset of edge-vector element P[k], k = 0..14
+            if (k <= 4) return (k == 0 ? 3 : 4 - k) * TY_STRIDE - 1;
+            if (k == 5) return -TY_STRIDE - 1;
+            return -TY_STRIDE + (k == 14 ? 7 : k - 6);
+        };
+        int o0, o1, o2, kind;
+        if (m == VP8IR_B_TM_PRED) { o0 = poff(6 + pc); o1 = poff(4 - pr); o2 = poff(5); kind = 3; }
+        else {
+            const int e = k_bpred_tab[t], kk = e & 15;
+            kind = e >> 4;
+            o0 = poff(kk > 0 ? kk - 1 : 0); o1 = poff(kk); o2 = poff(kk < 14 ? kk + 1 : 14);
         }
+        gtab[t] = (u32)(o0 + 64) | ((u32)(o1 + 64) << 8) | ((u32)(o2 + 64) << 16) | ((u32)kind << 24);
     }
+    __syncthreads();
     // pixel-stage lane roles.  Luma: lane = block*4 + row  ->  (y, x0).  Chroma (lanes 0..31):
     // plane = lane>>4, block = (lane>>2)&3, row = lane&3.
     const int ly = ((lane >> 4) << 2) + (lane & 3), lx0 = ((lane >> 2) & 3) << 2;
@@ -461,54 +474,47 @@ vp8_recon_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g)
                     outY = add_clamp_pack(intra_pred4(y_mode, above, left, tl, dc), rY);
                 } else {
                     // ---- B_PRED (decodframe.c:200-236): 16 sub-blocks in raster order, each predicted
-                    // from already reconstructed pixels; lanes 0..15 = the block's 16 pixels.
+                    // from already reconstructed pixels; lanes 0..15 = the block's 16 pixels.  Every
+                    // predictor pixel is a function of at most three edge pixels, gathered straight from
+                    // the tile with per-lane byte offsets (one LDS turnaround per sub-block).
                     *(uint2 *)(wl->res + lane * 4) = make_uint2(((u32)rY[0] & 0xffff) | ((u32)rY[1] << 16),
                                                                 ((u32)rY[2] & 0xffff) | ((u32)rY[3] << 16));
+                    // the reference's "down copy" (reconintra4x4.c:305-317): the MB's above-right pixels also
+                    // serve as above-right of the right-hand block column of block rows 1..3
+                    if (lane < 3) *(u32 *)(tY + TY_AT(4 * lane + 3, 16)) = *(const u32 *)(tY + TY_AT(-1, 16));
                     wave_lds_sync();
                     const int pr = (lane >> 2) & 3, pc = lane & 3;
-                    int resb[16];
 #pragma unroll
-                    for (int b = 0; b < 16; b++) resb[b] = wl->res[b * 16 + (lane & 15)];
+                    for (int by = 0; by < 4; ++by) {
+                        // residuals and gather entries of this block row: independent of the prediction chain
+                        const u32 bmw = by == 0 ? bm0 : (by == 1 ? bm1 : (by == 2 ? bm2 : bm3));
+                        int resb[4];
+                        u32 ent[4];
 #pragma unroll
-                    for (int b = 0; b < 16; ++b) {
-                        const int by = b >> 2, bx = b & 3, oy = by * 4, ox = bx * 4;
-                        const u32 bmw = b < 4 ? bm0 : (b < 8 ? bm1 : (b < 12 ? bm2 : bm3));
-                        const int mode = (bmw >> (8 * (b & 3))) & 0xff;
-                        // edges: W0 = x-4..x-1 (top-left in byte 3), W1 = A0..A3, W2 = A4..A7 (the MB's own
-                        // above-right row for the right-hand block column), Ld = left column L0..L3
-                        const u32 W0 = *(const u32 *)(tY + TY_AT(oy - 1, ox - 4));
-                        const u32 W1 = *(const u32 *)(tY + TY_AT(oy - 1, ox));
-                        const u32 W2 = *(const u32 *)(tY + (bx == 3 ? TY_AT(-1, 16) : TY_AT(oy - 1, ox + 4)));
-                        const u32 Ld = bx == 0 ? ((const u32 *)wl->lcol)[by] : wl->colbuf[b - 1];
-                        int pred;
-                        if (mode == VP8IR_B_DC_PRED) {
-                            pred = (sad4(W1) + sad4(Ld) + 4) >> 3;
-                        } else if (mode == VP8IR_B_TM_PRED) {
-                            pred = clamp255((int)((W1 >> (8 * pc)) & 0xff) + (int)((Ld >> (8 * pr)) & 0xff) - (int)(W0 >> 24));
-                        } else {
-                            // V = P[0..15] as 4 dwords: {L3,L3,L2,L1} {L0,TL,A0,A1} {A2..A5} {A6,A7,A7,A7}
-                            const u32 V0 = perm(Ld, Ld, 0x01020303u);
-                            const u32 tt = perm(W0, Ld, 0x00000700u);          // {L0, TL, -, -}
-                            const u32 V1 = perm(W1, tt, 0x05040100u);
-                            const u32 V2 = __builtin_amdgcn_alignbyte(W2, W1, 2);
-                            const u32 V3 = perm(W2, W2, 0x03030302u);
-                            const u32 e = ((mode < 6 ? tabLo : tabHi) >> (8 * ((mode - 2) & 3))) & 0xff;
-                            const int kk = e & 15, kind = e >> 4;
-                            const int o = kk - 1 + (kind == 0);                // first byte of the 3-byte window
-                            const int j = o >> 2;
-                            const u32 lo = j == 0 ? V0 : (j == 1 ? V1 : (j == 2 ? V2 : V3));
-                            const u32 hi = j == 0 ? V1 : (j == 1 ? V2 : V3);
-                            const u32 win = __builtin_amdgcn_alignbyte(hi, lo, (u32)(o & 3));
-                            const int p0 = win & 0xff, p1 = (win >> 8) & 0xff, p2 = (win >> 16) & 0xff;
-                            // kinds 2 and 1: window = P[k-1],P[k],P[k+1]; kind 0: window starts at P[k]
-                            pred = kind == 2 ? (p0 + 2 * p1 + p2 + 2) >> 2 : (kind == 1 ? (p1 + p2 + 1) >> 1 : p0);
+                        for (int bx = 0; bx < 4; ++bx) {
+                            resb[bx] = wl->res[(by * 4 + bx) * 16 + (lane & 15)];
+                            ent[bx] = gtab[((bmw >> (8 * bx)) & 0xff) * 16 + (lane & 15)];
                         }
-                        const int v = clamp255(pred + resb[b]);
-                        if (lane < 16) {
-                            tY[TY_AT(oy + pr, ox + pc)] = (unsigned char)v;
-                            if (pc == 3) ((unsigned char *)(wl->colbuf + b))[pr] = (unsigned char)v;
+#pragma unroll
+                        for (int bx = 0; bx < 4; ++bx) {
+                            const int mode = (bmw >> (8 * bx)) & 0xff;
+                            const unsigned char *org = tY + TY_AT(by * 4, bx * 4) - 64;
+                            int pred;
+                            if (mode == VP8IR_B_DC_PRED) {
+                                const u32 W1 = *(const u32 *)(org + 64 - TY_STRIDE);
+                                pred = (sad4(W1) + org[63] + org[63 + TY_STRIDE] + org[63 + 2 * TY_STRIDE]
+                                        + org[63 + 3 * TY_STRIDE] + 4) >> 3;
+                            } else {
+                                const u32 e = ent[bx];
+                                const int p0 = org[e & 0xff], p1 = org[(e >> 8) & 0xff], p2 = org[(e >> 16) & 0xff];
+                                const int kind = e >> 24;
+                                const int t3 = (p0 + 2 * p1 + p2 + 2) >> 2, t2 = (p1 + p2 + 1) >> 1, tm = clamp255(p0 + p1 - p2);
+                                pred = kind == 2 ? t3 : (kind == 1 ? t2 : (kind == 0 ? p1 : tm));
+                            }
+                            const int v = clamp255(pred + resb[bx]);
+                            if (lane < 16) tY[TY_AT(by * 4 + pr, bx * 4 + pc)] = (unsigned char)v;
+                            wave_lds_sync();
                         }
-                        wave_lds_sync();
                     }
                     outY = *(const u32 *)(tY + TY_AT(ly, lx0));
                 }

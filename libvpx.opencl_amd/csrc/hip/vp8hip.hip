@@ -149,7 +149,7 @@ extern "C" void vp8hip_destroy(vp8hip_ctx *c)
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // per-wave LDS footprints; must match the kernels (WaveLds 2080 B + line slot, LfWaveLds 768 B)
-static size_t recon_lds_bytes(int nw, int aligned_w) { return 256 + (size_t)nw * (2080 + 2 * aligned_w + 96); }
+static size_t recon_lds_bytes(int nw, int aligned_w) { return 1024 + (size_t)nw * (2080 + 2 * aligned_w + 96); }
 static size_t lf_lds_bytes(int nw) { return 256 + (size_t)nw * 2 * 4096; }   // two frames per wave
 
 extern "C" int vp8hip_configure(vp8hip_ctx *c, int width, int height, int num_fb, int num_slots)
