@@ -56,10 +56,13 @@ __device__ __forceinline__ void compiler_fence()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+#ifndef VP8_POLL_SLEEP
+#define VP8_POLL_SLEEP 1   // s_sleep units (64 clocks) between polls of a progress flag
+#endif
 __device__ __forceinline__ void wg_wait_ge(int *flag, int value)
 {
     while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < value)
-        __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_s_sleep(VP8_POLL_SLEEP);
     compiler_fence();
 }
 

@@ -254,7 +254,18 @@ __device__ __forceinline__ void clamp_chroma_mv(int &row, int &col, int e_left, 
     if (2 * row > e_bottom + (18 << 3)) row = (e_bottom + (16 << 3)) >> 1;
 }
 
-extern "C" __global__ void __launch_bounds__(1024)
+// Two frames per wave: lanes 0..31 reconstruct frame A, lanes 32..63 frame B of a job pair, at the
+// same MB position.  The kernel is bound by VALU issue (one wave instruction costs 4 SIMD cycles
+// whatever the number of active lanes) and the B_PRED chain keeps only 16 lanes busy per frame, so
+// sharing the instruction stream between two independent frames nearly halves the cost of the
+// B_PRED-heavy key frames (and of chroma prediction); the 64-lane-wide steps take two passes of 32
+// lanes and cost the same per MB as before.
+//
+// Lane roles inside a half (hl = lane & 31):
+//   residual   : hl = block*4 + column; four passes: chroma (8 blocks), Y2 (hl < 4), luma blocks 0..7, 8..15
+//   prediction : hl = block*4 + row -> a 4-pixel row segment; luma in two passes, chroma in one
+//   B_PRED     : hl 0..15 = the 16 pixels of the current 4x4 sub-block
+extern "C" __global__ void __launch_bounds__(768)
 vp8_recon_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -262,26 +273,25 @@ vp8_recon_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int NW = blockDim.x >> 6;
     const int cols = g.mb_cols, rows = g.mb_rows;
+    const int half = lane >> 5, hl = lane & 31;
 
-    // ---- LDS carve: [progress flags 256 B][B_PRED gather table 640 B, pad to 1024][NW x WaveLds][NW x line slot]
+    // ---- LDS carve: [progress flags 256 B][B_PRED gather table 640 B, pad to 1024]
+    //                 [2*NW x WaveLds][2*NW x line slot]      (one working set and one line per half)
     int *prog = (int *)smem;
     u32 *gtab = (u32 *)(smem + 256);
-    WaveLds *wl = (WaveLds *)(smem + 1024) + wave;
+    WaveLds *wl = (WaveLds *)(smem + 1024) + wave * 2 + half;
     const int lbytes = 2 * g.aligned_w + 6 * LINE_PAD;
-    unsigned char *lines = smem + 1024 + NW * sizeof(WaveLds);
-    unsigned char *my_line = lines + wave * lbytes;
+    unsigned char *lines = smem + 1024 + 2 * NW * sizeof(WaveLds);
+    unsigned char *my_line = lines + (wave * 2 + half) * lbytes;
     // within a slot: Y at +0 (LINE_PAD + W + LINE_PAD), U, V each (LINE_PAD + W/2 + LINE_PAD)
     const int lU = 2 * LINE_PAD + g.aligned_w, lV = lU + 2 * LINE_PAD + g.aligned_w / 2;
 
     if (threadIdx.x < 64) prog[threadIdx.x] = 0;
-    if (lane < 3) {   // x = -4..-1 of every line: only x = -1 is ever used, the constant 129 left border
-        const int off = lane == 0 ? 0 : (lane == 1 ? lU : lV);
+    if (hl < 3) {   // x = -4..-1 of every line: only x = -1 is ever used, the constant 129 left border
+        const int off = hl == 0 ? 0 : (hl == 1 ? lU : lV);
         *(u32 *)(my_line + off + LINE_PAD - 4) = 0x81818181u;
     }
-    __syncthreads();
-
-    // ---- per-lane constants
-    // B_PRED gather table gtab[mode][pixel] (LDS, built once per workgroup): one dword per entry,
+    // B_PRED gather table gtab[mode][pixel] (built once per workgroup): one dword per entry,
     //   byte0..2 = tile byte offsets (relative to the block's top-left pixel, biased by +64) of the three
     //   edge pixels p0,p1,p2 the predictor reads, byte3 = kind:
     //   0: p1   1: (p1+p2+1)>>1   2: (p0+2*p1+p2+2)>>2   3: clamp(p0+p1-p2) (B_TM_PRED)
@@ -303,118 +313,122 @@ vp8_recon_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g)
         gtab[t] = (u32)(o0 + 64) | ((u32)(o1 + 64) << 8) | ((u32)(o2 + 64) << 16) | ((u32)kind << 24);
     }
     __syncthreads();
-    // pixel-stage lane roles.  Luma: lane = block*4 + row  ->  (y, x0).  Chroma (lanes 0..31):
-    // plane = lane>>4, block = (lane>>2)&3, row = lane&3.
-    const int ly = ((lane >> 4) << 2) + (lane & 3), lx0 = ((lane >> 2) & 3) << 2;
-    const int cpl = (lane >> 4) & 1, cy = (((lane >> 2) & 3) >> 1) * 4 + (lane & 3), cx0 = ((lane >> 2) & 1) << 2;
 
-    const int myjobs = (njobs - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
-    const int total_rows = myjobs * rows;
+    // prediction-stage roles: segment row / first column for luma pass 0 (blocks 0..7), pass 1 adds 8 rows;
+    // chroma: plane = hl>>4, block = (hl>>2)&3
+    const int ly0 = ((hl >> 4) << 2) + (hl & 3), lx0 = ((hl >> 2) & 3) << 2;
+    const int cpl = hl >> 4, cy = (((hl >> 2) & 3) >> 1) * 4 + (hl & 3), cx0 = ((hl >> 2) & 1) << 2;
+    const int col = hl & 3;
+
+    const int npairs = (njobs + 1) >> 1;
+    const int mypairs = (npairs - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int total_rows = mypairs * rows;
     const int dep_wave = (wave + NW - 1) % NW;
-    unsigned char *tY = wl->tY, *tU = wl->tU, *tV = wl->tV;
 
     for (int R = wave, k = 0; R < total_rows; R += NW, ++k) {
         const int jj = R / rows, r = R - jj * rows;
-        const DevJob &job = jobs[blockIdx.x + jj * gridDim.x];
-        const vp8ir_frame_hdr &hdr = job.hdr;
-        const bool bilinear = hdr.version != 0;
-        const bool fullpix = hdr.version == 3;
+        const int pair = blockIdx.x + jj * gridDim.x;
+        const bool haveB = 2 * pair + 1 < njobs;
+        const DevJob &jobA = jobs[2 * pair];
+        const DevJob &jobB = jobs[haveB ? 2 * pair + 1 : 2 * pair];
+        const bool valid = half == 0 || haveB;       // an odd job count leaves the last B half idle
+        const vp8ir_frame_hdr &hA = jobA.hdr, &hB = jobB.hdr;
+        const int version = half ? hB.version : hA.version;
+        const bool bilinear = version != 0, fullpix = version == 3;
 
         // Line-slot reuse guard.  Inside one frame the wavefront dependency chain already orders
         // "row R-NW+1 finished reading my previous line" before my first write; the chain is cut at
-        // a frame boundary, so check explicitly when row R-NW+1 belongs to another job.
+        // a frame boundary, so check explicitly when row R-NW+1 belongs to another job pair.
         if (k > 0 && (R - NW + 1) / rows != jj) {
             const int rd = (wave + 1) % NW;
             const int kr = (wave + 1 < NW) ? k - 1 : k;
             wg_wait_ge(&prog[rd], (kr + 1) << 16);
         }
-        build_dequant(hdr, wl->dq, lane);
-        if (lane < 8) ((u32 *)wl->lcol)[lane] = 0x81818181u;      // column 0: the left border is 129
-        if (lane >= 16 && lane < 32) tY[TY_AT(lane - 16, -1)] = 129;
+        build_dequant(half ? hB : hA, wl->dq, hl);
+        if (hl < 8) ((u32 *)wl->lcol)[hl] = 0x81818181u;        // column 0: the left border is 129
+        if (hl >= 16) wl->tY[TY_AT(hl - 16, -1)] = 129;
         wave_lds_sync();
 
-        const unsigned char *dep_line = lines + dep_wave * lbytes;
+        const unsigned char *dep_line = lines + (dep_wave * 2 + half) * lbytes;
         const int dep_seq = (R - 1) / NW;
-        g_cu32p mbrow = (g_cu32p)(job.mbs + (long)r * cols);          // 16 dwords per MB
-        g_cs16p coefrow = (g_cs16p)(job.coef + (long)r * cols * VP8IR_COEF_PER_MB);
-        g_u8p dY = (g_u8p)(job.dst + g.y_off + (long)r * 16 * g.y_stride);
-        g_u8p dU = (g_u8p)(job.dst + g.u_off + (long)r * 8 * g.uv_stride);
-        g_u8p dV = (g_u8p)(job.dst + g.v_off + (long)r * 8 * g.uv_stride);
+        const vp8ir_mb *mbs = half ? jobB.mbs : jobA.mbs;
+        const int16_t *coefs = half ? jobB.coef : jobA.coef;
+        const vp8ir_mv *mvs = half ? jobB.mvs : jobA.mvs;
+        uint8_t *dst = half ? jobB.dst : jobA.dst;
+        g_cu32p mbrow = (g_cu32p)(mbs + (long)r * cols);          // 16 dwords per MB
+        g_cs16p coefrow = (g_cs16p)(coefs + (long)r * cols * VP8IR_COEF_PER_MB);
+        g_u8p dY = (g_u8p)(dst + g.y_off + (long)r * 16 * g.y_stride);
+        g_u8p dU = (g_u8p)(dst + g.u_off + (long)r * 8 * g.uv_stride);
+        g_u8p dV = (g_u8p)(dst + g.v_off + (long)r * 8 * g.uv_stride);
 
-        // ---- software pipeline: MB descriptors two ahead (lanes 0..15 hold the 16 dwords of a
-        // vp8ir_mb), coefficients one ahead
-        u32 mbw0 = 0, mbw1 = 0;
-        if (lane < 16) {
-            mbw0 = mbrow[lane];
-            if (cols > 1) mbw1 = mbrow[16 + lane];
-        }
-        coef4 qY = { 0, 0 }, qC = { 0, 0 };
-        if (!(((u32)__builtin_amdgcn_readlane((int)mbw0, 0) >> 24) & VP8IR_MB_SKIP)) {
-            qY = *(g_cs4p)(coefrow + lane * 4);
-            if (lane < 36) qC = *(g_cs4p)(coefrow + 256 + lane * 4);
-        }
+        struct Coefs { coef4 y0, y1, c, y2; };     // luma blocks 0..7, 8..15, chroma, Y2 (hl < 4)
+        auto load_coefs = [&](int c) __attribute__((always_inline)) -> Coefs {
+            g_cs16p q = coefrow + (long)c * VP8IR_COEF_PER_MB;
+            Coefs v;
+            v.y0 = *(g_cs4p)(q + hl * 4);
+            v.y1 = *(g_cs4p)(q + 128 + hl * 4);
+            v.c = *(g_cs4p)(q + 256 + hl * 4);
+            v.y2 = (coef4){ 0, 0 };
+            if (hl < 4) v.y2 = *(g_cs4p)(q + 384 + hl * 4);
+            return v;
+        };
+        auto load_desc = [&](int c) -> u32 { return hl < 16 ? mbrow[c * 16 + hl] : 0u; };
+        auto half_sel = [&](u32 d, int idx) -> u32 {     // dword `idx` of this half's MB descriptor
+            const u32 a = (u32)__builtin_amdgcn_readlane((int)d, idx), b = (u32)__builtin_amdgcn_readlane((int)d, 32 + idx);
+            return half ? b : a;
+        };
 
-        for (int c = 0; c < cols; ++c) {
-            const u32 w0 = (u32)__builtin_amdgcn_readlane((int)mbw0, 0), w1 = (u32)__builtin_amdgcn_readlane((int)mbw0, 1);
+        // ------------------------------------------------------------------------------------------
+        // one macroblock (of each frame of the pair)
+        // ------------------------------------------------------------------------------------------
+        auto process = [&](const int c, const u32 mbw, const Coefs &q) __attribute__((always_inline)) {
+            unsigned char *const tY = wl->tY, *const tU = wl->tU, *const tV = wl->tV;   // lambda locals: selects between them stay in registers
+            const u32 w0 = half_sel(mbw, 0), w1 = half_sel(mbw, 1);
             const int y_mode = w0 & 0xff, uv_mode = (w0 >> 8) & 0xff, ref_frame = (w0 >> 16) & 0xff;
             const u32 flags = w0 >> 24;
             const bool skip = flags & VP8IR_MB_SKIP;
             const bool has_y2 = y_mode != VP8IR_B_PRED && y_mode != VP8IR_SPLITMV;
             const int seg = w1 & 3;
-            const u32 bm0 = (u32)__builtin_amdgcn_readlane((int)mbw0, 10), bm1 = (u32)__builtin_amdgcn_readlane((int)mbw0, 11);
-            const u32 bm2 = (u32)__builtin_amdgcn_readlane((int)mbw0, 12), bm3 = (u32)__builtin_amdgcn_readlane((int)mbw0, 13);
-            const coef4 cY = qY, cC = qC;
-            // prefetch: coefficients of MB c+1 (its descriptor is already here), descriptor of MB c+2
-            const u32 nflags = (u32)__builtin_amdgcn_readlane((int)mbw1, 0) >> 24;
-            mbw0 = mbw1;
-            if (c + 1 < cols && !(nflags & VP8IR_MB_SKIP)) {
-                g_cs16p q = coefrow + (long)(c + 1) * VP8IR_COEF_PER_MB;
-                qY = *(g_cs4p)(q + lane * 4);
-                if (lane < 36) qC = *(g_cs4p)(q + 256 + lane * 4);
-            }
-            if (c + 2 < cols && lane < 16) mbw1 = mbrow[(c + 2) * 16 + lane];
 
             // ---- residual (independent of every neighbour: done BEFORE waiting on the row above).
-            // rY[4]: lane = block*4+row, the row's 4 residuals.  rC[4]: lanes 0..31 chroma likewise.
-            int rY[4] = { 0, 0, 0, 0 }, rC[4] = { 0, 0, 0, 0 };
+            // rY0/rY1: the 4 residuals of luma segment (block hl>>2 [+8], row hl&3); rC: chroma likewise.
+            int rY0[4] = { 0, 0, 0, 0 }, rY1[4] = { 0, 0, 0, 0 }, rC[4] = { 0, 0, 0, 0 };
             if (!skip) {
                 const short *dq = wl->dq[seg];
-                const int col = lane & 3;
                 const int dq_y1dc = dq[0], dq_y1ac = dq[1], dq_y2dc = dq[2], dq_y2ac = dq[3], dq_uvdc = dq[4], dq_uvac = dq[5];
-                {   // chroma blocks (lanes 0..31) and the Y2 block (lanes 32..35), column pass
-                    int o[4], t[4];
-                    const bool is_y2 = lane >= 32;
-                    const int f0 = col == 0 ? (is_y2 ? dq_y2dc : dq_uvdc) : (is_y2 ? dq_y2ac : dq_uvac);
-                    const int fa = is_y2 ? dq_y2ac : dq_uvac;
-                    const int i0 = (short)(c4x(cC) * f0), i1 = (short)(c4y(cC) * fa), i2 = (short)(c4z(cC) * fa), i3 = (short)(c4w(cC) * fa);
-                    int oi[4], ow[4];
-                    idct_col(i0, i1, i2, i3, oi);
-                    {   // vp8_dequantize_b + first loop of vp8_short_inv_walsh4x4_c (idctllm.c:150-163)
-                        int a1 = i0 + i3, b1 = i1 + i2, c1 = i1 - i2, d1 = i0 - i3;
-                        ow[0] = a1 + b1; ow[1] = c1 + d1; ow[2] = a1 - b1; ow[3] = d1 - c1;
-                    }
-#pragma unroll
-                    for (int i = 0; i < 4; i++) o[i] = is_y2 ? ow[i] : oi[i];
+                int o[4], t[4];
+                {   // chroma blocks
+                    const int f0 = col == 0 ? dq_uvdc : dq_uvac;
+                    idct_col((short)(c4x(q.c) * f0), (short)(c4y(q.c) * dq_uvac), (short)(c4z(q.c) * dq_uvac),
+                             (short)(c4w(q.c) * dq_uvac), o);
                     quad_transpose16(o[0], o[1], o[2], o[3], lane, t);
                     idct_row(t, rC);
-                    if (has_y2 && is_y2 && lane < 36) {   // second loop (idctllm.c:168-186): row -> 4 block DCs
-                        int a1 = t[0] + t[3], b1 = t[1] + t[2], c1 = t[1] - t[2], d1 = t[0] - t[3];
-                        short *w = wl->wht_dc + (lane - 32) * 4;
-                        w[0] = (short)((a1 + b1 + 3) >> 3);
-                        w[1] = (short)((c1 + d1 + 3) >> 3);
-                        w[2] = (short)((a1 - b1 + 3) >> 3);
-                        w[3] = (short)((d1 - c1 + 3) >> 3);
+                }
+                {   // Y2: vp8_dequantize_b + vp8_short_inv_walsh4x4_c (idctllm.c:140-192); lanes hl < 4
+                    const int f0 = col == 0 ? dq_y2dc : dq_y2ac;
+                    const int i0 = (short)(c4x(q.y2) * f0), i1 = (short)(c4y(q.y2) * dq_y2ac);
+                    const int i2 = (short)(c4z(q.y2) * dq_y2ac), i3 = (short)(c4w(q.y2) * dq_y2ac);
+                    const int a1 = i0 + i3, b1 = i1 + i2, c1 = i1 - i2, d1 = i0 - i3;
+                    quad_transpose16(a1 + b1, c1 + d1, a1 - b1, d1 - c1, lane, t);
+                    if (has_y2 && hl < 4) {
+                        const int a2 = t[0] + t[3], b2 = t[1] + t[2], c2 = t[1] - t[2], d2 = t[0] - t[3];
+                        short *w = wl->wht_dc + hl * 4;
+                        w[0] = (short)((a2 + b2 + 3) >> 3);
+                        w[1] = (short)((c2 + d2 + 3) >> 3);
+                        w[2] = (short)((a2 - b2 + 3) >> 3);
+                        w[3] = (short)((d2 - c2 + 3) >> 3);
                     }
                 }
-                if (has_y2) wave_lds_sync();
-                {   // luma blocks
-                    int o[4], t[4];
+                wave_lds_sync();
+#pragma unroll
+                for (int p = 0; p < 2; p++) {   // luma blocks 0..7, then 8..15
+                    const coef4 cq = p ? q.y1 : q.y0;
                     int i0;
-                    if (col == 0) i0 = has_y2 ? (int)wl->wht_dc[lane >> 2] : (int)(short)(c4x(cY) * dq_y1dc);
-                    else i0 = (short)(c4x(cY) * dq_y1ac);
-                    idct_col(i0, (short)(c4y(cY) * dq_y1ac), (short)(c4z(cY) * dq_y1ac), (short)(c4w(cY) * dq_y1ac), o);
+                    if (col == 0) i0 = has_y2 ? (int)wl->wht_dc[p * 8 + (hl >> 2)] : (int)(short)(c4x(cq) * dq_y1dc);
+                    else i0 = (short)(c4x(cq) * dq_y1ac);
+                    idct_col(i0, (short)(c4y(cq) * dq_y1ac), (short)(c4z(cq) * dq_y1ac), (short)(c4w(cq) * dq_y1ac), o);
                     quad_transpose16(o[0], o[1], o[2], o[3], lane, t);
-                    idct_row(t, rY);
+                    idct_row(t, p ? rY1 : rY0);
                 }
             }
 
@@ -422,24 +436,23 @@ vp8_recon_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g)
             if (r > 0) wg_wait_ge(&prog[dep_wave], (dep_seq << 16) + min(c + 2, cols));
 
             // ---- above line -> tile row -1 (dword copies: Y x=-4..19, U/V x=-4..7)
-            if (lane < 12) {
-                const int pl = lane < 6 ? 0 : (lane < 9 ? 1 : 2), i = lane - (pl == 0 ? 0 : (pl == 1 ? 6 : 9));
+            if (hl < 12) {
+                const int pl = hl < 6 ? 0 : (hl < 9 ? 1 : 2), i = hl - (pl == 0 ? 0 : (pl == 1 ? 6 : 9));
                 u32 v = 0x7f7f7f7fu;                 // frame row 0: everything above is 127
                 if (r > 0) {
                     const unsigned char *src = dep_line + (pl == 0 ? 0 : (pl == 1 ? lU : lV)) + LINE_PAD
                                              + (pl == 0 ? c * 16 : c * 8) - 4 + i * 4;
                     v = *(const u32 *)src;
                 }
-                unsigned char *dst = (pl == 0 ? tY + TY_AT(-1, -4) : (pl == 1 ? tU : tV) + TC_AT(-1, -4)) + i * 4;
-                *(u32 *)dst = v;
+                unsigned char *dstp = (pl == 0 ? tY + TY_AT(-1, -4) : (pl == 1 ? tU : tV) + TC_AT(-1, -4)) + i * 4;
+                *(u32 *)dstp = v;
             }
             wave_lds_sync();
 
-            u32 outY = 0, outC = 0;
+            u32 outY0 = 0, outY1 = 0, outC = 0;
             if (ref_frame == VP8IR_INTRA_FRAME) {
                 const int up = r > 0, lf = c > 0;
-                // ---- chroma: DC sums by v_sad_u8 over uniformly read dwords
-                {
+                {   // ---- chroma: DC sums by v_sad_u8 over uniformly read dwords
                     const uint2 aU = *(const uint2 *)(tU + TC_AT(-1, 0)), aV = *(const uint2 *)(tV + TC_AT(-1, 0));
                     const uint2 lU2 = *(const uint2 *)(wl->lcol + 16), lV2 = *(const uint2 *)(wl->lcol + 24);
                     int dcU = 128, dcV = 128;
@@ -450,13 +463,11 @@ vp8_recon_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g)
                         dcU = (sU + (1 << (shift - 1))) >> shift;
                         dcV = (sV + (1 << (shift - 1))) >> shift;
                     }
-                    if (lane < 32) {
-                        const unsigned char *t = cpl ? tV : tU;
-                        const u32 above = *(const u32 *)(t + TC_AT(-1, cx0));
-                        const int left = wl->lcol[16 + cpl * 8 + cy];
-                        const int tl = t[TC_AT(-1, -1)];
-                        outC = add_clamp_pack(intra_pred4(uv_mode, above, left, tl, cpl ? dcV : dcU), rC);
-                    }
+                    const unsigned char *t = cpl ? tV : tU;
+                    const u32 above = *(const u32 *)(t + TC_AT(-1, cx0));
+                    const int left = wl->lcol[16 + cpl * 8 + cy];
+                    const int tl = t[TC_AT(-1, -1)];
+                    outC = add_clamp_pack(intra_pred4(uv_mode, above, left, tl, cpl ? dcV : dcU), rC);
                 }
                 if (y_mode != VP8IR_B_PRED) {
                     const uint4 aY = *(const uint4 *)(tY + TY_AT(-1, 0));
@@ -469,21 +480,24 @@ vp8_recon_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g)
                         dc = (s + (1 << (shift - 1))) >> shift;
                     }
                     const u32 above = *(const u32 *)(tY + TY_AT(-1, lx0));
-                    const int left = wl->lcol[ly];
                     const int tl = tY[TY_AT(-1, -1)];
-                    outY = add_clamp_pack(intra_pred4(y_mode, above, left, tl, dc), rY);
+                    outY0 = add_clamp_pack(intra_pred4(y_mode, above, wl->lcol[ly0], tl, dc), rY0);
+                    outY1 = add_clamp_pack(intra_pred4(y_mode, above, wl->lcol[ly0 + 8], tl, dc), rY1);
                 } else {
                     // ---- B_PRED (decodframe.c:200-236): 16 sub-blocks in raster order, each predicted
-                    // from already reconstructed pixels; lanes 0..15 = the block's 16 pixels.  Every
+                    // from already reconstructed pixels; lanes hl 0..15 = the block's 16 pixels.  Every
                     // predictor pixel is a function of at most three edge pixels, gathered straight from
                     // the tile with per-lane byte offsets (one LDS turnaround per sub-block).
-                    *(uint2 *)(wl->res + lane * 4) = make_uint2(((u32)rY[0] & 0xffff) | ((u32)rY[1] << 16),
-                                                                ((u32)rY[2] & 0xffff) | ((u32)rY[3] << 16));
+                    *(uint2 *)(wl->res + hl * 4) = make_uint2(((u32)rY0[0] & 0xffff) | ((u32)rY0[1] << 16),
+                                                              ((u32)rY0[2] & 0xffff) | ((u32)rY0[3] << 16));
+                    *(uint2 *)(wl->res + 128 + hl * 4) = make_uint2(((u32)rY1[0] & 0xffff) | ((u32)rY1[1] << 16),
+                                                                    ((u32)rY1[2] & 0xffff) | ((u32)rY1[3] << 16));
                     // the reference's "down copy" (reconintra4x4.c:305-317): the MB's above-right pixels also
                     // serve as above-right of the right-hand block column of block rows 1..3
-                    if (lane < 3) *(u32 *)(tY + TY_AT(4 * lane + 3, 16)) = *(const u32 *)(tY + TY_AT(-1, 16));
+                    if (hl < 3) *(u32 *)(tY + TY_AT(4 * hl + 3, 16)) = *(const u32 *)(tY + TY_AT(-1, 16));
+                    const u32 bm0 = half_sel(mbw, 10), bm1 = half_sel(mbw, 11), bm2 = half_sel(mbw, 12), bm3 = half_sel(mbw, 13);
                     wave_lds_sync();
-                    const int pr = (lane >> 2) & 3, pc = lane & 3;
+                    const int pr = (hl >> 2) & 3, pc = hl & 3;
 #pragma unroll
                     for (int by = 0; by < 4; ++by) {
                         // residuals and gather entries of this block row: independent of the prediction chain
@@ -492,8 +506,8 @@ vp8_recon_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g)
                         u32 ent[4];
 #pragma unroll
                         for (int bx = 0; bx < 4; ++bx) {
-                            resb[bx] = wl->res[(by * 4 + bx) * 16 + (lane & 15)];
-                            ent[bx] = gtab[((bmw >> (8 * bx)) & 0xff) * 16 + (lane & 15)];
+                            resb[bx] = wl->res[(by * 4 + bx) * 16 + (hl & 15)];
+                            ent[bx] = gtab[((bmw >> (8 * bx)) & 0xff) * 16 + (hl & 15)];
                         }
 #pragma unroll
                         for (int bx = 0; bx < 4; ++bx) {
@@ -512,30 +526,32 @@ vp8_recon_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g)
                                 pred = kind == 2 ? t3 : (kind == 1 ? t2 : (kind == 0 ? p1 : tm));
                             }
                             const int v = clamp255(pred + resb[bx]);
-                            if (lane < 16) tY[TY_AT(by * 4 + pr, bx * 4 + pc)] = (unsigned char)v;
+                            if (hl < 16) tY[TY_AT(by * 4 + pr, bx * 4 + pc)] = (unsigned char)v;
                             wave_lds_sync();
                         }
                     }
-                    outY = *(const u32 *)(tY + TY_AT(ly, lx0));
+                    outY0 = *(const u32 *)(tY + TY_AT(ly0, lx0));
+                    outY1 = *(const u32 *)(tY + TY_AT(ly0 + 8, lx0));
                 }
             } else {
                 // ---- inter MB (vp8_build_inter_predictors_mb, reconinter.c:560-606)
-                g_cmvp mv = (g_cmvp)(job.mvs + ((long)r * cols + c) * 16);
-                g_cu8p rf = (g_cu8p)job.ref[ref_frame];
+                g_cmvp mv = (g_cmvp)(mvs + ((long)r * cols + c) * 16);
+                g_cu8p rf = (g_cu8p)(half ? jobB.ref[ref_frame & 3] : jobA.ref[ref_frame & 3]);
                 const bool clampmv = flags & VP8IR_MB_CLAMP;
                 const int e_left = -((c * 16) << 3), e_right = ((cols - 1 - c) * 16) << 3;
                 const int e_top = -((r * 16) << 3), e_bottom = ((rows - 1 - r) * 16) << 3;
-                {   // luma: lane = block*4 + row
-                    const int blk = lane >> 2;
+#pragma unroll
+                for (int p = 0; p < 2; p++) {   // luma: segment of block p*8 + hl>>2, row hl&3
+                    const int blk = p * 8 + (hl >> 2), y = ly0 + 8 * p;
                     const u32 mvw = mv[blk];
                     int mrow = sext16(mvw), mcol = hi16(mvw);
                     if (clampmv) clamp_luma_mv(mrow, mcol, e_left, e_right, e_top, e_bottom);
-                    const u32 p = inter_row4(rf + g.y_off, g.y_stride, c * 16 + lx0, r * 16 + ly, mrow, mcol, bilinear,
-                                             g.aligned_w, g.aligned_h, 32);
-                    outY = add_clamp_pack(p, rY);
+                    const u32 pp = inter_row4(rf + g.y_off, g.y_stride, c * 16 + lx0, r * 16 + y, mrow, mcol, bilinear,
+                                              g.aligned_w, g.aligned_h, 32);
+                    if (p) outY1 = add_clamp_pack(pp, rY1); else outY0 = add_clamp_pack(pp, rY0);
                 }
-                if (lane < 32) {   // chroma
-                    const int blk = (lane >> 2) & 3;
+                {   // chroma
+                    const int blk = (hl >> 2) & 3;
                     int mrow, mcol;
                     if (y_mode != VP8IR_SPLITMV) {   // reconinter.c:419-424: from the CLAMPED luma MV
                         const u32 mvw = mv[0];
@@ -556,30 +572,50 @@ vp8_recon_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g)
                         if (fullpix) { mrow &= ~7; mcol &= ~7; }
                         if (clampmv) clamp_chroma_mv(mrow, mcol, e_left, e_right, e_top, e_bottom);
                     }
-                    const u32 p = inter_row4(rf + (cpl ? g.v_off : g.u_off), g.uv_stride, c * 8 + cx0, r * 8 + cy, mrow,
-                                             mcol, bilinear, g.aligned_w / 2, g.aligned_h / 2, 16);
-                    outC = add_clamp_pack(p, rC);
+                    const u32 pp = inter_row4(rf + (cpl ? g.v_off : g.u_off), g.uv_stride, c * 8 + cx0, r * 8 + cy, mrow,
+                                              mcol, bilinear, g.aligned_w / 2, g.aligned_h / 2, 16);
+                    outC = add_clamp_pack(pp, rC);
                 }
             }
 
             // ---- finished MB: frame (HBM, once), my line buffer (bottom rows), left column for MB c+1
-            *(g_u32p)(dY + (long)ly * g.y_stride + c * 16 + lx0) = outY;
-            if (ly == 15) *(u32 *)(my_line + LINE_PAD + c * 16 + lx0) = outY;
-            if (lx0 == 12) {
-                wl->lcol[ly] = (unsigned char)(outY >> 24);
-                tY[TY_AT(ly, -1)] = (unsigned char)(outY >> 24);
-            }
-            if (lane < 32) {
+            if (valid) {
+                *(g_u32p)(dY + (long)ly0 * g.y_stride + c * 16 + lx0) = outY0;
+                *(g_u32p)(dY + (long)(ly0 + 8) * g.y_stride + c * 16 + lx0) = outY1;
                 *(g_u32p)((cpl ? dV : dU) + (long)cy * g.uv_stride + c * 8 + cx0) = outC;
-                if (cy == 7) *(u32 *)(my_line + (cpl ? lV : lU) + LINE_PAD + c * 8 + cx0) = outC;
-                if (cx0 == 4) wl->lcol[16 + cpl * 8 + cy] = (unsigned char)(outC >> 24);
             }
-            if (c == cols - 1 && lane == 63) {
+            if (ly0 == 7) *(u32 *)(my_line + LINE_PAD + c * 16 + lx0) = outY1;          // pixel row 15
+            if (lx0 == 12) {
+                wl->lcol[ly0] = (unsigned char)(outY0 >> 24);
+                wl->lcol[ly0 + 8] = (unsigned char)(outY1 >> 24);
+                tY[TY_AT(ly0, -1)] = (unsigned char)(outY0 >> 24);
+                tY[TY_AT(ly0 + 8, -1)] = (unsigned char)(outY1 >> 24);
+            }
+            if (cy == 7) *(u32 *)(my_line + (cpl ? lV : lU) + LINE_PAD + c * 8 + cx0) = outC;
+            if (cx0 == 4) wl->lcol[16 + cpl * 8 + cy] = (unsigned char)(outC >> 24);
+            if (c == cols - 1 && hl == 31) {
                 // vp8_extend_mb_row (extend.c:160-185): what the next row's last MB sees as above-right
-                // is the last pixel of this line replicated (lane 63 holds pixel row 15, x = 12..15).
-                *(u32 *)(my_line + LINE_PAD + cols * 16) = (outY >> 24) * 0x01010101u;
+                // is the last pixel of this line replicated (hl 31 holds pixel row 15, x = 12..15).
+                *(u32 *)(my_line + LINE_PAD + cols * 16) = (outY1 >> 24) * 0x01010101u;
             }
             wg_publish_lds(&prog[wave], c + 1 == cols ? (k + 1) << 16 : (k << 16) + c + 1, lane);
+        };
+
+        // ---- software pipeline, unrolled by two so that no loaded register is ever copied:
+        // MB descriptors two ahead, coefficients one ahead (always fetched; a skipped MB's are ignored)
+        u32 dA = load_desc(0), dB = cols > 1 ? load_desc(1) : 0u;
+        Coefs qA = load_coefs(0), qB = qA;
+        for (int c0 = 0; c0 < cols; c0 += 2) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int c = c0 + u;
+                if (c < cols) {
+                    if (c + 1 < cols) { if (u) qA = load_coefs(c + 1); else qB = load_coefs(c + 1); }
+                    const u32 d = u ? dB : dA;
+                    process(c, d, u ? qB : qA);
+                    if (c + 2 < cols) { if (u) dB = load_desc(c + 2); else dA = load_desc(c + 2); }
+                }
+            }
         }
     }
 }

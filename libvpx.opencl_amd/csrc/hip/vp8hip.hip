@@ -149,7 +149,7 @@ extern "C" void vp8hip_destroy(vp8hip_ctx *c)
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // per-wave LDS footprints; must match the kernels (WaveLds 2080 B + line slot, LfWaveLds 768 B)
-static size_t recon_lds_bytes(int nw, int aligned_w) { return 1024 + (size_t)nw * (2080 + 2 * aligned_w + 96); }
+static size_t recon_lds_bytes(int nw, int aligned_w) { return 1024 + (size_t)nw * 2 * (2080 + 2 * aligned_w + 96); }   // two frames per wave
 static size_t lf_lds_bytes(int nw) { return 256 + (size_t)nw * 2 * 4096; }   // two frames per wave
 
 extern "C" int vp8hip_configure(vp8hip_ctx *c, int width, int height, int num_fb, int num_slots)
@@ -172,7 +172,7 @@ extern "C" int vp8hip_configure(vp8hip_ctx *c, int width, int height, int num_fb
 
     // waves per workgroup: one wave per MB row in flight; as many as LDS allows, at most 16, and
     // no more than the frame has rows (rounded up to 2, the minimum the line-buffer ring needs)
-    int nw = 16;
+    int nw = 12;       // __launch_bounds__(768) in vp8_recon.hip
     while (nw > 2 && (recon_lds_bytes(nw, g.aligned_w) > (size_t)c->max_lds)) nw -= 2;
     if (recon_lds_bytes(nw, g.aligned_w) > (size_t)c->max_lds)
         return fail(c, -2, "frame width %d needs more LDS than a CU has", width);
@@ -323,7 +323,9 @@ extern "C" int vp8hip_decode(vp8hip_ctx *c, const vp8hip_job *jobs, int njobs, i
     c->stats.lf_waves = c->lf_nw;
     HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
     if (stages & VP8HIP_STAGE_RECON) {
-        hipLaunchKernelGGL(vp8_recon_kernel, dim3(grid), dim3(64 * c->recon_nw), c->recon_lds, c->stream,
+        const int npairs = (njobs + 1) / 2;          // two frames per wave
+        const int rgrid = npairs < c->num_cu * wg_per_cu ? npairs : c->num_cu * wg_per_cu;
+        hipLaunchKernelGGL(vp8_recon_kernel, dim3(rgrid), dim3(64 * c->recon_nw), c->recon_lds, c->stream,
                            (const DevJob *)c->d_jobs, njobs, c->dg);
         HIPCHK(c, hipGetLastError());
     }
