@@ -12,6 +12,7 @@
 #include "vp8_common.hip.h"
 
 extern "C" __global__ void vp8_recon_kernel(const DevJob *jobs, int njobs, DevGeom g);
+extern "C" __global__ void vp8_recon_simt_kernel(const DevJob *jobs, int njobs, DevGeom g, int lgG, int P, int nstrands);
 extern "C" __global__ void vp8_loopfilter_kernel(const DevJob *jobs, int njobs, DevGeom g);
 extern "C" __global__ void vp8_extend_kernel(const DevJob *jobs, int njobs, DevGeom g);
 
@@ -323,10 +324,30 @@ extern "C" int vp8hip_decode(vp8hip_ctx *c, const vp8hip_job *jobs, int njobs, i
     c->stats.lf_waves = c->lf_nw;
     HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
     if (stages & VP8HIP_STAGE_RECON) {
+        const char *mode = getenv("VP8HIP_RECON");
+        if (mode && !strcmp(mode, "simt")) {
+            // one MB row per lane: G lanes per strand of frames, row period P >= max(cols, 2G+2).  The
+            // largest G that costs no idle steps (cols >= 2G+2), widened while the launch would leave
+            // SIMDs without a wave.
+            const int cols = c->dg.mb_cols;
+            int lgG = 1;
+            while (lgG < 6 && 2 * (2 << lgG) + 2 <= cols) lgG++;
+            while (lgG < 6 && (njobs + (64 >> lgG) - 1) / (64 >> lgG) < c->num_cu * 8) lgG++;
+            if (const char *e = getenv("VP8HIP_SIMT_LGG")) { int v = atoi(e); if (v >= 1 && v <= 6) lgG = v; }
+            const int G = 1 << lgG, spw = 64 >> lgG;
+            const int P = cols > 2 * G + 2 ? cols : 2 * G + 2;
+            int nwaves = (njobs + spw - 1) / spw;
+            int maxw = c->num_cu * 8;
+            if (const char *e = getenv("VP8HIP_SIMT_WAVES")) { int v = atoi(e); if (v >= 1) maxw = v; }
+            if (nwaves > maxw) nwaves = maxw;
+            hipLaunchKernelGGL(vp8_recon_simt_kernel, dim3(nwaves), dim3(64), 0, c->stream, (const DevJob *)c->d_jobs, njobs,
+                               c->dg, lgG, P, nwaves * spw);
+        } else {
         const int npairs = (njobs + 1) / 2;          // two frames per wave
         const int rgrid = npairs < c->num_cu * wg_per_cu ? npairs : c->num_cu * wg_per_cu;
         hipLaunchKernelGGL(vp8_recon_kernel, dim3(rgrid), dim3(64 * c->recon_nw), c->recon_lds, c->stream,
                            (const DevJob *)c->d_jobs, njobs, c->dg);
+        }
         HIPCHK(c, hipGetLastError());
     }
     HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
