@@ -26,6 +26,10 @@ struct DevGeom {
 
 #define WAVE 64
 
+// Macroblock-tiled scratch frame of the one-MB-row-per-lane pipeline: tile (r, c) at (r * mb_cols + c) *
+// VP8_TILE_BYTES = 16 luma rows x 16 B | 8 U rows x 8 B | 8 V rows x 8 B = three 128-byte lines.
+#define VP8_TILE_BYTES 384
+
 // Pointers that come out of a DevJob (i.e. out of memory) are generic to the compiler, which then
 // emits FLAT loads/stores: those count on lgkmcnt as well as vmcnt, so every LDS wait would also
 // wait for the global prefetches and the frame write-out.  Casting to the global address space

@@ -1,0 +1,479 @@
+// VP8 in-loop deblocking filter, "one macroblock row per LANE" formulation for gfx950.
+//
+// Same job as vp8_loopfilter.hip: vp8_loop_filter_frame (vp8/common/loopfilter.c:203-316) with the
+// filters of vp8/common/loopfilter_filters.c (normal: vp8_loop_filter_c / vp8_mbloop_filter_c behind
+// vp8_loop_filter_{mbv,bv,mbh,bh}_c; simple: vp8_loop_filter_simple_*), level / limit derivation of
+// loopfilter.c:24-201.  Organised like vp8_recon_simt.hip, for the same reason (the path is bound by
+// VALU issue, not by memory):
+//
+//   * lane p of a wave owns macroblock rows p, p+G, p+2G, ... of a strand of frames and filters one
+//     whole macroblock per step, two macroblocks behind lane p-1; the raster order of the reference
+//     (MB (r-1,c+1) has touched the three pixel columns left of it before MB (r,c) filters its top edge)
+//     holds by construction;
+//   * the filter arithmetic runs on TWO pixel lines per instruction as packed 16-bit lanes (v_pk_*):
+//     rows (y, y+1) for the vertical edges, columns (x, x+1) for the horizontal ones; the signed-char
+//     saturations of the reference become packed min/max;
+//   * the macroblock (plus the four columns left of it and the four rows above it) sits in a per-lane,
+//     lane-interleaved LDS tile, so both passes are short rolled loops over conflict-free ds_read_b32;
+//   * pixels another macroblock will still modify are not written early: the four right-hand columns
+//     wait in registers for the next macroblock's left edge, the four bottom rows travel to the lane
+//     below by DPP wave shift and are written by it.  The first lane of a strand reads them back from
+//     the frame (L2-coherent loads); the last lane of a strand and the last row of a frame write them.
+//     Every frame byte is written once, as aligned 16-byte (luma) / 8-byte (chroma) row pieces.
+#include "vp8_common.hip.h"
+#include <stddef.h>
+
+namespace {
+
+typedef unsigned int u32;
+typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+typedef u32 u32x2 __attribute__((ext_vector_type(2)));
+typedef GLOBAL_AS const u32x4 *g_cu32x4p;
+typedef GLOBAL_AS const u32x2 *g_cu32x2p;
+typedef GLOBAL_AS u32x4 *g_u32x4p;
+typedef GLOBAL_AS u32x2 *g_u32x2p;
+typedef short v2s __attribute__((ext_vector_type(2)));     // the same pixel position of two lines
+
+__device__ __forceinline__ u32 perm(u32 hi, u32 lo, u32 sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
+__device__ __forceinline__ u32 from_lane_above(u32 v)
+{
+    return (u32)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+}
+__device__ __forceinline__ u32 load_l2(const unsigned char *p)
+{
+    return __hip_atomic_load((const u32 *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long load_l2_64(const unsigned char *p)
+{
+    return __hip_atomic_load((const unsigned long long *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ v2s as_v2s(u32 v) { return __builtin_bit_cast(v2s, v); }
+__device__ __forceinline__ u32 as_u32(v2s v) { return __builtin_bit_cast(u32, v); }
+__device__ __forceinline__ v2s mk(int v) { return (v2s){ (short)v, (short)v }; }
+__device__ __forceinline__ v2s vmax(v2s a, v2s b) { return __builtin_elementwise_max(a, b); }
+__device__ __forceinline__ v2s vmin(v2s a, v2s b) { return __builtin_elementwise_min(a, b); }
+__device__ __forceinline__ v2s ad(v2s a, v2s b) { const v2s d = a - b; return vmax(d, -d); }      // |a - b|
+// x > lim ? -1 : 0 per half.  The empty asm hides the subtraction from LLVM, which would otherwise turn
+// the shift into a compare-and-select that gfx950 can only do one half at a time.
+__device__ __forceinline__ v2s gt(v2s x, v2s lim)
+{
+    v2s d = lim - x;
+    asm("" : "+v"(d));
+    return d >> 15;
+}
+__device__ __forceinline__ v2s sc(v2s x) { return vmax(vmin(x, mk(127)), mk(-128)); }           // vp8_signed_char_clamp
+
+struct Lim { v2s mblim, blim, lim, thr; };
+
+// The filters below are branch-free: `gate` (-1 / 0 per lane) switches an edge off by clearing its filter
+// mask, which makes every update the identity.  Straight-line code lets the scheduler interleave the
+// independent pixel-line pairs, which is what hides the one wait state gfx950 wants between dependent
+// packed-math instructions.
+
+// vp8_filter_mask + vp8_hevmask (loopfilter_filters.c:27-49) for p[0..7] = p3 p2 p1 p0 q0 q1 q2 q3
+__device__ __forceinline__ void masks(const v2s p[8], v2s lim, v2s elim, v2s thr, v2s gate, v2s &mask, v2s &hev)
+{
+    const v2s d10 = ad(p[2], p[3]), dq = ad(p[5], p[4]);
+    v2s m = vmax(vmax(ad(p[0], p[1]), ad(p[1], p[2])), vmax(d10, dq));
+    m = vmax(m, vmax(ad(p[6], p[5]), ad(p[7], p[6])));
+    const v2s e = (ad(p[3], p[4]) << 1) + (ad(p[2], p[5]) >> 1);
+    mask = ~(gt(m, lim) | gt(e, elim)) & gate;
+    hev = gt(vmax(d10, dq), thr);
+}
+
+// vp8_loop_filter_c (loopfilter_filters.c:51-95): inner edges, modifies p1 p0 q0 q1
+__device__ __forceinline__ void lf_inner(v2s p[8], const Lim &L, v2s gate)
+{
+    v2s mask, hev;
+    masks(p, L.lim, L.blim, L.thr, gate, mask, hev);
+    v2s ps1 = p[2] - 128, ps0 = p[3] - 128, qs0 = p[4] - 128, qs1 = p[5] - 128;
+    v2s f = sc(ps1 - qs1) & hev;
+    f = sc(f + (qs0 - ps0) * 3) & mask;
+    const v2s f1 = vmin(f + 4, mk(127)) >> 3, f2 = vmin(f + 3, mk(127)) >> 3;
+    qs0 = sc(qs0 - f1); ps0 = sc(ps0 + f2);
+    f = ((f1 + 1) >> 1) & ~hev;
+    qs1 = sc(qs1 - f); ps1 = sc(ps1 + f);
+    p[2] = ps1 + 128; p[3] = ps0 + 128; p[4] = qs0 + 128; p[5] = qs1 + 128;
+}
+
+// vp8_mbloop_filter_c (loopfilter_filters.c:161-214): macroblock edges, modifies p2 p1 p0 q0 q1 q2
+__device__ __forceinline__ void lf_mbedge(v2s p[8], const Lim &L, v2s gate)
+{
+    v2s mask, hev;
+    masks(p, L.lim, L.mblim, L.thr, gate, mask, hev);
+    v2s ps2 = p[1] - 128, ps1 = p[2] - 128, ps0 = p[3] - 128, qs0 = p[4] - 128, qs1 = p[5] - 128, qs2 = p[6] - 128;
+    v2s f = sc(ps1 - qs1);
+    f = sc(f + (qs0 - ps0) * 3) & mask;
+    v2s f2 = f & hev;
+    const v2s f1 = vmin(f2 + 4, mk(127)) >> 3;
+    f2 = vmin(f2 + 3, mk(127)) >> 3;
+    qs0 = sc(qs0 - f1); ps0 = sc(ps0 + f2);
+    f = f & ~hev;
+    v2s u = (f * 27 + 63) >> 7;
+    qs0 = sc(qs0 - u); ps0 = sc(ps0 + u);
+    u = (f * 18 + 63) >> 7;
+    qs1 = sc(qs1 - u); ps1 = sc(ps1 + u);
+    u = (f * 9 + 63) >> 7;
+    qs2 = sc(qs2 - u); ps2 = sc(ps2 + u);
+    p[1] = ps2 + 128; p[2] = ps1 + 128; p[3] = ps0 + 128; p[4] = qs0 + 128; p[5] = qs1 + 128; p[6] = qs2 + 128;
+}
+
+// vp8_loop_filter_simple_horizontal/vertical_edge_c (loopfilter_filters.c:292-355): modifies p0 q0
+__device__ __forceinline__ void lf_simple(v2s p[8], v2s elim, v2s gate)
+{
+    const v2s mask = ~gt((ad(p[3], p[4]) << 1) + (ad(p[2], p[5]) >> 1), elim) & gate;
+    v2s ps1 = p[2] - 128, ps0 = p[3] - 128, qs0 = p[4] - 128, qs1 = p[5] - 128;
+    v2s f = sc(ps1 - qs1);
+    f = sc(f + (qs0 - ps0) * 3) & mask;
+    const v2s f1 = vmin(f + 4, mk(127)) >> 3, f2 = vmin(f + 3, mk(127)) >> 3;
+    p[4] = sc(qs0 - f1) + 128; p[3] = sc(ps0 + f2) + 128;
+}
+
+// which filters the lanes of the wave need (wave-uniform) and each lane's gates
+struct Gates { v2s mb, inner, mb_s, inner_s; bool any_normal, any_simple; };
+
+// All edges of two pixel lines: a[0..4*W4+3] = positions -4 .. 4*W4-1 across the macroblock.  Order and
+// gating as vp8_loop_filter_frame (loopfilter.c:265-299): the MB edge at 0 (if there is a neighbour),
+// then the inner edges at 4, 8, 12 (if !skip_lf).
+template <int W4>
+__device__ __forceinline__ void filter_lines(v2s *a, const Gates &G, const Lim &L)
+{
+    if (G.any_normal) {
+        lf_mbedge(a, L, G.mb);
+#pragma unroll
+        for (int e = 1; e < W4; e++) lf_inner(a + 4 * e, L, G.inner);
+    }
+    if (G.any_simple) {
+        lf_simple(a, L.mblim, G.mb_s);
+#pragma unroll
+        for (int e = 1; e < W4; e++) lf_simple(a + 4 * e, L.blim, G.inner_s);
+    }
+}
+// the same for two independent sets of lines at once (more instruction-level parallelism)
+template <int W4>
+__device__ __forceinline__ void filter_lines2(v2s *a, v2s *b, const Gates &G, const Lim &L)
+{
+    if (G.any_normal) {
+        lf_mbedge(a, L, G.mb); lf_mbedge(b, L, G.mb);
+#pragma unroll
+        for (int e = 1; e < W4; e++) { lf_inner(a + 4 * e, L, G.inner); lf_inner(b + 4 * e, L, G.inner); }
+    }
+    if (G.any_simple) {
+        lf_simple(a, L.mblim, G.mb_s); lf_simple(b, L.mblim, G.mb_s);
+#pragma unroll
+        for (int e = 1; e < W4; e++) { lf_simple(a + 4 * e, L.blim, G.inner_s); lf_simple(b + 4 * e, L.blim, G.inner_s); }
+    }
+}
+
+template <int NX>
+__device__ __forceinline__ void unpack_rows(const u32 *ra, const u32 *rb, v2s *a)
+{
+#pragma unroll
+    for (int x = 0; x < NX; x++) {
+        const u32 A = ra[x * 64], B = rb[x * 64];
+        a[4 * x + 0] = as_v2s(perm(B, A, 0x0c040c00u)); a[4 * x + 1] = as_v2s(perm(B, A, 0x0c050c01u));
+        a[4 * x + 2] = as_v2s(perm(B, A, 0x0c060c02u)); a[4 * x + 3] = as_v2s(perm(B, A, 0x0c070c03u));
+    }
+}
+template <int NX>
+__device__ __forceinline__ void pack_rows(u32 *ra, u32 *rb, const v2s *a)
+{
+#pragma unroll
+    for (int x = 0; x < NX; x++) {
+        const u32 p01 = as_u32(a[4 * x]), p11 = as_u32(a[4 * x + 1]), p21 = as_u32(a[4 * x + 2]), p31 = as_u32(a[4 * x + 3]);
+        ra[x * 64] = perm(perm(p31, p21, 0x0c0c0400u), perm(p11, p01, 0x0c0c0400u), 0x05040100u);
+        rb[x * 64] = perm(perm(p31, p21, 0x0c0c0602u), perm(p11, p01, 0x0c0c0602u), 0x05040100u);
+    }
+}
+
+// One plane of one macroblock in the lane's LDS tile T[row * NX + xd][lane], NX = W4 + 1 dwords per row:
+// row = y + 4 (y = -4 .. H-1), xd = 0 the four pixels left of the macroblock, xd = 1 .. W4 its own.
+// gv / gh: gates of the vertical-edge and of the horizontal-edge pass.
+template <int W4, int H>
+__device__ __forceinline__ void filter_plane(u32 *T, const Gates &gv, const Gates &gh, const Lim &L)
+{
+    constexpr int NX = W4 + 1;
+    // ---- vertical edges: rows (y, y+1) packed, all positions x = -4 .. 4*W4-1 in registers; two row pairs a time
+#pragma unroll 1
+    for (int rp = 0; rp < H / 4; rp++) {
+        u32 *r0 = T + (4 + 4 * rp) * NX * 64, *r1 = r0 + NX * 64, *r2 = r1 + NX * 64, *r3 = r2 + NX * 64;
+        v2s a[4 * NX], b[4 * NX];
+        unpack_rows<NX>(r0, r1, a);
+        unpack_rows<NX>(r2, r3, b);
+        filter_lines2<W4>(a, b, gv, L);
+        pack_rows<NX>(r0, r1, a);
+        pack_rows<NX>(r2, r3, b);
+    }
+    // ---- horizontal edges: columns (x, x+1) packed, rows y = -4 .. H-1 of the two column pairs in registers
+#pragma unroll 1
+    for (int xd = 1; xd <= W4; xd++) {
+        u32 *col = T + xd * 64;
+        v2s lo[H + 4], hi[H + 4];
+#pragma unroll
+        for (int y = 0; y < H + 4; y++) {
+            const u32 D = col[y * NX * 64];
+            lo[y] = as_v2s(perm(D, D, 0x0c010c00u));
+            hi[y] = as_v2s(perm(D, D, 0x0c030c02u));
+        }
+        filter_lines2<H / 4>(lo, hi, gh, L);
+#pragma unroll
+        for (int y = 1; y < H + 4; y++) col[y * NX * 64] = perm(as_u32(hi[y]), as_u32(lo[y]), 0x06040200u);
+    }
+}
+
+// vp8_loop_filter_frame_init (loopfilter.c:117-201) for one macroblock
+__device__ __forceinline__ int mb_level(const vp8ir_frame_hdr &h, int seg, int ref, int y_mode)
+{
+    int base = h.filter_level;
+    if (h.segmentation_enabled) {
+        if (h.mb_segment_abs_delta) base = h.segment_lf[seg];
+        else { base += h.segment_lf[seg]; base = base < 0 ? 0 : (base > 63 ? 63 : base); }
+    }
+    if (!h.mode_ref_lf_delta_enabled) return base & 0xff;
+    int v = base + h.ref_lf_deltas[ref];
+    if (ref == VP8IR_INTRA_FRAME) {
+        if (y_mode == VP8IR_B_PRED) v += h.mode_lf_deltas[0];
+    } else {
+        // mode_lf_lut (loopfilter.c:52-63): NEAREST, NEAR, NEW -> 2, ZERO -> 1, SPLIT -> 3
+        const int m = y_mode == VP8IR_ZEROMV ? 1 : (y_mode == VP8IR_SPLITMV ? 3 : 2);
+        v += h.mode_lf_deltas[m];
+    }
+    return v < 0 ? 0 : (v > 63 ? 63 : v);
+}
+
+// vp8_loop_filter_update_sharpness + hev threshold LUT (loopfilter.c:24-96)
+__device__ __forceinline__ Lim mb_limits(int sharp, int level, int frame_type)
+{
+    int ilimit = level >> (sharp > 0);
+    ilimit >>= (sharp > 4);
+    if (sharp > 0 && ilimit > 9 - sharp) ilimit = 9 - sharp;
+    if (ilimit < 1) ilimit = 1;
+    int thr;
+    if (level >= 40) thr = frame_type == 0 ? 2 : 3;
+    else if (level >= 20) thr = frame_type == 0 ? 1 : 2;
+    else if (level >= 15) thr = 1;
+    else thr = 0;
+    Lim L;
+    L.lim = mk(ilimit); L.blim = mk((2 * level + ilimit) & 0xff); L.mblim = mk((2 * (level + 2) + ilimit) & 0xff);
+    L.thr = mk(thr);
+    return L;
+}
+
+} // namespace
+
+// grid = waves (one wave per block); lgG, P, nstrands as in vp8_recon_simt_kernel.  Works in place on the
+// jobs' macroblock-tiled scratch frames (DevJob::ref[0], see VP8_TILE_BYTES): a macroblock is three 128-byte
+// lines -- luma rows 0..7, luma rows 8..15, U+V -- and every line is written exactly once, whole, by the lane
+// that knows its final content:
+//   line 0 of MB (r,c)    by its own lane, one step later (after MB (r,c+1) revisited its last 4 columns);
+//   line 1 and the chroma line by the lane below (which filters their last three rows), or by the own lane
+//   when nobody is below (last row of the frame) or the lane below reads them back from memory (the first
+//   lane of a strand follows the last one).
+extern "C" __global__ void __launch_bounds__(64)
+vp8_loopfilter_simt_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g, int lgG, int P, int nstrands)
+{
+    __shared__ u32 tile[100 * 64];              // luma: 20 rows x 5 dwords; chroma reuses it: 12 rows x 3 dwords
+    const int lane = threadIdx.x;
+    const int G = 1 << lgG;
+    const int pos = lane & (G - 1);
+    const int spw = 64 >> lgG;
+    const int strand = blockIdx.x * spw + (lane >> lgG);
+    const int cols = g.mb_cols, rows = g.mb_rows;
+    const int myjobs = strand < njobs ? (njobs - strand + nstrands - 1) / nstrands : 0;
+    const int Vmax = myjobs * rows;
+    const int wavejobs = (njobs - (int)blockIdx.x * spw + nstrands - 1) / nstrands;
+    const int T = ((wavejobs * rows + G - 1) >> lgG) * P + 2 * (G - 1);
+    const long rowbytes = (long)cols * VP8_TILE_BYTES;
+    u32 *const TL = tile + lane;
+
+    // ---- per-lane row state
+    g_cu32p mbp = nullptr;
+    g_u8p trow = nullptr;                        // tile (r, 0)
+    const DevJob *job = jobs;
+    int r = 0;
+    bool lf_on = false, simple = false;
+    // the previous macroblock of the row: its first 12 (chroma: 4) pixel columns, final, and its last 4,
+    // which the current macroblock's left edge may still change
+    u32 pbY[16][3], sY[16], pbU[8], sU[8], pbV[8], sV[8];
+    // what the lane below asks for: luma rows 8..15 and the chroma rows of the macroblock finished two steps ago
+    u32 hY[8][4], hU[8][2], hV[8][2];
+#pragma unroll
+    for (int y = 0; y < 16; y++) { pbY[y][0] = pbY[y][1] = pbY[y][2] = sY[y] = 0; }
+#pragma unroll
+    for (int y = 0; y < 8; y++) {
+        pbU[y] = sU[y] = pbV[y] = sV[y] = 0;
+        hY[y][0] = hY[y][1] = hY[y][2] = hY[y][3] = hU[y][0] = hU[y][1] = hV[y][0] = hV[y][1] = 0;
+    }
+
+    int c = -2 * pos, V = pos;
+#pragma unroll 1
+    for (int t = 0; t < T; ++t, ++c) {
+        if (c == P) { c = 0; V += G; }
+        // rows 8..15 (luma) / all rows (chroma) of the macroblock above, from the lane above
+        u32 tY[8][4], tU[8][2], tV[8][2];
+#pragma unroll
+        for (int y = 0; y < 8; y++) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) tY[y][i] = from_lane_above(hY[y][i]);
+            tU[y][0] = from_lane_above(hU[y][0]); tU[y][1] = from_lane_above(hU[y][1]);
+            tV[y][0] = from_lane_above(hV[y][0]); tV[y][1] = from_lane_above(hV[y][1]);
+        }
+
+        // What the lane below will fetch at the start of the next step: the macroblock held from the previous
+        // step.  Its last four columns are still provisional if this step filters a left edge against them
+        // (they are fixed up below, after the vertical-edge pass); otherwise -- end of a row, idle step --
+        // they are final as they stand.
+#pragma unroll
+        for (int y = 0; y < 8; y++) {
+            hY[y][0] = pbY[8 + y][0]; hY[y][1] = pbY[8 + y][1]; hY[y][2] = pbY[8 + y][2]; hY[y][3] = sY[8 + y];
+            hU[y][0] = pbU[y]; hU[y][1] = sU[y]; hV[y][0] = pbV[y]; hV[y][1] = sV[y];
+        }
+
+        const bool act = c >= 0 && c < cols && V < Vmax;
+        if (act) {
+            if (c == 0) {
+                const int j = V / rows;
+                r = V - j * rows;
+                job = jobs + (strand + j * nstrands);
+                const vp8ir_frame_hdr &h = job->hdr;
+                lf_on = h.filter_level != 0;
+                simple = h.filter_type == 1;
+                mbp = (g_cu32p)(job->mbs + (long)r * cols);
+                trow = (g_u8p)(const_cast<uint8_t *>(job->ref[0]) + (long)r * rowbytes);
+            }
+            if (lf_on) {
+            const vp8ir_frame_hdr &h = job->hdr;
+            const u32 w0 = mbp[0], w1 = mbp[1];
+            const int y_mode = w0 & 0xff, ref_frame = (w0 >> 16) & 0xff;
+            const u32 flags = w0 >> 24;
+            const int level = mb_level(h, w1 & 3, ref_frame & 3, y_mode);
+            const Lim L = mb_limits(h.sharpness_level, level, h.frame_type);
+            const bool on = level != 0;
+            const bool skip_lf = y_mode != VP8IR_B_PRED && y_mode != VP8IR_SPLITMV && (flags & VP8IR_MB_SKIP);
+            const bool mbv = on && c > 0, inner = on && !skip_lf, mbh = on && r > 0;
+#ifdef VP8_LF_NOFILTER    // measurement aid: data movement only
+            const bool any_normal = false, any_simple = false;
+#else
+            const bool any_normal = __builtin_amdgcn_ballot_w64(on && !simple) != 0;
+            const bool any_simple = __builtin_amdgcn_ballot_w64(on && simple) != 0;
+#endif
+            auto gate = [](bool b) { return mk(b ? -1 : 0); };
+            const Gates gvY = { gate(mbv && !simple), gate(inner && !simple), gate(mbv && simple), gate(inner && simple), any_normal, any_simple };
+            const Gates ghY = { gate(mbh && !simple), gate(inner && !simple), gate(mbh && simple), gate(inner && simple), any_normal, any_simple };
+            // the simple filter leaves chroma alone (loopfilter.c:283-299)
+            const Gates gvC = { gvY.mb, gvY.inner, mk(0), mk(0), any_normal, false };
+            const Gates ghC = { ghY.mb, ghY.inner, mk(0), mk(0), any_normal, false };
+            const bool last_col = c == cols - 1;
+            // lines another lane would otherwise finish are written here when nobody below takes them over
+            const bool write_bottom = pos == G - 1 || r == rows - 1;
+            const bool readback = r > 0 && pos == 0;
+
+            g_u8p tp = trow + (long)c * VP8_TILE_BYTES;           // this macroblock's tile
+            u32x4 inY[16], inU[4], inV[4];
+#pragma unroll
+            for (int y = 0; y < 16; y++) inY[y] = *(g_cu32x4p)(tp + 16 * y);
+#pragma unroll
+            for (int y = 0; y < 4; y++) { inU[y] = *(g_cu32x4p)(tp + 256 + 16 * y); inV[y] = *(g_cu32x4p)(tp + 320 + 16 * y); }
+            if (readback) {
+                const unsigned char *ta = (const unsigned char *)tp - rowbytes;
+#pragma unroll
+                for (int y = 0; y < 8; y++) {
+                    const unsigned long long a = load_l2_64(ta + 128 + 16 * y), b = load_l2_64(ta + 128 + 16 * y + 8);
+                    tY[y][0] = (u32)a; tY[y][1] = (u32)(a >> 32); tY[y][2] = (u32)b; tY[y][3] = (u32)(b >> 32);
+                    const unsigned long long u = load_l2_64(ta + 256 + 8 * y), v = load_l2_64(ta + 320 + 8 * y);
+                    tU[y][0] = (u32)u; tU[y][1] = (u32)(u >> 32); tV[y][0] = (u32)v; tV[y][1] = (u32)(v >> 32);
+                }
+            }
+
+            // =============================== luma ===============================
+#pragma unroll
+            for (int y = 0; y < 16; y++) {
+                u32 *row = TL + (4 + y) * 5 * 64;
+                row[0] = sY[y]; row[64] = inY[y].x; row[128] = inY[y].y; row[192] = inY[y].z; row[256] = inY[y].w;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                u32 *row = TL + j * 5 * 64;
+#pragma unroll
+                for (int i = 0; i < 4; i++) row[(1 + i) * 64] = tY[4 + j][i];
+            }
+            filter_plane<4, 16>(TL, gvY, ghY, L);
+            // ---- the macroblock to the left is final now: its 12 held columns + the 4 just revisited
+            if (c > 0) {
+#pragma unroll
+                for (int y = 0; y < 16; y++) {
+                    const u32 s = TL[(4 + y) * 5 * 64];
+                    if (y < 8 || write_bottom) *(g_u32x4p)(tp - VP8_TILE_BYTES + 16 * y) = (u32x4){ pbY[y][0], pbY[y][1], pbY[y][2], s };
+                    if (y >= 8) hY[y - 8][3] = s;
+                }
+            }
+            // ---- line 1 of the macroblock above: rows 8..12 as received, rows 13..15 filtered
+            if (r > 0) {
+#pragma unroll
+                for (int y = 0; y < 5; y++)
+                    *(g_u32x4p)(tp - rowbytes + 128 + 16 * y) = (u32x4){ tY[y][0], tY[y][1], tY[y][2], tY[y][3] };
+#pragma unroll
+                for (int j = 1; j < 4; j++) {
+                    const u32 *row = TL + j * 5 * 64;
+                    *(g_u32x4p)(tp - rowbytes + 128 + 16 * (4 + j)) = (u32x4){ row[64], row[128], row[192], row[256] };
+                }
+            }
+            // ---- this macroblock: hold it, or finish it at the end of the row
+#pragma unroll
+            for (int y = 0; y < 16; y++) {
+                const u32 *row = TL + (4 + y) * 5 * 64;
+                const u32 d0 = row[64], d1 = row[128], d2 = row[192], d3 = row[256];
+                pbY[y][0] = d0; pbY[y][1] = d1; pbY[y][2] = d2; sY[y] = d3;
+                if (last_col && (y < 8 || write_bottom)) *(g_u32x4p)(tp + 16 * y) = (u32x4){ d0, d1, d2, d3 };
+            }
+            // =============================== chroma ===============================
+#pragma unroll
+            for (int pl = 0; pl < 2; pl++) {
+                g_u8p tc = tp + (pl ? 320 : 256);
+                u32 (&pb)[8] = pl ? pbV : pbU;
+                u32 (&sC)[8] = pl ? sV : sU;
+                u32 (&tC)[8][2] = pl ? tV : tU;
+                u32 (&hC)[8][2] = pl ? hV : hU;
+                const u32x4 (&in)[4] = pl ? inV : inU;
+#pragma unroll
+                for (int y = 0; y < 8; y++) {
+                    u32 *row = TL + (4 + y) * 3 * 64;
+                    row[0] = sC[y];
+                    row[64] = (y & 1) ? in[y >> 1].z : in[y >> 1].x; row[128] = (y & 1) ? in[y >> 1].w : in[y >> 1].y;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    u32 *row = TL + j * 3 * 64;
+                    row[64] = tC[4 + j][0]; row[128] = tC[4 + j][1];
+                }
+                filter_plane<2, 8>(TL, gvC, ghC, L);
+                if (c > 0) {
+#pragma unroll
+                    for (int y = 0; y < 8; y++) {
+                        const u32 s = TL[(4 + y) * 3 * 64];
+                        if (write_bottom) *(g_u32x2p)(tc - VP8_TILE_BYTES + 8 * y) = (u32x2){ pb[y], s };
+                        hC[y][1] = s;
+                    }
+                }
+                if (r > 0) {
+#pragma unroll
+                    for (int y = 0; y < 5; y++) *(g_u32x2p)(tc - rowbytes + 8 * y) = (u32x2){ tC[y][0], tC[y][1] };
+#pragma unroll
+                    for (int j = 1; j < 4; j++) {
+                        const u32 *row = TL + j * 3 * 64;
+                        *(g_u32x2p)(tc - rowbytes + 8 * (4 + j)) = (u32x2){ row[64], row[128] };
+                    }
+                }
+#pragma unroll
+                for (int y = 0; y < 8; y++) {
+                    const u32 *row = TL + (4 + y) * 3 * 64;
+                    const u32 d0 = row[64], d1 = row[128];
+                    pb[y] = d0; sC[y] = d1;
+                    if (last_col && write_bottom) *(g_u32x2p)(tc + 8 * y) = (u32x2){ d0, d1 };
+                }
+            }
+            }
+            mbp += 16;
+        }
+    }
+}

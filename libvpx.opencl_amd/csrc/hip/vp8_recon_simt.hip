@@ -36,6 +36,8 @@ typedef u32 u32x4 __attribute__((ext_vector_type(4)));
 typedef u32 u32x2 __attribute__((ext_vector_type(2)));
 typedef GLOBAL_AS const u32x4 *g_cu32x4p;
 typedef GLOBAL_AS const u32x2 *g_cu32x2p;
+typedef GLOBAL_AS u32x4 *g_u32x4p;
+typedef GLOBAL_AS u32x2 *g_u32x2p;
 
 __device__ __forceinline__ u32 perm(u32 hi, u32 lo, u32 sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
 __device__ __forceinline__ u32 alignb(u32 hi, u32 lo, u32 sh) { return __builtin_amdgcn_alignbyte(hi, lo, sh); }
@@ -315,8 +317,11 @@ __device__ __forceinline__ void segment_dequant(const vp8ir_frame_hdr &h, int se
 
 // grid = waves (one wave per block); lgG = log2(lanes per strand); P = steps per row period, >= max(cols, 2G+2);
 // nstrands = total strands of the launch: strand q reconstructs jobs q, q+nstrands, ...
+// tiled != 0: the frame goes to the job's macroblock-tiled scratch (DevJob::ref[0], VP8_TILE_BYTES per MB:
+// 16 luma rows of 16 B, 8 U rows of 8 B, 8 V rows of 8 B) instead of the raster frame buffer, so that every
+// lane writes whole 128-byte lines; vp8_detile_kernel converts after the loop filter.
 extern "C" __global__ void __launch_bounds__(64)
-vp8_recon_simt_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g, int lgG, int P, int nstrands)
+vp8_recon_simt_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g, int lgG, int P, int nstrands, int tiled)
 {
     __shared__ u32 predlds[16 * 64];            // inter prediction of the current group: [block*4+row][lane]
     const int lane = threadIdx.x;
@@ -325,6 +330,11 @@ vp8_recon_simt_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g, int
     const int spw = 64 >> lgG;
     const int strand = blockIdx.x * spw + (lane >> lgG);
     const int cols = g.mb_cols, rows = g.mb_rows;
+    // byte steps of the destination: between pixel rows, and between horizontally adjacent macroblocks
+    const long ysY = tiled ? 16 : g.y_stride, ysC = tiled ? 8 : g.uv_stride;
+    const long mbY = tiled ? VP8_TILE_BYTES : 16, mbC = tiled ? VP8_TILE_BYTES : 8;
+    const long upY = tiled ? (long)cols * VP8_TILE_BYTES - 15 * 16 : g.y_stride;     // from row 0 of an MB back to row 15 of the MB above
+    const long upC = tiled ? (long)cols * VP8_TILE_BYTES - 7 * 8 : g.uv_stride;
     const int myjobs = strand < njobs ? (njobs - strand + nstrands - 1) / nstrands : 0;
     const int Vmax = myjobs * rows;
     const int wavejobs = (njobs - (int)blockIdx.x * spw + nstrands - 1) / nstrands;     // first strand: the most jobs
@@ -345,6 +355,15 @@ vp8_recon_simt_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g, int
     // bottom lines of the macroblocks finished one and two steps ago (what the lane below asks for)
     u32 h1Y[4] = { 0, 0, 0, 0 }, h1U[2] = { 0, 0 }, h1V[2] = { 0, 0 };
     u32 h2Y[4] = { 0, 0, 0, 0 }, h2U[2] = { 0, 0 }, h2V[2] = { 0, 0 };
+
+    // software pipeline: the descriptor, the Y2 block and the first coefficient group of the NEXT macroblock
+    // of the row are fetched while the current one is being finished; inside a macroblock every group of
+    // four blocks is fetched one group ahead (`nxt`) and becomes `cur` when its turn comes.
+    u32 pf_w0 = 0, pf_w1 = 0;
+    u32x4 pf_bm = { 0, 0, 0, 0 }, pf_y2a = { 0, 0, 0, 0 }, pf_y2b = { 0, 0, 0, 0 };
+    u32x4 cur[8], nxt[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) cur[i] = nxt[i] = (u32x4){ 0, 0, 0, 0 };
 
     int c = -2 * pos, V = pos;
 #pragma unroll 1
@@ -378,17 +397,27 @@ vp8_recon_simt_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g, int
                 mbp = (g_cu32p)(job->mbs + (long)r * cols);
                 cfp = (g_cs16p)(job->coef + (long)r * cols * VP8IR_COEF_PER_MB);
                 mvp = (g_cu32p)(job->mvs + (long)r * cols * 16);
-                uint8_t *dst = job->dst;
-                dY = (g_u8p)(dst + g.y_off + (long)r * 16 * g.y_stride);
-                dU = (g_u8p)(dst + g.u_off + (long)r * 8 * g.uv_stride);
-                dV = (g_u8p)(dst + g.v_off + (long)r * 8 * g.uv_stride);
+                if (tiled) {
+                    dY = (g_u8p)(const_cast<uint8_t *>(job->ref[0]) + (long)r * cols * VP8_TILE_BYTES);   // tile (r, 0)
+                    dU = dY + 256; dV = dY + 320;
+                } else {
+                    uint8_t *dst = job->dst;
+                    dY = (g_u8p)(dst + g.y_off + (long)r * 16 * g.y_stride);
+                    dU = (g_u8p)(dst + g.u_off + (long)r * 8 * g.uv_stride);
+                    dV = (g_u8p)(dst + g.v_off + (long)r * 8 * g.uv_stride);
+                }
                 lY[0] = lY[1] = lY[2] = lY[3] = 0x81818181u;    // left border 129 (setupintrarecon.c:15-32)
                 lU[0] = lU[1] = lV[0] = lV[1] = 0x81818181u;
+                // nothing was prefetched for the first macroblock of a row
+                pf_w0 = mbp[0]; pf_w1 = mbp[1]; pf_bm = *(g_cu32x4p)(mbp + 10);
+                pf_y2a = *(g_cu32x4p)(cfp + 384); pf_y2b = *(g_cu32x4p)(cfp + 392);
+#pragma unroll
+                for (int i = 0; i < 8; i++) cur[i] = *(g_cu32x4p)(cfp + i * 8);
             }
             const bool top = r == 0;
             // ---- macroblock descriptor
-            const u32 w0 = mbp[0], w1 = mbp[1];
-            const u32x4 bm = *(g_cu32x4p)(mbp + 10);
+            const u32 w0 = pf_w0, w1 = pf_w1;
+            const u32x4 bm = pf_bm;
             const int y_mode = w0 & 0xff, uv_mode = (w0 >> 8) & 0xff, ref_frame = (w0 >> 16) & 0xff;
             const u32 flags = w0 >> 24;
             const bool skip = flags & VP8IR_MB_SKIP;
@@ -406,11 +435,11 @@ vp8_recon_simt_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g, int
                 aY[0] = aY[1] = aY[2] = aY[3] = arY = 0x7f7f7f7fu;
                 aU[0] = aU[1] = aV[0] = aV[1] = 0x7f7f7f7fu;
             } else if (pos == 0) {
-                const unsigned char *pa = (const unsigned char *)dY - g.y_stride + c * 16;
+                const unsigned char *pa = (const unsigned char *)dY - upY + c * mbY;
 #pragma unroll
                 for (int i = 0; i < 4; i++) aY[i] = load_l2(pa + 4 * i);
-                arY = load_l2(pa + 16);
-                const unsigned char *pu = (const unsigned char *)dU - g.uv_stride + c * 8, *pv = (const unsigned char *)dV - g.uv_stride + c * 8;
+                arY = load_l2(pa + mbY);
+                const unsigned char *pu = (const unsigned char *)dU - upC + c * mbC, *pv = (const unsigned char *)dV - upC + c * mbC;
                 aU[0] = load_l2(pu); aU[1] = load_l2(pu + 4);
                 aV[0] = load_l2(pv); aV[1] = load_l2(pv + 4);
             } else {
@@ -439,7 +468,7 @@ vp8_recon_simt_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g, int
 #pragma unroll
             for (int i = 0; i < 16; i++) dc[i] = 0;
             if (has_y2 && !skip) {
-                const u32x4 ca = *(g_cu32x4p)(cfp + 384), cb = *(g_cu32x4p)(cfp + 392);
+                const u32x4 ca = pf_y2a, cb = pf_y2b;
                 const u32 q[8] = { ca.x, ca.y, ca.z, ca.w, cb.x, cb.y, cb.z, cb.w };
                 const int fdc = dq1 & 0xffff, fac = dq1 >> 16;
                 int tt[16];
@@ -473,14 +502,13 @@ vp8_recon_simt_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g, int
             u32 abv[4] = { aY[0], aY[1], aY[2], aY[3] };     // line above the current block row (B_PRED chain)
             int tlrow = tlY;                                  // top-left of the block row's first block
             u32 nl[4] = { 0, 0, 0, 0 };                       // right column of this MB = left of the next
-            g_u8p prow = dY;
+            g_u8p prow = dY + c * mbY;
 #pragma unroll 1
             for (int by = 0; by < 4; by++) {
                 const u32 lcur = lY[0];
-                u32x4 cq[8];
-                if (!skip) {
+                if (!skip) {                                  // the group after this one (by = 3: the U blocks)
 #pragma unroll
-                    for (int i = 0; i < 8; i++) cq[i] = *(g_cu32x4p)(cfp + by * 64 + i * 8);
+                    for (int i = 0; i < 8; i++) nxt[i] = *(g_cu32x4p)(cfp + (by + 1) * 64 + i * 8);
                 }
                 if (any_inter) {
                     if (!intra) {
@@ -501,6 +529,7 @@ vp8_recon_simt_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g, int
                 const u32 bmw = by == 0 ? bm.x : by == 1 ? bm.y : by == 2 ? bm.z : bm.w;
                 u32 left = lcur;
                 int tl = tlrow;
+                u32 orow[4][4];                               // [row][block]: 16-byte rows for the write-out
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     u32 p[4];
@@ -517,23 +546,28 @@ vp8_recon_simt_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g, int
                     u32 o[4] = { p[0], p[1], p[2], p[3] };
                     if (!skip) {
                         int res[16];
-                        dequant_idct(cq[2 * k], cq[2 * k + 1], dq0 & 0xffff, dq0 >> 16, has_y2, dc[k], res);
+                        dequant_idct(cur[2 * k], cur[2 * k + 1], dq0 & 0xffff, dq0 >> 16, has_y2, dc[k], res);
 #pragma unroll
                         for (int jj = 0; jj < 4; jj++) o[jj] = add_clamp_pack(p[jj], res + 4 * jj);
                     }
 #pragma unroll
-                    for (int jj = 0; jj < 4; jj++) *(g_u32p)(prow + (long)jj * g.y_stride + c * 16 + k * 4) = o[jj];
+                    for (int jj = 0; jj < 4; jj++) orow[jj][k] = o[jj];
                     tl = abv[k] >> 24;
                     abv[k] = o[3];
                     left = right_column(o);
                 }
+#pragma unroll
+                for (int jj = 0; jj < 4; jj++)
+                    *(g_u32x4p)(prow + jj * ysY) = (u32x4){ orow[jj][0], orow[jj][1], orow[jj][2], orow[jj][3] };
                 // rotate the per-row shift registers
                 tlrow = lcur >> 24;
                 lY[0] = lY[1]; lY[1] = lY[2]; lY[2] = lY[3];
                 nl[0] = nl[1]; nl[1] = nl[2]; nl[2] = nl[3]; nl[3] = left;
 #pragma unroll
                 for (int i = 0; i < 12; i++) dc[i] = dc[i + 4];
-                prow += (long)4 * g.y_stride;
+                prow += 4 * ysY;
+#pragma unroll
+                for (int i = 0; i < 8; i++) cur[i] = nxt[i];
             }
 #pragma unroll
             for (int i = 0; i < 4; i++) { bY[i] = abv[i]; lY[i] = nl[i]; }
@@ -570,22 +604,29 @@ vp8_recon_simt_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g, int
                     }
                 }
             }
+            const bool more = c + 1 < cols;      // the row goes on: prefetch its next macroblock
 #pragma unroll 1
             for (int pl = 0; pl < 2; pl++) {
                 const u32 aC0 = pl ? aV[0] : aU[0], aC1 = pl ? aV[1] : aU[1];
                 const u32 lC0 = pl ? lV[0] : lU[0], lC1 = pl ? lV[1] : lU[1];
                 const int tlC = pl ? tlV : tlU;
-                g_u8p dC = pl ? dV : dU;
+                g_u8p dC = (pl ? dV : dU) + c * mbC;
                 int dcC = 128;
                 if (up | lf) {
                     const int shift = 2 + up + lf;
                     const int s = (up ? sad4(aC0) + sad4(aC1) : 0) + (lf ? sad4(lC0) + sad4(lC1) : 0);
                     dcC = (s + (1 << (shift - 1))) >> shift;
                 }
-                u32x4 cq[8];
-                if (!skip) {
+                if (pl == 0) {
+                    if (!skip) {                              // the V blocks
 #pragma unroll
-                    for (int i = 0; i < 8; i++) cq[i] = *(g_cu32x4p)(cfp + 256 + pl * 64 + i * 8);
+                        for (int i = 0; i < 8; i++) nxt[i] = *(g_cu32x4p)(cfp + 320 + i * 8);
+                    }
+                } else if (more) {                            // the next macroblock of the row
+                    pf_w0 = mbp[16]; pf_w1 = mbp[17]; pf_bm = *(g_cu32x4p)(mbp + 26);
+                    pf_y2a = *(g_cu32x4p)(cfp + VP8IR_COEF_PER_MB + 384); pf_y2b = *(g_cu32x4p)(cfp + VP8IR_COEF_PER_MB + 392);
+#pragma unroll
+                    for (int i = 0; i < 8; i++) nxt[i] = *(g_cu32x4p)(cfp + VP8IR_COEF_PER_MB + i * 8);
                 }
                 if (any_inter) {
                     if (!intra) {
@@ -601,6 +642,7 @@ vp8_recon_simt_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g, int
                     }
                 }
                 u32 bot[2] = { 0, 0 }, rc[2] = { 0, 0 };
+                u32 orow[8][2];
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     const int bx = k & 1, byc = k >> 1;
@@ -613,18 +655,21 @@ vp8_recon_simt_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g, int
                     u32 o[4] = { p[0], p[1], p[2], p[3] };
                     if (!skip) {
                         int res[16];
-                        dequant_idct(cq[2 * k], cq[2 * k + 1], dq2 & 0xffff, dq2 >> 16, false, 0, res);
+                        dequant_idct(cur[2 * k], cur[2 * k + 1], dq2 & 0xffff, dq2 >> 16, false, 0, res);
 #pragma unroll
                         for (int jj = 0; jj < 4; jj++) o[jj] = add_clamp_pack(p[jj], res + 4 * jj);
                     }
 #pragma unroll
-                    for (int jj = 0; jj < 4; jj++)
-                        *(g_u32p)(dC + (long)(byc * 4 + jj) * g.uv_stride + c * 8 + bx * 4) = o[jj];
+                    for (int jj = 0; jj < 4; jj++) orow[byc * 4 + jj][bx] = o[jj];
                     if (byc) bot[bx] = o[3];
                     if (bx) rc[byc] = right_column(o);
                 }
+#pragma unroll
+                for (int jj = 0; jj < 8; jj++) *(g_u32x2p)(dC + jj * ysC) = (u32x2){ orow[jj][0], orow[jj][1] };
                 if (pl) { bV[0] = bot[0]; bV[1] = bot[1]; lV[0] = rc[0]; lV[1] = rc[1]; }
                 else { bU[0] = bot[0]; bU[1] = bot[1]; lU[0] = rc[0]; lU[1] = rc[1]; }
+#pragma unroll
+                for (int i = 0; i < 8; i++) cur[i] = nxt[i];
             }
 
             prevLastY = aY[3] >> 24; prevLastU = aU[1] >> 24; prevLastV = aV[1] >> 24;

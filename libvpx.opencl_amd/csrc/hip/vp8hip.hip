@@ -12,9 +12,11 @@
 #include "vp8_common.hip.h"
 
 extern "C" __global__ void vp8_recon_kernel(const DevJob *jobs, int njobs, DevGeom g);
-extern "C" __global__ void vp8_recon_simt_kernel(const DevJob *jobs, int njobs, DevGeom g, int lgG, int P, int nstrands);
+extern "C" __global__ void vp8_recon_simt_kernel(const DevJob *jobs, int njobs, DevGeom g, int lgG, int P, int nstrands, int tiled);
+extern "C" __global__ void vp8_loopfilter_simt_kernel(const DevJob *jobs, int njobs, DevGeom g, int lgG, int P, int nstrands);
 extern "C" __global__ void vp8_loopfilter_kernel(const DevJob *jobs, int njobs, DevGeom g);
 extern "C" __global__ void vp8_extend_kernel(const DevJob *jobs, int njobs, DevGeom g);
+extern "C" __global__ void vp8_detile_kernel(const DevJob *jobs, int njobs, DevGeom g);
 
 static char g_create_error[256] = "";
 
@@ -42,6 +44,7 @@ struct vp8hip_ctx {
     std::vector<uint8_t *> fb;
     std::vector<Slot> slots;
     uint8_t *fb_block; char *slot_block_dev;
+    uint8_t *tile_block; size_t tile_cap;     // macroblock-tiled scratch frames of the one-MB-row-per-lane pipeline
     size_t slot_bytes, o_mbs, o_coef, o_mvs;
     // job staging
     DevJob *d_jobs; DevJob *h_jobs; int jobs_cap;
@@ -72,10 +75,12 @@ extern "C" const char *vp8hip_last_error(const vp8hip_ctx *ctx) { return ctx ? c
 static void free_pools(vp8hip_ctx *c)
 {
     if (c->fb_block) (void)hipFree(c->fb_block);
+    if (c->tile_block) (void)hipFree(c->tile_block);
+    c->tile_block = nullptr; c->tile_cap = 0;
     if (c->slot_block_dev) (void)hipFree(c->slot_block_dev);
     for (Slot &s : c->slots)
         if (s.h_block) (void)hipHostFree(s.h_block);
-    c->fb_block = nullptr; c->slot_block_dev = nullptr;
+    c->fb_block = nullptr; c->slot_block_dev = nullptr; c->tile_block = nullptr; c->tile_cap = 0;
     c->fb.clear(); c->slots.clear();
 }
 
@@ -103,7 +108,7 @@ extern "C" int vp8hip_create(int device, vp8hip_ctx **out)
     c->device = device;
     c->num_cu = prop.multiProcessorCount;
     c->max_lds = 160 * 1024;
-    c->fb_block = nullptr; c->slot_block_dev = nullptr;
+    c->fb_block = nullptr; c->slot_block_dev = nullptr; c->tile_block = nullptr; c->tile_cap = 0;
     c->d_jobs = nullptr; c->h_jobs = nullptr; c->jobs_cap = 0;
     c->width = c->height = 0;
     c->have_times = false;
@@ -292,6 +297,21 @@ extern "C" int vp8hip_decode(vp8hip_ctx *c, const vp8hip_job *jobs, int njobs, i
     }
     const int nfb = (int)c->fb.size(), nsl = (int)c->slots.size();
     bool any_lf = false;
+    // Which reconstruction kernel: the wave-per-MB-row kernel is the faster one while a launch has fewer
+    // frames than the chip has SIMDs to fill; the one-MB-row-per-lane kernel wins beyond that.
+    bool simt_recon = (stages & VP8HIP_STAGE_RECON) && njobs >= 3 * c->num_cu;
+    if (const char *e = getenv("VP8HIP_RECON"))      // tuning / test knob: force one of the two kernel families
+        simt_recon = (stages & VP8HIP_STAGE_RECON) && (!strcmp(e, "simt") ? true : (!strcmp(e, "wave") ? false : simt_recon));
+    // the lane-per-row kernels work on macroblock-tiled scratch frames; vp8_detile_kernel converts at the end
+    const bool tiled = simt_recon;
+    const size_t tile_frame = (size_t)c->nmb * VP8_TILE_BYTES;
+    if (tiled && c->tile_cap < tile_frame * njobs) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (c->tile_block) (void)hipFree(c->tile_block);
+        c->tile_block = nullptr; c->tile_cap = 0;
+        HIPCHK(c, hipMalloc((void **)&c->tile_block, tile_frame * njobs));
+        c->tile_cap = tile_frame * njobs;
+    }
     for (int i = 0; i < njobs; i++) {
         const vp8hip_job &j = jobs[i];
         if (j.ir_slot < 0 || j.ir_slot >= nsl || j.dst_fb < 0 || j.dst_fb >= nfb)
@@ -301,7 +321,7 @@ extern "C" int vp8hip_decode(vp8hip_ctx *c, const vp8hip_job *jobs, int njobs, i
         d.hdr = s.hdr_copy;
         d.mbs = s.d_mbs; d.coef = s.d_coef; d.mvs = s.d_mvs;
         d.dst = c->fb[j.dst_fb];
-        d.ref[0] = nullptr;
+        d.ref[0] = tiled ? c->tile_block + tile_frame * i : nullptr;
         for (int k = 1; k < 4; k++) {
             d.ref[k] = nullptr;
             if (s.hdr_copy.frame_type == 0) continue;          // key frames read no reference
@@ -323,39 +343,50 @@ extern "C" int vp8hip_decode(vp8hip_ctx *c, const vp8hip_job *jobs, int njobs, i
     c->stats.recon_waves = c->recon_nw;
     c->stats.lf_waves = c->lf_nw;
     HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+    // "one MB row per lane" kernels: G lanes per strand of frames, row period P >= max(cols, 2G+2).  The largest
+    // G that costs no idle steps (cols >= 2G+2), widened while the launch would leave SIMDs without a wave.
+    int lgG = 1;
+    {
+        const int cols = c->dg.mb_cols;
+        while (lgG < 6 && 2 * (2 << lgG) + 2 <= cols) lgG++;
+        while (lgG < 6 && (njobs + (64 >> lgG) - 1) / (64 >> lgG) < c->num_cu * 8) lgG++;
+        if (const char *e = getenv("VP8HIP_SIMT_LGG")) { int v = atoi(e); if (v >= 1 && v <= 6) lgG = v; }
+    }
+    const int simtG = 1 << lgG, spw = 64 >> lgG;
+    const int simtP = c->dg.mb_cols > 2 * simtG + 2 ? c->dg.mb_cols : 2 * simtG + 2;
+    int simt_waves = (njobs + spw - 1) / spw;
+    {
+        int maxw = c->num_cu * 4;
+        if (const char *e = getenv("VP8HIP_SIMT_WAVES")) { int v = atoi(e); if (v >= 1) maxw = v; }
+        if (simt_waves > maxw) simt_waves = maxw;
+    }
     if (stages & VP8HIP_STAGE_RECON) {
-        const char *mode = getenv("VP8HIP_RECON");
-        if (mode && !strcmp(mode, "simt")) {
-            // one MB row per lane: G lanes per strand of frames, row period P >= max(cols, 2G+2).  The
-            // largest G that costs no idle steps (cols >= 2G+2), widened while the launch would leave
-            // SIMDs without a wave.
-            const int cols = c->dg.mb_cols;
-            int lgG = 1;
-            while (lgG < 6 && 2 * (2 << lgG) + 2 <= cols) lgG++;
-            while (lgG < 6 && (njobs + (64 >> lgG) - 1) / (64 >> lgG) < c->num_cu * 8) lgG++;
-            if (const char *e = getenv("VP8HIP_SIMT_LGG")) { int v = atoi(e); if (v >= 1 && v <= 6) lgG = v; }
-            const int G = 1 << lgG, spw = 64 >> lgG;
-            const int P = cols > 2 * G + 2 ? cols : 2 * G + 2;
-            int nwaves = (njobs + spw - 1) / spw;
-            int maxw = c->num_cu * 8;
-            if (const char *e = getenv("VP8HIP_SIMT_WAVES")) { int v = atoi(e); if (v >= 1) maxw = v; }
-            if (nwaves > maxw) nwaves = maxw;
-            hipLaunchKernelGGL(vp8_recon_simt_kernel, dim3(nwaves), dim3(64), 0, c->stream, (const DevJob *)c->d_jobs, njobs,
-                               c->dg, lgG, P, nwaves * spw);
+        if (simt_recon) {
+            hipLaunchKernelGGL(vp8_recon_simt_kernel, dim3(simt_waves), dim3(64), 0, c->stream, (const DevJob *)c->d_jobs, njobs,
+                               c->dg, lgG, simtP, simt_waves * spw, tiled ? 1 : 0);
         } else {
-        const int npairs = (njobs + 1) / 2;          // two frames per wave
-        const int rgrid = npairs < c->num_cu * wg_per_cu ? npairs : c->num_cu * wg_per_cu;
-        hipLaunchKernelGGL(vp8_recon_kernel, dim3(rgrid), dim3(64 * c->recon_nw), c->recon_lds, c->stream,
-                           (const DevJob *)c->d_jobs, njobs, c->dg);
+            const int npairs = (njobs + 1) / 2;          // two frames per wave
+            const int rgrid = npairs < c->num_cu * wg_per_cu ? npairs : c->num_cu * wg_per_cu;
+            hipLaunchKernelGGL(vp8_recon_kernel, dim3(rgrid), dim3(64 * c->recon_nw), c->recon_lds, c->stream,
+                               (const DevJob *)c->d_jobs, njobs, c->dg);
         }
         HIPCHK(c, hipGetLastError());
     }
     HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
     if ((stages & VP8HIP_STAGE_LF) && any_lf) {
-        const int npairs = (njobs + 1) / 2;          // the loop filter works on two frames per wave
-        const int lfgrid = npairs < c->num_cu * wg_per_cu ? npairs : c->num_cu * wg_per_cu;
-        hipLaunchKernelGGL(vp8_loopfilter_kernel, dim3(lfgrid), dim3(64 * c->lf_nw), c->lf_lds, c->stream,
-                           (const DevJob *)c->d_jobs, njobs, c->dg);
+        if (tiled) {
+            hipLaunchKernelGGL(vp8_loopfilter_simt_kernel, dim3(simt_waves), dim3(64), 0, c->stream, (const DevJob *)c->d_jobs,
+                               njobs, c->dg, lgG, simtP, simt_waves * spw);
+        } else {
+            const int npairs = (njobs + 1) / 2;          // the loop filter works on two frames per wave
+            const int lfgrid = npairs < c->num_cu * wg_per_cu ? npairs : c->num_cu * wg_per_cu;
+            hipLaunchKernelGGL(vp8_loopfilter_kernel, dim3(lfgrid), dim3(64 * c->lf_nw), c->lf_lds, c->stream,
+                               (const DevJob *)c->d_jobs, njobs, c->dg);
+        }
+        HIPCHK(c, hipGetLastError());
+    }
+    if (tiled) {      // whatever stages ran, the frame buffer gets the result
+        hipLaunchKernelGGL(vp8_detile_kernel, dim3(c->dg.mb_rows, njobs), dim3(256), 0, c->stream, (const DevJob *)c->d_jobs, njobs, c->dg);
         HIPCHK(c, hipGetLastError());
     }
     HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
