@@ -20,6 +20,15 @@ def ctx(pkg):
     c.close()
 
 
+@pytest.fixture(params=["wave", "lane"], autouse=True)
+def kernel_family(request, monkeypatch):
+    """Every test runs with both kernel families: "wave" = one wave per MB row (small launches), "lane" = one
+    MB row per lane on macroblock-tiled scratch frames + detile (large launches).  VP8HIP_RECON is the library's
+    tuning knob that overrides the automatic choice (libvpx.opencl_amd/csrc/hip/vp8hip.hip)."""
+    monkeypatch.setenv("VP8HIP_RECON", "simt" if request.param == "lane" else "wave")
+    return request.param
+
+
 @pytest.mark.parametrize("name", FIXTURES)
 def test_fixture_md5_frame_by_frame(pkg, name):
     """decode_to_md5 parity: every shown frame equals the reference decoder's MD5."""
@@ -122,6 +131,21 @@ def test_full_size_1080p_batch_properties(pkg, ctx):
     # idempotence: decoding the same jobs again into the same buffers changes nothing
     ctx.decode([(i, i, None) for i in range(n)], 7)
     assert np.array_equal(a, ctx.download_full(3))
+
+
+def test_automatic_kernel_choice(pkg, ctx, kernel_family, monkeypatch):
+    """Without the override a launch of >= 3 frames per CU takes the lane-per-row kernels, a smaller one the
+    wave-per-row kernels; both sides of the threshold produce the reference's frames."""
+    if kernel_family == "lane":
+        pytest.skip("one run is enough")
+    monkeypatch.delenv("VP8HIP_RECON")
+    for nframes in (40, 1100):
+        gold, nsrc = _batch(pkg, ctx, "kf_q0_176x144", nframes)
+        for i in (0, 1, nframes // 2, nframes - 1):
+            assert pkg.planes_md5(*ctx.download_planes(i)) == gold[i % nsrc], (nframes, i)
+    gold, nsrc = _batch(pkg, ctx, "kf_640x360", 900)
+    for i in (0, 7, 450, 899):
+        assert pkg.planes_md5(*ctx.download_planes(i)) == gold[i % nsrc], i
 
 
 def test_full_size_4k(pkg, ctx):
