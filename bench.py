@@ -38,6 +38,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 B_RECON = 833 + 384      # coefficients+eobs+params read, pixels written (key frames)
 B_LF = 770               # pixels read + written, params
 B_EXTEND = 36
+B_DETILE = 384 + 384 + 36  # lane-per-row pipeline only: tiled scratch read, raster frame + borders written
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 WORKLOADS = {
@@ -85,7 +86,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--frames", type=int, default=1024, help="frames per GPU per step")
+    ap.add_argument("--frames", type=int, default=0,
+                    help="frames per GPU per step (default: 8192 for 1080p, 2048 for 4k -- about 110 GB of IR, "
+                         "tiled scratch and frame buffers resident in HBM; the lane-per-row kernels want several "
+                         "frames per wave on each of the chip's 1024 SIMDs)")
     ap.add_argument("--workload", default="1080p", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -109,7 +113,7 @@ def main():
     from vp8_testlib import load_package, golden_md5, ivf_path
     P = load_package()
     fixture, W, H = WORKLOADS[args.workload]
-    F = args.frames
+    F = args.frames or {"1080p": 8192, "4k": 2048}[args.workload]
 
     # ---- host feeder once (outside the timed region): 10 key frames -> IR
     w, h, frames = P.read_ivf(ivf_path(fixture))
@@ -180,8 +184,13 @@ def main():
     if rank == 0:
         K = args.steps
         total_pix = world * F * K * W * H
+        lane = st.recon_waves == 1            # the lane-per-row kernels ran (see vp8hip_stats)
         ms = {"recon": k_recon / K, "loopfilter": k_lf / K, "extend": k_ext / K}
-        bytes_per_launch = {"recon": B_RECON * nmb * F, "loopfilter": B_LF * nmb * F, "extend": B_EXTEND * nmb * F}
+        bytes_per_launch = {"recon": B_RECON * nmb * F, "loopfilter": B_LF * nmb * F,
+                            "extend": (B_DETILE if lane else B_EXTEND) * nmb * F}
+        names = ({"recon": "vp8_recon_simt_kernel", "loopfilter": "vp8_loopfilter_simt_kernel",
+                  "extend": "vp8_detile_kernel (tiled -> raster + border extension)"} if lane else
+                 {"recon": "vp8_recon_kernel", "loopfilter": "vp8_loopfilter_kernel", "extend": "vp8_extend_kernel"})
         dom = max(ms, key=lambda k: ms[k])
         achieved = bytes_per_launch[dom] / (ms[dom] * 1e-3) / 1e9
         out = {
@@ -205,19 +214,21 @@ def main():
                 "macroblocks_per_frame": nmb,
                 "parallelism": f"frame-parallel, {world} GPU(s), no pixel exchange",
                 "kernel_ms": {k: round(v, 4) for k, v in ms.items()},
+                "kernel_family": "one macroblock row per lane, macroblock-tiled scratch frames" if lane
+                                 else "one wave per macroblock row",
+                "kernels": names,
                 "waves_per_workgroup": {"recon": st.recon_waves, "loopfilter": st.lf_waves},
                 "workgroups": st.workgroups,
                 "host_feeder_s_for_source_frames": round(feed_s, 4),
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": {"recon": "vp8_recon_kernel", "loopfilter": "vp8_loopfilter_kernel",
-                           "extend": "vp8_extend_kernel"}[dom],
+                "kernel": names[dom],
                 "achieved": round(achieved, 2),
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 5),
-                "traffic": None,
+                "traffic": None,      # rocprofv3 TCC counter passes do not complete with these kernels
                 "algorithmic_bytes_per_launch": bytes_per_launch[dom],
                 "mean_launch_ms": round(ms[dom], 4),
                 "all_kernels_GBps": {k: round(bytes_per_launch[k] / (ms[k] * 1e-3) / 1e9, 2) if ms[k] > 0 else None

@@ -55,8 +55,9 @@ typedef struct vp8hip_job {
 } vp8hip_job;
 
 typedef struct vp8hip_stats {      /* filled by vp8hip_get_stats; times from HIP events, ms */
-    float recon_ms, lf_ms, extend_ms;   /* last vp8hip_decode call */
-    int   recon_waves, lf_waves;        /* waves per workgroup chosen for the geometry */
+    float recon_ms, lf_ms, extend_ms;   /* last vp8hip_decode call; extend_ms = border extension, plus the
+                                           tiled-to-raster pass when the lane-per-row kernels ran */
+    int   recon_waves, lf_waves;        /* waves per workgroup (1 = the lane-per-row kernels ran) */
     int   workgroups;
 } vp8hip_stats;
 

@@ -1,38 +1,76 @@
-// Macroblock-tiled scratch frame -> raster frame buffer (the coded area; vp8_extend_kernel adds the borders).
+// Macroblock-tiled scratch frame -> raster frame buffer, optionally with the reference's border extension.
 //
 // The one-MB-row-per-lane kernels keep a frame as one 384-byte tile per macroblock (VP8_TILE_BYTES: 16 luma
 // rows of 16 B, 8 U rows of 8 B, 8 V rows of 8 B) so that every lane reads and writes whole 128-byte lines.
 // The frame buffer the rest of the world sees -- reference frames for motion compensation, the frames handed
-// back through vp8hip_frame_download -- is the reference decoder's raster YV12 layout
-// (vpx_scale/generic/yv12config.c:55-112).  This pass is pure data movement at HBM speed: each workgroup
-// takes one macroblock row of one frame, eight macroblocks per iteration; eight neighbouring threads read
-// the same pixel row of eight tiles and write 128 (luma) / 64 (chroma) contiguous bytes.
+// back through vp8hip_frame_download -- is the reference decoder's raster YV12 layout with its 32-pixel
+// borders (vpx_scale/generic/yv12config.c:55-112).  This pass is pure data movement: each workgroup takes one
+// macroblock row of one frame, eight macroblocks per iteration; eight neighbouring threads read the same
+// pixel row of eight tiles and write 128 (luma) / 64 (chroma) contiguous bytes.  With `extend` set it also
+// does vp8_yv12_extend_frame_borders (vpx_scale/generic/yv12extend.c:24-145) on the fly -- the thread that
+// holds the first / last pixels of a row replicates them into the left / right border, the first / last
+// macroblock row replicates its outer pixel row (borders included) 32 (chroma: 16) times -- so a macroblock
+// row leaves the workgroup as one contiguous run of 16 full frame-buffer rows.
 #include "vp8_common.hip.h"
 
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+typedef GLOBAL_AS u32x4_t *g_x4p;
+typedef GLOBAL_AS u32x2_t *g_x2p;
 
 extern "C" __global__ void __launch_bounds__(256)
-vp8_detile_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g)
+vp8_detile_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g, int extend)
 {
     const DevJob &job = jobs[blockIdx.y];
-    const int r = blockIdx.x, cols = g.mb_cols;
+    const int r = blockIdx.x, cols = g.mb_cols, rows = g.mb_rows;
     const int t = threadIdx.x;
     const unsigned char *trow = job.ref[0] + (long)r * cols * VP8_TILE_BYTES;
     unsigned char *dst = job.dst;
     const int tile = t & 7;
+    const bool luma = t < 128;
+    const int pl = (t - 128) >> 6;                                  // chroma threads: 0 = U, 1 = V
+    const int row = luma ? t >> 3 : ((t - 128) >> 3) & 7;           // pixel row inside the macroblock
+    const int nrow = luma ? 16 : 8, border = luma ? 32 : 16;
+    const long stride = luma ? g.y_stride : g.uv_stride;
+    unsigned char *prow = dst + (luma ? g.y_off : (pl ? g.v_off : g.u_off)) + (long)(r * nrow + row) * stride;
+    // rows of the top / bottom border this thread's row is copied to (vertical extension)
+    const int vcopies = !extend ? 0 : ((r == 0 && row == 0) || (r == rows - 1 && row == nrow - 1)) ? border : 0;
+    const long vstep = (r == 0 && row == 0) ? -stride : stride;
+#pragma unroll 4
     for (int c0 = 0; c0 < cols; c0 += 8) {
         const int c = c0 + tile;
         if (c >= cols) continue;
         const unsigned char *tp = trow + (long)c * VP8_TILE_BYTES;
-        if (t < 128) {                                   // luma: row = t >> 3
-            const int row = t >> 3;
+        if (luma) {
             const u32x4_t v = *(const GLOBAL_AS u32x4_t *)(tp + 16 * row);
-            *(GLOBAL_AS u32x4_t *)(dst + g.y_off + (long)(r * 16 + row) * g.y_stride + c * 16) = v;
-        } else {                                         // chroma: U for t in 128..191, V for 192..255
-            const int pl = (t - 128) >> 6, row = ((t - 128) >> 3) & 7;
+            unsigned char *p = prow + c * 16;
+            *(g_x4p)p = v;
+            const bool lb = extend && c == 0, rb = extend && c == cols - 1;
+            const unsigned int l = (v.x & 0xff) * 0x01010101u, rr = (v.w >> 24) * 0x01010101u;
+            const u32x4_t lv = { l, l, l, l }, rv = { rr, rr, rr, rr };
+            if (lb) { *(g_x4p)(p - 32) = lv; *(g_x4p)(p - 16) = lv; }
+            if (rb) { *(g_x4p)(p + 16) = rv; *(g_x4p)(p + 32) = rv; }
+            for (int b = 1; b <= vcopies; b++) {
+                unsigned char *q = p + b * vstep;
+                *(g_x4p)q = v;
+                if (lb) { *(g_x4p)(q - 32) = lv; *(g_x4p)(q - 16) = lv; }
+                if (rb) { *(g_x4p)(q + 16) = rv; *(g_x4p)(q + 32) = rv; }
+            }
+        } else {
             const u32x2_t v = *(const GLOBAL_AS u32x2_t *)(tp + 256 + 64 * pl + 8 * row);
-            *(GLOBAL_AS u32x2_t *)(dst + (pl ? g.v_off : g.u_off) + (long)(r * 8 + row) * g.uv_stride + c * 8) = v;
+            unsigned char *p = prow + c * 8;
+            *(g_x2p)p = v;
+            const bool lb = extend && c == 0, rb = extend && c == cols - 1;
+            const unsigned int l = (v.x & 0xff) * 0x01010101u, rr = (v.y >> 24) * 0x01010101u;
+            const u32x2_t lv = { l, l }, rv = { rr, rr };
+            if (lb) { *(g_x2p)(p - 16) = lv; *(g_x2p)(p - 8) = lv; }
+            if (rb) { *(g_x2p)(p + 8) = rv; *(g_x2p)(p + 16) = rv; }
+            for (int b = 1; b <= vcopies; b++) {
+                unsigned char *q = p + b * vstep;
+                *(g_x2p)q = v;
+                if (lb) { *(g_x2p)(q - 16) = lv; *(g_x2p)(q - 8) = lv; }
+                if (rb) { *(g_x2p)(q + 8) = rv; *(g_x2p)(q + 16) = rv; }
+            }
         }
     }
 }

@@ -16,7 +16,7 @@ extern "C" __global__ void vp8_recon_simt_kernel(const DevJob *jobs, int njobs, 
 extern "C" __global__ void vp8_loopfilter_simt_kernel(const DevJob *jobs, int njobs, DevGeom g, int lgG, int P, int nstrands);
 extern "C" __global__ void vp8_loopfilter_kernel(const DevJob *jobs, int njobs, DevGeom g);
 extern "C" __global__ void vp8_extend_kernel(const DevJob *jobs, int njobs, DevGeom g);
-extern "C" __global__ void vp8_detile_kernel(const DevJob *jobs, int njobs, DevGeom g);
+extern "C" __global__ void vp8_detile_kernel(const DevJob *jobs, int njobs, DevGeom g, int extend);
 
 static char g_create_error[256] = "";
 
@@ -360,6 +360,7 @@ extern "C" int vp8hip_decode(vp8hip_ctx *c, const vp8hip_job *jobs, int njobs, i
         if (const char *e = getenv("VP8HIP_SIMT_WAVES")) { int v = atoi(e); if (v >= 1) maxw = v; }
         if (simt_waves > maxw) simt_waves = maxw;
     }
+    if (tiled) { c->stats.workgroups = simt_waves; c->stats.recon_waves = 1; c->stats.lf_waves = 1; }
     if (stages & VP8HIP_STAGE_RECON) {
         if (simt_recon) {
             hipLaunchKernelGGL(vp8_recon_simt_kernel, dim3(simt_waves), dim3(64), 0, c->stream, (const DevJob *)c->d_jobs, njobs,
@@ -385,12 +386,12 @@ extern "C" int vp8hip_decode(vp8hip_ctx *c, const vp8hip_job *jobs, int njobs, i
         }
         HIPCHK(c, hipGetLastError());
     }
-    if (tiled) {      // whatever stages ran, the frame buffer gets the result
-        hipLaunchKernelGGL(vp8_detile_kernel, dim3(c->dg.mb_rows, njobs), dim3(256), 0, c->stream, (const DevJob *)c->d_jobs, njobs, c->dg);
-        HIPCHK(c, hipGetLastError());
-    }
     HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
-    if (stages & VP8HIP_STAGE_EXTEND) {
+    if (tiled) {      // whatever stages ran, the frame buffer gets the result; borders are extended on the way
+        hipLaunchKernelGGL(vp8_detile_kernel, dim3(c->dg.mb_rows, njobs), dim3(256), 0, c->stream, (const DevJob *)c->d_jobs, njobs, c->dg,
+                           (stages & VP8HIP_STAGE_EXTEND) ? 1 : 0);
+        HIPCHK(c, hipGetLastError());
+    } else if (stages & VP8HIP_STAGE_EXTEND) {
         int bx = (c->geom.aligned_h + 64) / 4;
         if (bx < 1) bx = 1;
         if (bx > 64) bx = 64;
