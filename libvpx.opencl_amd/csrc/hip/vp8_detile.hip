@@ -36,40 +36,53 @@ vp8_detile_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g, int ext
     // rows of the top / bottom border this thread's row is copied to (vertical extension)
     const int vcopies = !extend ? 0 : ((r == 0 && row == 0) || (r == rows - 1 && row == nrow - 1)) ? border : 0;
     const long vstep = (r == 0 && row == 0) ? -stride : stride;
-#pragma unroll 4
-    for (int c0 = 0; c0 < cols; c0 += 8) {
-        const int c = c0 + tile;
-        if (c >= cols) continue;
-        const unsigned char *tp = trow + (long)c * VP8_TILE_BYTES;
-        if (luma) {
-            const u32x4_t v = *(const GLOBAL_AS u32x4_t *)(tp + 16 * row);
-            unsigned char *p = prow + c * 16;
-            *(g_x4p)p = v;
-            const bool lb = extend && c == 0, rb = extend && c == cols - 1;
-            const unsigned int l = (v.x & 0xff) * 0x01010101u, rr = (v.w >> 24) * 0x01010101u;
-            const u32x4_t lv = { l, l, l, l }, rv = { rr, rr, rr, rr };
-            if (lb) { *(g_x4p)(p - 32) = lv; *(g_x4p)(p - 16) = lv; }
-            if (rb) { *(g_x4p)(p + 16) = rv; *(g_x4p)(p + 32) = rv; }
-            for (int b = 1; b <= vcopies; b++) {
-                unsigned char *q = p + b * vstep;
-                *(g_x4p)q = v;
-                if (lb) { *(g_x4p)(q - 32) = lv; *(g_x4p)(q - 16) = lv; }
-                if (rb) { *(g_x4p)(q + 16) = rv; *(g_x4p)(q + 32) = rv; }
+    // four iterations' worth of loads are issued before the first store: the pass is latency-bound otherwise
+    for (int cb = 0; cb < cols; cb += 32) {
+        u32x4_t vy[4];
+        u32x2_t vc[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int c = cb + 8 * k + tile;
+            if (c < cols) {
+                const unsigned char *tp = trow + (long)c * VP8_TILE_BYTES;
+                if (luma) vy[k] = *(const GLOBAL_AS u32x4_t *)(tp + 16 * row);
+                else vc[k] = *(const GLOBAL_AS u32x2_t *)(tp + 256 + 64 * pl + 8 * row);
             }
-        } else {
-            const u32x2_t v = *(const GLOBAL_AS u32x2_t *)(tp + 256 + 64 * pl + 8 * row);
-            unsigned char *p = prow + c * 8;
-            *(g_x2p)p = v;
-            const bool lb = extend && c == 0, rb = extend && c == cols - 1;
-            const unsigned int l = (v.x & 0xff) * 0x01010101u, rr = (v.y >> 24) * 0x01010101u;
-            const u32x2_t lv = { l, l }, rv = { rr, rr };
-            if (lb) { *(g_x2p)(p - 16) = lv; *(g_x2p)(p - 8) = lv; }
-            if (rb) { *(g_x2p)(p + 8) = rv; *(g_x2p)(p + 16) = rv; }
-            for (int b = 1; b <= vcopies; b++) {
-                unsigned char *q = p + b * vstep;
-                *(g_x2p)q = v;
-                if (lb) { *(g_x2p)(q - 16) = lv; *(g_x2p)(q - 8) = lv; }
-                if (rb) { *(g_x2p)(q + 8) = rv; *(g_x2p)(q + 16) = rv; }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int c = cb + 8 * k + tile;
+            if (c >= cols) continue;
+            if (luma) {
+                const u32x4_t v = vy[k];
+                unsigned char *p = prow + c * 16;
+                *(g_x4p)p = v;
+                const bool lb = extend && c == 0, rb = extend && c == cols - 1;
+                const unsigned int l = (v.x & 0xff) * 0x01010101u, rr = (v.w >> 24) * 0x01010101u;
+                const u32x4_t lv = { l, l, l, l }, rv = { rr, rr, rr, rr };
+                if (lb) { *(g_x4p)(p - 32) = lv; *(g_x4p)(p - 16) = lv; }
+                if (rb) { *(g_x4p)(p + 16) = rv; *(g_x4p)(p + 32) = rv; }
+                for (int b = 1; b <= vcopies; b++) {
+                    unsigned char *q = p + b * vstep;
+                    *(g_x4p)q = v;
+                    if (lb) { *(g_x4p)(q - 32) = lv; *(g_x4p)(q - 16) = lv; }
+                    if (rb) { *(g_x4p)(q + 16) = rv; *(g_x4p)(q + 32) = rv; }
+                }
+            } else {
+                const u32x2_t v = vc[k];
+                unsigned char *p = prow + c * 8;
+                *(g_x2p)p = v;
+                const bool lb = extend && c == 0, rb = extend && c == cols - 1;
+                const unsigned int l = (v.x & 0xff) * 0x01010101u, rr = (v.y >> 24) * 0x01010101u;
+                const u32x2_t lv = { l, l }, rv = { rr, rr };
+                if (lb) { *(g_x2p)(p - 16) = lv; *(g_x2p)(p - 8) = lv; }
+                if (rb) { *(g_x2p)(p + 8) = rv; *(g_x2p)(p + 16) = rv; }
+                for (int b = 1; b <= vcopies; b++) {
+                    unsigned char *q = p + b * vstep;
+                    *(g_x2p)q = v;
+                    if (lb) { *(g_x2p)(q - 16) = lv; *(g_x2p)(q - 8) = lv; }
+                    if (rb) { *(g_x2p)(q + 8) = rv; *(g_x2p)(q + 16) = rv; }
+                }
             }
         }
     }
