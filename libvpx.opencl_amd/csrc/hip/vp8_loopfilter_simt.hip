@@ -47,96 +47,119 @@ __device__ __forceinline__ unsigned long long load_l2_64(const unsigned char *p)
 {
     return __hip_atomic_load((const unsigned long long *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ v2s as_v2s(u32 v) { return __builtin_bit_cast(v2s, v); }
+// Pixels travel through the filters as 8.8 fixed point, the byte in the HIGH half of each 16-bit lane:
+//   * unsigned (v2u) for the masks: |a-b| = max-min, comparisons by saturating subtraction;
+//   * signed (v2s, pixel ^ 0x80 in the high byte) for the filter arithmetic, where the 16-bit saturation of
+//     `v_pk_add_i16 ... clamp` IS the reference's vp8_signed_char_clamp (every operand is a multiple of 256),
+//     so a saturating add costs one instruction instead of add + min + max.
+typedef unsigned short v2u __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2u as_v2u(u32 v) { return __builtin_bit_cast(v2u, v); }
+__device__ __forceinline__ u32 as_u32(v2u v) { return __builtin_bit_cast(u32, v); }
 __device__ __forceinline__ u32 as_u32(v2s v) { return __builtin_bit_cast(u32, v); }
-__device__ __forceinline__ v2s mk(int v) { return (v2s){ (short)v, (short)v }; }
-__device__ __forceinline__ v2s vmax(v2s a, v2s b) { return __builtin_elementwise_max(a, b); }
-__device__ __forceinline__ v2s vmin(v2s a, v2s b) { return __builtin_elementwise_min(a, b); }
-__device__ __forceinline__ v2s ad(v2s a, v2s b) { const v2s d = a - b; return vmax(d, -d); }      // |a - b|
-// x > lim ? -1 : 0 per half.  The empty asm hides the subtraction from LLVM, which would otherwise turn
-// the shift into a compare-and-select that gfx950 can only do one half at a time.
-__device__ __forceinline__ v2s gt(v2s x, v2s lim)
+__device__ __forceinline__ v2s as_v2s(u32 v) { return __builtin_bit_cast(v2s, v); }
+__device__ __forceinline__ v2u mku(int v) { return (v2u){ (unsigned short)v, (unsigned short)v }; }
+__device__ __forceinline__ v2s mks(int v) { return (v2s){ (short)v, (short)v }; }
+__device__ __forceinline__ v2u umax(v2u a, v2u b) { return __builtin_elementwise_max(a, b); }
+__device__ __forceinline__ v2u umin(v2u a, v2u b) { return __builtin_elementwise_min(a, b); }
+__device__ __forceinline__ v2u adu(v2u a, v2u b) { return umax(a, b) - umin(a, b); }                  // |a - b|
+__device__ __forceinline__ v2u usubs(v2u a, v2u b) { return __builtin_elementwise_sub_sat(a, b); }    // max(a - b, 0)
+__device__ __forceinline__ v2u uadds(v2u a, v2u b) { return __builtin_elementwise_add_sat(a, b); }
+__device__ __forceinline__ v2s adds(v2s a, v2s b) { return __builtin_elementwise_add_sat(a, b); }     // signed-char clamp
+__device__ __forceinline__ v2s subs(v2s a, v2s b) { return __builtin_elementwise_sub_sat(a, b); }
+// x != 0 ? 0 : 0xffff (nz_clear) and x != 0 ? 0xffff : 0 (nz_set) per half.  The empty asm hides the 0/1 value from
+// LLVM, which would otherwise turn the subtraction into a compare-and-select that gfx950 does one half at a time.
+__device__ __forceinline__ v2u nz01(v2u x) { v2u t = umin(x, mku(1)); asm("" : "+v"(t)); return t; }
+__device__ __forceinline__ v2u nz_clear(v2u x) { return nz01(x) - mku(1); }
+__device__ __forceinline__ v2u nz_set(v2u x) { return mku(0) - nz01(x); }
+__device__ __forceinline__ v2s sgn(v2u p) { return as_v2s(as_u32(p) ^ 0x80008000u); }                // pixel -> signed
+__device__ __forceinline__ v2u pix(v2s s) { return as_v2u(as_u32(s) ^ 0x80008000u); }
+__device__ __forceinline__ v2s hib(v2s v) { return as_v2s(as_u32(v) & 0xff00ff00u); }                // floor to a whole byte
+
+struct Lim { v2u mblim, blim, lim, thr; };     // the limits, << 8
+
+// The filters are branch-free: `gate` (0xffff / 0 per lane) switches an edge off by clearing its filter mask,
+// which makes every update the identity.  Straight-line code lets the scheduler interleave the independent
+// pixel-line pairs, which is what hides the wait state gfx950 wants between dependent packed-math ops.
+
+// vp8_filter_mask + vp8_hevmask (loopfilter_filters.c:27-49) for p[0..7] = p3 p2 p1 p0 q0 q1 q2 q3:
+// mask = 0xffff where the edge is filtered, hev = 0xffff where the high-edge-variance rule applies
+__device__ __forceinline__ void masks(const v2u p[8], v2u lim, v2u elim, v2u thr, v2u gate, v2u &mask, v2u &hev)
 {
-    v2s d = lim - x;
-    asm("" : "+v"(d));
-    return d >> 15;
+    const v2u d10 = adu(p[2], p[3]), dq = adu(p[5], p[4]);
+    const v2u dh = umax(d10, dq);
+    v2u m = umax(umax(adu(p[0], p[1]), adu(p[1], p[2])), dh);
+    m = umax(m, umax(adu(p[6], p[5]), adu(p[7], p[6])));
+    const v2u a = adu(p[3], p[4]);
+    const v2u e = uadds(uadds(a, a), (adu(p[2], p[5]) >> 1) & mku(0xff00));      // 2|p0-q0| + |p1-q1|/2, saturating
+    const v2u over = usubs(m, lim) | usubs(e, elim);                              // non-zero: leave the edge alone
+    mask = nz_clear(over) & gate;
+    hev = nz_set(usubs(dh, thr));
 }
-__device__ __forceinline__ v2s sc(v2s x) { return vmax(vmin(x, mk(127)), mk(-128)); }           // vp8_signed_char_clamp
 
-struct Lim { v2s mblim, blim, lim, thr; };
-
-// The filters below are branch-free: `gate` (-1 / 0 per lane) switches an edge off by clearing its filter
-// mask, which makes every update the identity.  Straight-line code lets the scheduler interleave the
-// independent pixel-line pairs, which is what hides the one wait state gfx950 wants between dependent
-// packed-math instructions.
-
-// vp8_filter_mask + vp8_hevmask (loopfilter_filters.c:27-49) for p[0..7] = p3 p2 p1 p0 q0 q1 q2 q3
-__device__ __forceinline__ void masks(const v2s p[8], v2s lim, v2s elim, v2s thr, v2s gate, v2s &mask, v2s &hev)
+// filter_value = clamp(filter_value + 3 * (qs0 - ps0)) (loopfilter_filters.c:66, 176): three saturating adds of
+// the saturated difference give the same result as one clamp of the exact sum (same-signed increments)
+__device__ __forceinline__ v2s add3w(v2s f, v2s qs0, v2s ps0)
 {
-    const v2s d10 = ad(p[2], p[3]), dq = ad(p[5], p[4]);
-    v2s m = vmax(vmax(ad(p[0], p[1]), ad(p[1], p[2])), vmax(d10, dq));
-    m = vmax(m, vmax(ad(p[6], p[5]), ad(p[7], p[6])));
-    const v2s e = (ad(p[3], p[4]) << 1) + (ad(p[2], p[5]) >> 1);
-    mask = ~(gt(m, lim) | gt(e, elim)) & gate;
-    hev = gt(vmax(d10, dq), thr);
+    const v2s w = subs(qs0, ps0);
+    return adds(adds(adds(f, w), w), w);
 }
 
 // vp8_loop_filter_c (loopfilter_filters.c:51-95): inner edges, modifies p1 p0 q0 q1
-__device__ __forceinline__ void lf_inner(v2s p[8], const Lim &L, v2s gate)
+__device__ __forceinline__ void lf_inner(v2u p[8], const Lim &L, v2u gate)
 {
-    v2s mask, hev;
+    v2u mask, hev;
     masks(p, L.lim, L.blim, L.thr, gate, mask, hev);
-    v2s ps1 = p[2] - 128, ps0 = p[3] - 128, qs0 = p[4] - 128, qs1 = p[5] - 128;
-    v2s f = sc(ps1 - qs1) & hev;
-    f = sc(f + (qs0 - ps0) * 3) & mask;
-    const v2s f1 = vmin(f + 4, mk(127)) >> 3, f2 = vmin(f + 3, mk(127)) >> 3;
-    qs0 = sc(qs0 - f1); ps0 = sc(ps0 + f2);
-    f = ((f1 + 1) >> 1) & ~hev;
-    qs1 = sc(qs1 - f); ps1 = sc(ps1 + f);
-    p[2] = ps1 + 128; p[3] = ps0 + 128; p[4] = qs0 + 128; p[5] = qs1 + 128;
+    v2s ps1 = sgn(p[2]), ps0 = sgn(p[3]), qs0 = sgn(p[4]), qs1 = sgn(p[5]);
+    v2s f = as_v2s(as_u32(subs(ps1, qs1)) & as_u32(hev));
+    f = as_v2s(as_u32(add3w(f, qs0, ps0)) & as_u32(mask));
+    const v2s f1 = hib(adds(f, mks(0x0400)) >> 3), f2 = hib(adds(f, mks(0x0300)) >> 3);
+    qs0 = subs(qs0, f1); ps0 = adds(ps0, f2);
+    f = as_v2s(as_u32((f1 + mks(0x0100)) >> 1) & (~as_u32(hev) & 0xff00ff00u));
+    qs1 = subs(qs1, f); ps1 = adds(ps1, f);
+    p[2] = pix(ps1); p[3] = pix(ps0); p[4] = pix(qs0); p[5] = pix(qs1);
 }
 
 // vp8_mbloop_filter_c (loopfilter_filters.c:161-214): macroblock edges, modifies p2 p1 p0 q0 q1 q2
-__device__ __forceinline__ void lf_mbedge(v2s p[8], const Lim &L, v2s gate)
+__device__ __forceinline__ void lf_mbedge(v2u p[8], const Lim &L, v2u gate)
 {
-    v2s mask, hev;
+    v2u mask, hev;
     masks(p, L.lim, L.mblim, L.thr, gate, mask, hev);
-    v2s ps2 = p[1] - 128, ps1 = p[2] - 128, ps0 = p[3] - 128, qs0 = p[4] - 128, qs1 = p[5] - 128, qs2 = p[6] - 128;
-    v2s f = sc(ps1 - qs1);
-    f = sc(f + (qs0 - ps0) * 3) & mask;
-    v2s f2 = f & hev;
-    const v2s f1 = vmin(f2 + 4, mk(127)) >> 3;
-    f2 = vmin(f2 + 3, mk(127)) >> 3;
-    qs0 = sc(qs0 - f1); ps0 = sc(ps0 + f2);
-    f = f & ~hev;
-    v2s u = (f * 27 + 63) >> 7;
-    qs0 = sc(qs0 - u); ps0 = sc(ps0 + u);
-    u = (f * 18 + 63) >> 7;
-    qs1 = sc(qs1 - u); ps1 = sc(ps1 + u);
-    u = (f * 9 + 63) >> 7;
-    qs2 = sc(qs2 - u); ps2 = sc(ps2 + u);
-    p[1] = ps2 + 128; p[2] = ps1 + 128; p[3] = ps0 + 128; p[4] = qs0 + 128; p[5] = qs1 + 128; p[6] = qs2 + 128;
+    v2s ps2 = sgn(p[1]), ps1 = sgn(p[2]), ps0 = sgn(p[3]), qs0 = sgn(p[4]), qs1 = sgn(p[5]), qs2 = sgn(p[6]);
+    v2s f = as_v2s(as_u32(add3w(subs(ps1, qs1), qs0, ps0)) & as_u32(mask));
+    v2s f2 = as_v2s(as_u32(f) & as_u32(hev));
+    const v2s f1 = hib(adds(f2, mks(0x0400)) >> 3);
+    f2 = hib(adds(f2, mks(0x0300)) >> 3);
+    qs0 = subs(qs0, f1); ps0 = adds(ps0, f2);
+    const v2s F = as_v2s(as_u32(f) & ~as_u32(hev)) >> 8;             // plain signed value, -128 .. 127
+    v2s u = ((F * 27 + 63) >> 7) << 8;
+    qs0 = subs(qs0, u); ps0 = adds(ps0, u);
+    u = ((F * 18 + 63) >> 7) << 8;
+    qs1 = subs(qs1, u); ps1 = adds(ps1, u);
+    u = ((F * 9 + 63) >> 7) << 8;
+    qs2 = subs(qs2, u); ps2 = adds(ps2, u);
+    p[1] = pix(ps2); p[2] = pix(ps1); p[3] = pix(ps0); p[4] = pix(qs0); p[5] = pix(qs1); p[6] = pix(qs2);
 }
 
 // vp8_loop_filter_simple_horizontal/vertical_edge_c (loopfilter_filters.c:292-355): modifies p0 q0
-__device__ __forceinline__ void lf_simple(v2s p[8], v2s elim, v2s gate)
+__device__ __forceinline__ void lf_simple(v2u p[8], v2u elim, v2u gate)
 {
-    const v2s mask = ~gt((ad(p[3], p[4]) << 1) + (ad(p[2], p[5]) >> 1), elim) & gate;
-    v2s ps1 = p[2] - 128, ps0 = p[3] - 128, qs0 = p[4] - 128, qs1 = p[5] - 128;
-    v2s f = sc(ps1 - qs1);
-    f = sc(f + (qs0 - ps0) * 3) & mask;
-    const v2s f1 = vmin(f + 4, mk(127)) >> 3, f2 = vmin(f + 3, mk(127)) >> 3;
-    p[4] = sc(qs0 - f1) + 128; p[3] = sc(ps0 + f2) + 128;
+    const v2u a = adu(p[3], p[4]);
+    const v2u e = uadds(uadds(a, a), (adu(p[2], p[5]) >> 1) & mku(0xff00));
+    const v2u mask = nz_clear(usubs(e, elim)) & gate;
+    v2s ps1 = sgn(p[2]), ps0 = sgn(p[3]), qs0 = sgn(p[4]), qs1 = sgn(p[5]);
+    const v2s f = as_v2s(as_u32(add3w(subs(ps1, qs1), qs0, ps0)) & as_u32(mask));
+    const v2s f1 = hib(adds(f, mks(0x0400)) >> 3), f2 = hib(adds(f, mks(0x0300)) >> 3);
+    p[4] = pix(subs(qs0, f1)); p[3] = pix(adds(ps0, f2));
 }
 
 // which filters the lanes of the wave need (wave-uniform) and each lane's gates
-struct Gates { v2s mb, inner, mb_s, inner_s; bool any_normal, any_simple; };
+struct Gates { v2u mb, inner, mb_s, inner_s; bool any_normal, any_simple; };
 
 // All edges of two pixel lines: a[0..4*W4+3] = positions -4 .. 4*W4-1 across the macroblock.  Order and
 // gating as vp8_loop_filter_frame (loopfilter.c:265-299): the MB edge at 0 (if there is a neighbour),
 // then the inner edges at 4, 8, 12 (if !skip_lf).
 template <int W4>
-__device__ __forceinline__ void filter_lines(v2s *a, const Gates &G, const Lim &L)
+__device__ __forceinline__ void filter_lines(v2u *a, const Gates &G, const Lim &L)
 {
     if (G.any_normal) {
         lf_mbedge(a, L, G.mb);
@@ -151,7 +174,7 @@ __device__ __forceinline__ void filter_lines(v2s *a, const Gates &G, const Lim &
 }
 // the same for two independent sets of lines at once (more instruction-level parallelism)
 template <int W4>
-__device__ __forceinline__ void filter_lines2(v2s *a, v2s *b, const Gates &G, const Lim &L)
+__device__ __forceinline__ void filter_lines2(v2u *a, v2u *b, const Gates &G, const Lim &L)
 {
     if (G.any_normal) {
         lf_mbedge(a, L, G.mb); lf_mbedge(b, L, G.mb);
@@ -166,23 +189,23 @@ __device__ __forceinline__ void filter_lines2(v2s *a, v2s *b, const Gates &G, co
 }
 
 template <int NX>
-__device__ __forceinline__ void unpack_rows(const u32 *ra, const u32 *rb, v2s *a)
+__device__ __forceinline__ void unpack_rows(const u32 *ra, const u32 *rb, v2u *a)
 {
 #pragma unroll
     for (int x = 0; x < NX; x++) {
         const u32 A = ra[x * 64], B = rb[x * 64];
-        a[4 * x + 0] = as_v2s(perm(B, A, 0x0c040c00u)); a[4 * x + 1] = as_v2s(perm(B, A, 0x0c050c01u));
-        a[4 * x + 2] = as_v2s(perm(B, A, 0x0c060c02u)); a[4 * x + 3] = as_v2s(perm(B, A, 0x0c070c03u));
+        a[4 * x + 0] = as_v2u(perm(B, A, 0x040c000cu)); a[4 * x + 1] = as_v2u(perm(B, A, 0x050c010cu));
+        a[4 * x + 2] = as_v2u(perm(B, A, 0x060c020cu)); a[4 * x + 3] = as_v2u(perm(B, A, 0x070c030cu));
     }
 }
 template <int NX>
-__device__ __forceinline__ void pack_rows(u32 *ra, u32 *rb, const v2s *a)
+__device__ __forceinline__ void pack_rows(u32 *ra, u32 *rb, const v2u *a)
 {
 #pragma unroll
     for (int x = 0; x < NX; x++) {
         const u32 p01 = as_u32(a[4 * x]), p11 = as_u32(a[4 * x + 1]), p21 = as_u32(a[4 * x + 2]), p31 = as_u32(a[4 * x + 3]);
-        ra[x * 64] = perm(perm(p31, p21, 0x0c0c0400u), perm(p11, p01, 0x0c0c0400u), 0x05040100u);
-        rb[x * 64] = perm(perm(p31, p21, 0x0c0c0602u), perm(p11, p01, 0x0c0c0602u), 0x05040100u);
+        ra[x * 64] = perm(perm(p31, p21, 0x0c0c0501u), perm(p11, p01, 0x0c0c0501u), 0x05040100u);
+        rb[x * 64] = perm(perm(p31, p21, 0x0c0c0703u), perm(p11, p01, 0x0c0c0703u), 0x05040100u);
     }
 }
 
@@ -197,7 +220,7 @@ __device__ __forceinline__ void filter_plane(u32 *T, const Gates &gv, const Gate
 #pragma unroll 1
     for (int rp = 0; rp < H / 4; rp++) {
         u32 *r0 = T + (4 + 4 * rp) * NX * 64, *r1 = r0 + NX * 64, *r2 = r1 + NX * 64, *r3 = r2 + NX * 64;
-        v2s a[4 * NX], b[4 * NX];
+        v2u a[4 * NX], b[4 * NX];
         unpack_rows<NX>(r0, r1, a);
         unpack_rows<NX>(r2, r3, b);
         filter_lines2<W4>(a, b, gv, L);
@@ -208,16 +231,16 @@ __device__ __forceinline__ void filter_plane(u32 *T, const Gates &gv, const Gate
 #pragma unroll 1
     for (int xd = 1; xd <= W4; xd++) {
         u32 *col = T + xd * 64;
-        v2s lo[H + 4], hi[H + 4];
+        v2u lo[H + 4], hi[H + 4];
 #pragma unroll
         for (int y = 0; y < H + 4; y++) {
             const u32 D = col[y * NX * 64];
-            lo[y] = as_v2s(perm(D, D, 0x0c010c00u));
-            hi[y] = as_v2s(perm(D, D, 0x0c030c02u));
+            lo[y] = as_v2u(perm(D, D, 0x010c000cu));
+            hi[y] = as_v2u(perm(D, D, 0x030c020cu));
         }
         filter_lines2<H / 4>(lo, hi, gh, L);
 #pragma unroll
-        for (int y = 1; y < H + 4; y++) col[y * NX * 64] = perm(as_u32(hi[y]), as_u32(lo[y]), 0x06040200u);
+        for (int y = 1; y < H + 4; y++) col[y * NX * 64] = perm(as_u32(hi[y]), as_u32(lo[y]), 0x07050301u);
     }
 }
 
@@ -254,8 +277,8 @@ __device__ __forceinline__ Lim mb_limits(int sharp, int level, int frame_type)
     else if (level >= 15) thr = 1;
     else thr = 0;
     Lim L;
-    L.lim = mk(ilimit); L.blim = mk((2 * level + ilimit) & 0xff); L.mblim = mk((2 * (level + 2) + ilimit) & 0xff);
-    L.thr = mk(thr);
+    L.lim = mku(ilimit << 8); L.blim = mku(((2 * level + ilimit) & 0xff) << 8); L.mblim = mku(((2 * (level + 2) + ilimit) & 0xff) << 8);
+    L.thr = mku(thr << 8);
     return L;
 }
 
@@ -357,12 +380,12 @@ vp8_loopfilter_simt_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g
             const bool any_normal = __builtin_amdgcn_ballot_w64(on && !simple) != 0;
             const bool any_simple = __builtin_amdgcn_ballot_w64(on && simple) != 0;
 #endif
-            auto gate = [](bool b) { return mk(b ? -1 : 0); };
+            auto gate = [](bool b) { return mku(b ? 0xffff : 0); };
             const Gates gvY = { gate(mbv && !simple), gate(inner && !simple), gate(mbv && simple), gate(inner && simple), any_normal, any_simple };
             const Gates ghY = { gate(mbh && !simple), gate(inner && !simple), gate(mbh && simple), gate(inner && simple), any_normal, any_simple };
             // the simple filter leaves chroma alone (loopfilter.c:283-299)
-            const Gates gvC = { gvY.mb, gvY.inner, mk(0), mk(0), any_normal, false };
-            const Gates ghC = { ghY.mb, ghY.inner, mk(0), mk(0), any_normal, false };
+            const Gates gvC = { gvY.mb, gvY.inner, mku(0), mku(0), any_normal, false };
+            const Gates ghC = { ghY.mb, ghY.inner, mku(0), mku(0), any_normal, false };
             const bool last_col = c == cols - 1;
             // lines another lane would otherwise finish are written here when nobody below takes them over
             const bool write_bottom = pos == G - 1 || r == rows - 1;

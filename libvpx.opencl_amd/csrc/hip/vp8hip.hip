@@ -299,7 +299,12 @@ extern "C" int vp8hip_decode(vp8hip_ctx *c, const vp8hip_job *jobs, int njobs, i
     bool any_lf = false;
     // Which reconstruction kernel: the wave-per-MB-row kernel is the faster one while a launch has fewer
     // frames than the chip has SIMDs to fill; the one-MB-row-per-lane kernel wins beyond that.
-    bool simt_recon = (stages & VP8HIP_STAGE_RECON) && njobs >= 3 * c->num_cu;
+    // (Its inter prediction still works 4x4 block by 4x4 block and loses to the wave-per-row kernel on inter
+    // frames, so launches that contain inter frames stay with the latter.)
+    bool all_key = true;
+    for (int i = 0; i < njobs && all_key; i++)
+        if (jobs[i].ir_slot >= 0 && jobs[i].ir_slot < nsl) all_key = c->slots[jobs[i].ir_slot].hdr_copy.frame_type == 0;
+    bool simt_recon = (stages & VP8HIP_STAGE_RECON) && all_key && njobs >= 3 * c->num_cu;
     if (const char *e = getenv("VP8HIP_RECON"))      // tuning / test knob: force one of the two kernel families
         simt_recon = (stages & VP8HIP_STAGE_RECON) && (!strcmp(e, "simt") ? true : (!strcmp(e, "wave") ? false : simt_recon));
     // the lane-per-row kernels work on macroblock-tiled scratch frames; vp8_detile_kernel converts at the end

@@ -36,14 +36,36 @@ def make(kind):
 jobs = (P.Job * F)()
 for i in range(F):
     jobs[i].ir_slot, jobs[i].dst_fb = i, i
-for kind in ("dc_skip", "dc_dense", "tm_dense", "bpred_skip", "bpred_dense"):
-    hdr, mbs, coef, mvs = make(kind)
+def make_inter(split):
+    hdr, mbs, coef, mvs = synth_ir(W, H, 7, inter=True, dense=0.3, segmented=False)
+    hdr.filter_level = 20; hdr.mode_ref_lf_delta_enabled = 0; hdr.sharpness_level = 0
+    if not split:
+        sel = mbs[:, 0] == 9
+        mbs[sel, 0] = 8
+        mvs[sel, :] = mvs[sel, :1]
+    return hdr, mbs, coef, mvs
+
+KINDS = ("dc_skip", "dc_dense", "tm_dense", "bpred_skip", "bpred_dense", "inter_nosplit", "inter_mixed")
+if len(sys.argv) > 2:
+    KINDS = tuple(sys.argv[2].split(","))
+from vp8_testlib import random_frame
+for k in range(3):
+    ctx.upload_frame(F - 1 - k, random_frame(ctx.g, 50 + k)) if False else None
+for kind in KINDS:
+    inter = kind.startswith("inter")
+    hdr, mbs, coef, mvs = make_inter(kind == "inter_mixed") if inter else make(kind)
+    if inter:   # every job reads the same three reference buffers (the last three of the pool), decodes elsewhere
+        for i in range(F):
+            jobs[i].ref_fb[1], jobs[i].ref_fb[2], jobs[i].ref_fb[3] = F - 1, F - 2, F - 3
+        njobs = F - 3
+    else:
+        njobs = F
     ctx.fill_slot(0, hdr, mbs, coef, mvs)
     for i in range(1, F): ctx.ir_copy(i, 0)
-    ctx.decode_array(jobs, F, 7); ctx.sync()
+    ctx.decode_array(jobs, njobs, 7); ctx.sync()
     r = l = 0.0
     for _ in range(3):
-        ctx.decode_array(jobs, F, 7); st = ctx.stats(); r += st.recon_ms; l += st.lf_ms
+        ctx.decode_array(jobs, njobs, 7); st = ctx.stats(); r += st.recon_ms; l += st.lf_ms
     r /= 3; l /= 3
     per_mb_ns = r * 1e6 / (F * n)
     print(f"{kind:12s} recon {r:8.3f} ms  lf {l:8.3f} ms   recon {per_mb_ns*256/1:8.1f} ns per MB per CU   ({F*n*1217/r/1e6:7.1f} GB/s alg)")
