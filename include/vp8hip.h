@@ -96,9 +96,14 @@ int  vp8hip_frame_copy(vp8hip_ctx *ctx, int dst_fb, int src_fb);
 
 int  vp8hip_sync(vp8hip_ctx *ctx);
 int  vp8hip_get_stats(vp8hip_ctx *ctx, vp8hip_stats *st);
-/* The HIP stream (hipStream_t, as void*) all work of this context is enqueued on, so callers
- * can bracket it with their own events. */
+/* The HIP stream (hipStream_t, as void*) the work of this context is enqueued on, so callers can
+ * bracket it with their own events.  One exception: after a large all-key-frame launch the last pass
+ * (tiled scratch -> raster frame buffer + borders) runs on a second, internal stream so that it overlaps
+ * the next launch.  Every vp8hip_* call that touches frame buffers orders itself behind it; a caller that
+ * enqueues its OWN work on vp8hip_stream() to read frame buffers calls vp8hip_join() first, which makes the
+ * stream wait (on the device, not the host) for that pass. */
 void *vp8hip_stream(vp8hip_ctx *ctx);
+int  vp8hip_join(vp8hip_ctx *ctx);
 
 #ifdef __cplusplus
 }

@@ -34,6 +34,13 @@ struct vp8hip_ctx {
     hipStream_t stream;
     hipEvent_t ev[4];
     hipEvent_t ev_jobs;            // job table of the previous call has been copied
+    // The tiled -> raster pass of the lane-per-row pipeline is memory-bound while recon and loop filter are
+    // VALU-bound, so it runs on a second stream and overlaps the NEXT launch's recon.  Two scratch frame sets
+    // and two device job tables alternate; any other use of the frame buffers first joins the second stream.
+    hipStream_t stream2;
+    hipEvent_t ev_lf_done, ev_detile_done[2], ev_dt[2];
+    bool detile_used[2], detile_pending;
+    int parity;
     char err[256];
     // geometry
     int width, height;
@@ -44,15 +51,15 @@ struct vp8hip_ctx {
     std::vector<uint8_t *> fb;
     std::vector<Slot> slots;
     uint8_t *fb_block; char *slot_block_dev;
-    uint8_t *tile_block; size_t tile_cap;     // macroblock-tiled scratch frames of the one-MB-row-per-lane pipeline
+    uint8_t *tile_block[2]; size_t tile_cap[2];   // macroblock-tiled scratch frames of the lane-per-row pipeline
     size_t slot_bytes, o_mbs, o_coef, o_mvs;
     // job staging
-    DevJob *d_jobs; DevJob *h_jobs; int jobs_cap;
+    DevJob *d_jobs2[2]; DevJob *d_jobs; DevJob *h_jobs; int jobs_cap;   // d_jobs = d_jobs2[parity of the call]
     // launch configuration
     int num_cu, max_lds;
     int recon_nw, lf_nw;
     size_t recon_lds, lf_lds;
-    bool have_times;
+    bool have_times, times_tiled;
     vp8hip_stats stats;
 };
 
@@ -75,12 +82,12 @@ extern "C" const char *vp8hip_last_error(const vp8hip_ctx *ctx) { return ctx ? c
 static void free_pools(vp8hip_ctx *c)
 {
     if (c->fb_block) (void)hipFree(c->fb_block);
-    if (c->tile_block) (void)hipFree(c->tile_block);
-    c->tile_block = nullptr; c->tile_cap = 0;
+    for (int k = 0; k < 2; k++) { if (c->tile_block[k]) (void)hipFree(c->tile_block[k]); c->tile_block[k] = nullptr; c->tile_cap[k] = 0; }
     if (c->slot_block_dev) (void)hipFree(c->slot_block_dev);
     for (Slot &s : c->slots)
         if (s.h_block) (void)hipHostFree(s.h_block);
-    c->fb_block = nullptr; c->slot_block_dev = nullptr; c->tile_block = nullptr; c->tile_cap = 0;
+    c->fb_block = nullptr; c->slot_block_dev = nullptr;
+    for (int k = 0; k < 2; k++) { c->tile_block[k] = nullptr; c->tile_cap[k] = 0; }
     c->fb.clear(); c->slots.clear();
 }
 
@@ -108,22 +115,32 @@ extern "C" int vp8hip_create(int device, vp8hip_ctx **out)
     c->device = device;
     c->num_cu = prop.multiProcessorCount;
     c->max_lds = 160 * 1024;
-    c->fb_block = nullptr; c->slot_block_dev = nullptr; c->tile_block = nullptr; c->tile_cap = 0;
-    c->d_jobs = nullptr; c->h_jobs = nullptr; c->jobs_cap = 0;
+    c->fb_block = nullptr; c->slot_block_dev = nullptr;
+    for (int k = 0; k < 2; k++) { c->tile_block[k] = nullptr; c->tile_cap[k] = 0; }
+    c->d_jobs = nullptr; c->d_jobs2[0] = c->d_jobs2[1] = nullptr; c->h_jobs = nullptr; c->jobs_cap = 0;
+    c->detile_used[0] = c->detile_used[1] = false; c->detile_pending = false; c->parity = 0;
     c->width = c->height = 0;
-    c->have_times = false;
+    c->have_times = false; c->times_tiled = false;
     memset(&c->stats, 0, sizeof c->stats);
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) {
         fail(nullptr, -1, "hipStreamCreate: %s", hipGetErrorString(e));
         delete c;
         return -1;
     }
+    if ((e = hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking)) != hipSuccess) {
+        fail(nullptr, -1, "hipStreamCreate: %s", hipGetErrorString(e));
+        (void)hipStreamDestroy(c->stream);
+        delete c;
+        return -1;
+    }
     for (int i = 0; i < 4; i++) (void)hipEventCreate(&c->ev[i]);
     (void)hipEventCreateWithFlags(&c->ev_jobs, hipEventDisableTiming);
+    (void)hipEventCreateWithFlags(&c->ev_lf_done, hipEventDisableTiming);
+    for (int k = 0; k < 2; k++) { (void)hipEventCreateWithFlags(&c->ev_detile_done[k], hipEventDisableTiming); (void)hipEventCreate(&c->ev_dt[k]); }
     e = hipFuncSetAttribute((const void *)vp8_recon_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_lds);
     if (e != hipSuccess) {
         fail(nullptr, -1, "hipFuncSetAttribute(recon, %d B LDS): %s", c->max_lds, hipGetErrorString(e));
-        (void)hipStreamDestroy(c->stream);
+        (void)hipStreamDestroy(c->stream); (void)hipStreamDestroy(c->stream2);
         delete c;
         return -1;
     }
@@ -143,12 +160,16 @@ extern "C" void vp8hip_destroy(vp8hip_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    (void)hipStreamSynchronize(c->stream2);
     free_pools(c);
-    if (c->d_jobs) (void)hipFree(c->d_jobs);
+    for (int k = 0; k < 2; k++) if (c->d_jobs2[k]) (void)hipFree(c->d_jobs2[k]);
     if (c->h_jobs) (void)hipHostFree(c->h_jobs);
     for (int i = 0; i < 4; i++) (void)hipEventDestroy(c->ev[i]);
     (void)hipEventDestroy(c->ev_jobs);
+    (void)hipEventDestroy(c->ev_lf_done);
+    for (int k = 0; k < 2; k++) { (void)hipEventDestroy(c->ev_detile_done[k]); (void)hipEventDestroy(c->ev_dt[k]); }
     (void)hipStreamDestroy(c->stream);
+    (void)hipStreamDestroy(c->stream2);
     delete c;
 }
 
@@ -165,6 +186,8 @@ extern "C" int vp8hip_configure(vp8hip_ctx *c, int width, int height, int num_fb
         return fail(c, -2, "vp8hip_configure: bad arguments %dx%d fb=%d slots=%d", width, height, num_fb, num_slots);
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream2));
+    c->detile_pending = false; c->detile_used[0] = c->detile_used[1] = false;
     free_pools(c);
     c->width = width; c->height = height;
     vp8ir_geom_init(&c->geom, width, height);
@@ -278,6 +301,24 @@ extern "C" int vp8hip_ir_copy(vp8hip_ctx *c, int dst, int src)
     return 0;
 }
 
+// Make the main stream wait for a tiled -> raster pass still running on the second stream.  Every entry point
+// that reads or writes frame buffers (other than another lane-per-row launch, which is ordered behind it on
+// the second stream anyway) calls this first.
+static int join_detile(vp8hip_ctx *c)
+{
+    if (c->detile_pending) {
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_detile_done[c->parity ^ 1], 0));
+        c->detile_pending = false;
+    }
+    return 0;
+}
+extern "C" int vp8hip_join(vp8hip_ctx *c)
+{
+    if (!c) return -2;
+    HIPCHK(c, hipSetDevice(c->device));
+    return join_detile(c);
+}
+
 extern "C" int vp8hip_decode(vp8hip_ctx *c, const vp8hip_job *jobs, int njobs, int stages)
 {
     if (!c || !jobs || njobs <= 0) return fail(c, -2, "vp8hip_decode: bad arguments");
@@ -286,10 +327,11 @@ extern "C" int vp8hip_decode(vp8hip_ctx *c, const vp8hip_job *jobs, int njobs, i
     if (njobs > c->jobs_cap) {
         // the staging arrays are reused by in-flight launches: drain before growing
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        if (c->d_jobs) (void)hipFree(c->d_jobs);
+        HIPCHK(c, hipStreamSynchronize(c->stream2));
+        for (int k = 0; k < 2; k++) if (c->d_jobs2[k]) (void)hipFree(c->d_jobs2[k]);
         if (c->h_jobs) (void)hipHostFree(c->h_jobs);
         c->jobs_cap = njobs < 64 ? 64 : njobs;
-        HIPCHK(c, hipMalloc((void **)&c->d_jobs, sizeof(DevJob) * c->jobs_cap));
+        for (int k = 0; k < 2; k++) HIPCHK(c, hipMalloc((void **)&c->d_jobs2[k], sizeof(DevJob) * c->jobs_cap));
         HIPCHK(c, hipHostMalloc((void **)&c->h_jobs, sizeof(DevJob) * c->jobs_cap, hipHostMallocDefault));
     } else {
         // h_jobs is read by an async copy of the previous call; wait for that copy only
@@ -310,13 +352,22 @@ extern "C" int vp8hip_decode(vp8hip_ctx *c, const vp8hip_job *jobs, int njobs, i
     // the lane-per-row kernels work on macroblock-tiled scratch frames; vp8_detile_kernel converts at the end
     const bool tiled = simt_recon;
     const size_t tile_frame = (size_t)c->nmb * VP8_TILE_BYTES;
-    if (tiled && c->tile_cap < tile_frame * njobs) {
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        if (c->tile_block) (void)hipFree(c->tile_block);
-        c->tile_block = nullptr; c->tile_cap = 0;
-        HIPCHK(c, hipMalloc((void **)&c->tile_block, tile_frame * njobs));
-        c->tile_cap = tile_frame * njobs;
+    const int par = c->parity;
+    if (!tiled) {
+        if (join_detile(c)) return -1;             // this launch touches the raster frame buffers directly
+    } else {
+        // scratch set and job table `par` were last read by the tiled -> raster pass two launches ago
+        if (c->detile_used[par]) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_detile_done[par], 0));
+        if (c->tile_cap[par] < tile_frame * njobs) {
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream2));
+            if (c->tile_block[par]) (void)hipFree(c->tile_block[par]);
+            c->tile_block[par] = nullptr; c->tile_cap[par] = 0;
+            HIPCHK(c, hipMalloc((void **)&c->tile_block[par], tile_frame * njobs));
+            c->tile_cap[par] = tile_frame * njobs;
+        }
     }
+    c->d_jobs = c->d_jobs2[par];
     for (int i = 0; i < njobs; i++) {
         const vp8hip_job &j = jobs[i];
         if (j.ir_slot < 0 || j.ir_slot >= nsl || j.dst_fb < 0 || j.dst_fb >= nfb)
@@ -326,7 +377,7 @@ extern "C" int vp8hip_decode(vp8hip_ctx *c, const vp8hip_job *jobs, int njobs, i
         d.hdr = s.hdr_copy;
         d.mbs = s.d_mbs; d.coef = s.d_coef; d.mvs = s.d_mvs;
         d.dst = c->fb[j.dst_fb];
-        d.ref[0] = tiled ? c->tile_block + tile_frame * i : nullptr;
+        d.ref[0] = tiled ? c->tile_block[par] + tile_frame * i : nullptr;
         for (int k = 1; k < 4; k++) {
             d.ref[k] = nullptr;
             if (s.hdr_copy.frame_type == 0) continue;          // key frames read no reference
@@ -393,9 +444,20 @@ extern "C" int vp8hip_decode(vp8hip_ctx *c, const vp8hip_job *jobs, int njobs, i
     }
     HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
     if (tiled) {      // whatever stages ran, the frame buffer gets the result; borders are extended on the way
-        hipLaunchKernelGGL(vp8_detile_kernel, dim3(c->dg.mb_rows, njobs), dim3(256), 0, c->stream, (const DevJob *)c->d_jobs, njobs, c->dg,
+        const bool own_stream = !(getenv("VP8HIP_DETILE_STREAM") && !atoi(getenv("VP8HIP_DETILE_STREAM")));
+        hipStream_t ds = own_stream ? c->stream2 : c->stream;
+        if (own_stream) {
+            HIPCHK(c, hipEventRecord(c->ev_lf_done, c->stream));
+            HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_lf_done, 0));
+        }
+        HIPCHK(c, hipEventRecord(c->ev_dt[0], ds));
+        hipLaunchKernelGGL(vp8_detile_kernel, dim3(c->dg.mb_rows, njobs), dim3(256), 0, ds, (const DevJob *)c->d_jobs, njobs, c->dg,
                            (stages & VP8HIP_STAGE_EXTEND) ? 1 : 0);
         HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipEventRecord(c->ev_dt[1], ds));
+        HIPCHK(c, hipEventRecord(c->ev_detile_done[par], ds));
+        c->detile_used[par] = true; c->detile_pending = true; c->parity = par ^ 1;
+        c->times_tiled = true;
     } else if (stages & VP8HIP_STAGE_EXTEND) {
         int bx = (c->geom.aligned_h + 64) / 4;
         if (bx < 1) bx = 1;
@@ -404,6 +466,7 @@ extern "C" int vp8hip_decode(vp8hip_ctx *c, const vp8hip_job *jobs, int njobs, i
                            njobs, c->dg);
         HIPCHK(c, hipGetLastError());
     }
+    if (!tiled) c->times_tiled = false;
     HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
     c->have_times = true;
     return 0;
@@ -413,6 +476,7 @@ extern "C" int vp8hip_sync(vp8hip_ctx *c)
 {
     if (!c) return -2;
     HIPCHK(c, hipSetDevice(c->device));
+    if (join_detile(c)) return -1;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return 0;
 }
@@ -424,7 +488,11 @@ extern "C" int vp8hip_get_stats(vp8hip_ctx *c, vp8hip_stats *st)
         HIPCHK(c, hipEventSynchronize(c->ev[3]));
         (void)hipEventElapsedTime(&c->stats.recon_ms, c->ev[0], c->ev[1]);
         (void)hipEventElapsedTime(&c->stats.lf_ms, c->ev[1], c->ev[2]);
-        (void)hipEventElapsedTime(&c->stats.extend_ms, c->ev[2], c->ev[3]);
+        if (c->times_tiled) {
+            HIPCHK(c, hipEventSynchronize(c->ev_dt[1]));
+            (void)hipEventElapsedTime(&c->stats.extend_ms, c->ev_dt[0], c->ev_dt[1]);
+        } else
+            (void)hipEventElapsedTime(&c->stats.extend_ms, c->ev[2], c->ev[3]);
     }
     *st = c->stats;
     return 0;
@@ -437,6 +505,7 @@ extern "C" int vp8hip_frame_download(vp8hip_ctx *c, int fb, int full, uint8_t *y
 {
     if (!c || fb < 0 || fb >= (int)c->fb.size() || !y) return fail(c, -2, "vp8hip_frame_download: bad arguments");
     HIPCHK(c, hipSetDevice(c->device));
+    if (join_detile(c)) return -1;
     const vp8ir_geom &g = c->geom;
     if (full) {
         HIPCHK(c, hipMemcpyAsync(y, c->fb[fb], (size_t)g.frame_size, hipMemcpyDeviceToHost, c->stream));
@@ -458,6 +527,7 @@ extern "C" int vp8hip_frame_upload(vp8hip_ctx *c, int fb, const uint8_t *buf)
 {
     if (!c || fb < 0 || fb >= (int)c->fb.size() || !buf) return fail(c, -2, "vp8hip_frame_upload: bad arguments");
     HIPCHK(c, hipSetDevice(c->device));
+    if (join_detile(c)) return -1;
     HIPCHK(c, hipMemcpyAsync(c->fb[fb], buf, (size_t)c->geom.frame_size, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return 0;
@@ -468,6 +538,7 @@ extern "C" int vp8hip_frame_copy(vp8hip_ctx *c, int dst, int src)
     if (!c || dst < 0 || src < 0 || dst >= (int)c->fb.size() || src >= (int)c->fb.size())
         return fail(c, -2, "vp8hip_frame_copy: bad arguments");
     HIPCHK(c, hipSetDevice(c->device));
+    if (join_detile(c)) return -1;
     HIPCHK(c, hipMemcpyAsync(c->fb[dst], c->fb[src], (size_t)c->geom.frame_size, hipMemcpyDeviceToDevice, c->stream));
     return 0;
 }
