@@ -240,6 +240,7 @@ def load_hip():
         L.vp8hip_frame_upload.argtypes = [c_void_p, c_int, c_void_p]
         L.vp8hip_frame_copy.argtypes = [c_void_p, c_int, c_int]
         L.vp8hip_sync.argtypes = [c_void_p]
+        L.vp8hip_join.argtypes = [c_void_p]
         L.vp8hip_get_stats.argtypes = [c_void_p, c_void_p]
         L.vp8hip_stream.argtypes = [c_void_p]
         L.vp8hip_stream.restype = c_void_p
@@ -322,6 +323,10 @@ class Vp8Hip:
 
     def sync(self):
         self._chk(self.L.vp8hip_sync(self.h), "vp8hip_sync")
+
+    def join(self):
+        """Order the context's main stream behind a tiled->raster pass still running on the internal stream."""
+        self._chk(self.L.vp8hip_join(self.h), "vp8hip_join")
 
     def stats(self):
         s = Stats()
