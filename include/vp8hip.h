@@ -96,6 +96,9 @@ int  vp8hip_frame_copy(vp8hip_ctx *ctx, int dst_fb, int src_fb);
 
 int  vp8hip_sync(vp8hip_ctx *ctx);
 int  vp8hip_get_stats(vp8hip_ctx *ctx, vp8hip_stats *st);
+/* Stats of an earlier launch: back = 0 the last vp8hip_decode call, 1 the one before, ... (up to 31).  Waits
+ * for that launch only, so a caller can time a pipelined sequence and read the kernel times afterwards. */
+int  vp8hip_get_stats_at(vp8hip_ctx *ctx, int back, vp8hip_stats *st);
 /* The HIP stream (hipStream_t, as void*) the work of this context is enqueued on, so callers can
  * bracket it with their own events.  One exception: after a large all-key-frame launch the last pass
  * (tiled scratch -> raster frame buffer + borders) runs on a second, internal stream so that it overlaps

@@ -241,6 +241,7 @@ def load_hip():
         L.vp8hip_frame_copy.argtypes = [c_void_p, c_int, c_int]
         L.vp8hip_sync.argtypes = [c_void_p]
         L.vp8hip_join.argtypes = [c_void_p]
+        L.vp8hip_get_stats_at.argtypes = [c_void_p, c_int, ctypes.POINTER(Stats)]
         L.vp8hip_get_stats.argtypes = [c_void_p, c_void_p]
         L.vp8hip_stream.argtypes = [c_void_p]
         L.vp8hip_stream.restype = c_void_p
@@ -328,9 +329,10 @@ class Vp8Hip:
         """Order the context's main stream behind a tiled->raster pass still running on the internal stream."""
         self._chk(self.L.vp8hip_join(self.h), "vp8hip_join")
 
-    def stats(self):
+    def stats(self, back=0):
+        """Kernel times of the last launch (back=0) or of an earlier one (back <= 31); waits for that launch only."""
         s = Stats()
-        self._chk(self.L.vp8hip_get_stats(self.h, ctypes.byref(s)), "vp8hip_get_stats")
+        self._chk(self.L.vp8hip_get_stats_at(self.h, back, ctypes.byref(s)), "vp8hip_get_stats_at")
         return s
 
     def stream(self):

@@ -11,6 +11,8 @@
 #include "vp8hip.h"
 #include "vp8_common.hip.h"
 
+#define VP8HIP_STATS_RING 32
+
 extern "C" __global__ void vp8_recon_kernel(const DevJob *jobs, int njobs, DevGeom g);
 extern "C" __global__ void vp8_recon_simt_kernel(const DevJob *jobs, int njobs, DevGeom g, int lgG, int P, int nstrands, int tiled);
 extern "C" __global__ void vp8_loopfilter_simt_kernel(const DevJob *jobs, int njobs, DevGeom g, int lgG, int P, int nstrands);
@@ -32,13 +34,17 @@ struct Slot {
 struct vp8hip_ctx {
     int device;
     hipStream_t stream;
-    hipEvent_t ev[4];
+    // timing events of the last VP8HIP_STATS_RING launches: [0..3] on the main stream around recon / loop filter /
+    // extend, [4..5] around the tiled -> raster pass on whichever stream it ran
+    hipEvent_t evr[VP8HIP_STATS_RING][6];
+    bool evr_tiled[VP8HIP_STATS_RING]; vp8hip_stats evr_stats[VP8HIP_STATS_RING];
+    long ncalls;
     hipEvent_t ev_jobs;            // job table of the previous call has been copied
     // The tiled -> raster pass of the lane-per-row pipeline is memory-bound while recon and loop filter are
     // VALU-bound, so it runs on a second stream and overlaps the NEXT launch's recon.  Two scratch frame sets
     // and two device job tables alternate; any other use of the frame buffers first joins the second stream.
     hipStream_t stream2;
-    hipEvent_t ev_lf_done, ev_detile_done[2], ev_dt[2];
+    hipEvent_t ev_lf_done, ev_detile_done[2];
     bool detile_used[2], detile_pending;
     int parity;
     char err[256];
@@ -59,7 +65,6 @@ struct vp8hip_ctx {
     int num_cu, max_lds;
     int recon_nw, lf_nw;
     size_t recon_lds, lf_lds;
-    bool have_times, times_tiled;
     vp8hip_stats stats;
 };
 
@@ -120,7 +125,7 @@ extern "C" int vp8hip_create(int device, vp8hip_ctx **out)
     c->d_jobs = nullptr; c->d_jobs2[0] = c->d_jobs2[1] = nullptr; c->h_jobs = nullptr; c->jobs_cap = 0;
     c->detile_used[0] = c->detile_used[1] = false; c->detile_pending = false; c->parity = 0;
     c->width = c->height = 0;
-    c->have_times = false; c->times_tiled = false;
+    c->ncalls = 0;
     memset(&c->stats, 0, sizeof c->stats);
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) {
         fail(nullptr, -1, "hipStreamCreate: %s", hipGetErrorString(e));
@@ -133,10 +138,10 @@ extern "C" int vp8hip_create(int device, vp8hip_ctx **out)
         delete c;
         return -1;
     }
-    for (int i = 0; i < 4; i++) (void)hipEventCreate(&c->ev[i]);
+    for (int r = 0; r < VP8HIP_STATS_RING; r++) for (int i = 0; i < 6; i++) (void)hipEventCreate(&c->evr[r][i]);
     (void)hipEventCreateWithFlags(&c->ev_jobs, hipEventDisableTiming);
     (void)hipEventCreateWithFlags(&c->ev_lf_done, hipEventDisableTiming);
-    for (int k = 0; k < 2; k++) { (void)hipEventCreateWithFlags(&c->ev_detile_done[k], hipEventDisableTiming); (void)hipEventCreate(&c->ev_dt[k]); }
+    for (int k = 0; k < 2; k++) (void)hipEventCreateWithFlags(&c->ev_detile_done[k], hipEventDisableTiming);
     e = hipFuncSetAttribute((const void *)vp8_recon_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_lds);
     if (e != hipSuccess) {
         fail(nullptr, -1, "hipFuncSetAttribute(recon, %d B LDS): %s", c->max_lds, hipGetErrorString(e));
@@ -164,10 +169,10 @@ extern "C" void vp8hip_destroy(vp8hip_ctx *c)
     free_pools(c);
     for (int k = 0; k < 2; k++) if (c->d_jobs2[k]) (void)hipFree(c->d_jobs2[k]);
     if (c->h_jobs) (void)hipHostFree(c->h_jobs);
-    for (int i = 0; i < 4; i++) (void)hipEventDestroy(c->ev[i]);
+    for (int r = 0; r < VP8HIP_STATS_RING; r++) for (int i = 0; i < 6; i++) (void)hipEventDestroy(c->evr[r][i]);
     (void)hipEventDestroy(c->ev_jobs);
     (void)hipEventDestroy(c->ev_lf_done);
-    for (int k = 0; k < 2; k++) { (void)hipEventDestroy(c->ev_detile_done[k]); (void)hipEventDestroy(c->ev_dt[k]); }
+    for (int k = 0; k < 2; k++) (void)hipEventDestroy(c->ev_detile_done[k]);
     (void)hipStreamDestroy(c->stream);
     (void)hipStreamDestroy(c->stream2);
     delete c;
@@ -398,7 +403,8 @@ extern "C" int vp8hip_decode(vp8hip_ctx *c, const vp8hip_job *jobs, int njobs, i
     c->stats.workgroups = grid;
     c->stats.recon_waves = c->recon_nw;
     c->stats.lf_waves = c->lf_nw;
-    HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+    hipEvent_t *ev = c->evr[c->ncalls % VP8HIP_STATS_RING];
+    HIPCHK(c, hipEventRecord(ev[0], c->stream));
     // "one MB row per lane" kernels: G lanes per strand of frames, row period P >= max(cols, 2G+2).  The largest
     // G that costs no idle steps (cols >= 2G+2), widened while the launch would leave SIMDs without a wave.
     int lgG = 1;
@@ -429,7 +435,7 @@ extern "C" int vp8hip_decode(vp8hip_ctx *c, const vp8hip_job *jobs, int njobs, i
         }
         HIPCHK(c, hipGetLastError());
     }
-    HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+    HIPCHK(c, hipEventRecord(ev[1], c->stream));
     if ((stages & VP8HIP_STAGE_LF) && any_lf) {
         if (tiled) {
             hipLaunchKernelGGL(vp8_loopfilter_simt_kernel, dim3(simt_waves), dim3(64), 0, c->stream, (const DevJob *)c->d_jobs,
@@ -442,7 +448,7 @@ extern "C" int vp8hip_decode(vp8hip_ctx *c, const vp8hip_job *jobs, int njobs, i
         }
         HIPCHK(c, hipGetLastError());
     }
-    HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
+    HIPCHK(c, hipEventRecord(ev[2], c->stream));
     if (tiled) {      // whatever stages ran, the frame buffer gets the result; borders are extended on the way
         const bool own_stream = !(getenv("VP8HIP_DETILE_STREAM") && !atoi(getenv("VP8HIP_DETILE_STREAM")));
         hipStream_t ds = own_stream ? c->stream2 : c->stream;
@@ -450,14 +456,13 @@ extern "C" int vp8hip_decode(vp8hip_ctx *c, const vp8hip_job *jobs, int njobs, i
             HIPCHK(c, hipEventRecord(c->ev_lf_done, c->stream));
             HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_lf_done, 0));
         }
-        HIPCHK(c, hipEventRecord(c->ev_dt[0], ds));
+        HIPCHK(c, hipEventRecord(ev[4], ds));
         hipLaunchKernelGGL(vp8_detile_kernel, dim3(c->dg.mb_rows, njobs), dim3(256), 0, ds, (const DevJob *)c->d_jobs, njobs, c->dg,
                            (stages & VP8HIP_STAGE_EXTEND) ? 1 : 0);
         HIPCHK(c, hipGetLastError());
-        HIPCHK(c, hipEventRecord(c->ev_dt[1], ds));
+        HIPCHK(c, hipEventRecord(ev[5], ds));
         HIPCHK(c, hipEventRecord(c->ev_detile_done[par], ds));
         c->detile_used[par] = true; c->detile_pending = true; c->parity = par ^ 1;
-        c->times_tiled = true;
     } else if (stages & VP8HIP_STAGE_EXTEND) {
         int bx = (c->geom.aligned_h + 64) / 4;
         if (bx < 1) bx = 1;
@@ -466,9 +471,10 @@ extern "C" int vp8hip_decode(vp8hip_ctx *c, const vp8hip_job *jobs, int njobs, i
                            njobs, c->dg);
         HIPCHK(c, hipGetLastError());
     }
-    if (!tiled) c->times_tiled = false;
-    HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
-    c->have_times = true;
+    HIPCHK(c, hipEventRecord(ev[3], c->stream));
+    c->evr_tiled[c->ncalls % VP8HIP_STATS_RING] = tiled;
+    c->evr_stats[c->ncalls % VP8HIP_STATS_RING] = c->stats;
+    c->ncalls++;
     return 0;
 }
 
@@ -481,22 +487,25 @@ extern "C" int vp8hip_sync(vp8hip_ctx *c)
     return 0;
 }
 
-extern "C" int vp8hip_get_stats(vp8hip_ctx *c, vp8hip_stats *st)
+extern "C" int vp8hip_get_stats_at(vp8hip_ctx *c, int back, vp8hip_stats *st)
 {
-    if (!c || !st) return -2;
-    if (c->have_times) {
-        HIPCHK(c, hipEventSynchronize(c->ev[3]));
-        (void)hipEventElapsedTime(&c->stats.recon_ms, c->ev[0], c->ev[1]);
-        (void)hipEventElapsedTime(&c->stats.lf_ms, c->ev[1], c->ev[2]);
-        if (c->times_tiled) {
-            HIPCHK(c, hipEventSynchronize(c->ev_dt[1]));
-            (void)hipEventElapsedTime(&c->stats.extend_ms, c->ev_dt[0], c->ev_dt[1]);
-        } else
-            (void)hipEventElapsedTime(&c->stats.extend_ms, c->ev[2], c->ev[3]);
-    }
-    *st = c->stats;
+    if (!c || !st || back < 0 || back >= VP8HIP_STATS_RING) return -2;
+    if (back >= c->ncalls) { memset(st, 0, sizeof *st); return c->ncalls ? fail(c, -2, "vp8hip_get_stats_at: only %ld launches so far", c->ncalls) : 0; }
+    const int r = (int)((c->ncalls - 1 - back) % VP8HIP_STATS_RING);
+    hipEvent_t *ev = c->evr[r];
+    vp8hip_stats out = c->evr_stats[r];
+    HIPCHK(c, hipEventSynchronize(ev[3]));
+    (void)hipEventElapsedTime(&out.recon_ms, ev[0], ev[1]);
+    (void)hipEventElapsedTime(&out.lf_ms, ev[1], ev[2]);
+    if (c->evr_tiled[r]) {
+        HIPCHK(c, hipEventSynchronize(ev[5]));
+        (void)hipEventElapsedTime(&out.extend_ms, ev[4], ev[5]);
+    } else
+        (void)hipEventElapsedTime(&out.extend_ms, ev[2], ev[3]);
+    *st = out;
     return 0;
 }
+extern "C" int vp8hip_get_stats(vp8hip_ctx *c, vp8hip_stats *st) { return vp8hip_get_stats_at(c, 0, st); }
 
 extern "C" void *vp8hip_stream(vp8hip_ctx *c) { return c ? (void *)c->stream : nullptr; }
 
