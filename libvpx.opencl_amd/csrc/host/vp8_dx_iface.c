@@ -259,13 +259,81 @@ static vpx_codec_err_t ctl_get_int(vpx_codec_alg_priv_t *p, int ctrl_id, va_list
 static vpx_codec_err_t ctl_incapable(vpx_codec_alg_priv_t *p, int ctrl_id, va_list ap)
 {
     (void)ctrl_id; (void)ap;
-    /* VP8_SET_REFERENCE / VP8_COPY_REFERENCE / postproc: outside the hot path */
+    /* postproc: outside the hot path */
     return set_detail(p, VPX_CODEC_INCAPABLE, "control not implemented by the HIP decoder");
 }
 
+/* VP8_COPY_REFERENCE / VP8_SET_REFERENCE (vp8_dx_iface.c:611-651 -> vp8dx_get_reference / vp8dx_set_reference,
+ * onyxd_if.c:161-230).  The reference frames live in HBM; the image is staged through a host copy of one frame
+ * buffer.  As in the reference the image must have the frame buffers' (16-aligned) dimensions, and a set
+ * reference gets its borders extended (vp8_yv12_copy_frame = copy + extend). */
+static void extend_host_plane(uint8_t *p, int stride, int w, int h, int border)
+{
+    int r, i;
+    for (r = 0; r < h; r++) {
+        memset(p + r * stride - border, p[r * stride], (size_t)border);
+        memset(p + r * stride + w, p[r * stride + w - 1], (size_t)border);
+    }
+    for (i = 1; i <= border; i++) {
+        memcpy(p - border - i * stride, p - border, (size_t)w + 2 * border);
+        memcpy(p - border + (h - 1 + i) * stride, p - border + (h - 1) * stride, (size_t)w + 2 * border);
+    }
+}
+
+static vpx_codec_err_t ctl_reference(vpx_codec_alg_priv_t *p, int ctrl_id, va_list ap)
+{
+    vpx_ref_frame_t *rf = va_arg(ap, vpx_ref_frame_t *);
+    const vp8ir_geom *g = &p->geom;
+    uint8_t *buf;
+    int fb, r;
+    if (!rf) return VPX_CODEC_INVALID_PARAM;
+    if (!p->decoder_init || !p->hip) return set_detail(p, VPX_CODEC_ERROR, "no frame has been decoded yet");
+    if (rf->frame_type != VP8_LAST_FRAME && rf->frame_type != VP8_GOLD_FRAME && rf->frame_type != VP8_ALTR_FRAME)
+        return set_detail(p, VPX_CODEC_ERROR, "Invalid reference frame");
+    if ((int)rf->img.d_w != g->aligned_w || (int)rf->img.d_h != g->aligned_h ||
+        rf->img.x_chroma_shift != 1 || rf->img.y_chroma_shift != 1)
+        return set_detail(p, VPX_CODEC_ERROR, "Incorrect buffer dimensions");
+    buf = (uint8_t *)malloc((size_t)g->frame_size);
+    if (!buf) return VPX_CODEC_MEM_ERROR;
+    if (ctrl_id == VP8_COPY_REFERENCE) {
+        fb = rf->frame_type == VP8_LAST_FRAME ? p->refs.lst_idx : rf->frame_type == VP8_GOLD_FRAME ? p->refs.gld_idx
+                                                                                                   : p->refs.alt_idx;
+        if (vp8hip_frame_download(p->hip, fb, 1, buf, NULL, NULL, 0, 0)) { free(buf); return gpu_error(p, "vp8hip_frame_download"); }
+        for (r = 0; r < g->aligned_h; r++)
+            memcpy(rf->img.planes[VPX_PLANE_Y] + (size_t)r * rf->img.stride[VPX_PLANE_Y],
+                   buf + g->y_off + (size_t)r * g->y_stride, (size_t)g->aligned_w);
+        for (r = 0; r < g->aligned_h / 2; r++) {
+            memcpy(rf->img.planes[VPX_PLANE_U] + (size_t)r * rf->img.stride[VPX_PLANE_U],
+                   buf + g->u_off + (size_t)r * g->uv_stride, (size_t)g->aligned_w / 2);
+            memcpy(rf->img.planes[VPX_PLANE_V] + (size_t)r * rf->img.stride[VPX_PLANE_V],
+                   buf + g->v_off + (size_t)r * g->uv_stride, (size_t)g->aligned_w / 2);
+        }
+    } else {
+        fb = vp8_refs_retarget_free(&p->refs, (int)rf->frame_type);
+        if (fb < 0) { free(buf); return set_detail(p, VPX_CODEC_ERROR, "no free frame buffer"); }
+        memset(buf, 0, (size_t)g->frame_size);
+        for (r = 0; r < g->aligned_h; r++)
+            memcpy(buf + g->y_off + (size_t)r * g->y_stride,
+                   rf->img.planes[VPX_PLANE_Y] + (size_t)r * rf->img.stride[VPX_PLANE_Y], (size_t)g->aligned_w);
+        for (r = 0; r < g->aligned_h / 2; r++) {
+            memcpy(buf + g->u_off + (size_t)r * g->uv_stride,
+                   rf->img.planes[VPX_PLANE_U] + (size_t)r * rf->img.stride[VPX_PLANE_U], (size_t)g->aligned_w / 2);
+            memcpy(buf + g->v_off + (size_t)r * g->uv_stride,
+                   rf->img.planes[VPX_PLANE_V] + (size_t)r * rf->img.stride[VPX_PLANE_V], (size_t)g->aligned_w / 2);
+        }
+        extend_host_plane(buf + g->y_off, g->y_stride, g->aligned_w, g->aligned_h, VP8IR_BORDER);
+        extend_host_plane(buf + g->u_off, g->uv_stride, g->aligned_w / 2, g->aligned_h / 2, VP8IR_BORDER / 2);
+        extend_host_plane(buf + g->v_off, g->uv_stride, g->aligned_w / 2, g->aligned_h / 2, VP8IR_BORDER / 2);
+        if (vp8hip_frame_upload(p->hip, fb, buf)) { free(buf); return gpu_error(p, "vp8hip_frame_upload"); }
+        p->fb_corrupted[fb] = 0;
+    }
+    free(buf);
+    return VPX_CODEC_OK;
+}
+
 static vpx_codec_ctrl_fn_map_t vp8_ctf_maps[] = {
-    { VP8_SET_REFERENCE, ctl_incapable },
-    { VP8_COPY_REFERENCE, ctl_incapable },
+    { VP8_SET_REFERENCE, ctl_reference },
+    { VP8_COPY_REFERENCE, ctl_reference },
     { VP8_SET_POSTPROC, ctl_incapable },
     { VP8D_GET_LAST_REF_UPDATES, ctl_get_int },
     { VP8D_GET_FRAME_CORRUPTED, ctl_get_int },

@@ -888,6 +888,19 @@ static void retarget(vp8_refs *r, int *idx, int to)
     r->ref_cnt[to]++;
 }
 
+/* vp8dx_set_reference (onyxd_if.c:192-230): point one reference (1 last, 2 golden, 4 alt-ref) at a free buffer,
+ * leaving whatever else still shares the old one untouched.  Returns the buffer to fill, or -1. */
+int vp8_refs_retarget_free(vp8_refs *r, int which)
+{
+    int i, *idx = which == 1 ? &r->lst_idx : which == 2 ? &r->gld_idx : which == 4 ? &r->alt_idx : NULL;
+    if (!idx) return -1;
+    for (i = 0; i < 4; i++)
+        if (r->ref_cnt[i] == 0) break;
+    if (i == 4) return -1;
+    retarget(r, idx, i);
+    return i;
+}
+
 int vp8_refs_swap(vp8_refs *r, const vp8ir_frame_hdr *h)
 {
     int err = 0;

@@ -66,6 +66,7 @@ void vp8_refs_on_alloc(vp8_refs *r);              /* vp8_alloc_frame_buffers, al
 int  vp8_refs_get_free(vp8_refs *r);              /* -> new_idx, or -1 */
 void vp8_refs_release_new(vp8_refs *r);           /* frame failed: give new_idx back */
 int  vp8_refs_swap(vp8_refs *r, const vp8ir_frame_hdr *hdr);
+int  vp8_refs_retarget_free(vp8_refs *r, int which);   /* vp8dx_set_reference: which = 1 last, 2 golden, 4 alt-ref */
 
 #ifdef __cplusplus
 }
