@@ -82,7 +82,7 @@ COMMON = ["--ivf", "--i420", "-p", "1", "--lag-in-frames=0", "-t", "1"]
 ALLKEY = ["--kf-max-dist=0", "--kf-min-dist=0"]
 INTER = ["--kf-max-dist=9999", "--auto-alt-ref=0"]
 
-# name: (w, h, frames, seed, noise, encoder args)
+# name: (w, h, frames, seed, noise, encoder args[, global motion in px/frame])
 FIXTURES = {
     # (1) config-1 plumbing stream: 640x360, 10 key frames, profile 0, normal loop filter
     "kf_640x360": (640, 360, 10, 11, 10, ALLKEY + ["--good", "--cpu-used=4", "--end-usage=cq", "--cq-level=14",
@@ -112,10 +112,12 @@ FIXTURES = {
     # (7) 4K key frames (config 5)
     "kf_3840x2160": (3840, 2160, 3, 5, 4, ALLKEY + ["--good", "--cpu-used=6", "--end-usage=cq", "--cq-level=24",
                                                      "--target-bitrate=30000"]),
-    # golden / alt-ref with hidden (show_frame=0) frames: lagged 2-pass-less ARF
-    "p_arf_176x144": (176, 144, 70, 51, 6, ["--ivf", "--i420", "-p", "2", "-t", "1", "--kf-max-dist=9999",
-                                           "--auto-alt-ref=1", "--lag-in-frames=16", "--good", "--cpu-used=1",
-                                           "--target-bitrate=120", "--arnr-maxframes=5", "--arnr-strength=3"]),
+    # golden / alt-ref with hidden (show_frame=0) frames: two-pass, lagged, slow motion so that the encoder's
+    # ARF decision fires (5 hidden frames among 95 packets)
+    "p_arf_176x144": (176, 144, 90, 52, 2, ["--ivf", "--i420", "-p", "2", "-t", "1", "--kf-max-dist=9999",
+                                           "--auto-alt-ref=1", "--lag-in-frames=16", "--good", "--cpu-used=0",
+                                           "--target-bitrate=200", "--arnr-maxframes=5", "--arnr-strength=3"],
+                      (0.25, 0.125)),
     # sharpness != 0 (loop-filter limit tables), error-resilient stream
     "p_sharp_320x240": (320, 240, 8, 61, 10, INTER + ["--good", "--cpu-used=1", "--sharpness=5",
                                                        "--error-resilient=1", "--target-bitrate=500"]),
@@ -149,13 +151,14 @@ def main():
         if not os.path.exists(exe):
             raise SystemExit(f"{exe} missing: run `make -C oracle ref` (dev container only)")
     for name in names:
-        w, h, frames, seed, noise, args = FIXTURES[name]
+        w, h, frames, seed, noise, args = FIXTURES[name][:6]
+        speed = FIXTURES[name][6] if len(FIXTURES[name]) > 6 else (1.375, 0.625)
         ivf = os.path.join(HERE, name + ".ivf")
         md5 = os.path.join(HERE, name + ".md5")
         with tempfile.TemporaryDirectory(dir="/tmp") as td:
             yuv = os.path.join(td, "in.yuv")
             with open(yuv, "wb") as f:
-                f.write(synth_i420(w, h, frames, seed, noise))
+                f.write(synth_i420(w, h, frames, seed, noise, speed))
             base = args if "-p" in args else COMMON + args
             run([VPXENC, *base, "-w", str(w), "-h", str(h), "-o", ivf, yuv])
         run([REFMD5, ivf, md5])
