@@ -60,10 +60,25 @@ def cpu_baseline(fixture, budget_s=12.0):
             reps = max(1, min(400, int(budget_s / one)))
             out = subprocess.run([ref, "--time", str(reps), ivf], capture_output=True, text=True, timeout=600)
             frames, pixels, secs = out.stdout.split()
-            return {"value": round(float(pixels) / float(secs) / 1e6, 2), "unit": "Mpix/s", "cores": cores,
-                    "kind": "reference",
-                    "sample": f"{fixture}.ivf x{reps} passes ({frames} frames) through oracle/_ref (reference "
-                              f"generic-C decoder, gcc -O3, 1 thread), time inside vpx_codec_decode only"}
+            res = {"value": round(float(pixels) / float(secs) / 1e6, 2), "unit": "Mpix/s", "cores": cores,
+                   "kind": "reference",
+                   "sample": f"{fixture}.ivf x{reps} passes ({frames} frames) through oracle/_ref (reference "
+                             f"generic-C decoder, gcc -O3, 1 thread), time inside vpx_codec_decode only"}
+            # the same decoder frame-parallel on every host core (all-key-frame streams shard by frame): one process
+            # per core, each decoding the whole sample; aggregate = sum of the per-process rates
+            ncpu = os.cpu_count() or 1
+            if ncpu > 1:
+                r2 = max(1, reps // 6)
+                procs = [subprocess.Popen([ref, "--time", str(r2), ivf], stdout=subprocess.PIPE, text=True)
+                         for _ in range(ncpu)]
+                agg = 0.0
+                for pr in procs:
+                    o, _ = pr.communicate(timeout=900)
+                    _, px, sc = o.split()
+                    agg += float(px) / float(sc) / 1e6
+                res["all_cores"] = {"value": round(agg, 1), "unit": "Mpix/s", "cores": ncpu,
+                                    "sample": f"{ncpu} processes x {r2} passes of the same stream"}
+            return res
         except Exception as e:  # noqa: BLE001 - fall through to the port
             sys.stderr.write(f"[bench] reference baseline failed ({e}); using the port\n")
     # port: host feeder + oracle pixel path (checker code, timed here only as a baseline)
@@ -190,6 +205,29 @@ def main():
         alone[0] += st.recon_ms / 3
         alone[1] += st.lf_ms / 3
         alone[2] += st.extend_ms / 3
+    # single-frame latency: one frame per launch (what a single-stream decoder sees), kernels only
+    one = (P.Job * 1)()
+    one[0].ir_slot, one[0].dst_fb = 0, 0
+    for k in range(4):
+        one[0].ref_fb[k] = -1
+    ctx.decode_array(one, 1, P.STAGE_ALL); ctx.sync()
+    tl = time.perf_counter()
+    for _ in range(20):
+        ctx.decode_array(one, 1, P.STAGE_ALL)
+    ctx.sync()
+    latency_ms = (time.perf_counter() - tl) / 20 * 1e3
+    # what the HBM system delivers to a plain device-to-device copy on this box (SURVEY.md 8d asks for the probe)
+    copy_gbps = None
+    if rank == 0:
+        a = torch.empty(2 << 30, dtype=torch.uint8, device="cuda")
+        b = torch.empty_like(a)
+        b.copy_(a); torch.cuda.synchronize()
+        tc = time.perf_counter()
+        for _ in range(5):
+            b.copy_(a)
+        torch.cuda.synchronize()
+        copy_gbps = 2 * a.numel() * 5 / (time.perf_counter() - tc) / 1e9
+        del a, b
     if dist is not None:
         t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -237,6 +275,7 @@ def main():
                 "waves_per_workgroup": {"recon": st.recon_waves, "loopfilter": st.lf_waves},
                 "workgroups": st.workgroups,
                 "host_feeder_s_for_source_frames": round(feed_s, 4),
+                "single_frame_launch_ms": round(latency_ms, 3),
             },
             "roofline": {
                 "bound": "hbm",
@@ -252,6 +291,7 @@ def main():
                                      for k in ms},
                 "pipeline": {"achieved": round(pipeline_gbps, 2), "frac": round(pipeline_gbps / HBM_PEAK_GBPS, 5),
                              "note": "all kernels' algorithmic bytes / whole step time"},
+                "device_copy_probe_GBps": round(copy_gbps, 1) if copy_gbps else None,
             },
         }
         if not args.no_cpu_baseline:
