@@ -200,6 +200,19 @@ __device__ __forceinline__ u32 inter_row4(g_cu8p ref, int stride, int px, int py
     sy = max(-border + 2, min(sy, h + border - 4));
     g_cu8p s = ref + (long)sy * stride + sx;
     int out[4];
+    // Six-tap source rows are fetched as aligned dwords and shifted into place (v_alignbyte_b32): three loads per
+    // row instead of nine byte loads.  rowpx(r, p): pixels s[r*stride - 2 .. r*stride + 6] of source row r.
+    const u32 sh = (u32)(unsigned long)(s - 2) & 3u;
+    g_cu8p sa = s - 2 - sh;
+    auto rowpx = [&](int r, int p[9]) {
+        g_cu32p rp = (g_cu32p)(sa + (long)r * stride);
+        const u32 d0 = rp[0], d1 = rp[1], d2 = rp[2];
+        const u32 w0 = __builtin_amdgcn_alignbyte(d1, d0, sh), w1 = __builtin_amdgcn_alignbyte(d2, d1, sh);
+        const u32 w2 = __builtin_amdgcn_alignbyte(0u, d2, sh);
+#pragma unroll
+        for (int i = 0; i < 4; i++) { p[i] = (w0 >> (8 * i)) & 0xff; p[4 + i] = (w1 >> (8 * i)) & 0xff; }
+        p[8] = w2 & 0xff;
+    };
     if ((fx | fy) == 0) {
 #pragma unroll
         for (int i = 0; i < 4; i++) out[i] = s[i];
@@ -219,10 +232,8 @@ __device__ __forceinline__ u32 inter_row4(g_cu8p ref, int stride, int px, int py
         int acc[4] = { 64, 64, 64, 64 };
 #pragma unroll
         for (int r = 0; r < 6; r++) {
-            g_cu8p row = s + (long)(r - 2) * stride;
             int p[9];
-#pragma unroll
-            for (int i = 0; i < 9; i++) p[i] = row[i - 2];
+            rowpx(r - 2, p);
             const int vt = k_sixtap[fy][r];
 #pragma unroll
             for (int i = 0; i < 4; i++) {
