@@ -148,6 +148,35 @@ def test_automatic_kernel_choice(pkg, ctx, kernel_family, monkeypatch):
         assert pkg.planes_md5(*ctx.download_planes(i)) == gold[i % nsrc], i
 
 
+def test_back_to_back_launches_and_stats_ring(pkg, ctx, kernel_family):
+    """Launches are asynchronous and pipeline on the device (the lane family finishes on a second stream with
+    double-buffered scratch): three launches without a host sync in between, then downloads -- which order
+    themselves behind the last pass -- must see the reference's frames; the per-launch kernel times of all three
+    are still readable afterwards (vp8hip_get_stats_at)."""
+    n = 64
+    w, h, frames = pkg.read_ivf(ivf_path("kf_q0_176x144"))
+    gold = golden_md5("kf_q0_176x144")
+    ctx.configure(w, h, n, n)
+    parser = pkg.Parser()
+    for i, data in enumerate(frames):
+        hdr = ctx.parse_into_slot(parser, data, i)
+        parser.swap(hdr)
+        ctx.upload(i)
+    parser.close()
+    for i in range(len(frames), n):
+        ctx.ir_copy(i, i % len(frames))
+    for rot in range(3):          # launch k decodes slot (i + k) into buffer i
+        ctx.decode([((i + rot) % n, i, None) for i in range(n)], 7)
+    for i in (0, 1, 17, n - 1):
+        assert pkg.planes_md5(*ctx.download_planes(i)) == gold[((i + 2) % n) % len(frames)], i
+    for back in range(3):
+        st = ctx.stats(back)
+        assert st.recon_ms > 0 and st.extend_ms > 0
+        assert st.recon_waves == (1 if kernel_family == "lane" else st.recon_waves)
+    ctx.join()
+    ctx.sync()
+
+
 def test_full_size_4k(pkg, ctx):
     gold, nsrc = _batch(pkg, ctx, "kf_3840x2160", 96)
     for i in (0, 1, 2, 47, 95):
