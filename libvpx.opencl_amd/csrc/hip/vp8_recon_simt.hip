@@ -39,6 +39,14 @@ typedef GLOBAL_AS const u32x2 *g_cu32x2p;
 typedef GLOBAL_AS u32x4 *g_u32x4p;
 typedef GLOBAL_AS u32x2 *g_u32x2p;
 
+typedef short v2s __attribute__((ext_vector_type(2)));      // two 16-bit lanes: v_pk_* arithmetic
+__device__ __forceinline__ v2s as_v2s(u32 v) { return __builtin_bit_cast(v2s, v); }
+__device__ __forceinline__ u32 as_u32(v2s v) { return __builtin_bit_cast(u32, v); }
+__device__ __forceinline__ v2s pk(int lo, int hi) { return (v2s){ (short)lo, (short)hi }; }
+__device__ __forceinline__ v2s clamp255_2(v2s v)
+{
+    return __builtin_elementwise_min(__builtin_elementwise_max(v, pk(0, 0)), pk(255, 255));
+}
 __device__ __forceinline__ u32 perm(u32 hi, u32 lo, u32 sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
 __device__ __forceinline__ u32 alignb(u32 hi, u32 lo, u32 sh) { return __builtin_amdgcn_alignbyte(hi, lo, sh); }
 __device__ __forceinline__ u32 lerp(u32 a, u32 b, u32 c) { return __builtin_amdgcn_lerp(a, b, c); }
@@ -95,11 +103,12 @@ __device__ __forceinline__ void dequant_idct(const u32x4 ca, const u32x4 cb, int
     int t[16];                                   // t[row*4+col], i16 like the reference's `short output[16]`
 #pragma unroll
     for (int col = 0; col < 4; col++) {
-        int i0 = (short)(sext16(q[2 * col]) * (col == 0 ? dqdc : dqac));
+        // DQ = (short)(Q * DQC) (dequantize.c:17-27): the low half of a 16x16 product, two coefficients per v_pk_mul_lo_u16
+        const v2s p01 = as_v2s(q[2 * col]) * (col == 0 ? pk(dqdc, dqac) : pk(dqac, dqac));
+        const v2s p23 = as_v2s(q[2 * col + 1]) * pk(dqac, dqac);
+        int i0 = p01.x;
         if (col == 0 && dc_given) i0 = dc_in;
-        const int i1 = (short)(hi16(q[2 * col]) * dqac);
-        const int i2 = (short)(sext16(q[2 * col + 1]) * dqac);
-        const int i3 = (short)(hi16(q[2 * col + 1]) * dqac);
+        const int i1 = p01.y, i2 = p23.x, i3 = p23.y;
         int o0, o1, o2, o3;
         idct1d(i0, i1, i2, i3, o0, o1, o2, o3);  // vertical pass: column `col`, rows 0..3
         t[0 + col] = (short)o0; t[4 + col] = (short)o1; t[8 + col] = (short)o2; t[12 + col] = (short)o3;
@@ -113,12 +122,20 @@ __device__ __forceinline__ void dequant_idct(const u32x4 ca, const u32x4 cb, int
     }
 }
 
+// clamp(pred + residual) for a row of four pixels (the tail of vp8_short_idct4x4llm / vp8_dc_only_idct_add), two
+// pixels per instruction: predictor bytes widened to 16-bit lanes, residuals (|r| < 2^12) packed beside them
 __device__ __forceinline__ u32 add_clamp_pack(u32 pred, const int *r)
 {
-    u32 out = 0;
-#pragma unroll
-    for (int i = 0; i < 4; i++) out |= (u32)clamp255((int)((pred >> (8 * i)) & 0xff) + r[i]) << (8 * i);
-    return out;
+    const v2s lo = clamp255_2(as_v2s(perm(pred, pred, 0x0c010c00u)) + pk(r[0], r[1]));
+    const v2s hi = clamp255_2(as_v2s(perm(pred, pred, 0x0c030c02u)) + pk(r[2], r[3]));
+    return perm(as_u32(hi), as_u32(lo), 0x06040200u);
+}
+
+// TM prediction of a row of four pixels: clamp(above[i] + left - top_left), above given as two packed pairs
+__device__ __forceinline__ u32 tm_row(v2s a01, v2s a23, int l_minus_tl)
+{
+    const v2s d = pk(l_minus_tl, l_minus_tl);
+    return perm(as_u32(clamp255_2(a23 + d)), as_u32(clamp255_2(a01 + d)), 0x06040200u);
 }
 
 // right-hand pixel column of a 4x4 block given as four row dwords -> one dword, top pixel in byte 0
@@ -137,14 +154,9 @@ __device__ __forceinline__ void mb_mode_pred(int mode, u32 above, u32 left, int 
         p[0] = perm(left, left, 0x00000000u); p[1] = perm(left, left, 0x01010101u);
         p[2] = perm(left, left, 0x02020202u); p[3] = perm(left, left, 0x03030303u);
     } else {
+        const v2s a01 = as_v2s(perm(above, above, 0x0c010c00u)), a23 = as_v2s(perm(above, above, 0x0c030c02u));
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int l = (int)((left >> (8 * j)) & 0xff) - tl;
-            u32 o = 0;
-#pragma unroll
-            for (int i = 0; i < 4; i++) o |= (u32)clamp255(l + (int)((above >> (8 * i)) & 0xff)) << (8 * i);
-            p[j] = o;
-        }
+        for (int j = 0; j < 4; j++) p[j] = tm_row(a01, a23, (int)((left >> (8 * j)) & 0xff) - tl);
     }
 }
 
@@ -160,14 +172,9 @@ __device__ __forceinline__ void bpred4x4(int mode, u32 a0, u32 a1, u32 left, int
         return;
     }
     if (mode == VP8IR_B_TM_PRED) {
+        const v2s a01 = as_v2s(perm(a0, a0, 0x0c010c00u)), a23 = as_v2s(perm(a0, a0, 0x0c030c02u));
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int l = (int)((left >> (8 * j)) & 0xff) - tl;
-            u32 o = 0;
-#pragma unroll
-            for (int i = 0; i < 4; i++) o |= (u32)clamp255(l + (int)((a0 >> (8 * i)) & 0xff)) << (8 * i);
-            p[j] = o;
-        }
+        for (int j = 0; j < 4; j++) p[j] = tm_row(a01, a23, (int)((left >> (8 * j)) & 0xff) - tl);
         return;
     }
     const u32 E0 = perm(left, left, 0x01020303u);                       // L3 L3 L2 L1

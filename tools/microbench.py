@@ -5,7 +5,8 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 import numpy as np
 from vp8_testlib import load_package, synth_ir
 P = load_package()
-W, H, F = 1920, 1088, int(sys.argv[1]) if len(sys.argv) > 1 else 256
+W, H = (int(v) for v in os.environ.get("MB_SIZE", "1920x1088").split("x"))
+F = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 ctx = P.Vp8Hip(0); ctx.configure(W, H, F, F)
 n = ctx.nmb
 
