@@ -101,10 +101,12 @@ int  vp8hip_get_stats(vp8hip_ctx *ctx, vp8hip_stats *st);
 int  vp8hip_get_stats_at(vp8hip_ctx *ctx, int back, vp8hip_stats *st);
 /* The HIP stream (hipStream_t, as void*) the work of this context is enqueued on, so callers can
  * bracket it with their own events.  One exception: after a large all-key-frame launch the last pass
- * (tiled scratch -> raster frame buffer + borders) runs on a second, internal stream so that it overlaps
- * the next launch.  Every vp8hip_* call that touches frame buffers orders itself behind it; a caller that
- * enqueues its OWN work on vp8hip_stream() to read frame buffers calls vp8hip_join() first, which makes the
- * stream wait (on the device, not the host) for that pass. */
+ * (tiled scratch -> raster frame buffer + borders) runs on a second, internal stream, and is only launched
+ * together with the next such launch (it then runs beside that launch's loop filter) or by the next call that
+ * needs it.  Every vp8hip_* call that touches frame buffers (download, upload, copy, sync, a launch of the other
+ * kernel family, get_stats) takes care of that; a caller that enqueues its OWN work on vp8hip_stream() to read
+ * frame buffers calls vp8hip_join() first, which launches the pass if need be and makes the stream wait (on the
+ * device, not the host) for it. */
 void *vp8hip_stream(vp8hip_ctx *ctx);
 int  vp8hip_join(vp8hip_ctx *ctx);
 

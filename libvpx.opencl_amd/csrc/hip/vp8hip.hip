@@ -46,6 +46,9 @@ struct vp8hip_ctx {
     hipStream_t stream2;
     hipEvent_t ev_lf_done, ev_detile_done[2];
     bool detile_used[2], detile_pending;
+    // a tiled -> raster pass not launched yet: it goes out beside the NEXT launch's loop filter (or at the next join)
+    struct { bool valid; DevJob *jobs; int njobs, extend, par; hipEvent_t *ev; } deferred;
+    hipEvent_t ev_recon_done;
     int parity;
     char err[256];
     // geometry
@@ -124,6 +127,7 @@ extern "C" int vp8hip_create(int device, vp8hip_ctx **out)
     for (int k = 0; k < 2; k++) { c->tile_block[k] = nullptr; c->tile_cap[k] = 0; }
     c->d_jobs = nullptr; c->d_jobs2[0] = c->d_jobs2[1] = nullptr; c->h_jobs = nullptr; c->jobs_cap = 0;
     c->detile_used[0] = c->detile_used[1] = false; c->detile_pending = false; c->parity = 0;
+    c->deferred.valid = false;
     c->width = c->height = 0;
     c->ncalls = 0;
     memset(&c->stats, 0, sizeof c->stats);
@@ -141,6 +145,7 @@ extern "C" int vp8hip_create(int device, vp8hip_ctx **out)
     for (int r = 0; r < VP8HIP_STATS_RING; r++) for (int i = 0; i < 6; i++) (void)hipEventCreate(&c->evr[r][i]);
     (void)hipEventCreateWithFlags(&c->ev_jobs, hipEventDisableTiming);
     (void)hipEventCreateWithFlags(&c->ev_lf_done, hipEventDisableTiming);
+    (void)hipEventCreateWithFlags(&c->ev_recon_done, hipEventDisableTiming);
     for (int k = 0; k < 2; k++) (void)hipEventCreateWithFlags(&c->ev_detile_done[k], hipEventDisableTiming);
     e = hipFuncSetAttribute((const void *)vp8_recon_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_lds);
     if (e != hipSuccess) {
@@ -160,10 +165,13 @@ extern "C" int vp8hip_create(int device, vp8hip_ctx **out)
     return 0;
 }
 
+static int join_detile(vp8hip_ctx *c);
+
 extern "C" void vp8hip_destroy(vp8hip_ctx *c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    (void)join_detile(c);
     (void)hipStreamSynchronize(c->stream);
     (void)hipStreamSynchronize(c->stream2);
     free_pools(c);
@@ -172,6 +180,7 @@ extern "C" void vp8hip_destroy(vp8hip_ctx *c)
     for (int r = 0; r < VP8HIP_STATS_RING; r++) for (int i = 0; i < 6; i++) (void)hipEventDestroy(c->evr[r][i]);
     (void)hipEventDestroy(c->ev_jobs);
     (void)hipEventDestroy(c->ev_lf_done);
+    (void)hipEventDestroy(c->ev_recon_done);
     for (int k = 0; k < 2; k++) (void)hipEventDestroy(c->ev_detile_done[k]);
     (void)hipStreamDestroy(c->stream);
     (void)hipStreamDestroy(c->stream2);
@@ -190,6 +199,7 @@ extern "C" int vp8hip_configure(vp8hip_ctx *c, int width, int height, int num_fb
     if (width <= 0 || height <= 0 || width > 16383 || height > 16383 || num_fb < 1 || num_slots < 1)
         return fail(c, -2, "vp8hip_configure: bad arguments %dx%d fb=%d slots=%d", width, height, num_fb, num_slots);
     HIPCHK(c, hipSetDevice(c->device));
+    if (c->width && join_detile(c)) return -1;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream2));
     c->detile_pending = false; c->detile_used[0] = c->detile_used[1] = false;
@@ -309,8 +319,26 @@ extern "C" int vp8hip_ir_copy(vp8hip_ctx *c, int dst, int src)
 // Make the main stream wait for a tiled -> raster pass still running on the second stream.  Every entry point
 // that reads or writes frame buffers (other than another lane-per-row launch, which is ordered behind it on
 // the second stream anyway) calls this first.
+// Launch the deferred tiled -> raster pass on the second stream, behind `after` (an event on the main stream).
+static int launch_deferred(vp8hip_ctx *c, hipEvent_t after)
+{
+    if (!c->deferred.valid) return 0;
+    HIPCHK(c, hipStreamWaitEvent(c->stream2, after, 0));
+    HIPCHK(c, hipEventRecord(c->deferred.ev[4], c->stream2));
+    hipLaunchKernelGGL(vp8_detile_kernel, dim3(c->dg.mb_rows, c->deferred.njobs), dim3(256), 0, c->stream2,
+                       (const DevJob *)c->deferred.jobs, c->deferred.njobs, c->dg, c->deferred.extend);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipEventRecord(c->deferred.ev[5], c->stream2));
+    HIPCHK(c, hipEventRecord(c->ev_detile_done[c->deferred.par], c->stream2));
+    c->deferred.valid = false;
+    return 0;
+}
 static int join_detile(vp8hip_ctx *c)
 {
+    if (c->deferred.valid) {
+        HIPCHK(c, hipEventRecord(c->ev_lf_done, c->stream));
+        if (launch_deferred(c, c->ev_lf_done)) return -1;
+    }
     if (c->detile_pending) {
         HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_detile_done[c->parity ^ 1], 0));
         c->detile_pending = false;
@@ -436,6 +464,10 @@ extern "C" int vp8hip_decode(vp8hip_ctx *c, const vp8hip_job *jobs, int njobs, i
         HIPCHK(c, hipGetLastError());
     }
     HIPCHK(c, hipEventRecord(ev[1], c->stream));
+    if (tiled && c->deferred.valid) {          // the previous launch's tiled -> raster pass runs beside this loop filter
+        HIPCHK(c, hipEventRecord(c->ev_recon_done, c->stream));
+        if (launch_deferred(c, c->ev_recon_done)) return -1;
+    }
     if ((stages & VP8HIP_STAGE_LF) && any_lf) {
         if (tiled) {
             hipLaunchKernelGGL(vp8_loopfilter_simt_kernel, dim3(simt_waves), dim3(64), 0, c->stream, (const DevJob *)c->d_jobs,
@@ -451,7 +483,14 @@ extern "C" int vp8hip_decode(vp8hip_ctx *c, const vp8hip_job *jobs, int njobs, i
     HIPCHK(c, hipEventRecord(ev[2], c->stream));
     if (tiled) {      // whatever stages ran, the frame buffer gets the result; borders are extended on the way
         const bool own_stream = !(getenv("VP8HIP_DETILE_STREAM") && !atoi(getenv("VP8HIP_DETILE_STREAM")));
+        // deferred by default: the pass is launched with the NEXT lane-per-row launch, right after its recon, so
+        // that it runs beside that launch's loop filter (which it disturbs less than the recon), or at the next join
+        const bool defer = own_stream && !(getenv("VP8HIP_DETILE_DEFER") && !atoi(getenv("VP8HIP_DETILE_DEFER")));
         hipStream_t ds = own_stream ? c->stream2 : c->stream;
+        if (defer) {
+            c->deferred.valid = true; c->deferred.jobs = c->d_jobs; c->deferred.njobs = njobs;
+            c->deferred.extend = (stages & VP8HIP_STAGE_EXTEND) ? 1 : 0; c->deferred.par = par; c->deferred.ev = ev;
+        } else {
         if (own_stream) {
             HIPCHK(c, hipEventRecord(c->ev_lf_done, c->stream));
             HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_lf_done, 0));
@@ -462,6 +501,7 @@ extern "C" int vp8hip_decode(vp8hip_ctx *c, const vp8hip_job *jobs, int njobs, i
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipEventRecord(ev[5], ds));
         HIPCHK(c, hipEventRecord(c->ev_detile_done[par], ds));
+        }
         c->detile_used[par] = true; c->detile_pending = true; c->parity = par ^ 1;
     } else if (stages & VP8HIP_STAGE_EXTEND) {
         int bx = (c->geom.aligned_h + 64) / 4;
@@ -492,6 +532,7 @@ extern "C" int vp8hip_get_stats_at(vp8hip_ctx *c, int back, vp8hip_stats *st)
     if (!c || !st || back < 0 || back >= VP8HIP_STATS_RING) return -2;
     if (back >= c->ncalls) { memset(st, 0, sizeof *st); return c->ncalls ? fail(c, -2, "vp8hip_get_stats_at: only %ld launches so far", c->ncalls) : 0; }
     const int r = (int)((c->ncalls - 1 - back) % VP8HIP_STATS_RING);
+    if (c->deferred.valid && join_detile(c)) return -1;      // its events are read below: it has to be launched
     hipEvent_t *ev = c->evr[r];
     vp8hip_stats out = c->evr_stats[r];
     HIPCHK(c, hipEventSynchronize(ev[3]));
