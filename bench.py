@@ -102,7 +102,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--frames", type=int, default=0,
-                    help="frames per GPU per step (default: 8192 for 1080p, 2048 for 4k -- about 110 GB of IR, "
+                    help="frames per GPU per step (default: 8192 for 1080p, 2048 for 4k -- about 165 GB of IR, "
                          "tiled scratch and frame buffers resident in HBM; the lane-per-row kernels want several "
                          "frames per wave on each of the chip's 1024 SIMDs)")
     ap.add_argument("--workload", default="1080p", choices=sorted(WORKLOADS))

@@ -12,6 +12,7 @@
 #include "vp8_common.hip.h"
 
 #define VP8HIP_STATS_RING 32
+#define VP8HIP_NBUF 3          // scratch frame sets / job tables in rotation (see vp8hip_ctx)
 
 extern "C" __global__ void vp8_recon_kernel(const DevJob *jobs, int njobs, DevGeom g);
 extern "C" __global__ void vp8_recon_simt_kernel(const DevJob *jobs, int njobs, DevGeom g, int lgG, int P, int nstrands, int tiled);
@@ -44,12 +45,12 @@ struct vp8hip_ctx {
     // VALU-bound, so it runs on a second stream and overlaps the NEXT launch's recon.  Two scratch frame sets
     // and two device job tables alternate; any other use of the frame buffers first joins the second stream.
     hipStream_t stream2;
-    hipEvent_t ev_lf_done, ev_detile_done[2];
-    bool detile_used[2], detile_pending;
+    hipEvent_t ev_lf_done, ev_detile_done[VP8HIP_NBUF];
+    bool detile_used[VP8HIP_NBUF], detile_pending;
     // a tiled -> raster pass not launched yet: it goes out beside the NEXT launch's loop filter (or at the next join)
     struct { bool valid; DevJob *jobs; int njobs, extend, par; hipEvent_t *ev; } deferred;
     hipEvent_t ev_recon_done;
-    int parity;
+    int parity, last_par;        // set used by the next lane-per-row launch / by the last one
     char err[256];
     // geometry
     int width, height;
@@ -60,10 +61,10 @@ struct vp8hip_ctx {
     std::vector<uint8_t *> fb;
     std::vector<Slot> slots;
     uint8_t *fb_block; char *slot_block_dev;
-    uint8_t *tile_block[2]; size_t tile_cap[2];   // macroblock-tiled scratch frames of the lane-per-row pipeline
+    uint8_t *tile_block[VP8HIP_NBUF]; size_t tile_cap[VP8HIP_NBUF];   // macroblock-tiled scratch frames of the lane-per-row pipeline
     size_t slot_bytes, o_mbs, o_coef, o_mvs;
     // job staging
-    DevJob *d_jobs2[2]; DevJob *d_jobs; DevJob *h_jobs; int jobs_cap;   // d_jobs = d_jobs2[parity of the call]
+    DevJob *d_jobs2[VP8HIP_NBUF]; DevJob *d_jobs; DevJob *h_jobs; int jobs_cap;   // d_jobs = d_jobs2[parity of the call]
     // launch configuration
     int num_cu, max_lds;
     int recon_nw, lf_nw;
@@ -90,12 +91,12 @@ extern "C" const char *vp8hip_last_error(const vp8hip_ctx *ctx) { return ctx ? c
 static void free_pools(vp8hip_ctx *c)
 {
     if (c->fb_block) (void)hipFree(c->fb_block);
-    for (int k = 0; k < 2; k++) { if (c->tile_block[k]) (void)hipFree(c->tile_block[k]); c->tile_block[k] = nullptr; c->tile_cap[k] = 0; }
+    for (int k = 0; k < VP8HIP_NBUF; k++) { if (c->tile_block[k]) (void)hipFree(c->tile_block[k]); c->tile_block[k] = nullptr; c->tile_cap[k] = 0; }
     if (c->slot_block_dev) (void)hipFree(c->slot_block_dev);
     for (Slot &s : c->slots)
         if (s.h_block) (void)hipHostFree(s.h_block);
     c->fb_block = nullptr; c->slot_block_dev = nullptr;
-    for (int k = 0; k < 2; k++) { c->tile_block[k] = nullptr; c->tile_cap[k] = 0; }
+    for (int k = 0; k < VP8HIP_NBUF; k++) { c->tile_block[k] = nullptr; c->tile_cap[k] = 0; }
     c->fb.clear(); c->slots.clear();
 }
 
@@ -124,9 +125,11 @@ extern "C" int vp8hip_create(int device, vp8hip_ctx **out)
     c->num_cu = prop.multiProcessorCount;
     c->max_lds = 160 * 1024;
     c->fb_block = nullptr; c->slot_block_dev = nullptr;
-    for (int k = 0; k < 2; k++) { c->tile_block[k] = nullptr; c->tile_cap[k] = 0; }
-    c->d_jobs = nullptr; c->d_jobs2[0] = c->d_jobs2[1] = nullptr; c->h_jobs = nullptr; c->jobs_cap = 0;
-    c->detile_used[0] = c->detile_used[1] = false; c->detile_pending = false; c->parity = 0;
+    for (int k = 0; k < VP8HIP_NBUF; k++) { c->tile_block[k] = nullptr; c->tile_cap[k] = 0; }
+    c->d_jobs = nullptr; c->h_jobs = nullptr; c->jobs_cap = 0;
+    for (int k = 0; k < VP8HIP_NBUF; k++) c->d_jobs2[k] = nullptr;
+    for (int k = 0; k < VP8HIP_NBUF; k++) c->detile_used[k] = false;
+    c->detile_pending = false; c->parity = 0; c->last_par = 0;
     c->deferred.valid = false;
     c->width = c->height = 0;
     c->ncalls = 0;
@@ -146,7 +149,7 @@ extern "C" int vp8hip_create(int device, vp8hip_ctx **out)
     (void)hipEventCreateWithFlags(&c->ev_jobs, hipEventDisableTiming);
     (void)hipEventCreateWithFlags(&c->ev_lf_done, hipEventDisableTiming);
     (void)hipEventCreateWithFlags(&c->ev_recon_done, hipEventDisableTiming);
-    for (int k = 0; k < 2; k++) (void)hipEventCreateWithFlags(&c->ev_detile_done[k], hipEventDisableTiming);
+    for (int k = 0; k < VP8HIP_NBUF; k++) (void)hipEventCreateWithFlags(&c->ev_detile_done[k], hipEventDisableTiming);
     e = hipFuncSetAttribute((const void *)vp8_recon_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_lds);
     if (e != hipSuccess) {
         fail(nullptr, -1, "hipFuncSetAttribute(recon, %d B LDS): %s", c->max_lds, hipGetErrorString(e));
@@ -175,13 +178,13 @@ extern "C" void vp8hip_destroy(vp8hip_ctx *c)
     (void)hipStreamSynchronize(c->stream);
     (void)hipStreamSynchronize(c->stream2);
     free_pools(c);
-    for (int k = 0; k < 2; k++) if (c->d_jobs2[k]) (void)hipFree(c->d_jobs2[k]);
+    for (int k = 0; k < VP8HIP_NBUF; k++) if (c->d_jobs2[k]) (void)hipFree(c->d_jobs2[k]);
     if (c->h_jobs) (void)hipHostFree(c->h_jobs);
     for (int r = 0; r < VP8HIP_STATS_RING; r++) for (int i = 0; i < 6; i++) (void)hipEventDestroy(c->evr[r][i]);
     (void)hipEventDestroy(c->ev_jobs);
     (void)hipEventDestroy(c->ev_lf_done);
     (void)hipEventDestroy(c->ev_recon_done);
-    for (int k = 0; k < 2; k++) (void)hipEventDestroy(c->ev_detile_done[k]);
+    for (int k = 0; k < VP8HIP_NBUF; k++) (void)hipEventDestroy(c->ev_detile_done[k]);
     (void)hipStreamDestroy(c->stream);
     (void)hipStreamDestroy(c->stream2);
     delete c;
@@ -202,7 +205,8 @@ extern "C" int vp8hip_configure(vp8hip_ctx *c, int width, int height, int num_fb
     if (c->width && join_detile(c)) return -1;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream2));
-    c->detile_pending = false; c->detile_used[0] = c->detile_used[1] = false;
+    c->detile_pending = false;
+    for (int k = 0; k < VP8HIP_NBUF; k++) c->detile_used[k] = false;
     free_pools(c);
     c->width = width; c->height = height;
     vp8ir_geom_init(&c->geom, width, height);
@@ -340,7 +344,7 @@ static int join_detile(vp8hip_ctx *c)
         if (launch_deferred(c, c->ev_lf_done)) return -1;
     }
     if (c->detile_pending) {
-        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_detile_done[c->parity ^ 1], 0));
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_detile_done[c->last_par], 0));
         c->detile_pending = false;
     }
     return 0;
@@ -361,10 +365,10 @@ extern "C" int vp8hip_decode(vp8hip_ctx *c, const vp8hip_job *jobs, int njobs, i
         // the staging arrays are reused by in-flight launches: drain before growing
         HIPCHK(c, hipStreamSynchronize(c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream2));
-        for (int k = 0; k < 2; k++) if (c->d_jobs2[k]) (void)hipFree(c->d_jobs2[k]);
+        for (int k = 0; k < VP8HIP_NBUF; k++) if (c->d_jobs2[k]) (void)hipFree(c->d_jobs2[k]);
         if (c->h_jobs) (void)hipHostFree(c->h_jobs);
         c->jobs_cap = njobs < 64 ? 64 : njobs;
-        for (int k = 0; k < 2; k++) HIPCHK(c, hipMalloc((void **)&c->d_jobs2[k], sizeof(DevJob) * c->jobs_cap));
+        for (int k = 0; k < VP8HIP_NBUF; k++) HIPCHK(c, hipMalloc((void **)&c->d_jobs2[k], sizeof(DevJob) * c->jobs_cap));
         HIPCHK(c, hipHostMalloc((void **)&c->h_jobs, sizeof(DevJob) * c->jobs_cap, hipHostMallocDefault));
     } else {
         // h_jobs is read by an async copy of the previous call; wait for that copy only
@@ -389,7 +393,8 @@ extern "C" int vp8hip_decode(vp8hip_ctx *c, const vp8hip_job *jobs, int njobs, i
     if (!tiled) {
         if (join_detile(c)) return -1;             // this launch touches the raster frame buffers directly
     } else {
-        // scratch set and job table `par` were last read by the tiled -> raster pass two launches ago
+        // scratch set and job table `par` were last read by the tiled -> raster pass VP8HIP_NBUF launches ago (three
+        // sets: that pass, launched beside the previous launch's loop filter, may still be finishing)
         if (c->detile_used[par]) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_detile_done[par], 0));
         if (c->tile_cap[par] < tile_frame * njobs) {
             HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -502,7 +507,7 @@ extern "C" int vp8hip_decode(vp8hip_ctx *c, const vp8hip_job *jobs, int njobs, i
         HIPCHK(c, hipEventRecord(ev[5], ds));
         HIPCHK(c, hipEventRecord(c->ev_detile_done[par], ds));
         }
-        c->detile_used[par] = true; c->detile_pending = true; c->parity = par ^ 1;
+        c->detile_used[par] = true; c->detile_pending = true; c->last_par = par; c->parity = (par + 1) % VP8HIP_NBUF;
     } else if (stages & VP8HIP_STAGE_EXTEND) {
         int bx = (c->geom.aligned_h + 64) / 4;
         if (bx < 1) bx = 1;
