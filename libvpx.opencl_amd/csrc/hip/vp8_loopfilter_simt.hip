@@ -66,16 +66,16 @@ __device__ __forceinline__ v2u usubs(v2u a, v2u b) { return __builtin_elementwis
 __device__ __forceinline__ v2u uadds(v2u a, v2u b) { return __builtin_elementwise_add_sat(a, b); }
 __device__ __forceinline__ v2s adds(v2s a, v2s b) { return __builtin_elementwise_add_sat(a, b); }     // signed-char clamp
 __device__ __forceinline__ v2s subs(v2s a, v2s b) { return __builtin_elementwise_sub_sat(a, b); }
-// x != 0 ? 0 : 0xffff (nz_clear) and x != 0 ? 0xffff : 0 (nz_set) per half.  The empty asm hides the 0/1 value from
-// LLVM, which would otherwise turn the subtraction into a compare-and-select that gfx950 does one half at a time.
-__device__ __forceinline__ v2u nz01(v2u x) { v2u t = umin(x, mku(1)); asm("" : "+v"(t)); return t; }
-__device__ __forceinline__ v2u nz_clear(v2u x) { return nz01(x) - mku(1); }
-__device__ __forceinline__ v2u nz_set(v2u x) { return mku(0) - nz01(x); }
+// x != 0 ? 0 : 0xffff (nz_clear) and x != 0 ? 0xffff : 0 (nz_set) per half, from max(1 - x, 0) by saturating subtraction.
+// `one` is the constant 1 | 1 << 16 made opaque to LLVM (one empty asm at kernel entry, see Lim::one): with a visible
+// constant the expression is canonicalised into a compare-and-select, which gfx950 can only do one half at a time.
+__device__ __forceinline__ v2u nz_clear(v2u x, v2u one) { return mku(0) - usubs(one, x); }
+__device__ __forceinline__ v2u nz_set(v2u x, v2u one) { return usubs(one, x) - one; }
 __device__ __forceinline__ v2s sgn(v2u p) { return as_v2s(as_u32(p) ^ 0x80008000u); }                // pixel -> signed
 __device__ __forceinline__ v2u pix(v2s s) { return as_v2u(as_u32(s) ^ 0x80008000u); }
 __device__ __forceinline__ v2s hib(v2s v) { return as_v2s(as_u32(v) & 0xff00ff00u); }                // floor to a whole byte
 
-struct Lim { v2u mblim, blim, lim, thr; };     // the limits, << 8
+struct Lim { v2u mblim, blim, lim, thr, one; };     // the limits, << 8; the opaque constant 1 of nz_clear / nz_set
 
 // The filters are branch-free: `gate` (0xffff / 0 per lane) switches an edge off by clearing its filter mask,
 // which makes every update the identity.  Straight-line code lets the scheduler interleave the independent
@@ -83,7 +83,7 @@ struct Lim { v2u mblim, blim, lim, thr; };     // the limits, << 8
 
 // vp8_filter_mask + vp8_hevmask (loopfilter_filters.c:27-49) for p[0..7] = p3 p2 p1 p0 q0 q1 q2 q3:
 // mask = 0xffff where the edge is filtered, hev = 0xffff where the high-edge-variance rule applies
-__device__ __forceinline__ void masks(const v2u p[8], v2u lim, v2u elim, v2u thr, v2u gate, v2u &mask, v2u &hev)
+__device__ __forceinline__ void masks(const v2u p[8], v2u lim, v2u elim, v2u thr, v2u one, v2u gate, v2u &mask, v2u &hev)
 {
     const v2u d10 = adu(p[2], p[3]), dq = adu(p[5], p[4]);
     const v2u dh = umax(d10, dq);
@@ -92,8 +92,8 @@ __device__ __forceinline__ void masks(const v2u p[8], v2u lim, v2u elim, v2u thr
     const v2u a = adu(p[3], p[4]);
     const v2u e = uadds(uadds(a, a), (adu(p[2], p[5]) >> 1) & mku(0xff00));      // 2|p0-q0| + |p1-q1|/2, saturating
     const v2u over = usubs(m, lim) | usubs(e, elim);                              // non-zero: leave the edge alone
-    mask = nz_clear(over) & gate;
-    hev = nz_set(usubs(dh, thr));
+    mask = nz_clear(over, one) & gate;
+    hev = nz_set(usubs(dh, thr), one);
 }
 
 // filter_value = clamp(filter_value + 3 * (qs0 - ps0)) (loopfilter_filters.c:66, 176): three saturating adds of
@@ -108,7 +108,7 @@ __device__ __forceinline__ v2s add3w(v2s f, v2s qs0, v2s ps0)
 __device__ __forceinline__ void lf_inner(v2u p[8], const Lim &L, v2u gate)
 {
     v2u mask, hev;
-    masks(p, L.lim, L.blim, L.thr, gate, mask, hev);
+    masks(p, L.lim, L.blim, L.thr, L.one, gate, mask, hev);
     v2s ps1 = sgn(p[2]), ps0 = sgn(p[3]), qs0 = sgn(p[4]), qs1 = sgn(p[5]);
     v2s f = as_v2s(as_u32(subs(ps1, qs1)) & as_u32(hev));
     f = as_v2s(as_u32(add3w(f, qs0, ps0)) & as_u32(mask));
@@ -123,7 +123,7 @@ __device__ __forceinline__ void lf_inner(v2u p[8], const Lim &L, v2u gate)
 __device__ __forceinline__ void lf_mbedge(v2u p[8], const Lim &L, v2u gate)
 {
     v2u mask, hev;
-    masks(p, L.lim, L.mblim, L.thr, gate, mask, hev);
+    masks(p, L.lim, L.mblim, L.thr, L.one, gate, mask, hev);
     v2s ps2 = sgn(p[1]), ps1 = sgn(p[2]), ps0 = sgn(p[3]), qs0 = sgn(p[4]), qs1 = sgn(p[5]), qs2 = sgn(p[6]);
     v2s f = as_v2s(as_u32(add3w(subs(ps1, qs1), qs0, ps0)) & as_u32(mask));
     v2s f2 = as_v2s(as_u32(f) & as_u32(hev));
@@ -141,11 +141,11 @@ __device__ __forceinline__ void lf_mbedge(v2u p[8], const Lim &L, v2u gate)
 }
 
 // vp8_loop_filter_simple_horizontal/vertical_edge_c (loopfilter_filters.c:292-355): modifies p0 q0
-__device__ __forceinline__ void lf_simple(v2u p[8], v2u elim, v2u gate)
+__device__ __forceinline__ void lf_simple(v2u p[8], v2u elim, v2u one, v2u gate)
 {
     const v2u a = adu(p[3], p[4]);
     const v2u e = uadds(uadds(a, a), (adu(p[2], p[5]) >> 1) & mku(0xff00));
-    const v2u mask = nz_clear(usubs(e, elim)) & gate;
+    const v2u mask = nz_clear(usubs(e, elim), one) & gate;
     v2s ps1 = sgn(p[2]), ps0 = sgn(p[3]), qs0 = sgn(p[4]), qs1 = sgn(p[5]);
     const v2s f = as_v2s(as_u32(add3w(subs(ps1, qs1), qs0, ps0)) & as_u32(mask));
     const v2s f1 = hib(adds(f, mks(0x0400)) >> 3), f2 = hib(adds(f, mks(0x0300)) >> 3);
@@ -167,9 +167,9 @@ __device__ __forceinline__ void filter_lines(v2u *a, const Gates &G, const Lim &
         for (int e = 1; e < W4; e++) lf_inner(a + 4 * e, L, G.inner);
     }
     if (G.any_simple) {
-        lf_simple(a, L.mblim, G.mb_s);
+        lf_simple(a, L.mblim, L.one, G.mb_s);
 #pragma unroll
-        for (int e = 1; e < W4; e++) lf_simple(a + 4 * e, L.blim, G.inner_s);
+        for (int e = 1; e < W4; e++) lf_simple(a + 4 * e, L.blim, L.one, G.inner_s);
     }
 }
 // the same for two independent sets of lines at once (more instruction-level parallelism)
@@ -182,9 +182,9 @@ __device__ __forceinline__ void filter_lines2(v2u *a, v2u *b, const Gates &G, co
         for (int e = 1; e < W4; e++) { lf_inner(a + 4 * e, L, G.inner); lf_inner(b + 4 * e, L, G.inner); }
     }
     if (G.any_simple) {
-        lf_simple(a, L.mblim, G.mb_s); lf_simple(b, L.mblim, G.mb_s);
+        lf_simple(a, L.mblim, L.one, G.mb_s); lf_simple(b, L.mblim, L.one, G.mb_s);
 #pragma unroll
-        for (int e = 1; e < W4; e++) { lf_simple(a + 4 * e, L.blim, G.inner_s); lf_simple(b + 4 * e, L.blim, G.inner_s); }
+        for (int e = 1; e < W4; e++) { lf_simple(a + 4 * e, L.blim, L.one, G.inner_s); lf_simple(b + 4 * e, L.blim, L.one, G.inner_s); }
     }
 }
 
@@ -204,8 +204,9 @@ __device__ __forceinline__ void pack_rows(u32 *ra, u32 *rb, const v2u *a)
 #pragma unroll
     for (int x = 0; x < NX; x++) {
         const u32 p01 = as_u32(a[4 * x]), p11 = as_u32(a[4 * x + 1]), p21 = as_u32(a[4 * x + 2]), p31 = as_u32(a[4 * x + 3]);
-        ra[x * 64] = perm(perm(p31, p21, 0x0c0c0501u), perm(p11, p01, 0x0c0c0501u), 0x05040100u);
-        rb[x * 64] = perm(perm(p31, p21, 0x0c0c0703u), perm(p11, p01, 0x0c0c0703u), 0x05040100u);
+        const u32 t01 = perm(p11, p01, 0x07030501u), t23 = perm(p31, p21, 0x07030501u);     // A0 A1 B0 B1 | A2 A3 B2 B3
+        ra[x * 64] = perm(t23, t01, 0x05040100u);
+        rb[x * 64] = perm(t23, t01, 0x07060302u);
     }
 }
 
@@ -265,7 +266,7 @@ __device__ __forceinline__ int mb_level(const vp8ir_frame_hdr &h, int seg, int r
 }
 
 // vp8_loop_filter_update_sharpness + hev threshold LUT (loopfilter.c:24-96)
-__device__ __forceinline__ Lim mb_limits(int sharp, int level, int frame_type)
+__device__ __forceinline__ Lim mb_limits(int sharp, int level, int frame_type, v2u one)
 {
     int ilimit = level >> (sharp > 0);
     ilimit >>= (sharp > 4);
@@ -279,6 +280,7 @@ __device__ __forceinline__ Lim mb_limits(int sharp, int level, int frame_type)
     Lim L;
     L.lim = mku(ilimit << 8); L.blim = mku(((2 * level + ilimit) & 0xff) << 8); L.mblim = mku(((2 * (level + 2) + ilimit) & 0xff) << 8);
     L.thr = mku(thr << 8);
+    L.one = one;
     return L;
 }
 
@@ -308,6 +310,8 @@ vp8_loopfilter_simt_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g
     const int T = ((wavejobs * rows + G - 1) >> lgG) * P + 2 * (G - 1);
     const long rowbytes = (long)cols * VP8_TILE_BYTES;
     u32 *const TL = tile + lane;
+    v2u one = mku(1);
+    asm volatile("" : "+v"(one));            // see nz_clear
 
     // ---- per-lane row state
     g_cu32p mbp = nullptr;
@@ -370,7 +374,7 @@ vp8_loopfilter_simt_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g
             const int y_mode = w0 & 0xff, ref_frame = (w0 >> 16) & 0xff;
             const u32 flags = w0 >> 24;
             const int level = mb_level(h, w1 & 3, ref_frame & 3, y_mode);
-            const Lim L = mb_limits(h.sharpness_level, level, h.frame_type);
+            const Lim L = mb_limits(h.sharpness_level, level, h.frame_type, one);
             const bool on = level != 0;
             const bool skip_lf = y_mode != VP8IR_B_PRED && y_mode != VP8IR_SPLITMV && (flags & VP8IR_MB_SKIP);
             const bool mbv = on && c > 0, inner = on && !skip_lf, mbh = on && r > 0;
