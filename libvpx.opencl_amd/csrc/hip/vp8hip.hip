@@ -376,14 +376,15 @@ extern "C" int vp8hip_decode(vp8hip_ctx *c, const vp8hip_job *jobs, int njobs, i
     }
     const int nfb = (int)c->fb.size(), nsl = (int)c->slots.size();
     bool any_lf = false;
-    // Which reconstruction kernel: the wave-per-MB-row kernel is the faster one while a launch has fewer
-    // frames than the chip has SIMDs to fill; the one-MB-row-per-lane kernel wins beyond that.
+    // Which reconstruction kernel: the wave-per-MB-row kernels are the faster ones up to one frame pair per CU
+    // (512 frames on an MI355X: 126 vs 85 Gpix/s at 1080p); beyond that they need a second round of workgroups and
+    // the one-MB-row-per-lane kernels win (640 frames: 108 vs 85).
     // (Its inter prediction still works 4x4 block by 4x4 block and loses to the wave-per-row kernel on inter
     // frames, so launches that contain inter frames stay with the latter.)
     bool all_key = true;
     for (int i = 0; i < njobs && all_key; i++)
         if (jobs[i].ir_slot >= 0 && jobs[i].ir_slot < nsl) all_key = c->slots[jobs[i].ir_slot].hdr_copy.frame_type == 0;
-    bool simt_recon = (stages & VP8HIP_STAGE_RECON) && all_key && njobs >= 3 * c->num_cu;
+    bool simt_recon = (stages & VP8HIP_STAGE_RECON) && all_key && njobs > 2 * c->num_cu;
     if (const char *e = getenv("VP8HIP_RECON"))      // tuning / test knob: force one of the two kernel families
         simt_recon = (stages & VP8HIP_STAGE_RECON) && (!strcmp(e, "simt") ? true : (!strcmp(e, "wave") ? false : simt_recon));
     // the lane-per-row kernels work on macroblock-tiled scratch frames; vp8_detile_kernel converts at the end
@@ -397,12 +398,17 @@ extern "C" int vp8hip_decode(vp8hip_ctx *c, const vp8hip_job *jobs, int njobs, i
         // sets: that pass, launched beside the previous launch's loop filter, may still be finishing)
         if (c->detile_used[par]) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_detile_done[par], 0));
         if (c->tile_cap[par] < tile_frame * njobs) {
+            // grow ALL sets now: a launch in the middle of a pipelined sequence must not stop to allocate
+            if (join_detile(c)) return -1;          // a pass not launched yet still reads the old sets
             HIPCHK(c, hipStreamSynchronize(c->stream));
             HIPCHK(c, hipStreamSynchronize(c->stream2));
-            if (c->tile_block[par]) (void)hipFree(c->tile_block[par]);
-            c->tile_block[par] = nullptr; c->tile_cap[par] = 0;
-            HIPCHK(c, hipMalloc((void **)&c->tile_block[par], tile_frame * njobs));
-            c->tile_cap[par] = tile_frame * njobs;
+            for (int k = 0; k < VP8HIP_NBUF; k++) {
+                if (c->tile_cap[k] >= tile_frame * njobs) continue;
+                if (c->tile_block[k]) (void)hipFree(c->tile_block[k]);
+                c->tile_block[k] = nullptr; c->tile_cap[k] = 0;
+                HIPCHK(c, hipMalloc((void **)&c->tile_block[k], tile_frame * njobs));
+                c->tile_cap[k] = tile_frame * njobs;
+            }
         }
     }
     c->d_jobs = c->d_jobs2[par];
@@ -438,13 +444,18 @@ extern "C" int vp8hip_decode(vp8hip_ctx *c, const vp8hip_job *jobs, int njobs, i
     c->stats.lf_waves = c->lf_nw;
     hipEvent_t *ev = c->evr[c->ncalls % VP8HIP_STATS_RING];
     HIPCHK(c, hipEventRecord(ev[0], c->stream));
-    // "one MB row per lane" kernels: G lanes per strand of frames, row period P >= max(cols, 2G+2).  The largest
-    // G that costs no idle steps (cols >= 2G+2), widened while the launch would leave SIMDs without a wave.
+    // "one MB row per lane" kernels: G lanes per strand of frames, row period P >= max(cols, 2G+2).  G is at most
+    // the largest value that costs no idle steps (cols >= 2G+2), and otherwise as small as it can be while every
+    // strand of a full launch (4 waves per CU) still gets a frame: a small G means few pipeline-fill steps and a
+    // better fit of the frame's rows into whole row periods.
     int lgG = 1;
     {
         const int cols = c->dg.mb_cols;
-        while (lgG < 6 && 2 * (2 << lgG) + 2 <= cols) lgG++;
-        while (lgG < 6 && (njobs + (64 >> lgG) - 1) / (64 >> lgG) < c->num_cu * 8) lgG++;
+        int lgmax = 1;
+        while (lgmax < 6 && 2 * (2 << lgmax) + 2 <= cols) lgmax++;
+        const long lanes = (long)c->num_cu * 4 * 64;                      // one wave per SIMD
+        while (lgG < 6 && (lanes >> lgG) > njobs) lgG++;                  // strands of a full launch <= frames
+        if (lgG > lgmax && ((long)njobs << lgmax) >= lanes) lgG = lgmax;   // no idle steps, if that still fills every SIMD
         if (const char *e = getenv("VP8HIP_SIMT_LGG")) { int v = atoi(e); if (v >= 1 && v <= 6) lgG = v; }
     }
     const int simtG = 1 << lgG, spw = 64 >> lgG;

@@ -134,7 +134,7 @@ def test_full_size_1080p_batch_properties(pkg, ctx):
 
 
 def test_automatic_kernel_choice(pkg, ctx, kernel_family, monkeypatch):
-    """Without the override a launch of >= 3 frames per CU takes the lane-per-row kernels, a smaller one the
+    """Without the override a launch of more than 2 key frames per CU takes the lane-per-row kernels, a smaller one the
     wave-per-row kernels; both sides of the threshold produce the reference's frames."""
     if kernel_family == "lane":
         pytest.skip("one run is enough")
