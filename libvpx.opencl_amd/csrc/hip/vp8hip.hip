@@ -139,12 +139,7 @@ extern "C" int vp8hip_create(int device, vp8hip_ctx **out)
         delete c;
         return -1;
     }
-    if ((e = hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking)) != hipSuccess) {
-        fail(nullptr, -1, "hipStreamCreate: %s", hipGetErrorString(e));
-        (void)hipStreamDestroy(c->stream);
-        delete c;
-        return -1;
-    }
+    c->stream2 = nullptr;      // created by the first launch that wants it
     for (int r = 0; r < VP8HIP_STATS_RING; r++) for (int i = 0; i < 6; i++) (void)hipEventCreate(&c->evr[r][i]);
     (void)hipEventCreateWithFlags(&c->ev_jobs, hipEventDisableTiming);
     (void)hipEventCreateWithFlags(&c->ev_lf_done, hipEventDisableTiming);
@@ -153,7 +148,7 @@ extern "C" int vp8hip_create(int device, vp8hip_ctx **out)
     e = hipFuncSetAttribute((const void *)vp8_recon_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_lds);
     if (e != hipSuccess) {
         fail(nullptr, -1, "hipFuncSetAttribute(recon, %d B LDS): %s", c->max_lds, hipGetErrorString(e));
-        (void)hipStreamDestroy(c->stream); (void)hipStreamDestroy(c->stream2);
+        (void)hipStreamDestroy(c->stream);
         delete c;
         return -1;
     }
@@ -176,7 +171,7 @@ extern "C" void vp8hip_destroy(vp8hip_ctx *c)
     (void)hipSetDevice(c->device);
     (void)join_detile(c);
     (void)hipStreamSynchronize(c->stream);
-    (void)hipStreamSynchronize(c->stream2);
+    if (c->stream2) (void)hipStreamSynchronize(c->stream2);
     free_pools(c);
     for (int k = 0; k < VP8HIP_NBUF; k++) if (c->d_jobs2[k]) (void)hipFree(c->d_jobs2[k]);
     if (c->h_jobs) (void)hipHostFree(c->h_jobs);
@@ -186,7 +181,7 @@ extern "C" void vp8hip_destroy(vp8hip_ctx *c)
     (void)hipEventDestroy(c->ev_recon_done);
     for (int k = 0; k < VP8HIP_NBUF; k++) (void)hipEventDestroy(c->ev_detile_done[k]);
     (void)hipStreamDestroy(c->stream);
-    (void)hipStreamDestroy(c->stream2);
+    if (c->stream2) (void)hipStreamDestroy(c->stream2);
     delete c;
 }
 
@@ -204,7 +199,7 @@ extern "C" int vp8hip_configure(vp8hip_ctx *c, int width, int height, int num_fb
     HIPCHK(c, hipSetDevice(c->device));
     if (c->width && join_detile(c)) return -1;
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream2));
+    if (c->stream2) HIPCHK(c, hipStreamSynchronize(c->stream2));
     c->detile_pending = false;
     for (int k = 0; k < VP8HIP_NBUF; k++) c->detile_used[k] = false;
     free_pools(c);
@@ -364,7 +359,7 @@ extern "C" int vp8hip_decode(vp8hip_ctx *c, const vp8hip_job *jobs, int njobs, i
     if (njobs > c->jobs_cap) {
         // the staging arrays are reused by in-flight launches: drain before growing
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream2));
+        if (c->stream2) HIPCHK(c, hipStreamSynchronize(c->stream2));
         for (int k = 0; k < VP8HIP_NBUF; k++) if (c->d_jobs2[k]) (void)hipFree(c->d_jobs2[k]);
         if (c->h_jobs) (void)hipHostFree(c->h_jobs);
         c->jobs_cap = njobs < 64 ? 64 : njobs;
@@ -401,7 +396,7 @@ extern "C" int vp8hip_decode(vp8hip_ctx *c, const vp8hip_job *jobs, int njobs, i
             // grow ALL sets now: a launch in the middle of a pipelined sequence must not stop to allocate
             if (join_detile(c)) return -1;          // a pass not launched yet still reads the old sets
             HIPCHK(c, hipStreamSynchronize(c->stream));
-            HIPCHK(c, hipStreamSynchronize(c->stream2));
+            if (c->stream2) HIPCHK(c, hipStreamSynchronize(c->stream2));
             for (int k = 0; k < VP8HIP_NBUF; k++) {
                 if (c->tile_cap[k] >= tile_frame * njobs) continue;
                 if (c->tile_block[k]) (void)hipFree(c->tile_block[k]);
@@ -499,6 +494,7 @@ extern "C" int vp8hip_decode(vp8hip_ctx *c, const vp8hip_job *jobs, int njobs, i
     HIPCHK(c, hipEventRecord(ev[2], c->stream));
     if (tiled) {      // whatever stages ran, the frame buffer gets the result; borders are extended on the way
         const bool own_stream = !(getenv("VP8HIP_DETILE_STREAM") && !atoi(getenv("VP8HIP_DETILE_STREAM")));
+        if (own_stream && !c->stream2) HIPCHK(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
         // deferred by default: the pass is launched with the NEXT lane-per-row launch, right after its recon, so
         // that it runs beside that launch's loop filter (which it disturbs less than the recon), or at the next join
         const bool defer = own_stream && !(getenv("VP8HIP_DETILE_DEFER") && !atoi(getenv("VP8HIP_DETILE_DEFER")));
