@@ -89,6 +89,27 @@ def test_random_ir_against_oracle(pkg, ctx, w, h, inter, version, ftype):
         assert not d, (seed, d)
 
 
+@pytest.mark.parametrize("w,h,n", [(176, 144, 40), (48, 80, 150), (640, 368, 12)])
+def test_random_ir_batches_against_oracle(pkg, ctx, w, h, n):
+    """Many DIFFERENT random key frames in one launch (different modes, quantisers, filter types and levels per job):
+    the frames of a launch share waves -- lane halves in one family, strands of lanes in the other -- and must not
+    influence each other."""
+    ctx.configure(w, h, n, n)
+    g = ctx.g
+    irs = []
+    for i in range(n):
+        hdr, mbs, coef, mvs = synth_ir(w, h, 1000 + 13 * i + w, inter=False, version=i % 4, filter_type=i % 2,
+                                       dense=(0.1, 0.5, 0.9)[i % 3], big=i % 5 == 0, segmented=i % 3 != 0)
+        ctx.fill_slot(i, hdr, mbs, coef, mvs)
+        irs.append((hdr, mbs, coef, mvs))
+    ctx.decode([(i, i, None) for i in range(n)], 7)
+    for i in range(n):
+        o = np.zeros(g.frame_size, np.uint8)
+        oracle_decode(*irs[i], o, (o, o, o), 7)
+        d = bordered_area_equal(ctx.download_full(i), o, g)
+        assert not d, (i, d)
+
+
 def _batch(pkg, ctx, name, nframes):
     w, h, frames = pkg.read_ivf(ivf_path(name))
     gold = golden_md5(name)
