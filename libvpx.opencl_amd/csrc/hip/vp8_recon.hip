@@ -186,18 +186,26 @@ __device__ __forceinline__ u32 intra_pred4(int mode, u32 above, int left, int tl
     return out;
 }
 
+// clamp255(v >> 7), with the shift hidden from LLVM so that it does not form v_ashr_pk_u8_i32 (see vp8_recon_simt.hip)
+__device__ __forceinline__ int shr7_clamp255(int v)
+{
+    int t = v >> 7;
+    asm volatile("" : "+v"(t));
+    return clamp255(t);
+}
+
 // ---- inter prediction of a 4-pixel row segment (reconinter.c:161-227 + filter.c) --------------
 // ref points at pixel (0,0) of the plane; (px,py) = integer position of the first output pixel in
 // the current frame; mv in 1/8 pel.  border = 32 (luma) / 16 (chroma); plane w x h (coded size).
 __device__ __forceinline__ u32 inter_row4(g_cu8p ref, int stride, int px, int py, int mvrow, int mvcol,
-                                          bool bilinear, int w, int h, int border)
+                                          bool bilinear, int w, int h, int border, int j)
 {
     int sx = px + (mvcol >> 3), sy = py + (mvrow >> 3);
     const int fx = mvcol & 7, fy = mvrow & 7;
     // memory safety only (a conforming stream never triggers these): keep every tap inside the
     // allocated plane incl. its border.
     sx = max(-border + 2, min(sx, w + border - 10));
-    sy = max(-border + 2, min(sy, h + border - 4));
+    sy = max(-border + 2, min(sy, h + border - 7));
     g_cu8p s = ref + (long)sy * stride + sx;
     int out[4];
     // Six-tap source rows are fetched as aligned dwords and shifted into place (v_alignbyte_b32): three loads per
@@ -228,22 +236,45 @@ __device__ __forceinline__ u32 inter_row4(g_cu8p ref, int stride, int px, int py
             out[i] = (t0 * v0 + t1 * v1 + 64) >> 7;
         }
     } else {
-        // six-tap, both passes always (filter.c:41-128): H over rows -2..+3 with clamp, then V with clamp
-        int acc[4] = { 64, 64, 64, 64 };
-#pragma unroll
-        for (int r = 0; r < 6; r++) {
+        // six-tap, both passes always (filter.c:41-128): H over rows -2..+3 with clamp, then V with clamp.
+        // The four lanes of a quad are the four rows of one 4x4 block (j = row) with one MV: together they need the
+        // horizontally filtered source rows -2..6 of the block.  Lane j filters rows j-2 and j+2 (lane 0 also row 6)
+        // instead of its own six, and the quad exchanges the results (four clamped pixels = one dword) by DPP.
+        auto hrow = [&](int r) -> u32 {
             int p[9];
-            rowpx(r - 2, p);
-            const int vt = k_sixtap[fy][r];
+            rowpx(r, p);
+            u32 o = 0;
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 int t = p[i] * k_sixtap[fx][0] + p[i + 1] * k_sixtap[fx][1] + p[i + 2] * k_sixtap[fx][2]
                       + p[i + 3] * k_sixtap[fx][3] + p[i + 4] * k_sixtap[fx][4] + p[i + 5] * k_sixtap[fx][5] + 64;
-                acc[i] += clamp255(t >> 7) * vt;
+                o |= (u32)shr7_clamp255(t) << (8 * i);
             }
-        }
+            return o;
+        };
+        const u32 Ha = hrow(-2), Hb = hrow(2), Hc = hrow(j == 0 ? 6 : 2);
+        // quad rotations: lane i takes the value of lane (i + k) & 3
+        auto rot1 = [](u32 v) { return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x39, 0xf, 0xf, false); };
+        auto rot2 = [](u32 v) { return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, false); };
+        auto rot3 = [](u32 v) { return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x93, 0xf, 0xf, false); };
+        // every rotation is executed by the whole quad (a DPP read of a lane that sits in the other arm of a
+        // branch returns nothing), the selection happens afterwards
+        const u32 a1 = rot1(Ha), a2 = rot2(Ha), a3 = rot3(Ha);
+        const u32 b1 = rot1(Hb), b2 = rot2(Hb), b3 = rot3(Hb), c1 = rot1(Hc);
+        u32 H[6];      // filtered source rows j-2 .. j+3 of the block = rows -2 .. +3 of this lane's output row
+        H[0] = Ha;
+        H[1] = j + 1 < 4 ? a1 : b1;
+        H[2] = j + 2 < 4 ? a2 : b2;
+        H[3] = j + 3 < 4 ? a3 : b3;
+        H[4] = Hb;
+        H[5] = j == 3 ? c1 : b1;
 #pragma unroll
-        for (int i = 0; i < 4; i++) out[i] = clamp255(acc[i] >> 7);
+        for (int i = 0; i < 4; i++) {
+            int acc = 64;
+#pragma unroll
+            for (int k = 0; k < 6; k++) acc += (int)((H[k] >> (8 * i)) & 0xff) * k_sixtap[fy][k];
+            out[i] = shr7_clamp255(acc);
+        }
     }
     return (u32)out[0] | ((u32)out[1] << 8) | ((u32)out[2] << 16) | ((u32)out[3] << 24);
 }
@@ -558,7 +589,7 @@ vp8_recon_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g)
                     int mrow = sext16(mvw), mcol = hi16(mvw);
                     if (clampmv) clamp_luma_mv(mrow, mcol, e_left, e_right, e_top, e_bottom);
                     const u32 pp = inter_row4(rf + g.y_off, g.y_stride, c * 16 + lx0, r * 16 + y, mrow, mcol, bilinear,
-                                              g.aligned_w, g.aligned_h, 32);
+                                              g.aligned_w, g.aligned_h, 32, hl & 3);
                     if (p) outY1 = add_clamp_pack(pp, rY1); else outY0 = add_clamp_pack(pp, rY0);
                 }
                 {   // chroma
@@ -584,7 +615,7 @@ vp8_recon_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g)
                         if (clampmv) clamp_chroma_mv(mrow, mcol, e_left, e_right, e_top, e_bottom);
                     }
                     const u32 pp = inter_row4(rf + (cpl ? g.v_off : g.u_off), g.uv_stride, c * 8 + cx0, r * 8 + cy, mrow,
-                                              mcol, bilinear, g.aligned_w / 2, g.aligned_h / 2, 16);
+                                              mcol, bilinear, g.aligned_w / 2, g.aligned_h / 2, 16, hl & 3);
                     outC = add_clamp_pack(pp, rC);
                 }
             }

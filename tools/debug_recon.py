@@ -36,7 +36,7 @@ for fi, data in enumerate(frames[:nframes]):
                 b = np.lib.stride_tricks.as_strided(o[off + rr * n * st + cc * n:], (n, n), (st, 1))
                 if not np.array_equal(a, b):
                     bad.append((rr, cc, nm, a.copy(), b.copy()))
-    print(f"frame {fi}: type {hdr.frame_type} {len(bad)} bad MB-planes of {rows*cols*3}")
+    print(f"frame {fi}: type {hdr.frame_type} {len(bad)} bad MB-planes of {rows*cols*3}; bad rows {sorted(set(b[0] for b in bad))}")
     seen = 0
     for rr, cc, nm, a, b in sorted(bad, key=lambda t: (t[0] * 2 + t[1], t[2]))[:6]:
         m = mbs[rr * cols + cc]
