@@ -131,6 +131,15 @@ __device__ __forceinline__ u32 add_clamp_pack(u32 pred, const int *r)
     return perm(as_u32(hi), as_u32(lo), 0x06040200u);
 }
 
+// vp8_dc_only_idct_add_c (idctllm.c:112-137): a block with eob <= 1 (idct_blk.c:28-37) adds (dc + 4) >> 3 to all 16
+// predictor pixels.  Same result as the full transform of a DC-only block, at a sixth of its cost.
+__device__ __forceinline__ u32 add_dc_clamp_pack(u32 pred, v2s d)
+{
+    const v2s lo = clamp255_2(as_v2s(perm(pred, pred, 0x0c010c00u)) + d);
+    const v2s hi = clamp255_2(as_v2s(perm(pred, pred, 0x0c030c02u)) + d);
+    return perm(as_u32(hi), as_u32(lo), 0x06040200u);
+}
+
 // TM prediction of a row of four pixels: clamp(above[i] + left - top_left), above given as two packed pairs
 __device__ __forceinline__ u32 tm_row(v2s a01, v2s a23, int l_minus_tl)
 {
@@ -366,7 +375,7 @@ vp8_recon_simt_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g, int
     // software pipeline: the descriptor, the Y2 block and the first coefficient group of the NEXT macroblock
     // of the row are fetched while the current one is being finished; inside a macroblock every group of
     // four blocks is fetched one group ahead (`nxt`) and becomes `cur` when its turn comes.
-    u32 pf_w0 = 0, pf_w1 = 0;
+    u32x4 pf_m0 = { 0, 0, 0, 0 }, pf_m1 = { 0, 0, 0, 0 };   // descriptor words 0..7: modes, segment, eobs of blocks 0..23
     u32x4 pf_bm = { 0, 0, 0, 0 }, pf_y2a = { 0, 0, 0, 0 }, pf_y2b = { 0, 0, 0, 0 };
     u32x4 cur[8], nxt[8];
 #pragma unroll
@@ -416,14 +425,16 @@ vp8_recon_simt_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g, int
                 lY[0] = lY[1] = lY[2] = lY[3] = 0x81818181u;    // left border 129 (setupintrarecon.c:15-32)
                 lU[0] = lU[1] = lV[0] = lV[1] = 0x81818181u;
                 // nothing was prefetched for the first macroblock of a row
-                pf_w0 = mbp[0]; pf_w1 = mbp[1]; pf_bm = *(g_cu32x4p)(mbp + 10);
+                pf_m0 = *(g_cu32x4p)mbp; pf_m1 = *(g_cu32x4p)(mbp + 4); pf_bm = *(g_cu32x4p)(mbp + 10);
                 pf_y2a = *(g_cu32x4p)(cfp + 384); pf_y2b = *(g_cu32x4p)(cfp + 392);
 #pragma unroll
                 for (int i = 0; i < 8; i++) cur[i] = *(g_cu32x4p)(cfp + i * 8);
             }
             const bool top = r == 0;
             // ---- macroblock descriptor
-            const u32 w0 = pf_w0, w1 = pf_w1;
+            const u32 w0 = pf_m0.x, w1 = pf_m0.y;
+            // eobs (detokenize.c:363), a byte per block: luma block rows 0..3, then U | V
+            const u32 eobY[4] = { pf_m0.z, pf_m0.w, pf_m1.x, pf_m1.y }, eobU = pf_m1.z, eobV = pf_m1.w;
             const u32x4 bm = pf_bm;
             const int y_mode = w0 & 0xff, uv_mode = (w0 >> 8) & 0xff, ref_frame = (w0 >> 16) & 0xff;
             const u32 flags = w0 >> 24;
@@ -534,6 +545,7 @@ vp8_recon_simt_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g, int
                     }
                 }
                 const u32 bmw = by == 0 ? bm.x : by == 1 ? bm.y : by == 2 ? bm.z : bm.w;
+                const u32 eobw = by == 0 ? eobY[0] : by == 1 ? eobY[1] : by == 2 ? eobY[2] : eobY[3];
                 u32 left = lcur;
                 int tl = tlrow;
                 u32 orow[4][4];                               // [row][block]: 16-byte rows for the write-out
@@ -551,11 +563,21 @@ vp8_recon_simt_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g, int
                         for (int jj = 0; jj < 4; jj++) p[jj] = predlds[(k * 4 + jj) * 64 + lane];
                     }
                     u32 o[4] = { p[0], p[1], p[2], p[3] };
-                    if (!skip) {
-                        int res[16];
-                        dequant_idct(cur[2 * k], cur[2 * k + 1], dq0 & 0xffff, dq0 >> 16, has_y2, dc[k], res);
+                    // idct_blk.c:28-37: eob > 1 -> the full transform, else DC only.  The branch is taken per wave: the
+                    // DC-only path is only worth having when no lane needs the transform.
+                    const bool full = !skip && ((eobw >> (8 * k)) & 0xff) > 1;
+                    if (__builtin_amdgcn_ballot_w64(full) != 0) {
+                        if (!skip) {
+                            int res[16];
+                            dequant_idct(cur[2 * k], cur[2 * k + 1], dq0 & 0xffff, dq0 >> 16, has_y2, dc[k], res);
 #pragma unroll
-                        for (int jj = 0; jj < 4; jj++) o[jj] = add_clamp_pack(p[jj], res + 4 * jj);
+                            for (int jj = 0; jj < 4; jj++) o[jj] = add_clamp_pack(p[jj], res + 4 * jj);
+                        }
+                    } else if (!skip) {
+                        const int d0 = has_y2 ? dc[k] : (short)(sext16(cur[2 * k].x) * (int)(dq0 & 0xffff));
+                        const int d = (d0 + 4) >> 3;
+#pragma unroll
+                        for (int jj = 0; jj < 4; jj++) o[jj] = add_dc_clamp_pack(p[jj], pk(d, d));
                     }
 #pragma unroll
                     for (int jj = 0; jj < 4; jj++) orow[jj][k] = o[jj];
@@ -630,7 +652,7 @@ vp8_recon_simt_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g, int
                         for (int i = 0; i < 8; i++) nxt[i] = *(g_cu32x4p)(cfp + 320 + i * 8);
                     }
                 } else if (more) {                            // the next macroblock of the row
-                    pf_w0 = mbp[16]; pf_w1 = mbp[17]; pf_bm = *(g_cu32x4p)(mbp + 26);
+                    pf_m0 = *(g_cu32x4p)(mbp + 16); pf_m1 = *(g_cu32x4p)(mbp + 20); pf_bm = *(g_cu32x4p)(mbp + 26);
                     pf_y2a = *(g_cu32x4p)(cfp + VP8IR_COEF_PER_MB + 384); pf_y2b = *(g_cu32x4p)(cfp + VP8IR_COEF_PER_MB + 392);
 #pragma unroll
                     for (int i = 0; i < 8; i++) nxt[i] = *(g_cu32x4p)(cfp + VP8IR_COEF_PER_MB + i * 8);
@@ -660,11 +682,18 @@ vp8_recon_simt_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g, int
                         for (int jj = 0; jj < 4; jj++) p[jj] = predlds[(k * 4 + jj) * 64 + lane];
                     }
                     u32 o[4] = { p[0], p[1], p[2], p[3] };
-                    if (!skip) {
-                        int res[16];
-                        dequant_idct(cur[2 * k], cur[2 * k + 1], dq2 & 0xffff, dq2 >> 16, false, 0, res);
+                    const bool full = !skip && (((pl ? eobV : eobU) >> (8 * k)) & 0xff) > 1;
+                    if (__builtin_amdgcn_ballot_w64(full) != 0) {
+                        if (!skip) {
+                            int res[16];
+                            dequant_idct(cur[2 * k], cur[2 * k + 1], dq2 & 0xffff, dq2 >> 16, false, 0, res);
 #pragma unroll
-                        for (int jj = 0; jj < 4; jj++) o[jj] = add_clamp_pack(p[jj], res + 4 * jj);
+                            for (int jj = 0; jj < 4; jj++) o[jj] = add_clamp_pack(p[jj], res + 4 * jj);
+                        }
+                    } else if (!skip) {
+                        const int d = ((short)(sext16(cur[2 * k].x) * (int)(dq2 & 0xffff)) + 4) >> 3;
+#pragma unroll
+                        for (int jj = 0; jj < 4; jj++) o[jj] = add_dc_clamp_pack(p[jj], pk(d, d));
                     }
 #pragma unroll
                     for (int jj = 0; jj < 4; jj++) orow[byc * 4 + jj][bx] = o[jj];
