@@ -186,14 +186,6 @@ __device__ __forceinline__ u32 intra_pred4(int mode, u32 above, int left, int tl
     return out;
 }
 
-// clamp255(v >> 7), with the shift hidden from LLVM so that it does not form v_ashr_pk_u8_i32 (see vp8_recon_simt.hip)
-__device__ __forceinline__ int shr7_clamp255(int v)
-{
-    int t = v >> 7;
-    asm volatile("" : "+v"(t));
-    return clamp255(t);
-}
-
 // ---- inter prediction of a 4-pixel row segment (reconinter.c:161-227 + filter.c) --------------
 // ref points at pixel (0,0) of the plane; (px,py) = integer position of the first output pixel in
 // the current frame; mv in 1/8 pel.  border = 32 (luma) / 16 (chroma); plane w x h (coded size).
@@ -209,18 +201,9 @@ __device__ __forceinline__ u32 inter_row4(g_cu8p ref, int stride, int px, int py
     g_cu8p s = ref + (long)sy * stride + sx;
     int out[4];
     // Six-tap source rows are fetched as aligned dwords and shifted into place (v_alignbyte_b32): three loads per
-    // row instead of nine byte loads.  rowpx(r, p): pixels s[r*stride - 2 .. r*stride + 6] of source row r.
+    // row instead of nine byte loads.
     const u32 sh = (u32)(unsigned long)(s - 2) & 3u;
     g_cu8p sa = s - 2 - sh;
-    auto rowpx = [&](int r, int p[9]) {
-        g_cu32p rp = (g_cu32p)(sa + (long)r * stride);
-        const u32 d0 = rp[0], d1 = rp[1], d2 = rp[2];
-        const u32 w0 = __builtin_amdgcn_alignbyte(d1, d0, sh), w1 = __builtin_amdgcn_alignbyte(d2, d1, sh);
-        const u32 w2 = __builtin_amdgcn_alignbyte(0u, d2, sh);
-#pragma unroll
-        for (int i = 0; i < 4; i++) { p[i] = (w0 >> (8 * i)) & 0xff; p[4 + i] = (w1 >> (8 * i)) & 0xff; }
-        p[8] = w2 & 0xff;
-    };
     if ((fx | fy) == 0) {
 #pragma unroll
         for (int i = 0; i < 4; i++) out[i] = s[i];
@@ -240,17 +223,38 @@ __device__ __forceinline__ u32 inter_row4(g_cu8p ref, int stride, int px, int py
         // The four lanes of a quad are the four rows of one 4x4 block (j = row) with one MV: together they need the
         // horizontally filtered source rows -2..6 of the block.  Lane j filters rows j-2 and j+2 (lane 0 also row 6)
         // instead of its own six, and the quad exchanges the results (four clamped pixels = one dword) by DPP.
-        auto hrow = [&](int r) -> u32 {
-            int p[9];
-            rowpx(r, p);
-            u32 o = 0;
+        // Both passes run two pixels per instruction on 16-bit lanes: a first-pass sum lies in -8160 .. 40864, so
+        // biased by 8192 it is an unsigned 16-bit number and wrap-around arithmetic (v_pk_mad_u16, negative taps as
+        // their two's complement) is exact; (t + 8192) >> 7 == (t >> 7) + 64, and a saturating subtraction of 64 plus
+        // a minimum with 255 are the clamp.
+        typedef unsigned short v2u __attribute__((ext_vector_type(2)));
+        auto asv = [](u32 v) { return __builtin_bit_cast(v2u, v); };
+        auto asu = [](v2u v) { return __builtin_bit_cast(u32, v); };
+        auto perm = [](u32 hi, u32 lo, u32 sel) { return __builtin_amdgcn_perm(hi, lo, sel); };
+        auto tap2 = [&](int f, int k) { const unsigned short t = (unsigned short)k_sixtap[f][k]; return (v2u){ t, t }; };
+        auto finish = [&](v2u a01, v2u a23) -> u32 {         // two biased sums of two pixels -> four clamped bytes
+            const v2u c64 = { 64, 64 }, c255 = { 255, 255 };
+            const v2u r01 = __builtin_elementwise_min(__builtin_elementwise_sub_sat(a01 >> 7, c64), c255);
+            const v2u r23 = __builtin_elementwise_min(__builtin_elementwise_sub_sat(a23 >> 7, c64), c255);
+            return perm(asu(r23), asu(r01), 0x06040200u);
+        };
+        const v2u bias = { 64 + 8192, 64 + 8192 };
+        v2u tx[6], ty[6];
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                int t = p[i] * k_sixtap[fx][0] + p[i + 1] * k_sixtap[fx][1] + p[i + 2] * k_sixtap[fx][2]
-                      + p[i + 3] * k_sixtap[fx][3] + p[i + 4] * k_sixtap[fx][4] + p[i + 5] * k_sixtap[fx][5] + 64;
-                o |= (u32)shr7_clamp255(t) << (8 * i);
-            }
-            return o;
+        for (int k = 0; k < 6; k++) { tx[k] = tap2(fx, k); ty[k] = tap2(fy, k); }
+        auto hrow = [&](int r) -> u32 {
+            g_cu32p rp = (g_cu32p)(sa + (long)r * stride);
+            const u32 d0 = rp[0], d1 = rp[1], d2 = rp[2];
+            const u32 w0 = __builtin_amdgcn_alignbyte(d1, d0, sh), w1 = __builtin_amdgcn_alignbyte(d2, d1, sh);
+            const u32 w2 = __builtin_amdgcn_alignbyte(0u, d2, sh);
+            // P[k] = pixels (k, k+1) of the row, one per 16-bit lane
+            const v2u P[8] = { asv(perm(w0, w0, 0x0c010c00u)), asv(perm(w0, w0, 0x0c020c01u)), asv(perm(w0, w0, 0x0c030c02u)),
+                               asv(perm(w1, w0, 0x0c040c03u)), asv(perm(w1, w1, 0x0c010c00u)), asv(perm(w1, w1, 0x0c020c01u)),
+                               asv(perm(w1, w1, 0x0c030c02u)), asv(perm(w2, w1, 0x0c040c03u)) };
+            v2u a01 = bias, a23 = bias;
+#pragma unroll
+            for (int k = 0; k < 6; k++) { a01 += P[k] * tx[k]; a23 += P[k + 2] * tx[k]; }
+            return finish(a01, a23);
         };
         const u32 Ha = hrow(-2), Hb = hrow(2), Hc = hrow(j == 0 ? 6 : 2);
         // quad rotations: lane i takes the value of lane (i + k) & 3
@@ -268,13 +272,13 @@ __device__ __forceinline__ u32 inter_row4(g_cu8p ref, int stride, int px, int py
         H[3] = j + 3 < 4 ? a3 : b3;
         H[4] = Hb;
         H[5] = j == 3 ? c1 : b1;
+        v2u a01 = bias, a23 = bias;
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            int acc = 64;
-#pragma unroll
-            for (int k = 0; k < 6; k++) acc += (int)((H[k] >> (8 * i)) & 0xff) * k_sixtap[fy][k];
-            out[i] = shr7_clamp255(acc);
+        for (int k = 0; k < 6; k++) {
+            a01 += asv(perm(H[k], H[k], 0x0c010c00u)) * ty[k];
+            a23 += asv(perm(H[k], H[k], 0x0c030c02u)) * ty[k];
         }
+        return finish(a01, a23);
     }
     return (u32)out[0] | ((u32)out[1] << 8) | ((u32)out[2] << 16) | ((u32)out[3] << 24);
 }
