@@ -96,6 +96,46 @@ def cpu_baseline(fixture, budget_s=12.0):
                       f"whole-loop wall time (includes entropy decode and MD5)"}
 
 
+
+def inter_frame_probe(P, device, n=1024, name="p_1920x1080", k=5):
+    """BASELINE configs[2] beside the headline: six-tap motion compensation + IDCT + loop filter on REAL inter
+    frames.  The stream is decoded the normal way up to frame k-1, then n jobs decode frame k from the same
+    references into n different frame buffers (n independent streams in lock step); whole-launch wall time."""
+    from vp8_testlib import ivf_path
+    w, h, frames = P.read_ivf(ivf_path(name))
+    ctx = P.Vp8Hip(device)
+    ctx.configure(w, h, n + 4, 2)
+    parser = P.Parser()
+    for data in frames[:k]:
+        hdr = ctx.parse_into_slot(parser, data, 0)
+        ctx.upload(0)
+        r = parser.refs
+        ctx.decode([(0, r.new_idx, (r.lst_idx, r.gld_idx, r.alt_idx) if hdr.frame_type else None)], P.STAGE_ALL)
+        ctx.sync()
+        parser.swap(hdr)
+    hdr = ctx.parse_into_slot(parser, frames[k], 1)
+    ctx.upload(1)
+    r = parser.refs
+    jobs = (P.Job * n)()
+    for i in range(n):
+        jobs[i].ir_slot, jobs[i].dst_fb = 1, 4 + i
+        jobs[i].ref_fb[1], jobs[i].ref_fb[2], jobs[i].ref_fb[3] = r.lst_idx, r.gld_idx, r.alt_idx
+    ctx.decode_array(jobs, n, P.STAGE_ALL); ctx.sync()
+    reps = 5
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        ctx.decode_array(jobs, n, P.STAGE_ALL)
+    ctx.sync()
+    dt = (time.perf_counter() - t0) / reps
+    st = ctx.stats()
+    parser.close()
+    ctx.close()
+    return {"workload": f"{name}.ivf frame {k} (inter, six-tap, normal loop filter) x {n} independent copies per launch",
+            "Mpix_s": round(n * w * h / dt / 1e6, 1), "ms_per_launch": round(dt * 1e3, 3),
+            "kernel_ms": {"recon": round(st.recon_ms, 3), "loopfilter": round(st.lf_ms, 3), "extend": round(st.extend_ms, 3)},
+            "kernel_family": "one wave per macroblock row"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -107,6 +147,7 @@ def main():
                          "frames per wave on each of the chip's 1024 SIMDs)")
     ap.add_argument("--workload", default="1080p", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-inter-probe", action="store_true")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -294,10 +335,14 @@ def main():
                 "device_copy_probe_GBps": round(copy_gbps, 1) if copy_gbps else None,
             },
         }
+        ctx.close()
+        if world == 1 and args.workload == "1080p" and not args.no_inter_probe:
+            out["config"]["inter_frames"] = inter_frame_probe(P, local_rank)
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(fixture)
         print(json.dumps(out))
-    ctx.close()
+    else:
+        ctx.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -408,17 +408,29 @@ vp8_recon_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g)
         g_u8p dV = (g_u8p)(dst + g.v_off + (long)r * 8 * g.uv_stride);
 
         struct Coefs { coef4 y0, y1, c, y2; };     // luma blocks 0..7, 8..15, chroma, Y2 (hl < 4)
-        auto load_coefs = [&](int c) __attribute__((always_inline)) -> Coefs {
+        auto load_coefs = [&](int c, bool skipped) __attribute__((always_inline)) -> Coefs {
             g_cs16p q = coefrow + (long)c * VP8IR_COEF_PER_MB;
             Coefs v;
-            v.y0 = *(g_cs4p)(q + hl * 4);
-            v.y1 = *(g_cs4p)(q + 128 + hl * 4);
-            v.c = *(g_cs4p)(q + 256 + hl * 4);
-            v.y2 = (coef4){ 0, 0 };
-            if (hl < 4) v.y2 = *(g_cs4p)(q + 384 + hl * 4);
+            v.y0 = v.y1 = v.c = v.y2 = (coef4){ 0, 0 };
+            if (!skipped) {                       // a skipped MB's coefficients are undefined and never read
+                v.y0 = *(g_cs4p)(q + hl * 4);
+                v.y1 = *(g_cs4p)(q + 128 + hl * 4);
+                v.c = *(g_cs4p)(q + 256 + hl * 4);
+                if (hl < 4) v.y2 = *(g_cs4p)(q + 384 + hl * 4);
+            }
             return v;
         };
         auto load_desc = [&](int c) -> u32 { return hl < 16 ? mbrow[c * 16 + hl] : 0u; };
+        // the two luma MVs of this lane's segments (blocks hl>>2 and 8 + hl>>2), fetched one macroblock ahead so that
+        // the reference fetch does not wait for them (inter frames only; a non-split MB has its MV in all 16 entries)
+        g_cu32p mvrow = (g_cu32p)(mvs + (long)r * cols * 16);
+        const bool inter_frame = (half ? hB.frame_type : hA.frame_type) != 0;
+        struct Mv2 { u32 a, b; };
+        auto load_mv = [&](int c) -> Mv2 {
+            Mv2 m = { 0u, 0u };
+            if (inter_frame) { m.a = mvrow[c * 16 + (hl >> 2)]; m.b = mvrow[c * 16 + 8 + (hl >> 2)]; }
+            return m;
+        };
         auto half_sel = [&](u32 d, int idx) -> u32 {     // dword `idx` of this half's MB descriptor
             const u32 a = (u32)__builtin_amdgcn_readlane((int)d, idx), b = (u32)__builtin_amdgcn_readlane((int)d, 32 + idx);
             return half ? b : a;
@@ -427,7 +439,7 @@ vp8_recon_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g)
         // ------------------------------------------------------------------------------------------
         // one macroblock (of each frame of the pair)
         // ------------------------------------------------------------------------------------------
-        auto process = [&](const int c, const u32 mbw, const Coefs &q) __attribute__((always_inline)) {
+        auto process = [&](const int c, const u32 mbw, const Coefs &q, const Mv2 &mv2) __attribute__((always_inline)) {
             unsigned char *const tY = wl->tY, *const tU = wl->tU, *const tV = wl->tV;   // lambda locals: selects between them stay in registers
             const u32 w0 = half_sel(mbw, 0), w1 = half_sel(mbw, 1);
             const int y_mode = w0 & 0xff, uv_mode = (w0 >> 8) & 0xff, ref_frame = (w0 >> 16) & 0xff;
@@ -588,8 +600,8 @@ vp8_recon_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g)
                 const int e_top = -((r * 16) << 3), e_bottom = ((rows - 1 - r) * 16) << 3;
 #pragma unroll
                 for (int p = 0; p < 2; p++) {   // luma: segment of block p*8 + hl>>2, row hl&3
-                    const int blk = p * 8 + (hl >> 2), y = ly0 + 8 * p;
-                    const u32 mvw = mv[blk];
+                    const int y = ly0 + 8 * p;
+                    const u32 mvw = p ? mv2.b : mv2.a;
                     int mrow = sext16(mvw), mcol = hi16(mvw);
                     if (clampmv) clamp_luma_mv(mrow, mcol, e_left, e_right, e_top, e_bottom);
                     const u32 pp = inter_row4(rf + g.y_off, g.y_stride, c * 16 + lx0, r * 16 + y, mrow, mcol, bilinear,
@@ -600,7 +612,7 @@ vp8_recon_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g)
                     const int blk = (hl >> 2) & 3;
                     int mrow, mcol;
                     if (y_mode != VP8IR_SPLITMV) {   // reconinter.c:419-424: from the CLAMPED luma MV
-                        const u32 mvw = mv[0];
+                        const u32 mvw = mv2.a;
                         mrow = sext16(mvw); mcol = hi16(mvw);
                         if (clampmv) clamp_luma_mv(mrow, mcol, e_left, e_right, e_top, e_bottom);
                         mrow = (short)(mrow + (1 | (mrow >> 31)));
@@ -647,19 +659,25 @@ vp8_recon_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g)
             wg_publish_lds(&prog[wave], c + 1 == cols ? (k + 1) << 16 : (k << 16) + c + 1, lane);
         };
 
-        // ---- software pipeline, unrolled by two so that no loaded register is ever copied:
-        // MB descriptors two ahead, coefficients one ahead (always fetched; a skipped MB's are ignored)
+        // ---- software pipeline, unrolled by two: MB descriptors two ahead (issued before the current MB is worked
+        // on), coefficients and MVs one ahead -- by then the descriptor says whether the MB has coefficients at all
+        auto skipped = [&](u32 d) -> bool { return (half_sel(d, 0) >> 24) & VP8IR_MB_SKIP; };
         u32 dA = load_desc(0), dB = cols > 1 ? load_desc(1) : 0u;
-        Coefs qA = load_coefs(0), qB = qA;
+        Coefs qA = load_coefs(0, skipped(dA)), qB = qA;
+        Mv2 mA = load_mv(0), mB = mA;
         for (int c0 = 0; c0 < cols; c0 += 2) {
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const int c = c0 + u;
                 if (c < cols) {
-                    if (c + 1 < cols) { if (u) qA = load_coefs(c + 1); else qB = load_coefs(c + 1); }
                     const u32 d = u ? dB : dA;
-                    process(c, d, u ? qB : qA);
+                    const u32 dn = u ? dA : dB;          // descriptor of MB c+1
                     if (c + 2 < cols) { if (u) dB = load_desc(c + 2); else dA = load_desc(c + 2); }
+                    if (c + 1 < cols) {
+                        const bool sk = skipped(dn);
+                        if (u) { qA = load_coefs(c + 1, sk); mA = load_mv(c + 1); } else { qB = load_coefs(c + 1, sk); mB = load_mv(c + 1); }
+                    }
+                    process(c, d, u ? qB : qA, u ? mB : mA);
                 }
             }
         }
