@@ -186,6 +186,60 @@ __device__ __forceinline__ u32 intra_pred4(int mode, u32 above, int left, int tl
     return out;
 }
 
+// ---- six-tap building blocks (filter.c:41-128), two pixels per instruction on 16-bit lanes --------------
+// A first-pass sum lies in -8160 .. 40864, so biased by 8192 it is an unsigned 16-bit number and wrap-around
+// arithmetic (v_pk_mad_u16, negative taps as their two's complement) is exact; (t + 8192) >> 7 == (t >> 7) + 64, and
+// a saturating subtraction of 64 plus a minimum with 255 are the clamp.  The second pass has the same range.
+typedef unsigned short v2u16 __attribute__((ext_vector_type(2)));
+struct SixTaps { v2u16 t[6]; };
+__device__ __forceinline__ SixTaps sixtap_taps(int f)
+{
+    SixTaps r;
+#pragma unroll
+    for (int k = 0; k < 6; k++) { const unsigned short t = (unsigned short)k_sixtap[f][k]; r.t[k] = (v2u16){ t, t }; }
+    return r;
+}
+__device__ __forceinline__ u32 sixtap_finish(v2u16 a01, v2u16 a23)     // two biased sums of two pixels -> four clamped bytes
+{
+    const v2u16 c64 = { 64, 64 }, c255 = { 255, 255 };
+    const v2u16 r01 = __builtin_elementwise_min(__builtin_elementwise_sub_sat(a01 >> 7, c64), c255);
+    const v2u16 r23 = __builtin_elementwise_min(__builtin_elementwise_sub_sat(a23 >> 7, c64), c255);
+    return __builtin_amdgcn_perm(__builtin_bit_cast(u32, r23), __builtin_bit_cast(u32, r01), 0x06040200u);
+}
+// first pass for four output pixels: s points at the pixel two left of the first one (nine pixels are read, as three
+// aligned dwords shifted into place)
+__device__ __forceinline__ u32 sixtap_hrow(g_cu8p s, const SixTaps &tx)
+{
+    auto asv = [](u32 v) { return __builtin_bit_cast(v2u16, v); };
+    auto perm = [](u32 hi, u32 lo, u32 sel) { return __builtin_amdgcn_perm(hi, lo, sel); };
+    const u32 sh = (u32)(unsigned long)s & 3u;
+    g_cu32p rp = (g_cu32p)(s - sh);
+    const u32 d0 = rp[0], d1 = rp[1], d2 = rp[2];
+    const u32 w0 = __builtin_amdgcn_alignbyte(d1, d0, sh), w1 = __builtin_amdgcn_alignbyte(d2, d1, sh);
+    const u32 w2 = __builtin_amdgcn_alignbyte(0u, d2, sh);
+    // P[k] = pixels (k, k+1) of the row, one per 16-bit lane
+    const v2u16 P[8] = { asv(perm(w0, w0, 0x0c010c00u)), asv(perm(w0, w0, 0x0c020c01u)), asv(perm(w0, w0, 0x0c030c02u)),
+                         asv(perm(w1, w0, 0x0c040c03u)), asv(perm(w1, w1, 0x0c010c00u)), asv(perm(w1, w1, 0x0c020c01u)),
+                         asv(perm(w1, w1, 0x0c030c02u)), asv(perm(w2, w1, 0x0c040c03u)) };
+    const v2u16 bias = { 64 + 8192, 64 + 8192 };
+    v2u16 a01 = bias, a23 = bias;
+#pragma unroll
+    for (int k = 0; k < 6; k++) { a01 += P[k] * tx.t[k]; a23 += P[k + 2] * tx.t[k]; }
+    return sixtap_finish(a01, a23);
+}
+// second pass: H[k] = four first-pass pixels (bytes) of source row k - 2
+__device__ __forceinline__ u32 sixtap_vcol(const u32 H[6], const SixTaps &ty)
+{
+    const v2u16 bias = { 64 + 8192, 64 + 8192 };
+    v2u16 a01 = bias, a23 = bias;
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        a01 += __builtin_bit_cast(v2u16, __builtin_amdgcn_perm(H[k], H[k], 0x0c010c00u)) * ty.t[k];
+        a23 += __builtin_bit_cast(v2u16, __builtin_amdgcn_perm(H[k], H[k], 0x0c030c02u)) * ty.t[k];
+    }
+    return sixtap_finish(a01, a23);
+}
+
 // ---- inter prediction of a 4-pixel row segment (reconinter.c:161-227 + filter.c) --------------
 // ref points at pixel (0,0) of the plane; (px,py) = integer position of the first output pixel in
 // the current frame; mv in 1/8 pel.  border = 32 (luma) / 16 (chroma); plane w x h (coded size).
@@ -200,10 +254,6 @@ __device__ __forceinline__ u32 inter_row4(g_cu8p ref, int stride, int px, int py
     sy = max(-border + 2, min(sy, h + border - 7));
     g_cu8p s = ref + (long)sy * stride + sx;
     int out[4];
-    // Six-tap source rows are fetched as aligned dwords and shifted into place (v_alignbyte_b32): three loads per
-    // row instead of nine byte loads.
-    const u32 sh = (u32)(unsigned long)(s - 2) & 3u;
-    g_cu8p sa = s - 2 - sh;
     if ((fx | fy) == 0) {
 #pragma unroll
         for (int i = 0; i < 4; i++) out[i] = s[i];
@@ -223,39 +273,8 @@ __device__ __forceinline__ u32 inter_row4(g_cu8p ref, int stride, int px, int py
         // The four lanes of a quad are the four rows of one 4x4 block (j = row) with one MV: together they need the
         // horizontally filtered source rows -2..6 of the block.  Lane j filters rows j-2 and j+2 (lane 0 also row 6)
         // instead of its own six, and the quad exchanges the results (four clamped pixels = one dword) by DPP.
-        // Both passes run two pixels per instruction on 16-bit lanes: a first-pass sum lies in -8160 .. 40864, so
-        // biased by 8192 it is an unsigned 16-bit number and wrap-around arithmetic (v_pk_mad_u16, negative taps as
-        // their two's complement) is exact; (t + 8192) >> 7 == (t >> 7) + 64, and a saturating subtraction of 64 plus
-        // a minimum with 255 are the clamp.
-        typedef unsigned short v2u __attribute__((ext_vector_type(2)));
-        auto asv = [](u32 v) { return __builtin_bit_cast(v2u, v); };
-        auto asu = [](v2u v) { return __builtin_bit_cast(u32, v); };
-        auto perm = [](u32 hi, u32 lo, u32 sel) { return __builtin_amdgcn_perm(hi, lo, sel); };
-        auto tap2 = [&](int f, int k) { const unsigned short t = (unsigned short)k_sixtap[f][k]; return (v2u){ t, t }; };
-        auto finish = [&](v2u a01, v2u a23) -> u32 {         // two biased sums of two pixels -> four clamped bytes
-            const v2u c64 = { 64, 64 }, c255 = { 255, 255 };
-            const v2u r01 = __builtin_elementwise_min(__builtin_elementwise_sub_sat(a01 >> 7, c64), c255);
-            const v2u r23 = __builtin_elementwise_min(__builtin_elementwise_sub_sat(a23 >> 7, c64), c255);
-            return perm(asu(r23), asu(r01), 0x06040200u);
-        };
-        const v2u bias = { 64 + 8192, 64 + 8192 };
-        v2u tx[6], ty[6];
-#pragma unroll
-        for (int k = 0; k < 6; k++) { tx[k] = tap2(fx, k); ty[k] = tap2(fy, k); }
-        auto hrow = [&](int r) -> u32 {
-            g_cu32p rp = (g_cu32p)(sa + (long)r * stride);
-            const u32 d0 = rp[0], d1 = rp[1], d2 = rp[2];
-            const u32 w0 = __builtin_amdgcn_alignbyte(d1, d0, sh), w1 = __builtin_amdgcn_alignbyte(d2, d1, sh);
-            const u32 w2 = __builtin_amdgcn_alignbyte(0u, d2, sh);
-            // P[k] = pixels (k, k+1) of the row, one per 16-bit lane
-            const v2u P[8] = { asv(perm(w0, w0, 0x0c010c00u)), asv(perm(w0, w0, 0x0c020c01u)), asv(perm(w0, w0, 0x0c030c02u)),
-                               asv(perm(w1, w0, 0x0c040c03u)), asv(perm(w1, w1, 0x0c010c00u)), asv(perm(w1, w1, 0x0c020c01u)),
-                               asv(perm(w1, w1, 0x0c030c02u)), asv(perm(w2, w1, 0x0c040c03u)) };
-            v2u a01 = bias, a23 = bias;
-#pragma unroll
-            for (int k = 0; k < 6; k++) { a01 += P[k] * tx[k]; a23 += P[k + 2] * tx[k]; }
-            return finish(a01, a23);
-        };
+        const SixTaps tx = sixtap_taps(fx), ty = sixtap_taps(fy);
+        auto hrow = [&](int r) -> u32 { return sixtap_hrow(s - 2 + (long)r * stride, tx); };
         const u32 Ha = hrow(-2), Hb = hrow(2), Hc = hrow(j == 0 ? 6 : 2);
         // quad rotations: lane i takes the value of lane (i + k) & 3
         auto rot1 = [](u32 v) { return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x39, 0xf, 0xf, false); };
@@ -272,13 +291,7 @@ __device__ __forceinline__ u32 inter_row4(g_cu8p ref, int stride, int px, int py
         H[3] = j + 3 < 4 ? a3 : b3;
         H[4] = Hb;
         H[5] = j == 3 ? c1 : b1;
-        v2u a01 = bias, a23 = bias;
-#pragma unroll
-        for (int k = 0; k < 6; k++) {
-            a01 += asv(perm(H[k], H[k], 0x0c010c00u)) * ty[k];
-            a23 += asv(perm(H[k], H[k], 0x0c030c02u)) * ty[k];
-        }
-        return finish(a01, a23);
+        return sixtap_vcol(H, ty);
     }
     return (u32)out[0] | ((u32)out[1] << 8) | ((u32)out[2] << 16) | ((u32)out[3] << 24);
 }
@@ -598,6 +611,73 @@ vp8_recon_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g)
                 const bool clampmv = flags & VP8IR_MB_CLAMP;
                 const int e_left = -((c * 16) << 3), e_right = ((cols - 1 - c) * 16) << 3;
                 const int e_top = -((r * 16) << 3), e_bottom = ((rows - 1 - r) * 16) << 3;
+                if (y_mode != VP8IR_SPLITMV && !bilinear) {
+                    // One MV for the whole macroblock (vp8_build_inter16x16_predictors_mb, reconinter.c:384-441):
+                    // the first six-tap pass is shared through LDS -- 21 source rows x 4 segments for luma, 13 x 2
+                    // for each chroma plane, 136 row segments for 32 lanes instead of nine per lane.
+                    u32 *hb = (u32 *)wl->res;                 // B_PRED's residual buffer is idle in an inter MB
+                    int mrow = sext16(mv2.a), mcol = hi16(mv2.a);
+                    if (clampmv) clamp_luma_mv(mrow, mcol, e_left, e_right, e_top, e_bottom);
+                    // chroma MV from the CLAMPED luma MV (reconinter.c:419-424); version 0: no full-pixel mask
+                    int crow = (short)(mrow + (1 | (mrow >> 31))), ccol = (short)(mcol + (1 | (mcol >> 31)));
+                    crow /= 2; ccol /= 2;
+                    const bool fracY = ((mrow | mcol) & 7) != 0, fracC = ((crow | ccol) & 7) != 0;
+                    // memory safety only, as in inter_row4: every tap stays inside the plane and its border
+                    const int sx = max(-32 + 2, min(c * 16 + (mcol >> 3), g.aligned_w + 32 - 22));
+                    const int sy = max(-32 + 2, min(r * 16 + (mrow >> 3), g.aligned_h + 32 - 19));
+                    const int sxc = max(-16 + 2, min(c * 8 + (ccol >> 3), g.aligned_w / 2 + 16 - 14));
+                    const int syc = max(-16 + 2, min(r * 8 + (crow >> 3), g.aligned_h / 2 + 16 - 11));
+                    if (fracY) {
+                        const SixTaps tx = sixtap_taps(mcol & 7);
+                        g_cu8p base = rf + g.y_off + (long)(sy - 2) * g.y_stride + (sx - 2);
+#pragma unroll
+                        for (int i = 0; i < 3; i++) {
+                            const int t = hl + 32 * i;            // source row t>>2 (0 = two above), segment t&3
+                            if (t < 84) hb[t] = sixtap_hrow(base + (long)(t >> 2) * g.y_stride + (t & 3) * 4, tx);
+                        }
+                    }
+                    if (fracC) {
+                        const SixTaps tx = sixtap_taps(ccol & 7);
+#pragma unroll
+                        for (int i = 0; i < 2; i++) {
+                            const int t = hl + 32 * i, pl = t >= 26, rem = t - 26 * pl;
+                            if (t < 52) {
+                                g_cu8p base = rf + (pl ? g.v_off : g.u_off) + (long)(syc - 2 + (rem >> 1)) * g.uv_stride + (sxc - 2);
+                                hb[84 + t] = sixtap_hrow(base + (rem & 1) * 4, tx);
+                            }
+                        }
+                    }
+                    wave_lds_sync();
+                    u32 ppY0, ppY1, ppC;
+                    if (fracY) {
+                        const SixTaps ty = sixtap_taps(mrow & 7);
+                        u32 H[6];
+#pragma unroll
+                        for (int k = 0; k < 6; k++) H[k] = hb[(ly0 + k) * 4 + (lx0 >> 2)];
+                        ppY0 = sixtap_vcol(H, ty);
+#pragma unroll
+                        for (int k = 0; k < 6; k++) H[k] = hb[(ly0 + 8 + k) * 4 + (lx0 >> 2)];
+                        ppY1 = sixtap_vcol(H, ty);
+                    } else {                                      // vp8_copy_mem16x16 (reconinter.c:22-63)
+                        g_cu8p s0 = rf + g.y_off + (long)(sy + ly0) * g.y_stride + sx + lx0;
+                        g_cu8p s1 = s0 + 8 * (long)g.y_stride;
+                        ppY0 = (u32)s0[0] | ((u32)s0[1] << 8) | ((u32)s0[2] << 16) | ((u32)s0[3] << 24);
+                        ppY1 = (u32)s1[0] | ((u32)s1[1] << 8) | ((u32)s1[2] << 16) | ((u32)s1[3] << 24);
+                    }
+                    if (fracC) {
+                        const SixTaps ty = sixtap_taps(crow & 7);
+                        u32 H[6];
+#pragma unroll
+                        for (int k = 0; k < 6; k++) H[k] = hb[84 + cpl * 26 + (cy + k) * 2 + (cx0 >> 2)];
+                        ppC = sixtap_vcol(H, ty);
+                    } else {
+                        g_cu8p s0 = rf + (cpl ? g.v_off : g.u_off) + (long)(syc + cy) * g.uv_stride + sxc + cx0;
+                        ppC = (u32)s0[0] | ((u32)s0[1] << 8) | ((u32)s0[2] << 16) | ((u32)s0[3] << 24);
+                    }
+                    outY0 = add_clamp_pack(ppY0, rY0);
+                    outY1 = add_clamp_pack(ppY1, rY1);
+                    outC = add_clamp_pack(ppC, rC);
+                } else {
 #pragma unroll
                 for (int p = 0; p < 2; p++) {   // luma: segment of block p*8 + hl>>2, row hl&3
                     const int y = ly0 + 8 * p;
@@ -633,6 +713,7 @@ vp8_recon_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g)
                     const u32 pp = inter_row4(rf + (cpl ? g.v_off : g.u_off), g.uv_stride, c * 8 + cx0, r * 8 + cy, mrow,
                                               mcol, bilinear, g.aligned_w / 2, g.aligned_h / 2, 16, hl & 3);
                     outC = add_clamp_pack(pp, rC);
+                }
                 }
             }
 
