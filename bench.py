@@ -40,6 +40,12 @@ B_LF = 770               # pixels read + written, params
 B_EXTEND = 36
 B_DETILE = 384 + 384 + 36  # lane-per-row pipeline only: tiled scratch read, raster frame + borders written
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+# HBM traffic per macroblock of the lane-per-row kernels (1080p key frames, G = 8 as at the default launch size), from
+# `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, KiB; FETCH_SIZE doubled: the gfx950 correction
+# for 16-byte-per-lane loads, which the detile pass confirms -- it reads exactly 384 B/MB) over tools/pmc_one.py 7 1024
+# with VP8HIP_SIMT_LGG=3: profiles/r01_g_pmc_*_1024frames_G8.csv.  The counter passes crash or hang at 8192 frames per
+# launch and under torch, so bench.py scales these per-macroblock figures instead of counting live.
+PMC_TRAFFIC_B_PER_MB = {"recon": 2 * 448.68 + 385.22, "loopfilter": 2 * 239.63 + 414.12, "extend": 2 * 192.08 + 466.87}
 
 WORKLOADS = {
     "1080p": ("kf_1920x1080", 1920, 1080),
@@ -325,7 +331,12 @@ def main():
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 5),
-                "traffic": None,      # rocprofv3 TCC counter passes do not complete with these kernels
+                "traffic": round(PMC_TRAFFIC_B_PER_MB[dom] * nmb * F) if lane and args.workload == "1080p" else None,
+                "traffic_note": "HBM bytes per launch = per-macroblock FETCH_SIZE x2 + WRITE_SIZE of the same kernel measured "
+                                "with rocprofv3 --pmc at 1024 frames per launch (profiles/r01_g_pmc_*.csv) x macroblocks "
+                                "per launch; null for configurations that were not counted",
+                "traffic_bytes_per_macroblock": ({k: round(v, 1) for k, v in PMC_TRAFFIC_B_PER_MB.items()}
+                                                 if lane and args.workload == "1080p" else None),
                 "algorithmic_bytes_per_launch": bytes_per_launch[dom],
                 "mean_launch_ms": round(ms[dom], 4),
                 "all_kernels_GBps": {k: round(bytes_per_launch[k] / (ms[k] * 1e-3) / 1e9, 2) if ms[k] > 0 else None
