@@ -154,6 +154,7 @@ def main():
     ap.add_argument("--workload", default="1080p", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-inter-probe", action="store_true")
+    ap.add_argument("--no-end-to-end", action="store_true")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -349,6 +350,14 @@ def main():
         ctx.close()
         if world == 1 and args.workload == "1080p" and not args.no_inter_probe:
             out["config"]["inter_frames"] = inter_frame_probe(P, local_rank)
+        if world == 1 and args.workload == "1080p" and not args.no_end_to_end:
+            # host-inclusive rate (never `value`): compressed frames in host memory -> per-frame MD5, tools/e2e.py
+            try:
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                import e2e
+                out["config"]["end_to_end"] = e2e.run(P, local_rank, fixture=fixture)
+            except Exception as ex:      # a probe, not the benchmark: report, do not fail the line
+                out["config"]["end_to_end"] = {"error": repr(ex)}
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(fixture)
         print(json.dumps(out))

@@ -21,6 +21,6 @@ for round in 1 2; do
     for v in head work; do
         cp "$L/var/libvp8hip_$v.so" "$L/libvp8hip.so"
         echo "== $v"
-        python "$ROOT/bench.py" --no-cpu-baseline --no-inter-probe "$@" 2>&1 | grep -o '"value": [0-9.]*\|"ms_per_step": [0-9.]*\|"kernel_ms": {[^}]*}'
+        python "$ROOT/bench.py" --no-cpu-baseline --no-inter-probe --no-end-to-end "$@" 2>&1 | grep -o '"value": [0-9.]*\|"ms_per_step": [0-9.]*\|"kernel_ms": {[^}]*}'
     done
 done
