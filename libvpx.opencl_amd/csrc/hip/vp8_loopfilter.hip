@@ -208,8 +208,34 @@ __device__ __forceinline__ u32 pack4(const int *a) { return (u32)a[0] | ((u32)a[
 // MB position.  One MB keeps only 32 lanes busy (16 luma + 8 U + 8 V pixel lines) and the kernel is
 // bound by VALU issue (one wave instruction = 4 SIMD cycles whatever the number of active lanes),
 // so sharing the instruction stream between two independent frames halves the cost per MB.
-extern "C" __global__ void __launch_bounds__(1024)
-vp8_loopfilter_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g)
+//
+// XCU = true (small launches, see vp8_recon.hip): the rows of one frame pair are spread over the waves of S workgroups
+// on different CUs.  The four context rows a wave hands to the wave below (luma rows 12..15, chroma rows 4..7 of
+// its macroblocks, as far as it has filtered them) travel as 8-byte granules {4 pixels, launch epoch} through a
+// per-row buffer in global memory (agent-scope stores and polling loads; the tag is the progress flag), and the
+// upper wave leaves the rows the lower one finishes (luma 13..15, chroma 5..7) out of its own frame writes: two CUs
+// must never write the same bytes.
+typedef unsigned long long u64;
+typedef GLOBAL_AS u64 *g_u64p;
+__device__ __forceinline__ void gran_store(g_u64p p, u32 data, u32 tag)
+{
+    __hip_atomic_store(p, (u64)data | ((u64)tag << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ u64 gran_load(g_u64p p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// v: what an earlier gran_load of *p returned; polls only if that was too early
+__device__ __forceinline__ u32 gran_wait(g_u64p p, u64 v, u32 tag, int *err)
+{
+    for (int n = 0; (u32)(v >> 32) != tag; ++n) {
+        if (n > (1 << 22)) { *err = 2; break; }
+        __builtin_amdgcn_s_sleep(VP8_POLL_SLEEP);
+        v = gran_load(p);
+    }
+    return (u32)v;
+}
+
+template <bool XCU>
+__device__ __forceinline__ void lf_body(const DevJob *__restrict__ jobs, int njobs, DevGeom g, u64 *gran_base, u32 epoch,
+                                        int S, int *err)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
@@ -219,12 +245,17 @@ vp8_loopfilter_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g)
     const int half = lane >> 5, hl = lane & 31;
     int *prog = (int *)smem;
     LfWaveLds *wl = (LfWaveLds *)(smem + 256) + wave * 2 + half;
+    const int xq = blockIdx.x >> 3;
+    const int group = XCU ? (xq / S) * 8 + (int)(blockIdx.x & 7) : (int)blockIdx.x;
+    const int gw = XCU ? (xq % S) * NW + wave : wave;
+    const int TW = XCU ? S * NW : NW;
+    const int GS = cols * 32;           // granules per MB row: luma 4 rows x cols*4, then U, V 4 rows x cols*2 each
 
     if (threadIdx.x < 64) prog[threadIdx.x] = 0;
     __syncthreads();
 
     const int npairs = (njobs + 1) >> 1;
-    const int mypairs = (npairs - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int mypairs = XCU ? (group < npairs ? 1 : 0) : (npairs - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
     const int total_rows = mypairs * rows;
     const int dep_wave = (wave + NW - 1) % NW;
     // mode_lf_lut (loopfilter.c:52-63) indexed by MB mode: DC,V,H,TM -> 1, B_PRED -> 0,
@@ -242,9 +273,9 @@ vp8_loopfilter_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g)
     const bool is_top = li < 4;
     const int top_row = li - 4;
 
-    for (int R = wave, k = 0; R < total_rows; R += NW, ++k) {
+    for (int R = gw, k = 0; R < total_rows; R += TW, ++k) {
         const int jj = R / rows, r = R - jj * rows;
-        const int pair = blockIdx.x + jj * gridDim.x;
+        const int pair = XCU ? group : (int)blockIdx.x + jj * (int)gridDim.x;
         const bool haveB = 2 * pair + 1 < njobs;
         const DevJob &jobA = jobs[2 * pair];
         const DevJob &jobB = jobs[haveB ? 2 * pair + 1 : 2 * pair];
@@ -252,9 +283,11 @@ vp8_loopfilter_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g)
         const int dep_seq = (R - 1) / NW;
         const bool onA = hA.filter_level != 0, onB = haveB && hB.filter_level != 0;
         if (!onA && !onB) {                      // neither frame is filtered at all (onyxd_if.c:576)
-            wg_publish_lds(&prog[wave], (k + 1) << 16, lane);
+            if (!XCU) wg_publish_lds(&prog[wave], (k + 1) << 16, lane);
             continue;
         }
+        g_u64p gran_mine = (g_u64p)(gran_base + ((long)(pair * 2 + half) * rows + r) * GS);
+        g_u64p gran_above = gran_mine - GS;
         const bool frame_on = half ? onB : onA;
         // lane l holds lvl[seg][ref][mode class] of each frame, l = seg<<4 | ref<<2 | class
         const int lvlA = build_level(hA, lane), lvlB = build_level(hB, lane);
@@ -284,11 +317,23 @@ vp8_loopfilter_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g)
             // ---- context rows above: written by the wave of row r-1 (final-so-far values); the loads are
             // issued now and consumed after the vertical-edge pass
             u32x4 topv = { 0, 0, 0, 0 };
+            g_u64p gq = nullptr;
+            u64 g0 = 0, g1 = 0, g2 = 0, g3 = 0;
             if (r > 0) {
-                wg_wait_ge(&prog[dep_wave], (dep_seq << 16) + c + 1);
-                if (is_top) {
-                    if (luma) topv = *(g_cu32x4p)(trow + c * 16);
-                    else { const u32x2 t = *(g_cu32x2p)(trow + c * 8); topv.x = t.x; topv.y = t.y; }
+                if (XCU) {
+                    // granules of MB c of the row above exist once that row is done with MB c; requested now,
+                    // checked (and polled, if they were not there yet) after the vertical-edge pass
+                    if (is_top) {
+                        gq = gran_above + (luma ? li * cols * 4 + c * 4 : ((hl & 8) ? cols * 24 : cols * 16) + li * cols * 2 + c * 2);
+                        g0 = gran_load(gq); g1 = gran_load(gq + 1);
+                        if (luma) { g2 = gran_load(gq + 2); g3 = gran_load(gq + 3); }
+                    }
+                } else {
+                    wg_wait_ge(&prog[dep_wave], (dep_seq << 16) + c + 1);
+                    if (is_top) {
+                        if (luma) topv = *(g_cu32x4p)(trow + c * 16);
+                        else { const u32x2 t = *(g_cu32x2p)(trow + c * 8); topv.x = t.x; topv.y = t.y; }
+                    }
                 }
             }
 
@@ -305,6 +350,10 @@ vp8_loopfilter_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g)
                     *(u32 *)(tile + LC_AT(li, X - 4)) = pack4(a);
                     *(u32x2 *)(tile + LC_AT(li, X)) = (u32x2){ pack4(a + 4), pack4(a + 8) };
                 }
+            }
+            if (XCU && r > 0 && is_top) {
+                topv.x = gran_wait(gq, g0, epoch, err); topv.y = gran_wait(gq + 1, g1, epoch, err);
+                if (luma) { topv.z = gran_wait(gq + 2, g2, epoch, err); topv.w = gran_wait(gq + 3, g3, epoch, err); }
             }
             if (r > 0 && is_top) {
                 if (luma) *(u32x4 *)(tile + LY_AT(top_row, X)) = topv;
@@ -332,7 +381,9 @@ vp8_loopfilter_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g)
         auto flush = [&](const int m0, const int m1) {
             if (!frame_on) return;
             const int n = m1 - m0, y0 = r > 0 ? -3 : 0;
-            const int ny = 16 - y0, nc = 8 - y0;
+            // XCU: rows 13..15 (chroma 5..7) belong to the wave below, which writes their final values
+            const bool keep_bottom = XCU && r < rows - 1;
+            const int ny = (keep_bottom ? 13 : 16) - y0, nc = (keep_bottom ? 5 : 8) - y0;
             for (int t = hl; t < ny * n; t += 32) {
                 const int y = y0 + t / n, m = m0 + t % n;
                 *(g_u32x4p)(fY + (long)y * g.y_stride + m * 16) = *(const u32x4 *)(wl->tY + LY_AT(y, m * 16));
@@ -365,11 +416,27 @@ vp8_loopfilter_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g)
         // rows (x = 32 mod 64, i.e. MB index = 2 mod 4).  Publishing is one group late: by the time the
         // next group is written the previous group's stores have long been acknowledged, so the
         // vmcnt(0) in wg_publish_global costs (almost) nothing.
+        // XCU: hand MB m's bottom context rows (as filtered so far: final as far as this wave is concerned) to the wave
+        // below, one granule per lane: 16 luma (rows 12..15 x 4) + 8 U + 8 V (rows 4..7 x 2)
+        auto emit = [&](const int m) {
+            if (hl < 16) {
+                const int y = 12 + (hl >> 2), i = hl & 3;
+                gran_store(gran_mine + (hl >> 2) * cols * 4 + m * 4 + i, *(const u32 *)(wl->tY + LY_AT(y, m * 16 + i * 4)), epoch);
+            } else {
+                const int pl = (hl >> 3) & 1, yy = (hl >> 1) & 3, i = hl & 1;
+                gran_store(gran_mine + (pl ? cols * 24 : cols * 16) + yy * cols * 2 + m * 2 + i,
+                           *(const u32 *)((pl ? wl->tV : wl->tU) + LC_AT(4 + yy, m * 8 + i * 4)), epoch);
+            }
+        };
         int flushed = 0;
         auto after_mb = [&](const int c) {
             const bool last = c == cols - 1;
+            if (XCU && r < rows - 1) {
+                if (c > 0) emit(c - 1);
+                if (last) emit(c);
+            }
             if (last || (c & 3) == 2) {
-                wg_publish_global(&prog[wave], (k << 16) + flushed, lane);
+                if (!XCU) wg_publish_global(&prog[wave], (k << 16) + flushed, lane);
                 flush(flushed, last ? cols : c);
                 flushed = last ? cols : c;
             }
@@ -396,8 +463,22 @@ vp8_loopfilter_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g)
                 after_mb(c + 1);
             }
         }
-        wg_publish_global(&prog[wave], (k + 1) << 16, lane);
+        if (!XCU) wg_publish_global(&prog[wave], (k + 1) << 16, lane);
     }
+}
+
+extern "C" __global__ void __launch_bounds__(1024)
+vp8_loopfilter_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g)
+{
+    lf_body<false>(jobs, njobs, g, nullptr, 0u, 1, nullptr);
+}
+
+// grid = 8 * S * ceil(npairs / 8) workgroups of (at most) four waves; gran: npairs * 2 * rows * cols * 32 granules
+extern "C" __global__ void __launch_bounds__(256)
+vp8_loopfilter_xcu_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g, unsigned long long *gran, unsigned int epoch,
+                          int S, int *err)
+{
+    lf_body<true>(jobs, njobs, g, gran, epoch, S, err);
 }
 
 // ---- border extension ------------------------------------------------------------------------

@@ -324,8 +324,34 @@ __device__ __forceinline__ void clamp_chroma_mv(int &row, int &col, int e_left, 
 //   residual   : hl = block*4 + column; four passes: chroma (8 blocks), Y2 (hl < 4), luma blocks 0..7, 8..15
 //   prediction : hl = block*4 + row -> a 4-pixel row segment; luma in two passes, chroma in one
 //   B_PRED     : hl 0..15 = the 16 pixels of the current 4x4 sub-block
-extern "C" __global__ void __launch_bounds__(768)
-vp8_recon_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g)
+//
+// XCU = true: the rows of ONE frame pair are spread over the waves of S workgroups on different CUs (small launches:
+// a frame pair no longer has to live on one CU, vp8hip.hip picks S).  Nothing is shared through LDS then; the
+// unfiltered bottom pixel line of a row travels to the wave of the row below as 8-byte granules {4 pixels, tag} in
+// a per-row buffer in global memory, written and polled with agent-scope (sc1) accesses: the tag (the launch's
+// epoch) doubles as the progress flag, so there is no separate flag, no store-acknowledge wait and no fence.
+// A bounded poll turns a broken hand-over into an error status instead of a hang.
+typedef unsigned long long u64;
+typedef GLOBAL_AS u64 *g_u64p;
+__device__ __forceinline__ void gran_store(g_u64p p, u32 data, u32 tag)
+{
+    __hip_atomic_store(p, (u64)data | ((u64)tag << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ u64 gran_load(g_u64p p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// v: what an earlier gran_load of *p returned; polls only if that was too early
+__device__ __forceinline__ u32 gran_wait(g_u64p p, u64 v, u32 tag, int *err)
+{
+    for (int n = 0; (u32)(v >> 32) != tag; ++n) {
+        if (n > (1 << 22)) { *err = 1; break; }
+        __builtin_amdgcn_s_sleep(VP8_POLL_SLEEP);
+        v = gran_load(p);
+    }
+    return (u32)v;
+}
+
+template <bool XCU>
+__device__ __forceinline__ void recon_body(const DevJob *__restrict__ jobs, int njobs, DevGeom g, u64 *gran_base,
+                                           u32 epoch, int S, int *err)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
@@ -333,6 +359,13 @@ vp8_recon_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g)
     const int NW = blockDim.x >> 6;
     const int cols = g.mb_cols, rows = g.mb_rows;
     const int half = lane >> 5, hl = lane & 31;
+    // XCU: workgroups with equal blockIdx.x % 8 sit on one XCD under round-robin placement (speed only, never
+    // correctness); S consecutive ones of them form the group of one frame pair
+    const int xq = blockIdx.x >> 3;
+    const int group = XCU ? (xq / S) * 8 + (int)(blockIdx.x & 7) : (int)blockIdx.x;
+    const int gw = XCU ? (xq % S) * NW + wave : wave;      // this wave among the TW waves sharing the pair(s)
+    const int TW = XCU ? S * NW : NW;
+    const int GS = cols * 8 + 2;                           // granules per row: Y cols*4 + 1, U cols*2, V cols*2
 
     // ---- LDS carve: [progress flags 256 B][B_PRED gather table 640 B, pad to 1024]
     //                 [2*NW x WaveLds][2*NW x line slot]      (one working set and one line per half)
@@ -346,7 +379,7 @@ vp8_recon_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g)
     const int lU = 2 * LINE_PAD + g.aligned_w, lV = lU + 2 * LINE_PAD + g.aligned_w / 2;
 
     if (threadIdx.x < 64) prog[threadIdx.x] = 0;
-    if (hl < 3) {   // x = -4..-1 of every line: only x = -1 is ever used, the constant 129 left border
+    if (!XCU && hl < 3) {   // x = -4..-1 of every line: only x = -1 is ever used, the constant 129 left border
         const int off = hl == 0 ? 0 : (hl == 1 ? lU : lV);
         *(u32 *)(my_line + off + LINE_PAD - 4) = 0x81818181u;
     }
@@ -380,13 +413,14 @@ vp8_recon_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g)
     const int col = hl & 3;
 
     const int npairs = (njobs + 1) >> 1;
-    const int mypairs = (npairs - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    // XCU: one pair per group and launch (the per-row granule buffers are not reused inside a launch)
+    const int mypairs = XCU ? (group < npairs ? 1 : 0) : (npairs - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
     const int total_rows = mypairs * rows;
     const int dep_wave = (wave + NW - 1) % NW;
 
-    for (int R = wave, k = 0; R < total_rows; R += NW, ++k) {
+    for (int R = gw, k = 0; R < total_rows; R += TW, ++k) {
         const int jj = R / rows, r = R - jj * rows;
-        const int pair = blockIdx.x + jj * gridDim.x;
+        const int pair = XCU ? group : (int)blockIdx.x + jj * (int)gridDim.x;
         const bool haveB = 2 * pair + 1 < njobs;
         const DevJob &jobA = jobs[2 * pair];
         const DevJob &jobB = jobs[haveB ? 2 * pair + 1 : 2 * pair];
@@ -398,7 +432,7 @@ vp8_recon_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g)
         // Line-slot reuse guard.  Inside one frame the wavefront dependency chain already orders
         // "row R-NW+1 finished reading my previous line" before my first write; the chain is cut at
         // a frame boundary, so check explicitly when row R-NW+1 belongs to another job pair.
-        if (k > 0 && (R - NW + 1) / rows != jj) {
+        if (!XCU && k > 0 && (R - NW + 1) / rows != jj) {
             const int rd = (wave + 1) % NW;
             const int kr = (wave + 1 < NW) ? k - 1 : k;
             wg_wait_ge(&prog[rd], (kr + 1) << 16);
@@ -410,6 +444,9 @@ vp8_recon_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g)
 
         const unsigned char *dep_line = lines + (dep_wave * 2 + half) * lbytes;
         const int dep_seq = (R - 1) / NW;
+        // XCU: granule rows of this frame: mine (row r) and the one above
+        g_u64p gran_mine = (g_u64p)(gran_base + ((long)(pair * 2 + half) * rows + r) * GS);
+        g_u64p gran_above = gran_mine - GS;
         const vp8ir_mb *mbs = half ? jobB.mbs : jobA.mbs;
         const int16_t *coefs = half ? jobB.coef : jobA.coef;
         const vp8ir_mv *mvs = half ? jobB.mvs : jobA.mvs;
@@ -452,8 +489,18 @@ vp8_recon_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g)
         // ------------------------------------------------------------------------------------------
         // one macroblock (of each frame of the pair)
         // ------------------------------------------------------------------------------------------
+        // XCU: lane hl < 12 copies one dword of the above line per MB (Y x = -4..19, U and V x = -4..7); its granule is
+        // requested one macroblock ahead, so that the round trip to the other CU's data hides behind this MB's work
+        const int apl = hl < 6 ? 0 : (hl < 9 ? 1 : 2), ai = hl - (apl == 0 ? 0 : (apl == 1 ? 6 : 9));
+        auto above_gran = [&](int c) -> g_u64p {
+            const int x = (apl == 0 ? c * 16 : c * 8) - 4 + ai * 4;
+            return gran_above + (apl == 0 ? 0 : (apl == 1 ? cols * 4 + 1 : cols * 6 + 1)) + (x >> 2);
+        };
+        u64 gpre = 0;
         auto process = [&](const int c, const u32 mbw, const Coefs &q, const Mv2 &mv2) __attribute__((always_inline)) {
             unsigned char *const tY = wl->tY, *const tU = wl->tU, *const tV = wl->tV;   // lambda locals: selects between them stay in registers
+            const u64 gcur = gpre;
+            if (XCU && r > 0 && hl < 12 && c + 1 < cols) gpre = gran_load(above_gran(c + 1));
             const u32 w0 = half_sel(mbw, 0), w1 = half_sel(mbw, 1);
             const int y_mode = w0 & 0xff, uv_mode = (w0 >> 8) & 0xff, ref_frame = (w0 >> 16) & 0xff;
             const u32 flags = w0 >> 24;
@@ -504,16 +551,24 @@ vp8_recon_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g)
             }
 
             // ---- wait for the row above to be two MBs ahead (or finished)
-            if (r > 0) wg_wait_ge(&prog[dep_wave], (dep_seq << 16) + min(c + 2, cols));
+            if (!XCU && r > 0) wg_wait_ge(&prog[dep_wave], (dep_seq << 16) + min(c + 2, cols));
 
             // ---- above line -> tile row -1 (dword copies: Y x=-4..19, U/V x=-4..7)
             if (hl < 12) {
                 const int pl = hl < 6 ? 0 : (hl < 9 ? 1 : 2), i = hl - (pl == 0 ? 0 : (pl == 1 ? 6 : 9));
                 u32 v = 0x7f7f7f7fu;                 // frame row 0: everything above is 127
                 if (r > 0) {
-                    const unsigned char *src = dep_line + (pl == 0 ? 0 : (pl == 1 ? lU : lV)) + LINE_PAD
-                                             + (pl == 0 ? c * 16 : c * 8) - 4 + i * 4;
-                    v = *(const u32 *)src;
+                    if (XCU) {
+                        // the granule of x = 16..19 is written when the row above has finished MB c+1 (or its last
+                        // MB): polling it IS the "two MBs ahead" rule
+                        const int x = (pl == 0 ? c * 16 : c * 8) - 4 + i * 4;
+                        v = 0x81818181u;             // x < 0: the constant 129 left border
+                        if (x >= 0) v = gran_wait(above_gran(c), gcur, epoch, err);
+                    } else {
+                        const unsigned char *src = dep_line + (pl == 0 ? 0 : (pl == 1 ? lU : lV)) + LINE_PAD
+                                                 + (pl == 0 ? c * 16 : c * 8) - 4 + i * 4;
+                        v = *(const u32 *)src;
+                    }
                 }
                 unsigned char *dstp = (pl == 0 ? tY + TY_AT(-1, -4) : (pl == 1 ? tU : tV) + TC_AT(-1, -4)) + i * 4;
                 *(u32 *)dstp = v;
@@ -723,21 +778,26 @@ vp8_recon_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g)
                 *(g_u32p)(dY + (long)(ly0 + 8) * g.y_stride + c * 16 + lx0) = outY1;
                 *(g_u32p)((cpl ? dV : dU) + (long)cy * g.uv_stride + c * 8 + cx0) = outC;
             }
-            if (ly0 == 7) *(u32 *)(my_line + LINE_PAD + c * 16 + lx0) = outY1;          // pixel row 15
+            if (XCU) {
+                if (ly0 == 7) gran_store(gran_mine + c * 4 + (lx0 >> 2), outY1, epoch);                 // pixel row 15
+                if (cy == 7) gran_store(gran_mine + (cpl ? cols * 6 + 1 : cols * 4 + 1) + c * 2 + (cx0 >> 2), outC, epoch);
+                if (c == cols - 1 && hl == 31) gran_store(gran_mine + cols * 4, (outY1 >> 24) * 0x01010101u, epoch);
+            }
+            if (!XCU && ly0 == 7) *(u32 *)(my_line + LINE_PAD + c * 16 + lx0) = outY1;          // pixel row 15
             if (lx0 == 12) {
                 wl->lcol[ly0] = (unsigned char)(outY0 >> 24);
                 wl->lcol[ly0 + 8] = (unsigned char)(outY1 >> 24);
                 tY[TY_AT(ly0, -1)] = (unsigned char)(outY0 >> 24);
                 tY[TY_AT(ly0 + 8, -1)] = (unsigned char)(outY1 >> 24);
             }
-            if (cy == 7) *(u32 *)(my_line + (cpl ? lV : lU) + LINE_PAD + c * 8 + cx0) = outC;
+            if (!XCU && cy == 7) *(u32 *)(my_line + (cpl ? lV : lU) + LINE_PAD + c * 8 + cx0) = outC;
             if (cx0 == 4) wl->lcol[16 + cpl * 8 + cy] = (unsigned char)(outC >> 24);
-            if (c == cols - 1 && hl == 31) {
+            if (!XCU && c == cols - 1 && hl == 31) {
                 // vp8_extend_mb_row (extend.c:160-185): what the next row's last MB sees as above-right
                 // is the last pixel of this line replicated (hl 31 holds pixel row 15, x = 12..15).
                 *(u32 *)(my_line + LINE_PAD + cols * 16) = (outY1 >> 24) * 0x01010101u;
             }
-            wg_publish_lds(&prog[wave], c + 1 == cols ? (k + 1) << 16 : (k << 16) + c + 1, lane);
+            if (!XCU) wg_publish_lds(&prog[wave], c + 1 == cols ? (k + 1) << 16 : (k << 16) + c + 1, lane);
         };
 
         // ---- software pipeline, unrolled by two: MB descriptors two ahead (issued before the current MB is worked
@@ -763,4 +823,18 @@ vp8_recon_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g)
             }
         }
     }
+}
+
+extern "C" __global__ void __launch_bounds__(768)
+vp8_recon_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g)
+{
+    recon_body<false>(jobs, njobs, g, nullptr, 0u, 1, nullptr);
+}
+
+// grid = 8 * S * ceil(npairs / 8) workgroups of (at most) four waves; gran: npairs * 2 * rows * (cols * 8 + 2) granules
+extern "C" __global__ void __launch_bounds__(256)
+vp8_recon_xcu_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g, unsigned long long *gran, unsigned int epoch,
+                     int S, int *err)
+{
+    recon_body<true>(jobs, njobs, g, gran, epoch, S, err);
 }

@@ -15,6 +15,10 @@
 #define VP8HIP_NBUF 3          // scratch frame sets / job tables in rotation (see vp8hip_ctx)
 
 extern "C" __global__ void vp8_recon_kernel(const DevJob *jobs, int njobs, DevGeom g);
+extern "C" __global__ void vp8_recon_xcu_kernel(const DevJob *jobs, int njobs, DevGeom g, unsigned long long *gran, unsigned int epoch,
+                                                int S, int *err);
+extern "C" __global__ void vp8_loopfilter_xcu_kernel(const DevJob *jobs, int njobs, DevGeom g, unsigned long long *gran,
+                                                     unsigned int epoch, int S, int *err);
 extern "C" __global__ void vp8_recon_simt_kernel(const DevJob *jobs, int njobs, DevGeom g, int lgG, int P, int nstrands, int tiled);
 extern "C" __global__ void vp8_loopfilter_simt_kernel(const DevJob *jobs, int njobs, DevGeom g, int lgG, int P, int nstrands);
 extern "C" __global__ void vp8_loopfilter_kernel(const DevJob *jobs, int njobs, DevGeom g);
@@ -70,6 +74,12 @@ struct vp8hip_ctx {
     int recon_nw, lf_nw;
     size_t recon_lds, lf_lds;
     vp8hip_stats stats;
+    // Small launches spread every frame pair over several CUs (vp8_recon_xcu_kernel / vp8_loopfilter_xcu_kernel): granule
+    // buffers of the row-to-row hand-over, the launch counter that tags the granules, and the status word a kernel
+    // sets (host-mapped memory) when a hand-over does not arrive
+    unsigned long long *gran_recon, *gran_lf; size_t gran_recon_cap, gran_lf_cap;
+    unsigned int epoch;
+    int *h_status, *d_status;
 };
 
 static int fail(vp8hip_ctx *c, int code, const char *fmt, ...)
@@ -93,6 +103,9 @@ static void free_pools(vp8hip_ctx *c)
     if (c->fb_block) (void)hipFree(c->fb_block);
     for (int k = 0; k < VP8HIP_NBUF; k++) { if (c->tile_block[k]) (void)hipFree(c->tile_block[k]); c->tile_block[k] = nullptr; c->tile_cap[k] = 0; }
     if (c->slot_block_dev) (void)hipFree(c->slot_block_dev);
+    if (c->gran_recon) (void)hipFree(c->gran_recon);
+    if (c->gran_lf) (void)hipFree(c->gran_lf);
+    c->gran_recon = c->gran_lf = nullptr; c->gran_recon_cap = c->gran_lf_cap = 0;
     for (Slot &s : c->slots)
         if (s.h_block) (void)hipHostFree(s.h_block);
     c->fb_block = nullptr; c->slot_block_dev = nullptr;
@@ -133,6 +146,8 @@ extern "C" int vp8hip_create(int device, vp8hip_ctx **out)
     c->deferred.valid = false;
     c->width = c->height = 0;
     c->ncalls = 0;
+    c->gran_recon = c->gran_lf = nullptr; c->gran_recon_cap = c->gran_lf_cap = 0; c->epoch = 0;
+    c->h_status = c->d_status = nullptr;
     memset(&c->stats, 0, sizeof c->stats);
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) {
         fail(nullptr, -1, "hipStreamCreate: %s", hipGetErrorString(e));
@@ -175,6 +190,7 @@ extern "C" void vp8hip_destroy(vp8hip_ctx *c)
     free_pools(c);
     for (int k = 0; k < VP8HIP_NBUF; k++) if (c->d_jobs2[k]) (void)hipFree(c->d_jobs2[k]);
     if (c->h_jobs) (void)hipHostFree(c->h_jobs);
+    if (c->h_status) (void)hipHostFree(c->h_status);
     for (int r = 0; r < VP8HIP_STATS_RING; r++) for (int i = 0; i < 6; i++) (void)hipEventDestroy(c->evr[r][i]);
     (void)hipEventDestroy(c->ev_jobs);
     (void)hipEventDestroy(c->ev_lf_done);
@@ -437,6 +453,49 @@ extern "C" int vp8hip_decode(vp8hip_ctx *c, const vp8hip_job *jobs, int njobs, i
     c->stats.workgroups = grid;
     c->stats.recon_waves = c->recon_nw;
     c->stats.lf_waves = c->lf_nw;
+    // ---- small launches of the wave-per-row family: a frame pair is spread over S workgroups of XCU_NW waves on S CUs
+    // of one XCD (round-robin placement: workgroups b, b+8, b+16, ... share an XCD) instead of living on one CU, so
+    // that one 1080p frame keeps 68 SIMDs busy, not 4.  At most 32 CUs' worth of workgroups per XCD, one pair per group.
+    const int XCU_NW = 4;
+    int xcu_S = 1, xcu_grid = 0;
+    if (!tiled) {
+        const int npairs = (njobs + 1) / 2, rows = c->dg.mb_rows, cols = c->dg.mb_cols;
+        const int per_xcd = (npairs + 7) / 8;
+        int S = (rows + XCU_NW - 1) / XCU_NW;
+        if (S > 32 / per_xcd) S = 32 / per_xcd;
+        if (npairs > 64) S = 1;
+        if (const char *e = getenv("VP8HIP_XCU")) { if (!atoi(e)) S = 1; }
+        if (const char *e = getenv("VP8HIP_XCU_S")) { int v = atoi(e); if (v >= 1 && v <= 64) S = v; }
+        if (S > 1) {
+            xcu_S = S; xcu_grid = 8 * S * per_xcd;
+            if (!c->h_status) {
+                HIPCHK(c, hipHostMalloc((void **)&c->h_status, sizeof(int), hipHostMallocMapped));
+                *c->h_status = 0;
+                HIPCHK(c, hipHostGetDevicePointer((void **)&c->d_status, c->h_status, 0));
+            }
+            // granule buffers: recon one unfiltered pixel line per MB row (cols*8+2 granules), loop filter four
+            // context rows per MB row (cols*32), per frame; zeroed once -- the tags of later launches never repeat
+            const size_t need_r = (size_t)npairs * 2 * rows * (cols * 8 + 2) * 8, need_l = (size_t)npairs * 2 * rows * cols * 32 * 8;
+            if (c->gran_recon_cap < need_r || c->gran_lf_cap < need_l) {
+                HIPCHK(c, hipStreamSynchronize(c->stream));
+                if (c->gran_recon) (void)hipFree(c->gran_recon);
+                if (c->gran_lf) (void)hipFree(c->gran_lf);
+                c->gran_recon = c->gran_lf = nullptr; c->gran_recon_cap = c->gran_lf_cap = 0;
+                HIPCHK(c, hipMalloc((void **)&c->gran_recon, need_r));
+                HIPCHK(c, hipMalloc((void **)&c->gran_lf, need_l));
+                HIPCHK(c, hipMemsetAsync(c->gran_recon, 0, need_r, c->stream));
+                HIPCHK(c, hipMemsetAsync(c->gran_lf, 0, need_l, c->stream));
+                c->gran_recon_cap = need_r; c->gran_lf_cap = need_l;
+                c->epoch = 0;
+            }
+            if (++c->epoch == 0) {          // 2^32 launches later: start over with clean buffers
+                HIPCHK(c, hipMemsetAsync(c->gran_recon, 0, c->gran_recon_cap, c->stream));
+                HIPCHK(c, hipMemsetAsync(c->gran_lf, 0, c->gran_lf_cap, c->stream));
+                c->epoch = 1;
+            }
+            c->stats.workgroups = xcu_grid; c->stats.recon_waves = XCU_NW; c->stats.lf_waves = XCU_NW;
+        }
+    }
     hipEvent_t *ev = c->evr[c->ncalls % VP8HIP_STATS_RING];
     HIPCHK(c, hipEventRecord(ev[0], c->stream));
     // "one MB row per lane" kernels: G lanes per strand of frames, row period P >= max(cols, 2G+2).  G is at most
@@ -468,9 +527,14 @@ extern "C" int vp8hip_decode(vp8hip_ctx *c, const vp8hip_job *jobs, int njobs, i
                                c->dg, lgG, simtP, simt_waves * spw, tiled ? 1 : 0);
         } else {
             const int npairs = (njobs + 1) / 2;          // two frames per wave
+            if (xcu_S > 1) {
+                hipLaunchKernelGGL(vp8_recon_xcu_kernel, dim3(xcu_grid), dim3(64 * XCU_NW), 1024 + XCU_NW * 2 * 2080, c->stream,
+                                   (const DevJob *)c->d_jobs, njobs, c->dg, c->gran_recon, c->epoch, xcu_S, c->d_status);
+            } else {
             const int rgrid = npairs < c->num_cu * wg_per_cu ? npairs : c->num_cu * wg_per_cu;
             hipLaunchKernelGGL(vp8_recon_kernel, dim3(rgrid), dim3(64 * c->recon_nw), c->recon_lds, c->stream,
                                (const DevJob *)c->d_jobs, njobs, c->dg);
+            }
         }
         HIPCHK(c, hipGetLastError());
     }
@@ -485,9 +549,14 @@ extern "C" int vp8hip_decode(vp8hip_ctx *c, const vp8hip_job *jobs, int njobs, i
                                njobs, c->dg, lgG, simtP, simt_waves * spw);
         } else {
             const int npairs = (njobs + 1) / 2;          // the loop filter works on two frames per wave
+            if (xcu_S > 1) {
+                hipLaunchKernelGGL(vp8_loopfilter_xcu_kernel, dim3(xcu_grid), dim3(64 * XCU_NW), 256 + XCU_NW * 2 * 4096, c->stream,
+                                   (const DevJob *)c->d_jobs, njobs, c->dg, c->gran_lf, c->epoch, xcu_S, c->d_status);
+            } else {
             const int lfgrid = npairs < c->num_cu * wg_per_cu ? npairs : c->num_cu * wg_per_cu;
             hipLaunchKernelGGL(vp8_loopfilter_kernel, dim3(lfgrid), dim3(64 * c->lf_nw), c->lf_lds, c->stream,
                                (const DevJob *)c->d_jobs, njobs, c->dg);
+            }
         }
         HIPCHK(c, hipGetLastError());
     }
@@ -530,13 +599,25 @@ extern "C" int vp8hip_decode(vp8hip_ctx *c, const vp8hip_job *jobs, int njobs, i
     return 0;
 }
 
+// after a stream synchronisation: did a kernel of the cross-CU family give up on a hand-over?
+static int check_status(vp8hip_ctx *c)
+{
+    if (c->h_status && *c->h_status) {
+        const int st = *c->h_status;
+        *c->h_status = 0;
+        return fail(c, -1, "a row hand-over between CUs did not arrive (%s kernel): the frames of that launch are invalid",
+                    st == 1 ? "reconstruction" : "loop filter");
+    }
+    return 0;
+}
+
 extern "C" int vp8hip_sync(vp8hip_ctx *c)
 {
     if (!c) return -2;
     HIPCHK(c, hipSetDevice(c->device));
     if (join_detile(c)) return -1;
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    return 0;
+    return check_status(c);
 }
 
 extern "C" int vp8hip_get_stats_at(vp8hip_ctx *c, int back, vp8hip_stats *st)
@@ -582,7 +663,7 @@ extern "C" int vp8hip_frame_download(vp8hip_ctx *c, int fb, int full, uint8_t *y
                                    c->stream));
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    return 0;
+    return check_status(c);
 }
 
 extern "C" int vp8hip_frame_upload(vp8hip_ctx *c, int fb, const uint8_t *buf)

@@ -20,12 +20,18 @@ def ctx(pkg):
     c.close()
 
 
-@pytest.fixture(params=["wave", "lane"], autouse=True)
+@pytest.fixture(params=["wave", "wave1cu", "lane"], autouse=True)
 def kernel_family(request, monkeypatch):
-    """Every test runs with both kernel families: "wave" = one wave per MB row (small launches), "lane" = one
-    MB row per lane on macroblock-tiled scratch frames + detile (large launches).  VP8HIP_RECON is the library's
-    tuning knob that overrides the automatic choice (libvpx.opencl_amd/csrc/hip/vp8hip.hip)."""
+    """Every test runs with all kernel variants: "wave" = one wave per MB row with a frame pair spread over several
+    CUs where the launch is small enough (granule hand-over through global memory), "wave1cu" = the same kernels with
+    a frame pair on one CU (hand-over through LDS; what larger launches use), "lane" = one MB row per lane on
+    macroblock-tiled scratch frames + detile (large launches).  VP8HIP_RECON / VP8HIP_XCU are the library's tuning
+    knobs that override the automatic choice (libvpx.opencl_amd/csrc/hip/vp8hip.hip)."""
     monkeypatch.setenv("VP8HIP_RECON", "simt" if request.param == "lane" else "wave")
+    if request.param == "wave1cu":
+        monkeypatch.setenv("VP8HIP_XCU", "0")
+    else:
+        monkeypatch.delenv("VP8HIP_XCU", raising=False)
     return request.param
 
 
@@ -116,7 +122,7 @@ def _batch(pkg, ctx, name, nframes):
     nsrc = len(frames)
     ctx.configure(w, h, nframes, nframes)
     parser = pkg.Parser()
-    for i, data in enumerate(frames):
+    for i, data in enumerate(frames[:nframes]):
         hdr = ctx.parse_into_slot(parser, data, i)
         assert hdr.frame_type == 0
         parser.swap(hdr)
@@ -167,6 +173,25 @@ def test_automatic_kernel_choice(pkg, ctx, kernel_family, monkeypatch):
     gold, nsrc = _batch(pkg, ctx, "kf_640x360", 900)
     for i in (0, 7, 450, 899):
         assert pkg.planes_md5(*ctx.download_planes(i)) == gold[i % nsrc], i
+
+
+def test_cross_cu_small_launches(pkg, ctx, kernel_family):
+    """Launches of up to 64 frame pairs spread every pair over S workgroups on different CUs (S shrinks as the launch
+    grows: 17 for one 1080p pair, 32 / ceil(pairs / 8) at most); the rows hand their bottom lines over through tagged
+    granules in global memory.  Odd frame counts, one pair per XCD, several pairs per XCD, and the launch sizes
+    either side of the limit all give the reference's frames."""
+    if kernel_family != "wave":
+        pytest.skip("cross-CU variant only")
+    for name, counts in (("kf_q0_176x144", (1, 3, 18, 66, 128, 130)), ("kf_640x360", (2, 17))):
+        for nframes in counts:
+            gold, nsrc = _batch(pkg, ctx, name, nframes)
+            st = ctx.stats()
+            if nframes <= 128:
+                assert st.recon_waves == 4 and st.lf_waves == 4 and st.workgroups % 8 == 0, (name, nframes, st.workgroups)
+            else:
+                assert st.recon_waves > 4
+            for i in range(nframes):
+                assert pkg.planes_md5(*ctx.download_planes(i)) == gold[i % nsrc], (name, nframes, i)
 
 
 def test_back_to_back_launches_and_stats_ring(pkg, ctx, kernel_family):
