@@ -57,7 +57,8 @@ typedef struct vp8hip_job {
 typedef struct vp8hip_stats {      /* filled by vp8hip_get_stats; times from HIP events, ms */
     float recon_ms, lf_ms, extend_ms;   /* last vp8hip_decode call; extend_ms = border extension, plus the
                                            tiled-to-raster pass when the lane-per-row kernels ran */
-    int   recon_waves, lf_waves;        /* waves per workgroup (1 = the lane-per-row kernels ran) */
+    int   recon_waves, lf_waves;        /* waves per workgroup (1 = the lane-per-row kernels ran, 4 = the cross-CU
+                                           variant of the wave-per-row kernels: small launches) */
     int   workgroups;
 } vp8hip_stats;
 
@@ -94,6 +95,9 @@ int  vp8hip_frame_download(vp8hip_ctx *ctx, int fb, int full, uint8_t *y, uint8_
 int  vp8hip_frame_upload(vp8hip_ctx *ctx, int fb, const uint8_t *buf);
 int  vp8hip_frame_copy(vp8hip_ctx *ctx, int dst_fb, int src_fb);
 
+/* Waits for the context's work.  Also reports (-1 + vp8hip_last_error) if a kernel of the cross-CU family gave up on
+ * a row hand-over -- a defect, not an input error; the frames of that launch are invalid.  vp8hip_frame_download checks
+ * the same. */
 int  vp8hip_sync(vp8hip_ctx *ctx);
 int  vp8hip_get_stats(vp8hip_ctx *ctx, vp8hip_stats *st);
 /* Stats of an earlier launch: back = 0 the last vp8hip_decode call, 1 the one before, ... (up to 31).  Waits
