@@ -95,6 +95,12 @@ int  vp8hip_frame_download(vp8hip_ctx *ctx, int fb, int full, uint8_t *y, uint8_
 int  vp8hip_frame_upload(vp8hip_ctx *ctx, int fb, const uint8_t *buf);
 int  vp8hip_frame_copy(vp8hip_ctx *ctx, int dst_fb, int src_fb);
 
+/* Page-locked host memory for the caller's side of vp8hip_frame_download / vp8hip_frame_upload (a download into pageable
+ * memory runs at a fraction of the PCIe rate).  The reference keeps its frame buffers in host memory it owns
+ * (vp8_yv12_alloc_frame_buffer, vpx_scale/generic/yv12config.c:45-110); this is the host mirror's allocator. */
+void *vp8hip_host_alloc(vp8hip_ctx *ctx, size_t bytes);
+void  vp8hip_host_free(vp8hip_ctx *ctx, void *p);
+
 /* Waits for the context's work.  Also reports (-1 + vp8hip_last_error) if a kernel of the cross-CU family gave up on
  * a row hand-over -- a defect, not an input error; the frames of that launch are invalid.  vp8hip_frame_download checks
  * the same. */

@@ -666,6 +666,21 @@ extern "C" int vp8hip_frame_download(vp8hip_ctx *c, int fb, int full, uint8_t *y
     return check_status(c);
 }
 
+extern "C" void *vp8hip_host_alloc(vp8hip_ctx *c, size_t bytes)
+{
+    void *p = nullptr;
+    if (!c || !bytes) return nullptr;
+    if (hipSetDevice(c->device) != hipSuccess) return nullptr;
+    hipError_t e = hipHostMalloc(&p, bytes, hipHostMallocDefault);
+    if (e != hipSuccess) { fail(c, -1, "hipHostMalloc(%zu): %s", bytes, hipGetErrorString(e)); return nullptr; }
+    return p;
+}
+
+extern "C" void vp8hip_host_free(vp8hip_ctx *c, void *p)
+{
+    if (c && p) { (void)hipSetDevice(c->device); (void)hipHostFree(p); }
+}
+
 extern "C" int vp8hip_frame_upload(vp8hip_ctx *c, int fb, const uint8_t *buf)
 {
     if (!c || fb < 0 || fb >= (int)c->fb.size() || !buf) return fail(c, -2, "vp8hip_frame_upload: bad arguments");

@@ -13,6 +13,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include "vp8_parser.h"
 #include "vp8_rtcd.h"
@@ -38,7 +39,16 @@ struct vpx_codec_alg_priv {
     int                     show_corrupted;
     int                     ref_updates, ref_used;
     char                    detail[160];
+    double                  t_parse, t_launch, t_down;   /* VP8HIP_TRACE: seconds per phase of vp8_decode */
+    long                    t_frames;
 };
+
+static double now_s(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
 
 static vpx_codec_err_t set_detail(vpx_codec_alg_priv_t *p, vpx_codec_err_t code, const char *msg)
 {
@@ -69,9 +79,11 @@ static vpx_codec_err_t vp8_init(vpx_codec_ctx_t *ctx, void *mr_cfg)
 
 static vpx_codec_err_t vp8_destroy(vpx_codec_alg_priv_t *p)
 {
-    if (p->hip) vp8hip_destroy(p->hip);
+    if (getenv("VP8HIP_TRACE") && p->t_frames)
+        fprintf(stderr, "[vp8_dx] %ld frames: parse %.3f ms, upload+launch %.3f ms, wait+download %.3f ms per frame\n", p->t_frames,
+                p->t_parse / p->t_frames * 1e3, p->t_launch / p->t_frames * 1e3, p->t_down / p->t_frames * 1e3);
+    if (p->hip) { vp8hip_host_free(p->hip, p->host_frame); vp8hip_destroy(p->hip); }
     vp8_parser_destroy(p->parser);
-    free(p->host_frame);
     free(p);
     return VPX_CODEC_OK;
 }
@@ -134,6 +146,7 @@ static vpx_codec_err_t vp8_decode(vpx_codec_alg_priv_t *p, const uint8_t *data, 
     vp8ir_mv *h_mvs;
     vp8hip_job job;
     int rc, corrupt = 0, i, nmb;
+    double t0, t1, t2;
     (void)deadline;
 
     p->img_avail = 0;
@@ -166,6 +179,7 @@ static vpx_codec_err_t vp8_decode(vpx_codec_alg_priv_t *p, const uint8_t *data, 
     }
 
     if (vp8_refs_get_free(&p->refs) < 0) return set_detail(p, VPX_CODEC_ERROR, "no free frame buffer");
+    t0 = now_s();
     rc = vp8_parser_begin_frame(p->parser, data, data_sz, &hdr);
     if (rc) {
         vp8_refs_release_new(&p->refs);
@@ -177,8 +191,8 @@ static vpx_codec_err_t vp8_decode(vpx_codec_alg_priv_t *p, const uint8_t *data, 
             return gpu_error(p, "vp8hip_configure");
         }
         vp8hip_geometry(p->hip, &p->geom);
-        free(p->host_frame);
-        p->host_frame = (uint8_t *)malloc((size_t)p->geom.frame_size);
+        vp8hip_host_free(p->hip, p->host_frame);
+        p->host_frame = (uint8_t *)vp8hip_host_alloc(p->hip, (size_t)p->geom.frame_size);
         if (!p->host_frame) return VPX_CODEC_MEM_ERROR;
         p->width = hdr.width;
         p->height = hdr.height;
@@ -212,6 +226,7 @@ static vpx_codec_err_t vp8_decode(vpx_codec_alg_priv_t *p, const uint8_t *data, 
     if (p->ref_used & VP8_ALTR_FRAME) corrupt |= p->fb_corrupted[p->refs.alt_idx];
     p->fb_corrupted[p->refs.new_idx] = corrupt;
 
+    t1 = now_s();
     if (vp8hip_ir_upload(p->hip, 0)) { vp8_refs_release_new(&p->refs); return gpu_error(p, "vp8hip_ir_upload"); }
     job.ir_slot = 0;
     job.dst_fb = p->refs.new_idx;
@@ -224,15 +239,16 @@ static vpx_codec_err_t vp8_decode(vpx_codec_alg_priv_t *p, const uint8_t *data, 
     if (vp8_refs_swap(&p->refs, &hdr)) return set_detail(p, VPX_CODEC_ERROR, "invalid buffer copy flags");
     p->show_corrupted = p->fb_corrupted[p->refs.show_idx];
 
+    t2 = now_s();
     if (hdr.show_frame) {
-        const vp8ir_geom *g = &p->geom;
-        if (vp8hip_frame_download(p->hip, p->refs.show_idx, 0, p->host_frame + g->y_off, p->host_frame + g->u_off,
-                                  p->host_frame + g->v_off, g->y_stride, g->uv_stride))
+        /* the whole frame buffer, borders included, in one linear copy into the pinned mirror (same vp8ir_geom layout) */
+        if (vp8hip_frame_download(p->hip, p->refs.show_idx, 1, p->host_frame, NULL, NULL, 0, 0))
             return gpu_error(p, "vp8hip_frame_download");
         publish_image(p, user_priv);
         p->img_avail = 1;
     } else if (vp8hip_sync(p->hip))
         return gpu_error(p, "vp8hip_sync");
+    p->t_parse += t1 - t0; p->t_launch += t2 - t1; p->t_down += now_s() - t2; p->t_frames++;
     return VPX_CODEC_OK;
 }
 
