@@ -1,0 +1,248 @@
+/* batch_md5 [--threads T] [--batch B] [--loop N] <in.ivf> <out.md5>
+ *
+ * decode_to_md5 for streams of independently decodable frames (all key frames), at the rate the host can feed the
+ * GPU: SURVEY.md 8(f)1.  The output file has decode_to_md5's lines ("<md5>  img-<w>x<h>-<%04d>.i420", one per frame,
+ * in stream order) and is byte-identical to it.
+ *
+ * The reference decodes one frame at a time on one thread (decoder_tmpl.c:47-103).  Key frames reset every piece of
+ * decoder state (decodframe.c:610-639), so here T feeder threads run the entropy decoder (vp8_parser.h) on different
+ * frames at once, each writing the IR straight into the pinned staging of an IR slot (vp8hip_ir_map); the main thread
+ * uploads a batch of B slots, launches the pixel path for the whole batch (vp8hip_decode), downloads the previous
+ * batch into pinned host memory, and the same pool hashes it.  Three slot / frame-buffer sets rotate: batch k+1 is
+ * parsed while batch k is on the GPU and batch k-1 is downloaded and hashed.  --loop repeats the stream N times
+ * (benchmarking; the listing then has N * frames lines).
+ *
+ * Prints frames, seconds and frames/s for the region "first byte parsed .. last digest done" on stderr. */
+#include <pthread.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+#include <unistd.h>
+#include "ivf.h"
+#include "md5.h"
+#include "vp8_parser.h"
+#include "vp8hip.h"
+
+/* ---- a tiny pool: up to two "parallel for" tasks in flight, indices handed out one at a time ---------------------- */
+typedef void (*task_fn)(void *arg, int index, int worker);
+typedef struct task {
+    task_fn fn; void *arg;
+    int n, next, done;              /* guarded by pool.mu */
+} task;
+static struct {
+    pthread_mutex_t mu; pthread_cond_t work, finished;
+    task *slot[2];                  /* slot 0 is served first (the feeder), then slot 1 (hashing) */
+    int stop;
+} pool = { PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER, { NULL, NULL }, 0 };
+
+static void *worker_main(void *idp)
+{
+    const int id = (int)(size_t)idp;
+    pthread_mutex_lock(&pool.mu);
+    for (;;) {
+        task *t = NULL;
+        for (int s = 0; s < 2 && !t; s++)
+            if (pool.slot[s] && pool.slot[s]->next < pool.slot[s]->n) t = pool.slot[s];
+        if (!t) {
+            if (pool.stop) break;
+            pthread_cond_wait(&pool.work, &pool.mu);
+            continue;
+        }
+        const int i = t->next++;
+        pthread_mutex_unlock(&pool.mu);
+        t->fn(t->arg, i, id);
+        pthread_mutex_lock(&pool.mu);
+        if (++t->done == t->n) pthread_cond_broadcast(&pool.finished);
+    }
+    pthread_mutex_unlock(&pool.mu);
+    return NULL;
+}
+static void task_start(task *t, int slot, task_fn fn, void *arg, int n)
+{
+    pthread_mutex_lock(&pool.mu);
+    t->fn = fn; t->arg = arg; t->n = n; t->next = 0; t->done = 0;
+    pool.slot[slot] = t;
+    pthread_cond_broadcast(&pool.work);
+    pthread_mutex_unlock(&pool.mu);
+}
+static void task_wait(task *t, int slot)
+{
+    pthread_mutex_lock(&pool.mu);
+    while (t->done < t->n) pthread_cond_wait(&pool.finished, &pool.mu);
+    if (pool.slot[slot] == t) pool.slot[slot] = NULL;
+    pthread_mutex_unlock(&pool.mu);
+}
+
+/* ---- the stream in memory -------------------------------------------------------------------------------------------- */
+typedef struct frame { uint8_t *data; size_t size; } frame;
+static frame *g_frames; static int g_nframes;
+
+/* ---- per-run state shared with the workers ------------------------------------------------------------------------ */
+static vp8hip_ctx *g_hip;
+static vp8_parser **g_parsers;                      /* one per worker */
+static int g_batch, g_width, g_height;
+static vp8ir_geom g_geom;
+static struct { vp8ir_frame_hdr *hdr; vp8ir_mb *mbs; int16_t *coef; vp8ir_mv *mvs; } *g_maps;   /* 3 * batch slots */
+static uint8_t *g_host;                             /* batch pinned frame buffers */
+static unsigned char (*g_digest)[16];               /* one per frame of the whole run */
+static volatile int g_failed;
+
+typedef struct batch_ref { int b, n; long first; } batch_ref;     /* batch number, frames in it, index of its first frame */
+
+static void parse_one(void *arg, int i, int worker)
+{
+    const batch_ref *br = (const batch_ref *)arg;
+    const frame *f = &g_frames[(br->first + i) % g_nframes];
+    const int slot = (br->b % 3) * g_batch + i;
+    vp8ir_frame_hdr hdr;
+    int rc = vp8_parser_begin_frame(g_parsers[worker], f->data, f->size, &hdr);
+    if (!rc && (hdr.frame_type != 0 || hdr.width != g_width || hdr.height != g_height)) rc = VP8P_UNSUP_BITSTREAM;
+    if (!rc) rc = vp8_parser_decode_mbs(g_parsers[worker], g_maps[slot].mbs, g_maps[slot].coef, g_maps[slot].mvs, NULL);
+    if (rc) { g_failed = 1; return; }
+    *g_maps[slot].hdr = hdr;
+}
+
+static void hash_one(void *arg, int i, int worker)
+{
+    const batch_ref *br = (const batch_ref *)arg;
+    const uint8_t *fb = g_host + (size_t)i * g_geom.frame_size;
+    md5_state md5;
+    (void)worker;
+    md5_init(&md5);
+    for (int plane = 0; plane < 3; plane++) {
+        const int w = plane ? (g_width + 1) >> 1 : g_width, rows = plane ? (g_height + 1) >> 1 : g_height;
+        const int stride = plane ? g_geom.uv_stride : g_geom.y_stride;
+        const uint8_t *p = fb + (plane == 0 ? g_geom.y_off : plane == 1 ? g_geom.u_off : g_geom.v_off);
+        for (int y = 0; y < rows; y++, p += stride) md5_update(&md5, p, (size_t)w);
+    }
+    md5_final(&md5, g_digest[br->first + i]);
+}
+
+static double now_s(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+#define DIE(...) do { fprintf(stderr, __VA_ARGS__); fprintf(stderr, "\n"); exit(EXIT_FAILURE); } while (0)
+#define HIP(call) do { if (call) DIE("%s: %s", #call, vp8hip_last_error(g_hip)); } while (0)
+
+int main(int argc, char **argv)
+{
+    int threads = 0, loop = 1, a = 1;
+    g_batch = 128;
+    for (; a < argc && argv[a][0] == '-' && argv[a][1] == '-'; a++) {
+        if (!strcmp(argv[a], "--threads") && a + 1 < argc) threads = atoi(argv[++a]);
+        else if (!strcmp(argv[a], "--batch") && a + 1 < argc) g_batch = atoi(argv[++a]);
+        else if (!strcmp(argv[a], "--loop") && a + 1 < argc) loop = atoi(argv[++a]);
+        else DIE("Usage: %s [--threads T] [--batch B] [--loop N] <in.ivf> <out.md5>", argv[0]);
+    }
+    if (argc - a != 2 || g_batch < 1 || loop < 1)
+        DIE("Usage: %s [--threads T] [--batch B] [--loop N] <in.ivf> <out.md5>", argv[0]);
+    if (threads < 1) {
+        long n = sysconf(_SC_NPROCESSORS_ONLN);
+        threads = n > 33 ? 32 : (n > 2 ? (int)n - 1 : 1);      /* more than ~32 feeders gain nothing: the host memory system is the limit */
+    }
+
+    /* ---- read the whole stream; every frame must be a key frame of one size */
+    ivf_reader in;
+    const uint8_t *data; size_t size; int rc, cap = 0;
+    if (ivf_open(&in, argv[a])) DIE("%s is not an IVF file.", argv[a]);
+    while ((rc = ivf_next(&in, &data, &size)) == 1) {
+        int key, w, h;
+        if (g_nframes == cap) { cap = cap ? 2 * cap : 64; g_frames = (frame *)realloc(g_frames, sizeof(frame) * cap); }
+        if (vp8_parser_peek(data, size, &key, &w, &h) || !key)
+            DIE("frame %d is not a key frame: batch_md5 needs independently decodable frames (use decode_to_md5)", g_nframes + 1);
+        if (g_nframes == 0) { g_width = w; g_height = h; }
+        else if (w != g_width || h != g_height) DIE("frame %d changes the frame size (use decode_to_md5)", g_nframes + 1);
+        g_frames[g_nframes].data = (uint8_t *)malloc(size + 16);
+        memcpy(g_frames[g_nframes].data, data, size);
+        g_frames[g_nframes].size = size;
+        g_nframes++;
+    }
+    ivf_close(&in);
+    if (rc < 0 || !g_nframes) DIE("failed to read %s", argv[a]);
+    const long total = (long)g_nframes * loop;
+    if (g_batch > total) g_batch = (int)total;
+
+    /* ---- device and host state */
+    int device = -1;
+    if (getenv("VP8HIP_DEVICE")) device = atoi(getenv("VP8HIP_DEVICE"));
+    if (vp8hip_create(device, &g_hip)) DIE("vp8hip_create: %s (no CPU fallback)", vp8hip_last_error(NULL));
+    HIP(vp8hip_configure(g_hip, g_width, g_height, 3 * g_batch, 3 * g_batch));
+    HIP(vp8hip_geometry(g_hip, &g_geom));
+    g_maps = calloc((size_t)3 * g_batch, sizeof *g_maps);
+    for (int s = 0; s < 3 * g_batch; s++) HIP(vp8hip_ir_map(g_hip, s, &g_maps[s].hdr, &g_maps[s].mbs, &g_maps[s].coef, &g_maps[s].mvs));
+    g_host = (uint8_t *)vp8hip_host_alloc(g_hip, (size_t)g_batch * g_geom.frame_size);
+    if (!g_host) DIE("vp8hip_host_alloc: %s", vp8hip_last_error(g_hip));
+    g_digest = calloc((size_t)total, 16);
+    g_parsers = calloc((size_t)threads, sizeof *g_parsers);
+    pthread_t *tid = calloc((size_t)threads, sizeof *tid);
+    for (int t = 0; t < threads; t++) {
+        if (!(g_parsers[t] = vp8_parser_create())) DIE("out of memory");
+        pthread_create(&tid[t], NULL, worker_main, (void *)(size_t)t);
+    }
+    vp8hip_job *jobs = calloc((size_t)g_batch, sizeof *jobs);
+
+    /* ---- the pipeline */
+    const long nbatch = (total + g_batch - 1) / g_batch;
+    task parse_t, hash_t;
+    batch_ref cur = { 0, (int)(total < g_batch ? total : g_batch), 0 }, nxt, prev = { -1, 0, 0 }, hashing = { -1, 0, 0 };
+    const double t0 = now_s();
+    task_start(&parse_t, 0, parse_one, &cur, cur.n);
+    for (long b = 0; b < nbatch; b++) {
+        task_wait(&parse_t, 0);
+        if (g_failed) DIE("a frame of batch %ld failed to parse", b);
+        if (prev.b >= 0) {
+            /* the previous batch comes back BEFORE this one's uploads are queued on the (in-order) stream */
+            if (hashing.b >= 0) task_wait(&hash_t, 1);                      /* the pinned buffers are free again */
+            for (int i = 0; i < prev.n; i++)
+                HIP(vp8hip_frame_download(g_hip, (prev.b % 3) * g_batch + i, 1, g_host + (size_t)i * g_geom.frame_size, NULL, NULL, 0, 0));
+            hashing = prev;
+            task_start(&hash_t, 1, hash_one, &hashing, hashing.n);
+        }
+        for (int i = 0; i < cur.n; i++) {
+            const int s = (cur.b % 3) * g_batch + i;
+            HIP(vp8hip_ir_upload(g_hip, s));
+            jobs[i].ir_slot = s; jobs[i].dst_fb = s;
+            jobs[i].ref_fb[0] = jobs[i].ref_fb[1] = jobs[i].ref_fb[2] = jobs[i].ref_fb[3] = -1;
+        }
+        HIP(vp8hip_decode(g_hip, jobs, cur.n, VP8HIP_STAGE_ALL));
+        prev = cur;
+        if (b + 1 < nbatch) {
+            const long first = cur.first + cur.n;
+            nxt.b = cur.b + 1; nxt.first = first; nxt.n = (int)(total - first < g_batch ? total - first : g_batch);
+            cur = nxt;                                  /* slot set (b+1)%3: last used by batch b-2, downloaded already */
+            task_start(&parse_t, 0, parse_one, &cur, cur.n);
+        }
+    }
+    if (hashing.b >= 0) task_wait(&hash_t, 1);
+    for (int i = 0; i < prev.n; i++)
+        HIP(vp8hip_frame_download(g_hip, (prev.b % 3) * g_batch + i, 1, g_host + (size_t)i * g_geom.frame_size, NULL, NULL, 0, 0));
+    hashing = prev;
+    task_start(&hash_t, 1, hash_one, &hashing, hashing.n);
+    task_wait(&hash_t, 1);
+    const double dt = now_s() - t0;
+
+    /* ---- the listing */
+    FILE *out = fopen(argv[a + 1], "wb");
+    if (!out) DIE("Failed to open %s for writing", argv[a + 1]);
+    for (long f = 0; f < total; f++) {
+        for (int i = 0; i < 16; i++) fprintf(out, "%02x", g_digest[f][i]);
+        fprintf(out, "  img-%dx%d-%04ld.i420\n", g_width, g_height, f + 1);
+    }
+    fclose(out);
+    fprintf(stderr, "%ld frames in %.3f s: %.1f frames/s, %.1f Mpix/s (%d feeder threads, %d frames per launch)\n", total, dt,
+            total / dt, total / dt * g_width * g_height / 1e6, threads, g_batch);
+
+    pthread_mutex_lock(&pool.mu);
+    pool.stop = 1;
+    pthread_cond_broadcast(&pool.work);
+    pthread_mutex_unlock(&pool.mu);
+    for (int t = 0; t < threads; t++) { pthread_join(tid[t], NULL); vp8_parser_destroy(g_parsers[t]); }
+    vp8hip_host_free(g_hip, g_host);
+    vp8hip_destroy(g_hip);
+    return EXIT_SUCCESS;
+}

@@ -41,3 +41,31 @@ def test_api_rejects_bad_streams():
     r = subprocess.run([os.path.join(BIN, "decode_to_md5"), os.path.join(GOLDEN, "kf_640x360.md5"), "/dev/null"],
                        capture_output=True, text=True)
     assert r.returncode != 0 and "not an IVF" in r.stderr
+
+
+@pytest.mark.parametrize("name,args", [("kf_640x360", ["--threads", "4", "--batch", "3"]), ("kf_odd_67x45", ["--batch", "64"]),
+                                       ("kf_q0_176x144", ["--threads", "2", "--batch", "4", "--loop", "5"]),
+                                       ("kf_1920x1080", [])])
+def test_batch_md5_listing_equals_decode_to_md5(name, args, tmp_path):
+    """The threaded feeder + batched launches (batch_md5) write decode_to_md5's listing, line for line; looped, the
+    digests repeat with continuing frame numbers."""
+    out = tmp_path / "out.md5"
+    r = subprocess.run([os.path.join(BIN, "batch_md5")] + args + [ivf_path(name), str(out)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "frames/s" in r.stderr
+    loop = int(args[args.index("--loop") + 1]) if "--loop" in args else 1
+    gold = open(os.path.join(GOLDEN, name + ".md5")).read().splitlines()
+    got = open(out).read().splitlines()
+    assert len(got) == loop * len(gold)
+    if loop == 1:
+        assert got == gold
+    for i, line in enumerate(got):
+        digest, label = line.split()
+        assert digest == gold[i % len(gold)].split()[0]
+        assert label.endswith("-%04d.i420" % (i + 1))
+
+
+def test_batch_md5_refuses_inter_frames(tmp_path):
+    r = subprocess.run([os.path.join(BIN, "batch_md5"), ivf_path("p_lowrate_640x360"), str(tmp_path / "o")],
+                       capture_output=True, text=True)
+    assert r.returncode != 0 and "not a key frame" in r.stderr
