@@ -831,8 +831,8 @@ vp8_recon_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g)
     recon_body<false>(jobs, njobs, g, nullptr, 0u, 1, nullptr);
 }
 
-// grid = 8 * S * ceil(npairs / 8) workgroups of (at most) four waves; gran: npairs * 2 * rows * (cols * 8 + 2) granules
-extern "C" __global__ void __launch_bounds__(256)
+// grid = 8 * S * ceil(npairs / 8) workgroups of four or eight waves; gran: npairs * 2 * rows * (cols * 8 + 2) granules
+extern "C" __global__ void __launch_bounds__(512)
 vp8_recon_xcu_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g, unsigned long long *gran, unsigned int epoch,
                      int S, int *err)
 {

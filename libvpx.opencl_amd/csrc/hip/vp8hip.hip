@@ -167,6 +167,8 @@ extern "C" int vp8hip_create(int device, vp8hip_ctx **out)
         delete c;
         return -1;
     }
+    (void)hipFuncSetAttribute((const void *)vp8_recon_xcu_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_lds);
+    (void)hipFuncSetAttribute((const void *)vp8_loopfilter_xcu_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_lds);
     e = hipFuncSetAttribute((const void *)vp8_loopfilter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_lds);
     if (e != hipSuccess) {
         fail(nullptr, -1, "hipFuncSetAttribute(loopfilter, %d B LDS): %s", c->max_lds, hipGetErrorString(e));
@@ -456,16 +458,21 @@ extern "C" int vp8hip_decode(vp8hip_ctx *c, const vp8hip_job *jobs, int njobs, i
     // ---- small launches of the wave-per-row family: a frame pair is spread over S workgroups of XCU_NW waves on S CUs
     // of one XCD (round-robin placement: workgroups b, b+8, b+16, ... share an XCD) instead of living on one CU, so
     // that one 1080p frame keeps 68 SIMDs busy, not 4.  At most 32 CUs' worth of workgroups per XCD, one pair per group.
-    const int XCU_NW = 4;
+    int XCU_NW = 4;
     int xcu_S = 1, xcu_grid = 0;
     if (!tiled) {
         const int npairs = (njobs + 1) / 2, rows = c->dg.mb_rows, cols = c->dg.mb_cols;
         const int per_xcd = (npairs + 7) / 8;
-        int S = (rows + XCU_NW - 1) / XCU_NW;
-        if (S > 32 / per_xcd) S = 32 / per_xcd;
-        if (npairs > 64) S = 1;
+        int S = (rows + XCU_NW - 1) / XCU_NW;                // a wave per row ...
+        if (per_xcd > 32) S = 1;
+        else if (S > 32 / per_xcd) S = 32 / per_xcd;         // ... or one workgroup on every CU of the XCD
+        // fewer waves than rows: two waves per SIMD.  Worth it as long as a pair gets more waves than the twelve it
+        // has on a single CU (a wave's macroblock step is a latency chain; throughput goes with the number of waves)
+        if (S * XCU_NW < rows) XCU_NW = 8;
+        if (S * XCU_NW <= c->recon_nw) S = 1;
         if (const char *e = getenv("VP8HIP_XCU")) { if (!atoi(e)) S = 1; }
         if (const char *e = getenv("VP8HIP_XCU_S")) { int v = atoi(e); if (v >= 1 && v <= 64) S = v; }
+        if (const char *e = getenv("VP8HIP_XCU_NW")) { int v = atoi(e); if (v == 4 || v == 8) XCU_NW = v; }
         if (S > 1) {
             xcu_S = S; xcu_grid = 8 * S * per_xcd;
             if (!c->h_status) {
