@@ -295,6 +295,9 @@ def main():
         dom = max(ms_alone, key=lambda k: ms_alone[k])
         achieved = bytes_per_launch[dom] / (ms[dom] * 1e-3) / 1e9
         pipeline_gbps = sum(bytes_per_launch.values()) / (elapsed / K) / 1e9
+        # SURVEY.md 8(d)'s own figure for the full key-frame path: 1217 + 770 + 36 = 2023 B/MB -- without the bytes of the
+        # tiled -> raster pass, which is this implementation's extra pass, not part of the algorithm
+        survey_gbps = (B_RECON + B_LF + B_EXTEND) * nmb * F / (elapsed / K) / 1e9
         out = {
             "metric": "vp8_decode_pixel_path_mpix_per_s",
             "value": round(total_pix / elapsed / 1e6, 1),
@@ -342,8 +345,11 @@ def main():
                 "mean_launch_ms": round(ms[dom], 4),
                 "all_kernels_GBps": {k: round(bytes_per_launch[k] / (ms[k] * 1e-3) / 1e9, 2) if ms[k] > 0 else None
                                      for k in ms},
-                "pipeline": {"achieved": round(pipeline_gbps, 2), "frac": round(pipeline_gbps / HBM_PEAK_GBPS, 5),
-                             "note": "all kernels' algorithmic bytes / whole step time"},
+                "pipeline": {"achieved": round(survey_gbps, 2), "frac": round(survey_gbps / HBM_PEAK_GBPS, 5),
+                             "note": "SURVEY 8(d) bytes of the whole path (recon + loop filter + border extend = 2023 B/MB) / "
+                                     "whole step time",
+                             "achieved_counting_own_detile_pass": round(pipeline_gbps, 2),
+                             "frac_counting_own_detile_pass": round(pipeline_gbps / HBM_PEAK_GBPS, 5)},
                 "device_copy_probe_GBps": round(copy_gbps, 1) if copy_gbps else None,
             },
         }
