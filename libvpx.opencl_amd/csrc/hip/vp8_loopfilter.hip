@@ -484,29 +484,34 @@ vp8_loopfilter_xcu_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g,
 // ---- border extension ------------------------------------------------------------------------
 // vp8_yv12_extend_frame_borders (yv12extend.c:24-145): replicate the first/last pixel of every row
 // 32 (luma) / 16 (chroma) times, then the first/last (already widened) row 32 / 16 times.
-// grid = (rows-of-work, njobs); every thread writes one dword.
+// grid = (chunks, njobs).  Only border dwords are enumerated: per plane first the 2 * border rows above and below the
+// image (whole widened rows: contiguous stores), then the left and right pieces of the h image rows; every value comes
+// straight from the clamped source coordinate, so there is no ordering between the two parts.
 extern "C" __global__ void __launch_bounds__(256)
 vp8_extend_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g)
 {
     const DevJob &job = jobs[blockIdx.y];
-    // plane table
     for (int plane = 0; plane < 3; ++plane) {
         const int w = plane ? g.aligned_w / 2 : g.aligned_w, h = plane ? g.aligned_h / 2 : g.aligned_h;
         const int stride = plane ? g.uv_stride : g.y_stride, border = plane ? 16 : 32;
         g_u8p p = (g_u8p)(job.dst + (plane == 0 ? g.y_off : plane == 1 ? g.u_off : g.v_off));
-        const int full_w = w + 2 * border;               // bytes per widened row
-        const int dw_per_row = full_w / 4;
-        // phase A (left/right of every image row) and phase B (top/bottom rows) are fused: a thread
-        // owns one dword of one row of the widened plane (rows -border .. h+border-1) that lies in
-        // the border, and computes its value directly from the clamped source coordinate.
-        const long total = (long)(h + 2 * border) * dw_per_row;
-        for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-            const int row = (int)(i / dw_per_row) - border, xd = (int)(i % dw_per_row) * 4 - border;
-            const bool inside_x = xd >= 0 && xd < w, inside_y = row >= 0 && row < h;
-            if (inside_x && inside_y) continue;
+        const int row_dw = (w + 2 * border) / 4, side_dw = border / 4;
+        const int n_tb = 2 * border * row_dw;               // dwords above + below
+        const int total = n_tb + h * 2 * side_dw;           // + left and right of the image rows
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+            int row, xd;
+            if (i < n_tb) {
+                const int rr = i / row_dw;
+                xd = (i - rr * row_dw) * 4 - border;
+                row = rr < border ? rr - border : h + (rr - border);
+            } else {
+                const int j = i - n_tb, rr = j / (2 * side_dw), k = j - rr * 2 * side_dw;
+                row = rr;
+                xd = k < side_dw ? k * 4 - border : w + (k - side_dw) * 4;
+            }
             const int sy = row < 0 ? 0 : (row >= h ? h - 1 : row);
             unsigned int v;
-            if (inside_x) v = *(g_cu32p)(p + (long)sy * stride + xd);
+            if (xd >= 0 && xd < w) v = *(g_cu32p)(p + (long)sy * stride + xd);
             else v = p[(long)sy * stride + (xd < 0 ? 0 : w - 1)] * 0x01010101u;
             *(g_u32p)(p + (long)row * stride + xd) = v;
         }

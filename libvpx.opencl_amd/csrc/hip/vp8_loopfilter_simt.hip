@@ -295,7 +295,7 @@ __device__ __forceinline__ Lim mb_limits(int sharp, int level, int frame_type, v
 //   when nobody is below (last row of the frame) or the lane below reads them back from memory (the first
 //   lane of a strand follows the last one).
 extern "C" __global__ void __launch_bounds__(64)
-vp8_loopfilter_simt_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g, int lgG, int P, int nstrands)
+vp8_loopfilter_simt_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g, int lgG, int P, int nstrands, int raster)
 {
     __shared__ u32 tile[100 * 64];              // luma: 20 rows x 5 dwords; chroma reuses it: 12 rows x 3 dwords
     const int lane = threadIdx.x;
@@ -316,6 +316,7 @@ vp8_loopfilter_simt_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g
     // ---- per-lane row state
     g_cu32p mbp = nullptr;
     g_u8p trow = nullptr;                        // tile (r, 0)
+    g_u8p rasY = nullptr, rasU = nullptr, rasV = nullptr;   // raster == 1: pixel (0,0) of MB row r in the frame buffer
     const DevJob *job = jobs;
     int r = 0;
     bool lf_on = false, simple = false;
@@ -367,6 +368,9 @@ vp8_loopfilter_simt_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g
                 simple = h.filter_type == 1;
                 mbp = (g_cu32p)(job->mbs + (long)r * cols);
                 trow = (g_u8p)(const_cast<uint8_t *>(job->ref[0]) + (long)r * rowbytes);
+                rasY = (g_u8p)(job->dst + g.y_off + (long)r * 16 * g.y_stride);
+                rasU = (g_u8p)(job->dst + g.u_off + (long)r * 8 * g.uv_stride);
+                rasV = (g_u8p)(job->dst + g.v_off + (long)r * 8 * g.uv_stride);
             }
             if (lf_on) {
             const vp8ir_frame_hdr &h = job->hdr;
@@ -396,6 +400,16 @@ vp8_loopfilter_simt_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g
             const bool readback = r > 0 && pos == 0;
 
             g_u8p tp = trow + (long)c * VP8_TILE_BYTES;           // this macroblock's tile
+            // Where finished lines go.  raster == 0: back into the tiled scratch frame (vp8_detile_kernel converts later).
+            // raster == 1: FINAL lines straight into the raster frame buffer; lines that are only handed to the first
+            // lane of the strand (write_bottom on a row that is not the frame's last) still travel through the scratch.
+            const bool ras = raster != 0, ras_bottom = ras && r == rows - 1;
+            const int ysY = ras ? g.y_stride : 16, ysC = ras ? g.uv_stride : 8;
+            const int ybY = ras_bottom ? g.y_stride : 16, ybC = ras_bottom ? g.uv_stride : 8;
+            g_u8p o_left_lo = ras ? rasY + (c - 1) * 16 : tp - VP8_TILE_BYTES;                                   // MB c-1 rows 0..7
+            g_u8p o_left_hi = ras_bottom ? rasY + (c - 1) * 16 + 8 * g.y_stride : tp - VP8_TILE_BYTES + 128;      // MB c-1 rows 8..15
+            g_u8p o_own_lo = ras ? rasY + c * 16 : tp, o_own_hi = ras_bottom ? rasY + c * 16 + 8 * g.y_stride : tp + 128;
+            g_u8p o_above = ras ? rasY - 8 * g.y_stride + c * 16 : tp - rowbytes + 128;                           // MB (r-1, c) rows 8..15
             u32x4 inY[16], inU[4], inV[4];
 #pragma unroll
             for (int y = 0; y < 16; y++) inY[y] = *(g_cu32x4p)(tp + 16 * y);
@@ -430,7 +444,8 @@ vp8_loopfilter_simt_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g
 #pragma unroll
                 for (int y = 0; y < 16; y++) {
                     const u32 s = TL[(4 + y) * 5 * 64];
-                    if (y < 8 || write_bottom) *(g_u32x4p)(tp - VP8_TILE_BYTES + 16 * y) = (u32x4){ pbY[y][0], pbY[y][1], pbY[y][2], s };
+                    if (y < 8) *(g_u32x4p)(o_left_lo + ysY * y) = (u32x4){ pbY[y][0], pbY[y][1], pbY[y][2], s };
+                    else if (write_bottom) *(g_u32x4p)(o_left_hi + ybY * (y - 8)) = (u32x4){ pbY[y][0], pbY[y][1], pbY[y][2], s };
                     if (y >= 8) hY[y - 8][3] = s;
                 }
             }
@@ -438,11 +453,11 @@ vp8_loopfilter_simt_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g
             if (r > 0) {
 #pragma unroll
                 for (int y = 0; y < 5; y++)
-                    *(g_u32x4p)(tp - rowbytes + 128 + 16 * y) = (u32x4){ tY[y][0], tY[y][1], tY[y][2], tY[y][3] };
+                    *(g_u32x4p)(o_above + ysY * y) = (u32x4){ tY[y][0], tY[y][1], tY[y][2], tY[y][3] };
 #pragma unroll
                 for (int j = 1; j < 4; j++) {
                     const u32 *row = TL + j * 5 * 64;
-                    *(g_u32x4p)(tp - rowbytes + 128 + 16 * (4 + j)) = (u32x4){ row[64], row[128], row[192], row[256] };
+                    *(g_u32x4p)(o_above + ysY * (4 + j)) = (u32x4){ row[64], row[128], row[192], row[256] };
                 }
             }
             // ---- this macroblock: hold it, or finish it at the end of the row
@@ -451,12 +466,16 @@ vp8_loopfilter_simt_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g
                 const u32 *row = TL + (4 + y) * 5 * 64;
                 const u32 d0 = row[64], d1 = row[128], d2 = row[192], d3 = row[256];
                 pbY[y][0] = d0; pbY[y][1] = d1; pbY[y][2] = d2; sY[y] = d3;
-                if (last_col && (y < 8 || write_bottom)) *(g_u32x4p)(tp + 16 * y) = (u32x4){ d0, d1, d2, d3 };
+                if (last_col && y < 8) *(g_u32x4p)(o_own_lo + ysY * y) = (u32x4){ d0, d1, d2, d3 };
+                if (last_col && y >= 8 && write_bottom) *(g_u32x4p)(o_own_hi + ybY * (y - 8)) = (u32x4){ d0, d1, d2, d3 };
             }
             // =============================== chroma ===============================
 #pragma unroll
             for (int pl = 0; pl < 2; pl++) {
                 g_u8p tc = tp + (pl ? 320 : 256);
+                g_u8p rasC = pl ? rasV : rasU;
+                g_u8p oc_left = ras_bottom ? rasC + (c - 1) * 8 : tc - VP8_TILE_BYTES, oc_own = ras_bottom ? rasC + c * 8 : tc;
+                g_u8p oc_above = ras ? rasC - 8 * g.uv_stride + c * 8 : tc - rowbytes;
                 u32 (&pb)[8] = pl ? pbV : pbU;
                 u32 (&sC)[8] = pl ? sV : sU;
                 u32 (&tC)[8][2] = pl ? tV : tU;
@@ -478,17 +497,17 @@ vp8_loopfilter_simt_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g
 #pragma unroll
                     for (int y = 0; y < 8; y++) {
                         const u32 s = TL[(4 + y) * 3 * 64];
-                        if (write_bottom) *(g_u32x2p)(tc - VP8_TILE_BYTES + 8 * y) = (u32x2){ pb[y], s };
+                        if (write_bottom) *(g_u32x2p)(oc_left + ybC * y) = (u32x2){ pb[y], s };
                         hC[y][1] = s;
                     }
                 }
                 if (r > 0) {
 #pragma unroll
-                    for (int y = 0; y < 5; y++) *(g_u32x2p)(tc - rowbytes + 8 * y) = (u32x2){ tC[y][0], tC[y][1] };
+                    for (int y = 0; y < 5; y++) *(g_u32x2p)(oc_above + ysC * y) = (u32x2){ tC[y][0], tC[y][1] };
 #pragma unroll
                     for (int j = 1; j < 4; j++) {
                         const u32 *row = TL + j * 3 * 64;
-                        *(g_u32x2p)(tc - rowbytes + 8 * (4 + j)) = (u32x2){ row[64], row[128] };
+                        *(g_u32x2p)(oc_above + ysC * (4 + j)) = (u32x2){ row[64], row[128] };
                     }
                 }
 #pragma unroll
@@ -496,7 +515,7 @@ vp8_loopfilter_simt_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g
                     const u32 *row = TL + (4 + y) * 3 * 64;
                     const u32 d0 = row[64], d1 = row[128];
                     pb[y] = d0; sC[y] = d1;
-                    if (last_col && write_bottom) *(g_u32x2p)(tc + 8 * y) = (u32x2){ d0, d1 };
+                    if (last_col && write_bottom) *(g_u32x2p)(oc_own + ybC * y) = (u32x2){ d0, d1 };
                 }
             }
             }

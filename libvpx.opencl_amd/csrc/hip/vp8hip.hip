@@ -20,7 +20,7 @@ extern "C" __global__ void vp8_recon_xcu_kernel(const DevJob *jobs, int njobs, D
 extern "C" __global__ void vp8_loopfilter_xcu_kernel(const DevJob *jobs, int njobs, DevGeom g, unsigned long long *gran,
                                                      unsigned int epoch, int S, int *err);
 extern "C" __global__ void vp8_recon_simt_kernel(const DevJob *jobs, int njobs, DevGeom g, int lgG, int P, int nstrands, int tiled);
-extern "C" __global__ void vp8_loopfilter_simt_kernel(const DevJob *jobs, int njobs, DevGeom g, int lgG, int P, int nstrands);
+extern "C" __global__ void vp8_loopfilter_simt_kernel(const DevJob *jobs, int njobs, DevGeom g, int lgG, int P, int nstrands, int raster);
 extern "C" __global__ void vp8_loopfilter_kernel(const DevJob *jobs, int njobs, DevGeom g);
 extern "C" __global__ void vp8_extend_kernel(const DevJob *jobs, int njobs, DevGeom g);
 extern "C" __global__ void vp8_detile_kernel(const DevJob *jobs, int njobs, DevGeom g, int extend);
@@ -402,11 +402,19 @@ extern "C" int vp8hip_decode(vp8hip_ctx *c, const vp8hip_job *jobs, int njobs, i
         simt_recon = (stages & VP8HIP_STAGE_RECON) && (!strcmp(e, "simt") ? true : (!strcmp(e, "wave") ? false : simt_recon));
     // the lane-per-row kernels work on macroblock-tiled scratch frames; vp8_detile_kernel converts at the end
     const bool tiled = simt_recon;
+    // Optional (VP8HIP_LF_RASTER=1): when every frame of a lane-per-row launch is filtered, the loop filter can write its
+    // finished lines straight into the raster frame buffers -- no tiled -> raster pass, only the border extension is
+    // left.  Its 16-byte row pieces cost the loop filter 6-7 ms per 8192 1080p frames, about what the overlapped
+    // tiled -> raster pass costs: +2-3 % at 8192 frames per launch, -1 .. -4 % at 1024 .. 4096.  Off by default.
+    bool lf_raster = tiled && (stages & VP8HIP_STAGE_LF) && getenv("VP8HIP_LF_RASTER") && atoi(getenv("VP8HIP_LF_RASTER"));
+    for (int i = 0; i < njobs && lf_raster; i++)
+        if (jobs[i].ir_slot >= 0 && jobs[i].ir_slot < nsl) lf_raster = c->slots[jobs[i].ir_slot].hdr_copy.filter_level != 0;
     const size_t tile_frame = (size_t)c->nmb * VP8_TILE_BYTES;
     const int par = c->parity;
-    if (!tiled) {
+    if (!tiled || lf_raster) {
         if (join_detile(c)) return -1;             // this launch touches the raster frame buffers directly
-    } else {
+    }
+    if (tiled) {
         // scratch set and job table `par` were last read by the tiled -> raster pass VP8HIP_NBUF launches ago (three
         // sets: that pass, launched beside the previous launch's loop filter, may still be finishing)
         if (c->detile_used[par]) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_detile_done[par], 0));
@@ -553,7 +561,7 @@ extern "C" int vp8hip_decode(vp8hip_ctx *c, const vp8hip_job *jobs, int njobs, i
     if ((stages & VP8HIP_STAGE_LF) && any_lf) {
         if (tiled) {
             hipLaunchKernelGGL(vp8_loopfilter_simt_kernel, dim3(simt_waves), dim3(64), 0, c->stream, (const DevJob *)c->d_jobs,
-                               njobs, c->dg, lgG, simtP, simt_waves * spw);
+                               njobs, c->dg, lgG, simtP, simt_waves * spw, lf_raster ? 1 : 0);
         } else {
             const int npairs = (njobs + 1) / 2;          // the loop filter works on two frames per wave
             if (xcu_S > 1) {
@@ -568,7 +576,20 @@ extern "C" int vp8hip_decode(vp8hip_ctx *c, const vp8hip_job *jobs, int njobs, i
         HIPCHK(c, hipGetLastError());
     }
     HIPCHK(c, hipEventRecord(ev[2], c->stream));
-    if (tiled) {      // whatever stages ran, the frame buffer gets the result; borders are extended on the way
+    if (lf_raster) {
+        if (stages & VP8HIP_STAGE_EXTEND) {
+            // on the main stream: 1.8 ms per 8192 1080p frames; beside the next launch's recon (second stream) it
+            // stretched both by more than it takes alone
+            int bx = (c->geom.aligned_h + 64) / 4;
+            if (bx < 1) bx = 1;
+            if (bx > 64) bx = 64;
+            HIPCHK(c, hipEventRecord(ev[4], c->stream));
+            hipLaunchKernelGGL(vp8_extend_kernel, dim3(bx, njobs), dim3(256), 0, c->stream, (const DevJob *)c->d_jobs, njobs, c->dg);
+            HIPCHK(c, hipGetLastError());
+            HIPCHK(c, hipEventRecord(ev[5], c->stream));
+        }
+        c->parity = (par + 1) % VP8HIP_NBUF;
+    } else if (tiled) {      // whatever stages ran, the frame buffer gets the result; borders are extended on the way
         const bool own_stream = !(getenv("VP8HIP_DETILE_STREAM") && !atoi(getenv("VP8HIP_DETILE_STREAM")));
         if (own_stream && !c->stream2) HIPCHK(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
         // deferred by default: the pass is launched with the NEXT lane-per-row launch, right after its recon, so
@@ -600,7 +621,7 @@ extern "C" int vp8hip_decode(vp8hip_ctx *c, const vp8hip_job *jobs, int njobs, i
         HIPCHK(c, hipGetLastError());
     }
     HIPCHK(c, hipEventRecord(ev[3], c->stream));
-    c->evr_tiled[c->ncalls % VP8HIP_STATS_RING] = tiled;
+    c->evr_tiled[c->ncalls % VP8HIP_STATS_RING] = tiled && (!lf_raster || (stages & VP8HIP_STAGE_EXTEND));
     c->evr_stats[c->ncalls % VP8HIP_STATS_RING] = c->stats;
     c->ncalls++;
     return 0;

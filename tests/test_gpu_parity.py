@@ -20,14 +20,18 @@ def ctx(pkg):
     c.close()
 
 
-@pytest.fixture(params=["wave", "wave1cu", "lane"], autouse=True)
+@pytest.fixture(params=["wave", "wave1cu", "lane", "lane_raster"], autouse=True)
 def kernel_family(request, monkeypatch):
     """Every test runs with all kernel variants: "wave" = one wave per MB row with a frame pair spread over several
     CUs where the launch is small enough (granule hand-over through global memory), "wave1cu" = the same kernels with
     a frame pair on one CU (hand-over through LDS; what larger launches use), "lane" = one MB row per lane on
     macroblock-tiled scratch frames + detile (large launches).  VP8HIP_RECON / VP8HIP_XCU are the library's tuning
     knobs that override the automatic choice (libvpx.opencl_amd/csrc/hip/vp8hip.hip)."""
-    monkeypatch.setenv("VP8HIP_RECON", "simt" if request.param == "lane" else "wave")
+    monkeypatch.setenv("VP8HIP_RECON", "simt" if request.param.startswith("lane") else "wave")
+    if request.param == "lane_raster":      # the lane-per-row loop filter writing raster frame buffers itself (opt-in)
+        monkeypatch.setenv("VP8HIP_LF_RASTER", "1")
+    else:
+        monkeypatch.delenv("VP8HIP_LF_RASTER", raising=False)
     if request.param == "wave1cu":
         monkeypatch.setenv("VP8HIP_XCU", "0")
     else:
@@ -163,7 +167,7 @@ def test_full_size_1080p_batch_properties(pkg, ctx):
 def test_automatic_kernel_choice(pkg, ctx, kernel_family, monkeypatch):
     """Without the override a launch of more than 2 key frames per CU takes the lane-per-row kernels, a smaller one the
     wave-per-row kernels; both sides of the threshold produce the reference's frames."""
-    if kernel_family == "lane":
+    if kernel_family != "wave":
         pytest.skip("one run is enough")
     monkeypatch.delenv("VP8HIP_RECON")
     for nframes in (40, 1100):
@@ -220,7 +224,7 @@ def test_back_to_back_launches_and_stats_ring(pkg, ctx, kernel_family):
     for back in range(3):
         st = ctx.stats(back)
         assert st.recon_ms > 0 and st.extend_ms > 0
-        assert st.recon_waves == (1 if kernel_family == "lane" else st.recon_waves)
+        assert st.recon_waves == (1 if kernel_family.startswith("lane") else st.recon_waves)
     ctx.join()
     ctx.sync()
 
