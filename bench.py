@@ -43,15 +43,12 @@ HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 # HBM traffic per macroblock of the lane-per-row kernels (1080p key frames, G = 8 as at the default launch size), from
 # `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, KiB; FETCH_SIZE doubled: the gfx950 correction
 # for 16-byte-per-lane loads, which the detile pass confirms -- it reads exactly 384 B/MB) over tools/pmc_one.py 7 1024
-# with VP8HIP_SIMT_LGG=3: profiles/r01_g_pmc_*_1024frames_G8.csv.  The counter passes crash or hang at 8192 frames per
+# with VP8HIP_SIMT_LGG=3: profiles/r01_*_pmc_*_1024frames_G8*.csv.  The counter passes crash or hang at 8192 frames per
 # launch and under torch, so bench.py scales these per-macroblock figures instead of counting live.
-PMC_TRAFFIC_B_PER_MB = {"recon": 2 * 448.68 + 385.22, "loopfilter": 2 * 239.63 + 414.12, "extend": 2 * 192.08 + 466.87}
-
-WORKLOADS = {
-    "1080p": ("kf_1920x1080", 1920, 1080),
-    "4k": ("kf_3840x2160", 3840, 2160),
-}
-
+PMC_TRAFFIC_B_PER_MB = {        # the loop filter writes the raster frame buffers, then vp8_extend_kernel (default)
+    "recon": 2 * 447.7 + 384.0, "loopfilter": 2 * 242.2 + 634.4, "extend": 2 * 27.5 + 40.4}
+PMC_TRAFFIC_B_PER_MB_DETILE = { # tiled -> raster pass (vp8_detile_kernel) after the loop filter
+    "recon": 2 * 448.68 + 385.22, "loopfilter": 2 * 239.63 + 414.12, "extend": 2 * 192.08 + 466.87}
 
 def cpu_baseline(fixture, budget_s=12.0):
     """Time the reference decoder (or the port) on this host, single thread."""
@@ -285,11 +282,12 @@ def main():
         K = args.steps
         total_pix = world * F * K * W * H
         lane = st.recon_waves == 1            # the lane-per-row kernels ran (see vp8hip_stats)
+        detile = bool(st.detile_pass)         # ... finished by the tiled -> raster pass instead of the loop filter's own raster output
         ms = {"recon": k_recon / KS, "loopfilter": k_lf / KS, "extend": k_ext / KS}
         bytes_per_launch = {"recon": B_RECON * nmb * F, "loopfilter": B_LF * nmb * F,
-                            "extend": (B_DETILE if lane else B_EXTEND) * nmb * F}
+                            "extend": (B_DETILE if detile else B_EXTEND) * nmb * F}
         names = ({"recon": "vp8_recon_simt_kernel", "loopfilter": "vp8_loopfilter_simt_kernel",
-                  "extend": "vp8_detile_kernel (tiled -> raster + border extension)"} if lane else
+                  "extend": "vp8_detile_kernel (tiled -> raster + border extension)" if detile else "vp8_extend_kernel"} if lane else
                  {"recon": "vp8_recon_kernel", "loopfilter": "vp8_loopfilter_kernel", "extend": "vp8_extend_kernel"})
         ms_alone = {"recon": alone[0], "loopfilter": alone[1], "extend": alone[2]}
         dom = max(ms_alone, key=lambda k: ms_alone[k])
@@ -298,6 +296,7 @@ def main():
         # SURVEY.md 8(d)'s own figure for the full key-frame path: 1217 + 770 + 36 = 2023 B/MB -- without the bytes of the
         # tiled -> raster pass, which is this implementation's extra pass, not part of the algorithm
         survey_gbps = (B_RECON + B_LF + B_EXTEND) * nmb * F / (elapsed / K) / 1e9
+        pmc = PMC_TRAFFIC_B_PER_MB_DETILE if detile else PMC_TRAFFIC_B_PER_MB
         out = {
             "metric": "vp8_decode_pixel_path_mpix_per_s",
             "value": round(total_pix / elapsed / 1e6, 1),
@@ -335,11 +334,11 @@ def main():
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 5),
-                "traffic": round(PMC_TRAFFIC_B_PER_MB[dom] * nmb * F) if lane and args.workload == "1080p" else None,
+                "traffic": round(pmc[dom] * nmb * F) if lane and args.workload == "1080p" else None,
                 "traffic_note": "HBM bytes per launch = per-macroblock FETCH_SIZE x2 + WRITE_SIZE of the same kernel measured "
                                 "with rocprofv3 --pmc at 1024 frames per launch (profiles/r01_g_pmc_*.csv) x macroblocks "
                                 "per launch; null for configurations that were not counted",
-                "traffic_bytes_per_macroblock": ({k: round(v, 1) for k, v in PMC_TRAFFIC_B_PER_MB.items()}
+                "traffic_bytes_per_macroblock": ({k: round(v, 1) for k, v in pmc.items()}
                                                  if lane and args.workload == "1080p" else None),
                 "algorithmic_bytes_per_launch": bytes_per_launch[dom],
                 "mean_launch_ms": round(ms[dom], 4),

@@ -325,6 +325,10 @@ vp8_loopfilter_simt_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g
     u32 pbY[16][3], sY[16], pbU[8], sU[8], pbV[8], sV[8];
     // what the lane below asks for: luma rows 8..15 and the chroma rows of the macroblock finished two steps ago
     u32 hY[8][4], hU[8][2], hV[8][2];
+    // raster output: rows of an even macroblock wait one step for their right-hand neighbour, so that a frame row is
+    // written in 32-byte pieces (two 16-byte stores back to back) instead of 16-byte ones a step apart
+    u32x4 holdA[8], holdB[8];
+    u32x2 holdU[8], holdV[8];
 #pragma unroll
     for (int y = 0; y < 16; y++) { pbY[y][0] = pbY[y][1] = pbY[y][2] = sY[y] = 0; }
 #pragma unroll
@@ -444,20 +448,29 @@ vp8_loopfilter_simt_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g
 #pragma unroll
                 for (int y = 0; y < 16; y++) {
                     const u32 s = TL[(4 + y) * 5 * 64];
-                    if (y < 8) *(g_u32x4p)(o_left_lo + ysY * y) = (u32x4){ pbY[y][0], pbY[y][1], pbY[y][2], s };
+                    if (y < 8) {
+                        const u32x4 v = { pbY[y][0], pbY[y][1], pbY[y][2], s };
+                        if (!ras) *(g_u32x4p)(o_left_lo + ysY * y) = v;
+                        else if ((c - 1) & 1) { *(g_u32x4p)(o_left_lo + ysY * y - 16) = holdA[y]; *(g_u32x4p)(o_left_lo + ysY * y) = v; }
+                        else holdA[y] = v;
+                    }
                     else if (write_bottom) *(g_u32x4p)(o_left_hi + ybY * (y - 8)) = (u32x4){ pbY[y][0], pbY[y][1], pbY[y][2], s };
                     if (y >= 8) hY[y - 8][3] = s;
                 }
             }
             // ---- line 1 of the macroblock above: rows 8..12 as received, rows 13..15 filtered
             if (r > 0) {
+                const bool pair_hold = ras && !(c & 1) && !last_col, pair_flush = ras && (c & 1);
 #pragma unroll
-                for (int y = 0; y < 5; y++)
-                    *(g_u32x4p)(o_above + ysY * y) = (u32x4){ tY[y][0], tY[y][1], tY[y][2], tY[y][3] };
-#pragma unroll
-                for (int j = 1; j < 4; j++) {
-                    const u32 *row = TL + j * 5 * 64;
-                    *(g_u32x4p)(o_above + ysY * (4 + j)) = (u32x4){ row[64], row[128], row[192], row[256] };
+                for (int y = 0; y < 8; y++) {
+                    u32x4 v;
+                    if (y < 5) v = (u32x4){ tY[y][0], tY[y][1], tY[y][2], tY[y][3] };
+                    else { const u32 *row = TL + (y - 4) * 5 * 64; v = (u32x4){ row[64], row[128], row[192], row[256] }; }
+                    if (pair_hold) holdB[y] = v;
+                    else {
+                        if (pair_flush) *(g_u32x4p)(o_above + ysY * y - 16) = holdB[y];
+                        *(g_u32x4p)(o_above + ysY * y) = v;
+                    }
                 }
             }
             // ---- this macroblock: hold it, or finish it at the end of the row
@@ -466,7 +479,10 @@ vp8_loopfilter_simt_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g
                 const u32 *row = TL + (4 + y) * 5 * 64;
                 const u32 d0 = row[64], d1 = row[128], d2 = row[192], d3 = row[256];
                 pbY[y][0] = d0; pbY[y][1] = d1; pbY[y][2] = d2; sY[y] = d3;
-                if (last_col && y < 8) *(g_u32x4p)(o_own_lo + ysY * y) = (u32x4){ d0, d1, d2, d3 };
+                if (last_col && y < 8) {
+                    if (ras && (c & 1)) *(g_u32x4p)(o_own_lo + ysY * y - 16) = holdA[y];      // its even left neighbour was waiting
+                    *(g_u32x4p)(o_own_lo + ysY * y) = (u32x4){ d0, d1, d2, d3 };
+                }
                 if (last_col && y >= 8 && write_bottom) *(g_u32x4p)(o_own_hi + ybY * (y - 8)) = (u32x4){ d0, d1, d2, d3 };
             }
             // =============================== chroma ===============================
@@ -502,12 +518,18 @@ vp8_loopfilter_simt_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g
                     }
                 }
                 if (r > 0) {
+                    const bool pair_hold = ras && !(c & 1) && !last_col, pair_flush = ras && (c & 1);
+                    u32x2 (&hold)[8] = pl ? holdV : holdU;
 #pragma unroll
-                    for (int y = 0; y < 5; y++) *(g_u32x2p)(oc_above + ysC * y) = (u32x2){ tC[y][0], tC[y][1] };
-#pragma unroll
-                    for (int j = 1; j < 4; j++) {
-                        const u32 *row = TL + j * 3 * 64;
-                        *(g_u32x2p)(oc_above + ysC * (4 + j)) = (u32x2){ row[64], row[128] };
+                    for (int y = 0; y < 8; y++) {
+                        u32x2 v;
+                        if (y < 5) v = (u32x2){ tC[y][0], tC[y][1] };
+                        else { const u32 *row = TL + (y - 4) * 3 * 64; v = (u32x2){ row[64], row[128] }; }
+                        if (pair_hold) hold[y] = v;
+                        else {
+                            if (pair_flush) *(g_u32x2p)(oc_above + ysC * y - 8) = hold[y];
+                            *(g_u32x2p)(oc_above + ysC * y) = v;
+                        }
                     }
                 }
 #pragma unroll

@@ -402,11 +402,11 @@ extern "C" int vp8hip_decode(vp8hip_ctx *c, const vp8hip_job *jobs, int njobs, i
         simt_recon = (stages & VP8HIP_STAGE_RECON) && (!strcmp(e, "simt") ? true : (!strcmp(e, "wave") ? false : simt_recon));
     // the lane-per-row kernels work on macroblock-tiled scratch frames; vp8_detile_kernel converts at the end
     const bool tiled = simt_recon;
-    // Optional (VP8HIP_LF_RASTER=1): when every frame of a lane-per-row launch is filtered, the loop filter can write its
-    // finished lines straight into the raster frame buffers -- no tiled -> raster pass, only the border extension is
-    // left.  Its 16-byte row pieces cost the loop filter 6-7 ms per 8192 1080p frames, about what the overlapped
-    // tiled -> raster pass costs: +2-3 % at 8192 frames per launch, -1 .. -4 % at 1024 .. 4096.  Off by default.
-    bool lf_raster = tiled && (stages & VP8HIP_STAGE_LF) && getenv("VP8HIP_LF_RASTER") && atoi(getenv("VP8HIP_LF_RASTER"));
+    // When every frame of a lane-per-row launch is filtered, the loop filter writes its finished lines straight into the
+    // raster frame buffers (rows of two neighbouring macroblocks back to back: 32-byte pieces) and the tiled -> raster
+    // pass is skipped; only the border extension is left.  +6..10 % from 1536 frames per launch up (1080p), a tie at 2048,
+    // -4 % at 1024.  VP8HIP_LF_RASTER=0 keeps the tiled -> raster pass.
+    bool lf_raster = tiled && (stages & VP8HIP_STAGE_LF) && !(getenv("VP8HIP_LF_RASTER") && !atoi(getenv("VP8HIP_LF_RASTER")));
     for (int i = 0; i < njobs && lf_raster; i++)
         if (jobs[i].ir_slot >= 0 && jobs[i].ir_slot < nsl) lf_raster = c->slots[jobs[i].ir_slot].hdr_copy.filter_level != 0;
     const size_t tile_frame = (size_t)c->nmb * VP8_TILE_BYTES;
@@ -536,6 +536,7 @@ extern "C" int vp8hip_decode(vp8hip_ctx *c, const vp8hip_job *jobs, int njobs, i
         if (simt_waves > maxw) simt_waves = maxw;
     }
     if (tiled) { c->stats.workgroups = simt_waves; c->stats.recon_waves = 1; c->stats.lf_waves = 1; }
+    c->stats.detile_pass = tiled && !lf_raster;
     if (stages & VP8HIP_STAGE_RECON) {
         if (simt_recon) {
             hipLaunchKernelGGL(vp8_recon_simt_kernel, dim3(simt_waves), dim3(64), 0, c->stream, (const DevJob *)c->d_jobs, njobs,
