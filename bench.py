@@ -50,6 +50,12 @@ PMC_TRAFFIC_B_PER_MB = {        # the loop filter writes the raster frame buffer
 PMC_TRAFFIC_B_PER_MB_DETILE = { # tiled -> raster pass (vp8_detile_kernel) after the loop filter
     "recon": 2 * 448.68 + 385.22, "loopfilter": 2 * 239.63 + 414.12, "extend": 2 * 192.08 + 466.87}
 
+WORKLOADS = {
+    "1080p": ("kf_1920x1080", 1920, 1080),
+    "4k": ("kf_3840x2160", 3840, 2160),
+}
+
+
 def cpu_baseline(fixture, budget_s=12.0):
     """Time the reference decoder (or the port) on this host, single thread."""
     ivf = os.path.join(ROOT, "tests", "golden", fixture + ".ivf")
