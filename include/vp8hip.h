@@ -60,8 +60,8 @@ typedef struct vp8hip_stats {      /* filled by vp8hip_get_stats; times from HIP
     int   recon_waves, lf_waves;        /* waves per workgroup (1 = the lane-per-row kernels ran, 4 = the cross-CU
                                            variant of the wave-per-row kernels: small launches) */
     int   workgroups;
-    int   detile_pass;                  /* 1: a tiled -> raster pass finished the launch (lane-per-row kernels with an
-                                           unfiltered frame in the launch, or VP8HIP_LF_RASTER=0); extend_ms covers it */
+    int   detile_pass;                  /* 1: a tiled -> raster pass finished the launch (lane-per-row kernels with no
+                                           filtered frame in the launch, or VP8HIP_LF_RASTER=0); extend_ms covers it */
 } vp8hip_stats;
 
 /* device < 0: use the current HIP device.  Returns 0 or a negative error. */

@@ -376,14 +376,14 @@ vp8_loopfilter_simt_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g
                 rasU = (g_u8p)(job->dst + g.u_off + (long)r * 8 * g.uv_stride);
                 rasV = (g_u8p)(job->dst + g.v_off + (long)r * 8 * g.uv_stride);
             }
-            if (lf_on) {
+            if (lf_on || raster) {      // raster output: an unfiltered frame is still carried from the scratch to its frame buffer
             const vp8ir_frame_hdr &h = job->hdr;
             const u32 w0 = mbp[0], w1 = mbp[1];
             const int y_mode = w0 & 0xff, ref_frame = (w0 >> 16) & 0xff;
             const u32 flags = w0 >> 24;
             const int level = mb_level(h, w1 & 3, ref_frame & 3, y_mode);
             const Lim L = mb_limits(h.sharpness_level, level, h.frame_type, one);
-            const bool on = level != 0;
+            const bool on = lf_on && level != 0;
             const bool skip_lf = y_mode != VP8IR_B_PRED && y_mode != VP8IR_SPLITMV && (flags & VP8IR_MB_SKIP);
             const bool mbv = on && c > 0, inner = on && !skip_lf, mbh = on && r > 0;
 #ifdef VP8_LF_NOFILTER    // measurement aid: data movement only

@@ -402,13 +402,14 @@ extern "C" int vp8hip_decode(vp8hip_ctx *c, const vp8hip_job *jobs, int njobs, i
         simt_recon = (stages & VP8HIP_STAGE_RECON) && (!strcmp(e, "simt") ? true : (!strcmp(e, "wave") ? false : simt_recon));
     // the lane-per-row kernels work on macroblock-tiled scratch frames; vp8_detile_kernel converts at the end
     const bool tiled = simt_recon;
-    // When every frame of a lane-per-row launch is filtered, the loop filter writes its finished lines straight into the
-    // raster frame buffers (rows of two neighbouring macroblocks back to back: 32-byte pieces) and the tiled -> raster
+    // When the loop filter runs at all (some frame of the launch has filter_level != 0), it writes its finished lines
+    // straight into the raster frame buffers -- unfiltered frames are carried through with the filter gated off -- (rows of two neighbouring macroblocks back to back: 32-byte pieces) and the tiled -> raster
     // pass is skipped; only the border extension is left.  +6..10 % from 1536 frames per launch up (1080p), a tie at 2048,
     // -4 % at 1024.  VP8HIP_LF_RASTER=0 keeps the tiled -> raster pass.
-    bool lf_raster = tiled && (stages & VP8HIP_STAGE_LF) && !(getenv("VP8HIP_LF_RASTER") && !atoi(getenv("VP8HIP_LF_RASTER")));
-    for (int i = 0; i < njobs && lf_raster; i++)
-        if (jobs[i].ir_slot >= 0 && jobs[i].ir_slot < nsl) lf_raster = c->slots[jobs[i].ir_slot].hdr_copy.filter_level != 0;
+    bool lf_raster = false;
+    if (tiled && (stages & VP8HIP_STAGE_LF) && !(getenv("VP8HIP_LF_RASTER") && !atoi(getenv("VP8HIP_LF_RASTER"))))
+        for (int i = 0; i < njobs && !lf_raster; i++)     // some frame is filtered: the loop filter kernel runs anyway
+            if (jobs[i].ir_slot >= 0 && jobs[i].ir_slot < nsl) lf_raster = c->slots[jobs[i].ir_slot].hdr_copy.filter_level != 0;
     const size_t tile_frame = (size_t)c->nmb * VP8_TILE_BYTES;
     const int par = c->parity;
     if (!tiled || lf_raster) {
