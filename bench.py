@@ -369,7 +369,7 @@ def main():
                 out["config"]["end_to_end"] = e2e.run(P, local_rank, fixture=fixture)
             except Exception as ex:      # a probe, not the benchmark: report, do not fail the line
                 out["config"]["end_to_end"] = {"error": repr(ex)}
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # the contract: rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(fixture)
         print(json.dumps(out))
     else:
