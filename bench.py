@@ -360,7 +360,10 @@ def main():
         }
         ctx.close()
         if world == 1 and args.workload == "1080p" and not args.no_inter_probe:
-            out["config"]["inter_frames"] = inter_frame_probe(P, local_rank)
+            try:
+                out["config"]["inter_frames"] = inter_frame_probe(P, local_rank)
+            except Exception as ex:      # a probe, not the benchmark: report, do not fail the line
+                out["config"]["inter_frames"] = {"error": repr(ex)}
         if world == 1 and args.workload == "1080p" and not args.no_end_to_end:
             # host-inclusive rate (never `value`): compressed frames in host memory -> per-frame MD5, tools/e2e.py
             try:
