@@ -624,37 +624,52 @@ __device__ __forceinline__ void recon_body(const DevJob *__restrict__ jobs, int 
                     const u32 bm0 = half_sel(mbw, 10), bm1 = half_sel(mbw, 11), bm2 = half_sel(mbw, 12), bm3 = half_sel(mbw, 13);
                     wave_lds_sync();
                     const int pr = (hl >> 2) & 3, pc = hl & 3;
-#pragma unroll
-                    for (int by = 0; by < 4; ++by) {
-                        // residuals and gather entries of this block row: independent of the prediction chain
+                    // Block (bx, by) needs its left, above and above-right neighbours: all blocks with the same
+                    // bx + 2*by are independent.  Ten diagonals instead of sixteen blocks in a row: lanes 0..15 take
+                    // the diagonal's lower block, lanes 16..31 the upper one (bx + 2, by - 1), where there is one.
+                    const int grp = (hl >> 4) & 1;
+                    // residual and gather entry of a block: independent of the prediction chain, fetched one diagonal ahead
+                    auto block_of = [&](int d, int &by, int &bx, bool &active) {
+                        const int byA = d >> 1 < 3 ? d >> 1 : 3, bxA = d - 2 * byA;
+                        const bool hasB = byA >= 1 && bxA + 2 <= 3;
+                        by = (grp && hasB) ? byA - 1 : byA; bx = (grp && hasB) ? bxA + 2 : bxA;
+                        active = grp == 0 || hasB;
+                    };
+                    auto mode_of = [&](int by, int bx) -> int {
                         const u32 bmw = by == 0 ? bm0 : (by == 1 ? bm1 : (by == 2 ? bm2 : bm3));
-                        int resb[4];
-                        u32 ent[4];
+                        return (bmw >> (8 * bx)) & 0xff;
+                    };
+                    int res_nx = wl->res[hl & 15];
+                    u32 ent_nx = gtab[mode_of(0, 0) * 16 + (hl & 15)];
 #pragma unroll
-                        for (int bx = 0; bx < 4; ++bx) {
-                            resb[bx] = wl->res[(by * 4 + bx) * 16 + (hl & 15)];
-                            ent[bx] = gtab[((bmw >> (8 * bx)) & 0xff) * 16 + (hl & 15)];
+                    for (int d = 0; d < 10; ++d) {
+                        int by, bx; bool active;
+                        block_of(d, by, bx, active);
+                        const int mode = mode_of(by, bx);
+                        const int res_cur = res_nx;
+                        const u32 ent_cur = ent_nx;
+                        if (d + 1 < 10) {
+                            int by1, bx1; bool a1;
+                            block_of(d + 1, by1, bx1, a1);
+                            res_nx = wl->res[(by1 * 4 + bx1) * 16 + (hl & 15)];
+                            ent_nx = gtab[mode_of(by1, bx1) * 16 + (hl & 15)];
                         }
-#pragma unroll
-                        for (int bx = 0; bx < 4; ++bx) {
-                            const int mode = (bmw >> (8 * bx)) & 0xff;
-                            const unsigned char *org = tY + TY_AT(by * 4, bx * 4) - 64;
-                            int pred;
-                            if (mode == VP8IR_B_DC_PRED) {
-                                const u32 W1 = *(const u32 *)(org + 64 - TY_STRIDE);
-                                pred = (sad4(W1) + org[63] + org[63 + TY_STRIDE] + org[63 + 2 * TY_STRIDE]
-                                        + org[63 + 3 * TY_STRIDE] + 4) >> 3;
-                            } else {
-                                const u32 e = ent[bx];
-                                const int p0 = org[e & 0xff], p1 = org[(e >> 8) & 0xff], p2 = org[(e >> 16) & 0xff];
-                                const int kind = e >> 24;
-                                const int t3 = (p0 + 2 * p1 + p2 + 2) >> 2, t2 = (p1 + p2 + 1) >> 1, tm = clamp255(p0 + p1 - p2);
-                                pred = kind == 2 ? t3 : (kind == 1 ? t2 : (kind == 0 ? p1 : tm));
-                            }
-                            const int v = clamp255(pred + resb[bx]);
-                            if (hl < 16) tY[TY_AT(by * 4 + pr, bx * 4 + pc)] = (unsigned char)v;
-                            wave_lds_sync();
+                        const unsigned char *org = tY + TY_AT(by * 4, bx * 4) - 64;
+                        int pred;
+                        if (mode == VP8IR_B_DC_PRED) {
+                            const u32 W1 = *(const u32 *)(org + 64 - TY_STRIDE);
+                            pred = (sad4(W1) + org[63] + org[63 + TY_STRIDE] + org[63 + 2 * TY_STRIDE]
+                                    + org[63 + 3 * TY_STRIDE] + 4) >> 3;
+                        } else {
+                            const u32 e = ent_cur;
+                            const int p0 = org[e & 0xff], p1 = org[(e >> 8) & 0xff], p2 = org[(e >> 16) & 0xff];
+                            const int kind = e >> 24;
+                            const int t3 = (p0 + 2 * p1 + p2 + 2) >> 2, t2 = (p1 + p2 + 1) >> 1, tm = clamp255(p0 + p1 - p2);
+                            pred = kind == 2 ? t3 : (kind == 1 ? t2 : (kind == 0 ? p1 : tm));
                         }
+                        const int v = clamp255(pred + res_cur);
+                        if (active) tY[TY_AT(by * 4 + pr, bx * 4 + pc)] = (unsigned char)v;
+                        wave_lds_sync();
                     }
                     outY0 = *(const u32 *)(tY + TY_AT(ly0, lx0));
                     outY1 = *(const u32 *)(tY + TY_AT(ly0 + 8, lx0));
