@@ -514,15 +514,8 @@ __device__ __forceinline__ void recon_body(const DevJob *__restrict__ jobs, int 
             if (!skip) {
                 const short *dq = wl->dq[seg];
                 const int dq_y1dc = dq[0], dq_y1ac = dq[1], dq_y2dc = dq[2], dq_y2ac = dq[3], dq_uvdc = dq[4], dq_uvac = dq[5];
-                int o[4], t[4];
-                {   // chroma blocks
-                    const int f0 = col == 0 ? dq_uvdc : dq_uvac;
-                    idct_col((short)(c4x(q.c) * f0), (short)(c4y(q.c) * dq_uvac), (short)(c4z(q.c) * dq_uvac),
-                             (short)(c4w(q.c) * dq_uvac), o);
-                    quad_transpose16(o[0], o[1], o[2], o[3], lane, t);
-                    idct_row(t, rC);
-                }
                 {   // Y2: vp8_dequantize_b + vp8_short_inv_walsh4x4_c (idctllm.c:140-192); lanes hl < 4
+                    int t[4];
                     const int f0 = col == 0 ? dq_y2dc : dq_y2ac;
                     const int i0 = (short)(c4x(q.y2) * f0), i1 = (short)(c4y(q.y2) * dq_y2ac);
                     const int i2 = (short)(c4z(q.y2) * dq_y2ac), i3 = (short)(c4w(q.y2) * dq_y2ac);
@@ -538,16 +531,27 @@ __device__ __forceinline__ void recon_body(const DevJob *__restrict__ jobs, int 
                     }
                 }
                 wave_lds_sync();
-#pragma unroll
-                for (int p = 0; p < 2; p++) {   // luma blocks 0..7, then 8..15
-                    const coef4 cq = p ? q.y1 : q.y0;
-                    int i0;
-                    if (col == 0) i0 = has_y2 ? (int)wl->wht_dc[p * 8 + (hl >> 2)] : (int)(short)(c4x(cq) * dq_y1dc);
-                    else i0 = (short)(c4x(cq) * dq_y1ac);
-                    idct_col(i0, (short)(c4y(cq) * dq_y1ac), (short)(c4z(cq) * dq_y1ac), (short)(c4w(cq) * dq_y1ac), o);
-                    quad_transpose16(o[0], o[1], o[2], o[3], lane, t);
-                    idct_row(t, p ? rY1 : rY0);
+                // chroma, luma blocks 0..7 and luma blocks 8..15: three independent transforms, written pass by pass so
+                // that their dependent instruction chains interleave (one wave alone pays every instruction's latency)
+                int oC[4], o0[4], o1[4], tC[4], t0[4], t1[4];
+                int iA, iB;
+                if (col == 0) {
+                    iA = has_y2 ? (int)wl->wht_dc[hl >> 2] : (int)(short)(c4x(q.y0) * dq_y1dc);
+                    iB = has_y2 ? (int)wl->wht_dc[8 + (hl >> 2)] : (int)(short)(c4x(q.y1) * dq_y1dc);
+                } else {
+                    iA = (short)(c4x(q.y0) * dq_y1ac);
+                    iB = (short)(c4x(q.y1) * dq_y1ac);
                 }
+                idct_col((short)(c4x(q.c) * (col == 0 ? dq_uvdc : dq_uvac)), (short)(c4y(q.c) * dq_uvac), (short)(c4z(q.c) * dq_uvac),
+                         (short)(c4w(q.c) * dq_uvac), oC);
+                idct_col(iA, (short)(c4y(q.y0) * dq_y1ac), (short)(c4z(q.y0) * dq_y1ac), (short)(c4w(q.y0) * dq_y1ac), o0);
+                idct_col(iB, (short)(c4y(q.y1) * dq_y1ac), (short)(c4z(q.y1) * dq_y1ac), (short)(c4w(q.y1) * dq_y1ac), o1);
+                quad_transpose16(oC[0], oC[1], oC[2], oC[3], lane, tC);
+                quad_transpose16(o0[0], o0[1], o0[2], o0[3], lane, t0);
+                quad_transpose16(o1[0], o1[1], o1[2], o1[3], lane, t1);
+                idct_row(tC, rC);
+                idct_row(t0, rY0);
+                idct_row(t1, rY1);
             }
 
             // ---- wait for the row above to be two MBs ahead (or finished)
