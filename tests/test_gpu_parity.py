@@ -248,3 +248,50 @@ def test_abi_error_paths(pkg, ctx):
         ctx.decode([(0, 0, (-1, -1, -1))], 7)      # inter frame without references
     with pytest.raises(RuntimeError):
         ctx.decode([(0, 1, (1, 1, 1))], 7)         # decoding into its own reference
+
+
+@pytest.mark.parametrize("name,seed", [("p_lowrate_640x360", 1), ("p_split_352x288", 2), ("p_odd_130x98", 3), ("p_prof1_640x360", 4),
+                                       ("p_arf_176x144", 5)])
+def test_damaged_streams_still_match_the_oracle(pkg, ctx, name, seed):
+    """Inter frames with random byte damage behind their frame header: whatever modes, MVs and coefficients the feeder
+    reads out of them (or none: frames it rejects are dropped), the HIP path must neither fault nor hang and must
+    still produce the oracle's frame from the same IR -- arbitrary in-range MVs incl. far-out clamped ones, dense
+    garbage coefficients.  A clean launch afterwards shows the context is healthy."""
+    rng = np.random.default_rng(seed)
+    w, h, frames = pkg.read_ivf(ivf_path(name))
+    parser = pkg.Parser()
+    obufs, ndamaged, ndecoded = None, 0, 0
+    for k, data in enumerate(frames[:24]):
+        if k > 0 and rng.random() < 0.7 and len(data) > 40:
+            bad = bytearray(data)
+            for _ in range(int(rng.integers(1, 9))):
+                bad[int(rng.integers(10, len(bad)))] = int(rng.integers(0, 256))
+            data = bytes(bad)
+            ndamaged += 1
+        try:
+            hdr, changed, mbs, coef, mvs = pkg.parse_to_numpy(parser, data)
+        except ValueError:
+            continue                                    # the feeder rejected the frame (and gave its buffer back)
+        assert (hdr.width, hdr.height) == (w, h)        # bytes 0..9 (frame tag, key-frame size) are never damaged
+        if changed or obufs is None:
+            ctx.configure(hdr.width, hdr.height, 4, 1)
+            g = ctx.g
+            obufs = [np.zeros(g.frame_size, np.uint8) for _ in range(4)]
+        r = parser.refs
+        refs = (r.lst_idx, r.gld_idx, r.alt_idx)
+        for idx in set(refs) - {r.new_idx}:
+            ctx.upload_frame(idx, obufs[idx])
+        ctx.fill_slot(0, hdr, mbs, coef, mvs)
+        o = np.zeros(g.frame_size, np.uint8)
+        oracle_decode(hdr, mbs, coef, mvs, o, tuple(obufs[i] for i in refs), 7)
+        ctx.decode([(0, r.new_idx, refs if hdr.frame_type else None)], 7)
+        d = bordered_area_equal(ctx.download_full(r.new_idx), o, g)
+        assert not d, (name, k, d)
+        obufs[r.new_idx][:] = o
+        parser.swap(hdr)
+        ndecoded += 1
+    parser.close()
+    assert ndamaged >= 5 and ndecoded >= 5
+    gold, nsrc = _batch(pkg, ctx, "kf_odd_67x45", 3)
+    for i in range(3):
+        assert pkg.planes_md5(*ctx.download_planes(i)) == gold[i % nsrc]
