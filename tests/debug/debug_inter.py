@@ -2,7 +2,7 @@
 """Debug aid: one-MB inter frames (pure prediction, no residual) HIP vs oracle."""
 import os, sys
 import numpy as np
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from vp8_testlib import load_package, oracle_decode, synth_ir, random_frame
 P = load_package()
 ctx = P.Vp8Hip(0)

@@ -2,7 +2,7 @@
 """Debug aid: recon stage of the HIP path vs the oracle on one fixture, first mismatching MBs with their modes."""
 import os, sys
 import numpy as np
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from vp8_testlib import load_package, ivf_path, oracle_decode
 
 name = sys.argv[1] if len(sys.argv) > 1 else "kf_odd_67x45"
