@@ -336,7 +336,10 @@ __device__ __forceinline__ void segment_dequant(const vp8ir_frame_hdr &h, int se
 // tiled != 0: the frame goes to the job's macroblock-tiled scratch (DevJob::ref[0], VP8_TILE_BYTES per MB:
 // 16 luma rows of 16 B, 8 U rows of 8 B, 8 V rows of 8 B) instead of the raster frame buffer, so that every
 // lane writes whole 128-byte lines; vp8_detile_kernel converts after the loop filter.
-extern "C" __global__ void __launch_bounds__(64)
+#ifndef VP8_RECON_SIMT_WAVES_PER_SIMD
+#define VP8_RECON_SIMT_WAVES_PER_SIMD 1      // measurement knob: 2 caps the kernel at 256 VGPRs so two waves share a SIMD
+#endif
+extern "C" __global__ void __launch_bounds__(64, VP8_RECON_SIMT_WAVES_PER_SIMD)
 vp8_recon_simt_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g, int lgG, int P, int nstrands, int tiled)
 {
     __shared__ u32 predlds[16 * 64];            // inter prediction of the current group: [block*4+row][lane]
