@@ -11,10 +11,12 @@ struct DevJob {
     const int16_t  *coef;
     const vp8ir_mv *mvs;
     uint8_t        *dst;
-    const uint8_t  *ref[4];
-    // 64 + 8*8 = 128 B
+    const uint8_t  *ref[4];       // [1..3] = last / golden / alt-ref frame buffers (inter frames); [0] unused
+    uint8_t        *tile;         // lane-per-row (key-frame) pipeline: the job's macroblock-tiled scratch frame (VP8_TILE_BYTES per macroblock)
+    uint64_t        rsv[3];
+    // 64 + 8*8 + 4*8 = 160 B
 };
-static_assert(sizeof(DevJob) == 128, "DevJob layout");
+static_assert(sizeof(DevJob) == 160, "DevJob layout");
 
 // Frame geometry common to all jobs of a launch (vp8ir_geom, flattened for kernel args).
 struct DevGeom {
@@ -119,3 +121,23 @@ __constant__ static const unsigned short k_ac_q[128] = {
     119, 122, 125, 128, 131, 134, 137, 140, 143, 146, 149, 152, 155, 158, 161, 164, 167, 170, 173, 177, 181, 185,
     189, 193, 197, 201, 205, 209, 213, 217, 221, 225, 229, 234, 239, 245, 249, 254, 259, 264, 269, 274, 279, 284
 };
+
+// ---- in-kernel stamps (diagnostic builds only: -DVP8_STAMPS; never in the product build) ------------------
+// Where a lane-per-row kernel's step spends its cycles: STAMP(i) adds the shader cycles since the previous stamp
+// to bucket i (wave-uniform, kept in SGPRs); the first wave of the grid adds its buckets to a device array of its
+// own that no kernel reads (MI355X guide, "In-kernel stamps").  Shares only -- the build itself runs slower.
+#ifdef VP8_STAMPS
+#define VP8_NSTAMPS 16
+extern __device__ unsigned long long vp8_stamps_recon[VP8_NSTAMPS], vp8_stamps_lf[VP8_NSTAMPS];
+#define STAMP_DECL unsigned long long st_acc[VP8_NSTAMPS]; unsigned long long st_last; \
+    for (int i_ = 0; i_ < VP8_NSTAMPS; i_++) st_acc[i_] = 0; \
+    { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
+#define STAMP(i) { unsigned long long t_; __builtin_amdgcn_sched_barrier(0); \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); __builtin_amdgcn_sched_barrier(0); \
+    st_acc[i] += t_ - st_last; st_last = t_; }
+#define STAMP_FLUSH(arr) if (blockIdx.x == 0 && threadIdx.x == 0) { for (int i_ = 0; i_ < VP8_NSTAMPS; i_++) atomicAdd(&arr[i_], st_acc[i_]); }
+#else
+#define STAMP_DECL
+#define STAMP(i)
+#define STAMP_FLUSH(arr)
+#endif

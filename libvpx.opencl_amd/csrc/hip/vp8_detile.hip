@@ -24,7 +24,7 @@ vp8_detile_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g, int ext
     const DevJob &job = jobs[blockIdx.y];
     const int r = blockIdx.x, cols = g.mb_cols, rows = g.mb_rows;
     const int t = threadIdx.x;
-    const unsigned char *trow = job.ref[0] + (long)r * cols * VP8_TILE_BYTES;
+    const unsigned char *trow = job.tile + (long)r * cols * VP8_TILE_BYTES;
     unsigned char *dst = job.dst;
     const int tile = t & 7;
     const bool luma = t < 128;

@@ -287,7 +287,7 @@ __device__ __forceinline__ Lim mb_limits(int sharp, int level, int frame_type, v
 } // namespace
 
 // grid = waves (one wave per block); lgG, P, nstrands as in vp8_recon_simt_kernel.  Works in place on the
-// jobs' macroblock-tiled scratch frames (DevJob::ref[0], see VP8_TILE_BYTES): a macroblock is three 128-byte
+// jobs' macroblock-tiled scratch frames (DevJob::tile, see VP8_TILE_BYTES): a macroblock is three 128-byte
 // lines -- luma rows 0..7, luma rows 8..15, U+V -- and every line is written exactly once, whole, by the lane
 // that knows its final content:
 //   line 0 of MB (r,c)    by its own lane, one step later (after MB (r,c+1) revisited its last 4 columns);
@@ -338,8 +338,10 @@ vp8_loopfilter_simt_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g
     }
 
     int c = -2 * pos, V = pos;
+    STAMP_DECL
 #pragma unroll 1
     for (int t = 0; t < T; ++t, ++c) {
+        STAMP(0)
         if (c == P) { c = 0; V += G; }
         // rows 8..15 (luma) / all rows (chroma) of the macroblock above, from the lane above
         u32 tY[8][4], tU[8][2], tV[8][2];
@@ -361,6 +363,7 @@ vp8_loopfilter_simt_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g
             hU[y][0] = pbU[y]; hU[y][1] = sU[y]; hV[y][0] = pbV[y]; hV[y][1] = sV[y];
         }
 
+        STAMP(1)
         const bool act = c >= 0 && c < cols && V < Vmax;
         if (act) {
             if (c == 0) {
@@ -371,7 +374,7 @@ vp8_loopfilter_simt_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g
                 lf_on = h.filter_level != 0;
                 simple = h.filter_type == 1;
                 mbp = (g_cu32p)(job->mbs + (long)r * cols);
-                trow = (g_u8p)(const_cast<uint8_t *>(job->ref[0]) + (long)r * rowbytes);
+                trow = (g_u8p)(job->tile + (long)r * rowbytes);
                 rasY = (g_u8p)(job->dst + g.y_off + (long)r * 16 * g.y_stride);
                 rasU = (g_u8p)(job->dst + g.u_off + (long)r * 8 * g.uv_stride);
                 rasV = (g_u8p)(job->dst + g.v_off + (long)r * 8 * g.uv_stride);
@@ -430,6 +433,7 @@ vp8_loopfilter_simt_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g
                 }
             }
 
+            STAMP(2)
             // =============================== luma ===============================
 #pragma unroll
             for (int y = 0; y < 16; y++) {
@@ -442,7 +446,9 @@ vp8_loopfilter_simt_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g
 #pragma unroll
                 for (int i = 0; i < 4; i++) row[(1 + i) * 64] = tY[4 + j][i];
             }
+            STAMP(3)
             filter_plane<4, 16>(TL, gvY, ghY, L);
+            STAMP(4)
             // ---- the macroblock to the left is final now: its 12 held columns + the 4 just revisited
             if (c > 0) {
 #pragma unroll
@@ -485,6 +491,7 @@ vp8_loopfilter_simt_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g
                 }
                 if (last_col && y >= 8 && write_bottom) *(g_u32x4p)(o_own_hi + ybY * (y - 8)) = (u32x4){ d0, d1, d2, d3 };
             }
+            STAMP(5)
             // =============================== chroma ===============================
 #pragma unroll
             for (int pl = 0; pl < 2; pl++) {
@@ -508,7 +515,9 @@ vp8_loopfilter_simt_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g
                     u32 *row = TL + j * 3 * 64;
                     row[64] = tC[4 + j][0]; row[128] = tC[4 + j][1];
                 }
+                STAMP(6)
                 filter_plane<2, 8>(TL, gvC, ghC, L);
+                STAMP(7)
                 if (c > 0) {
 #pragma unroll
                     for (int y = 0; y < 8; y++) {
@@ -539,9 +548,11 @@ vp8_loopfilter_simt_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g
                     pb[y] = d0; sC[y] = d1;
                     if (last_col && write_bottom) *(g_u32x2p)(oc_own + ybC * y) = (u32x2){ d0, d1 };
                 }
+                STAMP(8)
             }
             }
             mbp += 16;
         }
     }
+    STAMP_FLUSH(vp8_stamps_lf)
 }

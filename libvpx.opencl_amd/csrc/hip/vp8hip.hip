@@ -19,7 +19,7 @@ extern "C" __global__ void vp8_recon_xcu_kernel(const DevJob *jobs, int njobs, D
                                                 int S, int *err);
 extern "C" __global__ void vp8_loopfilter_xcu_kernel(const DevJob *jobs, int njobs, DevGeom g, unsigned long long *gran,
                                                      unsigned int epoch, int S, int *err);
-extern "C" __global__ void vp8_recon_simt_kernel(const DevJob *jobs, int njobs, DevGeom g, int lgG, int P, int nstrands, int tiled);
+extern "C" __global__ void vp8_recon_simt_kernel(const DevJob *jobs, int njobs, DevGeom g, int lgG, int P, int nstrands, uint8_t *dummy);
 extern "C" __global__ void vp8_loopfilter_simt_kernel(const DevJob *jobs, int njobs, DevGeom g, int lgG, int P, int nstrands, int raster);
 extern "C" __global__ void vp8_loopfilter_kernel(const DevJob *jobs, int njobs, DevGeom g);
 extern "C" __global__ void vp8_extend_kernel(const DevJob *jobs, int njobs, DevGeom g);
@@ -36,8 +36,37 @@ struct Slot {
     char *h_block;                 // pinned mirror, allocated on first vp8hip_ir_map
 };
 
+// Tuning / test knobs, read from the environment by vp8hip_configure (never per launch):
+//   VP8HIP_RECON=simt|wave     force one of the two kernel families (simt: key-frame launches only)
+//   VP8HIP_LF_RASTER=0         lane-per-row family: finish with the tiled -> raster pass instead of letting the loop filter write raster
+//   VP8HIP_SIMT_LGG=1..6       lanes per strand (log2); VP8HIP_SIMT_WAVES=n  at most n waves per launch
+//   VP8HIP_WG_PER_CU, VP8HIP_XCU, VP8HIP_XCU_S, VP8HIP_XCU_NW, VP8HIP_RECON_NW, VP8HIP_LF_NW   wave-per-row family shapes
+//   VP8HIP_DETILE_STREAM=0 / VP8HIP_DETILE_DEFER=0   run the tiled -> raster pass on the main stream / at once
+struct Knobs {
+    int recon_force;       // 0 automatic, 1 lane-per-row, 2 wave-per-row
+    int lf_raster, lgG, simt_waves, wg_per_cu, xcu, xcu_S, xcu_NW, recon_nw, lf_nw, detile_stream, detile_defer;
+};
+static int env_int(const char *name, int dflt) { const char *e = getenv(name); return e && *e ? atoi(e) : dflt; }
+static void read_knobs(Knobs &k)
+{
+    const char *e = getenv("VP8HIP_RECON");
+    k.recon_force = !e ? 0 : !strcmp(e, "simt") ? 1 : !strcmp(e, "wave") ? 2 : 0;
+    k.lf_raster = env_int("VP8HIP_LF_RASTER", 1) != 0;
+    k.lgG = env_int("VP8HIP_SIMT_LGG", 0);
+    k.simt_waves = env_int("VP8HIP_SIMT_WAVES", 0);
+    k.wg_per_cu = env_int("VP8HIP_WG_PER_CU", 1);
+    k.xcu = env_int("VP8HIP_XCU", 1) != 0;
+    k.xcu_S = env_int("VP8HIP_XCU_S", 0);
+    k.xcu_NW = env_int("VP8HIP_XCU_NW", 0);
+    k.recon_nw = env_int("VP8HIP_RECON_NW", 0);
+    k.lf_nw = env_int("VP8HIP_LF_NW", 0);
+    k.detile_stream = env_int("VP8HIP_DETILE_STREAM", 1) != 0;
+    k.detile_defer = env_int("VP8HIP_DETILE_DEFER", 1) != 0;
+}
+
 struct vp8hip_ctx {
     int device;
+    Knobs knobs;
     hipStream_t stream;
     // timing events of the last VP8HIP_STATS_RING launches: [0..3] on the main stream around recon / loop filter /
     // extend, [4..5] around the tiled -> raster pass on whichever stream it ran
@@ -113,6 +142,15 @@ static void free_pools(vp8hip_ctx *c)
     c->fb.clear(); c->slots.clear();
 }
 
+static void destroy_events(vp8hip_ctx *c)
+{
+    for (int r = 0; r < VP8HIP_STATS_RING; r++) for (int i = 0; i < 6; i++) if (c->evr[r][i]) (void)hipEventDestroy(c->evr[r][i]);
+    if (c->ev_jobs) (void)hipEventDestroy(c->ev_jobs);
+    if (c->ev_lf_done) (void)hipEventDestroy(c->ev_lf_done);
+    if (c->ev_recon_done) (void)hipEventDestroy(c->ev_recon_done);
+    for (int k = 0; k < VP8HIP_NBUF; k++) if (c->ev_detile_done[k]) (void)hipEventDestroy(c->ev_detile_done[k]);
+}
+
 extern "C" int vp8hip_create(int device, vp8hip_ctx **out)
 {
     if (!out) return fail(nullptr, -2, "vp8hip_create: null out pointer");
@@ -138,6 +176,7 @@ extern "C" int vp8hip_create(int device, vp8hip_ctx **out)
     c->num_cu = prop.multiProcessorCount;
     c->max_lds = 160 * 1024;
     c->fb_block = nullptr; c->slot_block_dev = nullptr;
+    read_knobs(c->knobs);
     for (int k = 0; k < VP8HIP_NBUF; k++) { c->tile_block[k] = nullptr; c->tile_cap[k] = 0; }
     c->d_jobs = nullptr; c->h_jobs = nullptr; c->jobs_cap = 0;
     for (int k = 0; k < VP8HIP_NBUF; k++) c->d_jobs2[k] = nullptr;
@@ -155,23 +194,27 @@ extern "C" int vp8hip_create(int device, vp8hip_ctx **out)
         return -1;
     }
     c->stream2 = nullptr;      // created by the first launch that wants it
-    for (int r = 0; r < VP8HIP_STATS_RING; r++) for (int i = 0; i < 6; i++) (void)hipEventCreate(&c->evr[r][i]);
-    (void)hipEventCreateWithFlags(&c->ev_jobs, hipEventDisableTiming);
-    (void)hipEventCreateWithFlags(&c->ev_lf_done, hipEventDisableTiming);
-    (void)hipEventCreateWithFlags(&c->ev_recon_done, hipEventDisableTiming);
-    for (int k = 0; k < VP8HIP_NBUF; k++) (void)hipEventCreateWithFlags(&c->ev_detile_done[k], hipEventDisableTiming);
-    e = hipFuncSetAttribute((const void *)vp8_recon_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_lds);
-    if (e != hipSuccess) {
-        fail(nullptr, -1, "hipFuncSetAttribute(recon, %d B LDS): %s", c->max_lds, hipGetErrorString(e));
-        (void)hipStreamDestroy(c->stream);
-        delete c;
-        return -1;
+    // events: every creation is checked; on failure whatever exists is destroyed again (null handles are skipped)
+    for (int r = 0; r < VP8HIP_STATS_RING; r++) for (int i = 0; i < 6; i++) c->evr[r][i] = nullptr;
+    c->ev_jobs = c->ev_lf_done = c->ev_recon_done = nullptr;
+    for (int k = 0; k < VP8HIP_NBUF; k++) c->ev_detile_done[k] = nullptr;
+    e = hipSuccess;
+    for (int r = 0; r < VP8HIP_STATS_RING && e == hipSuccess; r++)
+        for (int i = 0; i < 6 && e == hipSuccess; i++) e = hipEventCreate(&c->evr[r][i]);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_jobs, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_lf_done, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_recon_done, hipEventDisableTiming);
+    for (int k = 0; k < VP8HIP_NBUF && e == hipSuccess; k++) e = hipEventCreateWithFlags(&c->ev_detile_done[k], hipEventDisableTiming);
+    const char *what = "hipEventCreate";
+    const void *big_lds[4] = { (const void *)vp8_recon_kernel, (const void *)vp8_recon_xcu_kernel,
+                               (const void *)vp8_loopfilter_xcu_kernel, (const void *)vp8_loopfilter_kernel };
+    for (int i = 0; i < 4 && e == hipSuccess; i++) {
+        what = "hipFuncSetAttribute(max dynamic LDS)";
+        e = hipFuncSetAttribute(big_lds[i], hipFuncAttributeMaxDynamicSharedMemorySize, c->max_lds);
     }
-    (void)hipFuncSetAttribute((const void *)vp8_recon_xcu_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_lds);
-    (void)hipFuncSetAttribute((const void *)vp8_loopfilter_xcu_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_lds);
-    e = hipFuncSetAttribute((const void *)vp8_loopfilter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, c->max_lds);
     if (e != hipSuccess) {
-        fail(nullptr, -1, "hipFuncSetAttribute(loopfilter, %d B LDS): %s", c->max_lds, hipGetErrorString(e));
+        fail(nullptr, -1, "%s: %s", what, hipGetErrorString(e));
+        destroy_events(c);
         (void)hipStreamDestroy(c->stream);
         delete c;
         return -1;
@@ -193,11 +236,7 @@ extern "C" void vp8hip_destroy(vp8hip_ctx *c)
     for (int k = 0; k < VP8HIP_NBUF; k++) if (c->d_jobs2[k]) (void)hipFree(c->d_jobs2[k]);
     if (c->h_jobs) (void)hipHostFree(c->h_jobs);
     if (c->h_status) (void)hipHostFree(c->h_status);
-    for (int r = 0; r < VP8HIP_STATS_RING; r++) for (int i = 0; i < 6; i++) (void)hipEventDestroy(c->evr[r][i]);
-    (void)hipEventDestroy(c->ev_jobs);
-    (void)hipEventDestroy(c->ev_lf_done);
-    (void)hipEventDestroy(c->ev_recon_done);
-    for (int k = 0; k < VP8HIP_NBUF; k++) (void)hipEventDestroy(c->ev_detile_done[k]);
+    destroy_events(c);
     (void)hipStreamDestroy(c->stream);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
     delete c;
@@ -209,7 +248,19 @@ static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 static size_t recon_lds_bytes(int nw, int aligned_w) { return 1024 + (size_t)nw * 2 * (2080 + 2 * aligned_w + 96); }   // two frames per wave
 static size_t lf_lds_bytes(int nw) { return 256 + (size_t)nw * 2 * 4096; }   // two frames per wave
 
+static int configure_pools(vp8hip_ctx *c, int width, int height, int num_fb, int num_slots);
+
 extern "C" int vp8hip_configure(vp8hip_ctx *c, int width, int height, int num_fb, int num_slots)
+{
+    const int rc = configure_pools(c, width, height, num_fb, num_slots);
+    if (rc && c) {               // a failed (re)configuration leaves an UNconfigured context, not a half-allocated one
+        free_pools(c);
+        c->width = c->height = 0;
+    }
+    return rc;
+}
+
+static int configure_pools(vp8hip_ctx *c, int width, int height, int num_fb, int num_slots)
 {
     if (!c) return -2;
     if (width <= 0 || height <= 0 || width > 16383 || height > 16383 || num_fb < 1 || num_slots < 1)
@@ -221,6 +272,7 @@ extern "C" int vp8hip_configure(vp8hip_ctx *c, int width, int height, int num_fb
     c->detile_pending = false;
     for (int k = 0; k < VP8HIP_NBUF; k++) c->detile_used[k] = false;
     free_pools(c);
+    read_knobs(c->knobs);
     c->width = width; c->height = height;
     vp8ir_geom_init(&c->geom, width, height);
     const vp8ir_geom &g = c->geom;
@@ -238,11 +290,11 @@ extern "C" int vp8hip_configure(vp8hip_ctx *c, int width, int height, int num_fb
     if (recon_lds_bytes(nw, g.aligned_w) > (size_t)c->max_lds)
         return fail(c, -2, "frame width %d needs more LDS than a CU has", width);
     while (nw > 2 && nw / 2 >= c->dg.mb_rows) nw /= 2;
-    if (const char *e = getenv("VP8HIP_RECON_NW")) { int v = atoi(e); if (v >= 2 && v <= nw) nw = v; }   // tuning knob
+    if (c->knobs.recon_nw >= 2 && c->knobs.recon_nw <= nw) nw = c->knobs.recon_nw;
     c->recon_nw = nw; c->recon_lds = recon_lds_bytes(nw, g.aligned_w);
     int lnw = 16;
     while (lnw > 2 && lnw / 2 >= c->dg.mb_rows) lnw /= 2;
-    if (const char *e = getenv("VP8HIP_LF_NW")) { int v = atoi(e); if (v >= 2 && v <= 16) lnw = v; }
+    if (c->knobs.lf_nw >= 2 && c->knobs.lf_nw <= 16) lnw = c->knobs.lf_nw;
     c->lf_nw = lnw; c->lf_lds = lf_lds_bytes(lnw);
 
     // frame buffers: one block, each buffer 256-B aligned
@@ -255,7 +307,7 @@ extern "C" int vp8hip_configure(vp8hip_ctx *c, int width, int height, int num_fb
     const size_t o_mbs = 64, o_coef = o_mbs + align_up((size_t)c->nmb * sizeof(vp8ir_mb), 256);
     const size_t o_mvs = o_coef + align_up((size_t)c->nmb * VP8IR_COEF_PER_MB * sizeof(int16_t), 256);
     const size_t slotsz = align_up(o_mvs + (size_t)c->nmb * 16 * sizeof(vp8ir_mv), 256);
-    HIPCHK(c, hipMalloc((void **)&c->slot_block_dev, slotsz * num_slots));
+    HIPCHK(c, hipMalloc((void **)&c->slot_block_dev, slotsz * num_slots + 4096));   // + room for prefetches past the last macroblock
     c->slot_bytes = slotsz; c->o_mbs = o_mbs; c->o_coef = o_coef; c->o_mvs = o_mvs;
     c->slots.resize(num_slots);
     for (int i = 0; i < num_slots; i++) {
@@ -397,9 +449,10 @@ extern "C" int vp8hip_decode(vp8hip_ctx *c, const vp8hip_job *jobs, int njobs, i
     bool all_key = true;
     for (int i = 0; i < njobs && all_key; i++)
         if (jobs[i].ir_slot >= 0 && jobs[i].ir_slot < nsl) all_key = c->slots[jobs[i].ir_slot].hdr_copy.frame_type == 0;
+    const Knobs &K = c->knobs;
     bool simt_recon = (stages & VP8HIP_STAGE_RECON) && all_key && njobs > 2 * c->num_cu;
-    if (const char *e = getenv("VP8HIP_RECON"))      // tuning / test knob: force one of the two kernel families
-        simt_recon = (stages & VP8HIP_STAGE_RECON) && (!strcmp(e, "simt") ? true : (!strcmp(e, "wave") ? false : simt_recon));
+    if (K.recon_force)           // tuning / test knob: force one of the two kernel families (lane-per-row: key frames only)
+        simt_recon = (stages & VP8HIP_STAGE_RECON) && all_key && K.recon_force == 1;
     // the lane-per-row kernels work on macroblock-tiled scratch frames; vp8_detile_kernel converts at the end
     const bool tiled = simt_recon;
     // When the loop filter runs at all (some frame of the launch has filter_level != 0), it writes its finished lines
@@ -407,7 +460,7 @@ extern "C" int vp8hip_decode(vp8hip_ctx *c, const vp8hip_job *jobs, int njobs, i
     // pass is skipped; only the border extension is left.  +6..10 % from 1536 frames per launch up (1080p), a tie at 2048,
     // -4 % at 1024.  VP8HIP_LF_RASTER=0 keeps the tiled -> raster pass.
     bool lf_raster = false;
-    if (tiled && (stages & VP8HIP_STAGE_LF) && !(getenv("VP8HIP_LF_RASTER") && !atoi(getenv("VP8HIP_LF_RASTER"))))
+    if (tiled && (stages & VP8HIP_STAGE_LF) && K.lf_raster)
         for (int i = 0; i < njobs && !lf_raster; i++)     // some frame is filtered: the loop filter kernel runs anyway
             if (jobs[i].ir_slot >= 0 && jobs[i].ir_slot < nsl) lf_raster = c->slots[jobs[i].ir_slot].hdr_copy.filter_level != 0;
     const size_t tile_frame = (size_t)c->nmb * VP8_TILE_BYTES;
@@ -420,16 +473,16 @@ extern "C" int vp8hip_decode(vp8hip_ctx *c, const vp8hip_job *jobs, int njobs, i
         // sets: that pass, launched beside the previous launch's loop filter, may still be finishing)
         if (c->detile_used[par]) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_detile_done[par], 0));
         if (c->tile_cap[par] < tile_frame * njobs) {
-            // grow ALL sets now: a launch in the middle of a pipelined sequence must not stop to allocate
+            // (re)allocate the scratch set in use (the other sets only exist once the tiled -> raster pass has rotated to them)
             if (join_detile(c)) return -1;          // a pass not launched yet still reads the old sets
             HIPCHK(c, hipStreamSynchronize(c->stream));
             if (c->stream2) HIPCHK(c, hipStreamSynchronize(c->stream2));
-            for (int k = 0; k < VP8HIP_NBUF; k++) {
-                if (c->tile_cap[k] >= tile_frame * njobs) continue;
-                if (c->tile_block[k]) (void)hipFree(c->tile_block[k]);
-                c->tile_block[k] = nullptr; c->tile_cap[k] = 0;
-                HIPCHK(c, hipMalloc((void **)&c->tile_block[k], tile_frame * njobs));
-                c->tile_cap[k] = tile_frame * njobs;
+            if (c->tile_cap[par] < tile_frame * njobs) {
+                if (c->tile_block[par]) (void)hipFree(c->tile_block[par]);
+                c->tile_block[par] = nullptr; c->tile_cap[par] = 0;
+                // + 8 KB: the dummy tile idle lanes write, and room for the lane-per-row kernels' prefetches past the last tile
+                HIPCHK(c, hipMalloc((void **)&c->tile_block[par], tile_frame * njobs + 8192));
+                c->tile_cap[par] = tile_frame * njobs;
             }
         }
     }
@@ -443,7 +496,8 @@ extern "C" int vp8hip_decode(vp8hip_ctx *c, const vp8hip_job *jobs, int njobs, i
         d.hdr = s.hdr_copy;
         d.mbs = s.d_mbs; d.coef = s.d_coef; d.mvs = s.d_mvs;
         d.dst = c->fb[j.dst_fb];
-        d.ref[0] = tiled ? c->tile_block[par] + tile_frame * i : nullptr;
+        d.ref[0] = nullptr;
+        d.tile = tiled ? c->tile_block[par] + tile_frame * i : nullptr;
         for (int k = 1; k < 4; k++) {
             d.ref[k] = nullptr;
             if (s.hdr_copy.frame_type == 0) continue;          // key frames read no reference
@@ -458,8 +512,7 @@ extern "C" int vp8hip_decode(vp8hip_ctx *c, const vp8hip_job *jobs, int njobs, i
     HIPCHK(c, hipMemcpyAsync(c->d_jobs, c->h_jobs, sizeof(DevJob) * njobs, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipEventRecord(c->ev_jobs, c->stream));
 
-    int wg_per_cu = 1;
-    if (const char *e = getenv("VP8HIP_WG_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 8) wg_per_cu = v; }
+    const int wg_per_cu = K.wg_per_cu >= 1 && K.wg_per_cu <= 8 ? K.wg_per_cu : 1;
     const int grid = njobs < c->num_cu * wg_per_cu ? njobs : c->num_cu * wg_per_cu;
     c->stats.workgroups = grid;
     c->stats.recon_waves = c->recon_nw;
@@ -479,9 +532,9 @@ extern "C" int vp8hip_decode(vp8hip_ctx *c, const vp8hip_job *jobs, int njobs, i
         // has on a single CU (a wave's macroblock step is a latency chain; throughput goes with the number of waves)
         if (S * XCU_NW < rows) XCU_NW = 8;
         if (S * XCU_NW <= c->recon_nw) S = 1;
-        if (const char *e = getenv("VP8HIP_XCU")) { if (!atoi(e)) S = 1; }
-        if (const char *e = getenv("VP8HIP_XCU_S")) { int v = atoi(e); if (v >= 1 && v <= 64) S = v; }
-        if (const char *e = getenv("VP8HIP_XCU_NW")) { int v = atoi(e); if (v == 4 || v == 8) XCU_NW = v; }
+        if (!K.xcu) S = 1;
+        if (K.xcu_S >= 1 && K.xcu_S <= 64) S = K.xcu_S;
+        if (K.xcu_NW == 4 || K.xcu_NW == 8) XCU_NW = K.xcu_NW;
         if (S > 1) {
             xcu_S = S; xcu_grid = 8 * S * per_xcd;
             if (!c->h_status) {
@@ -526,14 +579,14 @@ extern "C" int vp8hip_decode(vp8hip_ctx *c, const vp8hip_job *jobs, int njobs, i
         const long lanes = (long)c->num_cu * 4 * 64;                      // one wave per SIMD
         while (lgG < 6 && (lanes >> lgG) > njobs) lgG++;                  // strands of a full launch <= frames
         if (lgG > lgmax && ((long)njobs << lgmax) >= lanes) lgG = lgmax;   // no idle steps, if that still fills every SIMD
-        if (const char *e = getenv("VP8HIP_SIMT_LGG")) { int v = atoi(e); if (v >= 1 && v <= 6) lgG = v; }
+        if (K.lgG >= 1 && K.lgG <= 6) lgG = K.lgG;
     }
     const int simtG = 1 << lgG, spw = 64 >> lgG;
     const int simtP = c->dg.mb_cols > 2 * simtG + 2 ? c->dg.mb_cols : 2 * simtG + 2;
     int simt_waves = (njobs + spw - 1) / spw;
     {
         int maxw = c->num_cu * 4;
-        if (const char *e = getenv("VP8HIP_SIMT_WAVES")) { int v = atoi(e); if (v >= 1) maxw = v; }
+        if (K.simt_waves >= 1) maxw = K.simt_waves;
         if (simt_waves > maxw) simt_waves = maxw;
     }
     if (tiled) { c->stats.workgroups = simt_waves; c->stats.recon_waves = 1; c->stats.lf_waves = 1; }
@@ -541,7 +594,7 @@ extern "C" int vp8hip_decode(vp8hip_ctx *c, const vp8hip_job *jobs, int njobs, i
     if (stages & VP8HIP_STAGE_RECON) {
         if (simt_recon) {
             hipLaunchKernelGGL(vp8_recon_simt_kernel, dim3(simt_waves), dim3(64), 0, c->stream, (const DevJob *)c->d_jobs, njobs,
-                               c->dg, lgG, simtP, simt_waves * spw, tiled ? 1 : 0);
+                               c->dg, lgG, simtP, simt_waves * spw, c->tile_block[par] + tile_frame * njobs + 4096);
         } else {
             const int npairs = (njobs + 1) / 2;          // two frames per wave
             if (xcu_S > 1) {
@@ -590,13 +643,13 @@ extern "C" int vp8hip_decode(vp8hip_ctx *c, const vp8hip_job *jobs, int njobs, i
             HIPCHK(c, hipGetLastError());
             HIPCHK(c, hipEventRecord(ev[5], c->stream));
         }
-        c->parity = (par + 1) % VP8HIP_NBUF;
+        // no rotation: nothing reads this scratch set once the launch's loop filter is done
     } else if (tiled) {      // whatever stages ran, the frame buffer gets the result; borders are extended on the way
-        const bool own_stream = !(getenv("VP8HIP_DETILE_STREAM") && !atoi(getenv("VP8HIP_DETILE_STREAM")));
+        const bool own_stream = K.detile_stream;
         if (own_stream && !c->stream2) HIPCHK(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
         // deferred by default: the pass is launched with the NEXT lane-per-row launch, right after its recon, so
         // that it runs beside that launch's loop filter (which it disturbs less than the recon), or at the next join
-        const bool defer = own_stream && !(getenv("VP8HIP_DETILE_DEFER") && !atoi(getenv("VP8HIP_DETILE_DEFER")));
+        const bool defer = own_stream && K.detile_defer;
         hipStream_t ds = own_stream ? c->stream2 : c->stream;
         if (defer) {
             c->deferred.valid = true; c->deferred.jobs = c->d_jobs; c->deferred.njobs = njobs;
@@ -730,3 +783,18 @@ extern "C" int vp8hip_frame_copy(vp8hip_ctx *c, int dst, int src)
     HIPCHK(c, hipMemcpyAsync(c->fb[dst], c->fb[src], (size_t)c->geom.frame_size, hipMemcpyDeviceToDevice, c->stream));
     return 0;
 }
+
+#ifdef VP8_STAMPS
+// diagnostic builds only (see vp8_common.hip.h): read and clear the stamp buckets; which = 0 recon, 1 loop filter
+__device__ unsigned long long vp8_stamps_recon[VP8_NSTAMPS], vp8_stamps_lf[VP8_NSTAMPS];
+extern "C" int vp8hip_debug_stamps(vp8hip_ctx *c, int which, unsigned long long *out)
+{
+    if (!c || !out) return -2;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    unsigned long long zero[VP8_NSTAMPS] = { 0 };
+    if (which == 0) { HIPCHK(c, hipMemcpyFromSymbol(out, HIP_SYMBOL(vp8_stamps_recon), sizeof zero)); HIPCHK(c, hipMemcpyToSymbol(HIP_SYMBOL(vp8_stamps_recon), zero, sizeof zero)); }
+    else { HIPCHK(c, hipMemcpyFromSymbol(out, HIP_SYMBOL(vp8_stamps_lf), sizeof zero)); HIPCHK(c, hipMemcpyToSymbol(HIP_SYMBOL(vp8_stamps_lf), zero, sizeof zero)); }
+    return 0;
+}
+#endif
