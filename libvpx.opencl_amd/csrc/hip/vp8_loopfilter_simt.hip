@@ -47,11 +47,14 @@ __device__ __forceinline__ unsigned long long load_l2_64(const unsigned char *p)
 {
     return __hip_atomic_load((const unsigned long long *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// Pixels travel through the filters as 8.8 fixed point, the byte in the HIGH half of each 16-bit lane:
-//   * unsigned (v2u) for the masks: |a-b| = max-min, comparisons by saturating subtraction;
-//   * signed (v2s, pixel ^ 0x80 in the high byte) for the filter arithmetic, where the 16-bit saturation of
-//     `v_pk_add_i16 ... clamp` IS the reference's vp8_signed_char_clamp (every operand is a multiple of 256),
-//     so a saturating add costs one instruction instead of add + min + max.
+// Pixels travel through the filters as SIGNED 8.8 fixed point -- pixel ^ 0x80 (the reference's own bias,
+// loopfilter_filters.c:57-60) in the HIGH half of each 16-bit lane -- from the moment they are staged in the LDS tile
+// until they are read back for output (one XOR per dword of four pixels each way, not two per value and edge):
+//   * the filter arithmetic wants them that way: the 16-bit saturation of `v_pk_add_i16 ... clamp` IS the reference's
+//     vp8_signed_char_clamp (every operand is a multiple of 256), so a saturating add costs one instruction instead
+//     of add + min + max;
+//   * the masks only need |a-b|, which is max-min in any order-preserving representation: signed max / min, and the
+//     difference taken modulo 2^16 is the unsigned 8.8 distance; comparisons by unsigned saturating subtraction.
 typedef unsigned short v2u __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ v2u as_v2u(u32 v) { return __builtin_bit_cast(v2u, v); }
 __device__ __forceinline__ u32 as_u32(v2u v) { return __builtin_bit_cast(u32, v); }
@@ -61,7 +64,11 @@ __device__ __forceinline__ v2u mku(int v) { return (v2u){ (unsigned short)v, (un
 __device__ __forceinline__ v2s mks(int v) { return (v2s){ (short)v, (short)v }; }
 __device__ __forceinline__ v2u umax(v2u a, v2u b) { return __builtin_elementwise_max(a, b); }
 __device__ __forceinline__ v2u umin(v2u a, v2u b) { return __builtin_elementwise_min(a, b); }
-__device__ __forceinline__ v2u adu(v2u a, v2u b) { return umax(a, b) - umin(a, b); }                  // |a - b|
+__device__ __forceinline__ v2u adu(v2u a, v2u b)                                                     // |a - b| of two biased pixels
+{
+    const v2s x = __builtin_bit_cast(v2s, a), y = __builtin_bit_cast(v2s, b);
+    return __builtin_bit_cast(v2u, (v2s)(__builtin_elementwise_max(x, y) - __builtin_elementwise_min(x, y)));
+}
 __device__ __forceinline__ v2u usubs(v2u a, v2u b) { return __builtin_elementwise_sub_sat(a, b); }    // max(a - b, 0)
 __device__ __forceinline__ v2u uadds(v2u a, v2u b) { return __builtin_elementwise_add_sat(a, b); }
 __device__ __forceinline__ v2s adds(v2s a, v2s b) { return __builtin_elementwise_add_sat(a, b); }     // signed-char clamp
@@ -71,8 +78,9 @@ __device__ __forceinline__ v2s subs(v2s a, v2s b) { return __builtin_elementwise
 // constant the expression is canonicalised into a compare-and-select, which gfx950 can only do one half at a time.
 __device__ __forceinline__ v2u nz_clear(v2u x, v2u one) { return mku(0) - usubs(one, x); }
 __device__ __forceinline__ v2u nz_set(v2u x, v2u one) { return usubs(one, x) - one; }
-__device__ __forceinline__ v2s sgn(v2u p) { return as_v2s(as_u32(p) ^ 0x80008000u); }                // pixel -> signed
-__device__ __forceinline__ v2u pix(v2s s) { return as_v2u(as_u32(s) ^ 0x80008000u); }
+__device__ __forceinline__ v2s sgn(v2u p) { return as_v2s(as_u32(p)); }                              // (already biased: see above)
+__device__ __forceinline__ v2u pix(v2s s) { return as_v2u(as_u32(s)); }
+#define VP8_LF_BIAS 0x80808080u     // four pixels <-> four biased pixels, on the way into and out of the LDS tile
 __device__ __forceinline__ v2s hib(v2s v) { return as_v2s(as_u32(v) & 0xff00ff00u); }                // floor to a whole byte
 
 struct Lim { v2u mblim, blim, lim, thr, one; };     // the limits, << 8; the opaque constant 1 of nz_clear / nz_set
@@ -131,11 +139,13 @@ __device__ __forceinline__ void lf_mbedge(v2u p[8], const Lim &L, v2u gate)
     f2 = hib(adds(f2, mks(0x0300)) >> 3);
     qs0 = subs(qs0, f1); ps0 = adds(ps0, f2);
     const v2s F = as_v2s(as_u32(f) & ~as_u32(hev)) >> 8;             // plain signed value, -128 .. 127
-    v2s u = ((F * 27 + 63) >> 7) << 8;
+    // ((F * 27 + 63) >> 7) << 8 == (F * 54 + 126) with the low byte cleared (|F * 54 + 126| < 2^15): one multiply-add
+    // and one AND instead of multiply-add, shift, shift
+    v2s u = hib(F * 54 + 126);
     qs0 = subs(qs0, u); ps0 = adds(ps0, u);
-    u = ((F * 18 + 63) >> 7) << 8;
+    u = hib(F * 36 + 126);
     qs1 = subs(qs1, u); ps1 = adds(ps1, u);
-    u = ((F * 9 + 63) >> 7) << 8;
+    u = hib(F * 18 + 126);
     qs2 = subs(qs2, u); ps2 = adds(ps2, u);
     p[1] = pix(ps2); p[2] = pix(ps1); p[3] = pix(ps0); p[4] = pix(qs0); p[5] = pix(qs1); p[6] = pix(qs2);
 }
@@ -438,13 +448,13 @@ vp8_loopfilter_simt_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g
 #pragma unroll
             for (int y = 0; y < 16; y++) {
                 u32 *row = TL + (4 + y) * 5 * 64;
-                row[0] = sY[y]; row[64] = inY[y].x; row[128] = inY[y].y; row[192] = inY[y].z; row[256] = inY[y].w;
+                row[0] = sY[y] ^ VP8_LF_BIAS; row[64] = inY[y].x ^ VP8_LF_BIAS; row[128] = inY[y].y ^ VP8_LF_BIAS; row[192] = inY[y].z ^ VP8_LF_BIAS; row[256] = inY[y].w ^ VP8_LF_BIAS;
             }
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 u32 *row = TL + j * 5 * 64;
 #pragma unroll
-                for (int i = 0; i < 4; i++) row[(1 + i) * 64] = tY[4 + j][i];
+                for (int i = 0; i < 4; i++) row[(1 + i) * 64] = tY[4 + j][i] ^ VP8_LF_BIAS;
             }
             STAMP(3)
             filter_plane<4, 16>(TL, gvY, ghY, L);
@@ -453,7 +463,7 @@ vp8_loopfilter_simt_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g
             if (c > 0) {
 #pragma unroll
                 for (int y = 0; y < 16; y++) {
-                    const u32 s = TL[(4 + y) * 5 * 64];
+                    const u32 s = TL[(4 + y) * 5 * 64] ^ VP8_LF_BIAS;
                     if (y < 8) {
                         const u32x4 v = { pbY[y][0], pbY[y][1], pbY[y][2], s };
                         if (!ras) *(g_u32x4p)(o_left_lo + ysY * y) = v;
@@ -471,7 +481,7 @@ vp8_loopfilter_simt_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g
                 for (int y = 0; y < 8; y++) {
                     u32x4 v;
                     if (y < 5) v = (u32x4){ tY[y][0], tY[y][1], tY[y][2], tY[y][3] };
-                    else { const u32 *row = TL + (y - 4) * 5 * 64; v = (u32x4){ row[64], row[128], row[192], row[256] }; }
+                    else { const u32 *row = TL + (y - 4) * 5 * 64; v = (u32x4){ row[64] ^ VP8_LF_BIAS, row[128] ^ VP8_LF_BIAS, row[192] ^ VP8_LF_BIAS, row[256] ^ VP8_LF_BIAS }; }
                     if (pair_hold) holdB[y] = v;
                     else {
                         if (pair_flush) *(g_u32x4p)(o_above + ysY * y - 16) = holdB[y];
@@ -483,7 +493,7 @@ vp8_loopfilter_simt_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g
 #pragma unroll
             for (int y = 0; y < 16; y++) {
                 const u32 *row = TL + (4 + y) * 5 * 64;
-                const u32 d0 = row[64], d1 = row[128], d2 = row[192], d3 = row[256];
+                const u32 d0 = row[64] ^ VP8_LF_BIAS, d1 = row[128] ^ VP8_LF_BIAS, d2 = row[192] ^ VP8_LF_BIAS, d3 = row[256] ^ VP8_LF_BIAS;
                 pbY[y][0] = d0; pbY[y][1] = d1; pbY[y][2] = d2; sY[y] = d3;
                 if (last_col && y < 8) {
                     if (ras && (c & 1)) *(g_u32x4p)(o_own_lo + ysY * y - 16) = holdA[y];      // its even left neighbour was waiting
@@ -507,13 +517,13 @@ vp8_loopfilter_simt_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g
 #pragma unroll
                 for (int y = 0; y < 8; y++) {
                     u32 *row = TL + (4 + y) * 3 * 64;
-                    row[0] = sC[y];
-                    row[64] = (y & 1) ? in[y >> 1].z : in[y >> 1].x; row[128] = (y & 1) ? in[y >> 1].w : in[y >> 1].y;
+                    row[0] = sC[y] ^ VP8_LF_BIAS;
+                    row[64] = ((y & 1) ? in[y >> 1].z : in[y >> 1].x) ^ VP8_LF_BIAS; row[128] = ((y & 1) ? in[y >> 1].w : in[y >> 1].y) ^ VP8_LF_BIAS;
                 }
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     u32 *row = TL + j * 3 * 64;
-                    row[64] = tC[4 + j][0]; row[128] = tC[4 + j][1];
+                    row[64] = tC[4 + j][0] ^ VP8_LF_BIAS; row[128] = tC[4 + j][1] ^ VP8_LF_BIAS;
                 }
                 STAMP(6)
                 filter_plane<2, 8>(TL, gvC, ghC, L);
@@ -521,7 +531,7 @@ vp8_loopfilter_simt_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g
                 if (c > 0) {
 #pragma unroll
                     for (int y = 0; y < 8; y++) {
-                        const u32 s = TL[(4 + y) * 3 * 64];
+                        const u32 s = TL[(4 + y) * 3 * 64] ^ VP8_LF_BIAS;
                         if (write_bottom) *(g_u32x2p)(oc_left + ybC * y) = (u32x2){ pb[y], s };
                         hC[y][1] = s;
                     }
@@ -533,7 +543,7 @@ vp8_loopfilter_simt_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g
                     for (int y = 0; y < 8; y++) {
                         u32x2 v;
                         if (y < 5) v = (u32x2){ tC[y][0], tC[y][1] };
-                        else { const u32 *row = TL + (y - 4) * 3 * 64; v = (u32x2){ row[64], row[128] }; }
+                        else { const u32 *row = TL + (y - 4) * 3 * 64; v = (u32x2){ row[64] ^ VP8_LF_BIAS, row[128] ^ VP8_LF_BIAS }; }
                         if (pair_hold) hold[y] = v;
                         else {
                             if (pair_flush) *(g_u32x2p)(oc_above + ysC * y - 8) = hold[y];
@@ -544,7 +554,7 @@ vp8_loopfilter_simt_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g
 #pragma unroll
                 for (int y = 0; y < 8; y++) {
                     const u32 *row = TL + (4 + y) * 3 * 64;
-                    const u32 d0 = row[64], d1 = row[128];
+                    const u32 d0 = row[64] ^ VP8_LF_BIAS, d1 = row[128] ^ VP8_LF_BIAS;
                     pb[y] = d0; sC[y] = d1;
                     if (last_col && write_bottom) *(g_u32x2p)(oc_own + ybC * y) = (u32x2){ d0, d1 };
                 }
