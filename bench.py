@@ -12,9 +12,11 @@ independently decodable (reference: vp8/decoder/decodframe.c:610-639).  Before t
 frames are checked bit-exactly against the reference decoder's per-frame MD5s
 (tests/golden/*.md5).
 
-N > 1: launched by torch.distributed.run, one rank per GPU, every rank decodes its own F frames
-(frames shard one-per-GPU, no pixel exchange: "scaling": "weak").  RCCL (backend "nccl") carries
-only the start/stop barriers, the max-over-ranks time and the per-rank verification flag.
+N > 1: one rank per GPU -- under torch.distributed.run, or spawned by bench.py itself when no launcher set
+WORLD_SIZE -- decoding ONE looped stream of N * F frames in contiguous blocks of F (rank r: frames [r*F, (r+1)*F),
+libvpx.opencl_amd/sharding.py; no pixel exchange: "scaling": "weak").  RCCL (backend "nccl") carries the start/stop
+barriers, the per-rank times, the verification flag and the gathered MD5 listing of a sharded prefix stream,
+which must equal the 1-GPU listing.
 
 Prints ONE JSON line on rank 0 (see README / DESIGN.md for the field definitions):
   value      whole-job Mpix/s (display pixels) = N * F * K * w * h / seconds
@@ -39,6 +41,7 @@ B_RECON = 833 + 384      # coefficients+eobs+params read, pixels written (key fr
 B_LF = 770               # pixels read + written, params
 B_EXTEND = 36
 B_DETILE = 384 + 384 + 36  # lane-per-row pipeline only: tiled scratch read, raster frame + borders written
+B_INTER_FULL = 833 + 768 + 770 + 36   # full path on P frames
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 # HBM traffic per macroblock of the lane-per-row kernels (1080p key frames, G = 8 as at the default launch size), from
 # `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, KiB; FETCH_SIZE doubled: the gfx950 correction
@@ -106,14 +109,17 @@ def cpu_baseline(fixture, budget_s=12.0):
 
 
 
-def inter_frame_probe(P, device, n=1024, name="p_1920x1080", k=5):
-    """BASELINE configs[2] beside the headline: six-tap motion compensation + IDCT + loop filter on REAL inter
-    frames.  The stream is decoded the normal way up to frame k-1, then n jobs decode frame k from the same
-    references into n different frame buffers (n independent streams in lock step); whole-launch wall time."""
-    from vp8_testlib import ivf_path
+def inter_frame_probe(P, device, n=1024, name="p_dense_1920x1080", k=2):
+    """BASELINE configs[2] beside the headline: six-tap motion compensation + IDCT + loop filter on REAL inter frames.
+    The stream is decoded the normal way up to frame k-1; then n jobs decode frame k, every one from its OWN copy of the
+    IR (vp8hip_ir_copy) and its OWN copies of the three reference buffers (vp8hip_frame_copy) into its own frame buffer
+    -- n independent streams in lock step, nothing shared in cache -- and one of them is compared with the reference MD5.
+    Roofline by SURVEY 8(d): 2407 B/MB for the full inter path (833 residual + 768 prediction + 770 loop filter + 36)."""
+    from vp8_testlib import ivf_path, golden_md5
     w, h, frames = P.read_ivf(ivf_path(name))
+    gold = golden_md5(name)
     ctx = P.Vp8Hip(device)
-    ctx.configure(w, h, n + 4, 2)
+    ctx.configure(w, h, 4 + 2 * n, 2 + n)          # 4 decoder buffers, then per job: one reference copy, one destination
     parser = P.Parser()
     for data in frames[:k]:
         hdr = ctx.parse_into_slot(parser, data, 0)
@@ -123,13 +129,20 @@ def inter_frame_probe(P, device, n=1024, name="p_1920x1080", k=5):
         ctx.sync()
         parser.swap(hdr)
     hdr = ctx.parse_into_slot(parser, frames[k], 1)
+    assert hdr.frame_type == 1
     ctx.upload(1)
     r = parser.refs
+    distinct = len({r.lst_idx, r.gld_idx, r.alt_idx})
     jobs = (P.Job * n)()
     for i in range(n):
-        jobs[i].ir_slot, jobs[i].dst_fb = 1, 4 + i
-        jobs[i].ref_fb[1], jobs[i].ref_fb[2], jobs[i].ref_fb[3] = r.lst_idx, r.gld_idx, r.alt_idx
+        ctx.ir_copy(2 + i, 1)
+        # (the fixture's golden and alt-ref are the key frame and never referenced by frame k's macroblocks: one private
+        # copy of `last` per job is every byte the job reads; the other two indices still point at valid buffers)
+        ctx.L.vp8hip_frame_copy(ctx.h, 4 + 2 * i, r.lst_idx)
+        jobs[i].ir_slot, jobs[i].dst_fb = 2 + i, 5 + 2 * i
+        jobs[i].ref_fb[1], jobs[i].ref_fb[2], jobs[i].ref_fb[3] = 4 + 2 * i, r.gld_idx, r.alt_idx
     ctx.decode_array(jobs, n, P.STAGE_ALL); ctx.sync()
+    ok = P.planes_md5(*ctx.download_planes(5 + 2 * (n // 2))) == gold[k]
     reps = 5
     t0 = time.perf_counter()
     for _ in range(reps):
@@ -137,12 +150,85 @@ def inter_frame_probe(P, device, n=1024, name="p_1920x1080", k=5):
     ctx.sync()
     dt = (time.perf_counter() - t0) / reps
     st = ctx.stats()
+    nmb = ctx.nmb
     parser.close()
     ctx.close()
-    return {"workload": f"{name}.ivf frame {k} (inter, six-tap, normal loop filter) x {n} independent copies per launch",
+    gbps = B_INTER_FULL * nmb * n / dt / 1e9
+    return {"workload": f"{name}.ivf frame {k} (inter: {distinct} distinct references, six-tap, normal loop filter) x {n} jobs per "
+                        f"launch, each with its own IR slot, reference buffer and destination",
+            "md5_ok": bool(ok),
             "Mpix_s": round(n * w * h / dt / 1e6, 1), "ms_per_launch": round(dt * 1e3, 3),
             "kernel_ms": {"recon": round(st.recon_ms, 3), "loopfilter": round(st.lf_ms, 3), "extend": round(st.extend_ms, 3)},
-            "kernel_family": "one wave per macroblock row"}
+            "kernel_family": "one wave per macroblock row",
+            "roofline": {"bound": "hbm", "achieved": round(gbps, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": round(gbps / HBM_PEAK_GBPS, 5),
+                         "note": "SURVEY 8(d) full inter path 2407 B/MB x macroblocks per launch / wall time per launch"}}
+
+
+def load_stream(P, ctx, fixture, F, lo):
+    """Slots 0 .. F-1 of `ctx` <- frames lo .. lo+F-1 of the looped stream (frame i of the stream is source frame i mod nsrc;
+    every key frame is independently decodable).  Host feeder once per source frame, device-to-device copies for the rest."""
+    from vp8_testlib import ivf_path
+    w, h, frames = P.read_ivf(ivf_path(fixture))
+    nsrc = len(frames)
+    parser = P.Parser()
+    first = {}                                   # source frame -> first slot holding it
+    t0 = time.time()
+    for j in range(min(F, nsrc)):
+        k = (lo + j) % nsrc
+        hdr = ctx.parse_into_slot(parser, frames[k], j)
+        assert hdr.frame_type == 0, "bench stream must be all key frames"
+        parser.swap(hdr)
+        ctx.upload(j)
+        first[k] = j
+    feed_s = time.time() - t0
+    for j in range(nsrc, F):
+        ctx.ir_copy(j, first[(lo + j) % nsrc])
+    ctx.sync()
+    parser.close()
+    return nsrc, feed_s
+
+
+def timed_steps(P, ctx, jobs, F, steps, warmup, barrier):
+    for _ in range(warmup):
+        ctx.decode_array(jobs, F, P.STAGE_ALL)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ctx.decode_array(jobs, F, P.STAGE_ALL)     # asynchronous: consecutive launches pipeline on the device
+    barrier()
+    elapsed = time.perf_counter() - t0
+    # per-kernel times of the TIMED launches: HIP events recorded on the stream the kernels ran on, read back now
+    # (reading a launch's events waits for it, which inside the loop would serialise the launches)
+    KS = min(steps, 32)
+    ms = {"recon": 0.0, "loopfilter": 0.0, "extend": 0.0}
+    for back in range(KS):
+        st = ctx.stats(back)
+        ms["recon"] += st.recon_ms / KS
+        ms["loopfilter"] += st.lf_ms / KS
+        ms["extend"] += st.extend_ms / KS
+    return elapsed, ms, st
+
+
+def spawn_ranks(args):
+    """--gpus N without a launcher: start N fresh child processes, one rank per GPU, from a parent that never touches a GPU
+    (rank 0's stdout is passed through; the exit code is the worst child's)."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for pr in procs:
+        code = pr.wait()
+        rc = max(rc, code if code >= 0 else 1)
+    raise SystemExit(rc)
 
 
 def main():
@@ -151,56 +237,54 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--frames", type=int, default=0,
-                    help="frames per GPU per step (default: 8192 for 1080p, 2048 for 4k -- about 165 GB of IR, "
-                         "tiled scratch and frame buffers resident in HBM; the lane-per-row kernels want several "
-                         "frames per wave on each of the chip's 1024 SIMDs)")
+                    help="frames per GPU per step (default: 8192 for 1080p, 2048 for 4k: IR, tiled scratch and frame buffers "
+                         "resident in HBM; the lane-per-row kernels want several frames per wave on each of the chip's 1024 SIMDs)")
     ap.add_argument("--workload", default="1080p", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-inter-probe", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true")
+    ap.add_argument("--no-4k-probe", action="store_true")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        spawn_ranks(args)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     dist = None
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the VP8 pixel path has no CPU fallback")
+    # (test hook for boxes with one GPU: every rank on device 0, collectives over gloo -- the same code path otherwise)
+    one_dev = os.environ.get("VP8BENCH_TEST_SINGLE_DEVICE") == "1"
+    if one_dev:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
+    coll_dev = torch.device("cpu") if one_dev else torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if one_dev:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=coll_dev)
 
-    from vp8_testlib import load_package, golden_md5, ivf_path
+    from vp8_testlib import load_package, golden_md5
     P = load_package()
+    from libvpx_opencl_amd import sharding
     fixture, W, H = WORKLOADS[args.workload]
     F = args.frames or {"1080p": 8192, "4k": 2048}[args.workload]
-
-    # ---- host feeder once (outside the timed region): 10 key frames -> IR
-    w, h, frames = P.read_ivf(ivf_path(fixture))
-    assert (w, h) == (W, H)
-    nsrc = len(frames)
     gold = golden_md5(fixture)
+
+    # ---- the stream: world * F frames, frame i = source frame i mod nsrc; rank r decodes the contiguous block
+    # shard_range(world * F, world, r) -- entropy-decoded once on the host, outside the timed region
+    lo, hi = sharding.shard_range(world * F, world, rank)
+    assert hi - lo == F
     ctx = P.Vp8Hip(local_rank)
     ctx.configure(W, H, F, F)
-    parser = P.Parser()
-    t_feed0 = time.time()
-    for i, data in enumerate(frames):
-        hdr = ctx.parse_into_slot(parser, data, i)
-        assert hdr.frame_type == 0, "bench stream must be all key frames"
-        parser.swap(hdr)
-        ctx.upload(i)
-    feed_s = time.time() - t_feed0
-    for i in range(nsrc, F):
-        ctx.ir_copy(i, i % nsrc)
-    ctx.sync()
-    parser.close()
-
+    nsrc, feed_s = load_stream(P, ctx, fixture, F, lo)
     jobs = (P.Job * F)()
     for i in range(F):
         jobs[i].ir_slot, jobs[i].dst_fb = i, i
@@ -208,16 +292,46 @@ def main():
             jobs[i].ref_fb[k] = -1
     nmb = ctx.nmb
 
-    # ---- correctness gate: one untimed pass, check a spread of frames against the reference MD5s
+    # ---- correctness gate 1 (multi-GPU): a 16-frames-per-rank prefix stream decoded the sharded way -- every rank its block,
+    # MD5 of every frame, digests all-gathered over RCCL -- must give the 1-GPU decode_to_md5 listing
+    listing_ok = None
+    if dist is not None:
+        nv = 16 * world
+
+        def decode_block(vlo, vhi):
+            # frames vlo .. vhi-1 of the stream are source frames (i mod nsrc): decode them into buffers 0 .. from the slots
+            # of this rank's shard that hold the same source frames
+            want = [i % nsrc for i in range(vlo, vhi)]
+            have = {(lo + j) % nsrc: j for j in range(min(F, nsrc) - 1, -1, -1)}
+            vj = (P.Job * len(want))()
+            for n, k in enumerate(want):
+                vj[n].ir_slot, vj[n].dst_fb = have[k], n
+                for q in range(4):
+                    vj[n].ref_fb[q] = -1
+            ctx.decode_array(vj, len(want), P.STAGE_ALL)
+            ctx.sync()
+            return [P.planes_md5(*ctx.download_planes(n)) for n in range(len(want))]
+
+        listing = sharding.sharded_listing(dist, nv, decode_block, device=coll_dev)
+        listing_ok = listing == [gold[i % nsrc] for i in range(nv)]
+    # ---- correctness gate 2: one untimed pass of the timed launch, >= 64 frames spread over strands, waves and the whole
+    # shard checked against the reference MD5s
     ctx.decode_array(jobs, F, P.STAGE_ALL)
     ctx.sync()
+    import random
+    rnd = random.Random(1234 + rank)
+    sample = sorted(set([0, 1, 7, 8, 9, 63, 64, 65, F // 2, F - 2, F - 1] + [rnd.randrange(F) for _ in range(64)]))
+    sample = [i for i in sample if 0 <= i < F]
     ok = 1
-    for i in sorted(set([0, 1, nsrc - 1, F // 2, F - 1])):
-        if P.planes_md5(*ctx.download_planes(i)) != gold[i % nsrc]:
+    for i in sample:
+        if P.planes_md5(*ctx.download_planes(i)) != gold[(lo + i) % nsrc]:
             ok = 0
-            sys.stderr.write(f"[bench] rank {rank}: frame {i} MD5 mismatch\n")
+            sys.stderr.write(f"[bench] rank {rank}: frame {lo + i} MD5 mismatch\n")
+    if listing_ok is False:
+        ok = 0
+        sys.stderr.write(f"[bench] rank {rank}: the gathered sharded listing differs from the 1-GPU listing\n")
     if dist is not None:
-        t = torch.tensor([ok], device="cuda", dtype=torch.int32)
+        t = torch.tensor([ok], device=coll_dev, dtype=torch.int32)
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         ok = int(t.item())
     if not ok:
@@ -229,47 +343,32 @@ def main():
         torch.cuda.synchronize()
         ctx.sync()
 
-    for _ in range(args.warmup):
-        ctx.decode_array(jobs, F, P.STAGE_ALL)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        ctx.decode_array(jobs, F, P.STAGE_ALL)     # asynchronous: consecutive launches pipeline on the device
-    barrier()
-    elapsed = time.perf_counter() - t0
-    # per-kernel times of the TIMED launches: HIP events recorded on the streams the kernels ran on, read back
-    # now (reading a launch's events waits for it, which inside the loop would serialise the launches)
-    KS = min(args.steps, 32)
-    k_recon = k_lf = k_ext = 0.0
-    for back in range(KS):
-        st = ctx.stats(back)
-        k_recon += st.recon_ms
-        k_lf += st.lf_ms
-        k_ext += st.extend_ms
-    # the same kernels launched one at a time (the tiled -> raster pass of launch k otherwise overlaps the recon of
-    # launch k+1 and both stretch): stand-alone durations, used to name the dominant kernel
-    alone = [0.0, 0.0, 0.0]
-    for _ in range(3):
-        ctx.decode_array(jobs, F, P.STAGE_ALL)
-        ctx.sync()
-        st = ctx.stats()
-        alone[0] += st.recon_ms / 3
-        alone[1] += st.lf_ms / 3
-        alone[2] += st.extend_ms / 3
+    elapsed_local, ms, st = timed_steps(P, ctx, jobs, F, args.steps, args.warmup, barrier)
+    elapsed = elapsed_local
+    per_rank = [elapsed_local]
+    if dist is not None:
+        t = torch.tensor([elapsed_local], device=coll_dev, dtype=torch.float64)
+        allt = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(allt, t)
+        per_rank = [float(x.item()) for x in allt]
+        elapsed = max(per_rank)
     # single-frame latency: one frame per launch (what a single-stream decoder sees), kernels only
-    one = (P.Job * 1)()
-    one[0].ir_slot, one[0].dst_fb = 0, 0
-    for k in range(4):
-        one[0].ref_fb[k] = -1
-    ctx.decode_array(one, 1, P.STAGE_ALL); ctx.sync()
-    tl = time.perf_counter()
-    for _ in range(20):
-        ctx.decode_array(one, 1, P.STAGE_ALL)
-    ctx.sync()
-    latency_ms = (time.perf_counter() - tl) / 20 * 1e3
-    # what the HBM system delivers to a plain device-to-device copy on this box (SURVEY.md 8d asks for the probe)
+    latency_ms = None
     copy_gbps = None
     if rank == 0:
+        one = (P.Job * 1)()
+        one[0].ir_slot, one[0].dst_fb = 0, 0
+        for k in range(4):
+            one[0].ref_fb[k] = -1
+        ctx.decode_array(one, 1, P.STAGE_ALL); ctx.sync()
+        tl = time.perf_counter()
+        for _ in range(20):
+            ctx.decode_array(one, 1, P.STAGE_ALL)
+        ctx.sync()
+        latency_ms = (time.perf_counter() - tl) / 20 * 1e3
+    ctx.close()
+    if rank == 0:
+        # what the HBM system delivers to a plain device-to-device copy on this box (SURVEY.md 8d asks for the probe)
         a = torch.empty(2 << 30, dtype=torch.uint8, device="cuda")
         b = torch.empty_like(a)
         b.copy_(a); torch.cuda.synchronize()
@@ -279,30 +378,24 @@ def main():
         torch.cuda.synchronize()
         copy_gbps = 2 * a.numel() * 5 / (time.perf_counter() - tc) / 1e9
         del a, b
-    if dist is not None:
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        torch.cuda.empty_cache()
 
     if rank == 0:
         K = args.steps
         total_pix = world * F * K * W * H
         lane = st.recon_waves == 1            # the lane-per-row kernels ran (see vp8hip_stats)
         detile = bool(st.detile_pass)         # ... finished by the tiled -> raster pass instead of the loop filter's own raster output
-        ms = {"recon": k_recon / KS, "loopfilter": k_lf / KS, "extend": k_ext / KS}
         bytes_per_launch = {"recon": B_RECON * nmb * F, "loopfilter": B_LF * nmb * F,
                             "extend": (B_DETILE if detile else B_EXTEND) * nmb * F}
         names = ({"recon": "vp8_recon_simt_kernel", "loopfilter": "vp8_loopfilter_simt_kernel",
                   "extend": "vp8_detile_kernel (tiled -> raster + border extension)" if detile else "vp8_extend_kernel"} if lane else
                  {"recon": "vp8_recon_kernel", "loopfilter": "vp8_loopfilter_kernel", "extend": "vp8_extend_kernel"})
-        ms_alone = {"recon": alone[0], "loopfilter": alone[1], "extend": alone[2]}
-        dom = max(ms_alone, key=lambda k: ms_alone[k])
+        dom = max(ms, key=lambda k: ms[k])
         achieved = bytes_per_launch[dom] / (ms[dom] * 1e-3) / 1e9
-        pipeline_gbps = sum(bytes_per_launch.values()) / (elapsed / K) / 1e9
-        # SURVEY.md 8(d)'s own figure for the full key-frame path: 1217 + 770 + 36 = 2023 B/MB -- without the bytes of the
-        # tiled -> raster pass, which is this implementation's extra pass, not part of the algorithm
-        survey_gbps = (B_RECON + B_LF + B_EXTEND) * nmb * F / (elapsed / K) / 1e9
+        # SURVEY.md 8(d)'s own figure for the full key-frame path: 1217 + 770 + 36 = 2023 B/MB
+        survey_gbps = (B_RECON + B_LF + B_EXTEND) * nmb * F / (elapsed_local / K) / 1e9
         pmc = PMC_TRAFFIC_B_PER_MB_DETILE if detile else PMC_TRAFFIC_B_PER_MB
+        counted = lane and args.workload == "1080p"
         out = {
             "metric": "vp8_decode_pixel_path_mpix_per_s",
             "value": round(total_pix / elapsed / 1e6, 1),
@@ -317,14 +410,17 @@ def main():
             "dtype": "u8",
             "data": "synthetic",
             "config": {
-                "workload": f"{W}x{H} all-key-frame VP8 stream (tests/golden/{fixture}.ivf looped), full pixel "
-                            f"path: dequant+IDCT/WHT + intra recon + loop filter + border extend "
-                            f"(BASELINE configs[1]+[3]); IR resident in HBM, MD5-checked vs the reference",
+                "workload": f"{W}x{H} all-key-frame VP8 stream (tests/golden/{fixture}.ivf looped to {world * F} frames), full "
+                            f"pixel path: dequant+IDCT/WHT + intra recon + loop filter + border extend "
+                            f"(BASELINE configs[1]+[3]{'+[4]' if args.workload == '4k' else ''}); IR resident in HBM, MD5-checked vs the reference",
                 "frames_per_gpu_per_step": F,
                 "macroblocks_per_frame": nmb,
-                "parallelism": f"frame-parallel, {world} GPU(s), no pixel exchange",
+                "parallelism": f"one stream of {world * F} frames sharded in contiguous blocks over {world} GPU(s) (rank r: frames "
+                               f"[r*{F}, (r+1)*{F})), no pixel exchange; RCCL carries barriers, times and the MD5 listing",
+                "per_rank_Mpix_s": [round(F * K * W * H / t / 1e6, 1) for t in per_rank],
+                "sharded_md5_listing_equals_1gpu_listing": listing_ok,
+                "md5_checked_frames_per_rank": len(sample),
                 "kernel_ms": {k: round(v, 4) for k, v in ms.items()},
-                "kernel_ms_launched_alone": {k: round(v, 4) for k, v in ms_alone.items()},
                 "kernel_family": "one macroblock row per lane, macroblock-tiled scratch frames" if lane
                                  else "one wave per macroblock row",
                 "kernels": names,
@@ -340,25 +436,50 @@ def main():
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 5),
-                "traffic": round(pmc[dom] * nmb * F) if lane and args.workload == "1080p" else None,
-                "traffic_note": "HBM bytes per launch = per-macroblock FETCH_SIZE x2 + WRITE_SIZE of the same kernel measured "
-                                "with rocprofv3 --pmc at 1024 frames per launch (profiles/r01_g_pmc_*.csv) x macroblocks "
-                                "per launch; null for configurations that were not counted",
-                "traffic_bytes_per_macroblock": ({k: round(v, 1) for k, v in pmc.items()}
-                                                 if lane and args.workload == "1080p" else None),
+                "traffic": round(pmc[dom] * nmb * F) if counted else None,
+                "traffic_source": ("scaled: per-macroblock FETCH_SIZE x2 + WRITE_SIZE of this kernel from rocprofv3 --pmc passes at "
+                                   "1024 frames per launch (profiles/), times the macroblocks of this launch") if counted else None,
+                "traffic_bytes_per_macroblock": ({k: round(v, 1) for k, v in pmc.items()} if counted else None),
                 "algorithmic_bytes_per_launch": bytes_per_launch[dom],
                 "mean_launch_ms": round(ms[dom], 4),
                 "all_kernels_GBps": {k: round(bytes_per_launch[k] / (ms[k] * 1e-3) / 1e9, 2) if ms[k] > 0 else None
                                      for k in ms},
                 "pipeline": {"achieved": round(survey_gbps, 2), "frac": round(survey_gbps / HBM_PEAK_GBPS, 5),
                              "note": "SURVEY 8(d) bytes of the whole path (recon + loop filter + border extend = 2023 B/MB) / "
-                                     "whole step time",
-                             "achieved_counting_own_detile_pass": round(pipeline_gbps, 2),
-                             "frac_counting_own_detile_pass": round(pipeline_gbps / HBM_PEAK_GBPS, 5)},
+                                     "whole step time, one GPU"},
                 "device_copy_probe_GBps": round(copy_gbps, 1) if copy_gbps else None,
             },
         }
-        ctx.close()
+        if world == 1 and args.workload == "1080p" and not args.no_4k_probe:
+            # BASELINE configs[4]'s stream on one GPU: 3840x2160 all-key-frame, same path, measured the same way
+            try:
+                fx4, W4, H4 = WORKLOADS["4k"]
+                F4 = 2048
+                c4 = P.Vp8Hip(local_rank)
+                c4.configure(W4, H4, F4, F4)
+                ns4, _ = load_stream(P, c4, fx4, F4, 0)
+                j4 = (P.Job * F4)()
+                for i in range(F4):
+                    j4[i].ir_slot, j4[i].dst_fb = i, i
+                    for k in range(4):
+                        j4[i].ref_fb[k] = -1
+                g4 = golden_md5(fx4)
+                c4.decode_array(j4, F4, P.STAGE_ALL); c4.sync()
+                ok4 = all(P.planes_md5(*c4.download_planes(i)) == g4[i % ns4] for i in (0, 1, 2, 777, F4 // 2, F4 - 1))
+
+                def b4():
+                    torch.cuda.synchronize()
+                    c4.sync()
+                e4, ms4, _ = timed_steps(P, c4, j4, F4, 3, 1, b4)
+                gb4 = (B_RECON + B_LF + B_EXTEND) * c4.nmb * F4 / (e4 / 3) / 1e9
+                out["config"]["workload_4k"] = {
+                    "workload": f"{W4}x{H4} all-key-frame stream ({fx4}.ivf looped), {F4} frames per step, 3 steps",
+                    "md5_ok": bool(ok4), "Mpix_s": round(F4 * 3 * W4 * H4 / e4 / 1e6, 1), "ms_per_step": round(e4 / 3 * 1e3, 3),
+                    "kernel_ms": {k: round(v, 4) for k, v in ms4.items()},
+                    "roofline_pipeline": {"achieved": round(gb4, 2), "frac": round(gb4 / HBM_PEAK_GBPS, 5), "unit": "GB/s"}}
+                c4.close()
+            except Exception as ex:      # a probe, not the benchmark: report, do not fail the line
+                out["config"]["workload_4k"] = {"error": repr(ex)}
         if world == 1 and args.workload == "1080p" and not args.no_inter_probe:
             try:
                 out["config"]["inter_frames"] = inter_frame_probe(P, local_rank)
@@ -375,8 +496,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:      # the contract: rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(fixture)
         print(json.dumps(out))
-    else:
-        ctx.close()
+        sys.stdout.flush()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -28,3 +28,17 @@ def gather_digests(dist, local_hex, nframes, device=None):
         rows = bufs[r].cpu().numpy()
         out += [bytes(rows[i].tolist()).hex() for i in range(hi - lo)]
     return out
+
+
+def sharded_listing(dist, nframes, decode_block, device=None):
+    """The multi-GPU decode of one all-key-frame stream of `nframes` frames (every rank seeks the
+    same IVF by frame index, vpxdec.c:266-318): this rank decodes its contiguous block -- `decode_block(lo, hi)`
+    returns the MD5 hex digests of frames lo .. hi-1 in order -- and the digests are all-gathered into the
+    ordered `decode_to_md5` listing of the whole stream, identical on every rank.  bench.py calls this over RCCL
+    with the HIP pixel path behind `decode_block`, tests/test_sharding_cpu.py over gloo with the oracle."""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    lo, hi = shard_range(nframes, world, rank)
+    local = decode_block(lo, hi)
+    if len(local) != hi - lo:
+        raise RuntimeError(f"rank {rank}: decode_block({lo}, {hi}) returned {len(local)} digests")
+    return gather_digests(dist, local, nframes, device=device)

@@ -96,6 +96,10 @@ FIXTURES = {
     # (4) 1080p key + 9 inter frames, 6-tap MC, normal LF
     "p_1920x1080": (1920, 1080, 10, 7, 6, INTER + ["--good", "--cpu-used=5", "--end-usage=cq", "--cq-level=20",
                                                     "--target-bitrate=8000"]),
+    # (4b) the same kind of stream at a quality where the P frames carry real residuals (a third or more of their blocks with
+    # more than a DC coefficient, most macroblocks inter with fractional MVs): the throughput probe of BASELINE configs[2]
+    "p_dense_1920x1080": (1920, 1080, 4, 9, 10, INTER + ["--good", "--cpu-used=4", "--end-usage=cq", "--cq-level=28",
+                                                          "--min-q=20", "--max-q=50", "--target-bitrate=200000"]),
     # (5) profiles 1-3 (bilinear MC / simple LF / full-pixel), SPLITMV, 4 token partitions
     "p_prof1_640x360": (640, 360, 10, 21, 8, INTER + ["--good", "--cpu-used=0", "--profile=1", "--token-parts=2",
                                                        "--target-bitrate=1500"]),

@@ -22,18 +22,21 @@ def _worker(rank, world, port, name, q):
     P = load_package()
     from libvpx_opencl_amd import sharding
     w, h, frames = P.read_ivf(ivf_path(name))
-    lo, hi = sharding.shard_range(len(frames), world, rank)
-    local = []
     g = P.geom(w, h)
-    for data in frames[lo:hi]:                      # all key frames: each shard is self-contained
-        parser = P.Parser()
-        hdr, _, mbs, coef, mvs = P.parse_to_numpy(parser, data)
-        buf = np.zeros(g.frame_size, np.uint8)
-        oracle_decode(hdr, mbs, coef, mvs, buf, (None, None, None))
-        local.append(P.frame_md5(buf, g, w, h))
-        parser.close()
+
+    def decode_block(lo, hi):                       # all key frames: each shard is self-contained
+        out = []
+        for data in frames[lo:hi]:
+            parser = P.Parser()
+            hdr, _, mbs, coef, mvs = P.parse_to_numpy(parser, data)
+            buf = np.zeros(g.frame_size, np.uint8)
+            oracle_decode(hdr, mbs, coef, mvs, buf, (None, None, None))
+            out.append(P.frame_md5(buf, g, w, h))
+            parser.close()
+        return out
+
     dist.barrier()
-    full = sharding.gather_digests(dist, local, len(frames))
+    full = sharding.sharded_listing(dist, len(frames), decode_block)      # the code path bench.py --gpus N runs over RCCL
     if rank == 0:
         q.put(full)
     dist.barrier()
