@@ -325,6 +325,7 @@ vp8_loopfilter_simt_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g
 
     // ---- per-lane row state
     g_cu32p mbp = nullptr;
+    u32 nx_w0 = 0, nx_w1 = 0;                   // descriptor words 0, 1 of the macroblock after the current one, fetched a step ahead
     g_u8p trow = nullptr;                        // tile (r, 0)
     g_u8p rasY = nullptr, rasU = nullptr, rasV = nullptr;   // raster == 1: pixel (0,0) of MB row r in the frame buffer
     const DevJob *job = jobs;
@@ -384,14 +385,17 @@ vp8_loopfilter_simt_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g
                 lf_on = h.filter_level != 0;
                 simple = h.filter_type == 1;
                 mbp = (g_cu32p)(job->mbs + (long)r * cols);
+                nx_w0 = mbp[0]; nx_w1 = mbp[1];
                 trow = (g_u8p)(job->tile + (long)r * rowbytes);
                 rasY = (g_u8p)(job->dst + g.y_off + (long)r * 16 * g.y_stride);
                 rasU = (g_u8p)(job->dst + g.u_off + (long)r * 8 * g.uv_stride);
                 rasV = (g_u8p)(job->dst + g.v_off + (long)r * 8 * g.uv_stride);
             }
+            // (the descriptor was fetched a step ago: the tile loads below go out at once instead of behind a memory round trip)
+            const u32 w0 = nx_w0, w1 = nx_w1;
+            nx_w0 = mbp[16]; nx_w1 = mbp[17];     // (past the end of a row: the next row's first macroblock, or padding -- unused)
             if (lf_on || raster) {      // raster output: an unfiltered frame is still carried from the scratch to its frame buffer
             const vp8ir_frame_hdr &h = job->hdr;
-            const u32 w0 = mbp[0], w1 = mbp[1];
             const int y_mode = w0 & 0xff, ref_frame = (w0 >> 16) & 0xff;
             const u32 flags = w0 >> 24;
             const int level = mb_level(h, w1 & 3, ref_frame & 3, y_mode);
