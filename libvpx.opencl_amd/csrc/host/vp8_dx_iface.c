@@ -38,6 +38,11 @@ struct vpx_codec_alg_priv {
     int                     fb_corrupted[4];
     int                     show_corrupted;
     int                     ref_updates, ref_used;
+    /* VPX_CODEC_USE_INPUT_FRAGMENTS: the pieces of the frame being collected (borrowed until the flush call, like the
+       reference's pbi->fragments, onyxd_if.c:336-366) */
+    const uint8_t          *frag[9];
+    size_t                  frag_sz[9];
+    int                     num_frags;
     char                    detail[160];
     double                  t_parse, t_launch, t_down;   /* VP8HIP_TRACE: seconds per phase of vp8_decode */
     long                    t_frames;
@@ -145,7 +150,7 @@ static vpx_codec_err_t vp8_decode(vpx_codec_alg_priv_t *p, const uint8_t *data, 
     int16_t *h_coef;
     vp8ir_mv *h_mvs;
     vp8hip_job job;
-    int rc, corrupt = 0, i, nmb;
+    int rc, corrupt = 0, i, nmb, nfrags;
     double t0, t1, t2;
     (void)deadline;
 
@@ -172,15 +177,34 @@ static vpx_codec_err_t vp8_decode(vpx_codec_alg_priv_t *p, const uint8_t *data, 
     }
     if (!p->hip) return set_detail(p, VPX_CODEC_ERROR, "HIP pixel path unavailable (no CPU fallback)");
 
-    if (data == NULL && data_sz == 0) {
-        /* missing frame (onyxd_if.c:375-407): mark the last reference corrupt, nothing to show */
-        p->fb_corrupted[p->refs.lst_idx] = 1;
+    if ((p->base.init_flags & VPX_CODEC_USE_INPUT_FRAGMENTS) && !(data == NULL && data_sz == 0)) {
+        /* a piece of a frame: remember it and wait for the rest (onyxd_if.c:343-361) */
+        if (p->num_frags >= 9) {
+            p->num_frags = 0;
+            return set_detail(p, VPX_CODEC_UNSUP_BITSTREAM, "Too many fragments");
+        }
+        p->frag[p->num_frags] = data;
+        p->frag_sz[p->num_frags] = data_sz;
+        p->num_frags++;
         return VPX_CODEC_OK;
     }
+    if (!(p->base.init_flags & VPX_CODEC_USE_INPUT_FRAGMENTS)) {
+        p->frag[0] = data;
+        p->frag_sz[0] = data_sz;
+        p->num_frags = data ? 1 : 0;
+    }
+    if (p->num_frags == 0 || (p->num_frags == 1 && p->frag_sz[0] == 0)) {
+        /* missing frame (onyxd_if.c:375-407): mark the last reference corrupt, nothing to show */
+        p->fb_corrupted[p->refs.lst_idx] = 1;
+        p->num_frags = 0;
+        return VPX_CODEC_OK;
+    }
+    nfrags = p->num_frags;
+    p->num_frags = 0;                                 /* whatever happens below, the next call starts a new frame */
 
     if (vp8_refs_get_free(&p->refs) < 0) return set_detail(p, VPX_CODEC_ERROR, "no free frame buffer");
     t0 = now_s();
-    rc = vp8_parser_begin_frame(p->parser, data, data_sz, &hdr);
+    rc = vp8_parser_begin_frame_fragments(p->parser, p->frag, p->frag_sz, nfrags, &hdr);
     if (rc) {
         vp8_refs_release_new(&p->refs);
         return set_detail(p, (vpx_codec_err_t)rc, vp8_parser_error(p->parser));
@@ -188,12 +212,17 @@ static vpx_codec_err_t vp8_decode(vpx_codec_alg_priv_t *p, const uint8_t *data, 
     if (hdr.width != p->width || hdr.height != p->height) {       /* vp8_alloc_frame_buffers */
         if (vp8hip_configure(p->hip, hdr.width, hdr.height, 4, 1)) {
             vp8_refs_release_new(&p->refs);
+            p->width = p->height = 0;
             return gpu_error(p, "vp8hip_configure");
         }
         vp8hip_geometry(p->hip, &p->geom);
         vp8hip_host_free(p->hip, p->host_frame);
         p->host_frame = (uint8_t *)vp8hip_host_alloc(p->hip, (size_t)p->geom.frame_size);
-        if (!p->host_frame) return VPX_CODEC_MEM_ERROR;
+        if (!p->host_frame) {
+            vp8_refs_release_new(&p->refs);
+            p->width = p->height = 0;                 /* the next frame allocates again */
+            return VPX_CODEC_MEM_ERROR;
+        }
         p->width = hdr.width;
         p->height = hdr.height;
         p->si.w = hdr.width;
@@ -201,7 +230,10 @@ static vpx_codec_err_t vp8_decode(vpx_codec_alg_priv_t *p, const uint8_t *data, 
         vp8_refs_on_alloc(&p->refs);
         memset(p->fb_corrupted, 0, sizeof p->fb_corrupted);
     }
-    if (vp8hip_ir_map(p->hip, 0, &h_hdr, &h_mbs, &h_coef, &h_mvs)) return gpu_error(p, "vp8hip_ir_map");
+    if (vp8hip_ir_map(p->hip, 0, &h_hdr, &h_mbs, &h_coef, &h_mvs)) {
+        vp8_refs_release_new(&p->refs);
+        return gpu_error(p, "vp8hip_ir_map");
+    }
     rc = vp8_parser_decode_mbs(p->parser, h_mbs, h_coef, h_mvs, &corrupt);
     if (rc) {
         vp8_refs_release_new(&p->refs);
@@ -236,6 +268,7 @@ static vpx_codec_err_t vp8_decode(vpx_codec_alg_priv_t *p, const uint8_t *data, 
     job.ref_fb[VP8IR_ALTREF_FRAME] = p->refs.alt_idx;
     if (vp8_decode_frame_pixels(p->hip, &job, 1)) { vp8_refs_release_new(&p->refs); return gpu_error(p, "vp8hip_decode"); }
 
+    /* (swap_frame_buffers, onyxd_if.c:261-316, gives the new buffer's reference back even when it reports bad copy flags) */
     if (vp8_refs_swap(&p->refs, &hdr)) return set_detail(p, VPX_CODEC_ERROR, "invalid buffer copy flags");
     p->show_corrupted = p->fb_corrupted[p->refs.show_idx];
 
@@ -360,7 +393,7 @@ static vpx_codec_ctrl_fn_map_t vp8_ctf_maps[] = {
 const struct vpx_codec_iface vpx_codec_vp8_dx_algo = {
     "MI355X HIP VP8 Decoder (gfx950) " "v1.0.0",
     VPX_CODEC_INTERNAL_ABI_VERSION,
-    VPX_CODEC_CAP_DECODER | VP8_CAP_POSTPROC,
+    VPX_CODEC_CAP_DECODER | VP8_CAP_POSTPROC | VPX_CODEC_CAP_INPUT_FRAGMENTS,
     vp8_init,
     vp8_destroy,
     vp8_ctf_maps,

@@ -164,8 +164,20 @@ static int read_signed(vp8_boolreader *br, int nbits)
  * ---------------------------------------------------------------------------------------- */
 int vp8_parser_begin_frame(vp8_parser *p, const uint8_t *data, size_t size, vp8ir_frame_hdr *out)
 {
+    return vp8_parser_begin_frame_fragments(p, &data, &size, 1, out);
+}
+
+/* read_is_valid (decodframe.c:445-449) */
+static int span_ok(const uint8_t *start, size_t len, const uint8_t *end) { return start + len > start && start + len <= end; }
+
+int vp8_parser_begin_frame_fragments(vp8_parser *p, const uint8_t *const *frags, const size_t *frag_sizes, int nfrags,
+                                     vp8ir_frame_hdr *out)
+{
     vp8ir_frame_hdr *h = &p->hdr;
     vp8_boolreader *br = &p->first;
+    /* the frame header and the first partition are read from the first fragment only (decodframe.c:695-697) */
+    const uint8_t *data = nfrags > 0 ? frags[0] : NULL;
+    const size_t size = nfrags > 0 ? frag_sizes[0] : 0;
     const uint8_t *end = data + size;
     const uint8_t *cur = data;
     size_t first_len;
@@ -276,25 +288,56 @@ int vp8_parser_begin_frame(vp8_parser *p, const uint8_t *data, size_t size, vp8i
         }
     }
 
-    /* token partitions (setup_token_decoder, decodframe.c:501-592; single-fragment input) */
+    /* token partitions (setup_token_decoder, decodframe.c:501-592): the fragments are unpacked so that entry k of F / S is
+       partition k (k = 0: header + first partition + size table); a fragment may hold several partitions, the sizes of all but
+       the last come from the table, every one is checked against the end of the fragment it lies in */
     {
         int log2n = vp8br_literal(br, 2);
-        int n = 1 << log2n;
+        int n = 1 << log2n, fi;
         const uint8_t *sizes = data + 3 + (is_key ? 7 : 0) + first_len;
-        const uint8_t *part;
-        if (sizes > end || (size_t)(end - sizes) < (size_t)(3 * (n - 1)))
-            return fail(p, VP8P_CORRUPT_FRAME, "Truncated partition size data");
-        part = sizes + 3 * (n - 1);
-        for (i = 0; i < n; i++) {
-            size_t left = (size_t)(end - part), len = left;
-            if (i < n - 1) {
-                len = (size_t)(sizes[3 * i] | (sizes[3 * i + 1] << 8) | (sizes[3 * i + 2] << 16));
-                if (len > left)
-                    return fail(p, VP8P_CORRUPT_FRAME, "Truncated packet or corrupt partition length");
+        const uint8_t *F[10];
+        size_t S[10];
+        if (nfrags > 9)
+            return fail(p, VP8P_UNSUP_BITSTREAM, "Too many fragments");
+        memset(F, 0, sizeof F);
+        memset(S, 0, sizeof S);
+        for (i = 0; i < nfrags; i++) { F[i] = frags[i]; S[i] = frag_sizes[i]; }
+        for (fi = 0; fi < nfrags && fi <= n; fi++) {
+            size_t left = S[fi];
+            const uint8_t *fend = F[fi] + left;
+            if (fi == 0) {
+                const size_t ext_first = (size_t)(sizes - F[0]) + (size_t)(3 * (n - 1));   /* first partition + the size table */
+                if (sizes > end || ext_first > left)
+                    return fail(p, VP8P_CORRUPT_FRAME, "Truncated partition size data");
+                left -= ext_first;
+                if (left > 0) {                 /* the fragment goes on with token partitions */
+                    S[0] = ext_first;
+                    fi++;
+                    F[fi] = F[0] + ext_first;
+                }
             }
-            vp8br_init(&p->tok[i], part, len);
-            part += len;
+            while (left > 0) {
+                /* read_available_partition_size (decodframe.c:456-497), partition fi - 1 */
+                const int k = fi - 1;
+                size_t len = (size_t)(fend - F[fi]);
+                if (k < n - 1) {
+                    if (!span_ok(sizes + 3 * k, 3, end))
+                        return fail(p, VP8P_CORRUPT_FRAME, "Truncated partition size data");
+                    len = (size_t)(sizes[3 * k] | (sizes[3 * k + 1] << 8) | (sizes[3 * k + 2] << 16));
+                }
+                if (!span_ok(F[fi], len, fend))
+                    return fail(p, VP8P_CORRUPT_FRAME, "Truncated packet or corrupt partition length");
+                S[fi] = len;
+                left -= len;
+                if (left > 0) {
+                    if (fi >= n)                /* more bytes than partitions: the reference asserts here */
+                        return fail(p, VP8P_CORRUPT_FRAME, "Truncated packet or corrupt partition length");
+                    fi++;
+                    F[fi] = F[fi - 1] + len;
+                }
+            }
         }
+        for (i = 0; i < n; i++) vp8br_init(&p->tok[i], F[i + 1], S[i + 1]);     /* (a partition that never came: empty, the frame turns out corrupt) */
         p->num_tok = n;
         h->num_token_partitions = (uint8_t)n;
     }

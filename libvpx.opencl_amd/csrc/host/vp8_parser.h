@@ -40,6 +40,11 @@ int vp8_parser_peek(const uint8_t *data, size_t size, int *is_key, int *width, i
  * Fills *hdr.  On a key frame with new dimensions the parser re-allocates its per-MB state.
  * `data` must stay valid until vp8_parser_decode_mbs returns. */
 int vp8_parser_begin_frame(vp8_parser *p, const uint8_t *data, size_t size, vp8ir_frame_hdr *hdr);
+/* The same for a frame handed over in pieces (VPX_CODEC_USE_INPUT_FRAGMENTS: vp8dx_receive_compressed_data,
+ * vp8/decoder/onyxd_if.c:336-366; setup_token_decoder, vp8/decoder/decodframe.c:501-592): frags[0] holds the frame header and
+ * the first partition (and possibly more), each further fragment one or several whole token partitions. */
+int vp8_parser_begin_frame_fragments(vp8_parser *p, const uint8_t *const *frags, const size_t *frag_sizes, int nfrags,
+                                     vp8ir_frame_hdr *hdr);
 
 /* Step 2: per-MB modes / motion vectors (first partition) and coefficient tokens (token
  * partitions) for the frame opened by begin_frame, written to caller-owned arrays sized for

@@ -145,7 +145,39 @@ def stream_md5(name):
         f.write(r.stdout.split()[0] + "\n")
 
 
+def ref_controls(name):
+    """What the REFERENCE decoder answers, packet by packet, to VP8D_GET_LAST_REF_UPDATES, VP8D_GET_LAST_REF_USED and
+    VP8D_GET_FRAME_CORRUPTED (vp8/vp8_dx_iface.c:653-720), through its public API in oracle/_ref/libvpxref.so."""
+    import ctypes
+    L = ctypes.CDLL(os.path.join(REFDIR, "libvpxref.so"))
+    L.vpx_codec_vp8_dx.restype = ctypes.c_void_p
+    L.vpx_codec_dec_init_ver.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_long, ctypes.c_int]
+    L.vpx_codec_decode.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_uint, ctypes.c_void_p, ctypes.c_long]
+    L.vpx_codec_control_.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+    data = open(os.path.join(HERE, name + ".ivf"), "rb").read()
+    pos, frames = 32, []
+    while pos + 12 <= len(data):
+        sz = int.from_bytes(data[pos:pos + 4], "little")
+        frames.append(data[pos + 12:pos + 12 + sz])
+        pos += 12 + sz
+    ctx = ctypes.create_string_buffer(256)
+    assert L.vpx_codec_dec_init_ver(ctx, L.vpx_codec_vp8_dx(), None, 0, 2 + 2 + 1) == 0
+    with open(os.path.join(HERE, name + ".refctl"), "w") as f:
+        f.write("# packet  VP8D_GET_LAST_REF_UPDATES  VP8D_GET_LAST_REF_USED  VP8D_GET_FRAME_CORRUPTED  (reference decoder)\n")
+        for i, fr in enumerate(frames):
+            assert L.vpx_codec_decode(ctx, fr, len(fr), None, 0) == 0
+            v = [ctypes.c_int(-1) for _ in range(3)]
+            for k, ctl in enumerate((256, 258, 257)):     # VP8D_GET_LAST_REF_UPDATES, VP8D_GET_LAST_REF_USED, VP8D_GET_FRAME_CORRUPTED (vpx/vp8dx.h:53-61)
+                assert L.vpx_codec_control_(ctx, ctl, ctypes.byref(v[k])) == 0
+            f.write(f"{i} {v[0].value} {v[1].value} {v[2].value}\n")
+    L.vpx_codec_destroy(ctx)
+
+
 def main():
+    if "--ref-controls" in sys.argv:
+        for name in ("p_arf_176x144", "p_split_352x288"):
+            ref_controls(name)
+        return
     if "--stream-md5-only" in sys.argv:
         for name in FIXTURES:
             stream_md5(name)

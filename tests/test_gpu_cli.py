@@ -69,3 +69,17 @@ def test_batch_md5_refuses_inter_frames(tmp_path):
     r = subprocess.run([os.path.join(BIN, "batch_md5"), ivf_path("p_lowrate_640x360"), str(tmp_path / "o")],
                        capture_output=True, text=True)
     assert r.returncode != 0 and "not a key frame" in r.stderr
+
+
+REF_VPXDEC_ON_HIP = os.path.join(ROOT, "oracle", "_ref", "vpxdec_ref_on_hip")
+
+
+@pytest.mark.skipif(not os.path.exists(REF_VPXDEC_ON_HIP), reason="oracle/_ref/vpxdec_ref_on_hip not built (make -C oracle ref)")
+@pytest.mark.parametrize("name", FIXTURES)
+def test_the_references_own_vpxdec_runs_on_the_product(name):
+    """The drop-in claim itself: the REFERENCE's vpxdec.c, compiled unchanged against include/vpx/*.h and linked with
+    libvpx_hip.so instead of the reference's libvpx (oracle/Makefile, rule vpxdec_ref_on_hip), prints the reference
+    decoder's `--md5 --i420` digest for every fixture (vpxdec.c:322-383)."""
+    r = subprocess.run([REF_VPXDEC_ON_HIP, "--md5", "--i420", ivf_path(name)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.split()[0] == open(os.path.join(GOLDEN, name + ".vpxdec_md5")).read().strip()

@@ -1,5 +1,7 @@
 """GPU (-m gpu): the vpx_codec API of libvpx_hip.so called directly (ctypes), for the parts the command line
-tools do not reach: VP8_COPY_REFERENCE / VP8_SET_REFERENCE (vp8/vp8_dx_iface.c:611-651 in the reference)."""
+tools do not reach: VP8_COPY_REFERENCE / VP8_SET_REFERENCE (vp8/vp8_dx_iface.c:611-651 in the reference),
+VP8D_GET_LAST_REF_UPDATES / _USED / VP8D_GET_FRAME_CORRUPTED (:653-720) and VPX_CODEC_USE_INPUT_FRAGMENTS
+(:416-417; vp8/decoder/onyxd_if.c:336-366, decodframe.c:501-592)."""
 import ctypes
 import hashlib
 import os
@@ -92,4 +94,66 @@ def test_copy_and_set_reference():
     for i in range(4, len(frames)):
         decode(i)
     L.vpx_img_free(ctypes.byref(ref.img))
+    L.vpx_codec_destroy(ctx)
+
+
+VP8D_GET_LAST_REF_UPDATES, VP8D_GET_FRAME_CORRUPTED, VP8D_GET_LAST_REF_USED = 256, 257, 258
+VPX_CODEC_USE_INPUT_FRAGMENTS = 0x40000
+
+
+@pytest.mark.parametrize("name", ["p_arf_176x144", "p_split_352x288"])
+def test_last_ref_controls_answer_like_the_reference(name):
+    """Packet by packet (hidden alt-ref frames included) the three read-only decoder controls give what the reference
+    decoder gave for the same stream: tests/golden/<name>.refctl, recorded from oracle/_ref/libvpxref.so by
+    tests/golden/make_fixtures.py --ref-controls."""
+    P = load_package()
+    _, _, frames = P.read_ivf(ivf_path(name))
+    want = [tuple(int(v) for v in l.split()[1:]) for l in open(os.path.join(ROOT, "tests", "golden", name + ".refctl")) if l[0] != "#"]
+    assert len(want) == len(frames)
+    L = _lib()
+    ctx = ctypes.create_string_buffer(256)
+    assert L.vpx_codec_dec_init_ver(ctx, L.vpx_codec_vp8_dx(), None, 0, VPX_DECODER_ABI_VERSION) == 0
+    for i, fr in enumerate(frames):
+        assert L.vpx_codec_decode(ctx, fr, len(fr), None, 0) == 0
+        got = []
+        for ctl in (VP8D_GET_LAST_REF_UPDATES, VP8D_GET_LAST_REF_USED, VP8D_GET_FRAME_CORRUPTED):
+            v = ctypes.c_int(-1)
+            assert L.vpx_codec_control_(ctx, ctl, ctypes.byref(v)) == 0
+            got.append(v.value)
+        assert tuple(got) == want[i], (i, got, want[i])
+    L.vpx_codec_destroy(ctx)
+
+
+@pytest.mark.parametrize("name,how", [("p_prof1_640x360", "each"), ("p_split_352x288", "each"), ("p_split_352x288", "header+rest"),
+                                      ("kf_640x360", "each"), ("p_odd_130x98", "whole")])
+def test_input_fragments(name, how):
+    """VPX_CODEC_USE_INPUT_FRAGMENTS: the frame arrives as several vpx_codec_decode calls (one partition per call; header and first
+    partition, then all token partitions in one call, which have to be unpacked; or the whole frame as one fragment) and is decoded by the flushing call
+    (NULL, 0): every shown frame equals the reference MD5, and nothing is shown before the flush."""
+    P = load_package()
+    _, _, frames = P.read_ivf(ivf_path(name))
+    gold = golden_md5(name)
+    L = _lib()
+    ctx = ctypes.create_string_buffer(256)
+    assert L.vpx_codec_dec_init_ver(ctx, L.vpx_codec_vp8_dx(), None, VPX_CODEC_USE_INPUT_FRAGMENTS, VPX_DECODER_ABI_VERSION) == 0
+    from test_fragments_cpu import cuts_for_stream
+    shown = 0
+    for fr, c in zip(frames, cuts_for_stream(P, frames)):
+        parts = [fr[a:b] for a, b in zip(c[:-1], c[1:])]
+        if how == "header+rest":
+            parts = [parts[0], b"".join(parts[1:])]
+        elif how == "whole":
+            parts = [fr]
+        keep = [ctypes.create_string_buffer(p, len(p)) for p in parts]       # borrowed by the decoder until the flush
+        for k in keep:
+            assert L.vpx_codec_decode(ctx, ctypes.cast(k, ctypes.c_char_p), len(k), None, 0) == 0
+            it = ctypes.c_void_p()
+            assert not L.vpx_codec_get_frame(ctx, ctypes.byref(it))
+        assert L.vpx_codec_decode(ctx, None, 0, None, 0) == 0
+        it = ctypes.c_void_p()
+        img = L.vpx_codec_get_frame(ctx, ctypes.byref(it))
+        if img:
+            assert _md5(img.contents) == gold[shown], shown
+            shown += 1
+    assert shown == len(gold)
     L.vpx_codec_destroy(ctx)
