@@ -51,6 +51,16 @@ enum { VP8IR_INTRA_FRAME = 0, VP8IR_LAST_FRAME, VP8IR_GOLDEN_FRAME, VP8IR_ALTREF
 #define VP8IR_MB_CLAMP  0x02u   /* need_to_clamp_mvs (decodemv.c:293,505) */
 
 #define VP8IR_COEF_PER_MB 400
+
+/* Sparse coefficient streams (the host -> device form of `coef`; the kernels always read the dense array).  Two of them, in
+ * macroblock order and block order 0..24 inside a macroblock:
+ *   blocks: the 16-coefficient blocks with more than one coded position, 32 bytes each;
+ *   dcs:    one int16 for every block whose only coded coefficient is its first (eob == 1, token decode started at 0).
+ * Which kind a block is follows from the descriptor alone (vp8ir_block_kind): a luma block of a macroblock with Y2 starts its
+ * token decode at position 1 (detokenize.c:361), so it has coefficients only if eob > 1; any other block is a DC with eob == 1
+ * and a full block with eob > 1; nothing in a skipped macroblock.  vp8ir_mb::sparse_first / dc_first locate a macroblock's
+ * first entry in either stream.  On the 1080p benchmark stream, descriptors included: 0.37 of the dense form's bytes (3.4 B per pixel dense), which
+ * is what PCIe and the host memory system -- not the GPU -- limit an all-key-frame pipeline by. */
 #define VP8IR_BORDER 32         /* VP8BORDERINPIXELS (vpx_scale/yv12config.h:20) */
 
 typedef struct vp8ir_mb {       /* 64 bytes */
@@ -65,7 +75,8 @@ typedef struct vp8ir_mb {       /* 64 bytes */
                                    Y blocks of an MB that has a Y2 block start at 1 */
     uint8_t rsv1[7];
     uint8_t b_modes[16];        /* B_PRED only */
-    uint8_t rsv2[8];
+    uint32_t sparse_first;      /* sparse coefficient streams only: index of this MB's first entry in `blocks` ... */
+    uint32_t dc_first;          /* ... and in `dcs` */
 } vp8ir_mb;
 
 typedef struct vp8ir_mv {       /* MV (vp8/common/mv.h:16-26): 1/8-pel units as stored by decodemv.c:112 */
@@ -101,6 +112,21 @@ typedef struct vp8ir_frame_hdr { /* 64 bytes */
     uint8_t  num_token_partitions;
     uint8_t  rsv[15];
 } vp8ir_frame_hdr;
+
+#if defined(__HIPCC__)
+#define VP8IR_INLINE __host__ __device__ static inline       /* the one helper the device side shares with the host */
+#else
+#define VP8IR_INLINE static inline
+#endif
+/* 0: block k of the macroblock has no coefficients, 1: only its first (in `dcs`), 2: a full block (in `blocks`) */
+VP8IR_INLINE int vp8ir_block_kind(const vp8ir_mb *m, int k)
+{
+    const int has_y2 = m->y_mode != VP8IR_B_PRED && m->y_mode != VP8IR_SPLITMV;
+    if (m->flags & VP8IR_MB_SKIP) return 0;
+    if (k == 24 && !has_y2) return 0;
+    if (m->eobs[k] > 1) return 2;
+    return (m->eobs[k] == 1 && !(has_y2 && k < 16)) ? 1 : 0;
+}
 
 typedef char vp8ir_static_assert_mb[(sizeof(vp8ir_mb) == 64) ? 1 : -1];
 typedef char vp8ir_static_assert_hdr[(sizeof(vp8ir_frame_hdr) == 64) ? 1 : -1];

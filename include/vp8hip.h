@@ -80,6 +80,15 @@ int  vp8hip_ir_map(vp8hip_ctx *ctx, int slot, vp8ir_frame_hdr **hdr, vp8ir_mb **
                    int16_t **coef, vp8ir_mv **mvs);
 /* Asynchronous H2D copy of one slot on the context's stream (mvs only for inter frames). */
 int  vp8hip_ir_upload(vp8hip_ctx *ctx, int slot);
+/* The same two steps with the coefficients as the SPARSE streams of include/vp8_ir.h (full blocks and lone DCs of the blocks
+ * that have coefficients at all: about a third of the dense form's bytes over PCIe on real streams): `blocks` is pinned
+ * staging for up to *cap_blocks blocks of 16 int16 (it shares its memory with the dense `coef` staging of vp8hip_ir_map: a slot
+ * is filled one way or the other), `dcs` for 25 int16 per macroblock; vp8hip_ir_upload_sparse copies header, descriptors (whose
+ * sparse_first / dc_first fields locate each macroblock's entries), nblocks blocks, ndcs DCs and, for inter frames, the MVs,
+ * and expands the streams into the slot's dense coefficient array on the device.  Asynchronous, on the context's stream. */
+int  vp8hip_ir_map_sparse(vp8hip_ctx *ctx, int slot, vp8ir_frame_hdr **hdr, vp8ir_mb **mbs, int16_t **blocks,
+                          size_t *cap_blocks, int16_t **dcs, vp8ir_mv **mvs);
+int  vp8hip_ir_upload_sparse(vp8hip_ctx *ctx, int slot, size_t nblocks, size_t ndcs);
 /* Device-to-device replication of an uploaded slot (synthetic looped streams: every key frame
  * is independently decodable, decodframe.c:610-639). */
 int  vp8hip_ir_copy(vp8hip_ctx *ctx, int dst_slot, int src_slot);
@@ -93,6 +102,14 @@ int  vp8hip_decode(vp8hip_ctx *ctx, const vp8hip_job *jobs, int njobs, int stage
  * ((w+1)/2) x ((h+1)/2) (U, V) written with the given destination strides.  Synchronous. */
 int  vp8hip_frame_download(vp8hip_ctx *ctx, int fb, int full, uint8_t *y, uint8_t *u, uint8_t *v,
                            int y_stride, int uv_stride);
+/* Batch form for pipelines (tools/e2e.py, bin/batch_md5): `count` consecutive frame buffers, whole, as ONE asynchronous copy on
+ * a stream of its own -- it starts when everything queued on the context's stream so far has finished and runs beside later
+ * uploads (PCIe is full duplex).  dst: page-locked memory (vp8hip_host_alloc), frame i at dst + i * vp8hip_frame_stride(ctx)
+ * (frame_size rounded up to 256).  vp8hip_download_wait returns when the copy has landed; one copy in flight at a time; a
+ * launch that writes one of these frame buffers waits for it by itself. */
+size_t vp8hip_frame_stride(const vp8hip_ctx *ctx);
+int  vp8hip_frames_download_async(vp8hip_ctx *ctx, int first_fb, int count, uint8_t *dst);
+int  vp8hip_download_wait(vp8hip_ctx *ctx);
 /* Upload a whole frame buffer (frame_size bytes) -- tests and VP8_SET_REFERENCE. */
 int  vp8hip_frame_upload(vp8hip_ctx *ctx, int fb, const uint8_t *buf);
 int  vp8hip_frame_copy(vp8hip_ctx *ctx, int dst_fb, int src_fb);

@@ -151,6 +151,8 @@ def load_host():
         L.vp8_parser_destroy.argtypes = [c_void_p]
         L.vp8_parser_begin_frame.argtypes = [c_void_p, ctypes.c_char_p, c_size_t, c_void_p]
         L.vp8_parser_decode_mbs.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
+        L.vp8_parser_decode_mbs_sparse.argtypes = [c_void_p, c_void_p, c_void_p, c_size_t, ctypes.POINTER(c_size_t), c_void_p,
+                                                   ctypes.POINTER(c_size_t), c_void_p, c_void_p]
         L.vp8_parser_error.argtypes = [c_void_p]
         L.vp8_parser_error.restype = ctypes.c_char_p
         for f in ("vp8_refs_init", "vp8_refs_on_alloc", "vp8_refs_release_new"):
@@ -199,6 +201,16 @@ class Parser:
             raise ValueError(f"vp8 macroblock data error {rc}: {self.L.vp8_parser_error(self.p).decode()}")
         return corrupt.value
 
+    def decode_mbs_sparse(self, mbs_ptr, blocks_ptr, cap_blocks, dcs_ptr, mvs_ptr):
+        """-> (full blocks, lone DCs written to the sparse coefficient streams, corrupt flag)"""
+        corrupt, nb, nd = c_int(0), c_size_t(0), c_size_t(0)
+        rc = self.L.vp8_parser_decode_mbs_sparse(self.p, mbs_ptr, blocks_ptr, cap_blocks, ctypes.byref(nb), dcs_ptr, ctypes.byref(nd),
+                                                 mvs_ptr, ctypes.byref(corrupt))
+        if rc:
+            self.L.vp8_refs_release_new(ctypes.byref(self.refs))
+            raise ValueError(f"vp8 macroblock data error {rc}: {self.L.vp8_parser_error(self.p).decode()}")
+        return nb.value, nd.value, corrupt.value
+
     def swap(self, hdr):
         self.L.vp8_refs_swap(ctypes.byref(self.refs), ctypes.byref(hdr))
 
@@ -234,6 +246,9 @@ def load_hip():
         L.vp8hip_geometry.argtypes = [c_void_p, c_void_p]
         L.vp8hip_ir_map.argtypes = [c_void_p, c_int] + [ctypes.POINTER(c_void_p)] * 4
         L.vp8hip_ir_upload.argtypes = [c_void_p, c_int]
+        L.vp8hip_ir_map_sparse.argtypes = [c_void_p, c_int, ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p),
+                                           ctypes.POINTER(c_size_t), ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p)]
+        L.vp8hip_ir_upload_sparse.argtypes = [c_void_p, c_int, c_size_t, c_size_t]
         L.vp8hip_ir_copy.argtypes = [c_void_p, c_int, c_int]
         L.vp8hip_decode.argtypes = [c_void_p, c_void_p, c_int, c_int]
         L.vp8hip_frame_download.argtypes = [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int]
@@ -301,6 +316,20 @@ class Vp8Hip:
         parser.decode_mbs(pm, pc, pv)
         ctypes.memmove(ph, ctypes.byref(hdr), 64)
         return hdr
+
+    def parse_into_slot_sparse(self, parser, data, slot):
+        """Feeder writes descriptors and the SPARSE coefficient stream into the pinned staging of `slot` and queues the upload
+        (+ expansion on the device); returns (hdr, blocks in the stream)."""
+        hdr, changed = parser.begin(data)
+        if (hdr.width, hdr.height) != (self.width, self.height):
+            raise RuntimeError("dimension change: reconfigure the context first")
+        ph, pm, pb, pd, pv, cap = c_void_p(), c_void_p(), c_void_p(), c_void_p(), c_void_p(), c_size_t()
+        self._chk(self.L.vp8hip_ir_map_sparse(self.h, slot, ctypes.byref(ph), ctypes.byref(pm), ctypes.byref(pb), ctypes.byref(cap),
+                                              ctypes.byref(pd), ctypes.byref(pv)), "vp8hip_ir_map_sparse")
+        nb, nd, _ = parser.decode_mbs_sparse(pm.value, pb.value, cap.value, pd.value, pv.value)
+        ctypes.memmove(ph.value, ctypes.byref(hdr), 64)
+        self._chk(self.L.vp8hip_ir_upload_sparse(self.h, slot, nb, nd), "vp8hip_ir_upload_sparse")
+        return hdr, nb * 32 + nd * 2
 
     def upload(self, slot):
         self._chk(self.L.vp8hip_ir_upload(self.h, slot), "vp8hip_ir_upload")

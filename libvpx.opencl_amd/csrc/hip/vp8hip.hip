@@ -25,6 +25,30 @@ extern "C" __global__ void vp8_loopfilter_kernel(const DevJob *jobs, int njobs, 
 extern "C" __global__ void vp8_extend_kernel(const DevJob *jobs, int njobs, DevGeom g);
 extern "C" __global__ void vp8_detile_kernel(const DevJob *jobs, int njobs, DevGeom g, int extend);
 
+// Sparse coefficient streams -> the dense coefficient array the kernels read (include/vp8_ir.h): one thread per 16 bytes of
+// output -- half a block --, which entry of which stream it comes from (or none: zeros) follows from the macroblock's descriptor.
+// (The descriptors arrive in the same staging buffer -- one host-to-device copy per frame -- and are put in place here too.)
+__global__ void __launch_bounds__(256)
+vp8_ir_expand_kernel(const vp8ir_mb *__restrict__ mbs, const int16_t *__restrict__ blocks, const int16_t *__restrict__ dcs,
+                     vp8ir_mb *__restrict__ mbs_out, int16_t *__restrict__ coef, int nmb)
+{
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+    const int mb = (int)(gid / 50), ch = (int)(gid % 50), k = ch >> 1;
+    if (mb >= nmb) return;
+    const vp8ir_mb &m = mbs[mb];
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    if (ch < 4) ((u32x4 *)(mbs_out + mb))[ch] = ((const u32x4 *)&m)[ch];
+    u32x4 v = { 0, 0, 0, 0 };
+    const int kind = vp8ir_block_kind(&m, k);
+    if (kind) {
+        int rank = 0;
+        for (int j = 0; j < k; j++) rank += vp8ir_block_kind(&m, j) == kind;
+        if (kind == 2) v = *(const u32x4 *)(blocks + ((size_t)m.sparse_first + rank) * 16 + (ch & 1) * 8);
+        else if (!(ch & 1)) v.x = (unsigned short)dcs[(size_t)m.dc_first + rank];      // IR order: the DC is the block's first entry
+    }
+    *(u32x4 *)(coef + (size_t)mb * VP8IR_COEF_PER_MB + k * 16 + (ch & 1) * 8) = v;
+}
+
 static char g_create_error[256] = "";
 
 struct Slot {
@@ -34,6 +58,8 @@ struct Slot {
     vp8ir_frame_hdr *h_hdr; vp8ir_mb *h_mbs; int16_t *h_coef; vp8ir_mv *h_mvs;
     vp8ir_frame_hdr hdr_copy;      // header as of the last upload / copy (host side, for job setup)
     char *h_block;                 // pinned mirror, allocated on first vp8hip_ir_map
+    char *d_sparse;                // device staging of a sparse upload: descriptors, blocks, DCs; allocated on first vp8hip_ir_upload_sparse
+    int16_t *h_dcs;                // pinned staging of the DC stream while the feeder writes it (behind the dense mirror in h_block)
 };
 
 // Tuning / test knobs, read from the environment by vp8hip_configure (never per launch):
@@ -109,6 +135,12 @@ struct vp8hip_ctx {
     unsigned long long *gran_recon, *gran_lf; size_t gran_recon_cap, gran_lf_cap;
     unsigned int epoch;
     int *h_status, *d_status;
+    // batch download of whole frame buffers on a stream of its own (vp8hip_frames_download_async): PCIe is full duplex, the next
+    // batch's uploads run beside it
+    hipStream_t stream_d2h;
+    hipEvent_t ev_d2h_from, ev_d2h_done;
+    int d2h_first, d2h_count;      // frame buffers of the copy in flight (count 0: none)
+    size_t fb_stride;
 };
 
 static int fail(vp8hip_ctx *c, int code, const char *fmt, ...)
@@ -135,8 +167,10 @@ static void free_pools(vp8hip_ctx *c)
     if (c->gran_recon) (void)hipFree(c->gran_recon);
     if (c->gran_lf) (void)hipFree(c->gran_lf);
     c->gran_recon = c->gran_lf = nullptr; c->gran_recon_cap = c->gran_lf_cap = 0;
-    for (Slot &s : c->slots)
+    for (Slot &s : c->slots) {
         if (s.h_block) (void)hipHostFree(s.h_block);
+        if (s.d_sparse) (void)hipFree(s.d_sparse);
+    }
     c->fb_block = nullptr; c->slot_block_dev = nullptr;
     for (int k = 0; k < VP8HIP_NBUF; k++) { c->tile_block[k] = nullptr; c->tile_cap[k] = 0; }
     c->fb.clear(); c->slots.clear();
@@ -194,6 +228,7 @@ extern "C" int vp8hip_create(int device, vp8hip_ctx **out)
         return -1;
     }
     c->stream2 = nullptr;      // created by the first launch that wants it
+    c->stream_d2h = nullptr; c->ev_d2h_from = c->ev_d2h_done = nullptr; c->d2h_first = c->d2h_count = 0; c->fb_stride = 0;
     // events: every creation is checked; on failure whatever exists is destroyed again (null handles are skipped)
     for (int r = 0; r < VP8HIP_STATS_RING; r++) for (int i = 0; i < 6; i++) c->evr[r][i] = nullptr;
     c->ev_jobs = c->ev_lf_done = c->ev_recon_done = nullptr;
@@ -237,6 +272,9 @@ extern "C" void vp8hip_destroy(vp8hip_ctx *c)
     if (c->h_jobs) (void)hipHostFree(c->h_jobs);
     if (c->h_status) (void)hipHostFree(c->h_status);
     destroy_events(c);
+    if (c->stream_d2h) { (void)hipStreamSynchronize(c->stream_d2h); (void)hipStreamDestroy(c->stream_d2h); }
+    if (c->ev_d2h_from) (void)hipEventDestroy(c->ev_d2h_from);
+    if (c->ev_d2h_done) (void)hipEventDestroy(c->ev_d2h_done);
     (void)hipStreamDestroy(c->stream);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
     delete c;
@@ -302,6 +340,9 @@ static int configure_pools(vp8hip_ctx *c, int width, int height, int num_fb, int
     HIPCHK(c, hipMalloc((void **)&c->fb_block, fbsz * num_fb));
     HIPCHK(c, hipMemsetAsync(c->fb_block, 0, fbsz * num_fb, c->stream));
     for (int i = 0; i < num_fb; i++) c->fb.push_back(c->fb_block + fbsz * i);
+    c->fb_stride = fbsz;
+    if (c->stream_d2h) HIPCHK(c, hipStreamSynchronize(c->stream_d2h));
+    c->d2h_count = 0;
 
     // IR slots
     const size_t o_mbs = 64, o_coef = o_mbs + align_up((size_t)c->nmb * sizeof(vp8ir_mb), 256);
@@ -316,6 +357,7 @@ static int configure_pools(vp8hip_ctx *c, int width, int height, int num_fb, int
         s.d_hdr = (vp8ir_frame_hdr *)d; s.d_mbs = (vp8ir_mb *)(d + o_mbs);
         s.d_coef = (int16_t *)(d + o_coef); s.d_mvs = (vp8ir_mv *)(d + o_mvs);
         s.h_block = nullptr; s.h_hdr = nullptr; s.h_mbs = nullptr; s.h_coef = nullptr; s.h_mvs = nullptr;
+        s.d_sparse = nullptr; s.h_dcs = nullptr;
         memset(&s.hdr_copy, 0, sizeof s.hdr_copy);
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -336,8 +378,9 @@ extern "C" int vp8hip_ir_map(vp8hip_ctx *c, int slot, vp8ir_frame_hdr **hdr, vp8
     Slot &s = c->slots[slot];
     if (!s.h_block) {   // pinned staging is created on first use: device-only slots cost no host memory
         HIPCHK(c, hipSetDevice(c->device));
-        HIPCHK(c, hipHostMalloc((void **)&s.h_block, c->slot_bytes, hipHostMallocDefault));
+        HIPCHK(c, hipHostMalloc((void **)&s.h_block, c->slot_bytes + (size_t)c->nmb * 50, hipHostMallocDefault));
         memset(s.h_block, 0, c->slot_bytes);
+        s.h_dcs = (int16_t *)(s.h_block + c->slot_bytes);
         s.h_hdr = (vp8ir_frame_hdr *)s.h_block; s.h_mbs = (vp8ir_mb *)(s.h_block + c->o_mbs);
         s.h_coef = (int16_t *)(s.h_block + c->o_coef); s.h_mvs = (vp8ir_mv *)(s.h_block + c->o_mvs);
     }
@@ -365,6 +408,45 @@ extern "C" int vp8hip_ir_upload(vp8hip_ctx *c, int slot)
     if (h.frame_type != 0)
         HIPCHK(c, hipMemcpyAsync(s.d_mvs, s.h_mvs, (size_t)c->nmb * 16 * sizeof(vp8ir_mv), hipMemcpyHostToDevice,
                                  c->stream));
+    return 0;
+}
+
+extern "C" int vp8hip_ir_map_sparse(vp8hip_ctx *c, int slot, vp8ir_frame_hdr **hdr, vp8ir_mb **mbs, int16_t **blocks,
+                                    size_t *cap_blocks, int16_t **dcs, vp8ir_mv **mvs)
+{
+    int16_t *coef = nullptr;
+    if (vp8hip_ir_map(c, slot, hdr, mbs, &coef, mvs)) return -2;
+    if (blocks) *blocks = coef;                     // the block stream is staged where the dense mirror would be: never both at once
+    if (cap_blocks) *cap_blocks = (size_t)c->nmb * 25;
+    if (dcs) *dcs = c->slots[slot].h_dcs;
+    return 0;
+}
+
+extern "C" int vp8hip_ir_upload_sparse(vp8hip_ctx *c, int slot, size_t nblocks, size_t ndcs)
+{
+    if (!c || slot < 0 || slot >= (int)c->slots.size()) return fail(c, -2, "vp8hip_ir_upload_sparse: bad slot %d", slot);
+    Slot &s = c->slots[slot];
+    if (!s.h_block) return fail(c, -2, "vp8hip_ir_upload_sparse: slot %d was never mapped", slot);
+    const vp8ir_frame_hdr &h = *s.h_hdr;
+    if (h.mb_cols != c->dg.mb_cols || h.mb_rows != c->dg.mb_rows)
+        return fail(c, -2, "vp8hip_ir_upload_sparse: header is %dx%d MBs, context configured for %dx%d", h.mb_cols,
+                    h.mb_rows, c->dg.mb_cols, c->dg.mb_rows);
+    if (nblocks + ndcs > (size_t)c->nmb * 25) return fail(c, -2, "vp8hip_ir_upload_sparse: %zu blocks + %zu DCs for %d macroblocks", nblocks, ndcs, c->nmb);
+    HIPCHK(c, hipSetDevice(c->device));
+    // One copy per frame: in the pinned mirror the descriptors are followed by the coefficient staging (c->o_coef), where the
+    // feeder wrote the blocks; the DCs, written elsewhere because nobody knew where the blocks would end, are moved up behind them.
+    const size_t o_blocks = c->o_coef - c->o_mbs, o_dcs = o_blocks + nblocks * 32, used = o_dcs + ((ndcs * 2 + 15) & ~(size_t)15);
+    if (!s.d_sparse) HIPCHK(c, hipMalloc((void **)&s.d_sparse, o_blocks + (size_t)c->nmb * 25 * 32 + 64));
+    memcpy((char *)s.h_mbs + o_dcs, s.h_dcs, ndcs * 2);
+    const int16_t *d_blocks = (const int16_t *)(s.d_sparse + o_blocks), *d_dcs = (const int16_t *)(s.d_sparse + o_dcs);
+    s.hdr_copy = h;
+    HIPCHK(c, hipMemcpyAsync(s.d_sparse, s.h_mbs, used, hipMemcpyHostToDevice, c->stream));
+    if (h.frame_type != 0)
+        HIPCHK(c, hipMemcpyAsync(s.d_mvs, s.h_mvs, (size_t)c->nmb * 16 * sizeof(vp8ir_mv), hipMemcpyHostToDevice, c->stream));
+    const long chunks = (long)c->nmb * 50;
+    hipLaunchKernelGGL(vp8_ir_expand_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, c->stream,
+                       (const vp8ir_mb *)s.d_sparse, d_blocks, d_dcs, s.d_mbs, s.d_coef, c->nmb);
+    HIPCHK(c, hipGetLastError());
     return 0;
 }
 
@@ -508,6 +590,11 @@ extern "C" int vp8hip_decode(vp8hip_ctx *c, const vp8hip_job *jobs, int njobs, i
             d.ref[k] = c->fb[f];
         }
         any_lf |= s.hdr_copy.filter_level != 0;
+    }
+    if (c->d2h_count) {      // a batch download still in flight: a launch that writes one of its frame buffers waits for it
+        bool hit = false;
+        for (int i = 0; i < njobs && !hit; i++) hit = jobs[i].dst_fb >= c->d2h_first && jobs[i].dst_fb < c->d2h_first + c->d2h_count;
+        if (hit) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_d2h_done, 0));
     }
     HIPCHK(c, hipMemcpyAsync(c->d_jobs, c->h_jobs, sizeof(DevJob) * njobs, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipEventRecord(c->ev_jobs, c->stream));
@@ -746,6 +833,38 @@ extern "C" int vp8hip_frame_download(vp8hip_ctx *c, int fb, int full, uint8_t *y
                                    c->stream));
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    return check_status(c);
+}
+
+extern "C" size_t vp8hip_frame_stride(const vp8hip_ctx *c) { return c ? c->fb_stride : 0; }
+
+extern "C" int vp8hip_frames_download_async(vp8hip_ctx *c, int first_fb, int count, uint8_t *dst)
+{
+    if (!c || first_fb < 0 || count < 1 || first_fb + count > (int)c->fb.size() || !dst)
+        return fail(c, -2, "vp8hip_frames_download_async: bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (join_detile(c)) return -1;
+    if (!c->stream_d2h) {
+        HIPCHK(c, hipStreamCreateWithFlags(&c->stream_d2h, hipStreamNonBlocking));
+        HIPCHK(c, hipEventCreateWithFlags(&c->ev_d2h_from, hipEventDisableTiming));
+        HIPCHK(c, hipEventCreateWithFlags(&c->ev_d2h_done, hipEventDisableTiming));
+    }
+    if (c->d2h_count) HIPCHK(c, hipEventSynchronize(c->ev_d2h_done));  // one copy in flight at a time
+    HIPCHK(c, hipEventRecord(c->ev_d2h_from, c->stream));             // everything queued so far: the frames' kernels
+    HIPCHK(c, hipStreamWaitEvent(c->stream_d2h, c->ev_d2h_from, 0));
+    HIPCHK(c, hipMemcpyAsync(dst, c->fb[first_fb], c->fb_stride * (size_t)count, hipMemcpyDeviceToHost, c->stream_d2h));
+    HIPCHK(c, hipEventRecord(c->ev_d2h_done, c->stream_d2h));
+    c->d2h_first = first_fb; c->d2h_count = count;
+    return 0;
+}
+
+extern "C" int vp8hip_download_wait(vp8hip_ctx *c)
+{
+    if (!c) return -2;
+    if (!c->d2h_count) return 0;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipEventSynchronize(c->ev_d2h_done));
+    c->d2h_count = 0;
     return check_status(c);
 }
 

@@ -83,12 +83,19 @@ static vp8hip_ctx *g_hip;
 static vp8_parser **g_parsers;                      /* one per worker */
 static int g_batch, g_width, g_height;
 static vp8ir_geom g_geom;
-static struct { vp8ir_frame_hdr *hdr; vp8ir_mb *mbs; int16_t *coef; vp8ir_mv *mvs; } *g_maps;   /* 3 * batch slots */
-static uint8_t *g_host;                             /* batch pinned frame buffers */
+/* 3 * batch slots; the coefficients go up as the sparse streams of include/vp8_ir.h (a third of the dense bytes) */
+static struct { vp8ir_frame_hdr *hdr; vp8ir_mb *mbs; int16_t *blocks, *dcs; size_t cap, nblocks, ndcs; vp8ir_mv *mvs; } *g_maps;
+static uint8_t *g_host[2];                          /* 2 x batch pinned frame buffers: one being filled by the GPU, one being hashed */
+static size_t g_stride;                             /* bytes from one frame buffer to the next */
 static unsigned char (*g_digest)[16];               /* one per frame of the whole run */
 static volatile int g_failed;
 
 typedef struct batch_ref { int b, n; long first; } batch_ref;     /* batch number, frames in it, index of its first frame */
+/* The pipeline, batch by batch (three slot / frame-buffer sets, two pinned host sets):
+ *   feeder threads   parse batch b+1 into slot set (b+1)%3            (sparse coefficient streams, include/vp8_ir.h)
+ *   this thread      uploads batch b (one copy + one expansion launch per frame), launches its pixel path, then asks for the
+ *                    frames back: ONE asynchronous device-to-host copy of the whole batch on a stream of its own
+ *   hash threads     MD5 of batch b-1, which that copy delivered during the previous iteration */
 
 static void parse_one(void *arg, int i, int worker)
 {
@@ -98,7 +105,8 @@ static void parse_one(void *arg, int i, int worker)
     vp8ir_frame_hdr hdr;
     int rc = vp8_parser_begin_frame(g_parsers[worker], f->data, f->size, &hdr);
     if (!rc && (hdr.frame_type != 0 || hdr.width != g_width || hdr.height != g_height)) rc = VP8P_UNSUP_BITSTREAM;
-    if (!rc) rc = vp8_parser_decode_mbs(g_parsers[worker], g_maps[slot].mbs, g_maps[slot].coef, g_maps[slot].mvs, NULL);
+    if (!rc) rc = vp8_parser_decode_mbs_sparse(g_parsers[worker], g_maps[slot].mbs, g_maps[slot].blocks, g_maps[slot].cap,
+                                               &g_maps[slot].nblocks, g_maps[slot].dcs, &g_maps[slot].ndcs, g_maps[slot].mvs, NULL);
     if (rc) { g_failed = 1; return; }
     *g_maps[slot].hdr = hdr;
 }
@@ -106,7 +114,7 @@ static void parse_one(void *arg, int i, int worker)
 static void hash_one(void *arg, int i, int worker)
 {
     const batch_ref *br = (const batch_ref *)arg;
-    const uint8_t *fb = g_host + (size_t)i * g_geom.frame_size;
+    const uint8_t *fb = g_host[br->b & 1] + (size_t)i * g_stride;
     md5_state md5;
     (void)worker;
     md5_init(&md5);
@@ -174,9 +182,11 @@ int main(int argc, char **argv)
     HIP(vp8hip_configure(g_hip, g_width, g_height, 3 * g_batch, 3 * g_batch));
     HIP(vp8hip_geometry(g_hip, &g_geom));
     g_maps = calloc((size_t)3 * g_batch, sizeof *g_maps);
-    for (int s = 0; s < 3 * g_batch; s++) HIP(vp8hip_ir_map(g_hip, s, &g_maps[s].hdr, &g_maps[s].mbs, &g_maps[s].coef, &g_maps[s].mvs));
-    g_host = (uint8_t *)vp8hip_host_alloc(g_hip, (size_t)g_batch * g_geom.frame_size);
-    if (!g_host) DIE("vp8hip_host_alloc: %s", vp8hip_last_error(g_hip));
+    for (int s = 0; s < 3 * g_batch; s++)
+        HIP(vp8hip_ir_map_sparse(g_hip, s, &g_maps[s].hdr, &g_maps[s].mbs, &g_maps[s].blocks, &g_maps[s].cap, &g_maps[s].dcs, &g_maps[s].mvs));
+    g_stride = vp8hip_frame_stride(g_hip);
+    for (int k = 0; k < 2; k++)
+        if (!(g_host[k] = (uint8_t *)vp8hip_host_alloc(g_hip, (size_t)g_batch * g_stride))) DIE("vp8hip_host_alloc: %s", vp8hip_last_error(g_hip));
     g_digest = calloc((size_t)total, 16);
     g_parsers = calloc((size_t)threads, sizeof *g_parsers);
     pthread_t *tid = calloc((size_t)threads, sizeof *tid);
@@ -195,32 +205,33 @@ int main(int argc, char **argv)
     for (long b = 0; b < nbatch; b++) {
         task_wait(&parse_t, 0);
         if (g_failed) DIE("a frame of batch %ld failed to parse", b);
-        if (prev.b >= 0) {
-            /* the previous batch comes back BEFORE this one's uploads are queued on the (in-order) stream */
-            if (hashing.b >= 0) task_wait(&hash_t, 1);                      /* the pinned buffers are free again */
-            for (int i = 0; i < prev.n; i++)
-                HIP(vp8hip_frame_download(g_hip, (prev.b % 3) * g_batch + i, 1, g_host + (size_t)i * g_geom.frame_size, NULL, NULL, 0, 0));
-            hashing = prev;
-            task_start(&hash_t, 1, hash_one, &hashing, hashing.n);
+        const batch_ref now = cur;
+        if (b + 1 < nbatch) {
+            /* the feeder goes on with the next batch at once -- slot set (b+1)%3 was last used by batch b-2, which came back an
+               iteration ago -- while this thread downloads batch b-1 and uploads and launches batch b */
+            const long first = cur.first + cur.n;
+            nxt.b = cur.b + 1; nxt.first = first; nxt.n = (int)(total - first < g_batch ? total - first : g_batch);
+            cur = nxt;
+            task_start(&parse_t, 0, parse_one, &cur, cur.n);
         }
-        for (int i = 0; i < cur.n; i++) {
-            const int s = (cur.b % 3) * g_batch + i;
-            HIP(vp8hip_ir_upload(g_hip, s));
+        for (int i = 0; i < now.n; i++) {
+            const int s = (now.b % 3) * g_batch + i;
+            HIP(vp8hip_ir_upload_sparse(g_hip, s, g_maps[s].nblocks, g_maps[s].ndcs));
             jobs[i].ir_slot = s; jobs[i].dst_fb = s;
             jobs[i].ref_fb[0] = jobs[i].ref_fb[1] = jobs[i].ref_fb[2] = jobs[i].ref_fb[3] = -1;
         }
-        HIP(vp8hip_decode(g_hip, jobs, cur.n, VP8HIP_STAGE_ALL));
-        prev = cur;
-        if (b + 1 < nbatch) {
-            const long first = cur.first + cur.n;
-            nxt.b = cur.b + 1; nxt.first = first; nxt.n = (int)(total - first < g_batch ? total - first : g_batch);
-            cur = nxt;                                  /* slot set (b+1)%3: last used by batch b-2, downloaded already */
-            task_start(&parse_t, 0, parse_one, &cur, cur.n);
+        HIP(vp8hip_decode(g_hip, jobs, now.n, VP8HIP_STAGE_ALL));
+        if (prev.b >= 0) {
+            HIP(vp8hip_download_wait(g_hip));                               /* batch b-1 is in host set (b-1)&1 */
+            if (hashing.b >= 0) task_wait(&hash_t, 1);                      /* batch b-2 hashed: host set b&1 is free again */
+            hashing = prev;
+            task_start(&hash_t, 1, hash_one, &hashing, hashing.n);
         }
+        HIP(vp8hip_frames_download_async(g_hip, (now.b % 3) * g_batch, now.n, g_host[now.b & 1]));
+        prev = now;
     }
+    HIP(vp8hip_download_wait(g_hip));
     if (hashing.b >= 0) task_wait(&hash_t, 1);
-    for (int i = 0; i < prev.n; i++)
-        HIP(vp8hip_frame_download(g_hip, (prev.b % 3) * g_batch + i, 1, g_host + (size_t)i * g_geom.frame_size, NULL, NULL, 0, 0));
     hashing = prev;
     task_start(&hash_t, 1, hash_one, &hashing, hashing.n);
     task_wait(&hash_t, 1);
@@ -242,7 +253,8 @@ int main(int argc, char **argv)
     pthread_cond_broadcast(&pool.work);
     pthread_mutex_unlock(&pool.mu);
     for (int t = 0; t < threads; t++) { pthread_join(tid[t], NULL); vp8_parser_destroy(g_parsers[t]); }
-    vp8hip_host_free(g_hip, g_host);
+    vp8hip_host_free(g_hip, g_host[0]);
+    vp8hip_host_free(g_hip, g_host[1]);
     vp8hip_destroy(g_hip);
     return EXIT_SUCCESS;
 }

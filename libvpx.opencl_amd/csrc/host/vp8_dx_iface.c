@@ -147,7 +147,8 @@ static vpx_codec_err_t vp8_decode(vpx_codec_alg_priv_t *p, const uint8_t *data, 
 {
     vp8ir_frame_hdr hdr, *h_hdr;
     vp8ir_mb *h_mbs;
-    int16_t *h_coef;
+    int16_t *h_blocks, *h_dcs;
+    size_t cap_blocks, nblocks = 0, ndcs = 0;
     vp8ir_mv *h_mvs;
     vp8hip_job job;
     int rc, corrupt = 0, i, nmb, nfrags;
@@ -230,11 +231,12 @@ static vpx_codec_err_t vp8_decode(vpx_codec_alg_priv_t *p, const uint8_t *data, 
         vp8_refs_on_alloc(&p->refs);
         memset(p->fb_corrupted, 0, sizeof p->fb_corrupted);
     }
-    if (vp8hip_ir_map(p->hip, 0, &h_hdr, &h_mbs, &h_coef, &h_mvs)) {
+    /* the coefficients go up as the sparse streams of include/vp8_ir.h: a third of the bytes the dense array would cost PCIe */
+    if (vp8hip_ir_map_sparse(p->hip, 0, &h_hdr, &h_mbs, &h_blocks, &cap_blocks, &h_dcs, &h_mvs)) {
         vp8_refs_release_new(&p->refs);
         return gpu_error(p, "vp8hip_ir_map");
     }
-    rc = vp8_parser_decode_mbs(p->parser, h_mbs, h_coef, h_mvs, &corrupt);
+    rc = vp8_parser_decode_mbs_sparse(p->parser, h_mbs, h_blocks, cap_blocks, &nblocks, h_dcs, &ndcs, h_mvs, &corrupt);
     if (rc) {
         vp8_refs_release_new(&p->refs);
         return set_detail(p, (vpx_codec_err_t)rc, vp8_parser_error(p->parser));
@@ -259,7 +261,7 @@ static vpx_codec_err_t vp8_decode(vpx_codec_alg_priv_t *p, const uint8_t *data, 
     p->fb_corrupted[p->refs.new_idx] = corrupt;
 
     t1 = now_s();
-    if (vp8hip_ir_upload(p->hip, 0)) { vp8_refs_release_new(&p->refs); return gpu_error(p, "vp8hip_ir_upload"); }
+    if (vp8hip_ir_upload_sparse(p->hip, 0, nblocks, ndcs)) { vp8_refs_release_new(&p->refs); return gpu_error(p, "vp8hip_ir_upload_sparse"); }
     job.ir_slot = 0;
     job.dst_fb = p->refs.new_idx;
     job.ref_fb[0] = -1;

@@ -824,10 +824,28 @@ static int read_mb_tokens(vp8_parser *p, vp8_boolreader *br, const mbinfo *m, en
     return total;
 }
 
+static int decode_mbs(vp8_parser *p, vp8ir_mb *mbs, int16_t *coef, int16_t *blocks, size_t cap_blocks, size_t *nblocks,
+                      int16_t *dcs, size_t *ndcs, vp8ir_mv *mvs, int *corrupt);
+
 int vp8_parser_decode_mbs(vp8_parser *p, vp8ir_mb *mbs, int16_t *coef, vp8ir_mv *mvs, int *corrupt)
+{
+    return decode_mbs(p, mbs, coef, NULL, 0, NULL, NULL, NULL, mvs, corrupt);
+}
+
+int vp8_parser_decode_mbs_sparse(vp8_parser *p, vp8ir_mb *mbs, int16_t *blocks, size_t cap_blocks, size_t *nblocks,
+                                 int16_t *dcs, size_t *ndcs, vp8ir_mv *mvs, int *corrupt)
+{
+    if (!blocks || !nblocks || !dcs || !ndcs) return fail(p, VP8P_INVALID_PARAM, "decode_mbs_sparse: no output streams");
+    return decode_mbs(p, mbs, NULL, blocks, cap_blocks, nblocks, dcs, ndcs, mvs, corrupt);
+}
+
+/* coef != NULL: dense output; else the sparse stream (vp8_ir.h) */
+static int decode_mbs(vp8_parser *p, vp8ir_mb *mbs, int16_t *coef, int16_t *blocks, size_t cap_blocks, size_t *nblocks,
+                      int16_t *dcs, size_t *ndcs, vp8ir_mv *mvs, int *corrupt)
 {
     int r, c, i, bad = 0;
     int is_key;
+    size_t nb = 0, nd = 0;
     if (!p->frame_open)
         return fail(p, VP8P_ERROR, "decode_mbs without begin_frame");
     is_key = p->hdr.frame_type == 0;
@@ -855,17 +873,32 @@ int vp8_parser_decode_mbs(vp8_parser *p, vp8ir_mb *mbs, int16_t *coef, vp8ir_mv 
                 memset(&left, 0, sizeof left);
                 if (!has_y2) { A->y2 = ay2; left.y2 = ly2; }
             } else {
-                int16_t *q = coef + n * VP8IR_COEF_PER_MB;
+                int16_t local[VP8IR_COEF_PER_MB];
+                int16_t *q = coef ? coef + n * VP8IR_COEF_PER_MB : local;
                 memset(q, 0, VP8IR_COEF_PER_MB * sizeof(int16_t));
                 if (read_mb_tokens(p, br, m, A, &left, q, o->eobs) == 0) {
                     m->skip = 1;                 /* decodframe.c:129: eobtotal==0 forces skip */
                     memset(o->eobs, 0, 25);
+                } else if (!coef) {              /* sparse streams: full blocks and lone DCs, in block order (vp8_ir.h) */
+                    int k;
+                    o->sparse_first = (uint32_t)nb;
+                    o->dc_first = (uint32_t)nd;
+                    for (k = 0; k < 25; k++) {
+                        if (k == 24 && !has_y2) break;
+                        if (o->eobs[k] > 1) {
+                            if (nb >= cap_blocks) return fail(p, VP8P_MEM_ERROR, "sparse coefficient stream overflow");
+                            memcpy(blocks + nb * 16, q + k * 16, 32);
+                            nb++;
+                        } else if (o->eobs[k] == 1 && !(has_y2 && k < 16))
+                            dcs[nd++] = q[k * 16];       /* (at most 25 per macroblock: the caller's array is that large) */
+                    }
                 }
             }
             o->y_mode = m->y_mode;
             o->uv_mode = m->uv_mode;
             o->ref_frame = m->ref_frame;
             o->flags = (uint8_t)((m->skip ? VP8IR_MB_SKIP : 0) | (m->need_clamp ? VP8IR_MB_CLAMP : 0));
+            if (!coef && m->skip) { o->sparse_first = (uint32_t)nb; o->dc_first = (uint32_t)nd; }
             o->segment_id = m->segment_id;
             o->partitioning = m->y_mode == VP8IR_SPLITMV ? m->partitioning : 0;
             if (m->y_mode == VP8IR_B_PRED)
@@ -890,6 +923,8 @@ int vp8_parser_decode_mbs(vp8_parser *p, vp8ir_mb *mbs, int16_t *coef, vp8ir_mv 
     if (p->restore_probs)
         p->fc = p->saved_fc;
     if (corrupt) *corrupt = bad;
+    if (nblocks) *nblocks = nb;
+    if (ndcs) *ndcs = nd;
     p->frame_open = 0;
     return VP8P_OK;
 }

@@ -55,6 +55,13 @@ int vp8_parser_begin_frame_fragments(vp8_parser *p, const uint8_t *const *frags,
  * Returns VP8P_OK, or an error; *corrupt (optional) reports a truncated partition. */
 int vp8_parser_decode_mbs(vp8_parser *p, vp8ir_mb *mbs, int16_t *coef, vp8ir_mv *mvs, int *corrupt);
 
+/* The same with the coefficients as the sparse streams of include/vp8_ir.h: `blocks` receives 16 int16 per block with more
+ * than one coded position (at most cap_blocks of them; 25 per macroblock is the worst case), `dcs` (room for 25 per macroblock)
+ * one int16 per block with a lone DC; *nblocks / *ndcs how many; mbs[].sparse_first / dc_first say where each macroblock's
+ * entries start. */
+int vp8_parser_decode_mbs_sparse(vp8_parser *p, vp8ir_mb *mbs, int16_t *blocks, size_t cap_blocks, size_t *nblocks,
+                                 int16_t *dcs, size_t *ndcs, vp8ir_mv *mvs, int *corrupt);
+
 const char *vp8_parser_error(const vp8_parser *p);
 
 /* Reference-buffer index bookkeeping shared by every decoder built on the parser:

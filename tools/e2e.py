@@ -30,37 +30,52 @@ def run(P, device=0, fixture="kf_1920x1080", nframes=1024, batch=128, threads=No
     ctx = P.Vp8Hip(device)
     # three sets of slots and frame buffers: batch k+1 is parsed while k is decoded and k-1 is downloaded and hashed
     ctx.configure(w, h, 3 * batch, 3 * batch)
-    maps = [ctx.ir_map(s) for s in range(3 * batch)]   # pinned staging, created by the main thread
+    import ctypes
+    c_void_p, c_size_t = ctypes.c_void_p, ctypes.c_size_t
+
+    def map_sparse(slot):            # pinned staging of a slot: header, descriptors, the two sparse coefficient streams, MVs
+        ph, pm, pb, pd, pv, cap = c_void_p(), c_void_p(), c_void_p(), c_void_p(), c_void_p(), c_size_t()
+        ctx._chk(ctx.L.vp8hip_ir_map_sparse(ctx.h, slot, ctypes.byref(ph), ctypes.byref(pm), ctypes.byref(pb), ctypes.byref(cap),
+                                            ctypes.byref(pd), ctypes.byref(pv)), "vp8hip_ir_map_sparse")
+        return ph.value, pm.value, pb.value, cap.value, pd.value, pv.value
+    maps = [map_sparse(s) for s in range(3 * batch)]   # created by the main thread
+    counts = [(0, 0)] * (3 * batch)                     # (full blocks, lone DCs) the feeder wrote per slot
+    h2d_bytes = [0]
     parsers = [P.Parser() for _ in range(threads)]
     free = list(range(threads))
-    import ctypes
 
     def parse(slot, data):
         k = free.pop()                                 # list.pop / append are atomic under the GIL
         ps = parsers[k]
         hdr, _ = ps.begin(data)
-        ph, pm, pc, pv = maps[slot]
-        ps.decode_mbs(pm, pc, pv)
+        ph, pm, pb, cap, pd, pv = maps[slot]
+        nb, nd, _ = ps.decode_mbs_sparse(pm, pb, cap, pd, pv)
+        counts[slot] = (nb, nd)
         ctypes.memmove(ph, ctypes.byref(hdr), 64)
         ps.swap(hdr)
         free.append(k)
         return hdr.frame_type
 
-    # whole frame buffers come back into pinned host memory (torch is only the allocator here): one contiguous copy
-    # per frame at PCIe speed instead of three strided ones into pageable memory
+    # whole frame buffers come back into pinned host memory (torch is only the allocator here): ONE asynchronous copy per batch on
+    # a stream of its own (vp8hip_frames_download_async), two host sets -- one being filled, one being hashed
     import numpy as np
     import torch
-    fsz = ctx.g.frame_size
-    pinned = torch.empty((batch, fsz), dtype=torch.uint8, pin_memory=True)
+    L = ctx.L
+    L.vp8hip_frame_stride.restype = ctypes.c_size_t
+    L.vp8hip_frame_stride.argtypes = [c_void_p]
+    L.vp8hip_frames_download_async.argtypes = [c_void_p, ctypes.c_int, ctypes.c_int, c_void_p]
+    L.vp8hip_download_wait.argtypes = [c_void_p]
+    stride = L.vp8hip_frame_stride(ctx.h)
+    pinned = torch.empty((2, batch, stride), dtype=torch.uint8, pin_memory=True)
     host = pinned.numpy()
 
-    def md5_frame(i):
-        return P.frame_md5(host[i], ctx.g, w, h)
+    def md5_frame(k, i):
+        return P.frame_md5(host[k, i], ctx.g, w, h)
 
     pool = ThreadPoolExecutor(threads)
     hpool = ThreadPoolExecutor(max(4, threads // 2))    # hashing has its own workers: it must not queue behind the feeder
     bad = 0
-    t_parse = t_gpu = t_out = t_first = t_d2h = 0.0
+    t_parse = t_gpu = t_out = 0.0
 
     def submit_parse(b):
         base = (b % 3) * batch
@@ -70,7 +85,9 @@ def run(P, device=0, fixture="kf_1920x1080", nframes=1024, batch=128, threads=No
     def launch(b, n):
         base = (b % 3) * batch
         for i in range(n):
-            ctx.upload(base + i)
+            nb, nd = counts[base + i]
+            ctx._chk(L.vp8hip_ir_upload_sparse(ctx.h, base + i, nb, nd), "vp8hip_ir_upload_sparse")
+            h2d_bytes[0] += nb * 32 + nd * 2 + ctx.nmb * 64
         ctx.decode([(base + i, base + i, None) for i in range(n)], P.STAGE_ALL)
 
     hashing = None                                     # (batch, futures) whose digests are still being computed
@@ -84,19 +101,12 @@ def run(P, device=0, fixture="kf_1920x1080", nframes=1024, batch=128, threads=No
                     bad += 1
             hashing = None
 
-    def download(b, n):
-        """D2H of batch b into the pinned buffer (after its digests of the previous round are in), hashing started."""
-        nonlocal hashing, t_first, t_d2h
+    def arrived(b, n):
+        """Batch b's copy has landed in host set b & 1: hash it (after the digests of batch b-1... of the set's previous user are in)."""
+        nonlocal hashing
+        ctx._chk(L.vp8hip_download_wait(ctx.h), "vp8hip_download_wait")
         collect()
-        base = (b % 3) * batch
-        t1 = time.perf_counter()
-        for i in range(n):                                                # synchronous D2H, in order
-            ctx._chk(ctx.L.vp8hip_frame_download(ctx.h, base + i, 1, host[i].ctypes.data, None, None, 0, 0), "download")
-            if i == 0:
-                t2 = time.perf_counter()         # the first download waits for the batch's kernels
-        t3 = time.perf_counter()
-        t_first += t2 - t1; t_d2h += t3 - t2
-        hashing = (b, [hpool.submit(md5_frame, i) for i in range(n)])
+        hashing = (b, [hpool.submit(md5_frame, b & 1, i) for i in range(n)])
 
     t0 = time.perf_counter()
     pending = submit_parse(0)
@@ -106,33 +116,36 @@ def run(P, device=0, fixture="kf_1920x1080", nframes=1024, batch=128, threads=No
         for f in pending:
             assert f.result() == 0, "end-to-end probe wants key frames"
         n = len(pending)
-        tb = time.perf_counter()
-        # the previous batch comes back BEFORE this one's uploads are queued on the (in-order) stream: the download
-        # then only waits for kernels that had a whole iteration to finish, and this batch's H2D overlaps the feeder
-        if prev is not None:
-            download(*prev)
-        tc = time.perf_counter()
-        launch(b, n)
         if b + 1 < nbatch:
-            pending = submit_parse(b + 1)              # set (b+1)%3: last used by batch b-2, downloaded already
+            # the feeder goes on with the next batch at once (slot set (b+1)%3 was last used by batch b-2, which came back an
+            # iteration ago) while this thread uploads and launches batch b and collects batch b-1
+            pending = submit_parse(b + 1)
+        tb = time.perf_counter()
+        launch(b, n)
+        tc = time.perf_counter()
+        if prev is not None:
+            arrived(*prev)                             # (its copy ran beside this batch's uploads)
+        ctx._chk(L.vp8hip_frames_download_async(ctx.h, (b % 3) * batch, n, host[b & 1].ctypes.data), "vp8hip_frames_download_async")
         prev = (b, n)
         td = time.perf_counter()
-        t_parse += tb - ta; t_out += tc - tb; t_gpu += td - tc
-    download(*prev)
+        t_parse += tb - ta; t_gpu += tc - tb; t_out += td - tc
+    arrived(*prev)
     collect()
     elapsed = time.perf_counter() - t0
     pool.shutdown()
     hpool.shutdown()
     for ps in parsers:
         ps.close()
+    ctx_nmb = ctx.nmb
     ctx.close()
     return {"workload": f"{fixture}.ivf looped to {nframes} key frames, compressed input in host memory -> per-frame MD5 "
                         f"(entropy decode on {threads} host threads, H2D of the IR, pixel path, D2H, MD5)",
             "Mpix_s": round(nframes * w * h / elapsed / 1e6, 1), "frames_per_s": round(nframes / elapsed, 1),
             "host_threads": threads, "frames": nframes, "frames_per_launch": batch, "md5_mismatches": bad,
+            "h2d_bytes_per_pixel": round(h2d_bytes[0] / (nframes * w * h), 3),
+            "h2d_bytes_per_pixel_dense_ir": round(ctx_nmb * 864 / (w * h), 3),
             "main_thread_s": {"waiting_for_feeder": round(t_parse, 3), "upload_and_launch": round(t_gpu, 3),
-                              "download": round(t_out, 3),
-                              "of_which_waiting_for_kernels": round(t_first, 3), "of_which_d2h": round(t_d2h, 3)}}
+                              "waiting_for_the_previous_batch_to_arrive": round(t_out, 3)}}
 
 
 if __name__ == "__main__":
