@@ -14,6 +14,7 @@
 // (same CU, same L1/L2: workgroup-scope release/acquire).  Vertical edges use one lane per pixel
 // row, horizontal edges one lane per pixel column; Y, U and V edges of the same kind share a step.
 #include "vp8_common.hip.h"
+#include "vp8_block_prims.hip.h"
 
 // Per-wave LDS tile = a RING of 8 macroblock columns: luma 20 rows (y = -4..15) x 128 bytes, chroma
 // 12 rows (y = -4..7) x 64 bytes, addressed by the absolute x inside the MB row modulo the ring.
@@ -32,106 +33,11 @@ struct __attribute__((aligned(16))) LfWaveLds {
 };
 static_assert(sizeof(LfWaveLds) == 4096, "LfWaveLds layout");
 
-__device__ __forceinline__ int sc8(int v) { return v < -128 ? -128 : (v > 127 ? 127 : v); }
-__device__ __forceinline__ int iabs(int v) { return v < 0 ? -v : v; }
-
-// vp8_filter_mask (loopfilter_filters.c:27-40): true = filter this position
-__device__ __forceinline__ bool lf_mask(int limit, int blimit, const int p[8])
-{
-    bool m = iabs(p[0] - p[1]) > limit;
-    m |= iabs(p[1] - p[2]) > limit;
-    m |= iabs(p[2] - p[3]) > limit;
-    m |= iabs(p[5] - p[4]) > limit;
-    m |= iabs(p[6] - p[5]) > limit;
-    m |= iabs(p[7] - p[6]) > limit;
-    m |= iabs(p[3] - p[4]) * 2 + iabs(p[2] - p[5]) / 2 > blimit;
-    return !m;
-}
-// vp8_hevmask (:43-49)
-__device__ __forceinline__ bool lf_hev(int thr, const int p[8])
-{
-    return iabs(p[2] - p[3]) > thr || iabs(p[5] - p[4]) > thr;
-}
-// vp8_filter (:51-95): p[2..5] = p1 p0 q0 q1
-__device__ __forceinline__ void lf_inner(int p[8], bool mask, bool hev)
-{
-    int ps1 = p[2] - 128, ps0 = p[3] - 128, qs0 = p[4] - 128, qs1 = p[5] - 128;
-    int f = sc8(ps1 - qs1);
-    f = hev ? f : 0;
-    f = sc8(f + 3 * (qs0 - ps0));
-    f = mask ? f : 0;
-    int f1 = sc8(f + 4) >> 3, f2 = sc8(f + 3) >> 3;
-    p[4] = sc8(qs0 - f1) + 128;
-    p[3] = sc8(ps0 + f2) + 128;
-    f = (f1 + 1) >> 1;
-    f = hev ? 0 : f;
-    p[5] = sc8(qs1 - f) + 128;
-    p[2] = sc8(ps1 + f) + 128;
-}
-// vp8_mbfilter (:161-214): p[1..6] = p2 p1 p0 q0 q1 q2
-__device__ __forceinline__ void lf_mbedge(int p[8], bool mask, bool hev)
-{
-    int ps2 = p[1] - 128, ps1 = p[2] - 128, ps0 = p[3] - 128;
-    int qs0 = p[4] - 128, qs1 = p[5] - 128, qs2 = p[6] - 128;
-    int f = sc8(ps1 - qs1);
-    f = sc8(f + 3 * (qs0 - ps0));
-    f = mask ? f : 0;
-    int f2 = hev ? f : 0;
-    int f1 = sc8(f2 + 4) >> 3;
-    f2 = sc8(f2 + 3) >> 3;
-    qs0 = sc8(qs0 - f1);
-    ps0 = sc8(ps0 + f2);
-    f = hev ? 0 : f;
-    int u = sc8((63 + f * 27) >> 7);
-    p[4] = sc8(qs0 - u) + 128;
-    p[3] = sc8(ps0 + u) + 128;
-    u = sc8((63 + f * 18) >> 7);
-    p[5] = sc8(qs1 - u) + 128;
-    p[2] = sc8(ps1 + u) + 128;
-    u = sc8((63 + f * 9) >> 7);
-    p[6] = sc8(qs2 - u) + 128;
-    p[1] = sc8(ps2 + u) + 128;
-}
-// vp8_simple_filter_mask + vp8_simple_filter (:292-315): p[2..5] = p1 p0 q0 q1
-__device__ __forceinline__ void lf_simple(int p[8], int blimit)
-{
-    bool mask = iabs(p[3] - p[4]) * 2 + iabs(p[2] - p[5]) / 2 <= blimit;
-    int p1 = p[2] - 128, p0 = p[3] - 128, q0 = p[4] - 128, q1 = p[5] - 128;
-    int f = sc8(p1 - q1);
-    f = sc8(f + 3 * (q0 - p0));
-    f = mask ? f : 0;
-    int f1 = sc8(f + 4) >> 3;
-    p[4] = sc8(q0 - f1) + 128;
-    int f2 = sc8(f + 3) >> 3;
-    p[3] = sc8(p0 + f2) + 128;
-}
-
-struct LfParams { int mblim, blim, lim, hev_thr; };
-
 // All edges of one pixel line held in registers: a[0..19] = positions -4..15 across the MB
 // (x for the vertical-edge pass, y for the horizontal-edge pass; chroma lines use a[0..11]).
 // Order and gating exactly as vp8_loop_filter_frame (loopfilter.c:265-299): MB edge at 0 (if there
 // is a neighbour), then inner edges at 4, 8, 12 (if !skip_lf); chroma has edges 0 and 4 only and
 // is not touched by the simple filter.
-__device__ __forceinline__ void filter_edge(int *q0, int kind, const LfParams &lp, int edge_limit)
-{
-    int p[8];
-#pragma unroll
-    for (int i = 0; i < 8; i++) p[i] = q0[i - 4];
-    if (kind == 2) {
-        lf_simple(p, edge_limit);
-        q0[-1] = p[3]; q0[0] = p[4];
-        return;
-    }
-    const bool m = lf_mask(lp.lim, edge_limit, p), hv = lf_hev(lp.hev_thr, p);
-    if (kind == 1) {
-        lf_mbedge(p, m, hv);
-        q0[-3] = p[1]; q0[2] = p[6];
-    } else
-        lf_inner(p, m, hv);
-    q0[-2] = p[2]; q0[-1] = p[3]; q0[0] = p[4]; q0[1] = p[5];
-}
-
 __device__ __forceinline__ void filter_line(int a[20], bool luma, bool simple, bool mb_edge, bool inner,
                                             const LfParams &lp)
 {

@@ -28,36 +28,8 @@
 //     registers with v_perm / v_alignbyte, predictor table and residuals preloaded).
 //   * integer only (u8 pixels, i16 coefficients, i32 accumulators); no MFMA by design.
 #include "vp8_common.hip.h"
+#include "vp8_block_prims.hip.h"
 #include <stddef.h>
-
-// ---- 4x4 intra predictor table (derived from vp8/common/reconintra4x4.c:16-303, same as the
-// oracle's): edge vector P[0..14] = {L3,L3,L2,L1,L0,TL,A0..A7,A7}; entry = kind<<4 | k with kind
-// 0: P[k], 1: (P[k]+P[k+1]+1)>>1, 2: (P[k-1]+2P[k]+P[k+1]+2)>>2.  Rows = modes; B_DC / B_TM (rows
-// 0,1) are computed directly.
-#define C_(k) (0x00 | (k))
-#define A_(k) (0x10 | (k))
-#define F_(k) (0x20 | (k))
-__constant__ static const unsigned char k_bpred_tab[10 * 16] = {
-    0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0,
-    0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0,
-    F_(6), F_(7), F_(8), F_(9), F_(6), F_(7), F_(8), F_(9), F_(6), F_(7), F_(8), F_(9), F_(6), F_(7), F_(8), F_(9),
-    F_(4), F_(4), F_(4), F_(4), F_(3), F_(3), F_(3), F_(3), F_(2), F_(2), F_(2), F_(2), F_(1), F_(1), F_(1), F_(1),
-    F_(7), F_(8), F_(9), F_(10), F_(8), F_(9), F_(10), F_(11), F_(9), F_(10), F_(11), F_(12), F_(10), F_(11), F_(12), F_(13),
-    F_(5), F_(6), F_(7), F_(8), F_(4), F_(5), F_(6), F_(7), F_(3), F_(4), F_(5), F_(6), F_(2), F_(3), F_(4), F_(5),
-    A_(5), A_(6), A_(7), A_(8), F_(5), F_(6), F_(7), F_(8), F_(4), A_(5), A_(6), A_(7), F_(3), F_(5), F_(6), F_(7),
-    A_(6), A_(7), A_(8), A_(9), F_(7), F_(8), F_(9), F_(10), A_(7), A_(8), A_(9), F_(11), F_(8), F_(9), F_(10), F_(12),
-    A_(4), F_(5), F_(6), F_(7), A_(3), F_(4), A_(4), F_(5), A_(2), F_(3), A_(3), F_(4), A_(1), F_(2), A_(2), F_(3),
-    A_(3), F_(3), A_(2), F_(2), A_(2), F_(2), A_(1), F_(1), A_(1), F_(1), C_(1), C_(1), C_(1), C_(1), C_(1), C_(1),
-};
-#undef C_
-#undef A_
-#undef F_
-
-// sub-pixel filter taps (vp8/common/filter.c:16-39)
-__constant__ static const short k_sixtap[8][6] = {
-    { 0, 0, 128, 0, 0, 0 }, { 0, -6, 123, 12, -1, 0 }, { 2, -11, 108, 36, -8, 1 }, { 0, -9, 93, 50, -6, 0 },
-    { 3, -16, 77, 77, -16, 3 }, { 0, -6, 50, 93, -9, 0 }, { 1, -8, 36, 108, -11, 2 }, { 0, -1, 12, 123, -6, 0 }
-};
 
 // ---- per-wave LDS working set ----------------------------------------------------------------
 //   tY: 17 rows (y = -1..15), 40-byte rows: x = -4..-1 at 12..15, x = 0..15 at 16..31 (16-byte
@@ -84,15 +56,6 @@ static_assert(offsetof(WaveLds, tY) % 16 == 0 && offsetof(WaveLds, tU) % 16 == 0
               && offsetof(WaveLds, res) % 16 == 0, "WaveLds alignment");
 
 #define LINE_PAD 16   // line[LINE_PAD + x]; x = -4..-1 readable (x = -1 is the 129 left border), x up to W+3 valid
-
-typedef unsigned int u32;
-
-__device__ __forceinline__ u32 dpp_xor1(u32 v) { return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, false); }
-__device__ __forceinline__ u32 dpp_xor2(u32 v) { return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, false); }
-__device__ __forceinline__ u32 perm(u32 hi, u32 lo, u32 sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
-__device__ __forceinline__ int sad4(u32 v) { return (int)__builtin_amdgcn_sad_u8(v, 0u, 0u); }
-__device__ __forceinline__ int sext16(u32 v) { return (int)(short)(v & 0xffff); }
-__device__ __forceinline__ int hi16(u32 v) { return (int)v >> 16; }
 
 // 4x4 transpose of 16-bit values across the four lanes of a quad.  In: lane j holds column j as
 // (o0,o1,o2,o3) = rows 0..3 (truncated to 16 bits here, as the reference's `short output[16]`).
@@ -135,27 +98,6 @@ __device__ __forceinline__ void build_dequant(const vp8ir_frame_hdr &h, short (*
     }
 }
 
-// Column (vertical) pass of vp8_short_idct4x4llm_c (idctllm.c:39-60); results are truncated to
-// i16 by the packing in quad_transpose16.
-__device__ __forceinline__ void idct_col(int i0, int i1, int i2, int i3, int o[4])
-{
-    int a1 = i0 + i2, b1 = i0 - i2;
-    int c1 = ((i1 * 35468) >> 16) - (i3 + ((i3 * 20091) >> 16));
-    int d1 = (i1 + ((i1 * 20091) >> 16)) + ((i3 * 35468) >> 16);
-    o[0] = a1 + d1; o[3] = a1 - d1; o[1] = b1 + c1; o[2] = b1 - c1;
-}
-// Row (horizontal) pass with the (x+4)>>3 rounding (idctllm.c:65-88); outputs are i16 values.
-__device__ __forceinline__ void idct_row(const int t[4], int o[4])
-{
-    int a1 = t[0] + t[2], b1 = t[0] - t[2];
-    int c1 = ((t[1] * 35468) >> 16) - (t[3] + ((t[3] * 20091) >> 16));
-    int d1 = (t[1] + ((t[1] * 20091) >> 16)) + ((t[3] * 35468) >> 16);
-    o[0] = (short)((a1 + d1 + 4) >> 3);
-    o[3] = (short)((a1 - d1 + 4) >> 3);
-    o[1] = (short)((b1 + c1 + 4) >> 3);
-    o[2] = (short)((b1 - c1 + 4) >> 3);
-}
-
 // four int16 coefficients (one 4x4 block column) as loaded: two dwords
 typedef unsigned int coef4 __attribute__((ext_vector_type(2)));
 typedef GLOBAL_AS const coef4 *g_cs4p;
@@ -164,81 +106,6 @@ __device__ __forceinline__ int c4x(coef4 v) { return (int)(short)(v.x & 0xffff);
 __device__ __forceinline__ int c4y(coef4 v) { return (int)v.x >> 16; }
 __device__ __forceinline__ int c4z(coef4 v) { return (int)(short)(v.y & 0xffff); }
 __device__ __forceinline__ int c4w(coef4 v) { return (int)v.y >> 16; }
-
-__device__ __forceinline__ u32 add_clamp_pack(u32 pred, const int r[4])
-{
-    u32 out = 0;
-#pragma unroll
-    for (int i = 0; i < 4; i++) out |= (u32)clamp255((int)((pred >> (8 * i)) & 0xff) + r[i]) << (8 * i);
-    return out;
-}
-
-// Whole-block intra predictors (reconintra.c:139-241, 403-521) for a 4-pixel row segment:
-// above = the 4 pixels above the segment's columns, left = pixel left of the segment's row.
-__device__ __forceinline__ u32 intra_pred4(int mode, u32 above, int left, int tl, int dc)
-{
-    if (mode == VP8IR_DC_PRED) return (u32)dc * 0x01010101u;
-    if (mode == VP8IR_V_PRED) return above;
-    if (mode == VP8IR_H_PRED) return (u32)left * 0x01010101u;
-    u32 out = 0;
-#pragma unroll
-    for (int i = 0; i < 4; i++) out |= (u32)clamp255(left + (int)((above >> (8 * i)) & 0xff) - tl) << (8 * i);
-    return out;
-}
-
-// ---- six-tap building blocks (filter.c:41-128), two pixels per instruction on 16-bit lanes --------------
-// A first-pass sum lies in -8160 .. 40864, so biased by 8192 it is an unsigned 16-bit number and wrap-around
-// arithmetic (v_pk_mad_u16, negative taps as their two's complement) is exact; (t + 8192) >> 7 == (t >> 7) + 64, and
-// a saturating subtraction of 64 plus a minimum with 255 are the clamp.  The second pass has the same range.
-typedef unsigned short v2u16 __attribute__((ext_vector_type(2)));
-struct SixTaps { v2u16 t[6]; };
-__device__ __forceinline__ SixTaps sixtap_taps(int f)
-{
-    SixTaps r;
-#pragma unroll
-    for (int k = 0; k < 6; k++) { const unsigned short t = (unsigned short)k_sixtap[f][k]; r.t[k] = (v2u16){ t, t }; }
-    return r;
-}
-__device__ __forceinline__ u32 sixtap_finish(v2u16 a01, v2u16 a23)     // two biased sums of two pixels -> four clamped bytes
-{
-    const v2u16 c64 = { 64, 64 }, c255 = { 255, 255 };
-    const v2u16 r01 = __builtin_elementwise_min(__builtin_elementwise_sub_sat(a01 >> 7, c64), c255);
-    const v2u16 r23 = __builtin_elementwise_min(__builtin_elementwise_sub_sat(a23 >> 7, c64), c255);
-    return __builtin_amdgcn_perm(__builtin_bit_cast(u32, r23), __builtin_bit_cast(u32, r01), 0x06040200u);
-}
-// first pass for four output pixels: s points at the pixel two left of the first one (nine pixels are read, as three
-// aligned dwords shifted into place)
-__device__ __forceinline__ u32 sixtap_hrow(g_cu8p s, const SixTaps &tx)
-{
-    auto asv = [](u32 v) { return __builtin_bit_cast(v2u16, v); };
-    auto perm = [](u32 hi, u32 lo, u32 sel) { return __builtin_amdgcn_perm(hi, lo, sel); };
-    const u32 sh = (u32)(unsigned long)s & 3u;
-    g_cu32p rp = (g_cu32p)(s - sh);
-    const u32 d0 = rp[0], d1 = rp[1], d2 = rp[2];
-    const u32 w0 = __builtin_amdgcn_alignbyte(d1, d0, sh), w1 = __builtin_amdgcn_alignbyte(d2, d1, sh);
-    const u32 w2 = __builtin_amdgcn_alignbyte(0u, d2, sh);
-    // P[k] = pixels (k, k+1) of the row, one per 16-bit lane
-    const v2u16 P[8] = { asv(perm(w0, w0, 0x0c010c00u)), asv(perm(w0, w0, 0x0c020c01u)), asv(perm(w0, w0, 0x0c030c02u)),
-                         asv(perm(w1, w0, 0x0c040c03u)), asv(perm(w1, w1, 0x0c010c00u)), asv(perm(w1, w1, 0x0c020c01u)),
-                         asv(perm(w1, w1, 0x0c030c02u)), asv(perm(w2, w1, 0x0c040c03u)) };
-    const v2u16 bias = { 64 + 8192, 64 + 8192 };
-    v2u16 a01 = bias, a23 = bias;
-#pragma unroll
-    for (int k = 0; k < 6; k++) { a01 += P[k] * tx.t[k]; a23 += P[k + 2] * tx.t[k]; }
-    return sixtap_finish(a01, a23);
-}
-// second pass: H[k] = four first-pass pixels (bytes) of source row k - 2
-__device__ __forceinline__ u32 sixtap_vcol(const u32 H[6], const SixTaps &ty)
-{
-    const v2u16 bias = { 64 + 8192, 64 + 8192 };
-    v2u16 a01 = bias, a23 = bias;
-#pragma unroll
-    for (int k = 0; k < 6; k++) {
-        a01 += __builtin_bit_cast(v2u16, __builtin_amdgcn_perm(H[k], H[k], 0x0c010c00u)) * ty.t[k];
-        a23 += __builtin_bit_cast(v2u16, __builtin_amdgcn_perm(H[k], H[k], 0x0c030c02u)) * ty.t[k];
-    }
-    return sixtap_finish(a01, a23);
-}
 
 // ---- inter prediction of a 4-pixel row segment (reconinter.c:161-227 + filter.c) --------------
 // ref points at pixel (0,0) of the plane; (px,py) = integer position of the first output pixel in

@@ -198,6 +198,13 @@ static void intra_pred_plane(unsigned char *p, int stride, int n, int mode, int 
     }
 }
 
+/* The in-place predictor of one plane under an exported name (vp8_build_intra_predictors_mby_s / mbuv_s by the fields
+ * of MACROBLOCKD they read; n = 16 for luma, 8 for a chroma plane). */
+void vp8o_build_intra_predictors_plane_s(unsigned char *p, int stride, int n, int mode, int up, int left)
+{
+    intra_pred_plane(p, stride, n, mode, up, left);
+}
+
 /* ========================================================================================
  * a8: 4x4 sub-block intra prediction (reconintra4x4.c:16-303)
  *

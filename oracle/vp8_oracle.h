@@ -59,6 +59,7 @@ void vp8o_bilinear_predict(const unsigned char *src, int src_stride, int xoffset
 void vp8o_intra4x4_predict(const unsigned char above[8], const unsigned char left[4], unsigned char top_left,
                            int b_mode, unsigned char *dst, int dst_stride);
 /* same entry point with the reference's pointer convention (reads src[-stride-1 ..]) */
+void vp8o_build_intra_predictors_plane_s(unsigned char *p, int stride, int n, int mode, int up_available, int left_available);
 void vp8o_intra4x4_predict_ptr(unsigned char *src, int src_stride, int b_mode, unsigned char *dst, int dst_stride);
 
 /* loop_filter_info (vp8/common/loopfilter.h:51-57) with scalar members */

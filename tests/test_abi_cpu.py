@@ -52,3 +52,35 @@ def test_product_does_not_link_the_oracle():
         assert "oracle" not in out and "vpxref" not in out
         syms = subprocess.run(["nm", "-D", path], capture_output=True, text=True).stdout
         assert "vp8o_" not in syms
+
+
+def test_rtcd_table_exports(pkg):
+    """include/vp8_rtcd.h: every entry is a function pointer in libvpx_hip.so whose `_hip` specialisation libvp8hip.so
+    exports; the per-block part carries the names of the reference's decoder prototypes (vp8/common/rtcd_defs.sh:20-204)."""
+    src = open(os.path.join(ROOT, "include", "vp8_rtcd.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    blocks = re.findall(r"VP8_RTCD_ENTRY\(\w+, (vp8_\w+),", src)
+    frames = re.findall(r"RTCD_EXTERN int \(\*(\w+)\)", src)
+    assert len(blocks) == 32 and len(frames) == 4
+    host, hip = pkg.load_host(), pkg.load_hip()
+    for n in frames:
+        ctypes.c_void_p.in_dll(host, n)
+        assert hasattr(host, n + "_hip")
+    for n in blocks:
+        ctypes.c_void_p.in_dll(host, n)
+        assert hasattr(hip, n + "_hip"), f"libvp8hip.so does not export {n}_hip"
+    reference = """vp8_dequantize_b vp8_dequant_idct_add vp8_dequant_idct_add_y_block vp8_dequant_idct_add_uv_block
+        vp8_loop_filter_mbv vp8_loop_filter_bv vp8_loop_filter_mbh vp8_loop_filter_bh vp8_loop_filter_simple_mbv
+        vp8_loop_filter_simple_mbh vp8_loop_filter_simple_bv vp8_loop_filter_simple_bh vp8_short_idct4x4llm
+        vp8_short_inv_walsh4x4_1 vp8_short_inv_walsh4x4 vp8_dc_only_idct_add vp8_copy_mem16x16 vp8_copy_mem8x8
+        vp8_copy_mem8x4 vp8_build_intra_predictors_mby vp8_build_intra_predictors_mby_s vp8_build_intra_predictors_mbuv
+        vp8_build_intra_predictors_mbuv_s vp8_intra4x4_predict vp8_sixtap_predict16x16 vp8_sixtap_predict8x8
+        vp8_sixtap_predict8x4 vp8_sixtap_predict4x4 vp8_bilinear_predict16x16 vp8_bilinear_predict8x8
+        vp8_bilinear_predict8x4 vp8_bilinear_predict4x4""".split()
+    ours = [n[:-3] if n.endswith("_px") else n for n in blocks]      # the MACROBLOCKD entries, by fields: `_px`
+    assert sorted(ours) == sorted(reference)
+    # no frame-granular entry reuses a reference name with another signature
+    assert not set(frames) & {"vp8_loop_filter_frame", "vp8_yv12_extend_frame_borders_ptr"}
+    host.vpx_rtcd()
+    for n in frames + blocks:
+        assert ctypes.c_void_p.in_dll(host, n).value, n
