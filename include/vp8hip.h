@@ -102,6 +102,34 @@ int  vp8hip_decode(vp8hip_ctx *ctx, const vp8hip_job *jobs, int njobs, int stage
  * ((w+1)/2) x ((h+1)/2) (U, V) written with the given destination strides.  Synchronous. */
 int  vp8hip_frame_download(vp8hip_ctx *ctx, int fb, int full, uint8_t *y, uint8_t *u, uint8_t *v,
                            int y_stride, int uv_stride);
+/* Output-side post-processing (vp8/common/postproc.c): frame buffer src_fb -> dst_fb, never back into
+ * decoding.  The policy stays with the caller, as in the reference where vp8_post_proc_frame (postproc.c:903-1000) sits above
+ * the filters: it turns the frame's loop-filter level into the thresholds and draws the random phases.
+ *   VP8HIP_PP_DEBLOCK       vp8_deblock (:348-362): vp8_post_proc_down_and_across on Y, U, V with `flimit`
+ *   VP8HIP_PP_DEMACROBLOCK  vp8_deblock_and_de_macro_block (:328-346): the same, then vp8_mbpost_proc_across_ip and
+ *                           vp8_mbpost_proc_down on Y with `mb_flimit`; needs tmp_fb (a third buffer) and the dither table
+ *                           `rv` (vp8_rv, 440 entries) with this frame's rv_offset = 63 & rand() (:286)
+ *   VP8HIP_PP_ADDNOISE      vp8_plane_add_noise (:489-513) on Y: `noise` = the 3072-entry table fillrd (:410-465) built (NULL:
+ *                           unchanged since the previous call), noise_clamp = its blackclamp[0], noise_rows[r] = rand() & 0xff
+ *                           per row of the 16-aligned height.  Frames wider than 2816 are refused: the reference indexes
+ *                           past the end of its table for them.
+ * With neither of the first two flags dst_fb becomes a copy of src_fb (:982).  Asynchronous on the context's stream like
+ * vp8hip_decode; the host arrays may be reused when the call returns. */
+#define VP8HIP_PP_DEBLOCK       1
+#define VP8HIP_PP_DEMACROBLOCK  2
+#define VP8HIP_PP_ADDNOISE      4
+typedef struct vp8hip_pp {
+    int32_t flags;
+    int32_t flimit;
+    int32_t mb_flimit;
+    int32_t rv_offset;
+    int32_t noise_clamp;
+    const int16_t *rv;
+    const int8_t  *noise;
+    const uint8_t *noise_rows;
+} vp8hip_pp;
+int  vp8hip_postproc(vp8hip_ctx *ctx, int src_fb, int dst_fb, int tmp_fb, const vp8hip_pp *pp);
+
 /* Batch form for pipelines (tools/e2e.py, bin/batch_md5): `count` consecutive frame buffers, whole, as ONE asynchronous copy on
  * a stream of its own -- it starts when everything queued on the context's stream so far has finished and runs beside later
  * uploads (PCIe is full duplex).  dst: page-locked memory (vp8hip_host_alloc), frame i at dst + i * vp8hip_frame_stride(ctx)

@@ -232,6 +232,14 @@ def parse_to_numpy(parser, data):
 _hip = None
 
 
+class PostprocParams(ctypes.Structure):     # vp8hip_pp, include/vp8hip.h
+    _fields_ = [("flags", ctypes.c_int32), ("flimit", ctypes.c_int32), ("mb_flimit", ctypes.c_int32), ("rv_offset", ctypes.c_int32),
+                ("noise_clamp", ctypes.c_int32), ("rv", c_void_p), ("noise", c_void_p), ("noise_rows", c_void_p)]
+
+
+PP_DEBLOCK, PP_DEMACROBLOCK, PP_ADDNOISE = 1, 2, 4
+
+
 def load_hip():
     global _hip
     if _hip is None:
@@ -260,6 +268,7 @@ def load_hip():
         L.vp8hip_get_stats.argtypes = [c_void_p, c_void_p]
         L.vp8hip_stream.argtypes = [c_void_p]
         L.vp8hip_stream.restype = c_void_p
+        L.vp8hip_postproc.argtypes = [c_void_p, c_int, c_int, c_int, ctypes.POINTER(PostprocParams)]
         _hip = L
     return _hip
 
@@ -383,6 +392,15 @@ class Vp8Hip:
     def upload_frame(self, fb, buf):
         assert buf.nbytes == self.g.frame_size
         self._chk(self.L.vp8hip_frame_upload(self.h, fb, buf.ctypes.data), "upload")
+
+    def postproc(self, src_fb, dst_fb, tmp_fb, flags, flimit=0, mb_flimit=0, rv_offset=0, noise=None, noise_clamp=0, noise_rows=None):
+        """Output-side filters of vp8/common/postproc.c from frame buffer src_fb into dst_fb (include/vp8hip.h).  noise: int8
+        array of 3072, noise_rows: uint8 array, one phase per row of the aligned height."""
+        pp = PostprocParams(flags, flimit, mb_flimit, rv_offset, noise_clamp,
+                            ctypes.cast(load_host().vp8t_pp_rv, c_void_p) if flags & PP_DEMACROBLOCK else None,
+                            noise.ctypes.data if noise is not None else None,
+                            noise_rows.ctypes.data if noise_rows is not None else None)
+        self._chk(self.L.vp8hip_postproc(self.h, src_fb, dst_fb, tmp_fb, ctypes.byref(pp)), "postproc")
 
 
 def decode_ivf_gpu(path, device=-1, stages=STAGE_ALL):

@@ -24,6 +24,12 @@ extern "C" __global__ void vp8_loopfilter_simt_kernel(const DevJob *jobs, int nj
 extern "C" __global__ void vp8_loopfilter_kernel(const DevJob *jobs, int njobs, DevGeom g);
 extern "C" __global__ void vp8_extend_kernel(const DevJob *jobs, int njobs, DevGeom g);
 extern "C" __global__ void vp8_detile_kernel(const DevJob *jobs, int njobs, DevGeom g, int extend);
+// vp8_postproc.hip
+void vp8pp_down_and_across(hipStream_t st, const uint8_t *src, uint8_t *dst, int stride, int rows, int cols, int flimit);
+void vp8pp_mb_across(hipStream_t st, const uint8_t *src, uint8_t *dst, int stride, int rows, int cols, int flimit);
+void vp8pp_mb_down(hipStream_t st, const uint8_t *src, uint8_t *dst, int stride, int rows, int cols, int flimit, const short *rv);
+void vp8pp_add_noise(hipStream_t st, uint8_t *plane, int stride, int rows, int cols, int clamp, const signed char *noise,
+                     const uint8_t *row_offset);
 
 // Sparse coefficient streams -> the dense coefficient array the kernels read (include/vp8_ir.h): one thread per 16 bytes of
 // output -- half a block --, which entry of which stream it comes from (or none: zeros) follows from the macroblock's descriptor.
@@ -141,6 +147,8 @@ struct vp8hip_ctx {
     hipEvent_t ev_d2h_from, ev_d2h_done;
     int d2h_first, d2h_count;      // frame buffers of the copy in flight (count 0: none)
     size_t fb_stride;
+    // vp8hip_postproc: dither table (440 shorts), noise table (3072) and per-row noise phases (16384) on the device
+    char *d_pp; bool pp_rv_loaded;
 };
 
 static int fail(vp8hip_ctx *c, int code, const char *fmt, ...)
@@ -166,6 +174,8 @@ static void free_pools(vp8hip_ctx *c)
     if (c->slot_block_dev) (void)hipFree(c->slot_block_dev);
     if (c->gran_recon) (void)hipFree(c->gran_recon);
     if (c->gran_lf) (void)hipFree(c->gran_lf);
+    if (c->d_pp) (void)hipFree(c->d_pp);
+    c->d_pp = nullptr; c->pp_rv_loaded = false;
     c->gran_recon = c->gran_lf = nullptr; c->gran_recon_cap = c->gran_lf_cap = 0;
     for (Slot &s : c->slots) {
         if (s.h_block) (void)hipHostFree(s.h_block);
@@ -834,6 +844,57 @@ extern "C" int vp8hip_frame_download(vp8hip_ctx *c, int fb, int full, uint8_t *y
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return check_status(c);
+}
+
+// Output-side post-processing of one frame buffer into another (vp8_post_proc_frame, vp8/common/postproc.c:903-1000, minus
+// the policy: the caller has turned the frame's quantiser into thresholds and drawn the random phases).
+extern "C" int vp8hip_postproc(vp8hip_ctx *c, int src_fb, int dst_fb, int tmp_fb, const vp8hip_pp *pp)
+{
+    const int nfb = c ? (int)c->fb.size() : 0;
+    if (!c || !pp || src_fb < 0 || src_fb >= nfb || dst_fb < 0 || dst_fb >= nfb || dst_fb == src_fb)
+        return fail(c, -2, "vp8hip_postproc: bad arguments");
+    const bool demacro = pp->flags & VP8HIP_PP_DEMACROBLOCK, deblock = demacro || (pp->flags & VP8HIP_PP_DEBLOCK);
+    const bool noise = pp->flags & VP8HIP_PP_ADDNOISE;
+    if (demacro && (tmp_fb < 0 || tmp_fb >= nfb || tmp_fb == src_fb || tmp_fb == dst_fb || !pp->rv || pp->rv_offset < 0 || pp->rv_offset > 63))
+        return fail(c, -2, "vp8hip_postproc: demacroblocking needs a third frame buffer and the dither table");
+    const vp8ir_geom &g = c->geom;
+    // the noise row of a line starts up to 255 entries into the 3072-entry table (the reference indexes past its end for
+    // wider frames, postproc.c:499-510: no defined answer to reproduce)
+    if (noise && (!pp->noise_rows || g.aligned_w + 255 > 3072 || g.aligned_h > 16384))
+        return fail(c, -2, "vp8hip_postproc: noise needs the row phases and a frame at most 2816 wide");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (join_detile(c)) return -1;
+    if (c->d2h_count) { HIPCHK(c, hipEventSynchronize(c->ev_d2h_done)); c->d2h_count = 0; }   // a batch download may be reading dst
+    if (!c->d_pp) HIPCHK(c, hipMalloc((void **)&c->d_pp, 1024 + 3072 + 16384));
+    const short *d_rv = (const short *)c->d_pp;
+    signed char *d_noise = (signed char *)c->d_pp + 1024;
+    uint8_t *d_rows = (uint8_t *)c->d_pp + 1024 + 3072;
+    uint8_t *src = c->fb[src_fb], *dst = c->fb[dst_fb];
+    const struct { int off, stride, rows, cols; } pl[3] = { { g.y_off, g.y_stride, g.aligned_h, g.aligned_w },
+                                                            { g.u_off, g.uv_stride, g.aligned_h / 2, g.aligned_w / 2 },
+                                                            { g.v_off, g.uv_stride, g.aligned_h / 2, g.aligned_w / 2 } };
+    if (deblock) {
+        for (int k = 0; k < 3; k++)
+            vp8pp_down_and_across(c->stream, src + pl[k].off, dst + pl[k].off, pl[k].stride, pl[k].rows, pl[k].cols, pp->flimit);
+        if (demacro) {       // luma only (vp8_deblock_and_de_macro_block, postproc.c:328-346)
+            uint8_t *tmp = c->fb[tmp_fb];
+            if (!c->pp_rv_loaded) {
+                HIPCHK(c, hipMemcpyAsync(c->d_pp, pp->rv, 440 * sizeof(short), hipMemcpyHostToDevice, c->stream));
+                c->pp_rv_loaded = true;
+            }
+            vp8pp_mb_across(c->stream, dst + pl[0].off, tmp + pl[0].off, pl[0].stride, pl[0].rows, pl[0].cols, pp->mb_flimit);
+            vp8pp_mb_down(c->stream, tmp + pl[0].off, dst + pl[0].off, pl[0].stride, pl[0].rows, pl[0].cols, pp->mb_flimit,
+                          d_rv + pp->rv_offset);
+        }
+    } else       // vp8_yv12_copy_frame_ptr (postproc.c:982)
+        HIPCHK(c, hipMemcpyAsync(dst, src, (size_t)g.frame_size, hipMemcpyDeviceToDevice, c->stream));
+    if (noise) {
+        if (pp->noise) HIPCHK(c, hipMemcpyAsync(d_noise, pp->noise, 3072, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(d_rows, pp->noise_rows, (size_t)pl[0].rows, hipMemcpyHostToDevice, c->stream));
+        vp8pp_add_noise(c->stream, dst + pl[0].off, pl[0].stride, pl[0].rows, pl[0].cols, pp->noise_clamp, d_noise, d_rows);
+    }
+    HIPCHK(c, hipGetLastError());
+    return 0;
 }
 
 extern "C" size_t vp8hip_frame_stride(const vp8hip_ctx *c) { return c ? c->fb_stride : 0; }

@@ -20,7 +20,13 @@
 #include "vpx/vp8dx.h"
 #include "vpx_codec_internal.h"
 
-#define VP8_CAP_POSTPROC 0          /* CONFIG_POSTPROC 0 in the decoder-only generic build */
+#include "vp8_postproc_host.h"
+
+#define VP8_CAP_POSTPROC VPX_CODEC_CAP_POSTPROC      /* vp8_dx_iface.c:25 with CONFIG_POSTPROC */
+/* frame buffers: the reference's four (NUM_YV12_BUFFERS) + post_proc_buffer + a work buffer of the demacroblocking filter */
+#define FB_DECODE 4
+#define FB_POST   4
+#define FB_PPTMP  5
 
 struct vpx_codec_alg_priv {
     vpx_codec_priv_t        base;
@@ -43,6 +49,10 @@ struct vpx_codec_alg_priv {
     const uint8_t          *frag[9];
     size_t                  frag_sz[9];
     int                     num_frags;
+    /* VPX_CODEC_USE_POSTPROC (vp8_dx_iface.c:65-66,421-431,446-466) */
+    int                     postproc_cfg_set;
+    vp8_postproc_cfg_t      postproc_cfg;
+    vp8_pp_state           *pp;
     char                    detail[160];
     double                  t_parse, t_launch, t_down;   /* VP8HIP_TRACE: seconds per phase of vp8_decode */
     long                    t_frames;
@@ -89,6 +99,7 @@ static vpx_codec_err_t vp8_destroy(vpx_codec_alg_priv_t *p)
                 p->t_parse / p->t_frames * 1e3, p->t_launch / p->t_frames * 1e3, p->t_down / p->t_frames * 1e3);
     if (p->hip) { vp8hip_host_free(p->hip, p->host_frame); vp8hip_destroy(p->hip); }
     vp8_parser_destroy(p->parser);
+    free(p->pp);
     free(p);
     return VPX_CODEC_OK;
 }
@@ -211,7 +222,8 @@ static vpx_codec_err_t vp8_decode(vpx_codec_alg_priv_t *p, const uint8_t *data, 
         return set_detail(p, (vpx_codec_err_t)rc, vp8_parser_error(p->parser));
     }
     if (hdr.width != p->width || hdr.height != p->height) {       /* vp8_alloc_frame_buffers */
-        if (vp8hip_configure(p->hip, hdr.width, hdr.height, 4, 1)) {
+        if (vp8hip_configure(p->hip, hdr.width, hdr.height,
+                             (p->base.init_flags & VPX_CODEC_USE_POSTPROC) ? FB_DECODE + 2 : FB_DECODE, 1)) {
             vp8_refs_release_new(&p->refs);
             p->width = p->height = 0;
             return gpu_error(p, "vp8hip_configure");
@@ -276,8 +288,25 @@ static vpx_codec_err_t vp8_decode(vpx_codec_alg_priv_t *p, const uint8_t *data, 
 
     t2 = now_s();
     if (hdr.show_frame) {
+        int show_fb = p->refs.show_idx;
+        if (p->base.init_flags & VPX_CODEC_USE_POSTPROC) {
+            /* vp8dx_get_raw_frame -> vp8_post_proc_frame (onyxd_if.c:723, postproc.c:903): the shown frame goes through the
+               output filters into post_proc_buffer, and that is the image the application gets */
+            vp8hip_pp pp;
+            if (!p->postproc_cfg_set) {                       /* the reference's default (vp8_dx_iface.c:421-431) */
+                p->postproc_cfg.post_proc_flag = VP8_DEBLOCK | VP8_DEMACROBLOCK | VP8_MFQE;
+                p->postproc_cfg.deblocking_level = 4;
+                p->postproc_cfg.noise_level = 0;
+                p->postproc_cfg_set = 1;
+            }
+            if (!p->pp && !(p->pp = (vp8_pp_state *)calloc(1, sizeof *p->pp))) return VPX_CODEC_MEM_ERROR;
+            if (vp8_pp_prepare(p->pp, &p->postproc_cfg, hdr.filter_level, p->geom.aligned_h, &pp)) {
+                if (vp8hip_postproc(p->hip, show_fb, FB_POST, FB_PPTMP, &pp)) return gpu_error(p, "vp8hip_postproc");
+                show_fb = FB_POST;
+            }
+        }
         /* the whole frame buffer, borders included, in one linear copy into the pinned mirror (same vp8ir_geom layout) */
-        if (vp8hip_frame_download(p->hip, p->refs.show_idx, 1, p->host_frame, NULL, NULL, 0, 0))
+        if (vp8hip_frame_download(p->hip, show_fb, 1, p->host_frame, NULL, NULL, 0, 0))
             return gpu_error(p, "vp8hip_frame_download");
         publish_image(p, user_priv);
         p->img_avail = 1;
@@ -310,8 +339,19 @@ static vpx_codec_err_t ctl_get_int(vpx_codec_alg_priv_t *p, int ctrl_id, va_list
 static vpx_codec_err_t ctl_incapable(vpx_codec_alg_priv_t *p, int ctrl_id, va_list ap)
 {
     (void)ctrl_id; (void)ap;
-    /* postproc: outside the hot path */
+    /* the debug overlays of CONFIG_POSTPROC_VISUALIZER (vp8_dx_iface.c:674-697 answers the same way without it) */
     return set_detail(p, VPX_CODEC_INCAPABLE, "control not implemented by the HIP decoder");
+}
+
+/* vp8_set_postproc (vp8_dx_iface.c:653-672) */
+static vpx_codec_err_t ctl_set_postproc(vpx_codec_alg_priv_t *p, int ctrl_id, va_list ap)
+{
+    vp8_postproc_cfg_t *data = va_arg(ap, vp8_postproc_cfg_t *);
+    (void)ctrl_id;
+    if (!data) return VPX_CODEC_INVALID_PARAM;
+    p->postproc_cfg_set = 1;
+    p->postproc_cfg = *data;
+    return VPX_CODEC_OK;
 }
 
 /* VP8_COPY_REFERENCE / VP8_SET_REFERENCE (vp8_dx_iface.c:611-651 -> vp8dx_get_reference / vp8dx_set_reference,
@@ -385,7 +425,11 @@ static vpx_codec_err_t ctl_reference(vpx_codec_alg_priv_t *p, int ctrl_id, va_li
 static vpx_codec_ctrl_fn_map_t vp8_ctf_maps[] = {
     { VP8_SET_REFERENCE, ctl_reference },
     { VP8_COPY_REFERENCE, ctl_reference },
-    { VP8_SET_POSTPROC, ctl_incapable },
+    { VP8_SET_POSTPROC, ctl_set_postproc },
+    { VP8_SET_DBG_COLOR_REF_FRAME, ctl_incapable },
+    { VP8_SET_DBG_COLOR_MB_MODES, ctl_incapable },
+    { VP8_SET_DBG_COLOR_B_MODES, ctl_incapable },
+    { VP8_SET_DBG_DISPLAY_MV, ctl_incapable },
     { VP8D_GET_LAST_REF_UPDATES, ctl_get_int },
     { VP8D_GET_FRAME_CORRUPTED, ctl_get_int },
     { VP8D_GET_LAST_REF_USED, ctl_get_int },

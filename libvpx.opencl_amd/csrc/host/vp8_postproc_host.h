@@ -1,0 +1,29 @@
+/* Host side of the output-side post-processing: what vp8_post_proc_frame (vp8/common/postproc.c:903-1000) decides per frame
+ * before the filters run -- thresholds from the frame's loop-filter level, the random phases, the noise table -- handed to
+ * the device as a vp8hip_pp (include/vp8hip.h). */
+#ifndef VP8_POSTPROC_HOST_H
+#define VP8_POSTPROC_HOST_H
+#include "vp8hip.h"
+#include "vpx/vp8.h"
+
+typedef struct vp8_pp_state {           /* struct postproc_state, vp8/common/postproc.h:16-25 */
+    uint32_t rng[34]; int rng_pos; int rng_ready;      /* vp8_pp_rand */
+    int    last_q, last_noise;
+    int    clamp;                       /* blackclamp[0] == whiteclamp[0] */
+    int8_t noise[3072];
+    uint8_t noise_rows[16384];
+} vp8_pp_state;
+
+/* The reference draws its dither and noise phases from the C library's rand() and never seeds it (postproc.c:286,456,499), so
+ * what its binaries produce is defined by the C library's sequence for seed 1.  The GPU runtime shares the process and may
+ * draw from rand() itself, so that sequence is reproduced here, per decoder: glibc's default generator (additive feedback
+ * over 31 words, x[i] = x[i-31] + x[i-3], seeded by the 16807 Lehmer generator, first 310 outputs dropped, >> 1).
+ * tests/test_abi_cpu.py compares it with the C library's. */
+int vp8_pp_rand(vp8_pp_state *st);
+
+/* Fill *pp for one shown frame decoded with loop-filter level `filter_level`, `rows` = its 16-aligned height.  Draws in the
+ * reference's order: once per demacroblocked frame, 3072 times per new noise table, once per noisy row.  Returns the
+ * effective flags (0: show the frame as it is). */
+int vp8_pp_prepare(vp8_pp_state *st, const vp8_postproc_cfg_t *cfg, int filter_level, int rows, vp8hip_pp *pp);
+
+#endif

@@ -5,7 +5,10 @@
  * --md5 (one digest over all output, printed as "<md5>  <outfile>"), -o/--output, --noblit,
  * --summary / --progress (frames, microseconds inside vpx_codec_decode only, fps -- the same
  * bracket as vpxdec.c:1041-1055), --limit, --skip, -t/--threads (accepted, ignored: the GPU path has
- * no CPU worker threads), --codec=vp8, -v.  WebM / raw input and postproc are not provided.
+ * no CPU worker threads), --codec=vp8, -v, and the VP8 post-processing options --postproc, --deblock,
+ * --demacroblock-level=<n>, --noise-level=<n>, --mfqe (vpxdec.c:111-133, 779-812, 983-1002; MFQE is accepted and has no effect).
+ * WebM / raw input are not provided here (the reference's own vpxdec.c, built against this library by oracle/Makefile, reads
+ * them through its nestegg).
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -28,6 +31,10 @@ static void usage_exit(void)
             "      --i420            Output raw I420 frames\n"
             "      --flipuv          Flip the chroma planes in the output\n"
             "      --noblit          Don't process the decoded frames\n"
+            "      --postproc        Postprocess decoded frames\n"
+            "      --deblock         Enable VP8 deblocking\n"
+            "      --demacroblock-level=<arg>  Enable VP8 demacroblocking, w/ level\n"
+            "      --noise-level=<arg>         Enable VP8 postproc add noise\n"
             "      --progress        Show progress after each frame decodes\n"
             "      --limit=<arg>     Stop decoding after n frames\n"
             "      --skip=<arg>      Skip the first n input frames\n"
@@ -65,7 +72,8 @@ int main(int argc, char **argv)
 {
     const char *fn = NULL, *outfile = NULL, *v;
     int use_y4m_order = 0, flipuv = 0, noblit = 0, do_md5 = 0, progress = 0, summary = 0, verbose = 0;
-    int stop_after = 0, skip = 0, frame_in = 0, frame_out = 0, frames_corrupted = 0, rc;
+    int stop_after = 0, skip = 0, frame_in = 0, frame_out = 0, frames_corrupted = 0, rc, postproc = 0;
+    vp8_postproc_cfg_t pp_cfg = { 0, 0, 0 };
     unsigned long dx_time = 0;
     vpx_codec_ctx_t decoder;
     vpx_codec_dec_cfg_t cfg = { 0, 0, 0 };
@@ -86,7 +94,13 @@ int main(int argc, char **argv)
         else if (!strcmp(a, "--summary")) summary = 1;
         else if (!strcmp(a, "--md5")) do_md5 = 1;
         else if (!strcmp(a, "-v") || !strcmp(a, "--verbose")) verbose = 1;
-        else if (!strcmp(a, "--postproc")) fprintf(stderr, "Warning: postproc is not available; ignored\n");
+        else if (!strcmp(a, "--postproc")) postproc = 1;
+        else if (!strcmp(a, "--deblock")) postproc = 1, pp_cfg.post_proc_flag |= VP8_DEBLOCK;
+        else if (!strcmp(a, "--mfqe")) postproc = 1, pp_cfg.post_proc_flag |= VP8_MFQE;
+        else if ((v = optval(a, "--noise-level", argv, &i, argc, NULL)))
+            postproc = 1, pp_cfg.post_proc_flag |= VP8_ADDNOISE, pp_cfg.noise_level = atoi(v);
+        else if ((v = optval(a, "--demacroblock-level", argv, &i, argc, NULL)))
+            postproc = 1, pp_cfg.post_proc_flag |= VP8_DEMACROBLOCK, pp_cfg.deblocking_level = atoi(v);
         else if ((v = optval(a, "--codec", argv, &i, argc, NULL))) {
             if (strcmp(v, "vp8")) { fprintf(stderr, "Error: Unrecognized argument (%s) to --codec\n", v); return EXIT_FAILURE; }
         } else if ((v = optval(a, "--limit", argv, &i, argc, NULL))) stop_after = atoi(v);
@@ -109,8 +123,12 @@ int main(int argc, char **argv)
             if (!out) { fprintf(stderr, "Failed to output file"); return EXIT_FAILURE; }
         } else { fprintf(stderr, "Not dumping raw video to your terminal. Use '-o -' to override.\n"); return EXIT_FAILURE; }
     }
-    if (vpx_codec_dec_init(&decoder, vpx_codec_vp8_dx(), &cfg, 0)) {
+    if (vpx_codec_dec_init(&decoder, vpx_codec_vp8_dx(), &cfg, postproc ? VPX_CODEC_USE_POSTPROC : 0)) {
         fprintf(stderr, "Failed to initialize decoder: %s\n", vpx_codec_error(&decoder));
+        return EXIT_FAILURE;
+    }
+    if (pp_cfg.post_proc_flag && vpx_codec_control(&decoder, VP8_SET_POSTPROC, &pp_cfg)) {
+        fprintf(stderr, "Failed to configure postproc: %s\n", vpx_codec_error(&decoder));
         return EXIT_FAILURE;
     }
     if (verbose) fprintf(stderr, "%s\n", decoder.name);

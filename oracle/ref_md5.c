@@ -11,6 +11,10 @@
  *                                       "frames pixels seconds" (timing brackets only
  *                                       vpx_codec_decode, like vpxdec.c:1041-1055)
  *     ref_md5 --dump K in.ivf out.i420  write shown frame K (1-based) as raw I420
+ *     ref_md5 --pp FLAGS LEVEL NOISE in.ivf out.md5
+ *                                       per-frame md5 listing of the POST-PROCESSED output: the decoder is initialised with
+ *                                       VPX_CODEC_USE_POSTPROC and, unless FLAGS is -1 (the reference's default
+ *                                       configuration, vp8_dx_iface.c:421-431), VP8_SET_POSTPROC {FLAGS, LEVEL, NOISE}
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -25,10 +29,14 @@ static unsigned rd32(const unsigned char *p) { return p[0] | (p[1] << 8) | (p[2]
 static double now(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
 
 int main(int argc, char **argv) {
-    int reps = 1, timing = 0, dumpk = 0;
+    int reps = 1, timing = 0, dumpk = 0, pp = 0;
+    vp8_postproc_cfg_t ppcfg = { 0, 0, 0 };
     int ai = 1;
     if (argc > 2 && !strcmp(argv[1], "--time")) { timing = 1; reps = atoi(argv[2]); ai = 3; }
     else if (argc > 2 && !strcmp(argv[1], "--dump")) { dumpk = atoi(argv[2]); ai = 3; }
+    else if (argc > 4 && !strcmp(argv[1], "--pp")) {
+        pp = 1; ppcfg.post_proc_flag = atoi(argv[2]); ppcfg.deblocking_level = atoi(argv[3]); ppcfg.noise_level = atoi(argv[4]); ai = 5;
+    }
     if (argc - ai < (timing ? 1 : 2)) { fprintf(stderr, "usage: see header comment\n"); return 2; }
     FILE *f = fopen(argv[ai], "rb");
     if (!f) { perror(argv[ai]); return 1; }
@@ -41,7 +49,8 @@ int main(int argc, char **argv) {
     double secs = 0; long frames = 0; double pixels = 0;
     for (int r = 0; r < reps; r++) {
         vpx_codec_ctx_t c;
-        if (vpx_codec_dec_init(&c, vpx_codec_vp8_dx(), NULL, 0)) { fprintf(stderr, "init failed\n"); return 1; }
+        if (vpx_codec_dec_init(&c, vpx_codec_vp8_dx(), NULL, pp ? VPX_CODEC_USE_POSTPROC : 0)) { fprintf(stderr, "init failed\n"); return 1; }
+        if (pp && ppcfg.post_proc_flag >= 0 && vpx_codec_control(&c, VP8_SET_POSTPROC, &ppcfg)) { fprintf(stderr, "VP8_SET_POSTPROC failed\n"); return 1; }
         long pos = 32; int cnt = 0;
         while (pos + 12 <= n) {
             unsigned sz = rd32(buf + pos); pos += 12;

@@ -79,6 +79,16 @@ void vp8o_loop_filter_simple_bh(unsigned char *y, int ys, unsigned char blimit);
  * vp8_loop_filter_frame_init (loopfilter.c:117-201), vp8_loop_filter_update_sharpness (:66-96),
  * lf_init_lut (:24-64) */
 typedef struct vp8o_dequant { short y1[2], y2[2], uv[2]; } vp8o_dequant;   /* [0]=DC, [1]=AC */
+/* output-side post-processing (vp8/common/postproc.c), oracle/vp8_postproc_oracle.c */
+void vp8o_post_proc_down_and_across(const unsigned char *src, unsigned char *dst, int src_stride, int dst_stride,
+                                    int rows, int cols, int flimit);
+void vp8o_mbpost_proc_across(const unsigned char *src, unsigned char *dst, int stride, int rows, int cols, int flimit);
+void vp8o_mbpost_proc_down(const unsigned char *src, unsigned char *dst, int stride, int rows, int cols, int flimit, int rv_offset);
+void vp8o_plane_add_noise(unsigned char *plane, const signed char *noise, int clamp, int width, int height, int stride,
+                          const unsigned char *row_offset);
+void vp8o_pp_strengths(int filter_level, int deblocking_level, int *q, int *ppl, int *ppl_demacro, int *mb_flimit);
+void vp8o_pp_noise_table(int q, int a, const unsigned char *r, signed char noise[3072], int *clamp);
+
 void vp8o_mb_dequant(const vp8ir_frame_hdr *h, int segment_id, vp8o_dequant *dq);
 void vp8o_lf_levels(const vp8ir_frame_hdr *h, unsigned char lvl[4][4][4]);
 void vp8o_lf_limits(int sharpness, int filter_level, int frame_type, vp8o_lf_info *lfi);

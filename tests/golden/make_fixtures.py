@@ -173,7 +173,45 @@ def ref_controls(name):
     L.vpx_codec_destroy(ctx)
 
 
+# Post-processed output (vp8/common/postproc.c behind VPX_CODEC_USE_POSTPROC / VP8_SET_POSTPROC): tag -> the
+# vp8_postproc_cfg_t {post_proc_flag, deblocking_level, noise_level} handed to the REFERENCE decoder by oracle/ref_md5 --pp
+# (flags: VP8_DEBLOCK 1, VP8_DEMACROBLOCK 2, VP8_ADDNOISE 4, vpx/vp8.h:55-66).  The dither and noise phases come from the C
+# library's unseeded rand(), which every run of the reference binary sees in the same state.
+# Not recorded: VP8_MFQE, which is also part of the reference's default configuration (vp8_dx_iface.c:421-431).  The
+# reference dies with SIGSEGV in that path on four of these six streams (`vpxdec --postproc` as well as ref_md5 --pp -1 0 0),
+# so there is nothing to pin a restatement to.
+PP_CONFIGS = {
+    "deblock": (1, 0, 0),
+    "demacro4": (2, 4, 0),
+    "demacro9": (2, 9, 0),
+    "demacro0": (3, 0, 0),
+    "noise3": (4, 0, 3),
+    "deblock_noise1": (5, 0, 1),
+    "demacro6_noise2": (6, 6, 2),
+}
+PP_STREAMS = ("p_arf_176x144", "p_lowrate_640x360", "kf_odd_67x45", "p_odd_130x98", "p_sharp_320x240", "kf_640x360")
+
+
+def postproc_md5(name):
+    for tag, (flags, level, noise) in PP_CONFIGS.items():
+        out = os.path.join(HERE, f"{name}.pp_{tag}.md5")
+        run([REFMD5, "--pp", str(flags), str(level), str(noise), os.path.join(HERE, name + ".ivf"), out])
+
+
+PP_CLI = (("p_arf_176x144", ["--deblock"]), ("p_arf_176x144", ["--demacroblock-level=6", "--noise-level=2"]),
+          ("p_lowrate_640x360", ["--demacroblock-level=3"]), ("p_odd_130x98", ["--noise-level=4", "--deblock"]))
+
+
 def main():
+    if "--postproc" in sys.argv:
+        for name in PP_STREAMS:
+            postproc_md5(name)
+        # the reference's vpxdec with its own option names: one digest over all post-processed frames
+        with open(os.path.join(HERE, "postproc.pp_vpxdec_md5"), "w") as f:
+            for name, args in PP_CLI:
+                r = subprocess.run([VPXDEC, *args, "--md5", "--i420", os.path.join(HERE, name + ".ivf")], capture_output=True, text=True, check=True)
+                f.write(f"{name} {r.stdout.split()[0]} {' '.join(args)}\n")
+        return
     if "--ref-controls" in sys.argv:
         for name in ("p_arf_176x144", "p_split_352x288"):
             ref_controls(name)

@@ -84,3 +84,13 @@ def test_rtcd_table_exports(pkg):
     host.vpx_rtcd()
     for n in frames + blocks:
         assert ctypes.c_void_p.in_dll(host, n).value, n
+
+
+def test_postproc_phase_generator_is_the_c_librarys(pkg):
+    """The post-processing filters' random phases (vp8_postproc_host.h): the reference draws them from the C library's never
+    seeded rand(); the product reproduces that sequence per decoder instead of sharing rand() with the GPU runtime."""
+    H = pkg.load_host()
+    libc = ctypes.CDLL(None)
+    libc.srand(1)
+    st = ctypes.create_string_buffer(40000)
+    assert all(H.vp8_pp_rand(st) == libc.rand() for _ in range(20000))

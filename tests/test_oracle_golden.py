@@ -44,3 +44,23 @@ def test_fixture_matrix_covers_the_paths(pkg):
     assert seen["sharp"] and seen["skip"]
     assert {1, 2}.issubset(seen["refs"])
     assert {1, 4, 8}.issubset(seen["parts"])
+
+
+# ---- post-processed output (vp8/common/postproc.c): tests/golden/<stream>.pp_<tag>.md5, printed by the reference decoder
+#      with VPX_CODEC_USE_POSTPROC + VP8_SET_POSTPROC (make_fixtures.py --postproc) ----
+PP_CONFIGS = {"deblock": (1, 0, 0), "demacro4": (2, 4, 0), "demacro9": (2, 9, 0), "demacro0": (3, 0, 0), "noise3": (4, 0, 3),
+              "deblock_noise1": (5, 0, 1), "demacro6_noise2": (6, 6, 2)}
+PP_STREAMS = ("p_arf_176x144", "p_lowrate_640x360", "kf_odd_67x45", "p_odd_130x98", "p_sharp_320x240", "kf_640x360")
+
+
+def golden_pp_md5(name, tag):
+    import os
+    from vp8_testlib import GOLDEN
+    return [l.split()[0] for l in open(os.path.join(GOLDEN, f"{name}.pp_{tag}.md5"))]
+
+
+@pytest.mark.parametrize("name", PP_STREAMS)
+@pytest.mark.parametrize("tag", PP_CONFIGS)
+def test_postproc_fixture_md5(name, tag):
+    from vp8_testlib import oracle_postproc_ivf
+    assert oracle_postproc_ivf(name, *PP_CONFIGS[tag]) == golden_pp_md5(name, tag)

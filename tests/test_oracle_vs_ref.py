@@ -191,3 +191,69 @@ def test_quant_tables(libs):
             exp = [R.vp8_dc_quant(q, d), R.vp8_ac_yquant(q), R.vp8_dc2quant(q, d), R.vp8_ac2quant(q, d),
                    R.vp8_dc_uv_quant(q, d), R.vp8_ac_uv_quant(q, d)]
             assert list(out) == exp
+
+
+# ---- output-side post-processing (vp8/common/postproc.c; the reference build has CONFIG_POSTPROC 1) ----
+def _planes(rng, rows, cols, border=24):
+    """a plane with a border all round; the second one is flat-ish so that the filters actually fire"""
+    h, w = rows + 2 * border, cols + 2 * border
+    noisy = rng.integers(0, 256, size=(h, w)).astype(np.uint8)
+    base = rng.integers(0, 256, size=(h // 8 + 1, w // 8 + 1)).astype(np.int32)
+    flat = np.kron(base, np.ones((8, 8), np.int32))[:h, :w]
+    flat = np.clip(flat + rng.integers(-3, 4, size=(h, w)), 0, 255).astype(np.uint8)
+    return noisy, flat, border, w
+
+
+@pytest.mark.parametrize("rows,cols", [(16, 16), (48, 80), (144, 176)])
+def test_postproc_filters(libs, rows, cols):
+    O, R = libs
+    libc = ctypes.CDLL(None)
+    rng = np.random.default_rng(8)
+    for trial in range(6):
+        for src in _planes(rng, rows, cols)[:2]:
+            _, _, b, w = _planes(rng, rows, cols)
+            off = b * w + b
+            for flimit in (-3, 0, 2, 7, 30, 300):
+                a = np.zeros_like(src)
+                o = np.zeros_like(src)
+                R.vp8_post_proc_down_and_across_c(vp(src.ctypes.data + off), vp(a.ctypes.data + off), ci(w), ci(w), ci(rows), ci(cols), ci(flimit))
+                O.vp8o_post_proc_down_and_across(vp(src.ctypes.data + off), vp(o.ctypes.data + off), ci(w), ci(w), ci(rows), ci(cols), ci(flimit))
+                assert (a[b:b + rows, b:b + cols] == o[b:b + rows, b:b + cols]).all(), ("down_and_across", flimit)
+            for flimit in (0, 50, 533, 3000, 100000):
+                a = src.copy()
+                o = np.zeros_like(src)
+                R.vp8_mbpost_proc_across_ip_c(vp(a.ctypes.data + off), ci(w), ci(rows), ci(cols), ci(flimit))
+                O.vp8o_mbpost_proc_across(vp(src.ctypes.data + off), vp(o.ctypes.data + off), ci(w), ci(rows), ci(cols), ci(flimit))
+                assert (a[b:b + rows, b:b + cols] == o[b:b + rows, b:b + cols]).all(), ("across_ip", flimit)
+                seed = int(rng.integers(1, 1 << 30))
+                libc.srand(seed)
+                rv_offset = libc.rand() & 63
+                libc.srand(seed)
+                a = src.copy()
+                R.vp8_mbpost_proc_down_c(vp(a.ctypes.data + off), ci(w), ci(rows), ci(cols), ci(flimit))
+                O.vp8o_mbpost_proc_down(vp(src.ctypes.data + off), vp(o.ctypes.data + off), ci(w), ci(rows), ci(cols), ci(flimit), ci(rv_offset))
+                assert (a[b:b + rows, b:b + cols] == o[b:b + rows, b:b + cols]).all(), ("down", flimit)
+
+
+def test_postproc_noise_and_strengths(libs):
+    O, R = libs
+    libc = ctypes.CDLL(None)
+    rng = np.random.default_rng(9)
+    for trial in range(10):
+        rows, cols, w = 40, 72, 96
+        src = rng.integers(0, 256, size=(rows, w)).astype(np.uint8)
+        if trial % 2:
+            src[:, :36] = rng.integers(0, 6, size=(rows, 36))         # near black / near white: the clamps
+            src[:, 36:] = rng.integers(250, 256, size=(rows, w - 36))
+        noise = rng.integers(-20, 21, size=3072).astype(np.int8)
+        clamp = int(-noise.min())
+        cl = np.full(16, clamp, np.int8)
+        seed = int(rng.integers(1, 1 << 30))
+        libc.srand(seed)
+        offs = np.array([libc.rand() & 0xff for _ in range(rows)], np.uint8)
+        libc.srand(seed)
+        a, o = src.copy(), src.copy()
+        R.vp8_plane_add_noise_c(vp(a.ctypes.data), vp(noise.ctypes.data), vp(cl.ctypes.data), vp(cl.ctypes.data), vp(cl.ctypes.data),
+                                ctypes.c_uint(cols), ctypes.c_uint(rows), ci(w))
+        O.vp8o_plane_add_noise(vp(o.ctypes.data), vp(noise.ctypes.data), ci(clamp), ci(cols), ci(rows), ci(w), vp(offs.ctypes.data))
+        assert (a == o).all()

@@ -228,3 +228,69 @@ def random_frame(g, seed):
     rng = np.random.default_rng(seed)
     buf = rng.integers(0, 256, size=g.frame_size).astype(np.uint8)
     return buf
+
+
+# ------------------------------------------------------------------------------------------
+# output-side post-processing: vp8_post_proc_frame (vp8/common/postproc.c:903-1000) over the oracle's filters
+# ------------------------------------------------------------------------------------------
+PP_DEBLOCK, PP_DEMACROBLOCK, PP_ADDNOISE = 1, 2, 4
+
+
+class OraclePostproc:
+    """One decoder's post-processing state.  rand() is the C library's, drawn in the reference's order: once per
+    demacroblocked frame (postproc.c:286), 3072 times per noise table (:456) and once per noisy row (:499).  Call
+    libc.srand(1) first to be in the state a fresh process (the reference's vpxdec) is in."""
+
+    def __init__(self, flags, deblocking_level, noise_level):
+        self.flags, self.level, self.noise_level = flags, deblocking_level, noise_level
+        self.last_q = self.last_noise = 0
+        self.noise = np.zeros(3072, np.int8)
+        self.clamp = 0
+        self.libc = ctypes.CDLL(None)
+
+    def frame(self, buf, g, filter_level):
+        O = oracle()
+        ci, vp = ctypes.c_int, ctypes.c_void_p
+        q, ppl, ppl_dm, mbl = (ctypes.c_int() for _ in range(4))
+        O.vp8o_pp_strengths(ci(filter_level), ci(self.level), ctypes.byref(q), ctypes.byref(ppl), ctypes.byref(ppl_dm), ctypes.byref(mbl))
+        post = buf.copy()
+        planes = ((g.y_off, g.y_stride, g.aligned_h, g.aligned_w), (g.u_off, g.uv_stride, g.aligned_h // 2, g.aligned_w // 2),
+                  (g.v_off, g.uv_stride, g.aligned_h // 2, g.aligned_w // 2))
+        if self.flags & (PP_DEBLOCK | PP_DEMACROBLOCK):
+            lim = ppl_dm.value if self.flags & PP_DEMACROBLOCK else ppl.value
+            for off, stride, rows, cols in planes:
+                O.vp8o_post_proc_down_and_across(vp(buf.ctypes.data + off), vp(post.ctypes.data + off), ci(stride), ci(stride),
+                                                 ci(rows), ci(cols), ci(lim))
+            if self.flags & PP_DEMACROBLOCK:
+                off, stride, rows, cols = planes[0]
+                tmp = post.copy()
+                O.vp8o_mbpost_proc_across(vp(post.ctypes.data + off), vp(tmp.ctypes.data + off), ci(stride), ci(rows), ci(cols), ci(mbl.value))
+                rv = self.libc.rand() & 63
+                O.vp8o_mbpost_proc_down(vp(tmp.ctypes.data + off), vp(post.ctypes.data + off), ci(stride), ci(rows), ci(cols),
+                                        ci(mbl.value), ci(rv))
+        if self.flags & PP_ADDNOISE:
+            if self.last_q != q.value or self.last_noise != self.noise_level:      # :988-993; fillrd stores ITS q = 63 - q
+                r = np.array([self.libc.rand() & 0xff for _ in range(3072)], np.uint8)
+                c = ctypes.c_int()
+                O.vp8o_pp_noise_table(ci(63 - q.value), ci(self.noise_level), vp(r.ctypes.data), vp(self.noise.ctypes.data), ctypes.byref(c))
+                self.clamp = c.value
+                self.last_q, self.last_noise = 63 - q.value, self.noise_level
+            off, stride, rows, cols = planes[0]
+            offs = np.array([self.libc.rand() & 0xff for _ in range(rows)], np.uint8)
+            O.vp8o_plane_add_noise(vp(post.ctypes.data + off), vp(self.noise.ctypes.data), ci(self.clamp), ci(cols), ci(rows), ci(stride),
+                                   vp(offs.ctypes.data))
+        return post
+
+
+def oracle_postproc_ivf(name, flags, level, noise):
+    """Feeder + oracle + oracle post-processing over a fixture: per-shown-frame MD5s of the post-processed output."""
+    P = load_package()
+    _, kept = oracle_decode_ivf(name, keep_frames=True)
+    ctypes.CDLL(None).srand(1)
+    pp = OraclePostproc(flags, level, noise)
+    out = []
+    for hdr, mbs, coef, mvs, frame in kept:
+        if hdr.show_frame:
+            g = P.geom(hdr.width, hdr.height)
+            out.append(P.frame_md5(pp.frame(frame, g, hdr.filter_level), g, hdr.width, hdr.height))
+    return out
