@@ -7,8 +7,8 @@
  * bracket as vpxdec.c:1041-1055), --limit, --skip, -t/--threads (accepted, ignored: the GPU path has
  * no CPU worker threads), --codec=vp8, -v, and the VP8 post-processing options --postproc, --deblock,
  * --demacroblock-level=<n>, --noise-level=<n>, --mfqe (vpxdec.c:111-133, 779-812, 983-1002; MFQE is accepted and has no effect).
- * WebM / raw input are not provided here (the reference's own vpxdec.c, built against this library by oracle/Makefile, reads
- * them through its nestegg).
+ * Input: IVF or WebM, probed in that order like vpxdec.c:573-587 (webm.h; the reference reads WebM through its bundled
+ * nestegg).  Headerless raw input is not provided.
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -18,6 +18,7 @@
 #include "vpx/vpx_decoder.h"
 #include "vpx/vp8dx.h"
 #include "ivf.h"
+#include "webm.h"
 #include "md5.h"
 
 static const char *exec_name;
@@ -78,6 +79,8 @@ int main(int argc, char **argv)
     vpx_codec_ctx_t decoder;
     vpx_codec_dec_cfg_t cfg = { 0, 0, 0 };
     ivf_reader in;
+    webm_reader wm;
+    int is_webm = 0;
     FILE *out = NULL;
     md5_state md5;
     const uint8_t *buf;
@@ -114,8 +117,11 @@ int main(int argc, char **argv)
     if (!fn) usage_exit();
     rc = ivf_open(&in, fn);
     if (rc == -1) { fprintf(stderr, "Failed to open file '%s'\n", fn); return EXIT_FAILURE; }
-    if (rc) { fprintf(stderr, "Unrecognized input file type.\n"); return EXIT_FAILURE; }
-    if (in.fourcc != 0x30385056) fprintf(stderr, "Notice -- IVF header indicates codec: %08x\n", in.fourcc);
+    if (rc) {
+        ivf_close(&in);
+        if (!strcmp(fn, "-") || webm_open(&wm, fn)) { fprintf(stderr, "Unrecognized input file type.\n"); return EXIT_FAILURE; }
+        is_webm = 1;
+    } else if (in.fourcc != 0x30385056) fprintf(stderr, "Notice -- IVF header indicates codec: %08x\n", in.fourcc);
     if (!noblit) {
         if (do_md5) md5_init(&md5);
         else if (outfile) {
@@ -133,8 +139,9 @@ int main(int argc, char **argv)
     }
     if (verbose) fprintf(stderr, "%s\n", decoder.name);
 
-    while (skip-- > 0 && ivf_next(&in, &buf, &buf_sz) == 1) { }
-    while (ivf_next(&in, &buf, &buf_sz) == 1) {
+#define NEXT_FRAME() (is_webm ? webm_next(&wm, &buf, &buf_sz) : ivf_next(&in, &buf, &buf_sz))
+    while (skip-- > 0 && NEXT_FRAME() == 1) { }
+    while (NEXT_FRAME() == 1) {
         vpx_codec_iter_t iter = NULL;
         vpx_image_t *img;
         unsigned long t0 = now_us();
@@ -183,5 +190,6 @@ fail:
         } else if (out && out != stdout) fclose(out);
     }
     ivf_close(&in);
+    if (is_webm) webm_close(&wm);
     return frames_corrupted ? EXIT_FAILURE : EXIT_SUCCESS;
 }

@@ -202,7 +202,26 @@ PP_CLI = (("p_arf_176x144", ["--deblock"]), ("p_arf_176x144", ["--demacroblock-l
           ("p_lowrate_640x360", ["--demacroblock-level=3"]), ("p_odd_130x98", ["--noise-level=4", "--deblock"]))
 
 
+def webm_fixture():
+    """The same encode written twice by the reference's vpxenc, as WebM (its default container, libmkv) and as IVF: the WebM
+    reader of the product's tools must hand out the IVF's frames; the digest is the reference vpxdec's over the WebM file."""
+    w, h, frames, seed = 176, 144, 12, 91
+    args = ["--i420", "-p", "1", "-t", "1", "--kf-max-dist=5", "--good", "--cpu-used=2", "--target-bitrate=300", "--lag-in-frames=0"]
+    with tempfile.TemporaryDirectory(dir="/tmp") as td:
+        yuv = os.path.join(td, "in.yuv")
+        with open(yuv, "wb") as f:
+            f.write(synth_i420(w, h, frames, seed, 5))
+        run([VPXENC, *args, "-w", str(w), "-h", str(h), "-o", os.path.join(HERE, "container_176x144.webm"), yuv])
+        run([VPXENC, *args, "--ivf", "-w", str(w), "-h", str(h), "-o", os.path.join(HERE, "container_176x144.ivf_twin"), yuv])
+    r = subprocess.run([VPXDEC, "--md5", "--i420", os.path.join(HERE, "container_176x144.webm")], capture_output=True, text=True, check=True)
+    with open(os.path.join(HERE, "container_176x144.webm.vpxdec_md5"), "w") as f:
+        f.write(r.stdout.split()[0] + "\n")
+
+
 def main():
+    if "--webm" in sys.argv:
+        webm_fixture()
+        return
     if "--postproc" in sys.argv:
         for name in PP_STREAMS:
             postproc_md5(name)

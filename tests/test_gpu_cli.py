@@ -83,3 +83,15 @@ def test_the_references_own_vpxdec_runs_on_the_product(name):
     r = subprocess.run([REF_VPXDEC_ON_HIP, "--md5", "--i420", ivf_path(name)], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     assert r.stdout.split()[0] == open(os.path.join(GOLDEN, name + ".vpxdec_md5")).read().strip()
+
+
+@pytest.mark.parametrize("exe", [os.path.join(BIN, "vpxdec"), REF_VPXDEC_ON_HIP])
+def test_webm_input(exe):
+    """WebM in, the reference vpxdec's digest out: the product's vpxdec with its own reader (webm.c), and the reference's
+    vpxdec.c (nestegg) on the product."""
+    if not os.path.exists(exe):
+        pytest.skip(f"{exe} not built")
+    webm = os.path.join(GOLDEN, "container_176x144.webm")
+    r = subprocess.run([exe, "--md5", "--i420", webm], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.split()[0] == open(webm + ".vpxdec_md5").read().strip()
