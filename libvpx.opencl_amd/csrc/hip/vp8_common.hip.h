@@ -126,6 +126,37 @@ __constant__ static const unsigned short k_ac_q[128] = {
 // Where a lane-per-row kernel's step spends its cycles: STAMP(i) adds the shader cycles since the previous stamp
 // to bucket i (wave-uniform, kept in SGPRs); the first wave of the grid adds its buckets to a device array of its
 // own that no kernel reads (MI355X guide, "In-kernel stamps").  Shares only -- the build itself runs slower.
+// ---- granule hand-over between the workgroups of a frame (vp8_recon_xcu_kernel / vp8_loopfilter_xcu_kernel) ----
+// A granule is 4 bytes of data and the tag (launch counter) of the launch that wrote it in one 8-byte word, stored and
+// loaded with one relaxed agent-scope access: the tag is the progress flag, there is no separate flag and no fence.
+// A bounded poll turns a broken hand-over into an error status instead of a hang: the first poll that runs out sets
+// *err (host-visible) and marks the launch in vp8_gran_broken; from then on every wait of that launch gives up after one
+// look, so the kernel drains in milliseconds instead of repeating the full budget per macroblock.
+typedef unsigned long long u64;
+typedef GLOBAL_AS u64 *g_u64p;
+extern __device__ unsigned int vp8_gran_broken;     // tag of the last launch in which a hand-over timed out (vp8hip.hip)
+__device__ __forceinline__ void gran_store(g_u64p p, unsigned int data, unsigned int tag)
+{
+    __hip_atomic_store(p, (u64)data | ((u64)tag << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ u64 gran_load(g_u64p p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// v: what an earlier gran_load of *p returned; polls only if that was too early
+__device__ __forceinline__ unsigned int gran_wait(g_u64p p, u64 v, unsigned int tag, int *err, int code)
+{
+    int budget = 0;
+    for (int n = 0; (unsigned int)(v >> 32) != tag; ++n) {
+        if (n == 0) budget = __hip_atomic_load(&vp8_gran_broken, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == tag ? 1 : (1 << 22);
+        if (n >= budget) {
+            *err = code;
+            __hip_atomic_store(&vp8_gran_broken, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+        }
+        __builtin_amdgcn_s_sleep(VP8_POLL_SLEEP);
+        v = gran_load(p);
+    }
+    return (unsigned int)v;
+}
+
 #ifdef VP8_STAMPS
 #define VP8_NSTAMPS 16
 extern __device__ unsigned long long vp8_stamps_recon[VP8_NSTAMPS], vp8_stamps_lf[VP8_NSTAMPS];

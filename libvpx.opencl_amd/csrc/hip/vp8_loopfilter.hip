@@ -121,23 +121,6 @@ __device__ __forceinline__ u32 pack4(const int *a) { return (u32)a[0] | ((u32)a[
 // per-row buffer in global memory (agent-scope stores and polling loads; the tag is the progress flag), and the
 // upper wave leaves the rows the lower one finishes (luma 13..15, chroma 5..7) out of its own frame writes: two CUs
 // must never write the same bytes.
-typedef unsigned long long u64;
-typedef GLOBAL_AS u64 *g_u64p;
-__device__ __forceinline__ void gran_store(g_u64p p, u32 data, u32 tag)
-{
-    __hip_atomic_store(p, (u64)data | ((u64)tag << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ u64 gran_load(g_u64p p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-// v: what an earlier gran_load of *p returned; polls only if that was too early
-__device__ __forceinline__ u32 gran_wait(g_u64p p, u64 v, u32 tag, int *err)
-{
-    for (int n = 0; (u32)(v >> 32) != tag; ++n) {
-        if (n > (1 << 22)) { *err = 2; break; }
-        __builtin_amdgcn_s_sleep(VP8_POLL_SLEEP);
-        v = gran_load(p);
-    }
-    return (u32)v;
-}
 
 template <bool XCU>
 __device__ __forceinline__ void lf_body(const DevJob *__restrict__ jobs, int njobs, DevGeom g, u64 *gran_base, u32 epoch,
@@ -258,8 +241,8 @@ __device__ __forceinline__ void lf_body(const DevJob *__restrict__ jobs, int njo
                 }
             }
             if (XCU && r > 0 && is_top) {
-                topv.x = gran_wait(gq, g0, epoch, err); topv.y = gran_wait(gq + 1, g1, epoch, err);
-                if (luma) { topv.z = gran_wait(gq + 2, g2, epoch, err); topv.w = gran_wait(gq + 3, g3, epoch, err); }
+                topv.x = gran_wait(gq, g0, epoch, err, 2); topv.y = gran_wait(gq + 1, g1, epoch, err, 2);
+                if (luma) { topv.z = gran_wait(gq + 2, g2, epoch, err, 2); topv.w = gran_wait(gq + 3, g3, epoch, err, 2); }
             }
             if (r > 0 && is_top) {
                 if (luma) *(u32x4 *)(tile + LY_AT(top_row, X)) = topv;

@@ -198,23 +198,6 @@ __device__ __forceinline__ void clamp_chroma_mv(int &row, int &col, int e_left, 
 // a per-row buffer in global memory, written and polled with agent-scope (sc1) accesses: the tag (the launch's
 // epoch) doubles as the progress flag, so there is no separate flag, no store-acknowledge wait and no fence.
 // A bounded poll turns a broken hand-over into an error status instead of a hang.
-typedef unsigned long long u64;
-typedef GLOBAL_AS u64 *g_u64p;
-__device__ __forceinline__ void gran_store(g_u64p p, u32 data, u32 tag)
-{
-    __hip_atomic_store(p, (u64)data | ((u64)tag << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ u64 gran_load(g_u64p p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-// v: what an earlier gran_load of *p returned; polls only if that was too early
-__device__ __forceinline__ u32 gran_wait(g_u64p p, u64 v, u32 tag, int *err)
-{
-    for (int n = 0; (u32)(v >> 32) != tag; ++n) {
-        if (n > (1 << 22)) { *err = 1; break; }
-        __builtin_amdgcn_s_sleep(VP8_POLL_SLEEP);
-        v = gran_load(p);
-    }
-    return (u32)v;
-}
 
 template <bool XCU>
 __device__ __forceinline__ void recon_body(const DevJob *__restrict__ jobs, int njobs, DevGeom g, u64 *gran_base,
@@ -434,7 +417,7 @@ __device__ __forceinline__ void recon_body(const DevJob *__restrict__ jobs, int 
                         // MB): polling it IS the "two MBs ahead" rule
                         const int x = (pl == 0 ? c * 16 : c * 8) - 4 + i * 4;
                         v = 0x81818181u;             // x < 0: the constant 129 left border
-                        if (x >= 0) v = gran_wait(above_gran(c), gcur, epoch, err);
+                        if (x >= 0) v = gran_wait(above_gran(c), gcur, epoch, err, 1);
                     } else {
                         const unsigned char *src = dep_line + (pl == 0 ? 0 : (pl == 1 ? lU : lV)) + LINE_PAD
                                                  + (pl == 0 ? c * 16 : c * 8) - 4 + i * 4;

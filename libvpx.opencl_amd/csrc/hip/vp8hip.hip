@@ -96,6 +96,8 @@ static void read_knobs(Knobs &k)
     k.detile_defer = env_int("VP8HIP_DETILE_DEFER", 1) != 0;
 }
 
+__device__ unsigned int vp8_gran_broken;      // see gran_wait (vp8_common.hip.h)
+
 struct vp8hip_ctx {
     int device;
     Knobs knobs;
@@ -632,6 +634,15 @@ extern "C" int vp8hip_decode(vp8hip_ctx *c, const vp8hip_job *jobs, int njobs, i
         if (!K.xcu) S = 1;
         if (K.xcu_S >= 1 && K.xcu_S <= 64) S = K.xcu_S;
         if (K.xcu_NW == 4 || K.xcu_NW == 8) XCU_NW = K.xcu_NW;
+        if (S > 1) {
+            // the workgroups of a group wait for each other: all of them have to be resident at once, on this device as it
+            // is (fewer CUs when partitioned), or the launch stays with one workgroup per pair
+            int per_cu_r = 0, per_cu_l = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_r, vp8_recon_xcu_kernel, 64 * XCU_NW, 1024 + XCU_NW * 2 * 2080) != hipSuccess
+                || hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_l, vp8_loopfilter_xcu_kernel, 64 * XCU_NW, 256 + XCU_NW * 2 * 4096) != hipSuccess
+                || 8 * S * per_xcd > c->num_cu * (per_cu_r < per_cu_l ? per_cu_r : per_cu_l))
+                S = 1;
+        }
         if (S > 1) {
             xcu_S = S; xcu_grid = 8 * S * per_xcd;
             if (!c->h_status) {
