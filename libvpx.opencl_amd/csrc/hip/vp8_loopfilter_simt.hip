@@ -304,10 +304,18 @@ __device__ __forceinline__ Lim mb_limits(int sharp, int level, int frame_type, v
 //   line 1 and the chroma line by the lane below (which filters their last three rows), or by the own lane
 //   when nobody is below (last row of the frame) or the lane below reads them back from memory (the first
 //   lane of a strand follows the last one).
-extern "C" __global__ void __launch_bounds__(64)
-vp8_loopfilter_simt_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g, int lgG, int P, int nstrands, int raster)
+//
+// PLANES selects what a wave filters: LF_BOTH (one wave does a macroblock's luma, then U, then V), or LF_LUMA / LF_CHROMA
+// for the split launch, where a luma kernel and a chroma kernel run side by side.  The two halves share nothing but the
+// macroblock descriptors -- separate lines of the tiled scratch frame, separate planes of the frame buffer -- and a luma
+// wave and a chroma wave together fit one SIMD (registers and LDS), which a pair of whole-macroblock waves does not: the
+// SIMD then has two instruction streams to issue from instead of one that stalls on every LDS and memory round trip.
+enum { LF_BOTH = 0, LF_LUMA = 1, LF_CHROMA = 2 };
+template <int PLANES>
+__device__ __forceinline__ void lf_simt_body(const DevJob *__restrict__ jobs, int njobs, DevGeom g, int lgG, int P, int nstrands, int raster)
 {
-    __shared__ u32 tile[100 * 64];              // luma: 20 rows x 5 dwords; chroma reuses it: 12 rows x 3 dwords
+    constexpr bool DO_Y = PLANES != LF_CHROMA, DO_C = PLANES != LF_LUMA;
+    __shared__ u32 tile[(DO_Y ? 100 : 36) * 64];   // luma: 20 rows x 5 dwords; chroma (reuses it): 12 rows x 3 dwords
     const int lane = threadIdx.x;
     const int G = 1 << lgG;
     const int pos = lane & (G - 1);
@@ -340,12 +348,15 @@ vp8_loopfilter_simt_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g
     // written in 32-byte pieces (two 16-byte stores back to back) instead of 16-byte ones a step apart
     u32x4 holdA[8], holdB[8];
     u32x2 holdU[8], holdV[8];
+    if constexpr (DO_Y) {
 #pragma unroll
-    for (int y = 0; y < 16; y++) { pbY[y][0] = pbY[y][1] = pbY[y][2] = sY[y] = 0; }
+        for (int y = 0; y < 16; y++) { pbY[y][0] = pbY[y][1] = pbY[y][2] = sY[y] = 0; }
 #pragma unroll
-    for (int y = 0; y < 8; y++) {
-        pbU[y] = sU[y] = pbV[y] = sV[y] = 0;
-        hY[y][0] = hY[y][1] = hY[y][2] = hY[y][3] = hU[y][0] = hU[y][1] = hV[y][0] = hV[y][1] = 0;
+        for (int y = 0; y < 8; y++) hY[y][0] = hY[y][1] = hY[y][2] = hY[y][3] = 0;
+    }
+    if constexpr (DO_C) {
+#pragma unroll
+        for (int y = 0; y < 8; y++) { pbU[y] = sU[y] = pbV[y] = sV[y] = 0; hU[y][0] = hU[y][1] = hV[y][0] = hV[y][1] = 0; }
     }
 
     int c = -2 * pos, V = pos;
@@ -358,10 +369,14 @@ vp8_loopfilter_simt_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g
         u32 tY[8][4], tU[8][2], tV[8][2];
 #pragma unroll
         for (int y = 0; y < 8; y++) {
+            if constexpr (DO_Y) {
 #pragma unroll
-            for (int i = 0; i < 4; i++) tY[y][i] = from_lane_above(hY[y][i]);
-            tU[y][0] = from_lane_above(hU[y][0]); tU[y][1] = from_lane_above(hU[y][1]);
-            tV[y][0] = from_lane_above(hV[y][0]); tV[y][1] = from_lane_above(hV[y][1]);
+                for (int i = 0; i < 4; i++) tY[y][i] = from_lane_above(hY[y][i]);
+            }
+            if constexpr (DO_C) {
+                tU[y][0] = from_lane_above(hU[y][0]); tU[y][1] = from_lane_above(hU[y][1]);
+                tV[y][0] = from_lane_above(hV[y][0]); tV[y][1] = from_lane_above(hV[y][1]);
+            }
         }
 
         // What the lane below will fetch at the start of the next step: the macroblock held from the previous
@@ -370,8 +385,8 @@ vp8_loopfilter_simt_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g
         // they are final as they stand.
 #pragma unroll
         for (int y = 0; y < 8; y++) {
-            hY[y][0] = pbY[8 + y][0]; hY[y][1] = pbY[8 + y][1]; hY[y][2] = pbY[8 + y][2]; hY[y][3] = sY[8 + y];
-            hU[y][0] = pbU[y]; hU[y][1] = sU[y]; hV[y][0] = pbV[y]; hV[y][1] = sV[y];
+            if constexpr (DO_Y) { hY[y][0] = pbY[8 + y][0]; hY[y][1] = pbY[8 + y][1]; hY[y][2] = pbY[8 + y][2]; hY[y][3] = sY[8 + y]; }
+            if constexpr (DO_C) { hU[y][0] = pbU[y]; hU[y][1] = sU[y]; hV[y][0] = pbV[y]; hV[y][1] = sV[y]; }
         }
 
         STAMP(1)
@@ -432,23 +447,32 @@ vp8_loopfilter_simt_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g
             g_u8p o_own_lo = ras ? rasY + c * 16 : tp, o_own_hi = ras_bottom ? rasY + c * 16 + 8 * g.y_stride : tp + 128;
             g_u8p o_above = ras ? rasY - 8 * g.y_stride + c * 16 : tp - rowbytes + 128;                           // MB (r-1, c) rows 8..15
             u32x4 inY[16], inU[4], inV[4];
+            if constexpr (DO_Y) {
 #pragma unroll
-            for (int y = 0; y < 16; y++) inY[y] = *(g_cu32x4p)(tp + 16 * y);
+                for (int y = 0; y < 16; y++) inY[y] = *(g_cu32x4p)(tp + 16 * y);
+            }
+            if constexpr (DO_C) {
 #pragma unroll
-            for (int y = 0; y < 4; y++) { inU[y] = *(g_cu32x4p)(tp + 256 + 16 * y); inV[y] = *(g_cu32x4p)(tp + 320 + 16 * y); }
+                for (int y = 0; y < 4; y++) { inU[y] = *(g_cu32x4p)(tp + 256 + 16 * y); inV[y] = *(g_cu32x4p)(tp + 320 + 16 * y); }
+            }
             if (readback) {
                 const unsigned char *ta = (const unsigned char *)tp - rowbytes;
 #pragma unroll
                 for (int y = 0; y < 8; y++) {
-                    const unsigned long long a = load_l2_64(ta + 128 + 16 * y), b = load_l2_64(ta + 128 + 16 * y + 8);
-                    tY[y][0] = (u32)a; tY[y][1] = (u32)(a >> 32); tY[y][2] = (u32)b; tY[y][3] = (u32)(b >> 32);
-                    const unsigned long long u = load_l2_64(ta + 256 + 8 * y), v = load_l2_64(ta + 320 + 8 * y);
-                    tU[y][0] = (u32)u; tU[y][1] = (u32)(u >> 32); tV[y][0] = (u32)v; tV[y][1] = (u32)(v >> 32);
+                    if constexpr (DO_Y) {
+                        const unsigned long long a = load_l2_64(ta + 128 + 16 * y), b = load_l2_64(ta + 128 + 16 * y + 8);
+                        tY[y][0] = (u32)a; tY[y][1] = (u32)(a >> 32); tY[y][2] = (u32)b; tY[y][3] = (u32)(b >> 32);
+                    }
+                    if constexpr (DO_C) {
+                        const unsigned long long u = load_l2_64(ta + 256 + 8 * y), v = load_l2_64(ta + 320 + 8 * y);
+                        tU[y][0] = (u32)u; tU[y][1] = (u32)(u >> 32); tV[y][0] = (u32)v; tV[y][1] = (u32)(v >> 32);
+                    }
                 }
             }
 
             STAMP(2)
             // =============================== luma ===============================
+            if constexpr (DO_Y) {
 #pragma unroll
             for (int y = 0; y < 16; y++) {
                 u32 *row = TL + (4 + y) * 5 * 64;
@@ -505,8 +529,10 @@ vp8_loopfilter_simt_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g
                 }
                 if (last_col && y >= 8 && write_bottom) *(g_u32x4p)(o_own_hi + ybY * (y - 8)) = (u32x4){ d0, d1, d2, d3 };
             }
+            }
             STAMP(5)
             // =============================== chroma ===============================
+            if constexpr (DO_C) {
 #pragma unroll
             for (int pl = 0; pl < 2; pl++) {
                 g_u8p tc = tp + (pl ? 320 : 256);
@@ -565,8 +591,25 @@ vp8_loopfilter_simt_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g
                 STAMP(8)
             }
             }
+            }
             mbp += 16;
         }
     }
     STAMP_FLUSH(vp8_stamps_lf)
+}
+
+extern "C" __global__ void __launch_bounds__(64)
+vp8_loopfilter_simt_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g, int lgG, int P, int nstrands, int raster)
+{
+    lf_simt_body<LF_BOTH>(jobs, njobs, g, lgG, P, nstrands, raster);
+}
+extern "C" __global__ void __launch_bounds__(64)
+vp8_loopfilter_simt_luma_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g, int lgG, int P, int nstrands, int raster)
+{
+    lf_simt_body<LF_LUMA>(jobs, njobs, g, lgG, P, nstrands, raster);
+}
+extern "C" __global__ void __launch_bounds__(64)
+vp8_loopfilter_simt_chroma_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g, int lgG, int P, int nstrands, int raster)
+{
+    lf_simt_body<LF_CHROMA>(jobs, njobs, g, lgG, P, nstrands, raster);
 }

@@ -21,6 +21,8 @@ extern "C" __global__ void vp8_loopfilter_xcu_kernel(const DevJob *jobs, int njo
                                                      unsigned int epoch, int S, int *err);
 extern "C" __global__ void vp8_recon_simt_kernel(const DevJob *jobs, int njobs, DevGeom g, int lgG, int P, int nstrands, uint8_t *dummy);
 extern "C" __global__ void vp8_loopfilter_simt_kernel(const DevJob *jobs, int njobs, DevGeom g, int lgG, int P, int nstrands, int raster);
+extern "C" __global__ void vp8_loopfilter_simt_luma_kernel(const DevJob *jobs, int njobs, DevGeom g, int lgG, int P, int nstrands, int raster);
+extern "C" __global__ void vp8_loopfilter_simt_chroma_kernel(const DevJob *jobs, int njobs, DevGeom g, int lgG, int P, int nstrands, int raster);
 extern "C" __global__ void vp8_loopfilter_kernel(const DevJob *jobs, int njobs, DevGeom g);
 extern "C" __global__ void vp8_extend_kernel(const DevJob *jobs, int njobs, DevGeom g);
 extern "C" __global__ void vp8_detile_kernel(const DevJob *jobs, int njobs, DevGeom g, int extend);
@@ -76,6 +78,7 @@ struct Slot {
 //   VP8HIP_DETILE_STREAM=0 / VP8HIP_DETILE_DEFER=0   run the tiled -> raster pass on the main stream / at once
 struct Knobs {
     int recon_force;       // 0 automatic, 1 lane-per-row, 2 wave-per-row
+    int lf_split;     // VP8HIP_LF_SPLIT=0: one lane-per-row loop-filter kernel for all three planes (default 1: luma and chroma kernels side by side)
     int lf_raster, lgG, simt_waves, wg_per_cu, xcu, xcu_S, xcu_NW, recon_nw, lf_nw, detile_stream, detile_defer;
 };
 static int env_int(const char *name, int dflt) { const char *e = getenv(name); return e && *e ? atoi(e) : dflt; }
@@ -89,6 +92,7 @@ static void read_knobs(Knobs &k)
     k.wg_per_cu = env_int("VP8HIP_WG_PER_CU", 1);
     k.xcu = env_int("VP8HIP_XCU", 1) != 0;
     k.xcu_S = env_int("VP8HIP_XCU_S", 0);
+    k.lf_split = env_int("VP8HIP_LF_SPLIT", 1);
     k.xcu_NW = env_int("VP8HIP_XCU_NW", 0);
     k.recon_nw = env_int("VP8HIP_RECON_NW", 0);
     k.lf_nw = env_int("VP8HIP_LF_NW", 0);
@@ -149,6 +153,7 @@ struct vp8hip_ctx {
     hipEvent_t ev_d2h_from, ev_d2h_done;
     int d2h_first, d2h_count;      // frame buffers of the copy in flight (count 0: none)
     size_t fb_stride;
+    hipStream_t stream3; hipEvent_t ev_split_from, ev_split_done;     // chroma half of the split lane-per-row loop filter
     // vp8hip_postproc: dither table (440 shorts), noise table (3072) and per-row noise phases (16384) on the device
     char *d_pp; bool pp_rv_loaded;
 };
@@ -289,6 +294,10 @@ extern "C" void vp8hip_destroy(vp8hip_ctx *c)
     if (c->ev_d2h_done) (void)hipEventDestroy(c->ev_d2h_done);
     (void)hipStreamDestroy(c->stream);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
+    if (c->stream3) {
+        (void)hipStreamSynchronize(c->stream3); (void)hipStreamDestroy(c->stream3);
+        (void)hipEventDestroy(c->ev_split_from); (void)hipEventDestroy(c->ev_split_done);
+    }
     delete c;
 }
 
@@ -722,7 +731,24 @@ extern "C" int vp8hip_decode(vp8hip_ctx *c, const vp8hip_job *jobs, int njobs, i
         if (launch_deferred(c, c->ev_recon_done)) return -1;
     }
     if ((stages & VP8HIP_STAGE_LF) && any_lf) {
-        if (tiled) {
+        if (tiled && K.lf_split) {
+            // luma and chroma as two kernels side by side: a luma wave (268 registers, 25.6 KB of LDS) and a chroma wave (187,
+            // 9.2 KB) share a SIMD, so every SIMD has two instruction streams to issue from.  The chroma kernel goes out on
+            // a stream of its own behind the recon, and the main stream takes it back in before anything reads the frames.
+            if (!c->stream3) {
+                HIPCHK(c, hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking));
+                HIPCHK(c, hipEventCreateWithFlags(&c->ev_split_from, hipEventDisableTiming));
+                HIPCHK(c, hipEventCreateWithFlags(&c->ev_split_done, hipEventDisableTiming));
+            }
+            HIPCHK(c, hipEventRecord(c->ev_split_from, c->stream));
+            HIPCHK(c, hipStreamWaitEvent(c->stream3, c->ev_split_from, 0));
+            hipLaunchKernelGGL(vp8_loopfilter_simt_luma_kernel, dim3(simt_waves), dim3(64), 0, c->stream, (const DevJob *)c->d_jobs,
+                               njobs, c->dg, lgG, simtP, simt_waves * spw, lf_raster ? 1 : 0);
+            hipLaunchKernelGGL(vp8_loopfilter_simt_chroma_kernel, dim3(simt_waves), dim3(64), 0, c->stream3, (const DevJob *)c->d_jobs,
+                               njobs, c->dg, lgG, simtP, simt_waves * spw, lf_raster ? 1 : 0);
+            HIPCHK(c, hipEventRecord(c->ev_split_done, c->stream3));
+            HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_split_done, 0));
+        } else if (tiled) {
             hipLaunchKernelGGL(vp8_loopfilter_simt_kernel, dim3(simt_waves), dim3(64), 0, c->stream, (const DevJob *)c->d_jobs,
                                njobs, c->dg, lgG, simtP, simt_waves * spw, lf_raster ? 1 : 0);
         } else {
