@@ -48,8 +48,10 @@ HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 # for 16-byte-per-lane loads, which the detile pass confirms -- it reads exactly 384 B/MB) over tools/pmc_one.py 7 1024
 # with VP8HIP_SIMT_LGG=3: profiles/r01_*_pmc_*_1024frames_G8*.csv.  The counter passes crash or hang at 8192 frames per
 # launch and under torch, so bench.py scales these per-macroblock figures instead of counting live.
-PMC_TRAFFIC_B_PER_MB = {        # the loop filter writes the raster frame buffers, then vp8_extend_kernel (default)
-    "recon": 2 * 447.7 + 384.0, "loopfilter": 2 * 242.2 + 634.4, "extend": 2 * 27.5 + 40.4}
+PMC_TRAFFIC_B_PER_MB = {        # the loop filter (luma + chroma kernels) writes the raster frame buffers, then vp8_extend_kernel (default);
+    # profiles/r02_a_pmc_{FETCH,WRITE}_SIZE_1024frames_G8.csv.  The loop filter's 1014 B/MB of writes against 384 B/MB of pixels are
+    # the 32-byte (luma) and 16-byte (chroma) pieces of frame rows a lane has to give at a time
+    "recon": 2 * 529.5 + 385.7, "loopfilter": 2 * (168.1 + 104.1) + 535.6 + 478.8, "extend": 2 * 27.5 + 40.4}
 PMC_TRAFFIC_B_PER_MB_DETILE = { # tiled -> raster pass (vp8_detile_kernel) after the loop filter
     "recon": 2 * 448.68 + 385.22, "loopfilter": 2 * 239.63 + 414.12, "extend": 2 * 192.08 + 466.87}
 
@@ -387,7 +389,12 @@ def main():
         detile = bool(st.detile_pass)         # ... finished by the tiled -> raster pass instead of the loop filter's own raster output
         bytes_per_launch = {"recon": B_RECON * nmb * F, "loopfilter": B_LF * nmb * F,
                             "extend": (B_DETILE if detile else B_EXTEND) * nmb * F}
-        names = ({"recon": "vp8_recon_simt_kernel", "loopfilter": "vp8_loopfilter_simt_kernel",
+        # (the lane-per-row loop filter is two kernels side by side on two streams, luma and chroma; "loopfilter" is the interval
+        #  both take together, which is the duration of the luma kernel -- the chroma kernel ends inside it)
+        split = os.environ.get("VP8HIP_LF_SPLIT", "1") != "0"
+        names = ({"recon": "vp8_recon_simt_kernel",
+                  "loopfilter": "vp8_loopfilter_simt_luma_kernel (with vp8_loopfilter_simt_chroma_kernel beside it)" if split
+                                else "vp8_loopfilter_simt_kernel",
                   "extend": "vp8_detile_kernel (tiled -> raster + border extension)" if detile else "vp8_extend_kernel"} if lane else
                  {"recon": "vp8_recon_kernel", "loopfilter": "vp8_loopfilter_kernel", "extend": "vp8_extend_kernel"})
         dom = max(ms, key=lambda k: ms[k])
