@@ -180,6 +180,7 @@ static vpx_codec_err_t vp8_decode(vpx_codec_alg_priv_t *p, const uint8_t *data, 
         vpx_rtcd();
         p->parser = vp8_parser_create();
         if (!p->parser) return VPX_CODEC_MEM_ERROR;
+        vp8_parser_set_threads(p->parser, (int)p->cfg.threads);   /* oxcf.max_threads = ctx->cfg.threads, vp8_dx_iface.c:413 */
         vp8_refs_init(&p->refs);
         p->decoder_init = 1;
         if (vp8hip_create(device, &p->hip)) {

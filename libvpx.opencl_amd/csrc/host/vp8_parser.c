@@ -6,6 +6,8 @@
  */
 #include "vp8_parser.h"
 
+#include <pthread.h>
+#include <sched.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -69,6 +71,8 @@ struct vp8_parser {
     mbinfo *mi_alloc, *mi;       /* mi points at MB (0,0); stride mb_cols + 1 */
     int mi_stride;
     entropy_ctx *above;
+    int threads;                 /* vp8_parser_set_threads */
+    int *progress;               /* per macroblock row, threaded token decode */
     char err[96];
 };
 
@@ -96,6 +100,7 @@ const char *vp8_parser_error(const vp8_parser *p) { return p->err; }
 vp8_parser *vp8_parser_create(void)
 {
     vp8_parser *p = (vp8_parser *)calloc(1, sizeof *p);
+    if (p) p->threads = 1;
     return p;
 }
 
@@ -104,6 +109,7 @@ void vp8_parser_destroy(vp8_parser *p)
     if (!p) return;
     free(p->mi_alloc);
     free(p->above);
+    free(p->progress);
     free(p);
 }
 
@@ -839,13 +845,142 @@ int vp8_parser_decode_mbs_sparse(vp8_parser *p, vp8ir_mb *mbs, int16_t *blocks, 
     return decode_mbs(p, mbs, NULL, blocks, cap_blocks, nblocks, dcs, ndcs, mvs, corrupt);
 }
 
+/* ---- token partitions -----------------------------------------------------------------------
+ * Macroblock row r is coded in partition r mod N (decodframe.c:1116-1129), and the partitions are independent bool-coder
+ * streams (setup_token_decoder, decodframe.c:501-592): the only thing row r needs from row r-1 is the "block had
+ * coefficients" context of the macroblock straight above.  With vp8_parser_set_threads(T > 1) the rows of a frame with
+ * several partitions are decoded by up to min(T, N) threads, each owning the partitions t, t+T, ..., rows in order;
+ * a row runs at most as far as the row above has got (per-row progress counters, release / acquire), which is how the
+ * reference's own multi-threaded decoder synchronises (vp8/decoder/threading.c, sync_range).  The output is the serial
+ * decoder's byte for byte: sparse streams are written per thread into disjoint regions of the caller's arrays and
+ * closed up afterwards. */
+#define PROGRESS_STRIDE 16       /* ints: a cache line per row counter */
+typedef struct tok_stream {      /* where a thread's sparse output goes */
+    int16_t *blocks, *dcs;
+    size_t first_block, first_dc;    /* region start inside the caller's arrays (entries) */
+    size_t cap_blocks;               /* entries this region may take */
+    size_t nb, nd;
+} tok_stream;
+
+typedef struct tok_job {
+    vp8_parser *p;
+    vp8ir_mb *mbs;
+    int16_t *coef;
+    vp8ir_mv *mvs;
+    int nthreads;
+    volatile int *progress;          /* per row: macroblocks finished */
+    volatile int overflow;
+} tok_job;
+
+typedef struct tok_worker { tok_job *job; int id; tok_stream out; int bad; pthread_t thread; } tok_worker;
+
+/* one macroblock row; returns nonzero when the thread's sparse region is full */
+static int decode_row(tok_job *j, tok_stream *out, int r, vp8_boolreader *br)
+{
+    vp8_parser *p = j->p;
+    int16_t *coef = j->coef;
+    vp8ir_mv *mvs = j->mvs;
+    entropy_ctx left;
+    mbinfo *m = p->mi + r * p->mi_stride;
+    int c, i;
+    memset(&left, 0, sizeof left);
+    for (c = 0; c < p->mb_cols; c++, m++) {
+        size_t n = (size_t)r * p->mb_cols + c;
+        vp8ir_mb *o = &j->mbs[n];
+        entropy_ctx *A = &p->above[c];
+        int has_y2 = m->y_mode != VP8IR_B_PRED && m->y_mode != VP8IR_SPLITMV;
+        if (j->progress && r > 0 && (c & 3) == 0) {   /* the four macroblocks above have left their context in p->above[] */
+            const int need = c + 4 < p->mb_cols ? c + 4 : p->mb_cols;
+            int spins = 0;
+            while (__atomic_load_n(&j->progress[(r - 1) * PROGRESS_STRIDE], __ATOMIC_ACQUIRE) < need) {
+                if (j->overflow) return 1;
+                if (++spins < 2000) __builtin_ia32_pause(); else sched_yield();
+            }
+        }
+        memset(o, 0, sizeof *o);
+        if (m->skip) {                       /* vp8_reset_mb_tokens_context, detokenize.c:70-85 */
+            uint8_t ay2 = A->y2, ly2 = left.y2;
+            memset(A, 0, sizeof *A);
+            memset(&left, 0, sizeof left);
+            if (!has_y2) { A->y2 = ay2; left.y2 = ly2; }
+        } else {
+            int16_t local[VP8IR_COEF_PER_MB];
+            int16_t *q = coef ? coef + n * VP8IR_COEF_PER_MB : local;
+            memset(q, 0, VP8IR_COEF_PER_MB * sizeof(int16_t));
+            if (read_mb_tokens(p, br, m, A, &left, q, o->eobs) == 0) {
+                m->skip = 1;                 /* decodframe.c:129: eobtotal==0 forces skip */
+                memset(o->eobs, 0, 25);
+            } else if (!coef) {              /* sparse streams: full blocks and lone DCs, in block order (vp8_ir.h) */
+                int k;
+                o->sparse_first = (uint32_t)(out->first_block + out->nb);
+                o->dc_first = (uint32_t)(out->first_dc + out->nd);
+                for (k = 0; k < 25; k++) {
+                    if (k == 24 && !has_y2) break;
+                    if (o->eobs[k] > 1) {
+                        if (out->nb >= out->cap_blocks) { j->overflow = 1; return 1; }
+                        memcpy(out->blocks + (out->first_block + out->nb) * 16, q + k * 16, 32);
+                        out->nb++;
+                    } else if (o->eobs[k] == 1 && !(has_y2 && k < 16))
+                        out->dcs[out->first_dc + out->nd++] = q[k * 16];   /* (at most 25 per macroblock: the caller's array is that large) */
+                }
+            }
+        }
+        if (j->progress && ((c & 3) == 3 || c == p->mb_cols - 1)) __atomic_store_n(&j->progress[r * PROGRESS_STRIDE], c + 1, __ATOMIC_RELEASE);
+        o->y_mode = m->y_mode;
+        o->uv_mode = m->uv_mode;
+        o->ref_frame = m->ref_frame;
+        o->flags = (uint8_t)((m->skip ? VP8IR_MB_SKIP : 0) | (m->need_clamp ? VP8IR_MB_CLAMP : 0));
+        if (!coef && m->skip) { o->sparse_first = (uint32_t)(out->first_block + out->nb); o->dc_first = (uint32_t)(out->first_dc + out->nd); }
+        o->segment_id = m->segment_id;
+        o->partitioning = m->y_mode == VP8IR_SPLITMV ? m->partitioning : 0;
+        if (m->y_mode == VP8IR_B_PRED)
+            for (i = 0; i < 16; i++) o->b_modes[i] = m->b[i].mode;
+        if (mvs) {
+            vp8ir_mv *mv = mvs + n * 16;
+            for (i = 0; i < 16; i++) {
+                int32_t x = m->ref_frame == VP8IR_INTRA_FRAME ? 0
+                          : (m->y_mode == VP8IR_SPLITMV ? m->b[i].mv : m->mv);
+                mv16 v = mv_unpack(x);
+                mv[i].row = v.row;
+                mv[i].col = v.col;
+            }
+        }
+    }
+    return 0;
+}
+
+/* which thread decodes row r: the owner of its partition */
+static inline int row_owner(const vp8_parser *p, int r, int nthreads) { return (r & (p->num_tok - 1)) % nthreads; }
+
+static void *tok_worker_main(void *arg)
+{
+    tok_worker *w = (tok_worker *)arg;
+    tok_job *j = w->job;
+    vp8_parser *p = j->p;
+    int r;
+    for (r = 0; r < p->mb_rows; r++) {
+        vp8_boolreader *br = &p->tok[r & (p->num_tok - 1)];
+        if (row_owner(p, r, j->nthreads) != w->id) continue;
+        if (decode_row(j, &w->out, r, br)) break;
+        w->bad |= vp8br_overrun(br);
+    }
+    return NULL;
+}
+
+void vp8_parser_set_threads(vp8_parser *p, int threads)
+{
+    if (p) p->threads = threads < 1 ? 1 : (threads > 8 ? 8 : threads);
+}
+
 /* coef != NULL: dense output; else the sparse stream (vp8_ir.h) */
 static int decode_mbs(vp8_parser *p, vp8ir_mb *mbs, int16_t *coef, int16_t *blocks, size_t cap_blocks, size_t *nblocks,
                       int16_t *dcs, size_t *ndcs, vp8ir_mv *mvs, int *corrupt)
 {
-    int r, c, i, bad = 0;
+    int r, t, bad = 0, nthreads;
     int is_key;
     size_t nb = 0, nd = 0;
+    tok_job job;
+    tok_worker w[8];
     if (!p->frame_open)
         return fail(p, VP8P_ERROR, "decode_mbs without begin_frame");
     is_key = p->hdr.frame_type == 0;
@@ -856,65 +991,71 @@ static int decode_mbs(vp8_parser *p, vp8ir_mb *mbs, int16_t *coef, int16_t *bloc
     bad |= vp8br_overrun(&p->first);
 
     memset(p->above, 0, (size_t)p->mb_cols * sizeof(entropy_ctx));
-    for (r = 0; r < p->mb_rows; r++) {
-        vp8_boolreader *br = &p->tok[r & (p->num_tok - 1)];   /* round-robin, decodframe.c:1116-1129 */
-        entropy_ctx left;
-        mbinfo *m = p->mi + r * p->mi_stride;
-        memset(&left, 0, sizeof left);
-        for (c = 0; c < p->mb_cols; c++, m++) {
-            size_t n = (size_t)r * p->mb_cols + c;
-            vp8ir_mb *o = &mbs[n];
-            entropy_ctx *A = &p->above[c];
-            int has_y2 = m->y_mode != VP8IR_B_PRED && m->y_mode != VP8IR_SPLITMV;
-            memset(o, 0, sizeof *o);
-            if (m->skip) {                       /* vp8_reset_mb_tokens_context, detokenize.c:70-85 */
-                uint8_t ay2 = A->y2, ly2 = left.y2;
-                memset(A, 0, sizeof *A);
-                memset(&left, 0, sizeof left);
-                if (!has_y2) { A->y2 = ay2; left.y2 = ly2; }
-            } else {
-                int16_t local[VP8IR_COEF_PER_MB];
-                int16_t *q = coef ? coef + n * VP8IR_COEF_PER_MB : local;
-                memset(q, 0, VP8IR_COEF_PER_MB * sizeof(int16_t));
-                if (read_mb_tokens(p, br, m, A, &left, q, o->eobs) == 0) {
-                    m->skip = 1;                 /* decodframe.c:129: eobtotal==0 forces skip */
-                    memset(o->eobs, 0, 25);
-                } else if (!coef) {              /* sparse streams: full blocks and lone DCs, in block order (vp8_ir.h) */
-                    int k;
-                    o->sparse_first = (uint32_t)nb;
-                    o->dc_first = (uint32_t)nd;
-                    for (k = 0; k < 25; k++) {
-                        if (k == 24 && !has_y2) break;
-                        if (o->eobs[k] > 1) {
-                            if (nb >= cap_blocks) return fail(p, VP8P_MEM_ERROR, "sparse coefficient stream overflow");
-                            memcpy(blocks + nb * 16, q + k * 16, 32);
-                            nb++;
-                        } else if (o->eobs[k] == 1 && !(has_y2 && k < 16))
-                            dcs[nd++] = q[k * 16];       /* (at most 25 per macroblock: the caller's array is that large) */
-                    }
-                }
-            }
-            o->y_mode = m->y_mode;
-            o->uv_mode = m->uv_mode;
-            o->ref_frame = m->ref_frame;
-            o->flags = (uint8_t)((m->skip ? VP8IR_MB_SKIP : 0) | (m->need_clamp ? VP8IR_MB_CLAMP : 0));
-            if (!coef && m->skip) { o->sparse_first = (uint32_t)nb; o->dc_first = (uint32_t)nd; }
-            o->segment_id = m->segment_id;
-            o->partitioning = m->y_mode == VP8IR_SPLITMV ? m->partitioning : 0;
-            if (m->y_mode == VP8IR_B_PRED)
-                for (i = 0; i < 16; i++) o->b_modes[i] = m->b[i].mode;
-            if (mvs) {
-                vp8ir_mv *mv = mvs + n * 16;
-                for (i = 0; i < 16; i++) {
-                    int32_t x = m->ref_frame == VP8IR_INTRA_FRAME ? 0
-                              : (m->y_mode == VP8IR_SPLITMV ? m->b[i].mv : m->mv);
-                    mv16 v = mv_unpack(x);
-                    mv[i].row = v.row;
-                    mv[i].col = v.col;
-                }
+    memset(&job, 0, sizeof job);
+    memset(w, 0, sizeof w);
+    job.p = p; job.mbs = mbs; job.coef = coef; job.mvs = mvs;
+    nthreads = p->threads < p->num_tok ? p->threads : p->num_tok;
+    if (nthreads > p->mb_rows) nthreads = p->mb_rows;
+    /* a thread's sparse region has to hold the worst case of its rows; with a smaller array the frame is decoded serially */
+    if (nthreads > 1 && !coef && cap_blocks < (size_t)p->mb_rows * p->mb_cols * 25) nthreads = 1;
+    if (nthreads > 1) {
+        int *pr = (int *)realloc(p->progress, (size_t)p->mb_rows * PROGRESS_STRIDE * sizeof(int));
+        if (pr) p->progress = pr; else nthreads = 1;
+    }
+    if (nthreads <= 1) {
+        w[0].out.blocks = blocks; w[0].out.dcs = dcs; w[0].out.cap_blocks = cap_blocks;
+        for (r = 0; r < p->mb_rows; r++) {
+            vp8_boolreader *br = &p->tok[r & (p->num_tok - 1)];   /* round-robin, decodframe.c:1116-1129 */
+            if (decode_row(&job, &w[0].out, r, br)) return fail(p, VP8P_MEM_ERROR, "sparse coefficient stream overflow");
+            bad |= vp8br_overrun(br);
+        }
+        nb = w[0].out.nb; nd = w[0].out.nd;
+    } else {
+        size_t at = 0;
+        int started = 0;
+        memset(p->progress, 0, (size_t)p->mb_rows * PROGRESS_STRIDE * sizeof(int));
+        job.progress = p->progress;
+        job.nthreads = nthreads;
+        for (t = 0; t < nthreads; t++) {
+            size_t rows_t = 0;
+            for (r = 0; r < p->mb_rows; r++) rows_t += row_owner(p, r, nthreads) == t;
+            w[t].job = &job; w[t].id = t;
+            w[t].out.blocks = blocks; w[t].out.dcs = dcs;
+            w[t].out.first_block = w[t].out.first_dc = at;         /* the same offsets serve both arrays: 25 entries per macroblock */
+            w[t].out.cap_blocks = rows_t * p->mb_cols * 25;
+            at += w[t].out.cap_blocks;
+        }
+        for (t = 1; t < nthreads; t++) {
+            if (pthread_create(&w[t].thread, NULL, tok_worker_main, &w[t])) break;
+            started = t;
+        }
+        if (started != nthreads - 1) {                    /* could not start them all: nobody may wait for a missing row */
+            job.overflow = 1;
+            for (t = 1; t <= started; t++) pthread_join(w[t].thread, NULL);
+            return fail(p, VP8P_MEM_ERROR, "cannot start the token partition threads");
+        }
+        tok_worker_main(&w[0]);
+        for (t = 1; t < nthreads; t++) pthread_join(w[t].thread, NULL);
+        if (job.overflow) return fail(p, VP8P_MEM_ERROR, "sparse coefficient stream overflow");
+        for (t = 0; t < nthreads; t++) bad |= w[t].bad;
+        if (!coef) {
+            /* close the gaps: thread t's entries follow thread t-1's, and its macroblocks' indices move with them.
+               (Macroblock order inside the streams is by thread, then by row: the streams are addressed through
+               sparse_first / dc_first only.) */
+            for (t = 0; t < nthreads; t++) {
+                const size_t db = w[t].out.first_block - nb, dd = w[t].out.first_dc - nd;
+                if (db) memmove(blocks + nb * 16, blocks + w[t].out.first_block * 16, w[t].out.nb * 32);
+                if (dd) memmove(dcs + nd, dcs + w[t].out.first_dc, w[t].out.nd * sizeof(int16_t));
+                if (db || dd)
+                    for (r = 0; r < p->mb_rows; r++)
+                        if (row_owner(p, r, nthreads) == t) {
+                            vp8ir_mb *o = mbs + (size_t)r * p->mb_cols;
+                            int c;
+                            for (c = 0; c < p->mb_cols; c++) { o[c].sparse_first -= (uint32_t)db; o[c].dc_first -= (uint32_t)dd; }
+                        }
+                nb += w[t].out.nb; nd += w[t].out.nd;
             }
         }
-        bad |= vp8br_overrun(br);
     }
 
     if (is_key && !bad) p->have_key_frame = 1;

@@ -31,6 +31,10 @@ enum {
 typedef struct vp8_parser vp8_parser;
 
 vp8_parser *vp8_parser_create(void);
+/* Token partitions of a frame are decoded by up to `threads` threads (1..8; default 1).  Only frames coded with several
+ * partitions gain (decodframe.c:501-592); the output is the serial decoder's byte for byte.  This is what
+ * vpx_codec_dec_cfg_t::threads asks for (vpx/vpx_decoder.h:101-106; the reference's vp8/decoder/threading.c). */
+void vp8_parser_set_threads(vp8_parser *p, int threads);
 void vp8_parser_destroy(vp8_parser *p);
 
 /* vp8_peek_si (vp8/vp8_dx_iface.c:245-285): key-frame start code + 14-bit dimensions. */

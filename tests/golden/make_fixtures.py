@@ -125,6 +125,10 @@ FIXTURES = {
     # sharpness != 0 (loop-filter limit tables), error-resilient stream
     "p_sharp_320x240": (320, 240, 8, 61, 10, INTER + ["--good", "--cpu-used=1", "--sharpness=5",
                                                        "--error-resilient=1", "--target-bitrate=500"]),
+    # 1080p key frames coded with 8 token partitions (the reference encoder's --token-parts=3): what the threaded token
+    # decode of the feeder is for
+    "kf_8part_1920x1080": (1920, 1080, 3, 81, 6, ALLKEY + ["--good", "--cpu-used=5", "--end-usage=cq", "--cq-level=20",
+                                                             "--target-bitrate=20000", "--token-parts=3"]),
     # low bitrate: high filter levels, many skipped MBs (mb_skip_coeff / skip_lf paths)
     "p_lowrate_640x360": (640, 360, 10, 71, 4, INTER + ["--good", "--cpu-used=3", "--target-bitrate=150"]),
 }
