@@ -180,6 +180,194 @@ __device__ __forceinline__ void clamp_chroma_mv(int &row, int &col, int e_left, 
     if (2 * row > e_bottom + (18 << 3)) row = (e_bottom + (16 << 3)) >> 1;
 }
 
+// Roles of the 32 lanes that work on one macroblock: luma segments (block hl>>2 and the one eight further, row hl&3 of it),
+// one chroma segment (plane cpl, row cy, first column cx0), `col` = the block column a lane transforms.
+struct MbLanes { int hl, ly0, lx0, cpl, cy, cx0, col; };
+__device__ __forceinline__ MbLanes mb_lanes(int hl)
+{
+    MbLanes m;
+    m.hl = hl;
+    m.ly0 = ((hl >> 4) << 2) + (hl & 3); m.lx0 = ((hl >> 2) & 3) << 2;
+    m.cpl = hl >> 4; m.cy = (((hl >> 2) & 3) >> 1) * 4 + (hl & 3); m.cx0 = ((hl >> 2) & 1) << 2;
+    m.col = hl & 3;
+    return m;
+}
+struct Coefs { coef4 y0, y1, c, y2; };     // luma blocks 0..7, 8..15, chroma, Y2 (hl < 4)
+struct Mv2 { u32 a, b; };                  // the MVs of a lane's two luma segments
+
+// The residual of a macroblock (dequantisation, Y2 WHT, inverse DCT: decodframe.c:239-296, idctllm.c), by the 32 lanes
+// of its half wave.  rY0/rY1: the 4 residuals of luma segment (block hl>>2 [+8], row hl&3); rC: chroma likewise.
+__device__ __forceinline__ void mb_residual(WaveLds *wl, const Coefs &q, bool skip, bool has_y2, int seg, const MbLanes &R, int lane,
+                                            int rY0[4], int rY1[4], int rC[4])
+{
+    const int hl = R.hl, col = R.col;
+    // ---- residual (independent of every neighbour: done BEFORE waiting on the row above).
+    // rY0/rY1: the 4 residuals of luma segment (block hl>>2 [+8], row hl&3); rC: chroma likewise.
+    #pragma unroll
+    for (int i = 0; i < 4; i++) rY0[i] = rY1[i] = rC[i] = 0;
+    if (!skip) {
+        const short *dq = wl->dq[seg];
+        const int dq_y1dc = dq[0], dq_y1ac = dq[1], dq_y2dc = dq[2], dq_y2ac = dq[3], dq_uvdc = dq[4], dq_uvac = dq[5];
+        {   // Y2: vp8_dequantize_b + vp8_short_inv_walsh4x4_c (idctllm.c:140-192); lanes hl < 4
+            int t[4];
+            const int f0 = col == 0 ? dq_y2dc : dq_y2ac;
+            const int i0 = (short)(c4x(q.y2) * f0), i1 = (short)(c4y(q.y2) * dq_y2ac);
+            const int i2 = (short)(c4z(q.y2) * dq_y2ac), i3 = (short)(c4w(q.y2) * dq_y2ac);
+            const int a1 = i0 + i3, b1 = i1 + i2, c1 = i1 - i2, d1 = i0 - i3;
+            quad_transpose16(a1 + b1, c1 + d1, a1 - b1, d1 - c1, lane, t);
+            if (has_y2 && hl < 4) {
+                const int a2 = t[0] + t[3], b2 = t[1] + t[2], c2 = t[1] - t[2], d2 = t[0] - t[3];
+                short *w = wl->wht_dc + hl * 4;
+                w[0] = (short)((a2 + b2 + 3) >> 3);
+                w[1] = (short)((c2 + d2 + 3) >> 3);
+                w[2] = (short)((a2 - b2 + 3) >> 3);
+                w[3] = (short)((d2 - c2 + 3) >> 3);
+            }
+        }
+        wave_lds_sync();
+        // chroma, luma blocks 0..7 and luma blocks 8..15: three independent transforms, written pass by pass so
+        // that their dependent instruction chains interleave (one wave alone pays every instruction's latency)
+        int oC[4], o0[4], o1[4], tC[4], t0[4], t1[4];
+        int iA, iB;
+        if (col == 0) {
+            iA = has_y2 ? (int)wl->wht_dc[hl >> 2] : (int)(short)(c4x(q.y0) * dq_y1dc);
+            iB = has_y2 ? (int)wl->wht_dc[8 + (hl >> 2)] : (int)(short)(c4x(q.y1) * dq_y1dc);
+        } else {
+            iA = (short)(c4x(q.y0) * dq_y1ac);
+            iB = (short)(c4x(q.y1) * dq_y1ac);
+        }
+        idct_col((short)(c4x(q.c) * (col == 0 ? dq_uvdc : dq_uvac)), (short)(c4y(q.c) * dq_uvac), (short)(c4z(q.c) * dq_uvac),
+                 (short)(c4w(q.c) * dq_uvac), oC);
+        idct_col(iA, (short)(c4y(q.y0) * dq_y1ac), (short)(c4z(q.y0) * dq_y1ac), (short)(c4w(q.y0) * dq_y1ac), o0);
+        idct_col(iB, (short)(c4y(q.y1) * dq_y1ac), (short)(c4z(q.y1) * dq_y1ac), (short)(c4w(q.y1) * dq_y1ac), o1);
+        quad_transpose16(oC[0], oC[1], oC[2], oC[3], lane, tC);
+        quad_transpose16(o0[0], o0[1], o0[2], o0[3], lane, t0);
+        quad_transpose16(o1[0], o1[1], o1[2], o1[3], lane, t1);
+        idct_row(tC, rC);
+        idct_row(t0, rY0);
+        idct_row(t1, rY1);
+    }
+}
+
+// The prediction of an inter macroblock plus its residual (vp8_build_inter_predictors_mb, reconinter.c:560-606), by the 32
+// lanes of its half wave: mv = the macroblock's 16 MVs, mv2 = those of this lane's segments, rf = the reference frame
+// buffer.  Uses wl->res as scratch (the first six-tap pass of a macroblock with one MV is shared through it).
+__device__ __forceinline__ void mb_inter(const DevGeom &g, WaveLds *wl, g_cu8p rf, g_cmvp mv, const Mv2 &mv2, u32 flags, int y_mode,
+                                         int r, int c, bool bilinear, bool fullpix, const MbLanes &R,
+                                         const int rY0[4], const int rY1[4], const int rC[4], u32 &outY0, u32 &outY1, u32 &outC)
+{
+    const int hl = R.hl, ly0 = R.ly0, lx0 = R.lx0, cpl = R.cpl, cy = R.cy, cx0 = R.cx0;
+    const int cols = g.mb_cols, rows = g.mb_rows;
+    // ---- inter MB (vp8_build_inter_predictors_mb, reconinter.c:560-606)
+        const bool clampmv = flags & VP8IR_MB_CLAMP;
+    const int e_left = -((c * 16) << 3), e_right = ((cols - 1 - c) * 16) << 3;
+    const int e_top = -((r * 16) << 3), e_bottom = ((rows - 1 - r) * 16) << 3;
+    if (y_mode != VP8IR_SPLITMV && !bilinear) {
+        // One MV for the whole macroblock (vp8_build_inter16x16_predictors_mb, reconinter.c:384-441):
+        // the first six-tap pass is shared through LDS -- 21 source rows x 4 segments for luma, 13 x 2
+        // for each chroma plane, 136 row segments for 32 lanes instead of nine per lane.
+        u32 *hb = (u32 *)wl->res;                 // B_PRED's residual buffer is idle in an inter MB
+        int mrow = sext16(mv2.a), mcol = hi16(mv2.a);
+        if (clampmv) clamp_luma_mv(mrow, mcol, e_left, e_right, e_top, e_bottom);
+        // chroma MV from the CLAMPED luma MV (reconinter.c:419-424); version 0: no full-pixel mask
+        int crow = (short)(mrow + (1 | (mrow >> 31))), ccol = (short)(mcol + (1 | (mcol >> 31)));
+        crow /= 2; ccol /= 2;
+        const bool fracY = ((mrow | mcol) & 7) != 0, fracC = ((crow | ccol) & 7) != 0;
+        // memory safety only, as in inter_row4: every tap stays inside the plane and its border
+        const int sx = max(-32 + 2, min(c * 16 + (mcol >> 3), g.aligned_w + 32 - 22));
+        const int sy = max(-32 + 2, min(r * 16 + (mrow >> 3), g.aligned_h + 32 - 19));
+        const int sxc = max(-16 + 2, min(c * 8 + (ccol >> 3), g.aligned_w / 2 + 16 - 14));
+        const int syc = max(-16 + 2, min(r * 8 + (crow >> 3), g.aligned_h / 2 + 16 - 11));
+        if (fracY) {
+            const SixTaps tx = sixtap_taps(mcol & 7);
+            g_cu8p base = rf + g.y_off + (long)(sy - 2) * g.y_stride + (sx - 2);
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+                const int t = hl + 32 * i;            // source row t>>2 (0 = two above), segment t&3
+                if (t < 84) hb[t] = sixtap_hrow(base + (long)(t >> 2) * g.y_stride + (t & 3) * 4, tx);
+            }
+        }
+        if (fracC) {
+            const SixTaps tx = sixtap_taps(ccol & 7);
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+                const int t = hl + 32 * i, pl = t >= 26, rem = t - 26 * pl;
+                if (t < 52) {
+                    g_cu8p base = rf + (pl ? g.v_off : g.u_off) + (long)(syc - 2 + (rem >> 1)) * g.uv_stride + (sxc - 2);
+                    hb[84 + t] = sixtap_hrow(base + (rem & 1) * 4, tx);
+                }
+            }
+        }
+        wave_lds_sync();
+        u32 ppY0, ppY1, ppC;
+        if (fracY) {
+            const SixTaps ty = sixtap_taps(mrow & 7);
+            u32 H[6];
+#pragma unroll
+            for (int k = 0; k < 6; k++) H[k] = hb[(ly0 + k) * 4 + (lx0 >> 2)];
+            ppY0 = sixtap_vcol(H, ty);
+#pragma unroll
+            for (int k = 0; k < 6; k++) H[k] = hb[(ly0 + 8 + k) * 4 + (lx0 >> 2)];
+            ppY1 = sixtap_vcol(H, ty);
+        } else {                                      // vp8_copy_mem16x16 (reconinter.c:22-63)
+            g_cu8p s0 = rf + g.y_off + (long)(sy + ly0) * g.y_stride + sx + lx0;
+            g_cu8p s1 = s0 + 8 * (long)g.y_stride;
+            ppY0 = (u32)s0[0] | ((u32)s0[1] << 8) | ((u32)s0[2] << 16) | ((u32)s0[3] << 24);
+            ppY1 = (u32)s1[0] | ((u32)s1[1] << 8) | ((u32)s1[2] << 16) | ((u32)s1[3] << 24);
+        }
+        if (fracC) {
+            const SixTaps ty = sixtap_taps(crow & 7);
+            u32 H[6];
+#pragma unroll
+            for (int k = 0; k < 6; k++) H[k] = hb[84 + cpl * 26 + (cy + k) * 2 + (cx0 >> 2)];
+            ppC = sixtap_vcol(H, ty);
+        } else {
+            g_cu8p s0 = rf + (cpl ? g.v_off : g.u_off) + (long)(syc + cy) * g.uv_stride + sxc + cx0;
+            ppC = (u32)s0[0] | ((u32)s0[1] << 8) | ((u32)s0[2] << 16) | ((u32)s0[3] << 24);
+        }
+        outY0 = add_clamp_pack(ppY0, rY0);
+        outY1 = add_clamp_pack(ppY1, rY1);
+        outC = add_clamp_pack(ppC, rC);
+    } else {
+#pragma unroll
+    for (int p = 0; p < 2; p++) {   // luma: segment of block p*8 + hl>>2, row hl&3
+        const int y = ly0 + 8 * p;
+        const u32 mvw = p ? mv2.b : mv2.a;
+        int mrow = sext16(mvw), mcol = hi16(mvw);
+        if (clampmv) clamp_luma_mv(mrow, mcol, e_left, e_right, e_top, e_bottom);
+        const u32 pp = inter_row4(rf + g.y_off, g.y_stride, c * 16 + lx0, r * 16 + y, mrow, mcol, bilinear,
+                                  g.aligned_w, g.aligned_h, 32, hl & 3);
+        if (p) outY1 = add_clamp_pack(pp, rY1); else outY0 = add_clamp_pack(pp, rY0);
+    }
+    {   // chroma
+        const int blk = (hl >> 2) & 3;
+        int mrow, mcol;
+        if (y_mode != VP8IR_SPLITMV) {   // reconinter.c:419-424: from the CLAMPED luma MV
+            const u32 mvw = mv2.a;
+            mrow = sext16(mvw); mcol = hi16(mvw);
+            if (clampmv) clamp_luma_mv(mrow, mcol, e_left, e_right, e_top, e_bottom);
+            mrow = (short)(mrow + (1 | (mrow >> 31)));
+            mcol = (short)(mcol + (1 | (mcol >> 31)));
+            mrow /= 2; mcol /= 2;
+            if (fullpix) { mrow &= ~7; mcol &= ~7; }
+        } else {                          // build_4x4uvmvs (reconinter.c:520-558): UNclamped MVs
+            const int kq = (blk >> 1) * 8 + (blk & 1) * 2;
+            const u32 m0 = mv[kq], m1 = mv[kq + 1], m4 = mv[kq + 4], m5 = mv[kq + 5];
+            mrow = sext16(m0) + sext16(m1) + sext16(m4) + sext16(m5);
+            mcol = hi16(m0) + hi16(m1) + hi16(m4) + hi16(m5);
+            mrow += 4 + ((mrow >> 31) << 3);
+            mcol += 4 + ((mcol >> 31) << 3);
+            mrow /= 8; mcol /= 8;
+            if (fullpix) { mrow &= ~7; mcol &= ~7; }
+            if (clampmv) clamp_chroma_mv(mrow, mcol, e_left, e_right, e_top, e_bottom);
+        }
+        const u32 pp = inter_row4(rf + (cpl ? g.v_off : g.u_off), g.uv_stride, c * 8 + cx0, r * 8 + cy, mrow,
+                                  mcol, bilinear, g.aligned_w / 2, g.aligned_h / 2, 16, hl & 3);
+        outC = add_clamp_pack(pp, rC);
+    }
+    }
+}
+
 // Two frames per wave: lanes 0..31 reconstruct frame A, lanes 32..63 frame B of a job pair, at the
 // same MB position.  The kernel is bound by VALU issue (one wave instruction costs 4 SIMD cycles
 // whatever the number of active lanes) and the B_PRED chain keeps only 16 lanes busy per frame, so
@@ -199,9 +387,14 @@ __device__ __forceinline__ void clamp_chroma_mv(int &row, int &col, int e_left, 
 // epoch) doubles as the progress flag, so there is no separate flag, no store-acknowledge wait and no fence.
 // A bounded poll turns a broken hand-over into an error status instead of a hang.
 
-template <bool XCU>
+//
+// INTER_DONE = true: the inter macroblocks of the launch have been reconstructed already by vp8_inter_mb_kernel (they need
+// nothing from their neighbours); this pass does the intra macroblocks, in dependency order as ever, and for an inter
+// macroblock only reads back the pixels it would have produced, to keep the line below it and the column right of it
+// supplied.  Frames without a single intra macroblock (intra_flags[job] == 0) are skipped altogether.
+template <bool XCU, bool INTER_DONE>
 __device__ __forceinline__ void recon_body(const DevJob *__restrict__ jobs, int njobs, DevGeom g, u64 *gran_base,
-                                           u32 epoch, int S, int *err)
+                                           u32 epoch, int S, int *err, const unsigned int *__restrict__ intra_flags)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
@@ -261,6 +454,7 @@ __device__ __forceinline__ void recon_body(const DevJob *__restrict__ jobs, int 
     const int ly0 = ((hl >> 4) << 2) + (hl & 3), lx0 = ((hl >> 2) & 3) << 2;
     const int cpl = hl >> 4, cy = (((hl >> 2) & 3) >> 1) * 4 + (hl & 3), cx0 = ((hl >> 2) & 1) << 2;
     const int col = hl & 3;
+    const MbLanes ML = mb_lanes(hl);
 
     const int npairs = (njobs + 1) >> 1;
     // XCU: one pair per group and launch (the per-row granule buffers are not reused inside a launch)
@@ -272,6 +466,11 @@ __device__ __forceinline__ void recon_body(const DevJob *__restrict__ jobs, int 
         const int jj = R / rows, r = R - jj * rows;
         const int pair = XCU ? group : (int)blockIdx.x + jj * (int)gridDim.x;
         const bool haveB = 2 * pair + 1 < njobs;
+        if (INTER_DONE && !intra_flags[2 * pair] && !(haveB && intra_flags[2 * pair + 1])) {
+            // nothing to do for this pair of frames; the row still counts in the hand-over protocol of the workgroup
+            if (!XCU) wg_publish_lds(&prog[wave], (k + 1) << 16, lane);
+            continue;
+        }
         const DevJob &jobA = jobs[2 * pair];
         const DevJob &jobB = jobs[haveB ? 2 * pair + 1 : 2 * pair];
         const bool valid = half == 0 || haveB;       // an odd job count leaves the last B half idle
@@ -307,7 +506,6 @@ __device__ __forceinline__ void recon_body(const DevJob *__restrict__ jobs, int 
         g_u8p dU = (g_u8p)(dst + g.u_off + (long)r * 8 * g.uv_stride);
         g_u8p dV = (g_u8p)(dst + g.v_off + (long)r * 8 * g.uv_stride);
 
-        struct Coefs { coef4 y0, y1, c, y2; };     // luma blocks 0..7, 8..15, chroma, Y2 (hl < 4)
         auto load_coefs = [&](int c, bool skipped) __attribute__((always_inline)) -> Coefs {
             g_cs16p q = coefrow + (long)c * VP8IR_COEF_PER_MB;
             Coefs v;
@@ -325,10 +523,9 @@ __device__ __forceinline__ void recon_body(const DevJob *__restrict__ jobs, int 
         // the reference fetch does not wait for them (inter frames only; a non-split MB has its MV in all 16 entries)
         g_cu32p mvrow = (g_cu32p)(mvs + (long)r * cols * 16);
         const bool inter_frame = (half ? hB.frame_type : hA.frame_type) != 0;
-        struct Mv2 { u32 a, b; };
         auto load_mv = [&](int c) -> Mv2 {
             Mv2 m = { 0u, 0u };
-            if (inter_frame) { m.a = mvrow[c * 16 + (hl >> 2)]; m.b = mvrow[c * 16 + 8 + (hl >> 2)]; }
+            if (inter_frame && !INTER_DONE) { m.a = mvrow[c * 16 + (hl >> 2)]; m.b = mvrow[c * 16 + 8 + (hl >> 2)]; }
             return m;
         };
         auto half_sel = [&](u32 d, int idx) -> u32 {     // dword `idx` of this half's MB descriptor
@@ -358,51 +555,10 @@ __device__ __forceinline__ void recon_body(const DevJob *__restrict__ jobs, int 
             const bool has_y2 = y_mode != VP8IR_B_PRED && y_mode != VP8IR_SPLITMV;
             const int seg = w1 & 3;
 
-            // ---- residual (independent of every neighbour: done BEFORE waiting on the row above).
-            // rY0/rY1: the 4 residuals of luma segment (block hl>>2 [+8], row hl&3); rC: chroma likewise.
-            int rY0[4] = { 0, 0, 0, 0 }, rY1[4] = { 0, 0, 0, 0 }, rC[4] = { 0, 0, 0, 0 };
-            if (!skip) {
-                const short *dq = wl->dq[seg];
-                const int dq_y1dc = dq[0], dq_y1ac = dq[1], dq_y2dc = dq[2], dq_y2ac = dq[3], dq_uvdc = dq[4], dq_uvac = dq[5];
-                {   // Y2: vp8_dequantize_b + vp8_short_inv_walsh4x4_c (idctllm.c:140-192); lanes hl < 4
-                    int t[4];
-                    const int f0 = col == 0 ? dq_y2dc : dq_y2ac;
-                    const int i0 = (short)(c4x(q.y2) * f0), i1 = (short)(c4y(q.y2) * dq_y2ac);
-                    const int i2 = (short)(c4z(q.y2) * dq_y2ac), i3 = (short)(c4w(q.y2) * dq_y2ac);
-                    const int a1 = i0 + i3, b1 = i1 + i2, c1 = i1 - i2, d1 = i0 - i3;
-                    quad_transpose16(a1 + b1, c1 + d1, a1 - b1, d1 - c1, lane, t);
-                    if (has_y2 && hl < 4) {
-                        const int a2 = t[0] + t[3], b2 = t[1] + t[2], c2 = t[1] - t[2], d2 = t[0] - t[3];
-                        short *w = wl->wht_dc + hl * 4;
-                        w[0] = (short)((a2 + b2 + 3) >> 3);
-                        w[1] = (short)((c2 + d2 + 3) >> 3);
-                        w[2] = (short)((a2 - b2 + 3) >> 3);
-                        w[3] = (short)((d2 - c2 + 3) >> 3);
-                    }
-                }
-                wave_lds_sync();
-                // chroma, luma blocks 0..7 and luma blocks 8..15: three independent transforms, written pass by pass so
-                // that their dependent instruction chains interleave (one wave alone pays every instruction's latency)
-                int oC[4], o0[4], o1[4], tC[4], t0[4], t1[4];
-                int iA, iB;
-                if (col == 0) {
-                    iA = has_y2 ? (int)wl->wht_dc[hl >> 2] : (int)(short)(c4x(q.y0) * dq_y1dc);
-                    iB = has_y2 ? (int)wl->wht_dc[8 + (hl >> 2)] : (int)(short)(c4x(q.y1) * dq_y1dc);
-                } else {
-                    iA = (short)(c4x(q.y0) * dq_y1ac);
-                    iB = (short)(c4x(q.y1) * dq_y1ac);
-                }
-                idct_col((short)(c4x(q.c) * (col == 0 ? dq_uvdc : dq_uvac)), (short)(c4y(q.c) * dq_uvac), (short)(c4z(q.c) * dq_uvac),
-                         (short)(c4w(q.c) * dq_uvac), oC);
-                idct_col(iA, (short)(c4y(q.y0) * dq_y1ac), (short)(c4z(q.y0) * dq_y1ac), (short)(c4w(q.y0) * dq_y1ac), o0);
-                idct_col(iB, (short)(c4y(q.y1) * dq_y1ac), (short)(c4z(q.y1) * dq_y1ac), (short)(c4w(q.y1) * dq_y1ac), o1);
-                quad_transpose16(oC[0], oC[1], oC[2], oC[3], lane, tC);
-                quad_transpose16(o0[0], o0[1], o0[2], o0[3], lane, t0);
-                quad_transpose16(o1[0], o1[1], o1[2], o1[3], lane, t1);
-                idct_row(tC, rC);
-                idct_row(t0, rY0);
-                idct_row(t1, rY1);
-            }
+            // ---- residual (independent of every neighbour: done BEFORE waiting on the row above)
+            int rY0[4], rY1[4], rC[4];
+            const bool elsewhere = INTER_DONE && ref_frame != VP8IR_INTRA_FRAME;
+            mb_residual(wl, q, skip || elsewhere, has_y2, seg, ML, lane, rY0, rY1, rC);
 
             // ---- wait for the row above to be two MBs ahead (or finished)
             if (!XCU && r > 0) wg_wait_ge(&prog[dep_wave], (dep_seq << 16) + min(c + 2, cols));
@@ -528,121 +684,20 @@ __device__ __forceinline__ void recon_body(const DevJob *__restrict__ jobs, int 
                     outY0 = *(const u32 *)(tY + TY_AT(ly0, lx0));
                     outY1 = *(const u32 *)(tY + TY_AT(ly0 + 8, lx0));
                 }
+            } else if (INTER_DONE) {
+                // ---- inter MB, finished by vp8_inter_mb_kernel: what this lane would have stored
+                outY0 = *(g_cu32p)(dY + (long)ly0 * g.y_stride + c * 16 + lx0);
+                outY1 = *(g_cu32p)(dY + (long)(ly0 + 8) * g.y_stride + c * 16 + lx0);
+                outC = *(g_cu32p)((cpl ? dV : dU) + (long)cy * g.uv_stride + c * 8 + cx0);
             } else {
-                // ---- inter MB (vp8_build_inter_predictors_mb, reconinter.c:560-606)
-                g_cmvp mv = (g_cmvp)(mvs + ((long)r * cols + c) * 16);
-                g_cu8p rf = (g_cu8p)(half ? jobB.ref[ref_frame & 3] : jobA.ref[ref_frame & 3]);
-                const bool clampmv = flags & VP8IR_MB_CLAMP;
-                const int e_left = -((c * 16) << 3), e_right = ((cols - 1 - c) * 16) << 3;
-                const int e_top = -((r * 16) << 3), e_bottom = ((rows - 1 - r) * 16) << 3;
-                if (y_mode != VP8IR_SPLITMV && !bilinear) {
-                    // One MV for the whole macroblock (vp8_build_inter16x16_predictors_mb, reconinter.c:384-441):
-                    // the first six-tap pass is shared through LDS -- 21 source rows x 4 segments for luma, 13 x 2
-                    // for each chroma plane, 136 row segments for 32 lanes instead of nine per lane.
-                    u32 *hb = (u32 *)wl->res;                 // B_PRED's residual buffer is idle in an inter MB
-                    int mrow = sext16(mv2.a), mcol = hi16(mv2.a);
-                    if (clampmv) clamp_luma_mv(mrow, mcol, e_left, e_right, e_top, e_bottom);
-                    // chroma MV from the CLAMPED luma MV (reconinter.c:419-424); version 0: no full-pixel mask
-                    int crow = (short)(mrow + (1 | (mrow >> 31))), ccol = (short)(mcol + (1 | (mcol >> 31)));
-                    crow /= 2; ccol /= 2;
-                    const bool fracY = ((mrow | mcol) & 7) != 0, fracC = ((crow | ccol) & 7) != 0;
-                    // memory safety only, as in inter_row4: every tap stays inside the plane and its border
-                    const int sx = max(-32 + 2, min(c * 16 + (mcol >> 3), g.aligned_w + 32 - 22));
-                    const int sy = max(-32 + 2, min(r * 16 + (mrow >> 3), g.aligned_h + 32 - 19));
-                    const int sxc = max(-16 + 2, min(c * 8 + (ccol >> 3), g.aligned_w / 2 + 16 - 14));
-                    const int syc = max(-16 + 2, min(r * 8 + (crow >> 3), g.aligned_h / 2 + 16 - 11));
-                    if (fracY) {
-                        const SixTaps tx = sixtap_taps(mcol & 7);
-                        g_cu8p base = rf + g.y_off + (long)(sy - 2) * g.y_stride + (sx - 2);
-#pragma unroll
-                        for (int i = 0; i < 3; i++) {
-                            const int t = hl + 32 * i;            // source row t>>2 (0 = two above), segment t&3
-                            if (t < 84) hb[t] = sixtap_hrow(base + (long)(t >> 2) * g.y_stride + (t & 3) * 4, tx);
-                        }
-                    }
-                    if (fracC) {
-                        const SixTaps tx = sixtap_taps(ccol & 7);
-#pragma unroll
-                        for (int i = 0; i < 2; i++) {
-                            const int t = hl + 32 * i, pl = t >= 26, rem = t - 26 * pl;
-                            if (t < 52) {
-                                g_cu8p base = rf + (pl ? g.v_off : g.u_off) + (long)(syc - 2 + (rem >> 1)) * g.uv_stride + (sxc - 2);
-                                hb[84 + t] = sixtap_hrow(base + (rem & 1) * 4, tx);
-                            }
-                        }
-                    }
-                    wave_lds_sync();
-                    u32 ppY0, ppY1, ppC;
-                    if (fracY) {
-                        const SixTaps ty = sixtap_taps(mrow & 7);
-                        u32 H[6];
-#pragma unroll
-                        for (int k = 0; k < 6; k++) H[k] = hb[(ly0 + k) * 4 + (lx0 >> 2)];
-                        ppY0 = sixtap_vcol(H, ty);
-#pragma unroll
-                        for (int k = 0; k < 6; k++) H[k] = hb[(ly0 + 8 + k) * 4 + (lx0 >> 2)];
-                        ppY1 = sixtap_vcol(H, ty);
-                    } else {                                      // vp8_copy_mem16x16 (reconinter.c:22-63)
-                        g_cu8p s0 = rf + g.y_off + (long)(sy + ly0) * g.y_stride + sx + lx0;
-                        g_cu8p s1 = s0 + 8 * (long)g.y_stride;
-                        ppY0 = (u32)s0[0] | ((u32)s0[1] << 8) | ((u32)s0[2] << 16) | ((u32)s0[3] << 24);
-                        ppY1 = (u32)s1[0] | ((u32)s1[1] << 8) | ((u32)s1[2] << 16) | ((u32)s1[3] << 24);
-                    }
-                    if (fracC) {
-                        const SixTaps ty = sixtap_taps(crow & 7);
-                        u32 H[6];
-#pragma unroll
-                        for (int k = 0; k < 6; k++) H[k] = hb[84 + cpl * 26 + (cy + k) * 2 + (cx0 >> 2)];
-                        ppC = sixtap_vcol(H, ty);
-                    } else {
-                        g_cu8p s0 = rf + (cpl ? g.v_off : g.u_off) + (long)(syc + cy) * g.uv_stride + sxc + cx0;
-                        ppC = (u32)s0[0] | ((u32)s0[1] << 8) | ((u32)s0[2] << 16) | ((u32)s0[3] << 24);
-                    }
-                    outY0 = add_clamp_pack(ppY0, rY0);
-                    outY1 = add_clamp_pack(ppY1, rY1);
-                    outC = add_clamp_pack(ppC, rC);
-                } else {
-#pragma unroll
-                for (int p = 0; p < 2; p++) {   // luma: segment of block p*8 + hl>>2, row hl&3
-                    const int y = ly0 + 8 * p;
-                    const u32 mvw = p ? mv2.b : mv2.a;
-                    int mrow = sext16(mvw), mcol = hi16(mvw);
-                    if (clampmv) clamp_luma_mv(mrow, mcol, e_left, e_right, e_top, e_bottom);
-                    const u32 pp = inter_row4(rf + g.y_off, g.y_stride, c * 16 + lx0, r * 16 + y, mrow, mcol, bilinear,
-                                              g.aligned_w, g.aligned_h, 32, hl & 3);
-                    if (p) outY1 = add_clamp_pack(pp, rY1); else outY0 = add_clamp_pack(pp, rY0);
-                }
-                {   // chroma
-                    const int blk = (hl >> 2) & 3;
-                    int mrow, mcol;
-                    if (y_mode != VP8IR_SPLITMV) {   // reconinter.c:419-424: from the CLAMPED luma MV
-                        const u32 mvw = mv2.a;
-                        mrow = sext16(mvw); mcol = hi16(mvw);
-                        if (clampmv) clamp_luma_mv(mrow, mcol, e_left, e_right, e_top, e_bottom);
-                        mrow = (short)(mrow + (1 | (mrow >> 31)));
-                        mcol = (short)(mcol + (1 | (mcol >> 31)));
-                        mrow /= 2; mcol /= 2;
-                        if (fullpix) { mrow &= ~7; mcol &= ~7; }
-                    } else {                          // build_4x4uvmvs (reconinter.c:520-558): UNclamped MVs
-                        const int kq = (blk >> 1) * 8 + (blk & 1) * 2;
-                        const u32 m0 = mv[kq], m1 = mv[kq + 1], m4 = mv[kq + 4], m5 = mv[kq + 5];
-                        mrow = sext16(m0) + sext16(m1) + sext16(m4) + sext16(m5);
-                        mcol = hi16(m0) + hi16(m1) + hi16(m4) + hi16(m5);
-                        mrow += 4 + ((mrow >> 31) << 3);
-                        mcol += 4 + ((mcol >> 31) << 3);
-                        mrow /= 8; mcol /= 8;
-                        if (fullpix) { mrow &= ~7; mcol &= ~7; }
-                        if (clampmv) clamp_chroma_mv(mrow, mcol, e_left, e_right, e_top, e_bottom);
-                    }
-                    const u32 pp = inter_row4(rf + (cpl ? g.v_off : g.u_off), g.uv_stride, c * 8 + cx0, r * 8 + cy, mrow,
-                                              mcol, bilinear, g.aligned_w / 2, g.aligned_h / 2, 16, hl & 3);
-                    outC = add_clamp_pack(pp, rC);
-                }
-                }
+                // ---- inter MB
+                mb_inter(g, wl, (g_cu8p)(half ? jobB.ref[ref_frame & 3] : jobA.ref[ref_frame & 3]),
+                         (g_cmvp)(mvs + ((long)r * cols + c) * 16), mv2, flags, y_mode, r, c, bilinear, fullpix, ML, rY0, rY1, rC,
+                         outY0, outY1, outC);
             }
 
             // ---- finished MB: frame (HBM, once), my line buffer (bottom rows), left column for MB c+1
-            if (valid) {
+            if (valid && !elsewhere) {
                 *(g_u32p)(dY + (long)ly0 * g.y_stride + c * 16 + lx0) = outY0;
                 *(g_u32p)(dY + (long)(ly0 + 8) * g.y_stride + c * 16 + lx0) = outY1;
                 *(g_u32p)((cpl ? dV : dU) + (long)cy * g.uv_stride + c * 8 + cx0) = outC;
@@ -671,7 +726,10 @@ __device__ __forceinline__ void recon_body(const DevJob *__restrict__ jobs, int 
 
         // ---- software pipeline, unrolled by two: MB descriptors two ahead (issued before the current MB is worked
         // on), coefficients and MVs one ahead -- by then the descriptor says whether the MB has coefficients at all
-        auto skipped = [&](u32 d) -> bool { return (half_sel(d, 0) >> 24) & VP8IR_MB_SKIP; };
+        auto skipped = [&](u32 d) -> bool {          // ... or is none of this pass's business
+            const u32 w0 = half_sel(d, 0);
+            return ((w0 >> 24) & VP8IR_MB_SKIP) || (INTER_DONE && ((w0 >> 16) & 0xff) != VP8IR_INTRA_FRAME);
+        };
         u32 dA = load_desc(0), dB = cols > 1 ? load_desc(1) : 0u;
         Coefs qA = load_coefs(0, skipped(dA)), qB = qA;
         Mv2 mA = load_mv(0), mB = mA;
@@ -697,7 +755,12 @@ __device__ __forceinline__ void recon_body(const DevJob *__restrict__ jobs, int 
 extern "C" __global__ void __launch_bounds__(768)
 vp8_recon_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g)
 {
-    recon_body<false>(jobs, njobs, g, nullptr, 0u, 1, nullptr);
+    recon_body<false, false>(jobs, njobs, g, nullptr, 0u, 1, nullptr, nullptr);
+}
+extern "C" __global__ void __launch_bounds__(768)
+vp8_recon_intra_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g, const unsigned int *intra_flags)
+{
+    recon_body<false, true>(jobs, njobs, g, nullptr, 0u, 1, nullptr, intra_flags);
 }
 
 // grid = 8 * S * ceil(npairs / 8) workgroups of four or eight waves; gran: npairs * 2 * rows * (cols * 8 + 2) granules
@@ -705,5 +768,90 @@ extern "C" __global__ void __launch_bounds__(512)
 vp8_recon_xcu_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g, unsigned long long *gran, unsigned int epoch,
                      int S, int *err)
 {
-    recon_body<true>(jobs, njobs, g, gran, epoch, S, err);
+    recon_body<true, false>(jobs, njobs, g, gran, epoch, S, err, nullptr);
+}
+extern "C" __global__ void __launch_bounds__(512)
+vp8_recon_intra_xcu_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g, unsigned long long *gran, unsigned int epoch,
+                           int S, int *err, const unsigned int *intra_flags)
+{
+    recon_body<true, true>(jobs, njobs, g, gran, epoch, S, err, intra_flags);
+}
+
+// ---- inter macroblocks, every one on its own -------------------------------------------------------------------
+// An inter macroblock is a function of the reference frames, its motion vectors and its coefficients only
+// (vp8_build_inter_predictors_mb + the residual, decodframe.c:112-296): nothing of the frame being decoded goes in.
+// So they are not walked row by row behind their neighbours: a half wave (32 lanes, the roles of MbLanes) takes any
+// macroblock, two macroblocks per wave, workgroups stride over the (job, macroblock pair) space; with a few KB of LDS and
+// no ordering there are eight waves per SIMD to hide the reference fetches behind.  Intra macroblocks of the same frames
+// are left to vp8_recon_intra_kernel, which finds out from intra_flags whether a frame has any.
+extern "C" __global__ void __launch_bounds__(256)
+vp8_inter_mb_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g, unsigned int *__restrict__ intra_flags)
+{
+    __shared__ WaveLds s_wl[8];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int half = lane >> 5, hl = lane & 31;
+    const MbLanes ML = mb_lanes(hl);
+    WaveLds *wl = &s_wl[wave * 2 + half];
+    const int cols = g.mb_cols, nmb = cols * g.mb_rows, upj = (nmb + 1) >> 1;
+    const long total = (long)njobs * upj;
+    int cur_job = -1;
+    for (long U = (long)blockIdx.x * 4 + wave; U < total; U += (long)gridDim.x * 4) {
+        const int j = (int)(U / upj), u = (int)(U - (long)j * upj);
+        const DevJob &job = jobs[j];
+        const vp8ir_frame_hdr &h = job.hdr;
+        if (h.frame_type == 0) {                 // a key frame in the launch: all of it is the other kernel's
+            if (u == 0 && lane == 0) atomicOr(&intra_flags[j], 1u);
+            continue;
+        }
+        if (j != cur_job) {
+            wave_lds_sync();
+            build_dequant(h, wl->dq, hl);
+            cur_job = j;
+            wave_lds_sync();
+        }
+        const int n = 2 * u + half;
+        const bool valid = n < nmb;
+        const int nn = valid ? n : nmb - 1;
+        const int r = nn / cols, c = nn - r * cols;
+        const u32 d = hl < 16 ? ((g_cu32p)(job.mbs + nn))[hl] : 0u;
+        auto half_sel = [&](int idx) -> u32 {
+            const u32 a = (u32)__builtin_amdgcn_readlane((int)d, idx), b = (u32)__builtin_amdgcn_readlane((int)d, 32 + idx);
+            return half ? b : a;
+        };
+        const u32 w0 = half_sel(0), w1 = half_sel(1);
+        const int y_mode = w0 & 0xff, ref_frame = (w0 >> 16) & 0xff;
+        const u32 flags = w0 >> 24;
+        const bool skip = flags & VP8IR_MB_SKIP;
+        const bool has_y2 = y_mode != VP8IR_B_PRED && y_mode != VP8IR_SPLITMV;
+        const bool inter = valid && ref_frame != VP8IR_INTRA_FRAME;
+        if (valid && !inter && hl == 0) atomicOr(&intra_flags[j], 1u);
+        Coefs q;
+        q.y0 = q.y1 = q.c = q.y2 = (coef4){ 0, 0 };
+        Mv2 mv2 = { 0u, 0u };
+        g_cmvp mv = (g_cmvp)(job.mvs + (long)nn * 16);
+        if (inter) {
+            mv2.a = mv[hl >> 2]; mv2.b = mv[8 + (hl >> 2)];
+            if (!skip) {
+                g_cs16p cq = (g_cs16p)(job.coef + (long)nn * VP8IR_COEF_PER_MB);
+                q.y0 = *(g_cs4p)(cq + hl * 4);
+                q.y1 = *(g_cs4p)(cq + 128 + hl * 4);
+                q.c = *(g_cs4p)(cq + 256 + hl * 4);
+                if (hl < 4) q.y2 = *(g_cs4p)(cq + 384 + hl * 4);
+            }
+        }
+        int rY0[4], rY1[4], rC[4];
+        mb_residual(wl, q, skip || !inter, has_y2, w1 & 3, ML, lane, rY0, rY1, rC);
+        if (inter) {
+            u32 outY0, outY1, outC;
+            mb_inter(g, wl, (g_cu8p)job.ref[ref_frame & 3], mv, mv2, flags, y_mode, r, c, h.version != 0, h.version == 3, ML,
+                     rY0, rY1, rC, outY0, outY1, outC);
+            g_u8p dY = (g_u8p)(job.dst + g.y_off + (long)r * 16 * g.y_stride);
+            g_u8p dC = (g_u8p)(job.dst + (ML.cpl ? g.v_off : g.u_off) + (long)r * 8 * g.uv_stride);
+            *(g_u32p)(dY + (long)ML.ly0 * g.y_stride + c * 16 + ML.lx0) = outY0;
+            *(g_u32p)(dY + (long)(ML.ly0 + 8) * g.y_stride + c * 16 + ML.lx0) = outY1;
+            *(g_u32p)(dC + (long)ML.cy * g.uv_stride + c * 8 + ML.cx0) = outC;
+        }
+        wave_lds_sync();                         // wl->res / wl->wht_dc are reused by the next macroblock
+    }
 }
