@@ -188,6 +188,7 @@ class Parser:
         hdr = FrameHdr()
         if self.L.vp8_refs_get_free(ctypes.byref(self.refs)) < 0:
             raise RuntimeError("no free frame buffer")
+        self._frame_data = data          # the parser borrows the compressed frame until decode_mbs has run (vp8_parser.h)
         rc = self.L.vp8_parser_begin_frame(self.p, data, len(data), ctypes.byref(hdr))
         if rc:
             self.L.vp8_refs_release_new(ctypes.byref(self.refs))
