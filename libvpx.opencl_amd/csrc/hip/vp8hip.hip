@@ -83,8 +83,9 @@ struct Slot {
 struct Knobs {
     int recon_force;       // 0 automatic, 1 lane-per-row, 2 wave-per-row
     int inter_split;  // VP8HIP_INTER_SPLIT=N: launches of up to N frames with inter frames among them run vp8_inter_mb_kernel first
-                      // (default 16; 0: never).  It shortens a frame's critical path (one 1080p P frame: recon 0.98 -> 0.64 ms) and
-                      // costs throughput (1024 frames: 7.2 -> 8.2 ms), so it is for the small launches of single-stream decoding
+                      // (default 384; 0: never).  It shortens a frame's critical path (1080p P frames, 1..16 per launch: recon 0.91 ->
+                      // 0.46-0.56 ms; 128: 1.56 -> 1.45) and costs throughput in launches that fill the chip anyway (512 frames:
+                      // 3.82 -> 4.03 ms, 1024: 7.2 -> 8.2)
     int lf_split;     // VP8HIP_LF_SPLIT=0: one lane-per-row loop-filter kernel for all three planes (default 1: luma and chroma kernels side by side)
     int lf_raster, lgG, simt_waves, wg_per_cu, xcu, xcu_S, xcu_NW, recon_nw, lf_nw, detile_stream, detile_defer;
 };
@@ -100,7 +101,7 @@ static void read_knobs(Knobs &k)
     k.xcu = env_int("VP8HIP_XCU", 1) != 0;
     k.xcu_S = env_int("VP8HIP_XCU_S", 0);
     k.lf_split = env_int("VP8HIP_LF_SPLIT", 1);
-    k.inter_split = env_int("VP8HIP_INTER_SPLIT", 16);
+    k.inter_split = env_int("VP8HIP_INTER_SPLIT", 384);
     k.xcu_NW = env_int("VP8HIP_XCU_NW", 0);
     k.recon_nw = env_int("VP8HIP_RECON_NW", 0);
     k.lf_nw = env_int("VP8HIP_LF_NW", 0);

@@ -28,7 +28,7 @@ def kernel_family(request, monkeypatch):
     macroblock-tiled scratch frames (large launches; the loop filter writes the raster frame buffers when every frame of
     the launch is filtered, else a detile pass does), "lane_detile" = the same with the detile pass always.  "..._split":
     launches with inter frames always run vp8_inter_mb_kernel (every inter macroblock on its own) before the row-ordered kernel
-    does the intra macroblocks -- by default only launches of up to 16 frames do; "wave1cu" never does.  VP8HIP_RECON /
+    does the intra macroblocks -- by default only launches of up to 384 frames do; "wave1cu" never does.  VP8HIP_RECON /
     VP8HIP_XCU / VP8HIP_INTER_SPLIT are the library's tuning knobs that override the automatic choice
     (libvpx.opencl_amd/csrc/hip/vp8hip.hip)."""
     monkeypatch.setenv("VP8HIP_RECON", "simt" if request.param.startswith("lane") else "wave")
