@@ -111,7 +111,7 @@ def cpu_baseline(fixture, budget_s=12.0):
 
 
 
-def inter_frame_probe(P, device, n=1024, name="p_dense_1920x1080", k=2):
+def inter_frame_probe(P, device, n=4096, name="p_dense_1920x1080", k=2):
     """BASELINE configs[2] beside the headline: six-tap motion compensation + IDCT + loop filter on REAL inter frames.
     The stream is decoded the normal way up to frame k-1; then n jobs decode frame k, every one from its OWN copy of the
     IR (vp8hip_ir_copy) and its OWN copies of the three reference buffers (vp8hip_frame_copy) into its own frame buffer
@@ -161,7 +161,8 @@ def inter_frame_probe(P, device, n=1024, name="p_dense_1920x1080", k=2):
             "md5_ok": bool(ok),
             "Mpix_s": round(n * w * h / dt / 1e6, 1), "ms_per_launch": round(dt * 1e3, 3),
             "kernel_ms": {"recon": round(st.recon_ms, 3), "loopfilter": round(st.lf_ms, 3), "extend": round(st.extend_ms, 3)},
-            "kernel_family": "one wave per macroblock row",
+            "kernel_family": ("wave-per-row recon into the tiled scratch frames, lane-per-row loop filter (luma + chroma kernels)"
+                              if st.lf_waves == 1 else "one wave per macroblock row"),
             "roofline": {"bound": "hbm", "achieved": round(gbps, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(gbps / HBM_PEAK_GBPS, 5),
                          "note": "SURVEY 8(d) full inter path 2407 B/MB x macroblocks per launch / wall time per launch"}}

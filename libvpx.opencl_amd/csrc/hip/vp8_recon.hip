@@ -500,6 +500,7 @@ __device__ __forceinline__ void recon_body(const DevJob *__restrict__ jobs, int 
         const int16_t *coefs = half ? jobB.coef : jobA.coef;
         const vp8ir_mv *mvs = half ? jobB.mvs : jobA.mvs;
         uint8_t *dst = half ? jobB.dst : jobA.dst;
+        g_u8p tile_out = INTER_DONE ? (g_u8p) nullptr : (g_u8p)(half ? jobB.tile : jobA.tile);
         g_cu32p mbrow = (g_cu32p)(mbs + (long)r * cols);          // 16 dwords per MB
         g_cs16p coefrow = (g_cs16p)(coefs + (long)r * cols * VP8IR_COEF_PER_MB);
         g_u8p dY = (g_u8p)(dst + g.y_off + (long)r * 16 * g.y_stride);
@@ -698,9 +699,18 @@ __device__ __forceinline__ void recon_body(const DevJob *__restrict__ jobs, int 
 
             // ---- finished MB: frame (HBM, once), my line buffer (bottom rows), left column for MB c+1
             if (valid && !elsewhere) {
+                if (tile_out) {
+                    // large launches with inter frames: into the job's macroblock-tiled scratch frame (three 128-byte lines per
+                    // macroblock, VP8_TILE_BYTES), which the lane-per-row loop filter takes from there
+                    g_u8p t = tile_out + ((long)r * cols + c) * VP8_TILE_BYTES;
+                    *(g_u32p)(t + ly0 * 16 + lx0) = outY0;
+                    *(g_u32p)(t + (ly0 + 8) * 16 + lx0) = outY1;
+                    *(g_u32p)(t + 256 + cpl * 64 + cy * 8 + cx0) = outC;
+                } else {
                 *(g_u32p)(dY + (long)ly0 * g.y_stride + c * 16 + lx0) = outY0;
                 *(g_u32p)(dY + (long)(ly0 + 8) * g.y_stride + c * 16 + lx0) = outY1;
                 *(g_u32p)((cpl ? dV : dU) + (long)cy * g.uv_stride + c * 8 + cx0) = outC;
+                }
             }
             if (XCU) {
                 if (ly0 == 7) gran_store(gran_mine + c * 4 + (lx0 >> 2), outY1, epoch);                 // pixel row 15

@@ -86,6 +86,10 @@ struct Knobs {
                       // (default 384; 0: never).  It shortens a frame's critical path (1080p P frames, 1..16 per launch: recon 0.91 ->
                       // 0.46-0.56 ms; 128: 1.56 -> 1.45) and costs throughput in launches that fill the chip anyway (512 frames:
                       // 3.82 -> 4.03 ms, 1024: 7.2 -> 8.2)
+    int inter_tiled;  // VP8HIP_INTER_TILED=N: launches of N or more frames with inter frames among them hand over to the lane-per-row loop
+                      // filter through the tiled scratch frames (default 640; 0: never).  1080p P frames, recon + loop filter per launch:
+                      // 512 frames 6.5 -> 7.4 ms, 768: 11.5 -> 10.6, 1024: 13.2 -> 10.9, 8192: 101.8 -> 73.2 (the recon's 4-byte stores
+                      // complete 128-byte tile lines, which they never do in a raster frame)
     int lf_split;     // VP8HIP_LF_SPLIT=0: one lane-per-row loop-filter kernel for all three planes (default 1: luma and chroma kernels side by side)
     int lf_raster, lgG, simt_waves, wg_per_cu, xcu, xcu_S, xcu_NW, recon_nw, lf_nw, detile_stream, detile_defer;
 };
@@ -102,6 +106,7 @@ static void read_knobs(Knobs &k)
     k.xcu_S = env_int("VP8HIP_XCU_S", 0);
     k.lf_split = env_int("VP8HIP_LF_SPLIT", 1);
     k.inter_split = env_int("VP8HIP_INTER_SPLIT", 384);
+    k.inter_tiled = env_int("VP8HIP_INTER_TILED", 640);
     k.xcu_NW = env_int("VP8HIP_XCU_NW", 0);
     k.recon_nw = env_int("VP8HIP_RECON_NW", 0);
     k.lf_nw = env_int("VP8HIP_LF_NW", 0);
@@ -569,8 +574,13 @@ extern "C" int vp8hip_decode(vp8hip_ctx *c, const vp8hip_job *jobs, int njobs, i
     bool simt_recon = (stages & VP8HIP_STAGE_RECON) && all_key && njobs > 2 * c->num_cu;
     if (K.recon_force)           // tuning / test knob: force one of the two kernel families (lane-per-row: key frames only)
         simt_recon = (stages & VP8HIP_STAGE_RECON) && all_key && K.recon_force == 1;
+    // Large launches with inter frames: the wave-per-row recon (inter prediction is its business) writes the tiled scratch
+    // frames too, and the loop filter is the lane-per-row one, at half the time per frame of the wave-per-row filter once the
+    // launch fills the chip
+    const bool inter_tiled = (stages & VP8HIP_STAGE_RECON) && (stages & VP8HIP_STAGE_LF) && !all_key && K.inter_tiled > 0
+                             && njobs >= K.inter_tiled;
     // the lane-per-row kernels work on macroblock-tiled scratch frames; vp8_detile_kernel converts at the end
-    const bool tiled = simt_recon;
+    const bool tiled = simt_recon || inter_tiled;
     // When the loop filter runs at all (some frame of the launch has filter_level != 0), it writes its finished lines
     // straight into the raster frame buffers -- unfiltered frames are carried through with the filter gated off -- (rows of two neighbouring macroblocks back to back: 32-byte pieces) and the tiled -> raster
     // pass is skipped; only the border extension is left.  +6..10 % from 1536 frames per launch up (1080p), a tie at 2048,
@@ -719,7 +729,7 @@ extern "C" int vp8hip_decode(vp8hip_ctx *c, const vp8hip_job *jobs, int njobs, i
         if (K.simt_waves >= 1) maxw = K.simt_waves;
         if (simt_waves > maxw) simt_waves = maxw;
     }
-    if (tiled) { c->stats.workgroups = simt_waves; c->stats.recon_waves = 1; c->stats.lf_waves = 1; }
+    if (tiled) { c->stats.workgroups = simt_waves; c->stats.recon_waves = simt_recon ? 1 : c->recon_nw; c->stats.lf_waves = 1; }
     c->stats.detile_pass = tiled && !lf_raster;
     if (stages & VP8HIP_STAGE_RECON) {
         if (simt_recon) {
@@ -729,7 +739,7 @@ extern "C" int vp8hip_decode(vp8hip_ctx *c, const vp8hip_job *jobs, int njobs, i
             const int npairs = (njobs + 1) / 2;          // two frames per wave
             // launches with inter frames: their inter macroblocks first, every one on its own (vp8_inter_mb_kernel), then the
             // row-ordered kernel for the intra macroblocks only
-            const bool inter_first = !all_key && njobs <= K.inter_split;
+            const bool inter_first = !all_key && njobs <= K.inter_split && !tiled;
             if (inter_first) {
                 if (c->intra_flags_cap < njobs) {
                     if (c->d_intra_flags) (void)hipFree(c->d_intra_flags);

@@ -20,7 +20,7 @@ def ctx(pkg):
     c.close()
 
 
-@pytest.fixture(params=["wave", "wave1cu", "wave_split", "wave1cu_split", "lane", "lane_detile"], autouse=True)
+@pytest.fixture(params=["wave", "wave1cu", "wave_split", "wave1cu_split", "wave_tiled", "lane", "lane_detile"], autouse=True)
 def kernel_family(request, monkeypatch):
     """Every test runs with all kernel variants: "wave" = one wave per MB row with a frame pair spread over several
     CUs where the launch is small enough (granule hand-over through global memory), "wave1cu" = the same kernels with
@@ -28,7 +28,9 @@ def kernel_family(request, monkeypatch):
     macroblock-tiled scratch frames (large launches; the loop filter writes the raster frame buffers when every frame of
     the launch is filtered, else a detile pass does), "lane_detile" = the same with the detile pass always.  "..._split":
     launches with inter frames always run vp8_inter_mb_kernel (every inter macroblock on its own) before the row-ordered kernel
-    does the intra macroblocks -- by default only launches of up to 384 frames do; "wave1cu" never does.  VP8HIP_RECON /
+    does the intra macroblocks -- by default only launches of up to 384 frames do; "wave1cu" never does.  "wave_tiled": every
+    launch with inter frames hands over from the wave-per-row recon to the lane-per-row loop filter through the tiled scratch
+    frames (by default launches of 640 frames and more).  VP8HIP_RECON /
     VP8HIP_XCU / VP8HIP_INTER_SPLIT are the library's tuning knobs that override the automatic choice
     (libvpx.opencl_amd/csrc/hip/vp8hip.hip)."""
     monkeypatch.setenv("VP8HIP_RECON", "simt" if request.param.startswith("lane") else "wave")
@@ -40,6 +42,10 @@ def kernel_family(request, monkeypatch):
         monkeypatch.setenv("VP8HIP_XCU", "0")
     else:
         monkeypatch.delenv("VP8HIP_XCU", raising=False)
+    if request.param == "wave_tiled":
+        monkeypatch.setenv("VP8HIP_INTER_TILED", "1")
+    else:
+        monkeypatch.delenv("VP8HIP_INTER_TILED", raising=False)
     if request.param.endswith("_split"):
         monkeypatch.setenv("VP8HIP_INTER_SPLIT", "100000")
     elif request.param == "wave1cu":
