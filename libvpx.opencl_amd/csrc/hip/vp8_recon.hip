@@ -500,7 +500,7 @@ __device__ __forceinline__ void recon_body(const DevJob *__restrict__ jobs, int 
         const int16_t *coefs = half ? jobB.coef : jobA.coef;
         const vp8ir_mv *mvs = half ? jobB.mvs : jobA.mvs;
         uint8_t *dst = half ? jobB.dst : jobA.dst;
-        g_u8p tile_out = INTER_DONE ? (g_u8p) nullptr : (g_u8p)(half ? jobB.tile : jobA.tile);
+        g_u8p tile_out = (g_u8p)(half ? jobB.tile : jobA.tile);
         g_cu32p mbrow = (g_cu32p)(mbs + (long)r * cols);          // 16 dwords per MB
         g_cs16p coefrow = (g_cs16p)(coefs + (long)r * cols * VP8IR_COEF_PER_MB);
         g_u8p dY = (g_u8p)(dst + g.y_off + (long)r * 16 * g.y_stride);
@@ -687,9 +687,16 @@ __device__ __forceinline__ void recon_body(const DevJob *__restrict__ jobs, int 
                 }
             } else if (INTER_DONE) {
                 // ---- inter MB, finished by vp8_inter_mb_kernel: what this lane would have stored
+                if (tile_out) {
+                    g_cu8p t = (g_cu8p)tile_out + ((long)r * cols + c) * VP8_TILE_BYTES;
+                    outY0 = *(g_cu32p)(t + ly0 * 16 + lx0);
+                    outY1 = *(g_cu32p)(t + (ly0 + 8) * 16 + lx0);
+                    outC = *(g_cu32p)(t + 256 + cpl * 64 + cy * 8 + cx0);
+                } else {
                 outY0 = *(g_cu32p)(dY + (long)ly0 * g.y_stride + c * 16 + lx0);
                 outY1 = *(g_cu32p)(dY + (long)(ly0 + 8) * g.y_stride + c * 16 + lx0);
                 outC = *(g_cu32p)((cpl ? dV : dU) + (long)cy * g.uv_stride + c * 8 + cx0);
+                }
             } else {
                 // ---- inter MB
                 mb_inter(g, wl, (g_cu8p)(half ? jobB.ref[ref_frame & 3] : jobA.ref[ref_frame & 3]),
@@ -856,11 +863,18 @@ vp8_inter_mb_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g, unsig
             u32 outY0, outY1, outC;
             mb_inter(g, wl, (g_cu8p)job.ref[ref_frame & 3], mv, mv2, flags, y_mode, r, c, h.version != 0, h.version == 3, ML,
                      rY0, rY1, rC, outY0, outY1, outC);
+            if (job.tile) {
+                g_u8p t = (g_u8p)job.tile + (long)nn * VP8_TILE_BYTES;
+                *(g_u32p)(t + ML.ly0 * 16 + ML.lx0) = outY0;
+                *(g_u32p)(t + (ML.ly0 + 8) * 16 + ML.lx0) = outY1;
+                *(g_u32p)(t + 256 + ML.cpl * 64 + ML.cy * 8 + ML.cx0) = outC;
+            } else {
             g_u8p dY = (g_u8p)(job.dst + g.y_off + (long)r * 16 * g.y_stride);
             g_u8p dC = (g_u8p)(job.dst + (ML.cpl ? g.v_off : g.u_off) + (long)r * 8 * g.uv_stride);
             *(g_u32p)(dY + (long)ML.ly0 * g.y_stride + c * 16 + ML.lx0) = outY0;
             *(g_u32p)(dY + (long)(ML.ly0 + 8) * g.y_stride + c * 16 + ML.lx0) = outY1;
             *(g_u32p)(dC + (long)ML.cy * g.uv_stride + c * 8 + ML.cx0) = outC;
+            }
         }
         wave_lds_sync();                         // wl->res / wl->wht_dc are reused by the next macroblock
     }

@@ -739,7 +739,7 @@ extern "C" int vp8hip_decode(vp8hip_ctx *c, const vp8hip_job *jobs, int njobs, i
             const int npairs = (njobs + 1) / 2;          // two frames per wave
             // launches with inter frames: their inter macroblocks first, every one on its own (vp8_inter_mb_kernel), then the
             // row-ordered kernel for the intra macroblocks only
-            const bool inter_first = !all_key && njobs <= K.inter_split && !tiled;
+            const bool inter_first = !all_key && njobs <= K.inter_split;
             if (inter_first) {
                 if (c->intra_flags_cap < njobs) {
                     if (c->d_intra_flags) (void)hipFree(c->d_intra_flags);
