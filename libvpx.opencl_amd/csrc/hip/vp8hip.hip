@@ -785,7 +785,10 @@ extern "C" int vp8hip_decode(vp8hip_ctx *c, const vp8hip_job *jobs, int njobs, i
             // 9.2 KB) share a SIMD, so every SIMD has two instruction streams to issue from.  The chroma kernel goes out on
             // a stream of its own behind the recon, and the main stream takes it back in before anything reads the frames.
             if (!c->stream3) {
-                HIPCHK(c, hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking));
+                // (a stream of the lowest priority class: the luma kernel, which takes longer, is served first where the two compete)
+                int prio_least = 0, prio_greatest = 0;
+                HIPCHK(c, hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+                HIPCHK(c, hipStreamCreateWithPriority(&c->stream3, hipStreamNonBlocking, prio_least));
                 HIPCHK(c, hipEventCreateWithFlags(&c->ev_split_from, hipEventDisableTiming));
                 HIPCHK(c, hipEventCreateWithFlags(&c->ev_split_done, hipEventDisableTiming));
             }
