@@ -146,7 +146,8 @@ VP8_RTCD_ENTRY(void, vp8_bilinear_predict4x4,
                (unsigned char *src, int src_pitch, int xofst, int yofst, unsigned char *dst, int dst_pitch))
 
 /* Device the per-block entries run on (default 0); call before the first per-block entry.  Returns 0, or -1 once
-   the staging buffers exist on another device. */
+   the staging buffers exist on another device.  (A per-block call makes that device the calling thread's current HIP
+   device and leaves it so.) */
 int vp8_rtcd_blocks_set_device(int device);
 
 void vpx_rtcd(void);

@@ -170,7 +170,7 @@ struct vp8hip_ctx {
     unsigned int *d_intra_flags; int intra_flags_cap;       // per job of a launch: the frame has intra macroblocks (vp8_inter_mb_kernel)
     hipStream_t stream3; hipEvent_t ev_split_from, ev_split_done;     // chroma half of the split lane-per-row loop filter
     // vp8hip_postproc: dither table (440 shorts), noise table (3072) and per-row noise phases (16384) on the device
-    char *d_pp; bool pp_rv_loaded;
+    char *d_pp, *h_pp; bool pp_rv_loaded; hipEvent_t ev_pp;
 };
 
 static int fail(vp8hip_ctx *c, int code, const char *fmt, ...)
@@ -196,7 +196,7 @@ static void free_pools(vp8hip_ctx *c)
     if (c->slot_block_dev) (void)hipFree(c->slot_block_dev);
     if (c->gran_recon) (void)hipFree(c->gran_recon);
     if (c->gran_lf) (void)hipFree(c->gran_lf);
-    if (c->d_pp) (void)hipFree(c->d_pp);
+    if (c->d_pp) { (void)hipFree(c->d_pp); (void)hipHostFree(c->h_pp); (void)hipEventDestroy(c->ev_pp); c->h_pp = nullptr; }
     if (c->d_intra_flags) (void)hipFree(c->d_intra_flags);
     c->d_intra_flags = nullptr; c->intra_flags_cap = 0;
     c->d_pp = nullptr; c->pp_rv_loaded = false;
@@ -954,7 +954,13 @@ extern "C" int vp8hip_postproc(vp8hip_ctx *c, int src_fb, int dst_fb, int tmp_fb
     HIPCHK(c, hipSetDevice(c->device));
     if (join_detile(c)) return -1;
     if (c->d2h_count) { HIPCHK(c, hipEventSynchronize(c->ev_d2h_done)); c->d2h_count = 0; }   // a batch download may be reading dst
-    if (!c->d_pp) HIPCHK(c, hipMalloc((void **)&c->d_pp, 1024 + 3072 + 16384));
+    if (!c->d_pp) {
+        HIPCHK(c, hipMalloc((void **)&c->d_pp, 1024 + 3072 + 16384));
+        // the caller's tables go through a pinned copy of our own, so that they may be reused the moment the call returns
+        HIPCHK(c, hipHostMalloc((void **)&c->h_pp, 1024 + 3072 + 16384, hipHostMallocDefault));
+        HIPCHK(c, hipEventCreateWithFlags(&c->ev_pp, hipEventDisableTiming));
+    } else
+        HIPCHK(c, hipEventSynchronize(c->ev_pp));       // the previous call's copies have left the pinned staging
     const short *d_rv = (const short *)c->d_pp;
     signed char *d_noise = (signed char *)c->d_pp + 1024;
     uint8_t *d_rows = (uint8_t *)c->d_pp + 1024 + 3072;
@@ -968,7 +974,8 @@ extern "C" int vp8hip_postproc(vp8hip_ctx *c, int src_fb, int dst_fb, int tmp_fb
         if (demacro) {       // luma only (vp8_deblock_and_de_macro_block, postproc.c:328-346)
             uint8_t *tmp = c->fb[tmp_fb];
             if (!c->pp_rv_loaded) {
-                HIPCHK(c, hipMemcpyAsync(c->d_pp, pp->rv, 440 * sizeof(short), hipMemcpyHostToDevice, c->stream));
+                memcpy(c->h_pp, pp->rv, 440 * sizeof(short));
+                HIPCHK(c, hipMemcpyAsync(c->d_pp, c->h_pp, 440 * sizeof(short), hipMemcpyHostToDevice, c->stream));
                 c->pp_rv_loaded = true;
             }
             vp8pp_mb_across(c->stream, dst + pl[0].off, tmp + pl[0].off, pl[0].stride, pl[0].rows, pl[0].cols, pp->mb_flimit);
@@ -978,11 +985,16 @@ extern "C" int vp8hip_postproc(vp8hip_ctx *c, int src_fb, int dst_fb, int tmp_fb
     } else       // vp8_yv12_copy_frame_ptr (postproc.c:982)
         HIPCHK(c, hipMemcpyAsync(dst, src, (size_t)g.frame_size, hipMemcpyDeviceToDevice, c->stream));
     if (noise) {
-        if (pp->noise) HIPCHK(c, hipMemcpyAsync(d_noise, pp->noise, 3072, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipMemcpyAsync(d_rows, pp->noise_rows, (size_t)pl[0].rows, hipMemcpyHostToDevice, c->stream));
+        if (pp->noise) {
+            memcpy(c->h_pp + 1024, pp->noise, 3072);
+            HIPCHK(c, hipMemcpyAsync(d_noise, c->h_pp + 1024, 3072, hipMemcpyHostToDevice, c->stream));
+        }
+        memcpy(c->h_pp + 1024 + 3072, pp->noise_rows, (size_t)pl[0].rows);
+        HIPCHK(c, hipMemcpyAsync(d_rows, c->h_pp + 1024 + 3072, (size_t)pl[0].rows, hipMemcpyHostToDevice, c->stream));
         vp8pp_add_noise(c->stream, dst + pl[0].off, pl[0].stride, pl[0].rows, pl[0].cols, pp->noise_clamp, d_noise, d_rows);
     }
     HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipEventRecord(c->ev_pp, c->stream));
     return 0;
 }
 
