@@ -95,3 +95,13 @@ def test_webm_input(exe):
     r = subprocess.run([exe, "--md5", "--i420", webm], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     assert r.stdout.split()[0] == open(webm + ".vpxdec_md5").read().strip()
+
+
+def test_vpxdec_threads_option():
+    """-t N = vpx_codec_dec_cfg_t::threads: token partitions of a frame on several host threads (vp8_parser_set_threads); the
+    8-partition 1080p stream decodes to the reference's digest whatever N."""
+    name = "kf_8part_1920x1080"
+    for t in ("1", "3", "8"):
+        r = subprocess.run([os.path.join(BIN, "vpxdec"), "-t", t, "--md5", "--i420", ivf_path(name)], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        assert r.stdout.split()[0] == open(os.path.join(GOLDEN, name + ".vpxdec_md5")).read().strip(), t

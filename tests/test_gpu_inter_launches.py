@@ -1,0 +1,64 @@
+"""GPU: launches with inter frames at the sizes where vp8hip_decode changes its kernels by itself (no knobs set): up to 384
+frames -- inter macroblocks by vp8_inter_mb_kernel first --, 385..639 -- the row-ordered kernels alone --, 640 and more -- through
+the macroblock-tiled scratch frames to the lane-per-row loop filter.  Real 1080p P frames (dense fixture), every job decoding
+the same frame from the same references into its own buffer: all outputs equal the reference decoder's MD5 and each other,
+whole buffers (borders included) are the same on every path."""
+import numpy as np
+import pytest
+
+from vp8_testlib import golden_md5, ivf_path
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def decoded(pkg):
+    """context with frames 0..1 of the dense P stream decoded; frame 2 (inter) parsed into slot 1"""
+    P = pkg
+    name, k = "p_dense_1920x1080", 2
+    w, h, frames = P.read_ivf(ivf_path(name))
+    ctx = P.Vp8Hip(0)
+    ctx.configure(w, h, 4 + 700, 2)
+    parser = P.Parser()
+    for data in frames[:k]:
+        hdr = ctx.parse_into_slot(parser, data, 0)
+        ctx.upload(0)
+        r = parser.refs
+        ctx.decode([(0, r.new_idx, (r.lst_idx, r.gld_idx, r.alt_idx) if hdr.frame_type else None)], P.STAGE_ALL)
+        ctx.sync()
+        parser.swap(hdr)
+    hdr = ctx.parse_into_slot(parser, frames[k], 1)
+    assert hdr.frame_type == 1
+    ctx.upload(1)
+    r = parser.refs
+    yield P, ctx, (r.lst_idx, r.gld_idx, r.alt_idx), golden_md5(name)[k]
+    parser.close()
+    ctx.close()
+
+
+def _launch(P, ctx, refs, n):
+    jobs = (P.Job * n)()
+    for i in range(n):
+        jobs[i].ir_slot, jobs[i].dst_fb = 1, 4 + i
+        jobs[i].ref_fb[1], jobs[i].ref_fb[2], jobs[i].ref_fb[3] = refs
+    ctx.decode_array(jobs, n, P.STAGE_ALL)
+    ctx.sync()
+    return ctx.stats()
+
+
+def test_every_launch_size_regime_gives_the_reference_frame(decoded, monkeypatch):
+    P, ctx, refs, gold = decoded
+    for v in ("VP8HIP_INTER_SPLIT", "VP8HIP_INTER_TILED", "VP8HIP_RECON", "VP8HIP_XCU", "VP8HIP_LF_RASTER"):
+        monkeypatch.delenv(v, raising=False)
+    whole = None
+    for n, lane_lf in ((1, False), (3, False), (384, False), (500, False), (640, True), (700, True)):
+        for i in range(n):                                   # nothing left over from the previous launch
+            ctx.upload_frame(4 + i, np.zeros(ctx.g.frame_size, np.uint8)) if i in (0, n // 2, n - 1) else None
+        st = _launch(P, ctx, refs, n)
+        assert (st.lf_waves == 1) == lane_lf, (n, st.lf_waves)       # 640 and more: the lane-per-row loop filter ran
+        for i in sorted({0, n // 2, n - 1}):
+            assert P.planes_md5(*ctx.download_planes(4 + i)) == gold, (n, i)
+        full = ctx.download_full(4 + n - 1)
+        if whole is None:
+            whole = full
+        assert np.array_equal(full, whole), n                # borders included, bit for bit the same on every path
