@@ -392,7 +392,7 @@ def main():
                             "extend": (B_DETILE if detile else B_EXTEND) * nmb * F}
         # (the lane-per-row loop filter is two kernels side by side on two streams, luma and chroma; "loopfilter" is the interval
         #  both take together, which is the duration of the luma kernel -- the chroma kernel ends inside it)
-        split = os.environ.get("VP8HIP_LF_SPLIT", "1") != "0"
+        split = st.lf_kernels == 2      # (large launches settle on whichever is faster in this process)
         names = ({"recon": "vp8_recon_simt_kernel",
                   "loopfilter": "vp8_loopfilter_simt_luma_kernel (with vp8_loopfilter_simt_chroma_kernel beside it)" if split
                                 else "vp8_loopfilter_simt_kernel",

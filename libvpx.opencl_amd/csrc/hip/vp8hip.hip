@@ -90,7 +90,9 @@ struct Knobs {
                       // filter through the tiled scratch frames (default 640; 0: never).  1080p P frames, recon + loop filter per launch:
                       // 512 frames 6.5 -> 7.4 ms, 768: 11.5 -> 10.6, 1024: 13.2 -> 10.9, 8192: 101.8 -> 73.2 (the recon's 4-byte stores
                       // complete 128-byte tile lines, which they never do in a raster frame)
-    int lf_split;     // VP8HIP_LF_SPLIT=0: one lane-per-row loop-filter kernel for all three planes (default 1: luma and chroma kernels side by side)
+    // VP8HIP_LF_SPLIT: lane-per-row loop filter 0 = one kernel for all three planes, 2 = luma and chroma kernels side by side,
+    // 1 (default) = side by side for launches below 1024 frames, above that whichever a trial of both finds faster
+    int lf_split;
     int lf_raster, lgG, simt_waves, wg_per_cu, xcu, xcu_S, xcu_NW, recon_nw, lf_nw, detile_stream, detile_defer;
 };
 static int env_int(const char *name, int dflt) { const char *e = getenv(name); return e && *e ? atoi(e) : dflt; }
@@ -124,6 +126,12 @@ struct vp8hip_ctx {
     // extend, [4..5] around the tiled -> raster pass on whichever stream it ran
     hipEvent_t evr[VP8HIP_STATS_RING][6];
     bool evr_tiled[VP8HIP_STATS_RING]; vp8hip_stats evr_stats[VP8HIP_STATS_RING];
+    // Lane-per-row loop filter as one kernel or as luma + chroma kernels side by side: which is faster is a property of the
+    // process (the pair takes 27 or 32 ms, the single kernel 30.5), so large launches try both and keep the
+    // winner.  evr_lf_mode: what a launch of the ring used (-1: not a candidate, 0: one kernel, 1: the pair), evr_lf_njobs:
+    // its size; lf_auto: -1 undecided, else the mode chosen for launches of lf_auto_njobs frames
+    int evr_lf_mode[VP8HIP_STATS_RING], evr_lf_njobs[VP8HIP_STATS_RING];
+    int lf_auto, lf_auto_njobs, lf_auto_count; float lf_auto_ms[2]; bool lf_auto_have[2];
     long ncalls;
     hipEvent_t ev_jobs;            // job table of the previous call has been copied
     // The tiled -> raster pass of the lane-per-row pipeline is memory-bound while recon and loop filter are
@@ -253,6 +261,8 @@ extern "C" int vp8hip_create(int device, vp8hip_ctx **out)
     c->deferred.valid = false;
     c->width = c->height = 0;
     c->ncalls = 0;
+    c->lf_auto = -1; c->lf_auto_njobs = 0;
+    for (int r = 0; r < VP8HIP_STATS_RING; r++) c->evr_lf_mode[r] = -1;
     c->gran_recon = c->gran_lf = nullptr; c->gran_recon_cap = c->gran_lf_cap = 0; c->epoch = 0;
     c->h_status = c->d_status = nullptr;
     memset(&c->stats, 0, sizeof c->stats);
@@ -780,7 +790,44 @@ extern "C" int vp8hip_decode(vp8hip_ctx *c, const vp8hip_job *jobs, int njobs, i
         if (launch_deferred(c, c->ev_recon_done)) return -1;
     }
     if ((stages & VP8HIP_STAGE_LF) && any_lf) {
-        if (tiled && K.lf_split) {
+        // one kernel, or luma + chroma side by side: K.lf_split 0 / 2 force it; 1 (default) lets launches of 1024 frames and
+        // more find out -- early launches go out one way and the other, and as soon as one of each has finished (their events
+        // are only queried, never waited for) the faster one stays
+        bool lf_pair = K.lf_split == 2 || (K.lf_split == 1 && njobs < 1024);
+        if (tiled && K.lf_split == 1 && njobs >= 1024) {
+            if (c->lf_auto_njobs != njobs) {
+                c->lf_auto = -1; c->lf_auto_njobs = njobs; c->lf_auto_have[0] = c->lf_auto_have[1] = false; c->lf_auto_count = 0;
+                for (int r = 0; r < VP8HIP_STATS_RING; r++) c->evr_lf_mode[r] = -1;
+            }
+            if (c->lf_auto < 0) {
+                for (int r = 0; r < VP8HIP_STATS_RING; r++) {
+                    const int m = c->evr_lf_mode[r];
+                    if (m < 0 || c->evr_lf_njobs[r] != njobs || hipEventQuery(c->evr[r][2]) != hipSuccess) continue;
+                    float ms = 0;
+                    if (hipEventElapsedTime(&ms, c->evr[r][1], c->evr[r][2]) == hipSuccess && ms > 0) {
+                        // the fastest launch of each kind counts: the first ones also pay for first-touch effects
+                        if (!c->lf_auto_have[m] || ms < c->lf_auto_ms[m]) c->lf_auto_ms[m] = ms;
+                        c->lf_auto_have[m] = true;
+                    }
+                    c->evr_lf_mode[r] = -1;
+                }
+                (void)hipGetLastError();
+                if (c->lf_auto_have[0] && c->lf_auto_have[1]) {
+                    c->lf_auto = c->lf_auto_ms[1] <= c->lf_auto_ms[0] ? 1 : 0;
+                    if (getenv("VP8HIP_TRACE"))
+                        fprintf(stderr, "[vp8hip] loop filter of %d-frame launches: one kernel %.2f ms, luma + chroma side by side %.2f ms -> %s\n",
+                                njobs, c->lf_auto_ms[0], c->lf_auto_ms[1], c->lf_auto ? "side by side" : "one kernel");
+                }
+            }
+            // undecided: launch 0 of this size goes out as a pair and is not timed (first touches), launch 1 as a pair, launch 2
+            // as one kernel, later ones alternate until both kinds have been seen to finish
+            const int nth = c->lf_auto_count++;
+            lf_pair = c->lf_auto >= 0 ? c->lf_auto == 1 : (nth < 2 || (nth & 1));
+            c->evr_lf_mode[c->ncalls % VP8HIP_STATS_RING] = (c->lf_auto >= 0 || nth == 0) ? -1 : (lf_pair ? 1 : 0);
+            c->evr_lf_njobs[c->ncalls % VP8HIP_STATS_RING] = njobs;
+        }
+        c->stats.lf_kernels = tiled ? (lf_pair ? 2 : 1) : 1;
+        if (tiled && lf_pair) {
             // luma and chroma as two kernels side by side: a luma wave (268 registers, 25.6 KB of LDS) and a chroma wave (187,
             // 9.2 KB) share a SIMD, so every SIMD has two instruction streams to issue from.  The chroma kernel goes out on
             // a stream of its own behind the recon, and the main stream takes it back in before anything reads the frames.

@@ -34,10 +34,14 @@ def lgG(request):
     return request.param
 
 
-@pytest.fixture(params=["raster", "detile"])
+@pytest.fixture(params=["raster", "detile", "raster_onekernel"])
 def lane_shape(request, lgG, monkeypatch):
+    """raster / detile: the loop filter writes the frame buffers itself / a tiled -> raster pass does; the loop filter runs as
+    luma + chroma kernels side by side, except "raster_onekernel": one kernel for all three planes (what large launches fall
+    back to when that is the faster one in the process at hand, VP8HIP_LF_SPLIT in vp8hip.hip)."""
     monkeypatch.setenv("VP8HIP_RECON", "simt")
     monkeypatch.setenv("VP8HIP_SIMT_LGG", str(lgG))
+    monkeypatch.setenv("VP8HIP_LF_SPLIT", "0" if request.param == "raster_onekernel" else "2")
     if request.param == "detile":
         monkeypatch.setenv("VP8HIP_LF_RASTER", "0")
     else:
@@ -101,7 +105,7 @@ def test_benchmark_shape_full_size(pkg, monkeypatch):
     kernel and shape choice.  Frames i and i + 10k decode copies of the same IR on different strands, waves and scratch
     sets: >= 64 of them, spread over the launch, must equal the reference MD5 and each other byte for byte (borders
     included); three launches back to back rotate the scratch sets and job tables."""
-    for k in ("VP8HIP_RECON", "VP8HIP_SIMT_LGG", "VP8HIP_SIMT_WAVES", "VP8HIP_LF_RASTER"):
+    for k in ("VP8HIP_RECON", "VP8HIP_SIMT_LGG", "VP8HIP_SIMT_WAVES", "VP8HIP_LF_RASTER", "VP8HIP_LF_SPLIT"):
         monkeypatch.delenv(k, raising=False)
     import torch
     free, _total = torch.cuda.mem_get_info(0)
@@ -127,6 +131,13 @@ def test_benchmark_shape_full_size(pkg, monkeypatch):
         jobs = (pkg.Job * n)()
         for i in range(n):
             jobs[i].ir_slot, jobs[i].dst_fb = i, i
+        # launches of this size try the loop filter as luma + chroma kernels side by side (launches 0, 1) and as one kernel
+        # (launch 2) and keep the faster: every one of these is checked, the later ones are whatever won
+        for trial in range(3):
+            ctx.decode_array(jobs, n, 7)
+            ctx.sync()
+            for i in (0, 9, n // 2 + 3, n - 1):
+                assert pkg.planes_md5(*ctx.download_planes(i)) == gold[i % nsrc], (trial, i)
         for _ in range(3):
             ctx.decode_array(jobs, n, 7)
         ctx.sync()
