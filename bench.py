@@ -392,12 +392,20 @@ def main():
                             "extend": (B_DETILE if detile else B_EXTEND) * nmb * F}
         # (the lane-per-row loop filter is two kernels side by side on two streams, luma and chroma; "loopfilter" is the interval
         #  both take together, which is the duration of the luma kernel -- the chroma kernel ends inside it)
-        split = st.lf_kernels == 2      # (large launches settle on whichever is faster in this process)
+        split = st.lf_kernels == 2      # (VP8HIP_FUSED=0 only: the two-kernel pipeline's loop filter as luma + chroma kernels)
+        fused = bool(getattr(st, "fused", 0))   # reconstruction + loop filter in ONE kernel (vp8_keyframe_simt_kernel): ms["recon"] is its time
+        if fused:
+            # SURVEY.md 8(d)'s byte model for the stages the kernel covers: residual + intra recon (1217) + loop filter (770)
+            bytes_per_launch["recon"] = (B_RECON + B_LF) * nmb * F
+            bytes_per_launch["loopfilter"] = 0
         names = ({"recon": "vp8_recon_simt_kernel",
                   "loopfilter": "vp8_loopfilter_simt_luma_kernel (with vp8_loopfilter_simt_chroma_kernel beside it)" if split
                                 else "vp8_loopfilter_simt_kernel",
                   "extend": "vp8_detile_kernel (tiled -> raster + border extension)" if detile else "vp8_extend_kernel"} if lane else
                  {"recon": "vp8_recon_kernel", "loopfilter": "vp8_loopfilter_kernel", "extend": "vp8_extend_kernel"})
+        if fused:
+            names["recon"] = "vp8_keyframe_simt_kernel"
+            names["loopfilter"] = None
         dom = max(ms, key=lambda k: ms[k])
         achieved = bytes_per_launch[dom] / (ms[dom] * 1e-3) / 1e9
         # SURVEY.md 8(d)'s own figure for the full key-frame path: 1217 + 770 + 36 = 2023 B/MB

@@ -62,7 +62,10 @@ typedef struct vp8hip_stats {      /* filled by vp8hip_get_stats; times from HIP
     int   workgroups;
     int   detile_pass;                  /* 1: a tiled -> raster pass finished the launch (lane-per-row kernels with no
                                            filtered frame in the launch, or VP8HIP_LF_RASTER=0); extend_ms covers it */
-    int   lf_kernels;                   /* lane-per-row loop filter: 2 = luma and chroma kernels side by side, 1 = one kernel */
+    int   lf_kernels;                   /* lane-per-row loop filter: 2 = luma and chroma kernels side by side, 1 = one kernel,
+                                           0 = none (fused) */
+    int   fused;                        /* 1: vp8_keyframe_simt_kernel reconstructed AND filtered the launch (all key frames, both
+                                           stages); recon_ms covers it, lf_ms is 0 */
 } vp8hip_stats;
 
 /* device < 0: use the current HIP device.  Returns 0 or a negative error. */

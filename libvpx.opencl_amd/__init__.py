@@ -95,7 +95,7 @@ class Job(ctypes.Structure):
 class Stats(ctypes.Structure):
     _fields_ = [("recon_ms", ctypes.c_float), ("lf_ms", ctypes.c_float), ("extend_ms", ctypes.c_float),
                 ("recon_waves", c_int), ("lf_waves", c_int), ("workgroups", c_int), ("detile_pass", c_int),
-                ("lf_kernels", c_int)]
+                ("lf_kernels", c_int), ("fused", c_int)]
 
 
 # ------------------------------------------------------------------------------------------

@@ -23,278 +23,7 @@
 #include "vp8_common.hip.h"
 #include <stddef.h>
 
-namespace {
-
-typedef unsigned int u32;
-typedef u32 u32x4 __attribute__((ext_vector_type(4)));
-typedef u32 u32x2 __attribute__((ext_vector_type(2)));
-typedef GLOBAL_AS const u32x4 *g_cu32x4p;
-typedef GLOBAL_AS const u32x2 *g_cu32x2p;
-typedef GLOBAL_AS u32x4 *g_u32x4p;
-typedef GLOBAL_AS u32x2 *g_u32x2p;
-typedef short v2s __attribute__((ext_vector_type(2)));     // the same pixel position of two lines
-
-__device__ __forceinline__ u32 perm(u32 hi, u32 lo, u32 sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
-__device__ __forceinline__ u32 from_lane_above(u32 v)
-{
-    return (u32)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
-}
-__device__ __forceinline__ u32 load_l2(const unsigned char *p)
-{
-    return __hip_atomic_load((const u32 *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ unsigned long long load_l2_64(const unsigned char *p)
-{
-    return __hip_atomic_load((const unsigned long long *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// Pixels travel through the filters as SIGNED 8.8 fixed point -- pixel ^ 0x80 (the reference's own bias,
-// loopfilter_filters.c:57-60) in the HIGH half of each 16-bit lane -- from the moment they are staged in the LDS tile
-// until they are read back for output (one XOR per dword of four pixels each way, not two per value and edge):
-//   * the filter arithmetic wants them that way: the 16-bit saturation of `v_pk_add_i16 ... clamp` IS the reference's
-//     vp8_signed_char_clamp (every operand is a multiple of 256), so a saturating add costs one instruction instead
-//     of add + min + max;
-//   * the masks only need |a-b|, which is max-min in any order-preserving representation: signed max / min, and the
-//     difference taken modulo 2^16 is the unsigned 8.8 distance; comparisons by unsigned saturating subtraction.
-typedef unsigned short v2u __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ v2u as_v2u(u32 v) { return __builtin_bit_cast(v2u, v); }
-__device__ __forceinline__ u32 as_u32(v2u v) { return __builtin_bit_cast(u32, v); }
-__device__ __forceinline__ u32 as_u32(v2s v) { return __builtin_bit_cast(u32, v); }
-__device__ __forceinline__ v2s as_v2s(u32 v) { return __builtin_bit_cast(v2s, v); }
-__device__ __forceinline__ v2u mku(int v) { return (v2u){ (unsigned short)v, (unsigned short)v }; }
-__device__ __forceinline__ v2s mks(int v) { return (v2s){ (short)v, (short)v }; }
-__device__ __forceinline__ v2u umax(v2u a, v2u b) { return __builtin_elementwise_max(a, b); }
-__device__ __forceinline__ v2u umin(v2u a, v2u b) { return __builtin_elementwise_min(a, b); }
-__device__ __forceinline__ v2u adu(v2u a, v2u b)                                                     // |a - b| of two biased pixels
-{
-    const v2s x = __builtin_bit_cast(v2s, a), y = __builtin_bit_cast(v2s, b);
-    return __builtin_bit_cast(v2u, (v2s)(__builtin_elementwise_max(x, y) - __builtin_elementwise_min(x, y)));
-}
-__device__ __forceinline__ v2u usubs(v2u a, v2u b) { return __builtin_elementwise_sub_sat(a, b); }    // max(a - b, 0)
-__device__ __forceinline__ v2u uadds(v2u a, v2u b) { return __builtin_elementwise_add_sat(a, b); }
-__device__ __forceinline__ v2s adds(v2s a, v2s b) { return __builtin_elementwise_add_sat(a, b); }     // signed-char clamp
-__device__ __forceinline__ v2s subs(v2s a, v2s b) { return __builtin_elementwise_sub_sat(a, b); }
-// x != 0 ? 0 : 0xffff (nz_clear) and x != 0 ? 0xffff : 0 (nz_set) per half, from max(1 - x, 0) by saturating subtraction.
-// `one` is the constant 1 | 1 << 16 made opaque to LLVM (one empty asm at kernel entry, see Lim::one): with a visible
-// constant the expression is canonicalised into a compare-and-select, which gfx950 can only do one half at a time.
-__device__ __forceinline__ v2u nz_clear(v2u x, v2u one) { return mku(0) - usubs(one, x); }
-__device__ __forceinline__ v2u nz_set(v2u x, v2u one) { return usubs(one, x) - one; }
-__device__ __forceinline__ v2s sgn(v2u p) { return as_v2s(as_u32(p)); }                              // (already biased: see above)
-__device__ __forceinline__ v2u pix(v2s s) { return as_v2u(as_u32(s)); }
-#define VP8_LF_BIAS 0x80808080u     // four pixels <-> four biased pixels, on the way into and out of the LDS tile
-__device__ __forceinline__ v2s hib(v2s v) { return as_v2s(as_u32(v) & 0xff00ff00u); }                // floor to a whole byte
-
-struct Lim { v2u mblim, blim, lim, thr, one; };     // the limits, << 8; the opaque constant 1 of nz_clear / nz_set
-
-// The filters are branch-free: `gate` (0xffff / 0 per lane) switches an edge off by clearing its filter mask,
-// which makes every update the identity.  Straight-line code lets the scheduler interleave the independent
-// pixel-line pairs, which is what hides the wait state gfx950 wants between dependent packed-math ops.
-
-// vp8_filter_mask + vp8_hevmask (loopfilter_filters.c:27-49) for p[0..7] = p3 p2 p1 p0 q0 q1 q2 q3:
-// mask = 0xffff where the edge is filtered, hev = 0xffff where the high-edge-variance rule applies
-__device__ __forceinline__ void masks(const v2u p[8], v2u lim, v2u elim, v2u thr, v2u one, v2u gate, v2u &mask, v2u &hev)
-{
-    const v2u d10 = adu(p[2], p[3]), dq = adu(p[5], p[4]);
-    const v2u dh = umax(d10, dq);
-    v2u m = umax(umax(adu(p[0], p[1]), adu(p[1], p[2])), dh);
-    m = umax(m, umax(adu(p[6], p[5]), adu(p[7], p[6])));
-    const v2u a = adu(p[3], p[4]);
-    const v2u e = uadds(uadds(a, a), (adu(p[2], p[5]) >> 1) & mku(0xff00));      // 2|p0-q0| + |p1-q1|/2, saturating
-    const v2u over = usubs(m, lim) | usubs(e, elim);                              // non-zero: leave the edge alone
-    mask = nz_clear(over, one) & gate;
-    hev = nz_set(usubs(dh, thr), one);
-}
-
-// filter_value = clamp(filter_value + 3 * (qs0 - ps0)) (loopfilter_filters.c:66, 176): three saturating adds of
-// the saturated difference give the same result as one clamp of the exact sum (same-signed increments)
-__device__ __forceinline__ v2s add3w(v2s f, v2s qs0, v2s ps0)
-{
-    const v2s w = subs(qs0, ps0);
-    return adds(adds(adds(f, w), w), w);
-}
-
-// vp8_loop_filter_c (loopfilter_filters.c:51-95): inner edges, modifies p1 p0 q0 q1
-__device__ __forceinline__ void lf_inner(v2u p[8], const Lim &L, v2u gate)
-{
-    v2u mask, hev;
-    masks(p, L.lim, L.blim, L.thr, L.one, gate, mask, hev);
-    v2s ps1 = sgn(p[2]), ps0 = sgn(p[3]), qs0 = sgn(p[4]), qs1 = sgn(p[5]);
-    v2s f = as_v2s(as_u32(subs(ps1, qs1)) & as_u32(hev));
-    f = as_v2s(as_u32(add3w(f, qs0, ps0)) & as_u32(mask));
-    const v2s f1 = hib(adds(f, mks(0x0400)) >> 3), f2 = hib(adds(f, mks(0x0300)) >> 3);
-    qs0 = subs(qs0, f1); ps0 = adds(ps0, f2);
-    f = as_v2s(as_u32((f1 + mks(0x0100)) >> 1) & (~as_u32(hev) & 0xff00ff00u));
-    qs1 = subs(qs1, f); ps1 = adds(ps1, f);
-    p[2] = pix(ps1); p[3] = pix(ps0); p[4] = pix(qs0); p[5] = pix(qs1);
-}
-
-// vp8_mbloop_filter_c (loopfilter_filters.c:161-214): macroblock edges, modifies p2 p1 p0 q0 q1 q2
-__device__ __forceinline__ void lf_mbedge(v2u p[8], const Lim &L, v2u gate)
-{
-    v2u mask, hev;
-    masks(p, L.lim, L.mblim, L.thr, L.one, gate, mask, hev);
-    v2s ps2 = sgn(p[1]), ps1 = sgn(p[2]), ps0 = sgn(p[3]), qs0 = sgn(p[4]), qs1 = sgn(p[5]), qs2 = sgn(p[6]);
-    v2s f = as_v2s(as_u32(add3w(subs(ps1, qs1), qs0, ps0)) & as_u32(mask));
-    v2s f2 = as_v2s(as_u32(f) & as_u32(hev));
-    const v2s f1 = hib(adds(f2, mks(0x0400)) >> 3);
-    f2 = hib(adds(f2, mks(0x0300)) >> 3);
-    qs0 = subs(qs0, f1); ps0 = adds(ps0, f2);
-    const v2s F = as_v2s(as_u32(f) & ~as_u32(hev)) >> 8;             // plain signed value, -128 .. 127
-    // ((F * 27 + 63) >> 7) << 8 == (F * 54 + 126) with the low byte cleared (|F * 54 + 126| < 2^15): one multiply-add
-    // and one AND instead of multiply-add, shift, shift
-    v2s u = hib(F * 54 + 126);
-    qs0 = subs(qs0, u); ps0 = adds(ps0, u);
-    u = hib(F * 36 + 126);
-    qs1 = subs(qs1, u); ps1 = adds(ps1, u);
-    u = hib(F * 18 + 126);
-    qs2 = subs(qs2, u); ps2 = adds(ps2, u);
-    p[1] = pix(ps2); p[2] = pix(ps1); p[3] = pix(ps0); p[4] = pix(qs0); p[5] = pix(qs1); p[6] = pix(qs2);
-}
-
-// vp8_loop_filter_simple_horizontal/vertical_edge_c (loopfilter_filters.c:292-355): modifies p0 q0
-__device__ __forceinline__ void lf_simple(v2u p[8], v2u elim, v2u one, v2u gate)
-{
-    const v2u a = adu(p[3], p[4]);
-    const v2u e = uadds(uadds(a, a), (adu(p[2], p[5]) >> 1) & mku(0xff00));
-    const v2u mask = nz_clear(usubs(e, elim), one) & gate;
-    v2s ps1 = sgn(p[2]), ps0 = sgn(p[3]), qs0 = sgn(p[4]), qs1 = sgn(p[5]);
-    const v2s f = as_v2s(as_u32(add3w(subs(ps1, qs1), qs0, ps0)) & as_u32(mask));
-    const v2s f1 = hib(adds(f, mks(0x0400)) >> 3), f2 = hib(adds(f, mks(0x0300)) >> 3);
-    p[4] = pix(subs(qs0, f1)); p[3] = pix(adds(ps0, f2));
-}
-
-// which filters the lanes of the wave need (wave-uniform) and each lane's gates
-struct Gates { v2u mb, inner, mb_s, inner_s; bool any_normal, any_simple; };
-
-// All edges of two pixel lines: a[0..4*W4+3] = positions -4 .. 4*W4-1 across the macroblock.  Order and
-// gating as vp8_loop_filter_frame (loopfilter.c:265-299): the MB edge at 0 (if there is a neighbour),
-// then the inner edges at 4, 8, 12 (if !skip_lf).
-template <int W4>
-__device__ __forceinline__ void filter_lines(v2u *a, const Gates &G, const Lim &L)
-{
-    if (G.any_normal) {
-        lf_mbedge(a, L, G.mb);
-#pragma unroll
-        for (int e = 1; e < W4; e++) lf_inner(a + 4 * e, L, G.inner);
-    }
-    if (G.any_simple) {
-        lf_simple(a, L.mblim, L.one, G.mb_s);
-#pragma unroll
-        for (int e = 1; e < W4; e++) lf_simple(a + 4 * e, L.blim, L.one, G.inner_s);
-    }
-}
-// the same for two independent sets of lines at once (more instruction-level parallelism)
-template <int W4>
-__device__ __forceinline__ void filter_lines2(v2u *a, v2u *b, const Gates &G, const Lim &L)
-{
-    if (G.any_normal) {
-        lf_mbedge(a, L, G.mb); lf_mbedge(b, L, G.mb);
-#pragma unroll
-        for (int e = 1; e < W4; e++) { lf_inner(a + 4 * e, L, G.inner); lf_inner(b + 4 * e, L, G.inner); }
-    }
-    if (G.any_simple) {
-        lf_simple(a, L.mblim, L.one, G.mb_s); lf_simple(b, L.mblim, L.one, G.mb_s);
-#pragma unroll
-        for (int e = 1; e < W4; e++) { lf_simple(a + 4 * e, L.blim, L.one, G.inner_s); lf_simple(b + 4 * e, L.blim, L.one, G.inner_s); }
-    }
-}
-
-template <int NX>
-__device__ __forceinline__ void unpack_rows(const u32 *ra, const u32 *rb, v2u *a)
-{
-#pragma unroll
-    for (int x = 0; x < NX; x++) {
-        const u32 A = ra[x * 64], B = rb[x * 64];
-        a[4 * x + 0] = as_v2u(perm(B, A, 0x040c000cu)); a[4 * x + 1] = as_v2u(perm(B, A, 0x050c010cu));
-        a[4 * x + 2] = as_v2u(perm(B, A, 0x060c020cu)); a[4 * x + 3] = as_v2u(perm(B, A, 0x070c030cu));
-    }
-}
-template <int NX>
-__device__ __forceinline__ void pack_rows(u32 *ra, u32 *rb, const v2u *a)
-{
-#pragma unroll
-    for (int x = 0; x < NX; x++) {
-        const u32 p01 = as_u32(a[4 * x]), p11 = as_u32(a[4 * x + 1]), p21 = as_u32(a[4 * x + 2]), p31 = as_u32(a[4 * x + 3]);
-        const u32 t01 = perm(p11, p01, 0x07030501u), t23 = perm(p31, p21, 0x07030501u);     // A0 A1 B0 B1 | A2 A3 B2 B3
-        ra[x * 64] = perm(t23, t01, 0x05040100u);
-        rb[x * 64] = perm(t23, t01, 0x07060302u);
-    }
-}
-
-// One plane of one macroblock in the lane's LDS tile T[row * NX + xd][lane], NX = W4 + 1 dwords per row:
-// row = y + 4 (y = -4 .. H-1), xd = 0 the four pixels left of the macroblock, xd = 1 .. W4 its own.
-// gv / gh: gates of the vertical-edge and of the horizontal-edge pass.
-template <int W4, int H>
-__device__ __forceinline__ void filter_plane(u32 *T, const Gates &gv, const Gates &gh, const Lim &L)
-{
-    constexpr int NX = W4 + 1;
-    // ---- vertical edges: rows (y, y+1) packed, all positions x = -4 .. 4*W4-1 in registers; two row pairs a time
-#pragma unroll 1
-    for (int rp = 0; rp < H / 4; rp++) {
-        u32 *r0 = T + (4 + 4 * rp) * NX * 64, *r1 = r0 + NX * 64, *r2 = r1 + NX * 64, *r3 = r2 + NX * 64;
-        v2u a[4 * NX], b[4 * NX];
-        unpack_rows<NX>(r0, r1, a);
-        unpack_rows<NX>(r2, r3, b);
-        filter_lines2<W4>(a, b, gv, L);
-        pack_rows<NX>(r0, r1, a);
-        pack_rows<NX>(r2, r3, b);
-    }
-    // ---- horizontal edges: columns (x, x+1) packed, rows y = -4 .. H-1 of the two column pairs in registers
-#pragma unroll 1
-    for (int xd = 1; xd <= W4; xd++) {
-        u32 *col = T + xd * 64;
-        v2u lo[H + 4], hi[H + 4];
-#pragma unroll
-        for (int y = 0; y < H + 4; y++) {
-            const u32 D = col[y * NX * 64];
-            lo[y] = as_v2u(perm(D, D, 0x010c000cu));
-            hi[y] = as_v2u(perm(D, D, 0x030c020cu));
-        }
-        filter_lines2<H / 4>(lo, hi, gh, L);
-#pragma unroll
-        for (int y = 1; y < H + 4; y++) col[y * NX * 64] = perm(as_u32(hi[y]), as_u32(lo[y]), 0x07050301u);
-    }
-}
-
-// vp8_loop_filter_frame_init (loopfilter.c:117-201) for one macroblock
-__device__ __forceinline__ int mb_level(const vp8ir_frame_hdr &h, int seg, int ref, int y_mode)
-{
-    int base = h.filter_level;
-    if (h.segmentation_enabled) {
-        if (h.mb_segment_abs_delta) base = h.segment_lf[seg];
-        else { base += h.segment_lf[seg]; base = base < 0 ? 0 : (base > 63 ? 63 : base); }
-    }
-    if (!h.mode_ref_lf_delta_enabled) return base & 0xff;
-    int v = base + h.ref_lf_deltas[ref];
-    if (ref == VP8IR_INTRA_FRAME) {
-        if (y_mode == VP8IR_B_PRED) v += h.mode_lf_deltas[0];
-    } else {
-        // mode_lf_lut (loopfilter.c:52-63): NEAREST, NEAR, NEW -> 2, ZERO -> 1, SPLIT -> 3
-        const int m = y_mode == VP8IR_ZEROMV ? 1 : (y_mode == VP8IR_SPLITMV ? 3 : 2);
-        v += h.mode_lf_deltas[m];
-    }
-    return v < 0 ? 0 : (v > 63 ? 63 : v);
-}
-
-// vp8_loop_filter_update_sharpness + hev threshold LUT (loopfilter.c:24-96)
-__device__ __forceinline__ Lim mb_limits(int sharp, int level, int frame_type, v2u one)
-{
-    int ilimit = level >> (sharp > 0);
-    ilimit >>= (sharp > 4);
-    if (sharp > 0 && ilimit > 9 - sharp) ilimit = 9 - sharp;
-    if (ilimit < 1) ilimit = 1;
-    int thr;
-    if (level >= 40) thr = frame_type == 0 ? 2 : 3;
-    else if (level >= 20) thr = frame_type == 0 ? 1 : 2;
-    else if (level >= 15) thr = 1;
-    else thr = 0;
-    Lim L;
-    L.lim = mku(ilimit << 8); L.blim = mku(((2 * level + ilimit) & 0xff) << 8); L.mblim = mku(((2 * (level + 2) + ilimit) & 0xff) << 8);
-    L.thr = mku(thr << 8);
-    L.one = one;
-    return L;
-}
-
-} // namespace
+#include "vp8_simt_prims.hip.h"
 
 // grid = waves (one wave per block); lgG, P, nstrands as in vp8_recon_simt_kernel.  Works in place on the
 // jobs' macroblock-tiled scratch frames (DevJob::tile, see VP8_TILE_BYTES): a macroblock is three 128-byte

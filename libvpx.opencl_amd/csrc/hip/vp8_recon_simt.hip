@@ -39,212 +39,7 @@
 #include "vp8_common.hip.h"
 #include <stddef.h>
 
-namespace {
-
-typedef unsigned int u32;
-typedef u32 u32x4 __attribute__((ext_vector_type(4)));
-typedef u32 u32x2 __attribute__((ext_vector_type(2)));
-typedef GLOBAL_AS const u32x4 *g_cu32x4p;
-typedef GLOBAL_AS const u32x2 *g_cu32x2p;
-typedef GLOBAL_AS u32x4 *g_u32x4p;
-typedef GLOBAL_AS u32x2 *g_u32x2p;
-
-typedef __attribute__((address_space(3))) void *lds_vp;
-typedef GLOBAL_AS const void *g_cvp;
-typedef short v2s __attribute__((ext_vector_type(2)));      // two 16-bit lanes: v_pk_* arithmetic
-__device__ __forceinline__ v2s as_v2s(u32 v) { return __builtin_bit_cast(v2s, v); }
-__device__ __forceinline__ u32 as_u32(v2s v) { return __builtin_bit_cast(u32, v); }
-__device__ __forceinline__ v2s pk(int lo, int hi) { return (v2s){ (short)lo, (short)hi }; }
-__device__ __forceinline__ u32 perm(u32 hi, u32 lo, u32 sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
-__device__ __forceinline__ u32 alignb(u32 hi, u32 lo, u32 sh) { return __builtin_amdgcn_alignbyte(hi, lo, sh); }
-__device__ __forceinline__ u32 lerp(u32 a, u32 b, u32 c) { return __builtin_amdgcn_lerp(a, b, c); }
-__device__ __forceinline__ int sad4(u32 v) { return (int)__builtin_amdgcn_sad_u8(v, 0u, 0u); }
-__device__ __forceinline__ u32 splat(int v) { return (u32)v * 0x01010101u; }
-// value held by the lane above (lane l-1); lane 0 keeps its own
-__device__ __forceinline__ u32 from_lane_above(u32 v)
-{
-    return (u32)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
-}
-// load that must observe another lane's earlier store to the frame: served by L2, never by the CU's L1
-__device__ __forceinline__ u32 load_l2(const unsigned char *p)
-{
-    return __hip_atomic_load((const u32 *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// two signed 16-bit values -> two bytes clamped to 0..255, in bits 15:0 (bits 31:16 zero): the saturation of this
-// instruction IS the clamp of vp8_dequant_idct_add_c / vp8_dc_only_idct_add_c / the TM predictor
-__device__ __forceinline__ u32 sat_pk_u8(v2s v)
-{
-    u32 d;
-    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(d) : "v"(as_u32(v)));
-    return d;
-}
-// four pixels = clamp(a + b) for two pairs of 16-bit lanes: (x0, x1) and (x2, x3)
-__device__ __forceinline__ u32 clamp_pack4(v2s s01, v2s s23)
-{
-    return perm(sat_pk_u8(s23), sat_pk_u8(s01), 0x05040100u);
-}
-
-// clamp(pred + residual) for a row of four pixels (the tail of vp8_short_idct4x4llm / vp8_dc_only_idct_add): predictor
-// bytes widened to 16-bit lanes, residuals as vp8_residual_kernel left them: (r0, r1), (r2, r3)
-__device__ __forceinline__ u32 add_clamp_pack(u32 pred, u32 r01, u32 r23)
-{
-    return clamp_pack4(as_v2s(perm(pred, pred, 0x0c010c00u)) + as_v2s(r01), as_v2s(perm(pred, pred, 0x0c030c02u)) + as_v2s(r23));
-}
-
-// TM prediction of a row of four pixels: clamp(above[i] + left - top_left), above given as two packed pairs
-__device__ __forceinline__ u32 tm_row(v2s a01, v2s a23, int l_minus_tl)
-{
-    const v2s d = pk(l_minus_tl, l_minus_tl);
-    return clamp_pack4(a01 + d, a23 + d);
-}
-
-// right-hand pixel column of a 4x4 block given as four row dwords -> one dword, top pixel in byte 0
-__device__ __forceinline__ u32 right_column(const u32 o[4])
-{
-    return perm(perm(o[3], o[2], 0x0c0c0703u), perm(o[1], o[0], 0x0c0c0703u), 0x05040100u);
-}
-
-// Whole-block predictors DC / V / H / TM (reconintra.c:139-241, 403-521) for one 4x4 block:
-// above = the 4 pixels above the block's columns, left = the 4 pixels left of its rows (top in byte 0).
-__device__ __forceinline__ void mb_mode_pred(int mode, u32 above, u32 left, int tl, int dc, u32 p[4])
-{
-    if (mode == VP8IR_DC_PRED) { p[0] = p[1] = p[2] = p[3] = splat(dc); }
-    else if (mode == VP8IR_V_PRED) { p[0] = p[1] = p[2] = p[3] = above; }
-    else if (mode == VP8IR_H_PRED) {
-        p[0] = perm(left, left, 0x00000000u); p[1] = perm(left, left, 0x01010101u);
-        p[2] = perm(left, left, 0x02020202u); p[3] = perm(left, left, 0x03030303u);
-    } else {
-        const v2s a01 = as_v2s(perm(above, above, 0x0c010c00u)), a23 = as_v2s(perm(above, above, 0x0c030c02u));
-#pragma unroll
-        for (int j = 0; j < 4; j++) p[j] = tm_row(a01, a23, (int)((left >> (8 * j)) & 0xff) - tl);
-    }
-}
-
-// vp8_intra4x4_predict (reconintra4x4.c:16-303) for one block.  a0 = above 4 pixels, a1 = the next 4
-// (above-right), left = left 4 pixels (top in byte 0), tl = top-left.  Edge vector as in the oracle:
-// P[0..14] = { L3, L3, L2, L1, L0, TL, A0..A7, A7 }; F[k] = (P[k-1]+2P[k]+P[k+1]+2)>>2,
-// G[k] = (P[k]+P[k+1]+1)>>1, both computed four pixels per instruction with v_lerp_u8:
-// (a+2b+c+2)>>2 == (((a+c)>>1) + b + 1)>>1 exactly.
-__device__ __forceinline__ void bpred4x4(int mode, u32 a0, u32 a1, u32 left, int tl, u32 p[4])
-{
-    if (mode == VP8IR_B_DC_PRED) {
-        p[0] = p[1] = p[2] = p[3] = splat((sad4(a0) + sad4(left) + 4) >> 3);
-        return;
-    }
-    if (mode == VP8IR_B_TM_PRED) {
-        const v2s a01 = as_v2s(perm(a0, a0, 0x0c010c00u)), a23 = as_v2s(perm(a0, a0, 0x0c030c02u));
-#pragma unroll
-        for (int j = 0; j < 4; j++) p[j] = tm_row(a01, a23, (int)((left >> (8 * j)) & 0xff) - tl);
-        return;
-    }
-    const u32 E0 = perm(left, left, 0x01020303u);                       // L3 L3 L2 L1
-    const u32 E1 = perm(a0, left, 0x05040c00u) | ((u32)tl << 8);        // L0 TL A0 A1
-    const u32 E2 = alignb(a1, a0, 2);                                   // A2 A3 A4 A5
-    const u32 E3 = perm(a1, a1, 0x03030302u);                           // A6 A7 A7 A7
-    // neighbours: M_w[j] = P[4w+j-1], N_w[j] = P[4w+j+1]
-    const u32 N0 = alignb(E1, E0, 1), N1 = alignb(E2, E1, 1), N2 = alignb(E3, E2, 1), N3 = E3 >> 8;
-    const u32 M0 = E0 << 8, M1 = alignb(E1, E0, 3), M2 = alignb(E2, E1, 3), M3 = alignb(E3, E2, 3);
-    const u32 one = 0x01010101u;
-    const u32 F0 = lerp(lerp(M0, N0, 0), E0, one), F1 = lerp(lerp(M1, N1, 0), E1, one);
-    const u32 F2 = lerp(lerp(M2, N2, 0), E2, one), F3 = lerp(lerp(M3, N3, 0), E3, one);
-    const u32 G0 = lerp(E0, N0, one), G1 = lerp(E1, N1, one), G2 = lerp(E2, N2, one);
-    switch (mode) {
-    case VP8IR_B_VE_PRED: p[0] = p[1] = p[2] = p[3] = alignb(F2, F1, 2); break;          // F6..F9
-    case VP8IR_B_HE_PRED:                                                                  // F4, F3, F2, F1
-        p[0] = perm(F1, F0, 0x04040404u); p[1] = perm(F1, F0, 0x03030303u);
-        p[2] = perm(F1, F0, 0x02020202u); p[3] = perm(F1, F0, 0x01010101u);
-        break;
-    case VP8IR_B_LD_PRED:                                                                  // F[7+r ..]
-        p[0] = alignb(F2, F1, 3); p[1] = F2; p[2] = alignb(F3, F2, 1); p[3] = alignb(F3, F2, 2);
-        break;
-    case VP8IR_B_RD_PRED:                                                                  // F[5-r ..]
-        p[0] = alignb(F2, F1, 1); p[1] = F1; p[2] = alignb(F1, F0, 3); p[3] = alignb(F1, F0, 2);
-        break;
-    case VP8IR_B_VR_PRED:
-        p[0] = alignb(G2, G1, 1);                 // G5 G6 G7 G8
-        p[1] = alignb(F2, F1, 1);                 // F5 F6 F7 F8
-        p[2] = perm(G1, F1, 0x07060500u);         // F4 G5 G6 G7
-        p[3] = perm(F1, F0, 0x07060503u);         // F3 F5 F6 F7
-        break;
-    case VP8IR_B_VL_PRED:
-        p[0] = alignb(G2, G1, 2);                 // G6 G7 G8 G9
-        p[1] = alignb(F2, F1, 3);                 // F7 F8 F9 F10
-        p[2] = perm(F2, alignb(G2, G1, 3), 0x07020100u);   // G7 G8 G9 F11
-        p[3] = perm(F3, F2, 0x04020100u);         // F8 F9 F10 F12
-        break;
-    case VP8IR_B_HD_PRED:
-        p[0] = perm(F1, G1, 0x07060500u);                             // G4 F5 F6 F7
-        p[1] = perm(perm(F1, G1, 0x0500040cu), G0, 0x07060503u);      // G3 F4 G4 F5
-        p[2] = perm(F1, perm(F0, G0, 0x0c030702u), 0x04020100u);      // G2 F3 G3 F4
-        p[3] = perm(F0, G0, 0x07020601u);                             // G1 F2 G2 F3
-        break;
-    default: /* VP8IR_B_HU_PRED */
-        p[0] = perm(F0, G0, 0x06020703u);                             // G3 F3 G2 F2
-        p[1] = perm(F0, G0, 0x05010602u);                             // G2 F2 G1 F1
-        p[2] = perm(E0, perm(F0, G0, 0x0c0c0501u), 0x05050100u);      // G1 F1 L3 L3
-        p[3] = perm(E0, E0, 0x01010101u);                             // L3 x4
-        break;
-    }
-}
-
-__device__ __forceinline__ int sext16(u32 v) { return (int)(short)(v & 0xffff); }
-__device__ __forceinline__ int hi16(u32 v) { return (int)v >> 16; }
-
-// one 1-D pass of vp8_short_idct4x4llm_c (idctllm.c:39-60 / 65-88) without the final rounding
-__device__ __forceinline__ void idct1d(int i0, int i1, int i2, int i3, int &o0, int &o1, int &o2, int &o3)
-{
-    const int a1 = i0 + i2, b1 = i0 - i2;
-    const int c1 = ((i1 * 35468) >> 16) - (i3 + ((i3 * 20091) >> 16));
-    const int d1 = (i1 + ((i1 * 20091) >> 16)) + ((i3 * 35468) >> 16);
-    o0 = a1 + d1; o3 = a1 - d1; o1 = b1 + c1; o2 = b1 - c1;
-}
-
-// The residual of vp8_dequant_idct_add_c (dequantize.c:29-44) for one block held by one thread.
-// ca, cb: the block's 16 coefficients as stored (IR order: column-major, two per dword); dc_in: the already
-// dequantised DC when the macroblock has a Y2 block (dequant factor 1, decodframe.c:92).  res[row*4+col].
-__device__ __forceinline__ void dequant_idct(const u32x4 ca, const u32x4 cb, int dqdc, int dqac, bool dc_given, int dc_in, int res[16])
-{
-    const u32 q[8] = { ca.x, ca.y, ca.z, ca.w, cb.x, cb.y, cb.z, cb.w };
-    int t[16];                                   // t[row*4+col], i16 like the reference's `short output[16]`
-#pragma unroll
-    for (int col = 0; col < 4; col++) {
-        // DQ = (short)(Q * DQC) (dequantize.c:17-27): the low half of a 16x16 product
-        const v2s p01 = as_v2s(q[2 * col]) * (col == 0 ? pk(dqdc, dqac) : pk(dqac, dqac));
-        const v2s p23 = as_v2s(q[2 * col + 1]) * pk(dqac, dqac);
-        int i0 = p01.x;
-        if (col == 0 && dc_given) i0 = dc_in;
-        const int i1 = p01.y, i2 = p23.x, i3 = p23.y;
-        int o0, o1, o2, o3;
-        idct1d(i0, i1, i2, i3, o0, o1, o2, o3);  // vertical pass: column `col`, rows 0..3
-        t[0 + col] = (short)o0; t[4 + col] = (short)o1; t[8 + col] = (short)o2; t[12 + col] = (short)o3;
-    }
-#pragma unroll
-    for (int row = 0; row < 4; row++) {
-        int o0, o1, o2, o3;
-        idct1d(t[row * 4], t[row * 4 + 1], t[row * 4 + 2], t[row * 4 + 3], o0, o1, o2, o3);
-        res[row * 4 + 0] = (o0 + 4) >> 3; res[row * 4 + 1] = (o1 + 4) >> 3;
-        res[row * 4 + 2] = (o2 + 4) >> 3; res[row * 4 + 3] = (o3 + 4) >> 3;
-    }
-}
-
-// six dequantisation factors of one segment (vp8cx_init_de_quantizer + mb_init_dequantizer, decodframe.c:50-109,
-// quant_common.c:39-132): packed as (y1dc | y1ac<<16, y2dc | y2ac<<16, uvdc | uvac<<16)
-__device__ __forceinline__ void segment_dequant(const vp8ir_frame_hdr &h, int seg, u32 dq[3])
-{
-    int q = h.base_qindex;
-    if (h.segmentation_enabled) q = h.mb_segment_abs_delta ? h.segment_quant[seg] : q + h.segment_quant[seg];
-    q = q < 0 ? 0 : (q > 127 ? 127 : q);
-    auto qi = [&](int delta) { const int v = q + delta; return v < 0 ? 0 : (v > 127 ? 127 : v); };
-    const int y1dc = k_dc_q[qi(h.y1dc_delta_q)], y1ac = k_ac_q[q];
-    const int y2dc = k_dc_q[qi(h.y2dc_delta_q)] * 2;
-    int y2ac = (k_ac_q[qi(h.y2ac_delta_q)] * 155) / 100; if (y2ac < 8) y2ac = 8;
-    int uvdc = k_dc_q[qi(h.uvdc_delta_q)]; if (uvdc > 132) uvdc = 132;
-    const int uvac = k_ac_q[qi(h.uvac_delta_q)];
-    dq[0] = (u32)y1dc | ((u32)y1ac << 16); dq[1] = (u32)y2dc | ((u32)y2ac << 16); dq[2] = (u32)uvdc | ((u32)uvac << 16);
-}
-
-} // namespace
+#include "vp8_simt_prims.hip.h"
 
 
 // grid = waves (one wave per block); lgG = log2(lanes per strand); P = steps per row period, >= max(cols, 2G+2);

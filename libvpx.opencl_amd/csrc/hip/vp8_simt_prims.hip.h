@@ -1,0 +1,469 @@
+// Per-lane building blocks of the lane-per-row kernels (vp8_recon_simt.hip, vp8_loopfilter_simt.hip, vp8_keyframe_simt.hip):
+// the intra predictors and the inverse transform on packed bytes / packed 16-bit lanes, and the loop-filter arithmetic on
+// signed 8.8 pairs.  Everything here is per-lane code -- one lane, one macroblock -- and shared by value: each kernel file
+// gets its own copy in an anonymous namespace.
+#pragma once
+#include "vp8_common.hip.h"
+#include <stddef.h>
+
+namespace {
+
+
+typedef unsigned int u32;
+typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+typedef u32 u32x2 __attribute__((ext_vector_type(2)));
+typedef GLOBAL_AS const u32x4 *g_cu32x4p;
+typedef GLOBAL_AS const u32x2 *g_cu32x2p;
+typedef GLOBAL_AS u32x4 *g_u32x4p;
+typedef GLOBAL_AS u32x2 *g_u32x2p;
+
+typedef __attribute__((address_space(3))) void *lds_vp;
+typedef GLOBAL_AS const void *g_cvp;
+typedef short v2s __attribute__((ext_vector_type(2)));      // two 16-bit lanes: v_pk_* arithmetic
+__device__ __forceinline__ v2s as_v2s(u32 v) { return __builtin_bit_cast(v2s, v); }
+__device__ __forceinline__ u32 as_u32(v2s v) { return __builtin_bit_cast(u32, v); }
+__device__ __forceinline__ v2s pk(int lo, int hi) { return (v2s){ (short)lo, (short)hi }; }
+__device__ __forceinline__ u32 perm(u32 hi, u32 lo, u32 sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
+__device__ __forceinline__ u32 alignb(u32 hi, u32 lo, u32 sh) { return __builtin_amdgcn_alignbyte(hi, lo, sh); }
+__device__ __forceinline__ u32 lerp(u32 a, u32 b, u32 c) { return __builtin_amdgcn_lerp(a, b, c); }
+__device__ __forceinline__ int sad4(u32 v) { return (int)__builtin_amdgcn_sad_u8(v, 0u, 0u); }
+__device__ __forceinline__ u32 splat(int v) { return (u32)v * 0x01010101u; }
+// value held by the lane above (lane l-1); lane 0 keeps its own
+__device__ __forceinline__ u32 from_lane_above(u32 v)
+{
+    return (u32)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+}
+// load that must observe another lane's earlier store to the frame: served by L2, never by the CU's L1
+__device__ __forceinline__ u32 load_l2(const unsigned char *p)
+{
+    return __hip_atomic_load((const u32 *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// two signed 16-bit values -> two bytes clamped to 0..255, in bits 15:0 (bits 31:16 zero): the saturation of this
+// instruction IS the clamp of vp8_dequant_idct_add_c / vp8_dc_only_idct_add_c / the TM predictor
+__device__ __forceinline__ u32 sat_pk_u8(v2s v)
+{
+    u32 d;
+    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(d) : "v"(as_u32(v)));
+    return d;
+}
+// four pixels = clamp(a + b) for two pairs of 16-bit lanes: (x0, x1) and (x2, x3)
+__device__ __forceinline__ u32 clamp_pack4(v2s s01, v2s s23)
+{
+    return perm(sat_pk_u8(s23), sat_pk_u8(s01), 0x05040100u);
+}
+
+// clamp(pred + residual) for a row of four pixels (the tail of vp8_short_idct4x4llm / vp8_dc_only_idct_add): predictor
+// bytes widened to 16-bit lanes, residuals as vp8_residual_kernel left them: (r0, r1), (r2, r3)
+__device__ __forceinline__ u32 add_clamp_pack(u32 pred, u32 r01, u32 r23)
+{
+    return clamp_pack4(as_v2s(perm(pred, pred, 0x0c010c00u)) + as_v2s(r01), as_v2s(perm(pred, pred, 0x0c030c02u)) + as_v2s(r23));
+}
+
+// TM prediction of a row of four pixels: clamp(above[i] + left - top_left), above given as two packed pairs
+__device__ __forceinline__ u32 tm_row(v2s a01, v2s a23, int l_minus_tl)
+{
+    const v2s d = pk(l_minus_tl, l_minus_tl);
+    return clamp_pack4(a01 + d, a23 + d);
+}
+
+// right-hand pixel column of a 4x4 block given as four row dwords -> one dword, top pixel in byte 0
+__device__ __forceinline__ u32 right_column(const u32 o[4])
+{
+    return perm(perm(o[3], o[2], 0x0c0c0703u), perm(o[1], o[0], 0x0c0c0703u), 0x05040100u);
+}
+
+// Whole-block predictors DC / V / H / TM (reconintra.c:139-241, 403-521) for one 4x4 block:
+// above = the 4 pixels above the block's columns, left = the 4 pixels left of its rows (top in byte 0).
+__device__ __forceinline__ void mb_mode_pred(int mode, u32 above, u32 left, int tl, int dc, u32 p[4])
+{
+    if (mode == VP8IR_DC_PRED) { p[0] = p[1] = p[2] = p[3] = splat(dc); }
+    else if (mode == VP8IR_V_PRED) { p[0] = p[1] = p[2] = p[3] = above; }
+    else if (mode == VP8IR_H_PRED) {
+        p[0] = perm(left, left, 0x00000000u); p[1] = perm(left, left, 0x01010101u);
+        p[2] = perm(left, left, 0x02020202u); p[3] = perm(left, left, 0x03030303u);
+    } else {
+        const v2s a01 = as_v2s(perm(above, above, 0x0c010c00u)), a23 = as_v2s(perm(above, above, 0x0c030c02u));
+#pragma unroll
+        for (int j = 0; j < 4; j++) p[j] = tm_row(a01, a23, (int)((left >> (8 * j)) & 0xff) - tl);
+    }
+}
+
+// vp8_intra4x4_predict (reconintra4x4.c:16-303) for one block.  a0 = above 4 pixels, a1 = the next 4
+// (above-right), left = left 4 pixels (top in byte 0), tl = top-left.  Edge vector as in the oracle:
+// P[0..14] = { L3, L3, L2, L1, L0, TL, A0..A7, A7 }; F[k] = (P[k-1]+2P[k]+P[k+1]+2)>>2,
+// G[k] = (P[k]+P[k+1]+1)>>1, both computed four pixels per instruction with v_lerp_u8:
+// (a+2b+c+2)>>2 == (((a+c)>>1) + b + 1)>>1 exactly.
+__device__ __forceinline__ void bpred4x4(int mode, u32 a0, u32 a1, u32 left, int tl, u32 p[4])
+{
+    if (mode == VP8IR_B_DC_PRED) {
+        p[0] = p[1] = p[2] = p[3] = splat((sad4(a0) + sad4(left) + 4) >> 3);
+        return;
+    }
+    if (mode == VP8IR_B_TM_PRED) {
+        const v2s a01 = as_v2s(perm(a0, a0, 0x0c010c00u)), a23 = as_v2s(perm(a0, a0, 0x0c030c02u));
+#pragma unroll
+        for (int j = 0; j < 4; j++) p[j] = tm_row(a01, a23, (int)((left >> (8 * j)) & 0xff) - tl);
+        return;
+    }
+    const u32 E0 = perm(left, left, 0x01020303u);                       // L3 L3 L2 L1
+    const u32 E1 = perm(a0, left, 0x05040c00u) | ((u32)tl << 8);        // L0 TL A0 A1
+    const u32 E2 = alignb(a1, a0, 2);                                   // A2 A3 A4 A5
+    const u32 E3 = perm(a1, a1, 0x03030302u);                           // A6 A7 A7 A7
+    // neighbours: M_w[j] = P[4w+j-1], N_w[j] = P[4w+j+1]
+    const u32 N0 = alignb(E1, E0, 1), N1 = alignb(E2, E1, 1), N2 = alignb(E3, E2, 1), N3 = E3 >> 8;
+    const u32 M0 = E0 << 8, M1 = alignb(E1, E0, 3), M2 = alignb(E2, E1, 3), M3 = alignb(E3, E2, 3);
+    const u32 one = 0x01010101u;
+    const u32 F0 = lerp(lerp(M0, N0, 0), E0, one), F1 = lerp(lerp(M1, N1, 0), E1, one);
+    const u32 F2 = lerp(lerp(M2, N2, 0), E2, one), F3 = lerp(lerp(M3, N3, 0), E3, one);
+    const u32 G0 = lerp(E0, N0, one), G1 = lerp(E1, N1, one), G2 = lerp(E2, N2, one);
+    switch (mode) {
+    case VP8IR_B_VE_PRED: p[0] = p[1] = p[2] = p[3] = alignb(F2, F1, 2); break;          // F6..F9
+    case VP8IR_B_HE_PRED:                                                                  // F4, F3, F2, F1
+        p[0] = perm(F1, F0, 0x04040404u); p[1] = perm(F1, F0, 0x03030303u);
+        p[2] = perm(F1, F0, 0x02020202u); p[3] = perm(F1, F0, 0x01010101u);
+        break;
+    case VP8IR_B_LD_PRED:                                                                  // F[7+r ..]
+        p[0] = alignb(F2, F1, 3); p[1] = F2; p[2] = alignb(F3, F2, 1); p[3] = alignb(F3, F2, 2);
+        break;
+    case VP8IR_B_RD_PRED:                                                                  // F[5-r ..]
+        p[0] = alignb(F2, F1, 1); p[1] = F1; p[2] = alignb(F1, F0, 3); p[3] = alignb(F1, F0, 2);
+        break;
+    case VP8IR_B_VR_PRED:
+        p[0] = alignb(G2, G1, 1);                 // G5 G6 G7 G8
+        p[1] = alignb(F2, F1, 1);                 // F5 F6 F7 F8
+        p[2] = perm(G1, F1, 0x07060500u);         // F4 G5 G6 G7
+        p[3] = perm(F1, F0, 0x07060503u);         // F3 F5 F6 F7
+        break;
+    case VP8IR_B_VL_PRED:
+        p[0] = alignb(G2, G1, 2);                 // G6 G7 G8 G9
+        p[1] = alignb(F2, F1, 3);                 // F7 F8 F9 F10
+        p[2] = perm(F2, alignb(G2, G1, 3), 0x07020100u);   // G7 G8 G9 F11
+        p[3] = perm(F3, F2, 0x04020100u);         // F8 F9 F10 F12
+        break;
+    case VP8IR_B_HD_PRED:
+        p[0] = perm(F1, G1, 0x07060500u);                             // G4 F5 F6 F7
+        p[1] = perm(perm(F1, G1, 0x0500040cu), G0, 0x07060503u);      // G3 F4 G4 F5
+        p[2] = perm(F1, perm(F0, G0, 0x0c030702u), 0x04020100u);      // G2 F3 G3 F4
+        p[3] = perm(F0, G0, 0x07020601u);                             // G1 F2 G2 F3
+        break;
+    default: /* VP8IR_B_HU_PRED */
+        p[0] = perm(F0, G0, 0x06020703u);                             // G3 F3 G2 F2
+        p[1] = perm(F0, G0, 0x05010602u);                             // G2 F2 G1 F1
+        p[2] = perm(E0, perm(F0, G0, 0x0c0c0501u), 0x05050100u);      // G1 F1 L3 L3
+        p[3] = perm(E0, E0, 0x01010101u);                             // L3 x4
+        break;
+    }
+}
+
+__device__ __forceinline__ int sext16(u32 v) { return (int)(short)(v & 0xffff); }
+__device__ __forceinline__ int hi16(u32 v) { return (int)v >> 16; }
+
+// one 1-D pass of vp8_short_idct4x4llm_c (idctllm.c:39-60 / 65-88) without the final rounding
+__device__ __forceinline__ void idct1d(int i0, int i1, int i2, int i3, int &o0, int &o1, int &o2, int &o3)
+{
+    const int a1 = i0 + i2, b1 = i0 - i2;
+    const int c1 = ((i1 * 35468) >> 16) - (i3 + ((i3 * 20091) >> 16));
+    const int d1 = (i1 + ((i1 * 20091) >> 16)) + ((i3 * 35468) >> 16);
+    o0 = a1 + d1; o3 = a1 - d1; o1 = b1 + c1; o2 = b1 - c1;
+}
+
+// The residual of vp8_dequant_idct_add_c (dequantize.c:29-44) for one block held by one thread.
+// ca, cb: the block's 16 coefficients as stored (IR order: column-major, two per dword); dc_in: the already
+// dequantised DC when the macroblock has a Y2 block (dequant factor 1, decodframe.c:92).  res[row*4+col].
+__device__ __forceinline__ void dequant_idct(const u32x4 ca, const u32x4 cb, int dqdc, int dqac, bool dc_given, int dc_in, int res[16])
+{
+    const u32 q[8] = { ca.x, ca.y, ca.z, ca.w, cb.x, cb.y, cb.z, cb.w };
+    int t[16];                                   // t[row*4+col], i16 like the reference's `short output[16]`
+#pragma unroll
+    for (int col = 0; col < 4; col++) {
+        // DQ = (short)(Q * DQC) (dequantize.c:17-27): the low half of a 16x16 product
+        const v2s p01 = as_v2s(q[2 * col]) * (col == 0 ? pk(dqdc, dqac) : pk(dqac, dqac));
+        const v2s p23 = as_v2s(q[2 * col + 1]) * pk(dqac, dqac);
+        int i0 = p01.x;
+        if (col == 0 && dc_given) i0 = dc_in;
+        const int i1 = p01.y, i2 = p23.x, i3 = p23.y;
+        int o0, o1, o2, o3;
+        idct1d(i0, i1, i2, i3, o0, o1, o2, o3);  // vertical pass: column `col`, rows 0..3
+        t[0 + col] = (short)o0; t[4 + col] = (short)o1; t[8 + col] = (short)o2; t[12 + col] = (short)o3;
+    }
+#pragma unroll
+    for (int row = 0; row < 4; row++) {
+        int o0, o1, o2, o3;
+        idct1d(t[row * 4], t[row * 4 + 1], t[row * 4 + 2], t[row * 4 + 3], o0, o1, o2, o3);
+        res[row * 4 + 0] = (o0 + 4) >> 3; res[row * 4 + 1] = (o1 + 4) >> 3;
+        res[row * 4 + 2] = (o2 + 4) >> 3; res[row * 4 + 3] = (o3 + 4) >> 3;
+    }
+}
+
+// six dequantisation factors of one segment (vp8cx_init_de_quantizer + mb_init_dequantizer, decodframe.c:50-109,
+// quant_common.c:39-132): packed as (y1dc | y1ac<<16, y2dc | y2ac<<16, uvdc | uvac<<16)
+__device__ __forceinline__ void segment_dequant(const vp8ir_frame_hdr &h, int seg, u32 dq[3])
+{
+    int q = h.base_qindex;
+    if (h.segmentation_enabled) q = h.mb_segment_abs_delta ? h.segment_quant[seg] : q + h.segment_quant[seg];
+    q = q < 0 ? 0 : (q > 127 ? 127 : q);
+    auto qi = [&](int delta) { const int v = q + delta; return v < 0 ? 0 : (v > 127 ? 127 : v); };
+    const int y1dc = k_dc_q[qi(h.y1dc_delta_q)], y1ac = k_ac_q[q];
+    const int y2dc = k_dc_q[qi(h.y2dc_delta_q)] * 2;
+    int y2ac = (k_ac_q[qi(h.y2ac_delta_q)] * 155) / 100; if (y2ac < 8) y2ac = 8;
+    int uvdc = k_dc_q[qi(h.uvdc_delta_q)]; if (uvdc > 132) uvdc = 132;
+    const int uvac = k_ac_q[qi(h.uvac_delta_q)];
+    dq[0] = (u32)y1dc | ((u32)y1ac << 16); dq[1] = (u32)y2dc | ((u32)y2ac << 16); dq[2] = (u32)uvdc | ((u32)uvac << 16);
+}
+
+
+// ---------------- loop filter ----------------
+
+
+__device__ __forceinline__ unsigned long long load_l2_64(const unsigned char *p)
+{
+    return __hip_atomic_load((const unsigned long long *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// Pixels travel through the filters as SIGNED 8.8 fixed point -- pixel ^ 0x80 (the reference's own bias,
+// loopfilter_filters.c:57-60) in the HIGH half of each 16-bit lane -- from the moment they are staged in the LDS tile
+// until they are read back for output (one XOR per dword of four pixels each way, not two per value and edge):
+//   * the filter arithmetic wants them that way: the 16-bit saturation of `v_pk_add_i16 ... clamp` IS the reference's
+//     vp8_signed_char_clamp (every operand is a multiple of 256), so a saturating add costs one instruction instead
+//     of add + min + max;
+//   * the masks only need |a-b|, which is max-min in any order-preserving representation: signed max / min, and the
+//     difference taken modulo 2^16 is the unsigned 8.8 distance; comparisons by unsigned saturating subtraction.
+typedef unsigned short v2u __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2u as_v2u(u32 v) { return __builtin_bit_cast(v2u, v); }
+__device__ __forceinline__ u32 as_u32(v2u v) { return __builtin_bit_cast(u32, v); }
+__device__ __forceinline__ v2u mku(int v) { return (v2u){ (unsigned short)v, (unsigned short)v }; }
+__device__ __forceinline__ v2s mks(int v) { return (v2s){ (short)v, (short)v }; }
+__device__ __forceinline__ v2u umax(v2u a, v2u b) { return __builtin_elementwise_max(a, b); }
+__device__ __forceinline__ v2u umin(v2u a, v2u b) { return __builtin_elementwise_min(a, b); }
+__device__ __forceinline__ v2u adu(v2u a, v2u b)                                                     // |a - b| of two biased pixels
+{
+    const v2s x = __builtin_bit_cast(v2s, a), y = __builtin_bit_cast(v2s, b);
+    return __builtin_bit_cast(v2u, (v2s)(__builtin_elementwise_max(x, y) - __builtin_elementwise_min(x, y)));
+}
+__device__ __forceinline__ v2u usubs(v2u a, v2u b) { return __builtin_elementwise_sub_sat(a, b); }    // max(a - b, 0)
+__device__ __forceinline__ v2u uadds(v2u a, v2u b) { return __builtin_elementwise_add_sat(a, b); }
+__device__ __forceinline__ v2s adds(v2s a, v2s b) { return __builtin_elementwise_add_sat(a, b); }     // signed-char clamp
+__device__ __forceinline__ v2s subs(v2s a, v2s b) { return __builtin_elementwise_sub_sat(a, b); }
+// x != 0 ? 0 : 0xffff (nz_clear) and x != 0 ? 0xffff : 0 (nz_set) per half, from max(1 - x, 0) by saturating subtraction.
+// `one` is the constant 1 | 1 << 16 made opaque to LLVM (one empty asm at kernel entry, see Lim::one): with a visible
+// constant the expression is canonicalised into a compare-and-select, which gfx950 can only do one half at a time.
+__device__ __forceinline__ v2u nz_clear(v2u x, v2u one) { return mku(0) - usubs(one, x); }
+__device__ __forceinline__ v2u nz_set(v2u x, v2u one) { return usubs(one, x) - one; }
+__device__ __forceinline__ v2s sgn(v2u p) { return as_v2s(as_u32(p)); }                              // (already biased: see above)
+__device__ __forceinline__ v2u pix(v2s s) { return as_v2u(as_u32(s)); }
+#define VP8_LF_BIAS 0x80808080u     // four pixels <-> four biased pixels, on the way into and out of the LDS tile
+__device__ __forceinline__ v2s hib(v2s v) { return as_v2s(as_u32(v) & 0xff00ff00u); }                // floor to a whole byte
+
+struct Lim { v2u mblim, blim, lim, thr, one; };     // the limits, << 8; the opaque constant 1 of nz_clear / nz_set
+
+// The filters are branch-free: `gate` (0xffff / 0 per lane) switches an edge off by clearing its filter mask,
+// which makes every update the identity.  Straight-line code lets the scheduler interleave the independent
+// pixel-line pairs, which is what hides the wait state gfx950 wants between dependent packed-math ops.
+
+// vp8_filter_mask + vp8_hevmask (loopfilter_filters.c:27-49) for p[0..7] = p3 p2 p1 p0 q0 q1 q2 q3:
+// mask = 0xffff where the edge is filtered, hev = 0xffff where the high-edge-variance rule applies
+__device__ __forceinline__ void masks(const v2u p[8], v2u lim, v2u elim, v2u thr, v2u one, v2u gate, v2u &mask, v2u &hev)
+{
+    const v2u d10 = adu(p[2], p[3]), dq = adu(p[5], p[4]);
+    const v2u dh = umax(d10, dq);
+    v2u m = umax(umax(adu(p[0], p[1]), adu(p[1], p[2])), dh);
+    m = umax(m, umax(adu(p[6], p[5]), adu(p[7], p[6])));
+    const v2u a = adu(p[3], p[4]);
+    const v2u e = uadds(uadds(a, a), (adu(p[2], p[5]) >> 1) & mku(0xff00));      // 2|p0-q0| + |p1-q1|/2, saturating
+    const v2u over = usubs(m, lim) | usubs(e, elim);                              // non-zero: leave the edge alone
+    mask = nz_clear(over, one) & gate;
+    hev = nz_set(usubs(dh, thr), one);
+}
+
+// filter_value = clamp(filter_value + 3 * (qs0 - ps0)) (loopfilter_filters.c:66, 176): three saturating adds of
+// the saturated difference give the same result as one clamp of the exact sum (same-signed increments)
+__device__ __forceinline__ v2s add3w(v2s f, v2s qs0, v2s ps0)
+{
+    const v2s w = subs(qs0, ps0);
+    return adds(adds(adds(f, w), w), w);
+}
+
+// vp8_loop_filter_c (loopfilter_filters.c:51-95): inner edges, modifies p1 p0 q0 q1
+__device__ __forceinline__ void lf_inner(v2u p[8], const Lim &L, v2u gate)
+{
+    v2u mask, hev;
+    masks(p, L.lim, L.blim, L.thr, L.one, gate, mask, hev);
+    v2s ps1 = sgn(p[2]), ps0 = sgn(p[3]), qs0 = sgn(p[4]), qs1 = sgn(p[5]);
+    v2s f = as_v2s(as_u32(subs(ps1, qs1)) & as_u32(hev));
+    f = as_v2s(as_u32(add3w(f, qs0, ps0)) & as_u32(mask));
+    const v2s f1 = hib(adds(f, mks(0x0400)) >> 3), f2 = hib(adds(f, mks(0x0300)) >> 3);
+    qs0 = subs(qs0, f1); ps0 = adds(ps0, f2);
+    f = as_v2s(as_u32((f1 + mks(0x0100)) >> 1) & (~as_u32(hev) & 0xff00ff00u));
+    qs1 = subs(qs1, f); ps1 = adds(ps1, f);
+    p[2] = pix(ps1); p[3] = pix(ps0); p[4] = pix(qs0); p[5] = pix(qs1);
+}
+
+// vp8_mbloop_filter_c (loopfilter_filters.c:161-214): macroblock edges, modifies p2 p1 p0 q0 q1 q2
+__device__ __forceinline__ void lf_mbedge(v2u p[8], const Lim &L, v2u gate)
+{
+    v2u mask, hev;
+    masks(p, L.lim, L.mblim, L.thr, L.one, gate, mask, hev);
+    v2s ps2 = sgn(p[1]), ps1 = sgn(p[2]), ps0 = sgn(p[3]), qs0 = sgn(p[4]), qs1 = sgn(p[5]), qs2 = sgn(p[6]);
+    v2s f = as_v2s(as_u32(add3w(subs(ps1, qs1), qs0, ps0)) & as_u32(mask));
+    v2s f2 = as_v2s(as_u32(f) & as_u32(hev));
+    const v2s f1 = hib(adds(f2, mks(0x0400)) >> 3);
+    f2 = hib(adds(f2, mks(0x0300)) >> 3);
+    qs0 = subs(qs0, f1); ps0 = adds(ps0, f2);
+    const v2s F = as_v2s(as_u32(f) & ~as_u32(hev)) >> 8;             // plain signed value, -128 .. 127
+    // ((F * 27 + 63) >> 7) << 8 == (F * 54 + 126) with the low byte cleared (|F * 54 + 126| < 2^15): one multiply-add
+    // and one AND instead of multiply-add, shift, shift
+    v2s u = hib(F * 54 + 126);
+    qs0 = subs(qs0, u); ps0 = adds(ps0, u);
+    u = hib(F * 36 + 126);
+    qs1 = subs(qs1, u); ps1 = adds(ps1, u);
+    u = hib(F * 18 + 126);
+    qs2 = subs(qs2, u); ps2 = adds(ps2, u);
+    p[1] = pix(ps2); p[2] = pix(ps1); p[3] = pix(ps0); p[4] = pix(qs0); p[5] = pix(qs1); p[6] = pix(qs2);
+}
+
+// vp8_loop_filter_simple_horizontal/vertical_edge_c (loopfilter_filters.c:292-355): modifies p0 q0
+__device__ __forceinline__ void lf_simple(v2u p[8], v2u elim, v2u one, v2u gate)
+{
+    const v2u a = adu(p[3], p[4]);
+    const v2u e = uadds(uadds(a, a), (adu(p[2], p[5]) >> 1) & mku(0xff00));
+    const v2u mask = nz_clear(usubs(e, elim), one) & gate;
+    v2s ps1 = sgn(p[2]), ps0 = sgn(p[3]), qs0 = sgn(p[4]), qs1 = sgn(p[5]);
+    const v2s f = as_v2s(as_u32(add3w(subs(ps1, qs1), qs0, ps0)) & as_u32(mask));
+    const v2s f1 = hib(adds(f, mks(0x0400)) >> 3), f2 = hib(adds(f, mks(0x0300)) >> 3);
+    p[4] = pix(subs(qs0, f1)); p[3] = pix(adds(ps0, f2));
+}
+
+// which filters the lanes of the wave need (wave-uniform) and each lane's gates
+struct Gates { v2u mb, inner, mb_s, inner_s; bool any_normal, any_simple; };
+
+// All edges of two pixel lines: a[0..4*W4+3] = positions -4 .. 4*W4-1 across the macroblock.  Order and
+// gating as vp8_loop_filter_frame (loopfilter.c:265-299): the MB edge at 0 (if there is a neighbour),
+// then the inner edges at 4, 8, 12 (if !skip_lf).
+template <int W4>
+__device__ __forceinline__ void filter_lines(v2u *a, const Gates &G, const Lim &L)
+{
+    if (G.any_normal) {
+        lf_mbedge(a, L, G.mb);
+#pragma unroll
+        for (int e = 1; e < W4; e++) lf_inner(a + 4 * e, L, G.inner);
+    }
+    if (G.any_simple) {
+        lf_simple(a, L.mblim, L.one, G.mb_s);
+#pragma unroll
+        for (int e = 1; e < W4; e++) lf_simple(a + 4 * e, L.blim, L.one, G.inner_s);
+    }
+}
+// the same for two independent sets of lines at once (more instruction-level parallelism)
+template <int W4>
+__device__ __forceinline__ void filter_lines2(v2u *a, v2u *b, const Gates &G, const Lim &L)
+{
+    if (G.any_normal) {
+        lf_mbedge(a, L, G.mb); lf_mbedge(b, L, G.mb);
+#pragma unroll
+        for (int e = 1; e < W4; e++) { lf_inner(a + 4 * e, L, G.inner); lf_inner(b + 4 * e, L, G.inner); }
+    }
+    if (G.any_simple) {
+        lf_simple(a, L.mblim, L.one, G.mb_s); lf_simple(b, L.mblim, L.one, G.mb_s);
+#pragma unroll
+        for (int e = 1; e < W4; e++) { lf_simple(a + 4 * e, L.blim, L.one, G.inner_s); lf_simple(b + 4 * e, L.blim, L.one, G.inner_s); }
+    }
+}
+
+template <int NX>
+__device__ __forceinline__ void unpack_rows(const u32 *ra, const u32 *rb, v2u *a)
+{
+#pragma unroll
+    for (int x = 0; x < NX; x++) {
+        const u32 A = ra[x * 64], B = rb[x * 64];
+        a[4 * x + 0] = as_v2u(perm(B, A, 0x040c000cu)); a[4 * x + 1] = as_v2u(perm(B, A, 0x050c010cu));
+        a[4 * x + 2] = as_v2u(perm(B, A, 0x060c020cu)); a[4 * x + 3] = as_v2u(perm(B, A, 0x070c030cu));
+    }
+}
+template <int NX>
+__device__ __forceinline__ void pack_rows(u32 *ra, u32 *rb, const v2u *a)
+{
+#pragma unroll
+    for (int x = 0; x < NX; x++) {
+        const u32 p01 = as_u32(a[4 * x]), p11 = as_u32(a[4 * x + 1]), p21 = as_u32(a[4 * x + 2]), p31 = as_u32(a[4 * x + 3]);
+        const u32 t01 = perm(p11, p01, 0x07030501u), t23 = perm(p31, p21, 0x07030501u);     // A0 A1 B0 B1 | A2 A3 B2 B3
+        ra[x * 64] = perm(t23, t01, 0x05040100u);
+        rb[x * 64] = perm(t23, t01, 0x07060302u);
+    }
+}
+
+// One plane of one macroblock in the lane's LDS tile T[row * NX + xd][lane], NX = W4 + 1 dwords per row:
+// row = y + 4 (y = -4 .. H-1), xd = 0 the four pixels left of the macroblock, xd = 1 .. W4 its own.
+// gv / gh: gates of the vertical-edge and of the horizontal-edge pass.
+template <int W4, int H>
+__device__ __forceinline__ void filter_plane(u32 *T, const Gates &gv, const Gates &gh, const Lim &L)
+{
+    constexpr int NX = W4 + 1;
+    // ---- vertical edges: rows (y, y+1) packed, all positions x = -4 .. 4*W4-1 in registers; two row pairs a time
+#pragma unroll 1
+    for (int rp = 0; rp < H / 4; rp++) {
+        u32 *r0 = T + (4 + 4 * rp) * NX * 64, *r1 = r0 + NX * 64, *r2 = r1 + NX * 64, *r3 = r2 + NX * 64;
+        v2u a[4 * NX], b[4 * NX];
+        unpack_rows<NX>(r0, r1, a);
+        unpack_rows<NX>(r2, r3, b);
+        filter_lines2<W4>(a, b, gv, L);
+        pack_rows<NX>(r0, r1, a);
+        pack_rows<NX>(r2, r3, b);
+    }
+    // ---- horizontal edges: columns (x, x+1) packed, rows y = -4 .. H-1 of the two column pairs in registers
+#pragma unroll 1
+    for (int xd = 1; xd <= W4; xd++) {
+        u32 *col = T + xd * 64;
+        v2u lo[H + 4], hi[H + 4];
+#pragma unroll
+        for (int y = 0; y < H + 4; y++) {
+            const u32 D = col[y * NX * 64];
+            lo[y] = as_v2u(perm(D, D, 0x010c000cu));
+            hi[y] = as_v2u(perm(D, D, 0x030c020cu));
+        }
+        filter_lines2<H / 4>(lo, hi, gh, L);
+#pragma unroll
+        for (int y = 1; y < H + 4; y++) col[y * NX * 64] = perm(as_u32(hi[y]), as_u32(lo[y]), 0x07050301u);
+    }
+}
+
+// vp8_loop_filter_frame_init (loopfilter.c:117-201) for one macroblock
+__device__ __forceinline__ int mb_level(const vp8ir_frame_hdr &h, int seg, int ref, int y_mode)
+{
+    int base = h.filter_level;
+    if (h.segmentation_enabled) {
+        if (h.mb_segment_abs_delta) base = h.segment_lf[seg];
+        else { base += h.segment_lf[seg]; base = base < 0 ? 0 : (base > 63 ? 63 : base); }
+    }
+    if (!h.mode_ref_lf_delta_enabled) return base & 0xff;
+    int v = base + h.ref_lf_deltas[ref];
+    if (ref == VP8IR_INTRA_FRAME) {
+        if (y_mode == VP8IR_B_PRED) v += h.mode_lf_deltas[0];
+    } else {
+        // mode_lf_lut (loopfilter.c:52-63): NEAREST, NEAR, NEW -> 2, ZERO -> 1, SPLIT -> 3
+        const int m = y_mode == VP8IR_ZEROMV ? 1 : (y_mode == VP8IR_SPLITMV ? 3 : 2);
+        v += h.mode_lf_deltas[m];
+    }
+    return v < 0 ? 0 : (v > 63 ? 63 : v);
+}
+
+// vp8_loop_filter_update_sharpness + hev threshold LUT (loopfilter.c:24-96)
+__device__ __forceinline__ Lim mb_limits(int sharp, int level, int frame_type, v2u one)
+{
+    int ilimit = level >> (sharp > 0);
+    ilimit >>= (sharp > 4);
+    if (sharp > 0 && ilimit > 9 - sharp) ilimit = 9 - sharp;
+    if (ilimit < 1) ilimit = 1;
+    int thr;
+    if (level >= 40) thr = frame_type == 0 ? 2 : 3;
+    else if (level >= 20) thr = frame_type == 0 ? 1 : 2;
+    else if (level >= 15) thr = 1;
+    else thr = 0;
+    Lim L;
+    L.lim = mku(ilimit << 8); L.blim = mku(((2 * level + ilimit) & 0xff) << 8); L.mblim = mku(((2 * (level + 2) + ilimit) & 0xff) << 8);
+    L.thr = mku(thr << 8);
+    L.one = one;
+    return L;
+}
+
+
+} // namespace

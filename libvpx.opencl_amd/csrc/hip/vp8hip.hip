@@ -23,6 +23,7 @@ extern "C" __global__ void vp8_recon_intra_kernel(const DevJob *jobs, int njobs,
 extern "C" __global__ void vp8_recon_intra_xcu_kernel(const DevJob *jobs, int njobs, DevGeom g, unsigned long long *gran, unsigned int epoch,
                                                       int S, int *err, const unsigned int *intra_flags);
 extern "C" __global__ void vp8_inter_mb_kernel(const DevJob *jobs, int njobs, DevGeom g, unsigned int *intra_flags);
+extern "C" __global__ void vp8_keyframe_simt_kernel(const DevJob *jobs, int njobs, DevGeom g, int lgG, int P, int nstrands, uint8_t *dummy);
 extern "C" __global__ void vp8_recon_simt_kernel(const DevJob *jobs, int njobs, DevGeom g, int lgG, int P, int nstrands, uint8_t *dummy);
 extern "C" __global__ void vp8_loopfilter_simt_kernel(const DevJob *jobs, int njobs, DevGeom g, int lgG, int P, int nstrands, int raster);
 extern "C" __global__ void vp8_loopfilter_simt_luma_kernel(const DevJob *jobs, int njobs, DevGeom g, int lgG, int P, int nstrands, int raster);
@@ -93,6 +94,9 @@ struct Knobs {
     // VP8HIP_LF_SPLIT: lane-per-row loop filter 0 = one kernel for all three planes, 2 = luma and chroma kernels side by side,
     // 1 (default) = side by side for launches below 1024 frames, above that whichever a trial of both finds faster
     int lf_split;
+    // VP8HIP_FUSED=0: all-key-frame launches of the lane-per-row family run reconstruction and loop filter as two kernels with the
+    // tiled scratch frames between them (the round-1/2 pipeline) instead of vp8_keyframe_simt_kernel
+    int fused;
     int lf_raster, lgG, simt_waves, wg_per_cu, xcu, xcu_S, xcu_NW, recon_nw, lf_nw, detile_stream, detile_defer;
 };
 static int env_int(const char *name, int dflt) { const char *e = getenv(name); return e && *e ? atoi(e) : dflt; }
@@ -107,6 +111,7 @@ static void read_knobs(Knobs &k)
     k.xcu = env_int("VP8HIP_XCU", 1) != 0;
     k.xcu_S = env_int("VP8HIP_XCU_S", 0);
     k.lf_split = env_int("VP8HIP_LF_SPLIT", 1);
+    k.fused = env_int("VP8HIP_FUSED", 1) != 0;
     k.inter_split = env_int("VP8HIP_INTER_SPLIT", 384);
     k.inter_tiled = env_int("VP8HIP_INTER_TILED", 640);
     k.xcu_NW = env_int("VP8HIP_XCU_NW", 0);
@@ -591,18 +596,22 @@ extern "C" int vp8hip_decode(vp8hip_ctx *c, const vp8hip_job *jobs, int njobs, i
                              && njobs >= K.inter_tiled;
     // the lane-per-row kernels work on macroblock-tiled scratch frames; vp8_detile_kernel converts at the end
     const bool tiled = simt_recon || inter_tiled;
+    // key frames only, both stages wanted: one kernel reconstructs and filters, and writes the raster frame buffers itself
+    const bool fused = simt_recon && (stages & VP8HIP_STAGE_LF) && K.fused;
     // When the loop filter runs at all (some frame of the launch has filter_level != 0), it writes its finished lines
     // straight into the raster frame buffers -- unfiltered frames are carried through with the filter gated off -- (rows of two neighbouring macroblocks back to back: 32-byte pieces) and the tiled -> raster
     // pass is skipped; only the border extension is left.  +6..10 % from 1536 frames per launch up (1080p), a tie at 2048,
     // -4 % at 1024.  VP8HIP_LF_RASTER=0 keeps the tiled -> raster pass.
-    bool lf_raster = false;
-    if (tiled && (stages & VP8HIP_STAGE_LF) && K.lf_raster)
+    bool lf_raster = fused;
+    if (!fused && tiled && (stages & VP8HIP_STAGE_LF) && K.lf_raster)
         for (int i = 0; i < njobs && !lf_raster; i++)     // some frame is filtered: the loop filter kernel runs anyway
             if (jobs[i].ir_slot >= 0 && jobs[i].ir_slot < nsl) lf_raster = c->slots[jobs[i].ir_slot].hdr_copy.filter_level != 0;
     const size_t tile_frame = (size_t)c->nmb * VP8_TILE_BYTES;
     const int par = c->parity;
-    if (!tiled || lf_raster) {
-        if (join_detile(c)) return -1;             // this launch touches the raster frame buffers directly
+    if (!tiled || lf_raster || !all_key) {
+        // this launch touches the raster frame buffers directly: it writes them, or (inter frames) reads reference frames a
+        // tiled -> raster pass of an earlier launch may still be producing
+        if (join_detile(c)) return -1;
     }
     if (tiled) {
         // scratch set and job table `par` were last read by the tiled -> raster pass VP8HIP_NBUF launches ago (three
@@ -742,7 +751,10 @@ extern "C" int vp8hip_decode(vp8hip_ctx *c, const vp8hip_job *jobs, int njobs, i
     if (tiled) { c->stats.workgroups = simt_waves; c->stats.recon_waves = simt_recon ? 1 : c->recon_nw; c->stats.lf_waves = 1; }
     c->stats.detile_pass = tiled && !lf_raster;
     if (stages & VP8HIP_STAGE_RECON) {
-        if (simt_recon) {
+        if (fused) {
+            hipLaunchKernelGGL(vp8_keyframe_simt_kernel, dim3(simt_waves), dim3(64), 0, c->stream, (const DevJob *)c->d_jobs, njobs,
+                               c->dg, lgG, simtP, simt_waves * spw, c->tile_block[par] + tile_frame * njobs + 4096);
+        } else if (simt_recon) {
             hipLaunchKernelGGL(vp8_recon_simt_kernel, dim3(simt_waves), dim3(64), 0, c->stream, (const DevJob *)c->d_jobs, njobs,
                                c->dg, lgG, simtP, simt_waves * spw, c->tile_block[par] + tile_frame * njobs + 4096);
         } else {
@@ -789,7 +801,9 @@ extern "C" int vp8hip_decode(vp8hip_ctx *c, const vp8hip_job *jobs, int njobs, i
         HIPCHK(c, hipEventRecord(c->ev_recon_done, c->stream));
         if (launch_deferred(c, c->ev_recon_done)) return -1;
     }
-    if ((stages & VP8HIP_STAGE_LF) && any_lf) {
+    c->stats.fused = fused;
+    if (fused) c->stats.lf_kernels = 0;
+    if ((stages & VP8HIP_STAGE_LF) && any_lf && !fused) {
         // one kernel, or luma + chroma side by side: K.lf_split 0 / 2 force it; 1 (default) lets launches of 1024 frames and
         // more find out -- early launches go out one way and the other, and as soon as one of each has finished (their events
         // are only queried, never waited for) the faster one stays

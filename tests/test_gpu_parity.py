@@ -20,13 +20,15 @@ def ctx(pkg):
     c.close()
 
 
-@pytest.fixture(params=["wave", "wave1cu", "wave_split", "wave1cu_split", "wave_tiled", "lane", "lane_detile"], autouse=True)
+@pytest.fixture(params=["wave", "wave1cu", "wave_split", "wave1cu_split", "wave_tiled", "lane", "lane_2k", "lane_detile"], autouse=True)
 def kernel_family(request, monkeypatch):
     """Every test runs with all kernel variants: "wave" = one wave per MB row with a frame pair spread over several
     CUs where the launch is small enough (granule hand-over through global memory), "wave1cu" = the same kernels with
-    a frame pair on one CU (hand-over through LDS; what larger launches use), "lane" = one MB row per lane on
-    macroblock-tiled scratch frames (large launches; the loop filter writes the raster frame buffers when every frame of
-    the launch is filtered, else a detile pass does), "lane_detile" = the same with the detile pass always.  "..._split":
+    a frame pair on one CU (hand-over through LDS; what larger launches use), "lane" = one MB row per lane (large launches):
+    launches of key frames with both stages run the fused kernel (vp8_keyframe_simt_kernel: reconstruction + loop filter in one
+    pass, raster output), "lane_2k" = the two-kernel pipeline on macroblock-tiled scratch frames instead (VP8HIP_FUSED=0; the loop
+    filter writes the raster frame buffers when some frame of the launch is filtered, else a detile pass does), "lane_detile" =
+    the same with the detile pass always.  "..._split":
     launches with inter frames always run vp8_inter_mb_kernel (every inter macroblock on its own) before the row-ordered kernel
     does the intra macroblocks -- by default only launches of up to 384 frames do; "wave1cu" never does.  "wave_tiled": every
     launch with inter frames hands over from the wave-per-row recon to the lane-per-row loop filter through the tiled scratch
@@ -38,6 +40,10 @@ def kernel_family(request, monkeypatch):
         monkeypatch.setenv("VP8HIP_LF_RASTER", "0")
     else:
         monkeypatch.delenv("VP8HIP_LF_RASTER", raising=False)
+    if request.param in ("lane_2k", "lane_detile"):
+        monkeypatch.setenv("VP8HIP_FUSED", "0")
+    else:
+        monkeypatch.delenv("VP8HIP_FUSED", raising=False)
     if request.param.startswith("wave1cu"):
         monkeypatch.setenv("VP8HIP_XCU", "0")
     else:

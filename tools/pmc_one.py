@@ -1,5 +1,5 @@
 import os, sys
-sys.path.insert(0, "tests")
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
 from vp8_testlib import load_package, ivf_path
 P = load_package()
 stage = int(sys.argv[1]); n = int(sys.argv[2])
