@@ -98,8 +98,10 @@ __device__ __forceinline__ void lf_block_row(const u32 (&o)[4][W4], u32 (&s)[4],
         CL[x][2] = as_v2u(perm(b1, b0, 0x050c010cu)); CL[x][3] = as_v2u(perm(b1, b0, 0x070c030cu));
         CH[x][2] = as_v2u(perm(b3, b2, 0x050c010cu)); CH[x][3] = as_v2u(perm(b3, b2, 0x070c030cu));
     }
-    // the horizontal edge between the rows above (p3..p0) and this block row (q0..q3)
-    if (gh.any_normal) {
+    // the horizontal edge between the rows above (p3..p0) and this block row (q0..q3).  (Not skipped when no lane of the wave
+    // wants the normal filter -- the gates switch it off lane by lane --: a branch around it costs ~90 registers, the 64 values
+    // in flight doubled at the join.)
+    {
         if (top_mb) {
 #pragma unroll
             for (int x = 0; x < W4; x++) {
@@ -108,6 +110,7 @@ __device__ __forceinline__ void lf_block_row(const u32 (&o)[4][W4], u32 (&s)[4],
                 lf_mbedge(p, L, gh.mb); lf_mbedge(q, L, gh.mb);
 #pragma unroll
                 for (int j = 0; j < 4; j++) { PL[x][j] = p[j]; CL[x][j] = p[4 + j]; PH[x][j] = q[j]; CH[x][j] = q[4 + j]; }
+                __builtin_amdgcn_sched_barrier(0);      // two lines' worth of temporaries at a time, not 2 * W4
             }
         } else {
 #pragma unroll
@@ -117,6 +120,7 @@ __device__ __forceinline__ void lf_block_row(const u32 (&o)[4][W4], u32 (&s)[4],
                 lf_inner(p, L, gh.inner); lf_inner(q, L, gh.inner);
 #pragma unroll
                 for (int j = 0; j < 4; j++) { PL[x][j] = p[j]; CL[x][j] = p[4 + j]; PH[x][j] = q[j]; CH[x][j] = q[4 + j]; }
+                __builtin_amdgcn_sched_barrier(0);      // two lines' worth of temporaries at a time, not 2 * W4
             }
         }
     }
@@ -158,18 +162,37 @@ __device__ __forceinline__ void frame_levels(const vp8ir_frame_hdr &h, u32 &plai
 
 } // namespace
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The two kernels: vp8_keyframe_luma_kernel and vp8_keyframe_chroma_kernel, launched side by side on two streams.  Luma and
+// chroma of an intra frame share nothing but the macroblock descriptors (separate planes of the frame buffer, separate
+// lines of the hand-over tile), and a luma wave and a chroma wave together fit one SIMD -- registers (VGPRs + AGPRs of both
+// <= 512) and LDS (both <= 40 KB) --, so every SIMD has two instruction streams to issue from: what one stalls on (LDS and
+// memory round trips, scalar / branch bubbles; a lone wave of this kind of code keeps the vector ALU busy less than half
+// the time) the other fills.
+//
 // grid = waves (one wave per block); lgG, P, nstrands as in vp8_recon_simt_kernel.  Every job must be a key frame.  The frames
 // go to the jobs' raster frame buffers (DevJob::dst, borders not included: vp8_extend_kernel); DevJob::tile is the hand-over
-// scratch of the strands' last lanes.  `dummy`: 512 bytes of scratch nobody reads (idle lanes store there: every memory
-// instruction of the step loop is unconditional, see vp8_recon_simt.hip on s_waitcnt).
-extern "C" __global__ void __launch_bounds__(64)
-vp8_keyframe_simt_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g, int lgG, int P, int nstrands, uint8_t *dummy)
+// scratch of the strands' last lanes.  `dummy`: 512 bytes of scratch nobody reads (idle lanes store there: the stores of the
+// step loop are unconditional, see vp8_recon_simt.hip on s_waitcnt).
+//
+// The residual transform is the cooperative one of vp8_recon_simt.hip on a diet, so that two waves' worth fits: a PHASE is
+// the four blocks the owner consumes next (luma: a block row; chroma: a plane); the lanes queue their blocks with
+// coefficients (at most 4 x 64 = 256: four rounds), the coefficients come by LDS-DMA into ONE 8 KB staging buffer, all lanes
+// transform one block each per round IN PLACE, and the owners fetch their residuals into registers before the next phase's
+// coefficients are requested into the same buffer (they are then on their way during the owner's prediction + filtering of
+// the current phase).  The macroblock descriptors of the next step come by LDS-DMA too (a 16-byte slot per lane and piece),
+// not through registers held for a step.
+template <bool LUMA>
+__device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njobs, DevGeom g, int lgG, int P, int nstrands, uint8_t *dummy)
 {
-    __shared__ __attribute__((aligned(16))) u32 s_res[64 * 68];
-    __shared__ __attribute__((aligned(16))) u32 s_stage[8 * 2 * 64 * 4];
-    __shared__ u32 s_queue[512];
-    __shared__ __attribute__((aligned(16))) u32x4 s_tab[64];
-    __shared__ __attribute__((aligned(16))) u32 s_y2dc[64 * 8];
+    constexpr int NDESC = LUMA ? 5 : 2;           // descriptor pieces per macroblock: words 0-3, 4-7 (+ sub-block modes, Y2 block)
+    constexpr int NPH = LUMA ? 4 : 2;             // phases per macroblock
+    __shared__ __attribute__((aligned(16))) u32 s_stage[4 * 2 * 64 * 4];   // [round][half][lane] 16 B: coefficients in, residuals out
+    __shared__ u32 s_queue[256];                                            // owner lane | block in phase << 6 | DC given << 8
+    __shared__ __attribute__((aligned(16))) u32x4 s_tab[64];                // per owner: coefficient pointer (lo, hi), quantiser
+    __shared__ __attribute__((aligned(16))) u32 s_y2dc[LUMA ? 64 * 8 : 4];  // per owner: the sixteen luma DCs out of the Y2 block
+    __shared__ __attribute__((aligned(16))) u32 s_desc[NDESC * 64 * 4];     // [piece][lane] 16 B: the next macroblock's descriptor
     const int lane = threadIdx.x;
     const int G = 1 << lgG;
     const int pos = lane & (G - 1);
@@ -181,351 +204,230 @@ vp8_keyframe_simt_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g, 
     const int Vmax = myjobs * rows;
     const int wavejobs = (njobs - (int)blockIdx.x * spw + nstrands - 1) / nstrands;
     const int T = ((wavejobs * rows + G - 1) >> lgG) * P + 2 * (G - 1);
-    u32 *const my_res = s_res + lane * 68;
-    const u32 stage_lane = (u32)(unsigned long)(lds_vp)s_stage + lane * 16;
-    const int ysY = g.y_stride, ysC = g.uv_stride;
+    const u32 stage_lane = (u32)(unsigned long)(lds_vp)s_stage + lane * 16;     // LDS byte address of this lane's slot of round 0, half 0
+    const u32 stage_base = (u32)(unsigned long)(lds_vp)s_stage;
+    const u32 desc_lane = (u32)(unsigned long)(lds_vp)s_desc + lane * 16;
+    const int ys = LUMA ? g.y_stride : g.uv_stride;
     v2u one = mku(1);
     asm volatile("" : "+v"(one));            // see nz_clear
 
     // ---- per-lane row state; the pointers are valid addresses at all times
-    g_cu32p mbp = (g_cu32p)jobs[0].mbs;
-    g_cs16p cfp = (g_cs16p)jobs[0].coef;
-    g_u8p tp = (g_u8p)dummy;                    // hand-over tile of the current macroblock
-    g_cu8p abp = (g_cu8p)dummy;                 // ... of the macroblock above it
-    g_u8p rasY = (g_u8p)dummy, rasU = (g_u8p)dummy, rasV = (g_u8p)dummy;     // pixel (0, 0) of macroblock row r in the frame buffer
+    g_cu32p mbp = (g_cu32p)jobs[0].mbs;         // descriptor of the current macroblock
+    g_cs16p cfp = (g_cs16p)jobs[0].coef;        // its coefficients
+    g_u8p tp = (g_u8p)dummy;                    // its hand-over tile
+    g_u8p ras = (g_u8p)dummy, ras2 = (g_u8p)dummy;     // pixel (0, 0) of macroblock row r in the frame buffer: Y, or U and V
     int r = 0;
-    u32 dqs[4][3];
+    u32 dqs[4][2];                              // luma: y1, y2 quantisers per segment (dc | ac << 16); chroma: uv in [s][0]
 #pragma unroll
-    for (int s = 0; s < 4; s++) dqs[s][0] = dqs[s][1] = dqs[s][2] = 0;
-    u32 lv_plain = 0, lv_bpred = 0;             // loop-filter levels of the frame, per segment
+    for (int s = 0; s < 4; s++) dqs[s][0] = dqs[s][1] = 0;
+    u32 lv_plain = 0, lv_bpred = 0;
     int sharp = 0; bool simple = false;
     s_tab[lane] = (u32x4){ (u32)(unsigned long)cfp, (u32)((unsigned long)cfp >> 32), 0u, 0u };
-    // ---- prediction context (unfiltered): left columns, last pixels of the previous step's above lines, bottom lines of the
-    // macroblocks finished one and two steps ago
-    u32 lY[4] = { 0, 0, 0, 0 }, lU[2] = { 0, 0 }, lV[2] = { 0, 0 };
-    int prevLastY = 0, prevLastU = 0, prevLastV = 0;
-    u32 h1Y[4] = { 0, 0, 0, 0 }, h1U[2] = { 0, 0 }, h1V[2] = { 0, 0 };
-    u32 h2Y[4] = { 0, 0, 0, 0 }, h2U[2] = { 0, 0 }, h2V[2] = { 0, 0 };
-    // ---- loop-filter context (filtered, biased): the last four pixels of every row of the macroblock to the left; the first
-    // twelve (chroma: four) of its bottom four rows; and what the lane below asks for: the bottom four rows of the
-    // macroblock finished two steps ago
-    u32 sY[16], pbY[4][3], hY[4][4], sU[8], sV[8], pbU[4], pbV[4], hU[4][2], hV[4][2];
+    // ---- prediction context (unfiltered).  Luma: l0[0..3] left column, h1/h2[0..3] bottom lines of the macroblocks finished one
+    // and two steps ago.  Chroma: U in [0..1], V in [2..3].
+    u32 l0[4] = { 0, 0, 0, 0 }, h1[4] = { 0, 0, 0, 0 }, h2[4] = { 0, 0, 0, 0 };
+    int prevLast = 0, prevLast2 = 0;            // last pixel of the previous step's line above: Y, or U and V
+    // ---- loop-filter context (filtered, biased).  Luma: sF[16] the last four pixels of every row of the macroblock to the left,
+    // pb[j][0..2] the first twelve of its bottom four rows, hF[j][0..3] the bottom four rows of the macroblock finished two steps
+    // ago (what the lane below asks for).  Chroma: U in sF[0..7], pb[j][0], hF[j][0..1]; V in sF[8..15], pb[j][1], hF[j][2..3].
+    u32 sF[16], pb[4][3], hF[4][4];
 #pragma unroll
-    for (int i = 0; i < 16; i++) sY[i] = 0;
+    for (int i = 0; i < 16; i++) sF[i] = 0;
 #pragma unroll
-    for (int i = 0; i < 8; i++) sU[i] = sV[i] = 0;
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        pbY[j][0] = pbY[j][1] = pbY[j][2] = 0; hY[j][0] = hY[j][1] = hY[j][2] = hY[j][3] = 0;
-        pbU[j] = pbV[j] = 0; hU[j][0] = hU[j][1] = hV[j][0] = hV[j][1] = 0;
-    }
-    // one step ahead, in plain registers (see vp8_recon_simt.hip)
-    u32x4 nx_m0 = { 0, 0, 0, 0 }, nx_m1 = { 0, 0, 0, 0 }, nx_bm = { 0, 0, 0, 0 }, nx_y2a = { 0, 0, 0, 0 }, nx_y2b = { 0, 0, 0, 0 };
-    u32 nx_aY[4] = { 0, 0, 0, 0 }, nx_ar = 0, nx_aU[2] = { 0, 0 }, nx_aV[2] = { 0, 0 };
-    // the chroma half of the previous step's macroblock, finished at the top of the next iteration
-    bool p_act = false, p_more = false, p_top = false, p_first = false, p_last = false, p_wb = false, p_hand = false, p_rb = false;
-    g_u8p p_tp = (g_u8p)dummy, p_rasU = (g_u8p)dummy, p_rasV = (g_u8p)dummy;
-    int p_uv_mode = 0, p_tlU = 0, p_tlV = 0, p_up = 0, p_lf = 0, p_c = 0;
-    u32 p_aU[2] = { 0, 0 }, p_aV[2] = { 0, 0 }, p_jmc = 0, p_bY[4] = { 0, 0, 0, 0 };
-    int p_lastU = 0, p_lastV = 0;
-    Lim p_L = { mku(0), mku(0), mku(0), mku(0), one };
-    Gates p_gvC = { mku(0), mku(0), mku(0), mku(0), false, false }, p_ghC = p_gvC;
+    for (int j = 0; j < 4; j++) { pb[j][0] = pb[j][1] = pb[j][2] = 0; hF[j][0] = hF[j][1] = hF[j][2] = hF[j][3] = 0; }
+    // ---- the macroblock after the current one, prepared at the end of the step before: descriptor words 0, 1, sub-block modes;
+    // which of its blocks have a residual, whether the luma DCs come out of the Y2 block; where its first phase's residuals are
+    u32 nx_w0 = 0, nx_w1 = 0, nx_jm = 0, nx_dcg = 0, nx_at4 = 0;
+    u32x4 nx_bm = { 0, 0, 0, 0 };
+    bool p_more = false;
 
-    int q_n = 0;
-    auto queue_phase = [&](const int ph, const u32 m8, const u32 dc_given) {
+    int q_n = 0;                                                     // blocks queued (wave-uniform)
+    // queue the blocks blk0 .. blk0+3 of every lane's macroblock that have coefficients (`m4`), behind the n0 already queued, and
+    // request their coefficients; returns where the lane's four blocks are (a byte each)
+    auto queue = [&](const int blk0, const u32 m4, const u32 dcg, const int n0) -> u32 {
         wave_lds_sync();
-        int n = 0;
+        int n = n0;
+        u32 at4 = 0;
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
-            const bool b = (m8 >> i) & 1;
+        for (int i = 0; i < 4; i++) {
+            const bool b = (m4 >> i) & 1;
             const unsigned long long bal = __builtin_amdgcn_ballot_w64(b);
             const u32 at = __builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, (u32)n));
-            if (b) s_queue[at] = (u32)lane | ((u32)i << 6) | (dc_given << 9);
+            if (b) { s_queue[at] = (u32)lane | ((u32)i << 6) | (dcg << 8); at4 |= at << (8 * i); }
             n += __builtin_popcountll(bal);
         }
         q_n = n;
         wave_lds_sync();
         const int R = (n + 63) >> 6;
 #pragma unroll 1
-        for (int rr = 0; rr < R; rr++) {
+        for (int rr = n0 >> 6; rr < R; rr++) {
             const int idx = rr * 64 + lane;
-            if (idx < n) {
+            if (idx >= n0 && idx < n) {
                 const u32 ent = s_queue[idx];
                 const u32x4 tb = s_tab[ent & 63];
-                g_cs16p cf = (g_cs16p)(((unsigned long)tb.y << 32) | tb.x) + (ph * 8 + (int)((ent >> 6) & 7)) * 16;
+                g_cs16p cf = (g_cs16p)(((unsigned long)tb.y << 32) | tb.x) + (blk0 + (int)((ent >> 6) & 3)) * 16;
                 __builtin_amdgcn_global_load_lds((g_cvp)cf, (lds_vp)(s_stage + rr * 512), 16, 0, 0);
                 __builtin_amdgcn_global_load_lds((g_cvp)(cf + 8), (lds_vp)(s_stage + rr * 512 + 256), 16, 0, 0);
             }
         }
+        return at4;
     };
-    auto drain_phase = [&](const int ph, const int younger) {
+    // all lanes transform the queued blocks n0 .. q_n-1, one per lane and round, in place.  `younger`: a LOWER bound of the
+    // memory instructions issued since `queue` (they may stay in flight)
+    auto drain = [&](const int blk0, const int n0, const int younger) {
         if (younger >= 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
         else if (younger >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (younger >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         wave_lds_sync();
         const int R = (q_n + 63) >> 6;
 #pragma unroll 1
-        for (int rr = 0; rr < R; rr++) {
-            if (rr * 64 + lane < q_n) {
-                const u32 ent = s_queue[rr * 64 + lane];
-                const int owner = ent & 63, i = (ent >> 6) & 7;
-                const bool given = (ent >> 9) & 1;
+        for (int rr = n0 >> 6; rr < R; rr++) {
+            const int idx = rr * 64 + lane;
+            if (idx >= n0 && idx < q_n) {
+                const u32 ent = s_queue[idx];
+                const int owner = ent & 63, i = (ent >> 6) & 3;
+                const bool given = (ent >> 8) & 1;
                 const u32x4 tb = s_tab[owner];
-                const u32 dq = ph < 2 ? tb.z : tb.w;
+                const u32 dq = tb.z;
                 u32x4 ca, cb;
                 asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024\n\ts_waitcnt lgkmcnt(0)"
                              : "=&v"(ca), "=&v"(cb) : "v"(stage_lane + rr * 2048) : "memory");
                 __builtin_amdgcn_sched_barrier(0);
                 int dc_in = 0;
-                if (given) { const int blk = ph * 8 + i; dc_in = (short)(s_y2dc[owner * 8 + (blk >> 1)] >> (16 * (blk & 1))); }
+                if (LUMA && given) { const int blk = blk0 + i; dc_in = (short)(s_y2dc[owner * 8 + (blk >> 1)] >> (16 * (blk & 1))); }
                 int res[16];
                 dequant_idct(ca, cb, dq & 0xffff, dq >> 16, given, dc_in, res);
-                u32 o[8];
-#pragma unroll
-                for (int q = 0; q < 8; q++) o[q] = ((u32)res[2 * q] & 0xffff) | ((u32)res[2 * q + 1] << 16);
-                u32x4 *dst = (u32x4 *)(s_res + owner * 68 + i * 8);
-                dst[0] = (u32x4){ o[0], o[1], o[2], o[3] };
-                dst[1] = (u32x4){ o[4], o[5], o[6], o[7] };
+                u32x4 oa, ob;
+                oa.x = ((u32)res[0] & 0xffff) | ((u32)res[1] << 16); oa.y = ((u32)res[2] & 0xffff) | ((u32)res[3] << 16);
+                oa.z = ((u32)res[4] & 0xffff) | ((u32)res[5] << 16); oa.w = ((u32)res[6] & 0xffff) | ((u32)res[7] << 16);
+                ob.x = ((u32)res[8] & 0xffff) | ((u32)res[9] << 16); ob.y = ((u32)res[10] & 0xffff) | ((u32)res[11] << 16);
+                ob.z = ((u32)res[12] & 0xffff) | ((u32)res[13] << 16); ob.w = ((u32)res[14] & 0xffff) | ((u32)res[15] << 16);
+                asm volatile("ds_write_b128 %0, %1\n\tds_write_b128 %0, %2 offset:1024"
+                             :: "v"(stage_lane + rr * 2048), "v"(oa), "v"(ob) : "memory");
             }
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         wave_lds_sync();
     };
+    // the owner's residuals of the phase just drained: block k's two halves in rr[2k], rr[2k+1] (garbage where it has none)
+    auto fetch = [&](const u32 at4, u32x4 (&rr)[8]) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const u32 at = (at4 >> (8 * k)) & 0xff;
+            const u32 addr = stage_base + ((at >> 6) << 11) + ((at & 63) << 4);
+            asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024" : "=&v"(rr[2 * k]), "=&v"(rr[2 * k + 1]) : "v"(addr) : "memory");
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rr[0]), "+v"(rr[1]), "+v"(rr[2]), "+v"(rr[3]), "+v"(rr[4]), "+v"(rr[5]), "+v"(rr[6]), "+v"(rr[7]) :: "memory");
+    };
 
+    // ---- what the transform needs to know about a macroblock, from its descriptor words (m0: words 0-3, m1: words 4-7) and, luma,
+    // its Y2 block: which of its blocks (luma: 16 bits, chroma: 8) have a residual (`jm`), whether the luma DCs come out of the Y2
+    // block (`dcg`); the lane's entry of s_tab (coefficient pointer, quantiser) and, with a Y2 block, of s_y2dc
     auto prepare_mb = [&](const u32x4 m0, const u32x4 m1, const u32x4 y2a, const u32x4 y2b, g_cs16p cf, u32 &jm, u32 &dcg) {
         const u32 w0 = m0.x, w1 = m0.y;
         const int y_mode = w0 & 0xff;
         const bool skip = (w0 >> 24) & VP8IR_MB_SKIP;
         const bool has_y2 = y_mode != VP8IR_B_PRED && y_mode != VP8IR_SPLITMV;
         const int seg = w1 & 3;
-        const u32 s00 = dqs[0][0], s01 = dqs[0][1], s02 = dqs[0][2], s10 = dqs[1][0], s11 = dqs[1][1], s12 = dqs[1][2];
-        const u32 s20 = dqs[2][0], s21 = dqs[2][1], s22 = dqs[2][2], s30 = dqs[3][0], s31 = dqs[3][1], s32 = dqs[3][2];
+        // (copies first: a select between by-reference captures would become a dynamic index into the closure, in scratch)
+        const u32 s00 = dqs[0][0], s01 = dqs[0][1], s10 = dqs[1][0], s11 = dqs[1][1];
+        const u32 s20 = dqs[2][0], s21 = dqs[2][1], s30 = dqs[3][0], s31 = dqs[3][1];
         const u32 dq0 = seg == 0 ? s00 : seg == 1 ? s10 : seg == 2 ? s20 : s30;
         const u32 dq1 = seg == 0 ? s01 : seg == 1 ? s11 : seg == 2 ? s21 : s31;
-        const u32 dq2 = seg == 0 ? s02 : seg == 1 ? s12 : seg == 2 ? s22 : s32;
-        const u32 e[6] = { m0.z, m0.w, m1.x, m1.y, m1.z, m1.w };
+        // eobs (detokenize.c:363), a byte per block, 0..16: which blocks have a token at all.  A luma block of a macroblock with
+        // Y2 always has its DC (idct_blk.c:20-44, decodframe.c:262-296).
         u32 m = 0;
+        if constexpr (LUMA) {
+            const u32 e[4] = { m0.z, m0.w, m1.x, m1.y };
 #pragma unroll
-        for (int q = 0; q < 6; q++) {
-            const u32 ge1 = ((e[q] + 0x7f7f7f7fu) & 0x80808080u) >> 7;
-            m |= (((ge1 * 0x00204081u) >> 21) & 0xfu) << (4 * q);
+            for (int q = 0; q < 4; q++) {
+                const u32 ge1 = ((e[q] + 0x7f7f7f7fu) & 0x80808080u) >> 7;        // bit 0 of each byte: eob >= 1
+                m |= (((ge1 * 0x00204081u) >> 21) & 0xfu) << (4 * q);
+            }
+            if (has_y2) m |= 0xffffu;
+        } else {
+            const u32 e[2] = { m1.z, m1.w };
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                const u32 ge1 = ((e[q] + 0x7f7f7f7fu) & 0x80808080u) >> 7;
+                m |= (((ge1 * 0x00204081u) >> 21) & 0xfu) << (4 * q);
+            }
         }
-        if (has_y2) m |= 0xffffu;
         if (skip) m = 0;
         jm = m;
-        dcg = has_y2 && !skip;
-        s_tab[lane] = (u32x4){ (u32)(unsigned long)cf, (u32)((unsigned long)cf >> 32), dq0, dq2 };
-        if (__builtin_amdgcn_ballot_w64(dcg != 0) != 0) {
-            if (dcg) {
-                const u32 q[8] = { y2a.x, y2a.y, y2a.z, y2a.w, y2b.x, y2b.y, y2b.z, y2b.w };
-                const int fdc = dq1 & 0xffff, fac = dq1 >> 16;
-                int tt[16], dc[16];
+        dcg = LUMA && has_y2 && !skip;
+        s_tab[lane] = (u32x4){ (u32)(unsigned long)cf, (u32)((unsigned long)cf >> 32), dq0, 0u };
+        if constexpr (LUMA) {
+            // Y2: vp8_dequantize_b + vp8_short_inv_walsh4x4_c (idctllm.c:140-192) -> the 16 luma DCs.  With nothing but a DC
+            // coefficient the full transform gives what vp8_short_inv_walsh4x4_1_c gives (decodframe.c:282-285).
+            if (__builtin_amdgcn_ballot_w64(dcg != 0) != 0) {
+                if (dcg) {
+                    const u32 q[8] = { y2a.x, y2a.y, y2a.z, y2a.w, y2b.x, y2b.y, y2b.z, y2b.w };
+                    const int fdc = dq1 & 0xffff, fac = dq1 >> 16;
+                    int tt[16], dc[16];
 #pragma unroll
-                for (int col = 0; col < 4; col++) {
-                    const int i0 = (short)(sext16(q[2 * col]) * (col == 0 ? fdc : fac));
-                    const int i1 = (short)(hi16(q[2 * col]) * fac);
-                    const int i2 = (short)(sext16(q[2 * col + 1]) * fac);
-                    const int i3 = (short)(hi16(q[2 * col + 1]) * fac);
-                    const int a1 = i0 + i3, b1 = i1 + i2, c1 = i1 - i2, d1 = i0 - i3;
-                    tt[0 + col] = (short)(a1 + b1); tt[4 + col] = (short)(c1 + d1);
-                    tt[8 + col] = (short)(a1 - b1); tt[12 + col] = (short)(d1 - c1);
+                    for (int col = 0; col < 4; col++) {
+                        const int i0 = (short)(sext16(q[2 * col]) * (col == 0 ? fdc : fac));
+                        const int i1 = (short)(hi16(q[2 * col]) * fac);
+                        const int i2 = (short)(sext16(q[2 * col + 1]) * fac);
+                        const int i3 = (short)(hi16(q[2 * col + 1]) * fac);
+                        const int a1 = i0 + i3, b1 = i1 + i2, c1 = i1 - i2, d1 = i0 - i3;
+                        tt[0 + col] = (short)(a1 + b1); tt[4 + col] = (short)(c1 + d1);
+                        tt[8 + col] = (short)(a1 - b1); tt[12 + col] = (short)(d1 - c1);
+                    }
+#pragma unroll
+                    for (int row = 0; row < 4; row++) {
+                        const int a1 = tt[row * 4] + tt[row * 4 + 3], b1 = tt[row * 4 + 1] + tt[row * 4 + 2];
+                        const int c1 = tt[row * 4 + 1] - tt[row * 4 + 2], d1 = tt[row * 4] - tt[row * 4 + 3];
+                        dc[row * 4 + 0] = (a1 + b1 + 3) >> 3; dc[row * 4 + 1] = (c1 + d1 + 3) >> 3;
+                        dc[row * 4 + 2] = (a1 - b1 + 3) >> 3; dc[row * 4 + 3] = (d1 - c1 + 3) >> 3;
+                    }
+                    u32 o[8];
+#pragma unroll
+                    for (int q2 = 0; q2 < 8; q2++) o[q2] = ((u32)dc[2 * q2] & 0xffff) | ((u32)dc[2 * q2 + 1] << 16);
+                    u32x4 *dst = (u32x4 *)(s_y2dc + lane * 8);
+                    dst[0] = (u32x4){ o[0], o[1], o[2], o[3] };
+                    dst[1] = (u32x4){ o[4], o[5], o[6], o[7] };
                 }
-#pragma unroll
-                for (int row = 0; row < 4; row++) {
-                    const int a1 = tt[row * 4] + tt[row * 4 + 3], b1 = tt[row * 4 + 1] + tt[row * 4 + 2];
-                    const int c1 = tt[row * 4 + 1] - tt[row * 4 + 2], d1 = tt[row * 4] - tt[row * 4 + 3];
-                    dc[row * 4 + 0] = (a1 + b1 + 3) >> 3; dc[row * 4 + 1] = (c1 + d1 + 3) >> 3;
-                    dc[row * 4 + 2] = (a1 - b1 + 3) >> 3; dc[row * 4 + 3] = (d1 - c1 + 3) >> 3;
-                }
-                u32 o[8];
-#pragma unroll
-                for (int q2 = 0; q2 < 8; q2++) o[q2] = ((u32)dc[2 * q2] & 0xffff) | ((u32)dc[2 * q2 + 1] << 16);
-                u32x4 *dst = (u32x4 *)(s_y2dc + lane * 8);
-                dst[0] = (u32x4){ o[0], o[1], o[2], o[3] };
-                dst[1] = (u32x4){ o[4], o[5], o[6], o[7] };
             }
+        }
+    };
+    // the next macroblock's descriptor pieces, requested into the lane's slots of s_desc (mb: its descriptor, cf: its coefficients)
+    auto request_desc = [&](g_cu32p mb, g_cs16p cf) {
+        __builtin_amdgcn_global_load_lds((g_cvp)mb, (lds_vp)(s_desc), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((g_cvp)(mb + 4), (lds_vp)(s_desc + 256), 16, 0, 0);
+        if constexpr (LUMA) {
+            __builtin_amdgcn_global_load_lds((g_cvp)(mb + 10), (lds_vp)(s_desc + 512), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((g_cvp)(cf + 384), (lds_vp)(s_desc + 768), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((g_cvp)(cf + 392), (lds_vp)(s_desc + 1024), 16, 0, 0);
         }
     };
 
     int c = -2 * pos - 1, V = pos;
     STAMP_DECL
 #pragma unroll 1
-    for (int t = 0; t <= T; ++t) {
+    for (int t = 0; t < T; ++t) {
         STAMP(0)
-        // ======================= tail of the previous step =======================
-        // prefetches of the macroblock two ahead of the pointers (descriptor, Y2 block) and of the unfiltered line above it
-        u32x4 pf_m0 = *(g_cu32x4p)(mbp + 32), pf_m1 = *(g_cu32x4p)(mbp + 36), pf_bm = *(g_cu32x4p)(mbp + 42);
-        u32x4 pf_y2a = *(g_cu32x4p)(cfp + 2 * VP8IR_COEF_PER_MB + 384), pf_y2b = *(g_cu32x4p)(cfp + 2 * VP8IR_COEF_PER_MB + 392);
-        u32 pf_aY[4], pf_ar, pf_aU[2], pf_aV[2];
-        {
-            const unsigned char *pa = (const unsigned char *)abp + 2 * VP8_TILE_BYTES;
-#pragma unroll
-            for (int i = 0; i < 4; i++) pf_aY[i] = load_l2(pa + HO_Y_LINE + 4 * i);
-            pf_ar = load_l2(pa + VP8_TILE_BYTES + HO_Y_LINE);
-            pf_aU[0] = load_l2(pa + HO_U_LINE); pf_aU[1] = load_l2(pa + HO_U_LINE + 4);
-            pf_aV[0] = load_l2(pa + HO_V_LINE); pf_aV[1] = load_l2(pa + HO_V_LINE + 4);
-        }
-        u32 n_jm = 0, n_dcg = 0;
-        if (p_more) prepare_mb(nx_m0, nx_m1, nx_y2a, nx_y2b, cfp + VP8IR_COEF_PER_MB, n_jm, n_dcg);
-        queue_phase(0, n_jm & 0xff, n_dcg);
-        STAMP(1)
-        // ---- chroma of the previous macroblock: U then V (an idle lane: garbage, into the dummy scratch).  The loop body
-        // works on "U"; the two planes' state changes places at its end.
-        u32 tU[4][2], tV[4][2];                 // filtered rows 4..7 of the macroblock above, from the lane above
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            tU[j][0] = from_lane_above(hU[j][0]); tU[j][1] = from_lane_above(hU[j][1]);
-            tV[j][0] = from_lane_above(hV[j][0]); tV[j][1] = from_lane_above(hV[j][1]);
-            // what the lane below will fetch at the start of the next step: the macroblock held from the step before (its last
-            // four columns are fixed up below, once this step's left edge has revisited them)
-            hU[j][0] = pbU[j]; hU[j][1] = sU[4 + j]; hV[j][0] = pbV[j]; hV[j][1] = sV[4 + j];
-        }
-        if (p_rb) {      // first lane of a strand: the rows come from the hand-over tile (wanted a plane's prediction from here)
-            const unsigned char *pa = (const unsigned char *)p_tp - rowbytes;
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                tU[j][0] = load_l2(pa + HO_U_ROWS + 8 * j); tU[j][1] = load_l2(pa + HO_U_ROWS + 8 * j + 4);
-                tV[j][0] = load_l2(pa + HO_V_ROWS + 8 * j); tV[j][1] = load_l2(pa + HO_V_ROWS + 8 * j + 4);
-            }
-        }
-        u32 bU[2] = { 0, 0 }, bV[2] = { 0, 0 };
-        g_u8p q_ras = p_rasU, q_ras2 = p_rasV;
-        u32 q_a0 = p_aU[0], q_a1 = p_aU[1], q_b0 = p_aV[0], q_b1 = p_aV[1];
-        int q_tl = p_tlU, q_tl2 = p_tlV;
-#pragma unroll 1
-        for (int pl = 0; pl < 2; pl++) {
-            const u32 aC0 = q_a0, aC1 = q_a1, lC0 = lU[0], lC1 = lU[1];
-            int dcC = 128;
-            if (p_up | p_lf) {
-                const int shift = 2 + p_up + p_lf;
-                const int s = (p_up ? sad4(aC0) + sad4(aC1) : 0) + (p_lf ? sad4(lC0) + sad4(lC1) : 0);
-                dcC = (s + (1 << (shift - 1))) >> shift;
-            }
-            const u32 rmg = p_jmc >> (4 * pl);
-            const u32 *rs = my_res + pl * 32;
-            u32 bot[2] = { 0, 0 }, rc[2] = { 0, 0 };
-            u32 o0[4][2], o1[4][2];
-            u32x4 rr[8];
-#pragma unroll
-            for (int k = 0; k < 8; k++) rr[k] = *(const u32x4 *)(rs + k * 4);
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const int bx = k & 1, byc = k >> 1;
-                u32 p[4];
-                mb_mode_pred(p_uv_mode, bx ? aC1 : aC0, byc ? lC1 : lC0, q_tl, dcC, p);
-                u32 o[4] = { p[0], p[1], p[2], p[3] };
-                const bool hasr = (rmg >> k) & 1;
-                if (__builtin_amdgcn_ballot_w64(hasr) != 0) {
-                    if (hasr) {
-                        const u32x4 ra = rr[2 * k], rb = rr[2 * k + 1];
-                        o[0] = add_clamp_pack(p[0], ra.x, ra.y); o[1] = add_clamp_pack(p[1], ra.z, ra.w);
-                        o[2] = add_clamp_pack(p[2], rb.x, rb.y); o[3] = add_clamp_pack(p[3], rb.z, rb.w);
-                    }
-                }
-#pragma unroll
-                for (int jj = 0; jj < 4; jj++) { if (byc) o1[jj][bx] = o[jj]; else o0[jj][bx] = o[jj]; }
-                if (byc) bot[bx] = o[3];
-                if (bx) rc[byc] = right_column(o);
-            }
-            bU[0] = bot[0]; bU[1] = bot[1]; lU[0] = rc[0]; lU[1] = rc[1];
-            STAMP(8)
-            // ---- loop filter of the plane, block row by block row
-            const int hoff = pl ? HO_V_ROWS : HO_U_ROWS, loff = pl ? HO_V_LINE : HO_U_LINE;
-            if (p_hand) *(g_u32x2p)(p_tp + loff) = (u32x2){ bot[0], bot[1] };        // unfiltered bottom line: hand-over
-            v2u PL[2][4], PH[2][4];
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                PL[0][j] = col_lo(tU[j][0]); PH[0][j] = col_hi(tU[j][0]);
-                PL[1][j] = col_lo(tU[j][1]); PH[1][j] = col_hi(tU[j][1]);
-            }
-            u32 s0[4] = { sU[0], sU[1], sU[2], sU[3] }, s1[4] = { sU[4], sU[5], sU[6], sU[7] }, d0[4][2], d1[4][2];
-            lf_block_row<2>(o0, s0, PL, PH, true, p_gvC, p_ghC, p_L, d0);
-            {   // rows 4..7 of the macroblock above: final
-                g_u8p pa = (p_act && !p_top) ? q_ras - 4 * ysC + p_c * 8 : (g_u8p)dummy;
-                const int st = (p_act && !p_top) ? ysC : 0;
-#pragma unroll
-                for (int j = 0; j < 4; j++)
-                    *(g_u32x2p)(pa + j * st) = (u32x2){ d0[j][0] ^ VP8_LF_BIAS, d0[j][1] ^ VP8_LF_BIAS };
-            }
-            lf_block_row<2>(o1, s1, PL, PH, false, p_gvC, p_ghC, p_L, d1);
-            {   // rows 0..3: the left neighbour's last dword and this macroblock's first
-                g_u8p po = p_act ? q_ras + p_c * 8 - 4 : (g_u8p)dummy + 16;
-                const int st = p_act ? ysC : 0;
-#pragma unroll
-                for (int j = 0; j < 4; j++)
-                    *(g_u32x2up)(po + j * st) = (u32x2){ s0[j] ^ VP8_LF_BIAS, d1[j][0] ^ VP8_LF_BIAS };
-            }
-            u32 e[4][2];
-#pragma unroll
-            for (int j = 0; j < 4; j++) { e[j][0] = col_pack(PL[0][j], PH[0][j]); e[j][1] = col_pack(PL[1][j], PH[1][j]); }
-            // the left neighbour's bottom rows are complete now (a lane that is idle, or first in its row, changed nothing)
-#pragma unroll
-            for (int j = 0; j < 4; j++) hU[j][1] = s1[j];
-            if (p_act) {
-                if (p_wb && !p_first) {       // nobody below takes them over: to the frame (last row) or the hand-over tile
-                    g_u8p pb = p_last ? q_ras + 4 * ysC + (p_c - 1) * 8 : p_tp - VP8_TILE_BYTES + hoff;
-                    const int st = p_last ? ysC : 8;
-                    const u32 x = p_last ? VP8_LF_BIAS : 0;         // (the hand-over tile keeps the filter's biased form)
-#pragma unroll
-                    for (int j = 0; j < 4; j++) *(g_u32x2p)(pb + j * st) = (u32x2){ hU[j][0] ^ x, hU[j][1] ^ x };
-                }
-#pragma unroll
-                for (int j = 0; j < 4; j++) { sU[j] = d1[j][1]; sU[4 + j] = e[j][1]; pbU[j] = e[j][0]; }
-                if (p_c == cols - 1) {        // end of the row: nobody revisits the last dword
-#pragma unroll
-                    for (int j = 0; j < 4; j++) *(GLOBAL_AS u32 *)(q_ras + j * ysC + p_c * 8 + 4) = d1[j][1] ^ VP8_LF_BIAS;
-                    if (p_wb) {
-                        g_u8p pb = p_last ? q_ras + 4 * ysC + p_c * 8 : p_tp + hoff;
-                        const int st = p_last ? ysC : 8;
-                        const u32 x = p_last ? VP8_LF_BIAS : 0;
-#pragma unroll
-                        for (int j = 0; j < 4; j++) *(g_u32x2p)(pb + j * st) = (u32x2){ e[j][0] ^ x, e[j][1] ^ x };
-                    }
-                }
-            }
-            STAMP(9)
-            // ---- the planes change places
-            SWAP_U32(bU[0], bV[0]) SWAP_U32(bU[1], bV[1]) SWAP_U32(lU[0], lV[0]) SWAP_U32(lU[1], lV[1])
-            SWAP_U32(q_a0, q_b0) SWAP_U32(q_a1, q_b1)
-            { const int t_ = q_tl; q_tl = q_tl2; q_tl2 = t_; }
-            { g_u8p t_ = q_ras; q_ras = q_ras2; q_ras2 = t_; }
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                SWAP_U32(tU[j][0], tV[j][0]) SWAP_U32(tU[j][1], tV[j][1]) SWAP_U32(hU[j][0], hV[j][0]) SWAP_U32(hU[j][1], hV[j][1])
-                SWAP_U32(pbU[j], pbV[j]) SWAP_U32(sU[j], sV[j]) SWAP_U32(sU[4 + j], sV[4 + j])
-            }
-        }
-        prevLastU = p_lastU; prevLastV = p_lastV;
-        if (p_act) { mbp += 16; cfp += VP8IR_COEF_PER_MB; tp += VP8_TILE_BYTES; abp += VP8_TILE_BYTES; }
-        // ---- prediction history: what the lane below will ask for in one and in two steps
-#pragma unroll
-        for (int i = 0; i < 4; i++) { h2Y[i] = h1Y[i]; h1Y[i] = p_act ? p_bY[i] : h1Y[i]; }
-#pragma unroll
-        for (int i = 0; i < 2; i++) { h2U[i] = h1U[i]; h1U[i] = p_act ? bU[i] : h1U[i]; h2V[i] = h1V[i]; h1V[i] = p_act ? bV[i] : h1V[i]; }
-        STAMP(2)
-
-        // ======================= this step =======================
         if (++c == P) { c = 0; V += G; }
-        u32 nY[4], nU[2], nV[2];
+        // ---- what the lane above finished: prediction context (two steps ago: straight above; last step: above-right) and the
+        // filter's context rows (two steps ago); then this lane's own offer: the macroblock held from the step before
+        u32 nA[4], nAR = 0, tF[4][4];
 #pragma unroll
-        for (int i = 0; i < 4; i++) nY[i] = from_lane_above(h2Y[i]);
-        const u32 nAR = from_lane_above(h1Y[0]);
-#pragma unroll
-        for (int i = 0; i < 2; i++) { nU[i] = from_lane_above(h2U[i]); nV[i] = from_lane_above(h2V[i]); }
-        // filtered rows 12..15 of the macroblock above; then this lane's own offer: the macroblock held from the step before
-        u32 tY[4][4];
+        for (int i = 0; i < 4; i++) nA[i] = from_lane_above(h2[i]);
+        if constexpr (LUMA) nAR = from_lane_above(h1[0]);
 #pragma unroll
         for (int j = 0; j < 4; j++) {
 #pragma unroll
-            for (int i = 0; i < 4; i++) tY[j][i] = from_lane_above(hY[j][i]);
-            hY[j][0] = pbY[j][0]; hY[j][1] = pbY[j][1]; hY[j][2] = pbY[j][2]; hY[j][3] = sY[12 + j];
+            for (int i = 0; i < 4; i++) tF[j][i] = from_lane_above(hF[j][i]);
+            if constexpr (LUMA) { hF[j][0] = pb[j][0]; hF[j][1] = pb[j][1]; hF[j][2] = pb[j][2]; hF[j][3] = sF[12 + j]; }
+            else { hF[j][0] = pb[j][0]; hF[j][1] = sF[4 + j]; hF[j][2] = pb[j][1]; hF[j][3] = sF[12 + j]; }
         }
-
-        const bool act = t < T && c >= 0 && c < cols && V < Vmax;
-        const bool late = act && !p_more;
-        u32 jm = n_jm, dc_given = n_dcg;
-        u32 cur_w0 = nx_m0.x, cur_w1 = nx_m0.y;
+        const bool act = c >= 0 && c < cols && V < Vmax;
+        const bool late = act && !p_more;        // first macroblock of a row: nothing was prepared a step ahead
+        u32 jm = nx_jm, dc_given = nx_dcg, at4 = nx_at4;
+        u32 cur_w0 = nx_w0, cur_w1 = nx_w1;
         u32x4 bm = nx_bm;
-        u32 rbaY[4] = { nx_aY[0], nx_aY[1], nx_aY[2], nx_aY[3] }, rbAR = nx_ar, rbaU[2] = { nx_aU[0], nx_aU[1] }, rbaV[2] = { nx_aV[0], nx_aV[1] };
         if (late) {
             // ---- new macroblock row (c == 0): which frame, which row; pointers, quantisers, filter levels; its first macroblock
             const int j = V / rows;
@@ -536,158 +438,158 @@ vp8_keyframe_simt_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g, 
             for (int s = 0; s < 4; s++) {
                 u32 d[3];
                 if (s < nseg) segment_dequant(h, s, d);
-                else { d[0] = dqs[0][0]; d[1] = dqs[0][1]; d[2] = dqs[0][2]; }
-                dqs[s][0] = d[0]; dqs[s][1] = d[1]; dqs[s][2] = d[2];
+                else { d[0] = dqs[0][0]; d[1] = dqs[0][1]; d[2] = dqs[0][0]; }
+                dqs[s][0] = LUMA ? d[0] : d[2]; dqs[s][1] = d[1];
             }
             frame_levels(h, lv_plain, lv_bpred);
             sharp = h.sharpness_level; simple = h.filter_type == 1;
             mbp = (g_cu32p)(job->mbs + (long)r * cols);
             cfp = (g_cs16p)(job->coef + (long)r * cols * VP8IR_COEF_PER_MB);
             tp = (g_u8p)(job->tile + (long)r * rowbytes);
-            abp = r == 0 ? (g_cu8p)tp : (g_cu8p)tp - rowbytes;
-            rasY = (g_u8p)(job->dst + g.y_off + (long)r * 16 * ysY);
-            rasU = (g_u8p)(job->dst + g.u_off + (long)r * 8 * ysC);
-            rasV = (g_u8p)(job->dst + g.v_off + (long)r * 8 * ysC);
-            lY[0] = lY[1] = lY[2] = lY[3] = 0x81818181u;    // left border 129 (setupintrarecon.c:15-32)
-            lU[0] = lU[1] = lV[0] = lV[1] = 0x81818181u;
-            const u32x4 m0 = *(g_cu32x4p)mbp, m1 = *(g_cu32x4p)(mbp + 4), b0 = *(g_cu32x4p)(mbp + 10);
-            const u32x4 y2a = *(g_cu32x4p)(cfp + 384), y2b = *(g_cu32x4p)(cfp + 392);
-            if (pos == 0) {
-                const unsigned char *pa = (const unsigned char *)abp;
-#pragma unroll
-                for (int i = 0; i < 4; i++) rbaY[i] = load_l2(pa + HO_Y_LINE + 4 * i);
-                rbAR = load_l2(pa + VP8_TILE_BYTES + HO_Y_LINE);
-                rbaU[0] = load_l2(pa + HO_U_LINE); rbaU[1] = load_l2(pa + HO_U_LINE + 4);
-                rbaV[0] = load_l2(pa + HO_V_LINE); rbaV[1] = load_l2(pa + HO_V_LINE + 4);
-            }
-            pf_m0 = *(g_cu32x4p)(mbp + 16); pf_m1 = *(g_cu32x4p)(mbp + 20); pf_bm = *(g_cu32x4p)(mbp + 26);
-            pf_y2a = *(g_cu32x4p)(cfp + VP8IR_COEF_PER_MB + 384); pf_y2b = *(g_cu32x4p)(cfp + VP8IR_COEF_PER_MB + 392);
-            if (pos == 0) {
-                const unsigned char *pa = (const unsigned char *)abp + VP8_TILE_BYTES;
-#pragma unroll
-                for (int i = 0; i < 4; i++) pf_aY[i] = load_l2(pa + HO_Y_LINE + 4 * i);
-                pf_ar = load_l2(pa + VP8_TILE_BYTES + HO_Y_LINE);
-                pf_aU[0] = load_l2(pa + HO_U_LINE); pf_aU[1] = load_l2(pa + HO_U_LINE + 4);
-                pf_aV[0] = load_l2(pa + HO_V_LINE); pf_aV[1] = load_l2(pa + HO_V_LINE + 4);
-            }
+            if constexpr (LUMA) ras = (g_u8p)(job->dst + g.y_off + (long)r * 16 * ys);
+            else { ras = (g_u8p)(job->dst + g.u_off + (long)r * 8 * ys); ras2 = (g_u8p)(job->dst + g.v_off + (long)r * 8 * ys); }
+            l0[0] = l0[1] = l0[2] = l0[3] = 0x81818181u;    // left border 129 (setupintrarecon.c:15-32)
+            u32x4 m0 = *(g_cu32x4p)mbp, m1 = *(g_cu32x4p)(mbp + 4), b0 = { 0, 0, 0, 0 }, y2a = { 0, 0, 0, 0 }, y2b = { 0, 0, 0, 0 };
+            if constexpr (LUMA) { b0 = *(g_cu32x4p)(mbp + 10); y2a = *(g_cu32x4p)(cfp + 384); y2b = *(g_cu32x4p)(cfp + 392); }
             // consumed here, so that no pending load leaves the branch
-            u32x4 m0s = m0, m1s = m1, b0s = b0, y2as = y2a, y2bs = y2b;
-            asm volatile("" : "+v"(m0s), "+v"(m1s), "+v"(b0s), "+v"(y2as), "+v"(y2bs));
-            asm volatile("" : "+v"(rbaY[0]), "+v"(rbaY[1]), "+v"(rbaY[2]), "+v"(rbaY[3]), "+v"(rbAR), "+v"(rbaU[0]), "+v"(rbaU[1]), "+v"(rbaV[0]), "+v"(rbaV[1]));
-            asm volatile("" : "+v"(pf_m0), "+v"(pf_m1), "+v"(pf_bm), "+v"(pf_y2a), "+v"(pf_y2b));
-            asm volatile("" : "+v"(pf_aY[0]), "+v"(pf_aY[1]), "+v"(pf_aY[2]), "+v"(pf_aY[3]), "+v"(pf_ar), "+v"(pf_aU[0]), "+v"(pf_aU[1]), "+v"(pf_aV[0]), "+v"(pf_aV[1]));
-            cur_w0 = m0s.x; cur_w1 = m0s.y; bm = b0s;
-            prepare_mb(m0s, m1s, y2as, y2bs, cfp, jm, dc_given);
+            asm volatile("" : "+v"(m0), "+v"(m1), "+v"(b0), "+v"(y2a), "+v"(y2b));
+            cur_w0 = m0.x; cur_w1 = m0.y; bm = b0;
+            prepare_mb(m0, m1, y2a, y2b, cfp, jm, dc_given);
         }
         if (!act) { jm = 0; dc_given = 0; }
+        // the row starters' first phase joins the queue behind the blocks the others had transformed at the end of the last step
+        if (__builtin_amdgcn_ballot_w64(late) != 0) {
+            const int n0 = q_n;
+            const u32 a = queue(LUMA ? 0 : 16, late ? jm & 0xf : 0, dc_given, n0);
+            if (late) at4 = a;
+            drain(LUMA ? 0 : 16, n0, 0);
+        }
+        // the descriptor of the macroblock after this one: on its way from here (a lane at the end of its row, or idle, fetches
+        // whatever follows: never used)
+        request_desc(mbp + 16, cfp + VP8IR_COEF_PER_MB);
+        STAMP(1)
         const bool top = r == 0;
         const bool more = act && c + 1 < cols;
-        const bool readback = act && pos == 0 && !top;
-        if (readback) {      // first lane of a strand: filtered rows 12..15 of the macroblock above from the hand-over tile (wanted
-                             // by the first block row's top edge, a block row of prediction from here)
-            const unsigned char *pa = (const unsigned char *)tp - rowbytes;
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-#pragma unroll
-                for (int i = 0; i < 4; i++) tY[j][i] = load_l2(pa + HO_Y_ROWS + 16 * j + 4 * i);
-            }
-        }
-        // ---- macroblock descriptor
+        const bool readback = act && pos == 0 && !top;          // first lane of a strand: its context comes from the hand-over tile
+        const bool last_col = act && c == cols - 1, last_row = r == rows - 1;
+        // bottom rows that no lane below takes over are written here: to the frame (last row), or to the hand-over tile
+        const bool write_bottom = pos == G - 1 || last_row;
+        const bool hand = act && pos == G - 1 && !last_row;
+        const g_u8p tpc = tp + (long)(act ? c : 0) * VP8_TILE_BYTES;                 // this macroblock's hand-over tile
+        // ---- macroblock descriptor; loop-filter parameters (vp8_loop_filter_frame, loopfilter.c:245-299)
         const int y_mode = cur_w0 & 0xff, uv_mode = (cur_w0 >> 8) & 0xff;
         const bool bpred = y_mode == VP8IR_B_PRED;
-        // ---- its loop-filter parameters (vp8_loop_filter_frame, loopfilter.c:245-299)
         const int level = act ? (int)(((bpred ? lv_bpred : lv_plain) >> (8 * (cur_w1 & 3))) & 0xff) : 0;
         const Lim L = mb_limits(sharp, level, 0, one);
         const bool on = level != 0;
         const bool skip_lf = !bpred && y_mode != VP8IR_SPLITMV && ((cur_w0 >> 24) & VP8IR_MB_SKIP);
         const bool mbv = on && c > 0, inner = on && !skip_lf, mbh = on && !top;
-        const bool any_normal = __builtin_amdgcn_ballot_w64(on && !simple) != 0;
-        const bool any_simple = __builtin_amdgcn_ballot_w64(on && simple) != 0;
-        auto gate = [](bool b) { return mku(b ? 0xffff : 0); };
-        const Gates gvY = { gate(mbv && !simple), gate(inner && !simple), gate(mbv && simple), gate(inner && simple), any_normal, any_simple };
-        const Gates ghY = { gate(mbh && !simple), gate(inner && !simple), gate(mbh && simple), gate(inner && simple), any_normal, any_simple };
         // the simple filter leaves chroma alone (loopfilter.c:283-299)
-        const Gates gvC = { gvY.mb, gvY.inner, mku(0), mku(0), any_normal, false };
-        const Gates ghC = { ghY.mb, ghY.inner, mku(0), mku(0), any_normal, false };
-        const bool last_col = act && c == cols - 1, last_row = r == rows - 1;
-        // bottom rows that no lane below takes over are written here: to the frame (last row), or to the hand-over tile
-        const bool write_bottom = pos == G - 1 || last_row;
-        const bool hand = act && pos == G - 1 && !last_row;
+        const bool any_normal = __builtin_amdgcn_ballot_w64(on && !simple) != 0;
+        const bool any_simple = LUMA && __builtin_amdgcn_ballot_w64(on && simple) != 0;
+        auto gate = [](bool b) { return mku(b ? 0xffff : 0); };
+        const Gates gv = { gate(mbv && !simple), gate(inner && !simple), gate(LUMA && mbv && simple), gate(LUMA && inner && simple), any_normal, any_simple };
+        const Gates gh = { gate(mbh && !simple), gate(inner && !simple), gate(LUMA && mbh && simple), gate(LUMA && inner && simple), any_normal, any_simple };
         // ---- unfiltered line above (127 above the frame; vp8_setup_intra_recon)
-        u32 aY[4], arY, aU[2], aV[2];
+        u32 aA[4], arY = 0;
         if (top) {
-            aY[0] = aY[1] = aY[2] = aY[3] = arY = 0x7f7f7f7fu;
-            aU[0] = aU[1] = aV[0] = aV[1] = 0x7f7f7f7fu;
-        } else if (pos == 0) {
-#pragma unroll
-            for (int i = 0; i < 4; i++) aY[i] = rbaY[i];
-            arY = rbAR;
-            aU[0] = rbaU[0]; aU[1] = rbaU[1]; aV[0] = rbaV[0]; aV[1] = rbaV[1];
+            aA[0] = aA[1] = aA[2] = aA[3] = arY = 0x7f7f7f7fu;
         } else {
 #pragma unroll
-            for (int i = 0; i < 4; i++) aY[i] = nY[i];
+            for (int i = 0; i < 4; i++) aA[i] = nA[i];
             arY = nAR;
-            aU[0] = nU[0]; aU[1] = nU[1]; aV[0] = nV[0]; aV[1] = nV[1];
         }
-        if (!top && c == cols - 1) arY = splat(aY[3] >> 24);
-        const int tlY = top ? 127 : (c == 0 ? 129 : prevLastY);
-        const int tlU = top ? 127 : (c == 0 ? 129 : prevLastU);
-        const int tlV = top ? 127 : (c == 0 ? 129 : prevLastV);
-        const int up = !top, lf = c > 0;
-        int dcY = 128;
-        if (up | lf) {
-            const int shift = 3 + up + lf;
-            const int s = (up ? sad4(aY[0]) + sad4(aY[1]) + sad4(aY[2]) + sad4(aY[3]) : 0)
-                        + (lf ? sad4(lY[0]) + sad4(lY[1]) + sad4(lY[2]) + sad4(lY[3]) : 0);
-            dcY = (s + (1 << (shift - 1))) >> shift;
-        }
-        u32 abv[4] = { aY[0], aY[1], aY[2], aY[3] };
-        int tlrow = tlY;
-        u32 nl[4] = { 0, 0, 0, 0 };
-        const g_u8p tpe = act ? tp : (g_u8p)dummy;
-        // ---- the filter's rows above the first block row: rows 12..15 of the macroblock above, as column pairs
-        v2u PL[4][4], PH[4][4];
+        if (readback) {
+            const unsigned char *pa = (const unsigned char *)tpc - rowbytes;
+            if constexpr (LUMA) {
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
+                for (int i = 0; i < 4; i++) aA[i] = load_l2(pa + HO_Y_LINE + 4 * i);
+                arY = load_l2(pa + VP8_TILE_BYTES + HO_Y_LINE);
 #pragma unroll
-            for (int x = 0; x < 4; x++) {
-                const u32 D = tY[j][x];
-                PL[x][j] = col_lo(D); PH[x][j] = col_hi(D);
+                for (int j = 0; j < 4; j++) {
+#pragma unroll
+                    for (int i = 0; i < 4; i++) tF[j][i] = load_l2(pa + HO_Y_ROWS + 16 * j + 4 * i);
+                }
+            } else {
+                aA[0] = load_l2(pa + HO_U_LINE); aA[1] = load_l2(pa + HO_U_LINE + 4);
+                aA[2] = load_l2(pa + HO_V_LINE); aA[3] = load_l2(pa + HO_V_LINE + 4);
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    tF[j][0] = load_l2(pa + HO_U_ROWS + 8 * j); tF[j][1] = load_l2(pa + HO_U_ROWS + 8 * j + 4);
+                    tF[j][2] = load_l2(pa + HO_V_ROWS + 8 * j); tF[j][3] = load_l2(pa + HO_V_ROWS + 8 * j + 4);
+                }
             }
         }
-        u32 sfix[4] = { 0, 0, 0, 0 };             // the left neighbour's last dword in the rows above the current block row, fixed up
-        // where the rows above the current block row go: first the macroblock above (aligned), then this one (shifted left by 4)
-        g_u8p prow = (act && !top) ? rasY - 4 * ysY + c * 16 : (g_u8p)dummy + 16;
-        int pstride = (act && !top) ? ysY : 0;
-        STAMP(3)
+        const int up = !top, lf = c > 0;
+        STAMP(2)
 
-        // ======================= luma: two transform phases of two block rows =======================
-        drain_phase(0, 8);
-        if (__builtin_amdgcn_ballot_w64(late) != 0) {
-            queue_phase(0, late ? jm & 0xff : 0, dc_given);
-            drain_phase(0, 0);
-        }
-        STAMP(4)
+        if constexpr (LUMA) {
+            // ======================= luma: four block rows =======================
+            // vp8_extend_mb_row (extend.c:160-185): right of the frame the line repeats its last pixel
+            if (!top && c == cols - 1) arY = splat(aA[3] >> 24);
+            const int tlY = top ? 127 : (c == 0 ? 129 : prevLast);
+            int dcY = 128;
+            if (up | lf) {
+                const int shift = 3 + up + lf;
+                const int s = (up ? sad4(aA[0]) + sad4(aA[1]) + sad4(aA[2]) + sad4(aA[3]) : 0)
+                            + (lf ? sad4(l0[0]) + sad4(l0[1]) + sad4(l0[2]) + sad4(l0[3]) : 0);
+                dcY = (s + (1 << (shift - 1))) >> shift;
+            }
+            u32 abv[4] = { aA[0], aA[1], aA[2], aA[3] };      // line above the current block row (B_PRED chain)
+            int tlrow = tlY;                                   // top-left of the block row's first block
+            u32 nl[4] = { 0, 0, 0, 0 };                        // right column of this macroblock = left of the next
+            // the filter's rows above the first block row: rows 12..15 of the macroblock above, as column pairs
+            v2u PL[4][4], PH[4][4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+#pragma unroll
+                for (int x = 0; x < 4; x++) { PL[x][j] = col_lo(tF[j][x]); PH[x][j] = col_hi(tF[j][x]); }
+            }
+            u32 sfix[4] = { 0, 0, 0, 0 };             // the left neighbour's last dword in the rows above the current block row, fixed up
+            // where the rows above the current block row go: first the macroblock above (aligned), then this one (shifted left by 4)
+            g_u8p prow = (act && !top) ? ras - 4 * ys + c * 16 : (g_u8p)dummy + 16;
+            int pstride = (act && !top) ? ys : 0;
 #pragma unroll 1
-        for (int ph = 0; ph < 2; ph++) {
-            queue_phase(ph + 1, (jm >> (8 * (ph + 1))) & 0xff, ph == 0 ? dc_given : 0);
-#pragma unroll 1
-            for (int by = 2 * ph; by < 2 * ph + 2; by++) {
-                const u32 lcur = lY[0];
-                const u32 bmw = by == 0 ? bm.x : by == 1 ? bm.y : by == 2 ? bm.z : bm.w;
+            for (int by = 0; by < 4; by++) {
+                // ---- the block row's residuals; then the next phase's coefficients are requested (the next block row's, or the next
+                // macroblock's first, whose descriptor has arrived by now: at least the 12 row stores below are younger)
+                u32x4 rr[8];
                 const u32 rmg = jm >> (by * 4);
-                const u32 *rs = my_res + (by & 1) * 32;
+                if (by < 3) {
+                    fetch(at4, rr);
+                    at4 = queue(4 * by + 4, (jm >> (4 * by + 4)) & 0xf, dc_given, 0);
+                } else {
+                    // (all of this macroblock's phases have been transformed: its entries of s_tab / s_y2dc are free)
+                    u32 n_jm = 0, n_dcg = 0;
+                    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                    {
+                        u32x4 m0, m1, y2a, y2b;
+                        asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:1024\n\t"
+                                     "ds_read_b128 %2, %4 offset:3072\n\tds_read_b128 %3, %4 offset:4096\n\ts_waitcnt lgkmcnt(0)"
+                                     : "=&v"(m0), "=&v"(m1), "=&v"(y2a), "=&v"(y2b) : "v"(desc_lane) : "memory");
+                        if (more) prepare_mb(m0, m1, y2a, y2b, cfp + VP8IR_COEF_PER_MB, n_jm, n_dcg);
+                        nx_w0 = m0.x; nx_w1 = m0.y; nx_jm = n_jm; nx_dcg = n_dcg;
+                    }
+                    asm volatile("ds_read_b128 %0, %1 offset:2048\n\ts_waitcnt lgkmcnt(0)" : "=&v"(nx_bm) : "v"(desc_lane) : "memory");
+                    fetch(at4, rr);
+                    nx_at4 = queue(0, n_jm & 0xf, n_dcg, 0);
+                }
+                STAMP(3)
+                const u32 lcur = l0[0];
+                const u32 bmw = by == 0 ? bm.x : by == 1 ? bm.y : by == 2 ? bm.z : bm.w;
                 u32 left = lcur;
                 int tl = tlrow;
-                u32 orow[4][4];
-                u32x4 rr[8];
-#pragma unroll
-                for (int k = 0; k < 8; k++) rr[k] = *(const u32x4 *)(rs + k * 4);
+                u32 orow[4][4];                               // [row][block]
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     u32 p[4];
-                    if (bpred) bpred4x4((bmw >> (8 * k)) & 0xff, abv[k], k < 3 ? abv[k + 1] : arY, left, tl, p);
-                    else mb_mode_pred(y_mode, aY[k], lcur, tlY, dcY, p);
+                    if (bpred) {
+                        // decodframe.c:200-236; above-right of the right-hand block column is the macroblock's own
+                        // above-right for every block row (reconintra4x4.c:305-317)
+                        bpred4x4((bmw >> (8 * k)) & 0xff, abv[k], k < 3 ? abv[k + 1] : arY, left, tl, p);
+                    } else {
+                        mb_mode_pred(y_mode, aA[k], lcur, tlY, dcY, p);
+                    }
                     u32 o[4] = { p[0], p[1], p[2], p[3] };
                     const bool hasr = (rmg >> k) & 1;
                     if (__builtin_amdgcn_ballot_w64(hasr) != 0) {
@@ -704,13 +606,13 @@ vp8_keyframe_simt_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g, 
                     left = right_column(o);
                 }
                 tlrow = lcur >> 24;
-                lY[0] = lY[1]; lY[1] = lY[2]; lY[2] = lY[3];
+                l0[0] = l0[1]; l0[1] = l0[2]; l0[2] = l0[3];
                 nl[0] = nl[1]; nl[1] = nl[2]; nl[2] = nl[3]; nl[3] = left;
-                STAMP(10)
+                STAMP(4)
                 // ---- loop filter: the vertical edges of this block row, the horizontal edge above it; the rows above are final
-                u32 sb[4] = { sY[0], sY[1], sY[2], sY[3] }, d[4][4];
-                lf_block_row<4>(orow, sb, PL, PH, by == 0, gvY, ghY, L, d);
-                STAMP(11)
+                u32 sb[4] = { sF[0], sF[1], sF[2], sF[3] }, d[4][4];
+                lf_block_row<4>(orow, sb, PL, PH, by == 0, gv, gh, L, d);
+                STAMP(5)
                 const bool first = by == 0;
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
@@ -719,74 +621,203 @@ vp8_keyframe_simt_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g, 
                 }
                 // rotate: the next block row's left context comes to the front, this macroblock's last dwords queue up behind
 #pragma unroll
-                for (int i = 0; i < 12; i++) sY[i] = sY[i + 4];
+                for (int i = 0; i < 12; i++) sF[i] = sF[i + 4];
 #pragma unroll
-                for (int j = 0; j < 4; j++) { sY[12 + j] = d[j][3]; sfix[j] = sb[j]; }
-                prow = act ? (first ? rasY + c * 16 - 4 : prow + 4 * ysY) : (g_u8p)dummy + 16;
-                pstride = act ? ysY : 0;
-                STAMP(12)
+                for (int j = 0; j < 4; j++) { sF[12 + j] = d[j][3]; sfix[j] = sb[j]; }
+                prow = act ? (first ? ras + c * 16 - 4 : prow + 4 * ys) : (g_u8p)dummy + 16;
+                pstride = act ? ys : 0;
+                // ---- the next phase's residuals (its coefficients have landed: the four row stores above are younger)
+                drain(by < 3 ? 4 * by + 4 : 0, 0, 4);
+                STAMP(6)
             }
-            STAMP(5)
-            drain_phase(ph + 1, 8);
-            STAMP(6)
-        }
-        // ---- the bottom four rows stay (the lane below finishes them); the left neighbour's are complete now
-        {
-            u32 e[4][4];
+            // ---- the bottom four rows stay (the lane below finishes them); the left neighbour's are complete now
+            {
+                u32 e[4][4];
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
+                for (int j = 0; j < 4; j++) {
 #pragma unroll
-                for (int x = 0; x < 4; x++) e[j][x] = col_pack(PL[x][j], PH[x][j]);
-                hY[j][3] = sfix[j];
-            }
-            // (sY: [junk of the first rotation, rows 0..3, 4..7, 8..11] -> rows 0..15)
-            u32 ns[16];
-#pragma unroll
-            for (int i = 0; i < 12; i++) ns[i] = sY[i + 4];
-#pragma unroll
-            for (int j = 0; j < 4; j++) ns[12 + j] = e[j][3];
-            if (act) {
-                if (hand) *(g_u32x4p)(tp + HO_Y_LINE) = (u32x4){ abv[0], abv[1], abv[2], abv[3] };     // unfiltered bottom line
-                if (write_bottom && c > 0) {
-                    g_u8p pb = last_row ? rasY + 12 * ysY + (c - 1) * 16 : tp - VP8_TILE_BYTES + HO_Y_ROWS;
-                    const int st = last_row ? ysY : 16;
-                    const u32 x = last_row ? VP8_LF_BIAS : 0;
-#pragma unroll
-                    for (int j = 0; j < 4; j++) *(g_u32x4p)(pb + j * st) = (u32x4){ hY[j][0], hY[j][1], hY[j][2], hY[j][3] } ^ x;
+                    for (int x = 0; x < 4; x++) e[j][x] = col_pack(PL[x][j], PH[x][j]);
+                    hF[j][3] = sfix[j];
                 }
+                // (sF: [junk of the first rotation, rows 0..3, 4..7, 8..11] -> rows 0..15)
+                u32 ns[16];
 #pragma unroll
-                for (int i = 0; i < 16; i++) sY[i] = ns[i];
+                for (int i = 0; i < 12; i++) ns[i] = sF[i + 4];
 #pragma unroll
-                for (int j = 0; j < 4; j++) { pbY[j][0] = e[j][0]; pbY[j][1] = e[j][1]; pbY[j][2] = e[j][2]; }
-                if (last_col) {
+                for (int j = 0; j < 4; j++) ns[12 + j] = e[j][3];
+                if (act) {
+                    if (hand) *(g_u32x4p)(tpc + HO_Y_LINE) = (u32x4){ abv[0], abv[1], abv[2], abv[3] };     // unfiltered bottom line
+                    if (write_bottom && c > 0) {
+                        g_u8p pbo = last_row ? ras + 12 * ys + (c - 1) * 16 : tpc - VP8_TILE_BYTES + HO_Y_ROWS;
+                        const int st = last_row ? ys : 16;
+                        const u32 x = last_row ? VP8_LF_BIAS : 0;         // (the hand-over tile keeps the filter's biased form)
 #pragma unroll
-                    for (int y = 0; y < 12; y++) *(GLOBAL_AS u32 *)(rasY + y * ysY + c * 16 + 12) = ns[y] ^ VP8_LF_BIAS;
-                    if (write_bottom) {
-                        g_u8p pb = last_row ? rasY + 12 * ysY + c * 16 : tp + HO_Y_ROWS;
-                        const int st = last_row ? ysY : 16;
-                        const u32 x = last_row ? VP8_LF_BIAS : 0;
+                        for (int j = 0; j < 4; j++) *(g_u32x4p)(pbo + j * st) = (u32x4){ hF[j][0], hF[j][1], hF[j][2], hF[j][3] } ^ x;
+                    }
 #pragma unroll
-                        for (int j = 0; j < 4; j++) *(g_u32x4p)(pb + j * st) = (u32x4){ e[j][0], e[j][1], e[j][2], e[j][3] } ^ x;
+                    for (int i = 0; i < 16; i++) sF[i] = ns[i];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) { pb[j][0] = e[j][0]; pb[j][1] = e[j][1]; pb[j][2] = e[j][2]; }
+                    if (last_col) {          // end of the row: nobody revisits the last dwords
+#pragma unroll
+                        for (int y = 0; y < 12; y++) *(GLOBAL_AS u32 *)(ras + y * ys + c * 16 + 12) = ns[y] ^ VP8_LF_BIAS;
+                        if (write_bottom) {
+                            g_u8p pbo = last_row ? ras + 12 * ys + c * 16 : tpc + HO_Y_ROWS;
+                            const int st = last_row ? ys : 16;
+                            const u32 x = last_row ? VP8_LF_BIAS : 0;
+#pragma unroll
+                            for (int j = 0; j < 4; j++) *(g_u32x4p)(pbo + j * st) = (u32x4){ e[j][0], e[j][1], e[j][2], e[j][3] } ^ x;
+                        }
                     }
                 }
             }
+            // ---- prediction context of the next step
+#pragma unroll
+            for (int i = 0; i < 4; i++) { l0[i] = nl[i]; h2[i] = h1[i]; h1[i] = act ? abv[i] : h1[i]; }
+            prevLast = aA[3] >> 24;
+        } else {
+            // ======================= chroma: U, then V =======================
+            // The loop body works on "U" (l0[0..1], aA[0..1], sF[0..7], pb[j][0], hF[j][0..1], tF[j][0..1], ras); the two planes'
+            // state changes places at its end.
+            int tlA = top ? 127 : (c == 0 ? 129 : prevLast), tlB = top ? 127 : (c == 0 ? 129 : prevLast2);
+            const int lastU = aA[1] >> 24, lastV = aA[3] >> 24;
+            u32 bA[2] = { 0, 0 }, bB[2] = { 0, 0 };           // unfiltered bottom lines of the two planes
+#pragma unroll 1
+            for (int pl = 0; pl < 2; pl++) {
+                u32x4 rr[8];
+                fetch(at4, rr);
+                const u32 rmg = jm >> (4 * pl);
+                if (pl == 0) at4 = queue(20, (jm >> 4) & 0xf, 0, 0);
+                else {
+                    u32 n_jm = 0, n_dcg = 0;
+                    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                    u32x4 m0, m1;
+                    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024\n\ts_waitcnt lgkmcnt(0)"
+                                 : "=&v"(m0), "=&v"(m1) : "v"(desc_lane) : "memory");
+                    const u32x4 z = { 0, 0, 0, 0 };
+                    if (more) prepare_mb(m0, m1, z, z, cfp + VP8IR_COEF_PER_MB, n_jm, n_dcg);
+                    nx_w0 = m0.x; nx_w1 = m0.y; nx_jm = n_jm; nx_dcg = 0;
+                    nx_at4 = queue(16, n_jm & 0xf, 0, 0);
+                }
+                STAMP(3)
+                const u32 aC0 = aA[0], aC1 = aA[1], lC0 = l0[0], lC1 = l0[1];
+                int dcC = 128;
+                if (up | lf) {
+                    const int shift = 2 + up + lf;
+                    const int s = (up ? sad4(aC0) + sad4(aC1) : 0) + (lf ? sad4(lC0) + sad4(lC1) : 0);
+                    dcC = (s + (1 << (shift - 1))) >> shift;
+                }
+                u32 bot[2] = { 0, 0 }, rc[2] = { 0, 0 };
+                u32 o0[4][2], o1[4][2];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int bx = k & 1, byc = k >> 1;
+                    u32 p[4];
+                    mb_mode_pred(uv_mode, bx ? aC1 : aC0, byc ? lC1 : lC0, tlA, dcC, p);
+                    u32 o[4] = { p[0], p[1], p[2], p[3] };
+                    const bool hasr = (rmg >> k) & 1;
+                    if (__builtin_amdgcn_ballot_w64(hasr) != 0) {
+                        if (hasr) {
+                            const u32x4 ra = rr[2 * k], rb = rr[2 * k + 1];
+                            o[0] = add_clamp_pack(p[0], ra.x, ra.y); o[1] = add_clamp_pack(p[1], ra.z, ra.w);
+                            o[2] = add_clamp_pack(p[2], rb.x, rb.y); o[3] = add_clamp_pack(p[3], rb.z, rb.w);
+                        }
+                    }
+#pragma unroll
+                    for (int jj = 0; jj < 4; jj++) { if (byc) o1[jj][bx] = o[jj]; else o0[jj][bx] = o[jj]; }
+                    if (byc) bot[bx] = o[3];
+                    if (bx) rc[byc] = right_column(o);
+                }
+                bA[0] = bot[0]; bA[1] = bot[1]; l0[0] = rc[0]; l0[1] = rc[1];
+                STAMP(4)
+                // ---- loop filter of the plane, block row by block row
+                const int hoff = pl ? HO_V_ROWS : HO_U_ROWS, loff = pl ? HO_V_LINE : HO_U_LINE;
+                if (hand) *(g_u32x2p)(tpc + loff) = (u32x2){ bot[0], bot[1] };        // unfiltered bottom line: hand-over
+                v2u PL[2][4], PH[2][4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    PL[0][j] = col_lo(tF[j][0]); PH[0][j] = col_hi(tF[j][0]);
+                    PL[1][j] = col_lo(tF[j][1]); PH[1][j] = col_hi(tF[j][1]);
+                }
+                u32 s0[4] = { sF[0], sF[1], sF[2], sF[3] }, s1[4] = { sF[4], sF[5], sF[6], sF[7] }, d0[4][2], d1[4][2];
+                lf_block_row<2>(o0, s0, PL, PH, true, gv, gh, L, d0);
+                {   // rows 4..7 of the macroblock above: final
+                    g_u8p pa = (act && !top) ? ras - 4 * ys + c * 8 : (g_u8p)dummy;
+                    const int st = (act && !top) ? ys : 0;
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                        *(g_u32x2p)(pa + j * st) = (u32x2){ d0[j][0] ^ VP8_LF_BIAS, d0[j][1] ^ VP8_LF_BIAS };
+                }
+                lf_block_row<2>(o1, s1, PL, PH, false, gv, gh, L, d1);
+                {   // rows 0..3: the left neighbour's last dword and this macroblock's first
+                    g_u8p po = act ? ras + c * 8 - 4 : (g_u8p)dummy + 16;
+                    const int st = act ? ys : 0;
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                        *(g_u32x2up)(po + j * st) = (u32x2){ s0[j] ^ VP8_LF_BIAS, d1[j][0] ^ VP8_LF_BIAS };
+                }
+                STAMP(5)
+                u32 e[4][2];
+#pragma unroll
+                for (int j = 0; j < 4; j++) { e[j][0] = col_pack(PL[0][j], PH[0][j]); e[j][1] = col_pack(PL[1][j], PH[1][j]); }
+                // the left neighbour's bottom rows are complete now (a lane that is idle, or first in its row, changed nothing)
+#pragma unroll
+                for (int j = 0; j < 4; j++) hF[j][1] = s1[j];
+                if (act) {
+                    if (write_bottom && c > 0) {       // nobody below takes them over: to the frame (last row) or the hand-over tile
+                        g_u8p pbo = last_row ? ras + 4 * ys + (c - 1) * 8 : tpc - VP8_TILE_BYTES + hoff;
+                        const int st = last_row ? ys : 8;
+                        const u32 x = last_row ? VP8_LF_BIAS : 0;         // (the hand-over tile keeps the filter's biased form)
+#pragma unroll
+                        for (int j = 0; j < 4; j++) *(g_u32x2p)(pbo + j * st) = (u32x2){ hF[j][0] ^ x, hF[j][1] ^ x };
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; j++) { sF[j] = d1[j][1]; sF[4 + j] = e[j][1]; pb[j][0] = e[j][0]; }
+                    if (last_col) {        // end of the row: nobody revisits the last dword
+#pragma unroll
+                        for (int j = 0; j < 4; j++) *(GLOBAL_AS u32 *)(ras + j * ys + c * 8 + 4) = d1[j][1] ^ VP8_LF_BIAS;
+                        if (write_bottom) {
+                            g_u8p pbo = last_row ? ras + 4 * ys + c * 8 : tpc + hoff;
+                            const int st = last_row ? ys : 8;
+                            const u32 x = last_row ? VP8_LF_BIAS : 0;
+#pragma unroll
+                            for (int j = 0; j < 4; j++) *(g_u32x2p)(pbo + j * st) = (u32x2){ e[j][0] ^ x, e[j][1] ^ x };
+                        }
+                    }
+                }
+                // ---- the other plane's residuals (or the next macroblock's first): the eight row stores above are younger
+                drain(pl == 0 ? 20 : 16, 0, 8);
+                STAMP(6)
+                // ---- the planes change places
+                SWAP_U32(bA[0], bB[0]) SWAP_U32(bA[1], bB[1]) SWAP_U32(l0[0], l0[2]) SWAP_U32(l0[1], l0[3])
+                SWAP_U32(aA[0], aA[2]) SWAP_U32(aA[1], aA[3])
+                { const int t_ = tlA; tlA = tlB; tlB = t_; }
+                { g_u8p t_ = ras; ras = ras2; ras2 = t_; }
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    SWAP_U32(tF[j][0], tF[j][2]) SWAP_U32(tF[j][1], tF[j][3]) SWAP_U32(hF[j][0], hF[j][2]) SWAP_U32(hF[j][1], hF[j][3])
+                    SWAP_U32(pb[j][0], pb[j][1]) SWAP_U32(sF[j], sF[8 + j]) SWAP_U32(sF[4 + j], sF[12 + j])
+                }
+            }
+            // ---- prediction context of the next step
+            h2[0] = h1[0]; h2[1] = h1[1]; h2[2] = h1[2]; h2[3] = h1[3];
+            h1[0] = act ? bA[0] : h1[0]; h1[1] = act ? bA[1] : h1[1]; h1[2] = act ? bB[0] : h1[2]; h1[3] = act ? bB[1] : h1[3];
+            prevLast = lastU; prevLast2 = lastV;
         }
-        STAMP(13)
-        // ---- hand the chroma half over to the next iteration; the prefetches become plain registers
-#pragma unroll
-        for (int i = 0; i < 4; i++) { lY[i] = nl[i]; p_bY[i] = abv[i]; }
-        prevLastY = aY[3] >> 24; p_lastU = aU[1] >> 24; p_lastV = aV[1] >> 24;
-        p_act = act; p_more = more; p_tp = tpe; p_uv_mode = uv_mode; p_tlU = tlU; p_tlV = tlV; p_up = up; p_lf = lf;
-        p_aU[0] = aU[0]; p_aU[1] = aU[1]; p_aV[0] = aV[0]; p_aV[1] = aV[1]; p_jmc = jm >> 16;
-        p_top = top; p_first = c == 0; p_last = last_row; p_wb = write_bottom; p_hand = hand; p_rb = readback; p_c = c;
-        p_rasU = rasU; p_rasV = rasV; p_L = L; p_gvC = gvC; p_ghC = ghC;
-        nx_m0 = pf_m0; nx_m1 = pf_m1; nx_bm = pf_bm; nx_y2a = pf_y2a; nx_y2b = pf_y2b;
-        asm volatile("" : "+v"(nx_m0), "+v"(nx_m1), "+v"(nx_bm), "+v"(nx_y2a), "+v"(nx_y2b));
-#pragma unroll
-        for (int i = 0; i < 4; i++) nx_aY[i] = pf_aY[i];
-        nx_ar = pf_ar; nx_aU[0] = pf_aU[0]; nx_aU[1] = pf_aU[1]; nx_aV[0] = pf_aV[0]; nx_aV[1] = pf_aV[1];
-        asm volatile("" : "+v"(nx_aY[0]), "+v"(nx_aY[1]), "+v"(nx_aY[2]), "+v"(nx_aY[3]), "+v"(nx_ar), "+v"(nx_aU[0]), "+v"(nx_aU[1]), "+v"(nx_aV[0]), "+v"(nx_aV[1]));
+        if (act) { mbp += 16; cfp += VP8IR_COEF_PER_MB; }
+        p_more = more;
         STAMP(7)
     }
-    STAMP_FLUSH(vp8_stamps_recon)
+    if constexpr (LUMA) { STAMP_FLUSH(vp8_stamps_recon) } else { STAMP_FLUSH(vp8_stamps_lf) }
+}
+
+extern "C" __global__ void __launch_bounds__(64)
+vp8_keyframe_luma_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g, int lgG, int P, int nstrands, uint8_t *dummy)
+{
+    kf_body<true>(jobs, njobs, g, lgG, P, nstrands, dummy);
+}
+extern "C" __global__ void __launch_bounds__(64)
+vp8_keyframe_chroma_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g, int lgG, int P, int nstrands, uint8_t *dummy)
+{
+    kf_body<false>(jobs, njobs, g, lgG, P, nstrands, dummy);
 }

@@ -23,7 +23,8 @@ extern "C" __global__ void vp8_recon_intra_kernel(const DevJob *jobs, int njobs,
 extern "C" __global__ void vp8_recon_intra_xcu_kernel(const DevJob *jobs, int njobs, DevGeom g, unsigned long long *gran, unsigned int epoch,
                                                       int S, int *err, const unsigned int *intra_flags);
 extern "C" __global__ void vp8_inter_mb_kernel(const DevJob *jobs, int njobs, DevGeom g, unsigned int *intra_flags);
-extern "C" __global__ void vp8_keyframe_simt_kernel(const DevJob *jobs, int njobs, DevGeom g, int lgG, int P, int nstrands, uint8_t *dummy);
+extern "C" __global__ void vp8_keyframe_luma_kernel(const DevJob *jobs, int njobs, DevGeom g, int lgG, int P, int nstrands, uint8_t *dummy);
+extern "C" __global__ void vp8_keyframe_chroma_kernel(const DevJob *jobs, int njobs, DevGeom g, int lgG, int P, int nstrands, uint8_t *dummy);
 extern "C" __global__ void vp8_recon_simt_kernel(const DevJob *jobs, int njobs, DevGeom g, int lgG, int P, int nstrands, uint8_t *dummy);
 extern "C" __global__ void vp8_loopfilter_simt_kernel(const DevJob *jobs, int njobs, DevGeom g, int lgG, int P, int nstrands, int raster);
 extern "C" __global__ void vp8_loopfilter_simt_luma_kernel(const DevJob *jobs, int njobs, DevGeom g, int lgG, int P, int nstrands, int raster);
@@ -557,6 +558,19 @@ extern "C" int vp8hip_join(vp8hip_ctx *c)
     return join_detile(c);
 }
 
+// the stream of the chroma half of a split launch (fused key-frame kernels, lane-per-row loop filter)
+static int ensure_stream3(vp8hip_ctx *c)
+{
+    if (c->stream3) return 0;
+    // (a stream of the lowest priority class: the luma kernel, which takes longer, is served first where the two compete)
+    int prio_least = 0, prio_greatest = 0;
+    HIPCHK(c, hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+    HIPCHK(c, hipStreamCreateWithPriority(&c->stream3, hipStreamNonBlocking, prio_least));
+    HIPCHK(c, hipEventCreateWithFlags(&c->ev_split_from, hipEventDisableTiming));
+    HIPCHK(c, hipEventCreateWithFlags(&c->ev_split_done, hipEventDisableTiming));
+    return 0;
+}
+
 extern "C" int vp8hip_decode(vp8hip_ctx *c, const vp8hip_job *jobs, int njobs, int stages)
 {
     if (!c || !jobs || njobs <= 0) return fail(c, -2, "vp8hip_decode: bad arguments");
@@ -752,8 +766,19 @@ extern "C" int vp8hip_decode(vp8hip_ctx *c, const vp8hip_job *jobs, int njobs, i
     c->stats.detile_pass = tiled && !lf_raster;
     if (stages & VP8HIP_STAGE_RECON) {
         if (fused) {
-            hipLaunchKernelGGL(vp8_keyframe_simt_kernel, dim3(simt_waves), dim3(64), 0, c->stream, (const DevJob *)c->d_jobs, njobs,
-                               c->dg, lgG, simtP, simt_waves * spw, c->tile_block[par] + tile_frame * njobs + 4096);
+            // luma and chroma as two kernels side by side: a luma wave (272 registers, 17 KB of LDS) and a chroma wave (232, 12 KB)
+            // share a SIMD, so every SIMD has two instruction streams to issue from.  The chroma kernel goes out on a stream of
+            // its own and the main stream takes it back in before anything reads the frames.
+            if (ensure_stream3(c)) return -1;
+            uint8_t *dummy = c->tile_block[par] + tile_frame * njobs + 4096;
+            HIPCHK(c, hipEventRecord(c->ev_split_from, c->stream));
+            HIPCHK(c, hipStreamWaitEvent(c->stream3, c->ev_split_from, 0));
+            hipLaunchKernelGGL(vp8_keyframe_luma_kernel, dim3(simt_waves), dim3(64), 0, c->stream, (const DevJob *)c->d_jobs, njobs,
+                               c->dg, lgG, simtP, simt_waves * spw, dummy);
+            hipLaunchKernelGGL(vp8_keyframe_chroma_kernel, dim3(simt_waves), dim3(64), 0, c->stream3, (const DevJob *)c->d_jobs, njobs,
+                               c->dg, lgG, simtP, simt_waves * spw, dummy + 1024);
+            HIPCHK(c, hipEventRecord(c->ev_split_done, c->stream3));
+            HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_split_done, 0));
         } else if (simt_recon) {
             hipLaunchKernelGGL(vp8_recon_simt_kernel, dim3(simt_waves), dim3(64), 0, c->stream, (const DevJob *)c->d_jobs, njobs,
                                c->dg, lgG, simtP, simt_waves * spw, c->tile_block[par] + tile_frame * njobs + 4096);
@@ -845,14 +870,7 @@ extern "C" int vp8hip_decode(vp8hip_ctx *c, const vp8hip_job *jobs, int njobs, i
             // luma and chroma as two kernels side by side: a luma wave (268 registers, 25.6 KB of LDS) and a chroma wave (187,
             // 9.2 KB) share a SIMD, so every SIMD has two instruction streams to issue from.  The chroma kernel goes out on
             // a stream of its own behind the recon, and the main stream takes it back in before anything reads the frames.
-            if (!c->stream3) {
-                // (a stream of the lowest priority class: the luma kernel, which takes longer, is served first where the two compete)
-                int prio_least = 0, prio_greatest = 0;
-                HIPCHK(c, hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
-                HIPCHK(c, hipStreamCreateWithPriority(&c->stream3, hipStreamNonBlocking, prio_least));
-                HIPCHK(c, hipEventCreateWithFlags(&c->ev_split_from, hipEventDisableTiming));
-                HIPCHK(c, hipEventCreateWithFlags(&c->ev_split_done, hipEventDisableTiming));
-            }
+            if (ensure_stream3(c)) return -1;
             HIPCHK(c, hipEventRecord(c->ev_split_from, c->stream));
             HIPCHK(c, hipStreamWaitEvent(c->stream3, c->ev_split_from, 0));
             hipLaunchKernelGGL(vp8_loopfilter_simt_luma_kernel, dim3(simt_waves), dim3(64), 0, c->stream, (const DevJob *)c->d_jobs,

@@ -19,12 +19,12 @@ buf = (ctypes.c_ulonglong * 16)()
 ctx.decode_array(jobs, n, 7); ctx.sync()
 L.vp8hip_debug_stamps(ctx.h, 0, buf)
 ctx.decode_array(jobs, n, 7); ctx.sync(); st = ctx.stats()
-names = ["loop overhead", "top: prefetches, prepare next MB, queue its phase 0", "chroma (rest: swaps, setup)", "this-step setup (DPP, row start, gates)",
-         "drain phase 0", "luma loop rest (queue next phase)", "drain phases 1, 2", "hand-over to next iteration", "chroma recon (both planes)",
-         "chroma loop filter + stores", "luma prediction + add (4 block rows)", "luma loop filter (lf_block_row x4)", "luma stores + rotate", "luma bottom rows / row end"]
-L.vp8hip_debug_stamps(ctx.h, 0, buf)
-tot = sum(buf)
-print(f"fused={st.fused}: {tot} cycles in wave 0 ({st.recon_ms:.2f} ms kernel, lf {st.lf_ms:.2f})")
-for i, v in enumerate(buf):
-    if v: print(f"   [{i:2d}] {100.0 * v / tot:5.1f} %  {v:12d} cyc  {names[i] if i < len(names) else ''}")
+names = ["loop overhead", "row start, late phase 0, descriptor request", "step setup (gates, line above, read-back)", "fetch residuals + queue next phase (+ prepare next MB)",
+         "prediction + add", "loop filter (+ row stores, chroma)", "stores/rotate + drain next phase", "bottom rows, context, end of step"]
+for which, kn in ((0, "luma kernel"), (1, "chroma kernel")):
+    L.vp8hip_debug_stamps(ctx.h, which, buf)
+    tot = sum(buf)
+    print(f"{kn} fused={st.fused}: {tot} cycles in wave 0 ({st.recon_ms:.2f} ms for both kernels)")
+    for i, v in enumerate(buf):
+        if v: print(f"   [{i:2d}] {100.0 * v / tot:5.1f} %  {v:12d} cyc  {names[i] if i < len(names) else ''}")
 ctx.close()
