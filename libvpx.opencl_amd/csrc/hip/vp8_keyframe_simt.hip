@@ -56,17 +56,20 @@ enum {
 };
 
 // One block row (four pixel rows) of one plane through the loop filter.  W4: dwords per row (4 luma, 2 chroma).
-//   o[j][x]     in:  rows j = 0..3 of the block row as reconstructed (plain pixels)
-//   s[j]        in:  the last four pixels of the macroblock to the left in these rows (biased), as its own filtering left
-//                    them; out: after this macroblock's left edge
-//   PL/PH[x][j] in:  the four rows above (biased, column pairs), vertical edges done; out: these four rows, vertical edges
-//                    and the edge above them done
-//   top_mb           the edge above is the macroblock's top edge (first block row)
-//   d[j][x]     out: the four rows above, final (biased dwords) -- but for their last dword, which the macroblock to the
-//                    right may still change
-// gv / gh: gates of the vertical-edge and of the horizontal-edge pass (loopfilter.c:265-299)
+//   o[j][x]   in:  rows j = 0..3 of the block row as reconstructed (plain pixels)
+//   s[j]      in:  the last four pixels of the macroblock to the left in these rows (biased), as its own filtering left
+//                  them; out: after this macroblock's left edge
+//   P[j][x]   in:  the four rows above (biased dwords), vertical edges done; out: these four rows, vertical edges and the
+//                  edge above them done
+//   top_mb         the edge above is the macroblock's top edge (first block row)
+//   d[j][x]   out: the four rows above, final (biased dwords) -- but for their last dword, which the macroblock to the
+//                  right may still change
+// gv / gh: gates of the vertical-edge and of the horizontal-edge pass (loopfilter.c:265-299).
+// The rows travel as packed dwords between the stages and are widened to 16-bit pairs one dword column at a time: the
+// widened form of a whole block row and of the rows above it (2 x 32 registers for luma) is what decided whether a luma and
+// a chroma wave fit one SIMD together.
 template <int W4>
-__device__ __forceinline__ void lf_block_row(const u32 (&o)[4][W4], u32 (&s)[4], v2u (&PL)[W4][4], v2u (&PH)[W4][4], const bool top_mb,
+__device__ __forceinline__ void lf_block_row(const u32 (&o)[4][W4], u32 (&s)[4], u32 (&P)[4][W4], const bool top_mb,
                                              const Gates &gv, const Gates &gh, const Lim &L, u32 (&d)[4][W4])
 {
     constexpr int NX = W4 + 1;
@@ -87,61 +90,24 @@ __device__ __forceinline__ void lf_block_row(const u32 (&o)[4][W4], u32 (&s)[4],
         s[0] = perm(t23, t01, 0x05040100u); s[1] = perm(t23, t01, 0x07060302u);
         s[2] = perm(u23, u01, 0x05040100u); s[3] = perm(u23, u01, 0x07060302u);
     }
-    // the block row as column pairs
-    v2u CL[W4][4], CH[W4][4];
+    // the horizontal edge between the rows above (p3..p0) and this block row (q0..q3), one dword column -- two column pairs --
+    // at a time.  (Not skipped when no lane of the wave wants the normal filter: the gates switch it off lane by lane.)
+    const v2u elim_s = top_mb ? L.mblim : L.blim, gate_s = top_mb ? gh.mb_s : gh.inner_s;
 #pragma unroll
     for (int x = 0; x < W4; x++) {
         const u32 a0 = as_u32(a[4 * x + 4]), a1 = as_u32(a[4 * x + 5]), a2 = as_u32(a[4 * x + 6]), a3 = as_u32(a[4 * x + 7]);
         const u32 b0 = as_u32(b[4 * x + 4]), b1 = as_u32(b[4 * x + 5]), b2 = as_u32(b[4 * x + 6]), b3 = as_u32(b[4 * x + 7]);
-        CL[x][0] = as_v2u(perm(a1, a0, 0x050c010cu)); CL[x][1] = as_v2u(perm(a1, a0, 0x070c030cu));
-        CH[x][0] = as_v2u(perm(a3, a2, 0x050c010cu)); CH[x][1] = as_v2u(perm(a3, a2, 0x070c030cu));
-        CL[x][2] = as_v2u(perm(b1, b0, 0x050c010cu)); CL[x][3] = as_v2u(perm(b1, b0, 0x070c030cu));
-        CH[x][2] = as_v2u(perm(b3, b2, 0x050c010cu)); CH[x][3] = as_v2u(perm(b3, b2, 0x070c030cu));
-    }
-    // the horizontal edge between the rows above (p3..p0) and this block row (q0..q3).  (Not skipped when no lane of the wave
-    // wants the normal filter -- the gates switch it off lane by lane --: a branch around it costs ~90 registers, the 64 values
-    // in flight doubled at the join.)
-    {
-        if (top_mb) {
+        v2u p[8] = { col_lo(P[0][x]), col_lo(P[1][x]), col_lo(P[2][x]), col_lo(P[3][x]),
+                     as_v2u(perm(a1, a0, 0x050c010cu)), as_v2u(perm(a1, a0, 0x070c030cu)), as_v2u(perm(b1, b0, 0x050c010cu)), as_v2u(perm(b1, b0, 0x070c030cu)) };
+        v2u q[8] = { col_hi(P[0][x]), col_hi(P[1][x]), col_hi(P[2][x]), col_hi(P[3][x]),
+                     as_v2u(perm(a3, a2, 0x050c010cu)), as_v2u(perm(a3, a2, 0x070c030cu)), as_v2u(perm(b3, b2, 0x050c010cu)), as_v2u(perm(b3, b2, 0x070c030cu)) };
+        if (top_mb) { lf_mbedge(p, L, gh.mb); lf_mbedge(q, L, gh.mb); }
+        else { lf_inner(p, L, gh.inner); lf_inner(q, L, gh.inner); }
+        if (gh.any_simple) { lf_simple(p, elim_s, L.one, gate_s); lf_simple(q, elim_s, L.one, gate_s); }
+        // the rows above are done; this block row takes their place
 #pragma unroll
-            for (int x = 0; x < W4; x++) {
-                v2u p[8] = { PL[x][0], PL[x][1], PL[x][2], PL[x][3], CL[x][0], CL[x][1], CL[x][2], CL[x][3] };
-                v2u q[8] = { PH[x][0], PH[x][1], PH[x][2], PH[x][3], CH[x][0], CH[x][1], CH[x][2], CH[x][3] };
-                lf_mbedge(p, L, gh.mb); lf_mbedge(q, L, gh.mb);
-#pragma unroll
-                for (int j = 0; j < 4; j++) { PL[x][j] = p[j]; CL[x][j] = p[4 + j]; PH[x][j] = q[j]; CH[x][j] = q[4 + j]; }
-                __builtin_amdgcn_sched_barrier(0);      // two lines' worth of temporaries at a time, not 2 * W4
-            }
-        } else {
-#pragma unroll
-            for (int x = 0; x < W4; x++) {
-                v2u p[8] = { PL[x][0], PL[x][1], PL[x][2], PL[x][3], CL[x][0], CL[x][1], CL[x][2], CL[x][3] };
-                v2u q[8] = { PH[x][0], PH[x][1], PH[x][2], PH[x][3], CH[x][0], CH[x][1], CH[x][2], CH[x][3] };
-                lf_inner(p, L, gh.inner); lf_inner(q, L, gh.inner);
-#pragma unroll
-                for (int j = 0; j < 4; j++) { PL[x][j] = p[j]; CL[x][j] = p[4 + j]; PH[x][j] = q[j]; CH[x][j] = q[4 + j]; }
-                __builtin_amdgcn_sched_barrier(0);      // two lines' worth of temporaries at a time, not 2 * W4
-            }
-        }
-    }
-    if (gh.any_simple) {
-        const v2u elim = top_mb ? L.mblim : L.blim, gate = top_mb ? gh.mb_s : gh.inner_s;
-#pragma unroll
-        for (int x = 0; x < W4; x++) {
-            v2u p[8] = { PL[x][0], PL[x][1], PL[x][2], PL[x][3], CL[x][0], CL[x][1], CL[x][2], CL[x][3] };
-            v2u q[8] = { PH[x][0], PH[x][1], PH[x][2], PH[x][3], CH[x][0], CH[x][1], CH[x][2], CH[x][3] };
-            lf_simple(p, elim, L.one, gate); lf_simple(q, elim, L.one, gate);
-            PL[x][3] = p[3]; CL[x][0] = p[4]; PH[x][3] = q[3]; CH[x][0] = q[4];
-        }
-    }
-    // the rows above are done; this block row takes their place
-#pragma unroll
-    for (int x = 0; x < W4; x++) {
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            d[j][x] = col_pack(PL[x][j], PH[x][j]);
-            PL[x][j] = CL[x][j]; PH[x][j] = CH[x][j];
-        }
+        for (int j = 0; j < 4; j++) { d[j][x] = col_pack(p[j], q[j]); P[j][x] = col_pack(p[4 + j], q[4 + j]); }
+        __builtin_amdgcn_sched_barrier(0);      // two lines' worth of temporaries at a time, not 2 * W4
     }
 }
 
@@ -158,6 +124,9 @@ __device__ __forceinline__ void frame_levels(const vp8ir_frame_hdr &h, u32 &plai
     }
 }
 
+#ifndef KF_SHIFT
+#define KF_SHIFT 4        // (timing experiments only: 0 = row pieces at their aligned, wrong, place)
+#endif
 #define SWAP_U32(a, b) { const u32 t_ = (a); (a) = (b); (b) = t_; }
 
 } // namespace
@@ -193,6 +162,10 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
     __shared__ __attribute__((aligned(16))) u32x4 s_tab[64];                // per owner: coefficient pointer (lo, hi), quantiser
     __shared__ __attribute__((aligned(16))) u32 s_y2dc[LUMA ? 64 * 8 : 4];  // per owner: the sixteen luma DCs out of the Y2 block
     __shared__ __attribute__((aligned(16))) u32 s_desc[NDESC * 64 * 4];     // [piece][lane] 16 B: the next macroblock's descriptor
+    // the last four pixels (filtered, biased) of every pixel row of the macroblock to the left, [row][lane]: luma rows 0..15;
+    // chroma U rows 0..7, V rows 8..15.  Per-lane state that is read and written once per step and indexed by the block row:
+    // in LDS it costs no registers and no rotation
+    __shared__ u32 s_sf[16 * 64];
     const int lane = threadIdx.x;
     const int G = 1 << lgG;
     const int pos = lane & (G - 1);
@@ -227,12 +200,13 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
     // and two steps ago.  Chroma: U in [0..1], V in [2..3].
     u32 l0[4] = { 0, 0, 0, 0 }, h1[4] = { 0, 0, 0, 0 }, h2[4] = { 0, 0, 0, 0 };
     int prevLast = 0, prevLast2 = 0;            // last pixel of the previous step's line above: Y, or U and V
-    // ---- loop-filter context (filtered, biased).  Luma: sF[16] the last four pixels of every row of the macroblock to the left,
-    // pb[j][0..2] the first twelve of its bottom four rows, hF[j][0..3] the bottom four rows of the macroblock finished two steps
-    // ago (what the lane below asks for).  Chroma: U in sF[0..7], pb[j][0], hF[j][0..1]; V in sF[8..15], pb[j][1], hF[j][2..3].
-    u32 sF[16], pb[4][3], hF[4][4];
+    // ---- loop-filter context (filtered, biased), besides s_sf.  Luma: pb[j][0..2] the first twelve pixels of the bottom four rows of
+    // the macroblock to the left, hF[j][0..3] the bottom four rows of the macroblock finished two steps ago (what the lane below
+    // asks for).  Chroma: U in pb[j][0], hF[j][0..1]; V in pb[j][1], hF[j][2..3].
+    u32 pb[4][3], hF[4][4];
+    u32 *const sF = s_sf + lane;
 #pragma unroll
-    for (int i = 0; i < 16; i++) sF[i] = 0;
+    for (int i = 0; i < 16; i++) sF[i * 64] = 0;
 #pragma unroll
     for (int j = 0; j < 4; j++) { pb[j][0] = pb[j][1] = pb[j][2] = 0; hF[j][0] = hF[j][1] = hF[j][2] = hF[j][3] = 0; }
     // ---- the macroblock after the current one, prepared at the end of the step before: descriptor words 0, 1, sub-block modes;
@@ -420,8 +394,8 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
         for (int j = 0; j < 4; j++) {
 #pragma unroll
             for (int i = 0; i < 4; i++) tF[j][i] = from_lane_above(hF[j][i]);
-            if constexpr (LUMA) { hF[j][0] = pb[j][0]; hF[j][1] = pb[j][1]; hF[j][2] = pb[j][2]; hF[j][3] = sF[12 + j]; }
-            else { hF[j][0] = pb[j][0]; hF[j][1] = sF[4 + j]; hF[j][2] = pb[j][1]; hF[j][3] = sF[12 + j]; }
+            if constexpr (LUMA) { hF[j][0] = pb[j][0]; hF[j][1] = pb[j][1]; hF[j][2] = pb[j][2]; hF[j][3] = sF[(12 + j) * 64]; }
+            else { hF[j][0] = pb[j][0]; hF[j][1] = sF[(4 + j) * 64]; hF[j][2] = pb[j][1]; hF[j][3] = sF[(12 + j) * 64]; }
         }
         const bool act = c >= 0 && c < cols && V < Vmax;
         const bool late = act && !p_more;        // first macroblock of a row: nothing was prepared a step ahead
@@ -538,13 +512,7 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
             u32 abv[4] = { aA[0], aA[1], aA[2], aA[3] };      // line above the current block row (B_PRED chain)
             int tlrow = tlY;                                   // top-left of the block row's first block
             u32 nl[4] = { 0, 0, 0, 0 };                        // right column of this macroblock = left of the next
-            // the filter's rows above the first block row: rows 12..15 of the macroblock above, as column pairs
-            v2u PL[4][4], PH[4][4];
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-#pragma unroll
-                for (int x = 0; x < 4; x++) { PL[x][j] = col_lo(tF[j][x]); PH[x][j] = col_hi(tF[j][x]); }
-            }
+            // the filter's rows above the first block row: rows 12..15 of the macroblock above (tF); from then on the block row before
             u32 sfix[4] = { 0, 0, 0, 0 };             // the left neighbour's last dword in the rows above the current block row, fixed up
             // where the rows above the current block row go: first the macroblock above (aligned), then this one (shifted left by 4)
             g_u8p prow = (act && !top) ? ras - 4 * ys + c * 16 : (g_u8p)dummy + 16;
@@ -557,6 +525,7 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
                 const u32 rmg = jm >> (by * 4);
                 if (by < 3) {
                     fetch(at4, rr);
+                    STAMP(8)
                     at4 = queue(4 * by + 4, (jm >> (4 * by + 4)) & 0xf, dc_given, 0);
                 } else {
                     // (all of this macroblock's phases have been transformed: its entries of s_tab / s_y2dc are free)
@@ -571,7 +540,9 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
                         nx_w0 = m0.x; nx_w1 = m0.y; nx_jm = n_jm; nx_dcg = n_dcg;
                     }
                     asm volatile("ds_read_b128 %0, %1 offset:2048\n\ts_waitcnt lgkmcnt(0)" : "=&v"(nx_bm) : "v"(desc_lane) : "memory");
+                    STAMP(9)
                     fetch(at4, rr);
+                    STAMP(8)
                     nx_at4 = queue(0, n_jm & 0xf, n_dcg, 0);
                 }
                 STAMP(3)
@@ -610,8 +581,8 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
                 nl[0] = nl[1]; nl[1] = nl[2]; nl[2] = nl[3]; nl[3] = left;
                 STAMP(4)
                 // ---- loop filter: the vertical edges of this block row, the horizontal edge above it; the rows above are final
-                u32 sb[4] = { sF[0], sF[1], sF[2], sF[3] }, d[4][4];
-                lf_block_row<4>(orow, sb, PL, PH, by == 0, gv, gh, L, d);
+                u32 sb[4] = { sF[(4 * by) * 64], sF[(4 * by + 1) * 64], sF[(4 * by + 2) * 64], sF[(4 * by + 3) * 64] }, d[4][4];
+                lf_block_row<4>(orow, sb, tF, by == 0, gv, gh, L, d);
                 STAMP(5)
                 const bool first = by == 0;
 #pragma unroll
@@ -619,32 +590,21 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
                     const u32x4 v = first ? (u32x4){ d[j][0], d[j][1], d[j][2], d[j][3] } : (u32x4){ sfix[j], d[j][0], d[j][1], d[j][2] };
                     *(g_u32x4up)(prow + j * pstride) = v ^ VP8_LF_BIAS;
                 }
-                // rotate: the next block row's left context comes to the front, this macroblock's last dwords queue up behind
+                // the rows just written keep their last dword for the next macroblock's left edge
 #pragma unroll
-                for (int i = 0; i < 12; i++) sF[i] = sF[i + 4];
-#pragma unroll
-                for (int j = 0; j < 4; j++) { sF[12 + j] = d[j][3]; sfix[j] = sb[j]; }
-                prow = act ? (first ? ras + c * 16 - 4 : prow + 4 * ys) : (g_u8p)dummy + 16;
+                for (int j = 0; j < 4; j++) { if (act && !first) sF[(4 * by - 4 + j) * 64] = d[j][3]; sfix[j] = sb[j]; }
+                prow = act ? (first ? ras + c * 16 - KF_SHIFT : prow + 4 * ys) : (g_u8p)dummy + 16;
                 pstride = act ? ys : 0;
+                STAMP(10)
                 // ---- the next phase's residuals (its coefficients have landed: the four row stores above are younger)
                 drain(by < 3 ? 4 * by + 4 : 0, 0, 4);
                 STAMP(6)
             }
             // ---- the bottom four rows stay (the lane below finishes them); the left neighbour's are complete now
             {
-                u32 e[4][4];
+                u32 (&e)[4][4] = tF;             // rows 12..15 as the last block row left them
 #pragma unroll
-                for (int j = 0; j < 4; j++) {
-#pragma unroll
-                    for (int x = 0; x < 4; x++) e[j][x] = col_pack(PL[x][j], PH[x][j]);
-                    hF[j][3] = sfix[j];
-                }
-                // (sF: [junk of the first rotation, rows 0..3, 4..7, 8..11] -> rows 0..15)
-                u32 ns[16];
-#pragma unroll
-                for (int i = 0; i < 12; i++) ns[i] = sF[i + 4];
-#pragma unroll
-                for (int j = 0; j < 4; j++) ns[12 + j] = e[j][3];
+                for (int j = 0; j < 4; j++) hF[j][3] = sfix[j];
                 if (act) {
                     if (hand) *(g_u32x4p)(tpc + HO_Y_LINE) = (u32x4){ abv[0], abv[1], abv[2], abv[3] };     // unfiltered bottom line
                     if (write_bottom && c > 0) {
@@ -655,12 +615,10 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
                         for (int j = 0; j < 4; j++) *(g_u32x4p)(pbo + j * st) = (u32x4){ hF[j][0], hF[j][1], hF[j][2], hF[j][3] } ^ x;
                     }
 #pragma unroll
-                    for (int i = 0; i < 16; i++) sF[i] = ns[i];
-#pragma unroll
-                    for (int j = 0; j < 4; j++) { pb[j][0] = e[j][0]; pb[j][1] = e[j][1]; pb[j][2] = e[j][2]; }
+                    for (int j = 0; j < 4; j++) { sF[(12 + j) * 64] = e[j][3]; pb[j][0] = e[j][0]; pb[j][1] = e[j][1]; pb[j][2] = e[j][2]; }
                     if (last_col) {          // end of the row: nobody revisits the last dwords
 #pragma unroll
-                        for (int y = 0; y < 12; y++) *(GLOBAL_AS u32 *)(ras + y * ys + c * 16 + 12) = ns[y] ^ VP8_LF_BIAS;
+                        for (int y = 0; y < 12; y++) *(GLOBAL_AS u32 *)(ras + y * ys + c * 16 + 12) = sF[y * 64] ^ VP8_LF_BIAS;
                         if (write_bottom) {
                             g_u8p pbo = last_row ? ras + 12 * ys + c * 16 : tpc + HO_Y_ROWS;
                             const int st = last_row ? ys : 16;
@@ -677,8 +635,8 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
             prevLast = aA[3] >> 24;
         } else {
             // ======================= chroma: U, then V =======================
-            // The loop body works on "U" (l0[0..1], aA[0..1], sF[0..7], pb[j][0], hF[j][0..1], tF[j][0..1], ras); the two planes'
-            // state changes places at its end.
+            // The loop body works on "U" (l0[0..1], aA[0..1], pb[j][0], hF[j][0..1], tF[j][0..1], ras); the two planes' state
+            // changes places at its end.
             int tlA = top ? 127 : (c == 0 ? 129 : prevLast), tlB = top ? 127 : (c == 0 ? 129 : prevLast2);
             const int lastU = aA[1] >> 24, lastV = aA[3] >> 24;
             u32 bA[2] = { 0, 0 }, bB[2] = { 0, 0 };           // unfiltered bottom lines of the two planes
@@ -733,14 +691,13 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
                 // ---- loop filter of the plane, block row by block row
                 const int hoff = pl ? HO_V_ROWS : HO_U_ROWS, loff = pl ? HO_V_LINE : HO_U_LINE;
                 if (hand) *(g_u32x2p)(tpc + loff) = (u32x2){ bot[0], bot[1] };        // unfiltered bottom line: hand-over
-                v2u PL[2][4], PH[2][4];
+                u32 Pc[4][2];
 #pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    PL[0][j] = col_lo(tF[j][0]); PH[0][j] = col_hi(tF[j][0]);
-                    PL[1][j] = col_lo(tF[j][1]); PH[1][j] = col_hi(tF[j][1]);
-                }
-                u32 s0[4] = { sF[0], sF[1], sF[2], sF[3] }, s1[4] = { sF[4], sF[5], sF[6], sF[7] }, d0[4][2], d1[4][2];
-                lf_block_row<2>(o0, s0, PL, PH, true, gv, gh, L, d0);
+                for (int j = 0; j < 4; j++) { Pc[j][0] = tF[j][0]; Pc[j][1] = tF[j][1]; }
+                u32 *const sP = sF + pl * 8 * 64;        // this plane's rows
+                u32 s0[4] = { sP[0], sP[64], sP[128], sP[192] }, s1[4] = { sP[256], sP[320], sP[384], sP[448] }, d0[4][2], d1[4][2];
+                lf_block_row<2>(o0, s0, Pc, true, gv, gh, L, d0);
+                STAMP(11)
                 {   // rows 4..7 of the macroblock above: final
                     g_u8p pa = (act && !top) ? ras - 4 * ys + c * 8 : (g_u8p)dummy;
                     const int st = (act && !top) ? ys : 0;
@@ -748,18 +705,18 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
                     for (int j = 0; j < 4; j++)
                         *(g_u32x2p)(pa + j * st) = (u32x2){ d0[j][0] ^ VP8_LF_BIAS, d0[j][1] ^ VP8_LF_BIAS };
                 }
-                lf_block_row<2>(o1, s1, PL, PH, false, gv, gh, L, d1);
+                STAMP(12)
+                lf_block_row<2>(o1, s1, Pc, false, gv, gh, L, d1);
+                STAMP(11)
                 {   // rows 0..3: the left neighbour's last dword and this macroblock's first
-                    g_u8p po = act ? ras + c * 8 - 4 : (g_u8p)dummy + 16;
+                    g_u8p po = act ? ras + c * 8 - KF_SHIFT : (g_u8p)dummy + 16;
                     const int st = act ? ys : 0;
 #pragma unroll
                     for (int j = 0; j < 4; j++)
                         *(g_u32x2up)(po + j * st) = (u32x2){ s0[j] ^ VP8_LF_BIAS, d1[j][0] ^ VP8_LF_BIAS };
                 }
-                STAMP(5)
-                u32 e[4][2];
-#pragma unroll
-                for (int j = 0; j < 4; j++) { e[j][0] = col_pack(PL[0][j], PH[0][j]); e[j][1] = col_pack(PL[1][j], PH[1][j]); }
+                STAMP(12)
+                u32 (&e)[4][2] = Pc;             // rows 4..7 as the second block row left them
                 // the left neighbour's bottom rows are complete now (a lane that is idle, or first in its row, changed nothing)
 #pragma unroll
                 for (int j = 0; j < 4; j++) hF[j][1] = s1[j];
@@ -772,7 +729,7 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
                         for (int j = 0; j < 4; j++) *(g_u32x2p)(pbo + j * st) = (u32x2){ hF[j][0] ^ x, hF[j][1] ^ x };
                     }
 #pragma unroll
-                    for (int j = 0; j < 4; j++) { sF[j] = d1[j][1]; sF[4 + j] = e[j][1]; pb[j][0] = e[j][0]; }
+                    for (int j = 0; j < 4; j++) { sP[j * 64] = d1[j][1]; sP[(4 + j) * 64] = e[j][1]; pb[j][0] = e[j][0]; }
                     if (last_col) {        // end of the row: nobody revisits the last dword
 #pragma unroll
                         for (int j = 0; j < 4; j++) *(GLOBAL_AS u32 *)(ras + j * ys + c * 8 + 4) = d1[j][1] ^ VP8_LF_BIAS;
@@ -796,7 +753,7 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     SWAP_U32(tF[j][0], tF[j][2]) SWAP_U32(tF[j][1], tF[j][3]) SWAP_U32(hF[j][0], hF[j][2]) SWAP_U32(hF[j][1], hF[j][3])
-                    SWAP_U32(pb[j][0], pb[j][1]) SWAP_U32(sF[j], sF[8 + j]) SWAP_U32(sF[4 + j], sF[12 + j])
+                    SWAP_U32(pb[j][0], pb[j][1])
                 }
             }
             // ---- prediction context of the next step
