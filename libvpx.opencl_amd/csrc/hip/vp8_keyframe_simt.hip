@@ -152,30 +152,30 @@ __device__ __forceinline__ void frame_levels(const vp8ir_frame_hdr &h, u32 &plai
 // coefficients are requested into the same buffer (they are then on their way during the owner's prediction + filtering of
 // the current phase).  The macroblock descriptors of the next step come by LDS-DMA too (a 16-byte slot per lane and piece),
 // not through registers held for a step.
+// LDS of a wave, whichever role it plays (19 KB: eight waves per CU, two per SIMD):
+//   s_stage  [round][half][lane] 16 B: coefficients in, residuals out        8192 B
+//   s_queue  owner lane | block in phase << 6 | DC given << 8                 512 B
+//   s_tab    per owner: coefficient offset (32-byte units from ir_base), quantiser   512 B
+//   s_y2dc   per owner: the sixteen luma DCs out of the Y2 block (luma)      2048 B
+//   s_desc   [piece][lane] 16 B: the next macroblock's descriptor (luma 5 pieces, chroma 2)   5120 B
+//   s_sf     [row][lane]: the last four pixels (filtered, biased) of pixel rows of the macroblock to the left -- luma rows 0..11,
+//            chroma U rows 0..3, V rows 0..3 (the bottom four rows' are in registers: they double as the lane below's context).
+//            Per-lane state read and written once per step and indexed by the block row: in LDS it costs no registers    3072 B
 template <bool LUMA>
-__device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njobs, DevGeom g, int lgG, int P, int nstrands, uint8_t *dummy)
+__device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njobs, DevGeom g, int lgG, int P, int nstrands, uint8_t *dummy,
+                                        const int wave, const char *ir_base, u32 *s_stage, unsigned short *s_queue, u32x2 *s_tab,
+                                        u32 *s_y2dc, u32 *s_desc, u32 *s_sf)
 {
-    constexpr int NDESC = LUMA ? 5 : 2;           // descriptor pieces per macroblock: words 0-3, 4-7 (+ sub-block modes, Y2 block)
-    constexpr int NPH = LUMA ? 4 : 2;             // phases per macroblock
-    __shared__ __attribute__((aligned(16))) u32 s_stage[4 * 2 * 64 * 4];   // [round][half][lane] 16 B: coefficients in, residuals out
-    __shared__ u32 s_queue[256];                                            // owner lane | block in phase << 6 | DC given << 8
-    __shared__ __attribute__((aligned(16))) u32x4 s_tab[64];                // per owner: coefficient pointer (lo, hi), quantiser
-    __shared__ __attribute__((aligned(16))) u32 s_y2dc[LUMA ? 64 * 8 : 4];  // per owner: the sixteen luma DCs out of the Y2 block
-    __shared__ __attribute__((aligned(16))) u32 s_desc[NDESC * 64 * 4];     // [piece][lane] 16 B: the next macroblock's descriptor
-    // the last four pixels (filtered, biased) of every pixel row of the macroblock to the left, [row][lane]: luma rows 0..15;
-    // chroma U rows 0..7, V rows 8..15.  Per-lane state that is read and written once per step and indexed by the block row:
-    // in LDS it costs no registers and no rotation
-    __shared__ u32 s_sf[16 * 64];
     const int lane = threadIdx.x;
     const int G = 1 << lgG;
     const int pos = lane & (G - 1);
     const int spw = 64 >> lgG;
-    const int strand = blockIdx.x * spw + (lane >> lgG);
+    const int strand = wave * spw + (lane >> lgG);
     const int cols = g.mb_cols, rows = g.mb_rows;
     const long rowbytes = (long)cols * VP8_TILE_BYTES;
     const int myjobs = strand < njobs ? (njobs - strand + nstrands - 1) / nstrands : 0;
     const int Vmax = myjobs * rows;
-    const int wavejobs = (njobs - (int)blockIdx.x * spw + nstrands - 1) / nstrands;
+    const int wavejobs = (njobs - wave * spw + nstrands - 1) / nstrands;
     const int T = ((wavejobs * rows + G - 1) >> lgG) * P + 2 * (G - 1);
     const u32 stage_lane = (u32)(unsigned long)(lds_vp)s_stage + lane * 16;     // LDS byte address of this lane's slot of round 0, half 0
     const u32 stage_base = (u32)(unsigned long)(lds_vp)s_stage;
@@ -195,7 +195,7 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
     for (int s = 0; s < 4; s++) dqs[s][0] = dqs[s][1] = 0;
     u32 lv_plain = 0, lv_bpred = 0;
     int sharp = 0; bool simple = false;
-    s_tab[lane] = (u32x4){ (u32)(unsigned long)cfp, (u32)((unsigned long)cfp >> 32), 0u, 0u };
+    s_tab[lane] = (u32x2){ (u32)(((const char *)jobs[0].coef - ir_base) >> 5), 0u };
     // ---- prediction context (unfiltered).  Luma: l0[0..3] left column, h1/h2[0..3] bottom lines of the macroblocks finished one
     // and two steps ago.  Chroma: U in [0..1], V in [2..3].
     u32 l0[4] = { 0, 0, 0, 0 }, h1[4] = { 0, 0, 0, 0 }, h2[4] = { 0, 0, 0, 0 };
@@ -205,8 +205,9 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
     // asks for).  Chroma: U in pb[j][0], hF[j][0..1]; V in pb[j][1], hF[j][2..3].
     u32 pb[4][3], hF[4][4];
     u32 *const sF = s_sf + lane;
+    u32 sB[4] = { 0, 0, 0, 0 }, sB2[4] = { 0, 0, 0, 0 };      // the left neighbour's last dword in the bottom four rows (chroma: U, V)
 #pragma unroll
-    for (int i = 0; i < 16; i++) sF[i * 64] = 0;
+    for (int i = 0; i < 12; i++) sF[i * 64] = 0;
 #pragma unroll
     for (int j = 0; j < 4; j++) { pb[j][0] = pb[j][1] = pb[j][2] = 0; hF[j][0] = hF[j][1] = hF[j][2] = hF[j][3] = 0; }
     // ---- the macroblock after the current one, prepared at the end of the step before: descriptor words 0, 1, sub-block modes;
@@ -227,7 +228,7 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
             const bool b = (m4 >> i) & 1;
             const unsigned long long bal = __builtin_amdgcn_ballot_w64(b);
             const u32 at = __builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, (u32)n));
-            if (b) { s_queue[at] = (u32)lane | ((u32)i << 6) | (dcg << 8); at4 |= at << (8 * i); }
+            if (b) { s_queue[at] = (unsigned short)((u32)lane | ((u32)i << 6) | (dcg << 8)); at4 |= at << (8 * i); }
             n += __builtin_popcountll(bal);
         }
         q_n = n;
@@ -238,8 +239,8 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
             const int idx = rr * 64 + lane;
             if (idx >= n0 && idx < n) {
                 const u32 ent = s_queue[idx];
-                const u32x4 tb = s_tab[ent & 63];
-                g_cs16p cf = (g_cs16p)(((unsigned long)tb.y << 32) | tb.x) + (blk0 + (int)((ent >> 6) & 3)) * 16;
+                const u32x2 tb = s_tab[ent & 63];
+                g_cs16p cf = (g_cs16p)(ir_base + ((unsigned long)tb.x << 5)) + (blk0 + (int)((ent >> 6) & 3)) * 16;
                 __builtin_amdgcn_global_load_lds((g_cvp)cf, (lds_vp)(s_stage + rr * 512), 16, 0, 0);
                 __builtin_amdgcn_global_load_lds((g_cvp)(cf + 8), (lds_vp)(s_stage + rr * 512 + 256), 16, 0, 0);
             }
@@ -262,8 +263,7 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
                 const u32 ent = s_queue[idx];
                 const int owner = ent & 63, i = (ent >> 6) & 3;
                 const bool given = (ent >> 8) & 1;
-                const u32x4 tb = s_tab[owner];
-                const u32 dq = tb.z;
+                const u32 dq = s_tab[owner].y;
                 u32x4 ca, cb;
                 asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024\n\ts_waitcnt lgkmcnt(0)"
                              : "=&v"(ca), "=&v"(cb) : "v"(stage_lane + rr * 2048) : "memory");
@@ -331,7 +331,7 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
         if (skip) m = 0;
         jm = m;
         dcg = LUMA && has_y2 && !skip;
-        s_tab[lane] = (u32x4){ (u32)(unsigned long)cf, (u32)((unsigned long)cf >> 32), dq0, 0u };
+        s_tab[lane] = (u32x2){ (u32)(((const char *)cf - ir_base) >> 5), dq0 };
         if constexpr (LUMA) {
             // Y2: vp8_dequantize_b + vp8_short_inv_walsh4x4_c (idctllm.c:140-192) -> the 16 luma DCs.  With nothing but a DC
             // coefficient the full transform gives what vp8_short_inv_walsh4x4_1_c gives (decodframe.c:282-285).
@@ -394,8 +394,8 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
         for (int j = 0; j < 4; j++) {
 #pragma unroll
             for (int i = 0; i < 4; i++) tF[j][i] = from_lane_above(hF[j][i]);
-            if constexpr (LUMA) { hF[j][0] = pb[j][0]; hF[j][1] = pb[j][1]; hF[j][2] = pb[j][2]; hF[j][3] = sF[(12 + j) * 64]; }
-            else { hF[j][0] = pb[j][0]; hF[j][1] = sF[(4 + j) * 64]; hF[j][2] = pb[j][1]; hF[j][3] = sF[(12 + j) * 64]; }
+            if constexpr (LUMA) { hF[j][0] = pb[j][0]; hF[j][1] = pb[j][1]; hF[j][2] = pb[j][2]; hF[j][3] = sB[j]; }
+            else { hF[j][0] = pb[j][0]; hF[j][1] = sB[j]; hF[j][2] = pb[j][1]; hF[j][3] = sB2[j]; }
         }
         const bool act = c >= 0 && c < cols && V < Vmax;
         const bool late = act && !p_more;        // first macroblock of a row: nothing was prepared a step ahead
@@ -581,7 +581,9 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
                 nl[0] = nl[1]; nl[1] = nl[2]; nl[2] = nl[3]; nl[3] = left;
                 STAMP(4)
                 // ---- loop filter: the vertical edges of this block row, the horizontal edge above it; the rows above are final
-                u32 sb[4] = { sF[(4 * by) * 64], sF[(4 * by + 1) * 64], sF[(4 * by + 2) * 64], sF[(4 * by + 3) * 64] }, d[4][4];
+                const int byr = by < 3 ? by : 2;
+                u32 sb[4] = { sF[(4 * byr) * 64], sF[(4 * byr + 1) * 64], sF[(4 * byr + 2) * 64], sF[(4 * byr + 3) * 64] }, d[4][4];
+                if (by == 3) { sb[0] = sB[0]; sb[1] = sB[1]; sb[2] = sB[2]; sb[3] = sB[3]; }
                 lf_block_row<4>(orow, sb, tF, by == 0, gv, gh, L, d);
                 STAMP(5)
                 const bool first = by == 0;
@@ -615,7 +617,7 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
                         for (int j = 0; j < 4; j++) *(g_u32x4p)(pbo + j * st) = (u32x4){ hF[j][0], hF[j][1], hF[j][2], hF[j][3] } ^ x;
                     }
 #pragma unroll
-                    for (int j = 0; j < 4; j++) { sF[(12 + j) * 64] = e[j][3]; pb[j][0] = e[j][0]; pb[j][1] = e[j][1]; pb[j][2] = e[j][2]; }
+                    for (int j = 0; j < 4; j++) { sB[j] = e[j][3]; pb[j][0] = e[j][0]; pb[j][1] = e[j][1]; pb[j][2] = e[j][2]; }
                     if (last_col) {          // end of the row: nobody revisits the last dwords
 #pragma unroll
                         for (int y = 0; y < 12; y++) *(GLOBAL_AS u32 *)(ras + y * ys + c * 16 + 12) = sF[y * 64] ^ VP8_LF_BIAS;
@@ -694,8 +696,8 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
                 u32 Pc[4][2];
 #pragma unroll
                 for (int j = 0; j < 4; j++) { Pc[j][0] = tF[j][0]; Pc[j][1] = tF[j][1]; }
-                u32 *const sP = sF + pl * 8 * 64;        // this plane's rows
-                u32 s0[4] = { sP[0], sP[64], sP[128], sP[192] }, s1[4] = { sP[256], sP[320], sP[384], sP[448] }, d0[4][2], d1[4][2];
+                u32 *const sP = sF + pl * 4 * 64;        // this plane's rows 0..3
+                u32 s0[4] = { sP[0], sP[64], sP[128], sP[192] }, s1[4] = { sB[0], sB[1], sB[2], sB[3] }, d0[4][2], d1[4][2];
                 lf_block_row<2>(o0, s0, Pc, true, gv, gh, L, d0);
                 STAMP(11)
                 {   // rows 4..7 of the macroblock above: final
@@ -729,7 +731,7 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
                         for (int j = 0; j < 4; j++) *(g_u32x2p)(pbo + j * st) = (u32x2){ hF[j][0] ^ x, hF[j][1] ^ x };
                     }
 #pragma unroll
-                    for (int j = 0; j < 4; j++) { sP[j * 64] = d1[j][1]; sP[(4 + j) * 64] = e[j][1]; pb[j][0] = e[j][0]; }
+                    for (int j = 0; j < 4; j++) { sP[j * 64] = d1[j][1]; sB[j] = e[j][1]; pb[j][0] = e[j][0]; }
                     if (last_col) {        // end of the row: nobody revisits the last dword
 #pragma unroll
                         for (int j = 0; j < 4; j++) *(GLOBAL_AS u32 *)(ras + j * ys + c * 8 + 4) = d1[j][1] ^ VP8_LF_BIAS;
@@ -753,7 +755,7 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     SWAP_U32(tF[j][0], tF[j][2]) SWAP_U32(tF[j][1], tF[j][3]) SWAP_U32(hF[j][0], hF[j][2]) SWAP_U32(hF[j][1], hF[j][3])
-                    SWAP_U32(pb[j][0], pb[j][1])
+                    SWAP_U32(pb[j][0], pb[j][1]) SWAP_U32(sB[j], sB2[j])
                 }
             }
             // ---- prediction context of the next step
@@ -765,16 +767,47 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
         p_more = more;
         STAMP(7)
     }
-    if constexpr (LUMA) { STAMP_FLUSH(vp8_stamps_recon) } else { STAMP_FLUSH(vp8_stamps_lf) }
+#ifdef VP8_STAMPS
+    if (wave == 0 && threadIdx.x == 0) { for (int i_ = 0; i_ < VP8_NSTAMPS; i_++) atomicAdd(LUMA ? &vp8_stamps_recon[i_] : &vp8_stamps_lf[i_], st_acc[i_]); }
+#endif
 }
 
-extern "C" __global__ void __launch_bounds__(64)
-vp8_keyframe_luma_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g, int lgG, int P, int nstrands, uint8_t *dummy)
+// One kernel, two roles.  A wave decides at run time whether it reconstructs luma or chroma, so that the two waves that
+// share a SIMD always play different roles: launched as two kernels side by side, nothing keeps the dispatcher from putting
+// two luma waves (or two chroma waves) on one SIMD and leaving another with a single wave, and a process in which it did
+// took 62 ms per 8192 frames instead of 49.  The first wave to arrive on a SIMD (an agent-scope counter per SIMD, indexed
+// by XCC / SE / SH / CU / SIMD id) takes luma, the second chroma, the third luma again ...; which STRANDS it works on comes
+// from one counter per role (if its role has run out of work it takes the other).  grid = 2 * nwaves.
+//   sched[0], sched[1]: next luma / chroma work item (zeroed before every launch); sched[16 + simd]: waves seen (never reset:
+//   only the parity matters).
+extern "C" __global__ void __launch_bounds__(64, 2)
+vp8_keyframe_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g, int lgG, int P, int nstrands, uint8_t *dummy,
+                    const char *ir_base, unsigned int *sched, int nwaves)
 {
-    kf_body<true>(jobs, njobs, g, lgG, P, nstrands, dummy);
-}
-extern "C" __global__ void __launch_bounds__(64)
-vp8_keyframe_chroma_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g, int lgG, int P, int nstrands, uint8_t *dummy)
-{
-    kf_body<false>(jobs, njobs, g, lgG, P, nstrands, dummy);
+    __shared__ __attribute__((aligned(16))) u32 s_stage[4 * 2 * 64 * 4];
+    __shared__ unsigned short s_queue[256];
+    __shared__ __attribute__((aligned(8))) u32x2 s_tab[64];
+    __shared__ __attribute__((aligned(16))) u32 s_y2dc[64 * 8];
+    __shared__ __attribute__((aligned(16))) u32 s_desc[5 * 64 * 4];
+    __shared__ u32 s_sf[12 * 64];
+    int role = 0, item = 0;
+    if (threadIdx.x == 0) {
+        const u32 hw = __builtin_amdgcn_s_getreg((31 << 11) | 4 /* HW_REG_HW_ID */);
+        const u32 xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20 /* HW_REG_XCC_ID */);
+        // SIMD_ID [5:4], CU_ID [11:8], SH_ID [12], SE_ID [15:13]; the pipe / queue fields in between differ from stream to stream
+        const u32 simd = ((hw >> 4) & 3) | (((hw >> 8) & 0xff) << 2) | ((xcc & 15) << 10);
+        const u32 seen = __hip_atomic_fetch_add(&sched[16 + simd], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        role = seen & 1;
+        item = (int)__hip_atomic_fetch_add(&sched[role], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (item >= nwaves) { role ^= 1; item = (int)__hip_atomic_fetch_add(&sched[role], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+#ifdef VP8_STAMPS       // diagnostic builds: where every wave ran and as what
+        sched[16 + 16384 + 4 * blockIdx.x] = hw; sched[16 + 16384 + 4 * blockIdx.x + 1] = xcc;
+        sched[16 + 16384 + 4 * blockIdx.x + 2] = (u32)role | (seen << 8); sched[16 + 16384 + 4 * blockIdx.x + 3] = (u32)item;
+#endif
+    }
+    role = __builtin_amdgcn_readfirstlane(role);
+    item = __builtin_amdgcn_readfirstlane(item);
+    if (item >= nwaves) return;         // (cannot happen with grid = 2 * nwaves)
+    if (role == 0) kf_body<true>(jobs, njobs, g, lgG, P, nstrands, dummy, item, ir_base, s_stage, s_queue, s_tab, s_y2dc, s_desc, s_sf);
+    else kf_body<false>(jobs, njobs, g, lgG, P, nstrands, dummy + 1024, item, ir_base, s_stage, s_queue, s_tab, s_y2dc, s_desc, s_sf);
 }

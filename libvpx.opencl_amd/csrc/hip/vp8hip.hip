@@ -23,8 +23,13 @@ extern "C" __global__ void vp8_recon_intra_kernel(const DevJob *jobs, int njobs,
 extern "C" __global__ void vp8_recon_intra_xcu_kernel(const DevJob *jobs, int njobs, DevGeom g, unsigned long long *gran, unsigned int epoch,
                                                       int S, int *err, const unsigned int *intra_flags);
 extern "C" __global__ void vp8_inter_mb_kernel(const DevJob *jobs, int njobs, DevGeom g, unsigned int *intra_flags);
-extern "C" __global__ void vp8_keyframe_luma_kernel(const DevJob *jobs, int njobs, DevGeom g, int lgG, int P, int nstrands, uint8_t *dummy);
-extern "C" __global__ void vp8_keyframe_chroma_kernel(const DevJob *jobs, int njobs, DevGeom g, int lgG, int P, int nstrands, uint8_t *dummy);
+extern "C" __global__ void vp8_keyframe_kernel(const DevJob *jobs, int njobs, DevGeom g, int lgG, int P, int nstrands, uint8_t *dummy,
+                                               const char *ir_base, unsigned int *sched, int nwaves);
+#ifdef VP8_STAMPS
+#define VP8HIP_SCHED_WORDS (16 + 16384 + 4 * 4096)     // + the diagnostic builds' log: four words per wave
+#else
+#define VP8HIP_SCHED_WORDS (16 + 16384)     // vp8_keyframe_kernel: two work counters, one arrival counter per SIMD of the device
+#endif
 extern "C" __global__ void vp8_recon_simt_kernel(const DevJob *jobs, int njobs, DevGeom g, int lgG, int P, int nstrands, uint8_t *dummy);
 extern "C" __global__ void vp8_loopfilter_simt_kernel(const DevJob *jobs, int njobs, DevGeom g, int lgG, int P, int nstrands, int raster);
 extern "C" __global__ void vp8_loopfilter_simt_luma_kernel(const DevJob *jobs, int njobs, DevGeom g, int lgG, int P, int nstrands, int raster);
@@ -185,6 +190,7 @@ struct vp8hip_ctx {
     hipStream_t stream3; hipEvent_t ev_split_from, ev_split_done;     // chroma half of the split lane-per-row loop filter
     // vp8hip_postproc: dither table (440 shorts), noise table (3072) and per-row noise phases (16384) on the device
     char *d_pp, *h_pp; bool pp_rv_loaded; hipEvent_t ev_pp;
+    unsigned int *d_sched;         // vp8_keyframe_kernel's role / work counters
 };
 
 static int fail(vp8hip_ctx *c, int code, const char *fmt, ...)
@@ -322,6 +328,7 @@ extern "C" void vp8hip_destroy(vp8hip_ctx *c)
     for (int k = 0; k < VP8HIP_NBUF; k++) if (c->d_jobs2[k]) (void)hipFree(c->d_jobs2[k]);
     if (c->h_jobs) (void)hipHostFree(c->h_jobs);
     if (c->h_status) (void)hipHostFree(c->h_status);
+    if (c->d_sched) (void)hipFree(c->d_sched);
     destroy_events(c);
     if (c->stream_d2h) { (void)hipStreamSynchronize(c->stream_d2h); (void)hipStreamDestroy(c->stream_d2h); }
     if (c->ev_d2h_from) (void)hipEventDestroy(c->ev_d2h_from);
@@ -391,7 +398,7 @@ static int configure_pools(vp8hip_ctx *c, int width, int height, int num_fb, int
     c->lf_nw = lnw; c->lf_lds = lf_lds_bytes(lnw);
 
     // frame buffers: one block, each buffer 256-B aligned
-    const size_t fbsz = align_up((size_t)g.frame_size, 256);
+    const size_t fbsz = align_up((size_t)g.frame_size, 256) + (size_t)env_int("VP8HIP_FB_PAD", 0);          // (placement experiments)
     HIPCHK(c, hipMalloc((void **)&c->fb_block, fbsz * num_fb));
     HIPCHK(c, hipMemsetAsync(c->fb_block, 0, fbsz * num_fb, c->stream));
     for (int i = 0; i < num_fb; i++) c->fb.push_back(c->fb_block + fbsz * i);
@@ -402,7 +409,7 @@ static int configure_pools(vp8hip_ctx *c, int width, int height, int num_fb, int
     // IR slots
     const size_t o_mbs = 64, o_coef = o_mbs + align_up((size_t)c->nmb * sizeof(vp8ir_mb), 256);
     const size_t o_mvs = o_coef + align_up((size_t)c->nmb * VP8IR_COEF_PER_MB * sizeof(int16_t), 256);
-    const size_t slotsz = align_up(o_mvs + (size_t)c->nmb * 16 * sizeof(vp8ir_mv), 256);
+    const size_t slotsz = align_up(o_mvs + (size_t)c->nmb * 16 * sizeof(vp8ir_mv), 256) + (size_t)env_int("VP8HIP_SLOT_PAD", 0);
     HIPCHK(c, hipMalloc((void **)&c->slot_block_dev, slotsz * num_slots + 4096));   // + room for prefetches past the last macroblock
     c->slot_bytes = slotsz; c->o_mbs = o_mbs; c->o_coef = o_coef; c->o_mvs = o_mvs;
     c->slots.resize(num_slots);
@@ -766,19 +773,15 @@ extern "C" int vp8hip_decode(vp8hip_ctx *c, const vp8hip_job *jobs, int njobs, i
     c->stats.detile_pass = tiled && !lf_raster;
     if (stages & VP8HIP_STAGE_RECON) {
         if (fused) {
-            // luma and chroma as two kernels side by side: a luma wave (272 registers, 17 KB of LDS) and a chroma wave (232, 12 KB)
-            // share a SIMD, so every SIMD has two instruction streams to issue from.  The chroma kernel goes out on a stream of
-            // its own and the main stream takes it back in before anything reads the frames.
-            if (ensure_stream3(c)) return -1;
-            uint8_t *dummy = c->tile_block[par] + tile_frame * njobs + 4096;
-            HIPCHK(c, hipEventRecord(c->ev_split_from, c->stream));
-            HIPCHK(c, hipStreamWaitEvent(c->stream3, c->ev_split_from, 0));
-            hipLaunchKernelGGL(vp8_keyframe_luma_kernel, dim3(simt_waves), dim3(64), 0, c->stream, (const DevJob *)c->d_jobs, njobs,
-                               c->dg, lgG, simtP, simt_waves * spw, dummy);
-            hipLaunchKernelGGL(vp8_keyframe_chroma_kernel, dim3(simt_waves), dim3(64), 0, c->stream3, (const DevJob *)c->d_jobs, njobs,
-                               c->dg, lgG, simtP, simt_waves * spw, dummy + 1024);
-            HIPCHK(c, hipEventRecord(c->ev_split_done, c->stream3));
-            HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_split_done, 0));
+            // one kernel, two waves per SIMD: the first to arrive on a SIMD reconstructs luma, the second chroma (see the kernel)
+            if (!c->d_sched) {
+                HIPCHK(c, hipMalloc((void **)&c->d_sched, sizeof(unsigned int) * VP8HIP_SCHED_WORDS));
+                HIPCHK(c, hipMemsetAsync(c->d_sched, 0, sizeof(unsigned int) * VP8HIP_SCHED_WORDS, c->stream));
+            }
+            HIPCHK(c, hipMemsetAsync(c->d_sched, 0, 2 * sizeof(unsigned int), c->stream));
+            hipLaunchKernelGGL(vp8_keyframe_kernel, dim3(2 * simt_waves), dim3(64), 0, c->stream, (const DevJob *)c->d_jobs, njobs,
+                               c->dg, lgG, simtP, simt_waves * spw, c->tile_block[par] + tile_frame * njobs + 4096,
+                               (const char *)c->slot_block_dev, c->d_sched, simt_waves);
         } else if (simt_recon) {
             hipLaunchKernelGGL(vp8_recon_simt_kernel, dim3(simt_waves), dim3(64), 0, c->stream, (const DevJob *)c->d_jobs, njobs,
                                c->dg, lgG, simtP, simt_waves * spw, c->tile_block[par] + tile_frame * njobs + 4096);
@@ -1145,6 +1148,14 @@ extern "C" int vp8hip_frame_copy(vp8hip_ctx *c, int dst, int src)
 }
 
 #ifdef VP8_STAMPS
+extern "C" int vp8hip_debug_sched(vp8hip_ctx *c, unsigned int *out, int nwords)
+{
+    if (!c || !out || !c->d_sched || nwords > VP8HIP_SCHED_WORDS) return -2;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(out, c->d_sched, sizeof(unsigned int) * nwords, hipMemcpyDeviceToHost));
+    return 0;
+}
 // diagnostic builds only (see vp8_common.hip.h): read and clear the stamp buckets; which = 0 recon, 1 loop filter
 __device__ unsigned long long vp8_stamps_recon[VP8_NSTAMPS], vp8_stamps_lf[VP8_NSTAMPS];
 extern "C" int vp8hip_debug_stamps(vp8hip_ctx *c, int which, unsigned long long *out)
