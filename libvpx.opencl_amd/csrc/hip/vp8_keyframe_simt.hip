@@ -124,6 +124,11 @@ __device__ __forceinline__ void frame_levels(const vp8ir_frame_hdr &h, u32 &plai
     }
 }
 
+#ifdef KF_NOSTORE          // (timing experiments only: the row stores of active lanes go to the dummy scratch too)
+#define KF_ACT(a) false
+#else
+#define KF_ACT(a) (a)
+#endif
 #ifndef KF_SHIFT
 #define KF_SHIFT 4        // (timing experiments only: 0 = row pieces at their aligned, wrong, place)
 #endif
@@ -153,9 +158,9 @@ __device__ __forceinline__ void frame_levels(const vp8ir_frame_hdr &h, u32 &plai
 // the current phase).  The macroblock descriptors of the next step come by LDS-DMA too (a 16-byte slot per lane and piece),
 // not through registers held for a step.
 // LDS of a wave, whichever role it plays (19 KB: eight waves per CU, two per SIMD):
-//   s_stage  [round][half][lane] 16 B: coefficients in, residuals out        8192 B
+//   s_stage  [block of the phase][half][lane] 16 B: the owner's coefficients in, residuals out     8192 B
 //   s_queue  owner lane | block in phase << 6 | DC given << 8                 512 B
-//   s_tab    per owner: coefficient offset (32-byte units from ir_base), quantiser   512 B
+//   s_tab    per owner: quantiser (dc | ac << 16)                             256 B
 //   s_y2dc   per owner: the sixteen luma DCs out of the Y2 block (luma)      2048 B
 //   s_desc   [piece][lane] 16 B: the next macroblock's descriptor (luma 5 pieces, chroma 2)   5120 B
 //   s_sf     [row][lane]: the last four pixels (filtered, biased) of pixel rows of the macroblock to the left -- luma rows 0..11,
@@ -163,7 +168,7 @@ __device__ __forceinline__ void frame_levels(const vp8ir_frame_hdr &h, u32 &plai
 //            Per-lane state read and written once per step and indexed by the block row: in LDS it costs no registers    3072 B
 template <bool LUMA>
 __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njobs, DevGeom g, int lgG, int P, int nstrands, uint8_t *dummy,
-                                        const int wave, const char *ir_base, u32 *s_stage, unsigned short *s_queue, u32x2 *s_tab,
+                                        const int wave, u32 *s_stage, unsigned short *s_queue, u32 *s_tab,
                                         u32 *s_y2dc, u32 *s_desc, u32 *s_sf)
 {
     const int lane = threadIdx.x;
@@ -195,7 +200,7 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
     for (int s = 0; s < 4; s++) dqs[s][0] = dqs[s][1] = 0;
     u32 lv_plain = 0, lv_bpred = 0;
     int sharp = 0; bool simple = false;
-    s_tab[lane] = (u32x2){ (u32)(((const char *)jobs[0].coef - ir_base) >> 5), 0u };
+    s_tab[lane] = 0;
     // ---- prediction context (unfiltered).  Luma: l0[0..3] left column, h1/h2[0..3] bottom lines of the macroblocks finished one
     // and two steps ago.  Chroma: U in [0..1], V in [2..3].
     u32 l0[4] = { 0, 0, 0, 0 }, h1[4] = { 0, 0, 0, 0 }, h2[4] = { 0, 0, 0, 0 };
@@ -211,44 +216,37 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
 #pragma unroll
     for (int j = 0; j < 4; j++) { pb[j][0] = pb[j][1] = pb[j][2] = 0; hF[j][0] = hF[j][1] = hF[j][2] = hF[j][3] = 0; }
     // ---- the macroblock after the current one, prepared at the end of the step before: descriptor words 0, 1, sub-block modes;
-    // which of its blocks have a residual, whether the luma DCs come out of the Y2 block; where its first phase's residuals are
-    u32 nx_w0 = 0, nx_w1 = 0, nx_jm = 0, nx_dcg = 0, nx_at4 = 0;
+    // which of its blocks have a residual, whether the luma DCs come out of the Y2 block
+    u32 nx_w0 = 0, nx_w1 = 0, nx_jm = 0, nx_dcg = 0;
     u32x4 nx_bm = { 0, 0, 0, 0 };
     bool p_more = false;
 
     int q_n = 0;                                                     // blocks queued (wave-uniform)
-    // queue the blocks blk0 .. blk0+3 of every lane's macroblock that have coefficients (`m4`), behind the n0 already queued, and
-    // request their coefficients; returns where the lane's four blocks are (a byte each)
-    auto queue = [&](const int blk0, const u32 m4, const u32 dcg, const int n0) -> u32 {
-        wave_lds_sync();
+    // The owner requests the coefficients of the blocks cfb[0..3] of its macroblock that have any (`m4`) into ITS OWN four staging
+    // slots (s_stage[block][half][lane]: no look-up stands between knowing the macroblock and the request), and the lanes
+    // queue these blocks, behind the n0 already queued, for the transform.
+    auto queue = [&](g_cs16p cfb, const u32 m4, const u32 dcg, const int n0) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            if ((m4 >> i) & 1) {
+                __builtin_amdgcn_global_load_lds((g_cvp)(cfb + i * 16), (lds_vp)(s_stage + i * 512), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((g_cvp)(cfb + i * 16 + 8), (lds_vp)(s_stage + i * 512 + 256), 16, 0, 0);
+            }
+        }
+        wave_lds_sync();                                             // the queue's last reader is done
         int n = n0;
-        u32 at4 = 0;
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const bool b = (m4 >> i) & 1;
             const unsigned long long bal = __builtin_amdgcn_ballot_w64(b);
             const u32 at = __builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, (u32)n));
-            if (b) { s_queue[at] = (unsigned short)((u32)lane | ((u32)i << 6) | (dcg << 8)); at4 |= at << (8 * i); }
+            if (b) s_queue[at] = (unsigned short)((u32)lane | ((u32)i << 6) | (dcg << 8));
             n += __builtin_popcountll(bal);
         }
         q_n = n;
-        wave_lds_sync();
-        const int R = (n + 63) >> 6;
-#pragma unroll 1
-        for (int rr = n0 >> 6; rr < R; rr++) {
-            const int idx = rr * 64 + lane;
-            if (idx >= n0 && idx < n) {
-                const u32 ent = s_queue[idx];
-                const u32x2 tb = s_tab[ent & 63];
-                g_cs16p cf = (g_cs16p)(ir_base + ((unsigned long)tb.x << 5)) + (blk0 + (int)((ent >> 6) & 3)) * 16;
-                __builtin_amdgcn_global_load_lds((g_cvp)cf, (lds_vp)(s_stage + rr * 512), 16, 0, 0);
-                __builtin_amdgcn_global_load_lds((g_cvp)(cf + 8), (lds_vp)(s_stage + rr * 512 + 256), 16, 0, 0);
-            }
-        }
-        return at4;
     };
-    // all lanes transform the queued blocks n0 .. q_n-1, one per lane and round, in place.  `younger`: a LOWER bound of the
-    // memory instructions issued since `queue` (they may stay in flight)
+    // all lanes transform the queued blocks n0 .. q_n-1, one per lane and round, whoever they belong to, in place (in the owner's
+    // slot).  `younger`: a LOWER bound of the memory instructions issued since `queue` (they may stay in flight)
     auto drain = [&](const int blk0, const int n0, const int younger) {
         if (younger >= 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
         else if (younger >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
@@ -263,10 +261,11 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
                 const u32 ent = s_queue[idx];
                 const int owner = ent & 63, i = (ent >> 6) & 3;
                 const bool given = (ent >> 8) & 1;
-                const u32 dq = s_tab[owner].y;
+                const u32 dq = s_tab[owner];
+                const u32 slot = stage_base + i * 2048 + owner * 16;
                 u32x4 ca, cb;
                 asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024\n\ts_waitcnt lgkmcnt(0)"
-                             : "=&v"(ca), "=&v"(cb) : "v"(stage_lane + rr * 2048) : "memory");
+                             : "=&v"(ca), "=&v"(cb) : "v"(slot) : "memory");
                 __builtin_amdgcn_sched_barrier(0);
                 int dc_in = 0;
                 if (LUMA && given) { const int blk = blk0 + i; dc_in = (short)(s_y2dc[owner * 8 + (blk >> 1)] >> (16 * (blk & 1))); }
@@ -277,21 +276,18 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
                 oa.z = ((u32)res[4] & 0xffff) | ((u32)res[5] << 16); oa.w = ((u32)res[6] & 0xffff) | ((u32)res[7] << 16);
                 ob.x = ((u32)res[8] & 0xffff) | ((u32)res[9] << 16); ob.y = ((u32)res[10] & 0xffff) | ((u32)res[11] << 16);
                 ob.z = ((u32)res[12] & 0xffff) | ((u32)res[13] << 16); ob.w = ((u32)res[14] & 0xffff) | ((u32)res[15] << 16);
-                asm volatile("ds_write_b128 %0, %1\n\tds_write_b128 %0, %2 offset:1024"
-                             :: "v"(stage_lane + rr * 2048), "v"(oa), "v"(ob) : "memory");
+                asm volatile("ds_write_b128 %0, %1\n\tds_write_b128 %0, %2 offset:1024" :: "v"(slot), "v"(oa), "v"(ob) : "memory");
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         wave_lds_sync();
     };
-    // the owner's residuals of the phase just drained: block k's two halves in rr[2k], rr[2k+1] (garbage where it has none)
-    auto fetch = [&](const u32 at4, u32x4 (&rr)[8]) {
+    // the owner's residuals of the phase just drained, out of its four slots: block k's two halves in rr[2k], rr[2k+1] (garbage
+    // where it has none)
+    auto fetch = [&](u32x4 (&rr)[8]) {
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const u32 at = (at4 >> (8 * k)) & 0xff;
-            const u32 addr = stage_base + ((at >> 6) << 11) + ((at & 63) << 4);
-            asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024" : "=&v"(rr[2 * k]), "=&v"(rr[2 * k + 1]) : "v"(addr) : "memory");
-        }
+        for (int k = 0; k < 4; k++)
+            asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024" : "=&v"(rr[2 * k]), "=&v"(rr[2 * k + 1]) : "v"(stage_lane + k * 2048) : "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rr[0]), "+v"(rr[1]), "+v"(rr[2]), "+v"(rr[3]), "+v"(rr[4]), "+v"(rr[5]), "+v"(rr[6]), "+v"(rr[7]) :: "memory");
     };
 
@@ -331,7 +327,7 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
         if (skip) m = 0;
         jm = m;
         dcg = LUMA && has_y2 && !skip;
-        s_tab[lane] = (u32x2){ (u32)(((const char *)cf - ir_base) >> 5), dq0 };
+        s_tab[lane] = dq0;
         if constexpr (LUMA) {
             // Y2: vp8_dequantize_b + vp8_short_inv_walsh4x4_c (idctllm.c:140-192) -> the 16 luma DCs.  With nothing but a DC
             // coefficient the full transform gives what vp8_short_inv_walsh4x4_1_c gives (decodframe.c:282-285).
@@ -399,7 +395,7 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
         }
         const bool act = c >= 0 && c < cols && V < Vmax;
         const bool late = act && !p_more;        // first macroblock of a row: nothing was prepared a step ahead
-        u32 jm = nx_jm, dc_given = nx_dcg, at4 = nx_at4;
+        u32 jm = nx_jm, dc_given = nx_dcg;
         u32 cur_w0 = nx_w0, cur_w1 = nx_w1;
         u32x4 bm = nx_bm;
         if (late) {
@@ -434,8 +430,7 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
         // the row starters' first phase joins the queue behind the blocks the others had transformed at the end of the last step
         if (__builtin_amdgcn_ballot_w64(late) != 0) {
             const int n0 = q_n;
-            const u32 a = queue(LUMA ? 0 : 16, late ? jm & 0xf : 0, dc_given, n0);
-            if (late) at4 = a;
+            queue(cfp + (LUMA ? 0 : 16 * 16), late ? jm & 0xf : 0, dc_given, n0);
             drain(LUMA ? 0 : 16, n0, 0);
         }
         // the descriptor of the macroblock after this one: on its way from here (a lane at the end of its row, or idle, fetches
@@ -515,8 +510,8 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
             // the filter's rows above the first block row: rows 12..15 of the macroblock above (tF); from then on the block row before
             u32 sfix[4] = { 0, 0, 0, 0 };             // the left neighbour's last dword in the rows above the current block row, fixed up
             // where the rows above the current block row go: first the macroblock above (aligned), then this one (shifted left by 4)
-            g_u8p prow = (act && !top) ? ras - 4 * ys + c * 16 : (g_u8p)dummy + 16;
-            int pstride = (act && !top) ? ys : 0;
+            g_u8p prow = KF_ACT(act && !top) ? ras - 4 * ys + c * 16 : (g_u8p)dummy + 16;
+            int pstride = KF_ACT(act && !top) ? ys : 0;
 #pragma unroll 1
             for (int by = 0; by < 4; by++) {
                 // ---- the block row's residuals; then the next phase's coefficients are requested (the next block row's, or the next
@@ -524,9 +519,9 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
                 u32x4 rr[8];
                 const u32 rmg = jm >> (by * 4);
                 if (by < 3) {
-                    fetch(at4, rr);
+                    fetch(rr);
                     STAMP(8)
-                    at4 = queue(4 * by + 4, (jm >> (4 * by + 4)) & 0xf, dc_given, 0);
+                    queue(cfp + (4 * by + 4) * 16, (jm >> (4 * by + 4)) & 0xf, dc_given, 0);
                 } else {
                     // (all of this macroblock's phases have been transformed: its entries of s_tab / s_y2dc are free)
                     u32 n_jm = 0, n_dcg = 0;
@@ -541,9 +536,9 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
                     }
                     asm volatile("ds_read_b128 %0, %1 offset:2048\n\ts_waitcnt lgkmcnt(0)" : "=&v"(nx_bm) : "v"(desc_lane) : "memory");
                     STAMP(9)
-                    fetch(at4, rr);
+                    fetch(rr);
                     STAMP(8)
-                    nx_at4 = queue(0, n_jm & 0xf, n_dcg, 0);
+                    queue(cfp + VP8IR_COEF_PER_MB, n_jm & 0xf, n_dcg, 0);
                 }
                 STAMP(3)
                 const u32 lcur = l0[0];
@@ -595,8 +590,8 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
                 // the rows just written keep their last dword for the next macroblock's left edge
 #pragma unroll
                 for (int j = 0; j < 4; j++) { if (act && !first) sF[(4 * by - 4 + j) * 64] = d[j][3]; sfix[j] = sb[j]; }
-                prow = act ? (first ? ras + c * 16 - KF_SHIFT : prow + 4 * ys) : (g_u8p)dummy + 16;
-                pstride = act ? ys : 0;
+                prow = KF_ACT(act) ? (first ? ras + c * 16 - KF_SHIFT : prow + 4 * ys) : (g_u8p)dummy + 16;
+                pstride = KF_ACT(act) ? ys : 0;
                 STAMP(10)
                 // ---- the next phase's residuals (its coefficients have landed: the four row stores above are younger)
                 drain(by < 3 ? 4 * by + 4 : 0, 0, 4);
@@ -645,9 +640,9 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
 #pragma unroll 1
             for (int pl = 0; pl < 2; pl++) {
                 u32x4 rr[8];
-                fetch(at4, rr);
+                fetch(rr);
                 const u32 rmg = jm >> (4 * pl);
-                if (pl == 0) at4 = queue(20, (jm >> 4) & 0xf, 0, 0);
+                if (pl == 0) queue(cfp + 20 * 16, (jm >> 4) & 0xf, 0, 0);
                 else {
                     u32 n_jm = 0, n_dcg = 0;
                     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
@@ -657,7 +652,7 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
                     const u32x4 z = { 0, 0, 0, 0 };
                     if (more) prepare_mb(m0, m1, z, z, cfp + VP8IR_COEF_PER_MB, n_jm, n_dcg);
                     nx_w0 = m0.x; nx_w1 = m0.y; nx_jm = n_jm; nx_dcg = 0;
-                    nx_at4 = queue(16, n_jm & 0xf, 0, 0);
+                    queue(cfp + VP8IR_COEF_PER_MB + 16 * 16, n_jm & 0xf, 0, 0);
                 }
                 STAMP(3)
                 const u32 aC0 = aA[0], aC1 = aA[1], lC0 = l0[0], lC1 = l0[1];
@@ -701,8 +696,8 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
                 lf_block_row<2>(o0, s0, Pc, true, gv, gh, L, d0);
                 STAMP(11)
                 {   // rows 4..7 of the macroblock above: final
-                    g_u8p pa = (act && !top) ? ras - 4 * ys + c * 8 : (g_u8p)dummy;
-                    const int st = (act && !top) ? ys : 0;
+                    g_u8p pa = KF_ACT(act && !top) ? ras - 4 * ys + c * 8 : (g_u8p)dummy;
+                    const int st = KF_ACT(act && !top) ? ys : 0;
 #pragma unroll
                     for (int j = 0; j < 4; j++)
                         *(g_u32x2p)(pa + j * st) = (u32x2){ d0[j][0] ^ VP8_LF_BIAS, d0[j][1] ^ VP8_LF_BIAS };
@@ -711,8 +706,8 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
                 lf_block_row<2>(o1, s1, Pc, false, gv, gh, L, d1);
                 STAMP(11)
                 {   // rows 0..3: the left neighbour's last dword and this macroblock's first
-                    g_u8p po = act ? ras + c * 8 - KF_SHIFT : (g_u8p)dummy + 16;
-                    const int st = act ? ys : 0;
+                    g_u8p po = KF_ACT(act) ? ras + c * 8 - KF_SHIFT : (g_u8p)dummy + 16;
+                    const int st = KF_ACT(act) ? ys : 0;
 #pragma unroll
                     for (int j = 0; j < 4; j++)
                         *(g_u32x2up)(po + j * st) = (u32x2){ s0[j] ^ VP8_LF_BIAS, d1[j][0] ^ VP8_LF_BIAS };
@@ -782,11 +777,11 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
 //   only the parity matters).
 extern "C" __global__ void __launch_bounds__(64, 2)
 vp8_keyframe_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g, int lgG, int P, int nstrands, uint8_t *dummy,
-                    const char *ir_base, unsigned int *sched, int nwaves)
+                    unsigned int *sched, int nwaves)
 {
     __shared__ __attribute__((aligned(16))) u32 s_stage[4 * 2 * 64 * 4];
     __shared__ unsigned short s_queue[256];
-    __shared__ __attribute__((aligned(8))) u32x2 s_tab[64];
+    __shared__ u32 s_tab[64];
     __shared__ __attribute__((aligned(16))) u32 s_y2dc[64 * 8];
     __shared__ __attribute__((aligned(16))) u32 s_desc[5 * 64 * 4];
     __shared__ u32 s_sf[12 * 64];
@@ -808,6 +803,6 @@ vp8_keyframe_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g, int l
     role = __builtin_amdgcn_readfirstlane(role);
     item = __builtin_amdgcn_readfirstlane(item);
     if (item >= nwaves) return;         // (cannot happen with grid = 2 * nwaves)
-    if (role == 0) kf_body<true>(jobs, njobs, g, lgG, P, nstrands, dummy, item, ir_base, s_stage, s_queue, s_tab, s_y2dc, s_desc, s_sf);
-    else kf_body<false>(jobs, njobs, g, lgG, P, nstrands, dummy + 1024, item, ir_base, s_stage, s_queue, s_tab, s_y2dc, s_desc, s_sf);
+    if (role == 0) kf_body<true>(jobs, njobs, g, lgG, P, nstrands, dummy, item, s_stage, s_queue, s_tab, s_y2dc, s_desc, s_sf);
+    else kf_body<false>(jobs, njobs, g, lgG, P, nstrands, dummy + 1024, item, s_stage, s_queue, s_tab, s_y2dc, s_desc, s_sf);
 }
