@@ -87,3 +87,52 @@ vp8_detile_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g, int ext
         }
     }
 }
+
+// The same pass for the tiles vp8_keyframe_kernel leaves (vp8_keyframe_simt.hip): rows x (cols + 1) tiles per frame; luma rows
+// 0..11 (chroma rows 0..3) of tile c hold the pixel columns 16c-4 .. 16c+11 (8c-4 .. 8c+3) -- the macroblock's WINDOW, shifted
+// left by the four pixels its left-edge filter still changes --, luma rows 12..15 (chroma 4..7) the macroblock's own columns.
+// Eight neighbouring threads copy the same pixel row of eight tiles: 128 (64) contiguous bytes of a frame row, for the
+// window rows at an offset of -4 (the pieces of neighbouring groups complete the lines).  The first window's four pixels left of
+// the frame and the last window's pixels right of it land in the border, which vp8_extend_kernel writes afterwards.
+//
+// This pass is meant to run BESIDE the next launch's vp8_keyframe_kernel, whose two waves per SIMD leave 16 of the SIMD's 512
+// registers free: it keeps to 16 (two pointers, one piece of data, a counter; one load in flight per thread -- memory-level
+// parallelism comes from the six free wave slots of every SIMD, not from unrolling), so its waves fit in that gap and the
+// pass is hidden behind a kernel that is bound by the vector ALU.
+typedef u32x4_t u32x4_u4 __attribute__((aligned(4)));
+typedef u32x2_t u32x2_u4 __attribute__((aligned(4)));
+extern "C" __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(16)))
+vp8_detile_kf_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g)
+{
+    const int cols = g.mb_cols, rows = g.mb_rows;
+    const int t = threadIdx.x;
+    const int tile = t & 7;
+    const int wv = __builtin_amdgcn_readfirstlane(t >> 6);          // waves 0, 1: luma; 2: U; 3: V
+    const bool luma = wv < 2;
+    const int pl = wv - 2;
+    const int row = luma ? t >> 3 : ((t - 128) >> 3) & 7;           // pixel row inside the macroblock
+    const bool window = luma ? row < 12 : row < 4;
+    const int src = luma ? (window ? 16 * row : 192 + 16 * (row - 12)) : (window ? 256 + 32 * pl + 8 * row : 320 + 32 * pl + 8 * (row - 4));
+    const int stride = luma ? g.y_stride : g.uv_stride;
+    // per-thread 32-bit offsets; the 64-bit bases are uniform (scalar registers)
+    const unsigned doff = (unsigned)((luma ? g.y_off : (pl ? g.v_off : g.u_off)) + row * stride - (window ? 4 : 0) + tile * (luma ? 16 : 8));
+    const unsigned soff = (unsigned)(tile * VP8_TILE_BYTES + src);
+    const int ntiles = (window ? cols + 1 : cols) - tile;           // tiles tile, tile + 8, ... of a macroblock row
+    // a workgroup takes macroblock rows blockIdx.x, blockIdx.x + gridDim.x, ... of the launch (row r of job j: unit j * rows + r)
+#pragma unroll 1
+    for (int unit = blockIdx.x; unit < njobs * rows; unit += gridDim.x) {
+        const int j = unit / rows, r = unit - j * rows;
+        const GLOBAL_AS unsigned char *sbase = (const GLOBAL_AS unsigned char *)jobs[j].tile + (long)r * (cols + 1) * VP8_TILE_BYTES;
+        GLOBAL_AS unsigned char *dbase = (GLOBAL_AS unsigned char *)jobs[j].dst + (long)(r * (luma ? 16 : 8)) * stride;
+        unsigned so = soff, dO = doff;
+        if (luma) {
+#pragma unroll 1
+            for (int left = ntiles; left > 0; left -= 8, so += 8 * VP8_TILE_BYTES, dO += 128)
+                *(GLOBAL_AS u32x4_u4 *)(dbase + dO) = *(const GLOBAL_AS u32x4_t *)(sbase + so);
+        } else {
+#pragma unroll 1
+            for (int left = ntiles; left > 0; left -= 8, so += 8 * VP8_TILE_BYTES, dO += 64)
+                *(GLOBAL_AS u32x2_u4 *)(dbase + dO) = *(const GLOBAL_AS u32x2_t *)(sbase + so);
+        }
+    }
+}

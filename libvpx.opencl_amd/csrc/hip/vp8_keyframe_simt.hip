@@ -45,14 +45,24 @@ __device__ __forceinline__ v2u col_lo(u32 D) { return as_v2u(perm(D, D, 0x010c00
 __device__ __forceinline__ v2u col_hi(u32 D) { return as_v2u(perm(D, D, 0x030c020cu)); }
 __device__ __forceinline__ u32 col_pack(v2u lo, v2u hi) { return perm(as_u32(hi), as_u32(lo), 0x07050301u); }
 
-// hand-over tile of a macroblock (VP8_TILE_BYTES): what the first lane of a strand reads back
+// The output: one 384-byte tile per macroblock in the job's scratch (DevJob::tile), rows x (cols + 1) of them, laid out by who
+// knows which pixels when, so that every 64-byte half of a tile's three 128-byte lines is written whole, by one lane, within
+// one step (the L2 merges the 16- and 8-byte stores of a step; what leaves it are full sectors -- 16-byte pieces of raster
+// rows written a step apart cost this kernel a third of its time and made it 46 or 60 ms depending on where the frame
+// buffers happened to lie):
+//   the WINDOW of macroblock (r, c) is the pixel columns 16c-4 .. 16c+11 (chroma 8c-4 .. 8c+3): the last four pixels of a row
+//   of the macroblock to the left are only final once this macroblock's left edge has been filtered;
+//   the bottom four rows (chroma: rows 4..7) of a macroblock are finished by the lane below, two steps later, and are kept
+//   macroblock-aligned.  vp8_detile_kf_kernel turns the tiles into the raster frame buffer.
 enum {
-    HO_Y_ROWS = 0,        // luma rows 12..15, filtered as far as this macroblock row goes: 4 x 16 B
-    HO_Y_LINE = 64,       // unfiltered luma row 15: 16 B
-    HO_U_ROWS = 128,      // U rows 4..7: 4 x 8 B
-    HO_V_ROWS = 160,
-    HO_U_LINE = 192,      // unfiltered U row 7: 8 B
-    HO_V_LINE = 200
+    KT_Y_WIN = 0,         // luma rows 0..11 of the window, 16 B each: written by the macroblock's own lane
+    KT_Y_BOT = 192,       // luma rows 12..15 of the macroblock, 16 B each: by the lane below (or its own at the frame's bottom)
+    KT_U_WIN = 256,       // U rows 0..3 of the window, 8 B each; V at + 32
+    KT_U_BOT = 320,       // U rows 4..7 of the macroblock; V at + 32
+    // behind the tiles, 32 bytes per macroblock: the UNFILTERED bottom pixel line (prediction context), which only the last lane
+    // of a strand leaves for the first (the filtered bottom rows it reads back from KT_Y_BOT / KT_U_BOT, where the last lane
+    // left them unfinished)
+    KH_Y = 0, KH_U = 16, KH_V = 24, KH_BYTES = 32
 };
 
 // One block row (four pixel rows) of one plane through the loop filter.  W4: dwords per row (4 luma, 2 chroma).
@@ -129,9 +139,6 @@ __device__ __forceinline__ void frame_levels(const vp8ir_frame_hdr &h, u32 &plai
 #else
 #define KF_ACT(a) (a)
 #endif
-#ifndef KF_SHIFT
-#define KF_SHIFT 4        // (timing experiments only: 0 = row pieces at their aligned, wrong, place)
-#endif
 #define SWAP_U32(a, b) { const u32 t_ = (a); (a) = (b); (b) = t_; }
 
 } // namespace
@@ -177,7 +184,7 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
     const int spw = 64 >> lgG;
     const int strand = wave * spw + (lane >> lgG);
     const int cols = g.mb_cols, rows = g.mb_rows;
-    const long rowbytes = (long)cols * VP8_TILE_BYTES;
+    const long rowbytes = (long)(cols + 1) * VP8_TILE_BYTES, hrow = (long)(cols + 1) * KH_BYTES;
     const int myjobs = strand < njobs ? (njobs - strand + nstrands - 1) / nstrands : 0;
     const int Vmax = myjobs * rows;
     const int wavejobs = (njobs - wave * spw + nstrands - 1) / nstrands;
@@ -185,15 +192,13 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
     const u32 stage_lane = (u32)(unsigned long)(lds_vp)s_stage + lane * 16;     // LDS byte address of this lane's slot of round 0, half 0
     const u32 stage_base = (u32)(unsigned long)(lds_vp)s_stage;
     const u32 desc_lane = (u32)(unsigned long)(lds_vp)s_desc + lane * 16;
-    const int ys = LUMA ? g.y_stride : g.uv_stride;
     v2u one = mku(1);
     asm volatile("" : "+v"(one));            // see nz_clear
 
     // ---- per-lane row state; the pointers are valid addresses at all times
     g_cu32p mbp = (g_cu32p)jobs[0].mbs;         // descriptor of the current macroblock
     g_cs16p cfp = (g_cs16p)jobs[0].coef;        // its coefficients
-    g_u8p tp = (g_u8p)dummy;                    // its hand-over tile
-    g_u8p ras = (g_u8p)dummy, ras2 = (g_u8p)dummy;     // pixel (0, 0) of macroblock row r in the frame buffer: Y, or U and V
+    g_u8p tp = (g_u8p)dummy, hp = (g_u8p)dummy; // first tile / first unfiltered line of its macroblock row
     int r = 0;
     u32 dqs[4][2];                              // luma: y1, y2 quantisers per segment (dc | ac << 16); chroma: uv in [s][0]
 #pragma unroll
@@ -416,8 +421,7 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
             mbp = (g_cu32p)(job->mbs + (long)r * cols);
             cfp = (g_cs16p)(job->coef + (long)r * cols * VP8IR_COEF_PER_MB);
             tp = (g_u8p)(job->tile + (long)r * rowbytes);
-            if constexpr (LUMA) ras = (g_u8p)(job->dst + g.y_off + (long)r * 16 * ys);
-            else { ras = (g_u8p)(job->dst + g.u_off + (long)r * 8 * ys); ras2 = (g_u8p)(job->dst + g.v_off + (long)r * 8 * ys); }
+            hp = (g_u8p)(job->tile + (long)rows * rowbytes + (long)r * hrow);
             l0[0] = l0[1] = l0[2] = l0[3] = 0x81818181u;    // left border 129 (setupintrarecon.c:15-32)
             u32x4 m0 = *(g_cu32x4p)mbp, m1 = *(g_cu32x4p)(mbp + 4), b0 = { 0, 0, 0, 0 }, y2a = { 0, 0, 0, 0 }, y2b = { 0, 0, 0, 0 };
             if constexpr (LUMA) { b0 = *(g_cu32x4p)(mbp + 10); y2a = *(g_cu32x4p)(cfp + 384); y2b = *(g_cu32x4p)(cfp + 392); }
@@ -444,7 +448,8 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
         // bottom rows that no lane below takes over are written here: to the frame (last row), or to the hand-over tile
         const bool write_bottom = pos == G - 1 || last_row;
         const bool hand = act && pos == G - 1 && !last_row;
-        const g_u8p tpc = tp + (long)(act ? c : 0) * VP8_TILE_BYTES;                 // this macroblock's hand-over tile
+        const g_u8p tpc = tp + (long)(act ? c : 0) * VP8_TILE_BYTES;                 // this macroblock's tile
+        const g_u8p hpc = hp + (long)(act ? c : 0) * KH_BYTES;                       // ... and unfiltered line
         // ---- macroblock descriptor; loop-filter parameters (vp8_loop_filter_frame, loopfilter.c:245-299)
         const int y_mode = cur_w0 & 0xff, uv_mode = (cur_w0 >> 8) & 0xff;
         const bool bpred = y_mode == VP8IR_B_PRED;
@@ -469,23 +474,23 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
             arY = nAR;
         }
         if (readback) {
-            const unsigned char *pa = (const unsigned char *)tpc - rowbytes;
+            const unsigned char *pa = (const unsigned char *)tpc - rowbytes, *ha = (const unsigned char *)hpc - hrow;
             if constexpr (LUMA) {
 #pragma unroll
-                for (int i = 0; i < 4; i++) aA[i] = load_l2(pa + HO_Y_LINE + 4 * i);
-                arY = load_l2(pa + VP8_TILE_BYTES + HO_Y_LINE);
+                for (int i = 0; i < 4; i++) aA[i] = load_l2(ha + KH_Y + 4 * i);
+                arY = load_l2(ha + KH_BYTES + KH_Y);
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
 #pragma unroll
-                    for (int i = 0; i < 4; i++) tF[j][i] = load_l2(pa + HO_Y_ROWS + 16 * j + 4 * i);
+                    for (int i = 0; i < 4; i++) tF[j][i] = load_l2(pa + KT_Y_BOT + 16 * j + 4 * i) ^ VP8_LF_BIAS;
                 }
             } else {
-                aA[0] = load_l2(pa + HO_U_LINE); aA[1] = load_l2(pa + HO_U_LINE + 4);
-                aA[2] = load_l2(pa + HO_V_LINE); aA[3] = load_l2(pa + HO_V_LINE + 4);
+                aA[0] = load_l2(ha + KH_U); aA[1] = load_l2(ha + KH_U + 4);
+                aA[2] = load_l2(ha + KH_V); aA[3] = load_l2(ha + KH_V + 4);
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
-                    tF[j][0] = load_l2(pa + HO_U_ROWS + 8 * j); tF[j][1] = load_l2(pa + HO_U_ROWS + 8 * j + 4);
-                    tF[j][2] = load_l2(pa + HO_V_ROWS + 8 * j); tF[j][3] = load_l2(pa + HO_V_ROWS + 8 * j + 4);
+                    tF[j][0] = load_l2(pa + KT_U_BOT + 8 * j) ^ VP8_LF_BIAS; tF[j][1] = load_l2(pa + KT_U_BOT + 8 * j + 4) ^ VP8_LF_BIAS;
+                    tF[j][2] = load_l2(pa + KT_U_BOT + 32 + 8 * j) ^ VP8_LF_BIAS; tF[j][3] = load_l2(pa + KT_U_BOT + 32 + 8 * j + 4) ^ VP8_LF_BIAS;
                 }
             }
         }
@@ -509,9 +514,9 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
             u32 nl[4] = { 0, 0, 0, 0 };                        // right column of this macroblock = left of the next
             // the filter's rows above the first block row: rows 12..15 of the macroblock above (tF); from then on the block row before
             u32 sfix[4] = { 0, 0, 0, 0 };             // the left neighbour's last dword in the rows above the current block row, fixed up
-            // where the rows above the current block row go: first the macroblock above (aligned), then this one (shifted left by 4)
-            g_u8p prow = KF_ACT(act && !top) ? ras - 4 * ys + c * 16 : (g_u8p)dummy + 16;
-            int pstride = KF_ACT(act && !top) ? ys : 0;
+            // where the rows above the current block row go: first the bottom rows of the macroblock above, then this one's window
+            g_u8p prow = KF_ACT(act && !top) ? tpc - rowbytes + KT_Y_BOT : (g_u8p)dummy;
+            int pstride = KF_ACT(act && !top) ? 16 : 0;
 #pragma unroll 1
             for (int by = 0; by < 4; by++) {
                 // ---- the block row's residuals; then the next phase's coefficients are requested (the next block row's, or the next
@@ -585,13 +590,13 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     const u32x4 v = first ? (u32x4){ d[j][0], d[j][1], d[j][2], d[j][3] } : (u32x4){ sfix[j], d[j][0], d[j][1], d[j][2] };
-                    *(g_u32x4up)(prow + j * pstride) = v ^ VP8_LF_BIAS;
+                    *(g_u32x4p)(prow + j * pstride) = v ^ VP8_LF_BIAS;
                 }
                 // the rows just written keep their last dword for the next macroblock's left edge
 #pragma unroll
                 for (int j = 0; j < 4; j++) { if (act && !first) sF[(4 * by - 4 + j) * 64] = d[j][3]; sfix[j] = sb[j]; }
-                prow = KF_ACT(act) ? (first ? ras + c * 16 - KF_SHIFT : prow + 4 * ys) : (g_u8p)dummy + 16;
-                pstride = KF_ACT(act) ? ys : 0;
+                prow = KF_ACT(act) ? (first ? tpc + KT_Y_WIN : prow + 64) : (g_u8p)dummy;
+                pstride = KF_ACT(act) ? 16 : 0;
                 STAMP(10)
                 // ---- the next phase's residuals (its coefficients have landed: the four row stores above are younger)
                 drain(by < 3 ? 4 * by + 4 : 0, 0, 4);
@@ -603,25 +608,21 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
 #pragma unroll
                 for (int j = 0; j < 4; j++) hF[j][3] = sfix[j];
                 if (act) {
-                    if (hand) *(g_u32x4p)(tpc + HO_Y_LINE) = (u32x4){ abv[0], abv[1], abv[2], abv[3] };     // unfiltered bottom line
-                    if (write_bottom && c > 0) {
-                        g_u8p pbo = last_row ? ras + 12 * ys + (c - 1) * 16 : tpc - VP8_TILE_BYTES + HO_Y_ROWS;
-                        const int st = last_row ? ys : 16;
-                        const u32 x = last_row ? VP8_LF_BIAS : 0;         // (the hand-over tile keeps the filter's biased form)
+                    if (hand) *(g_u32x4p)(hpc + KH_Y) = (u32x4){ abv[0], abv[1], abv[2], abv[3] };     // unfiltered bottom line
+                    if (write_bottom && c > 0) {     // nobody below takes the left neighbour's bottom rows over (the first lane of the
+                                                     // strand will read them back, finish them and write them again)
+                        g_u8p pbo = tpc - VP8_TILE_BYTES + KT_Y_BOT;
 #pragma unroll
-                        for (int j = 0; j < 4; j++) *(g_u32x4p)(pbo + j * st) = (u32x4){ hF[j][0], hF[j][1], hF[j][2], hF[j][3] } ^ x;
+                        for (int j = 0; j < 4; j++) *(g_u32x4p)(pbo + j * 16) = (u32x4){ hF[j][0], hF[j][1], hF[j][2], hF[j][3] } ^ VP8_LF_BIAS;
                     }
 #pragma unroll
                     for (int j = 0; j < 4; j++) { sB[j] = e[j][3]; pb[j][0] = e[j][0]; pb[j][1] = e[j][1]; pb[j][2] = e[j][2]; }
                     if (last_col) {          // end of the row: nobody revisits the last dwords
 #pragma unroll
-                        for (int y = 0; y < 12; y++) *(GLOBAL_AS u32 *)(ras + y * ys + c * 16 + 12) = sF[y * 64] ^ VP8_LF_BIAS;
+                        for (int y = 0; y < 12; y++) *(GLOBAL_AS u32 *)(tpc + VP8_TILE_BYTES + KT_Y_WIN + 16 * y) = sF[y * 64] ^ VP8_LF_BIAS;
                         if (write_bottom) {
-                            g_u8p pbo = last_row ? ras + 12 * ys + c * 16 : tpc + HO_Y_ROWS;
-                            const int st = last_row ? ys : 16;
-                            const u32 x = last_row ? VP8_LF_BIAS : 0;
 #pragma unroll
-                            for (int j = 0; j < 4; j++) *(g_u32x4p)(pbo + j * st) = (u32x4){ e[j][0], e[j][1], e[j][2], e[j][3] } ^ x;
+                            for (int j = 0; j < 4; j++) *(g_u32x4p)(tpc + KT_Y_BOT + j * 16) = (u32x4){ e[j][0], e[j][1], e[j][2], e[j][3] } ^ VP8_LF_BIAS;
                         }
                     }
                 }
@@ -686,8 +687,8 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
                 bA[0] = bot[0]; bA[1] = bot[1]; l0[0] = rc[0]; l0[1] = rc[1];
                 STAMP(4)
                 // ---- loop filter of the plane, block row by block row
-                const int hoff = pl ? HO_V_ROWS : HO_U_ROWS, loff = pl ? HO_V_LINE : HO_U_LINE;
-                if (hand) *(g_u32x2p)(tpc + loff) = (u32x2){ bot[0], bot[1] };        // unfiltered bottom line: hand-over
+                const int poff = 32 * pl;
+                if (hand) *(g_u32x2p)(hpc + KH_U + 8 * pl) = (u32x2){ bot[0], bot[1] };        // unfiltered bottom line: hand-over
                 u32 Pc[4][2];
 #pragma unroll
                 for (int j = 0; j < 4; j++) { Pc[j][0] = tF[j][0]; Pc[j][1] = tF[j][1]; }
@@ -696,8 +697,8 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
                 lf_block_row<2>(o0, s0, Pc, true, gv, gh, L, d0);
                 STAMP(11)
                 {   // rows 4..7 of the macroblock above: final
-                    g_u8p pa = KF_ACT(act && !top) ? ras - 4 * ys + c * 8 : (g_u8p)dummy;
-                    const int st = KF_ACT(act && !top) ? ys : 0;
+                    g_u8p pa = KF_ACT(act && !top) ? tpc - rowbytes + KT_U_BOT + poff : (g_u8p)dummy;
+                    const int st = KF_ACT(act && !top) ? 8 : 0;
 #pragma unroll
                     for (int j = 0; j < 4; j++)
                         *(g_u32x2p)(pa + j * st) = (u32x2){ d0[j][0] ^ VP8_LF_BIAS, d0[j][1] ^ VP8_LF_BIAS };
@@ -706,11 +707,11 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
                 lf_block_row<2>(o1, s1, Pc, false, gv, gh, L, d1);
                 STAMP(11)
                 {   // rows 0..3: the left neighbour's last dword and this macroblock's first
-                    g_u8p po = KF_ACT(act) ? ras + c * 8 - KF_SHIFT : (g_u8p)dummy + 16;
-                    const int st = KF_ACT(act) ? ys : 0;
+                    g_u8p po = KF_ACT(act) ? tpc + KT_U_WIN + poff : (g_u8p)dummy;
+                    const int st = KF_ACT(act) ? 8 : 0;
 #pragma unroll
                     for (int j = 0; j < 4; j++)
-                        *(g_u32x2up)(po + j * st) = (u32x2){ s0[j] ^ VP8_LF_BIAS, d1[j][0] ^ VP8_LF_BIAS };
+                        *(g_u32x2p)(po + j * st) = (u32x2){ s0[j] ^ VP8_LF_BIAS, d1[j][0] ^ VP8_LF_BIAS };
                 }
                 STAMP(12)
                 u32 (&e)[4][2] = Pc;             // rows 4..7 as the second block row left them
@@ -718,24 +719,19 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
 #pragma unroll
                 for (int j = 0; j < 4; j++) hF[j][1] = s1[j];
                 if (act) {
-                    if (write_bottom && c > 0) {       // nobody below takes them over: to the frame (last row) or the hand-over tile
-                        g_u8p pbo = last_row ? ras + 4 * ys + (c - 1) * 8 : tpc - VP8_TILE_BYTES + hoff;
-                        const int st = last_row ? ys : 8;
-                        const u32 x = last_row ? VP8_LF_BIAS : 0;         // (the hand-over tile keeps the filter's biased form)
+                    if (write_bottom && c > 0) {       // nobody below takes the left neighbour's bottom rows over
+                        g_u8p pbo = tpc - VP8_TILE_BYTES + KT_U_BOT + poff;
 #pragma unroll
-                        for (int j = 0; j < 4; j++) *(g_u32x2p)(pbo + j * st) = (u32x2){ hF[j][0] ^ x, hF[j][1] ^ x };
+                        for (int j = 0; j < 4; j++) *(g_u32x2p)(pbo + j * 8) = (u32x2){ hF[j][0] ^ VP8_LF_BIAS, hF[j][1] ^ VP8_LF_BIAS };
                     }
 #pragma unroll
                     for (int j = 0; j < 4; j++) { sP[j * 64] = d1[j][1]; sB[j] = e[j][1]; pb[j][0] = e[j][0]; }
                     if (last_col) {        // end of the row: nobody revisits the last dword
 #pragma unroll
-                        for (int j = 0; j < 4; j++) *(GLOBAL_AS u32 *)(ras + j * ys + c * 8 + 4) = d1[j][1] ^ VP8_LF_BIAS;
+                        for (int j = 0; j < 4; j++) *(GLOBAL_AS u32 *)(tpc + VP8_TILE_BYTES + KT_U_WIN + poff + 8 * j) = d1[j][1] ^ VP8_LF_BIAS;
                         if (write_bottom) {
-                            g_u8p pbo = last_row ? ras + 4 * ys + c * 8 : tpc + hoff;
-                            const int st = last_row ? ys : 8;
-                            const u32 x = last_row ? VP8_LF_BIAS : 0;
 #pragma unroll
-                            for (int j = 0; j < 4; j++) *(g_u32x2p)(pbo + j * st) = (u32x2){ e[j][0] ^ x, e[j][1] ^ x };
+                            for (int j = 0; j < 4; j++) *(g_u32x2p)(tpc + KT_U_BOT + poff + j * 8) = (u32x2){ e[j][0] ^ VP8_LF_BIAS, e[j][1] ^ VP8_LF_BIAS };
                         }
                     }
                 }
@@ -746,7 +742,6 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
                 SWAP_U32(bA[0], bB[0]) SWAP_U32(bA[1], bB[1]) SWAP_U32(l0[0], l0[2]) SWAP_U32(l0[1], l0[3])
                 SWAP_U32(aA[0], aA[2]) SWAP_U32(aA[1], aA[3])
                 { const int t_ = tlA; tlA = tlB; tlB = t_; }
-                { g_u8p t_ = ras; ras = ras2; ras2 = t_; }
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     SWAP_U32(tF[j][0], tF[j][2]) SWAP_U32(tF[j][1], tF[j][3]) SWAP_U32(hF[j][0], hF[j][2]) SWAP_U32(hF[j][1], hF[j][3])

@@ -37,6 +37,7 @@ extern "C" __global__ void vp8_loopfilter_simt_chroma_kernel(const DevJob *jobs,
 extern "C" __global__ void vp8_loopfilter_kernel(const DevJob *jobs, int njobs, DevGeom g);
 extern "C" __global__ void vp8_extend_kernel(const DevJob *jobs, int njobs, DevGeom g);
 extern "C" __global__ void vp8_detile_kernel(const DevJob *jobs, int njobs, DevGeom g, int extend);
+extern "C" __global__ void vp8_detile_kf_kernel(const DevJob *jobs, int njobs, DevGeom g);
 // vp8_postproc.hip
 void vp8pp_down_and_across(hipStream_t st, const uint8_t *src, uint8_t *dst, int stride, int rows, int cols, int flimit);
 void vp8pp_mb_across(hipStream_t st, const uint8_t *src, uint8_t *dst, int stride, int rows, int cols, int flimit);
@@ -103,6 +104,7 @@ struct Knobs {
     // VP8HIP_FUSED=0: all-key-frame launches of the lane-per-row family run reconstruction and loop filter as two kernels with the
     // tiled scratch frames between them (the round-1/2 pipeline) instead of vp8_keyframe_simt_kernel
     int fused;
+    int detile_blocks;     // VP8HIP_DETILE_BLOCKS=n: workgroups of the key-frame kernel's tiled -> raster pass (default: two per CU)
     int lf_raster, lgG, simt_waves, wg_per_cu, xcu, xcu_S, xcu_NW, recon_nw, lf_nw, detile_stream, detile_defer;
 };
 static int env_int(const char *name, int dflt) { const char *e = getenv(name); return e && *e ? atoi(e) : dflt; }
@@ -118,6 +120,7 @@ static void read_knobs(Knobs &k)
     k.xcu_S = env_int("VP8HIP_XCU_S", 0);
     k.lf_split = env_int("VP8HIP_LF_SPLIT", 1);
     k.fused = env_int("VP8HIP_FUSED", 1) != 0;
+    k.detile_blocks = env_int("VP8HIP_DETILE_BLOCKS", 0);
     k.inter_split = env_int("VP8HIP_INTER_SPLIT", 384);
     k.inter_tiled = env_int("VP8HIP_INTER_TILED", 640);
     k.xcu_NW = env_int("VP8HIP_XCU_NW", 0);
@@ -152,7 +155,7 @@ struct vp8hip_ctx {
     hipEvent_t ev_lf_done, ev_detile_done[VP8HIP_NBUF];
     bool detile_used[VP8HIP_NBUF], detile_pending;
     // a tiled -> raster pass not launched yet: it goes out beside the NEXT launch's loop filter (or at the next join)
-    struct { bool valid; DevJob *jobs; int njobs, extend, par; hipEvent_t *ev; } deferred;
+    struct { bool valid, kf; DevJob *jobs; int njobs, extend, par; hipEvent_t *ev; } deferred;
     hipEvent_t ev_recon_done;
     int parity, last_par;        // set used by the next lane-per-row launch / by the last one
     char err[256];
@@ -533,14 +536,37 @@ extern "C" int vp8hip_ir_copy(vp8hip_ctx *c, int dst, int src)
 // that reads or writes frame buffers (other than another lane-per-row launch, which is ordered behind it on
 // the second stream anyway) calls this first.
 // Launch the deferred tiled -> raster pass on the second stream, behind `after` (an event on the main stream).
+// the tiled -> raster pass (+ border extension) of a lane-per-row launch: vp8_detile_kernel for the two-kernel pipeline's tiles,
+// vp8_detile_kf_kernel + vp8_extend_kernel for the key-frame kernel's
+static int launch_detile(vp8hip_ctx *c, hipStream_t st, DevJob *jobs, int njobs, int extend, bool kf)
+{
+    if (kf) {
+        // Two workgroups per CU, each looping over macroblock rows: the pass runs beside the next launch's vp8_keyframe_kernel
+        // (its waves need 16 registers: they fit in the gap two of that kernel's waves leave on a SIMD) and is to trickle -- the
+        // pair is bound by HBM bandwidth when the pass goes at full speed, and the key-frame kernel then loses more than the pass
+        // gains.  8192 1080p frames per launch, ms per step: 2 per CU 45.7-47.1, 4 per CU 49.2-51.5, all at once 49.9-50.2, 1 per
+        // CU 65 (the pass becomes the longer one)
+        long units = (long)c->dg.mb_rows * njobs;
+        const int cap = c->knobs.detile_blocks > 0 ? c->knobs.detile_blocks : 2 * c->num_cu;
+        if (units > cap) units = cap;
+        hipLaunchKernelGGL(vp8_detile_kf_kernel, dim3((unsigned)units), dim3(256), 0, st, (const DevJob *)jobs, njobs, c->dg);
+        if (extend) {
+            int bx = (c->geom.aligned_h + 64) / 4;
+            if (bx < 1) bx = 1;
+            if (bx > 64) bx = 64;
+            hipLaunchKernelGGL(vp8_extend_kernel, dim3(bx, njobs), dim3(256), 0, st, (const DevJob *)jobs, njobs, c->dg);
+        }
+    } else
+        hipLaunchKernelGGL(vp8_detile_kernel, dim3(c->dg.mb_rows, njobs), dim3(256), 0, st, (const DevJob *)jobs, njobs, c->dg, extend);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
 static int launch_deferred(vp8hip_ctx *c, hipEvent_t after)
 {
     if (!c->deferred.valid) return 0;
     HIPCHK(c, hipStreamWaitEvent(c->stream2, after, 0));
     HIPCHK(c, hipEventRecord(c->deferred.ev[4], c->stream2));
-    hipLaunchKernelGGL(vp8_detile_kernel, dim3(c->dg.mb_rows, c->deferred.njobs), dim3(256), 0, c->stream2,
-                       (const DevJob *)c->deferred.jobs, c->deferred.njobs, c->dg, c->deferred.extend);
-    HIPCHK(c, hipGetLastError());
+    if (launch_detile(c, c->stream2, c->deferred.jobs, c->deferred.njobs, c->deferred.extend, c->deferred.kf)) return -1;
     HIPCHK(c, hipEventRecord(c->deferred.ev[5], c->stream2));
     HIPCHK(c, hipEventRecord(c->ev_detile_done[c->deferred.par], c->stream2));
     c->deferred.valid = false;
@@ -623,11 +649,13 @@ extern "C" int vp8hip_decode(vp8hip_ctx *c, const vp8hip_job *jobs, int njobs, i
     // straight into the raster frame buffers -- unfiltered frames are carried through with the filter gated off -- (rows of two neighbouring macroblocks back to back: 32-byte pieces) and the tiled -> raster
     // pass is skipped; only the border extension is left.  +6..10 % from 1536 frames per launch up (1080p), a tie at 2048,
     // -4 % at 1024.  VP8HIP_LF_RASTER=0 keeps the tiled -> raster pass.
-    bool lf_raster = fused;
+    bool lf_raster = false;
     if (!fused && tiled && (stages & VP8HIP_STAGE_LF) && K.lf_raster)
         for (int i = 0; i < njobs && !lf_raster; i++)     // some frame is filtered: the loop filter kernel runs anyway
             if (jobs[i].ir_slot >= 0 && jobs[i].ir_slot < nsl) lf_raster = c->slots[jobs[i].ir_slot].hdr_copy.filter_level != 0;
-    const size_t tile_frame = (size_t)c->nmb * VP8_TILE_BYTES;
+    // scratch of a frame: a tile per macroblock -- the key-frame kernel's layout has one more per macroblock row and 32 bytes of
+    // unfiltered line per tile behind them (vp8_keyframe_simt.hip)
+    const size_t tile_frame = align_up((size_t)c->dg.mb_rows * (c->dg.mb_cols + 1) * (VP8_TILE_BYTES + 32), 256);
     const int par = c->parity;
     if (!tiled || lf_raster || !all_key) {
         // this launch touches the raster frame buffers directly: it writes them, or (inter frames) reads reference frames a
@@ -914,13 +942,19 @@ extern "C" int vp8hip_decode(vp8hip_ctx *c, const vp8hip_job *jobs, int njobs, i
         // no rotation: nothing reads this scratch set once the launch's loop filter is done
     } else if (tiled) {      // whatever stages ran, the frame buffer gets the result; borders are extended on the way
         const bool own_stream = K.detile_stream;
-        if (own_stream && !c->stream2) HIPCHK(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+        if (own_stream && !c->stream2) {
+            int prio_least = 0, prio_greatest = 0;
+            HIPCHK(c, hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+            HIPCHK(c, hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio_least));
+        }
         // deferred by default: the pass is launched with the NEXT lane-per-row launch, right after its recon, so
         // that it runs beside that launch's loop filter (which it disturbs less than the recon), or at the next join
-        const bool defer = own_stream && K.detile_defer;
+        // (the key-frame kernel's pass goes out at once: its waves are small enough -- 16 registers -- to run in the gaps the next
+        // launch's kernel leaves on every SIMD)
+        const bool defer = own_stream && K.detile_defer && !fused;
         hipStream_t ds = own_stream ? c->stream2 : c->stream;
         if (defer) {
-            c->deferred.valid = true; c->deferred.jobs = c->d_jobs; c->deferred.njobs = njobs;
+            c->deferred.valid = true; c->deferred.kf = fused; c->deferred.jobs = c->d_jobs; c->deferred.njobs = njobs;
             c->deferred.extend = (stages & VP8HIP_STAGE_EXTEND) ? 1 : 0; c->deferred.par = par; c->deferred.ev = ev;
         } else {
         if (own_stream) {
@@ -928,9 +962,7 @@ extern "C" int vp8hip_decode(vp8hip_ctx *c, const vp8hip_job *jobs, int njobs, i
             HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_lf_done, 0));
         }
         HIPCHK(c, hipEventRecord(ev[4], ds));
-        hipLaunchKernelGGL(vp8_detile_kernel, dim3(c->dg.mb_rows, njobs), dim3(256), 0, ds, (const DevJob *)c->d_jobs, njobs, c->dg,
-                           (stages & VP8HIP_STAGE_EXTEND) ? 1 : 0);
-        HIPCHK(c, hipGetLastError());
+        if (launch_detile(c, ds, c->d_jobs, njobs, (stages & VP8HIP_STAGE_EXTEND) ? 1 : 0, fused)) return -1;
         HIPCHK(c, hipEventRecord(ev[5], ds));
         HIPCHK(c, hipEventRecord(c->ev_detile_done[par], ds));
         }

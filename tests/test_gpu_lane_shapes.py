@@ -115,7 +115,7 @@ def test_benchmark_shape_full_size(pkg, monkeypatch):
     w, h, frames = pkg.read_ivf(ivf_path(name))
     gold = golden_md5(name)
     nsrc = len(frames)
-    per_frame = 3_428_352 + 7_700_000 + 3 * 3_133_440 + 4096
+    per_frame = 3_428_352 + 7_700_000 + 3 * 3_423_000 + 4096
     n = 8192
     while n > 1024 and n * per_frame > free * 0.9:
         n //= 2
