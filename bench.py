@@ -52,6 +52,11 @@ PMC_TRAFFIC_B_PER_MB = {        # the loop filter (luma + chroma kernels) writes
     # profiles/r02_a_pmc_{FETCH,WRITE}_SIZE_1024frames_G8.csv.  The loop filter's 1014 B/MB of writes against 384 B/MB of pixels are
     # the 32-byte (luma) and 16-byte (chroma) pieces of frame rows a lane has to give at a time
     "recon": 2 * 529.5 + 385.7, "loopfilter": 2 * (168.1 + 104.1) + 535.6 + 478.8, "extend": 2 * 27.5 + 40.4}
+# vp8_keyframe_kernel (reconstruction + loop filter in one pass, macroblock-window tiles out) and its tiled -> raster pass + border
+# extension: profiles/r03_a_pmc_{fetch,write}_1024_G8.csv (1024 frames per launch, 8 lanes per strand as at the default launch size;
+# FETCH_SIZE doubled as above).  At 64 lanes per strand -- every SIMD busy, most lanes idle -- the kernel fetches 1390 B/MB
+# (profiles/r03_a_pmc_fetch_1024_G64.csv); its writes at 8192 frames per launch: 484 B/MB (r03_a_pmc_write_8192_sharedIR.csv).
+PMC_TRAFFIC_B_PER_MB_FUSED = {"recon": 2 * 511.1 + 468.0, "loopfilter": 0.0, "extend": 2 * 193.8 + 396.5 + 2 * 27.5 + 40.4}
 PMC_TRAFFIC_B_PER_MB_DETILE = { # tiled -> raster pass (vp8_detile_kernel) after the loop filter
     "recon": 2 * 448.68 + 385.22, "loopfilter": 2 * 239.63 + 414.12, "extend": 2 * 192.08 + 466.87}
 
@@ -393,7 +398,7 @@ def main():
         # (the lane-per-row loop filter is two kernels side by side on two streams, luma and chroma; "loopfilter" is the interval
         #  both take together, which is the duration of the luma kernel -- the chroma kernel ends inside it)
         split = st.lf_kernels == 2      # (VP8HIP_FUSED=0 only: the two-kernel pipeline's loop filter as luma + chroma kernels)
-        fused = bool(getattr(st, "fused", 0))   # reconstruction + loop filter in ONE kernel (vp8_keyframe_simt_kernel): ms["recon"] is its time
+        fused = bool(getattr(st, "fused", 0))   # reconstruction + loop filter in ONE kernel (vp8_keyframe_kernel): ms["recon"] is its time
         if fused:
             # SURVEY.md 8(d)'s byte model for the stages the kernel covers: residual + intra recon (1217) + loop filter (770)
             bytes_per_launch["recon"] = (B_RECON + B_LF) * nmb * F
@@ -404,13 +409,15 @@ def main():
                   "extend": "vp8_detile_kernel (tiled -> raster + border extension)" if detile else "vp8_extend_kernel"} if lane else
                  {"recon": "vp8_recon_kernel", "loopfilter": "vp8_loopfilter_kernel", "extend": "vp8_extend_kernel"})
         if fused:
-            names["recon"] = "vp8_keyframe_simt_kernel"
+            names["recon"] = "vp8_keyframe_kernel"
             names["loopfilter"] = None
+            names["extend"] = ("vp8_detile_kf_kernel + vp8_extend_kernel (tiled -> raster, then borders; on a second stream BESIDE the next "
+                               "launch's vp8_keyframe_kernel, so its time overlaps that kernel's)")
         dom = max(ms, key=lambda k: ms[k])
         achieved = bytes_per_launch[dom] / (ms[dom] * 1e-3) / 1e9
         # SURVEY.md 8(d)'s own figure for the full key-frame path: 1217 + 770 + 36 = 2023 B/MB
         survey_gbps = (B_RECON + B_LF + B_EXTEND) * nmb * F / (elapsed_local / K) / 1e9
-        pmc = PMC_TRAFFIC_B_PER_MB_DETILE if detile else PMC_TRAFFIC_B_PER_MB
+        pmc = PMC_TRAFFIC_B_PER_MB_FUSED if fused else PMC_TRAFFIC_B_PER_MB_DETILE if detile else PMC_TRAFFIC_B_PER_MB
         counted = lane and args.workload == "1080p"
         out = {
             "metric": "vp8_decode_pixel_path_mpix_per_s",
@@ -437,7 +444,8 @@ def main():
                 "sharded_md5_listing_equals_1gpu_listing": listing_ok,
                 "md5_checked_frames_per_rank": len(sample),
                 "kernel_ms": {k: round(v, 4) for k, v in ms.items()},
-                "kernel_family": "one macroblock row per lane, macroblock-tiled scratch frames" if lane
+                "kernel_family": ("one macroblock row per lane; reconstruction + loop filter fused, luma and chroma waves paired on every SIMD"
+                                  if fused else "one macroblock row per lane, macroblock-tiled scratch frames") if lane
                                  else "one wave per macroblock row",
                 "kernels": names,
                 "waves_per_workgroup": {"recon": st.recon_waves, "loopfilter": st.lf_waves},
@@ -452,10 +460,10 @@ def main():
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 5),
-                "traffic": round(pmc[dom] * nmb * F) if counted else None,
+                "traffic": round(pmc[dom] * nmb * F) if counted and pmc[dom] is not None else None,
                 "traffic_source": ("scaled: per-macroblock FETCH_SIZE x2 + WRITE_SIZE of this kernel from rocprofv3 --pmc passes at "
                                    "1024 frames per launch (profiles/), times the macroblocks of this launch") if counted else None,
-                "traffic_bytes_per_macroblock": ({k: round(v, 1) for k, v in pmc.items()} if counted else None),
+                "traffic_bytes_per_macroblock": ({k: (round(v, 1) if v is not None else None) for k, v in pmc.items()} if counted else None),
                 "algorithmic_bytes_per_launch": bytes_per_launch[dom],
                 "mean_launch_ms": round(ms[dom], 4),
                 "all_kernels_GBps": {k: round(bytes_per_launch[k] / (ms[k] * 1e-3) / 1e9, 2) if ms[k] > 0 else None

@@ -6,7 +6,7 @@ NF=${2:-8192}
 FX=${4:-kf_1920x1080}
 MBS=${5:-8160}
 SH=${6:-}
-[ -n "$3" ] && export VP8HIP_SIMT_LGG=$3
+
 cd /tmp; export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 run() {
