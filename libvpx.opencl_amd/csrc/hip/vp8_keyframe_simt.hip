@@ -266,14 +266,16 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
                 const u32 ent = s_queue[idx];
                 const int owner = ent & 63, i = (ent >> 6) & 3;
                 const bool given = (ent >> 8) & 1;
+                // (the quantiser and the Y2 DC are requested before the coefficients: one LDS round trip for all of them)
                 const u32 dq = s_tab[owner];
+                const int blk = blk0 + i;
+                const u32 y2w = LUMA ? s_y2dc[owner * 8 + (blk >> 1)] : 0u;
                 const u32 slot = stage_base + i * 2048 + owner * 16;
                 u32x4 ca, cb;
                 asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024\n\ts_waitcnt lgkmcnt(0)"
                              : "=&v"(ca), "=&v"(cb) : "v"(slot) : "memory");
                 __builtin_amdgcn_sched_barrier(0);
-                int dc_in = 0;
-                if (LUMA && given) { const int blk = blk0 + i; dc_in = (short)(s_y2dc[owner * 8 + (blk >> 1)] >> (16 * (blk & 1))); }
+                const int dc_in = (short)(y2w >> (16 * (blk & 1)));
                 int res[16];
                 dequant_idct(ca, cb, dq & 0xffff, dq >> 16, given, dc_in, res);
                 u32x4 oa, ob;
