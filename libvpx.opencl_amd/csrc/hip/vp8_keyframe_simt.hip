@@ -230,12 +230,17 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
     // The owner requests the coefficients of the blocks cfb[0..3] of its macroblock that have any (`m4`) into ITS OWN four staging
     // slots (s_stage[block][half][lane]: no look-up stands between knowing the macroblock and the request), and the lanes
     // queue these blocks, behind the n0 already queued, for the transform.
-    auto queue = [&](g_cs16p cfb, const u32 m4, const u32 dcg, const int n0) {
+    // (The slots this kernel decodes hold their coefficients PACKED: the blocks 0..23 of a macroblock that have any stand at the
+    // start of its 800 bytes, in block order -- vp8_ir_pack_kernel --, so that what is fetched is what is used: with a third of
+    // the blocks coded, the dense form touches four of every five 128-byte lines.  rank0: coded blocks of the macroblock in
+    // front of this phase's.)
+    auto queue = [&](g_cs16p cf_mb, const int rank0, const u32 m4, const u32 dcg, const int n0) {
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             if ((m4 >> i) & 1) {
-                __builtin_amdgcn_global_load_lds((g_cvp)(cfb + i * 16), (lds_vp)(s_stage + i * 512), 16, 0, 0);
-                __builtin_amdgcn_global_load_lds((g_cvp)(cfb + i * 16 + 8), (lds_vp)(s_stage + i * 512 + 256), 16, 0, 0);
+                g_cs16p cfb = cf_mb + (rank0 + __builtin_popcount(m4 & ((1u << i) - 1))) * 16;
+                __builtin_amdgcn_global_load_lds((g_cvp)cfb, (lds_vp)(s_stage + i * 512), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((g_cvp)(cfb + 8), (lds_vp)(s_stage + i * 512 + 256), 16, 0, 0);
             }
         }
         wave_lds_sync();                                             // the queue's last reader is done
@@ -330,6 +335,12 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
                 const u32 ge1 = ((e[q] + 0x7f7f7f7fu) & 0x80808080u) >> 7;
                 m |= (((ge1 * 0x00204081u) >> 21) & 0xfu) << (4 * q);
             }
+            // the coded luma blocks in front of the chroma ones, counted into bits 8..12
+            const u32 el[4] = { m0.z, m0.w, m1.x, m1.y };
+            u32 nl = 0;
+#pragma unroll
+            for (int q = 0; q < 4; q++) nl += __builtin_popcount((el[q] + 0x7f7f7f7fu) & 0x80808080u);
+            m |= (has_y2 ? 16u : nl) << 8;
         }
         if (skip) m = 0;
         jm = m;
@@ -436,7 +447,7 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
         // the row starters' first phase joins the queue behind the blocks the others had transformed at the end of the last step
         if (__builtin_amdgcn_ballot_w64(late) != 0) {
             const int n0 = q_n;
-            queue(cfp + (LUMA ? 0 : 16 * 16), late ? jm & 0xf : 0, dc_given, n0);
+            queue(cfp, LUMA ? 0 : (int)(jm >> 8), late ? jm & 0xf : 0, dc_given, n0);
             drain(LUMA ? 0 : 16, n0, 0);
         }
         // the descriptor of the macroblock after this one: on its way from here (a lane at the end of its row, or idle, fetches
@@ -528,7 +539,7 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
                 if (by < 3) {
                     fetch(rr);
                     STAMP(8)
-                    queue(cfp + (4 * by + 4) * 16, (jm >> (4 * by + 4)) & 0xf, dc_given, 0);
+                    queue(cfp, __builtin_popcount(jm & ((16u << (4 * by)) - 1)), (jm >> (4 * by + 4)) & 0xf, dc_given, 0);
                 } else {
                     // (all of this macroblock's phases have been transformed: its entries of s_tab / s_y2dc are free)
                     u32 n_jm = 0, n_dcg = 0;
@@ -545,7 +556,7 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
                     STAMP(9)
                     fetch(rr);
                     STAMP(8)
-                    queue(cfp + VP8IR_COEF_PER_MB, n_jm & 0xf, n_dcg, 0);
+                    queue(cfp + VP8IR_COEF_PER_MB, 0, n_jm & 0xf, n_dcg, 0);
                 }
                 STAMP(3)
                 const u32 lcur = l0[0];
@@ -645,7 +656,7 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
                 u32x4 rr[8];
                 fetch(rr);
                 const u32 rmg = jm >> (4 * pl);
-                if (pl == 0) queue(cfp + 20 * 16, (jm >> 4) & 0xf, 0, 0);
+                if (pl == 0) queue(cfp, (int)(jm >> 8) + __builtin_popcount(jm & 0xf), (jm >> 4) & 0xf, 0, 0);
                 else {
                     u32 n_jm = 0, n_dcg = 0;
                     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
@@ -655,7 +666,7 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
                     const u32x4 z = { 0, 0, 0, 0 };
                     if (more) prepare_mb(m0, m1, z, z, cfp + VP8IR_COEF_PER_MB, n_jm, n_dcg);
                     nx_w0 = m0.x; nx_w1 = m0.y; nx_jm = n_jm; nx_dcg = 0;
-                    queue(cfp + VP8IR_COEF_PER_MB + 16 * 16, n_jm & 0xf, 0, 0);
+                    queue(cfp + VP8IR_COEF_PER_MB, (int)(n_jm >> 8), n_jm & 0xf, 0, 0);
                 }
                 STAMP(3)
                 const u32 aC0 = aA[0], aC1 = aA[1], lC0 = l0[0], lC1 = l0[1];

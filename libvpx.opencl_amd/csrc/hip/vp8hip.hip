@@ -69,6 +69,52 @@ vp8_ir_expand_kernel(const vp8ir_mb *__restrict__ mbs, const int16_t *__restrict
     *(u32x4 *)(coef + (size_t)mb * VP8IR_COEF_PER_MB + k * 16 + (ch & 1) * 8) = v;
 }
 
+// Packed coefficients: the form vp8_keyframe_kernel reads a key frame's slot in.  The blocks 0..23 of a macroblock that have
+// coefficients (eob >= 1; every luma block of a macroblock with a Y2 block: their DCs come out of it, decodframe.c:262-296) move
+// to the front of its 800 bytes, in block order; the Y2 block stays where it is.  With a third of the blocks coded the dense
+// form makes a kernel fetch four of every five 128-byte lines of the array; packed, it fetches what it uses.  In place, one
+// thread per macroblock: a block only ever moves towards the front, past blocks that have moved already.  `unpack` restores the
+// dense form (zeros where a block has no coefficients) for the kernels that read that.  slots: indices into the slot pool.
+static __device__ __forceinline__ unsigned int vp8_coded_blocks(const vp8ir_mb &m)
+{
+    if (m.flags & VP8IR_MB_SKIP) return 0;
+    unsigned int mask = 0;
+    for (int k = 0; k < 24; k++) mask |= (unsigned int)(m.eobs[k] >= 1) << k;
+    if (m.y_mode != VP8IR_B_PRED && m.y_mode != VP8IR_SPLITMV) mask |= 0xffffu;
+    return mask;
+}
+__global__ void __launch_bounds__(256)
+vp8_ir_pack_kernel(char *slot_base, size_t slot_bytes, size_t o_mbs, size_t o_coef, const int *__restrict__ slots, int nslots, int nmb, int unpack)
+{
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+    const int si = (int)(gid / nmb), mb = (int)(gid - (long)si * nmb);
+    if (si >= nslots) return;
+    char *slot = slot_base + slot_bytes * (size_t)slots[si];
+    const vp8ir_mb &m = ((const vp8ir_mb *)(slot + o_mbs))[mb];
+    u32x4 *cf = (u32x4 *)((int16_t *)(slot + o_coef) + (size_t)mb * VP8IR_COEF_PER_MB);      // two per block
+    const unsigned int mask = vp8_coded_blocks(m);
+    if (!unpack) {
+        int r = 0;
+        for (int k = 0; k < 24; k++) {
+            if (!((mask >> k) & 1)) continue;
+            if (r != k) { const u32x4 a = cf[2 * k], b = cf[2 * k + 1]; cf[2 * r] = a; cf[2 * r + 1] = b; }
+            r++;
+        }
+    } else {
+        if (m.flags & VP8IR_MB_SKIP) return;
+        int r = __builtin_popcount(mask);
+        for (int k = 23; k >= 0; k--) {
+            if (!((mask >> k) & 1)) continue;
+            r--;
+            if (r != k) { const u32x4 a = cf[2 * r], b = cf[2 * r + 1]; cf[2 * k] = a; cf[2 * k + 1] = b; }
+        }
+        const u32x4 z = { 0, 0, 0, 0 };
+        for (int k = 0; k < 24; k++)
+            if (!((mask >> k) & 1)) { cf[2 * k] = z; cf[2 * k + 1] = z; }
+    }
+}
+
 static char g_create_error[256] = "";
 
 struct Slot {
@@ -80,6 +126,7 @@ struct Slot {
     char *h_block;                 // pinned mirror, allocated on first vp8hip_ir_map
     char *d_sparse;                // device staging of a sparse upload: descriptors, blocks, DCs; allocated on first vp8hip_ir_upload_sparse
     int16_t *h_dcs;                // pinned staging of the DC stream while the feeder writes it (behind the dense mirror in h_block)
+    bool packed;                   // the coefficients on the device are in vp8_keyframe_kernel's packed form (vp8_ir_pack_kernel)
 };
 
 // Tuning / test knobs, read from the environment by vp8hip_configure (never per launch):
@@ -188,6 +235,7 @@ struct vp8hip_ctx {
     // vp8hip_postproc: dither table (440 shorts), noise table (3072) and per-row noise phases (16384) on the device
     char *d_pp, *h_pp; bool pp_rv_loaded; hipEvent_t ev_pp;
     unsigned int *d_sched;         // vp8_keyframe_kernel's role / work counters
+    int *h_pack, *d_pack; int pack_cap;      // slots whose coefficients a launch has to pack / unpack first
 };
 
 static int fail(vp8hip_ctx *c, int code, const char *fmt, ...)
@@ -324,6 +372,8 @@ extern "C" void vp8hip_destroy(vp8hip_ctx *c)
     if (c->h_jobs) (void)hipHostFree(c->h_jobs);
     if (c->h_status) (void)hipHostFree(c->h_status);
     if (c->d_sched) (void)hipFree(c->d_sched);
+    if (c->d_pack) (void)hipFree(c->d_pack);
+    if (c->h_pack) (void)hipHostFree(c->h_pack);
     destroy_events(c);
     if (c->stream_d2h) { (void)hipStreamSynchronize(c->stream_d2h); (void)hipStreamDestroy(c->stream_d2h); }
     if (c->ev_d2h_from) (void)hipEventDestroy(c->ev_d2h_from);
@@ -414,7 +464,7 @@ static int configure_pools(vp8hip_ctx *c, int width, int height, int num_fb, int
         s.d_hdr = (vp8ir_frame_hdr *)d; s.d_mbs = (vp8ir_mb *)(d + o_mbs);
         s.d_coef = (int16_t *)(d + o_coef); s.d_mvs = (vp8ir_mv *)(d + o_mvs);
         s.h_block = nullptr; s.h_hdr = nullptr; s.h_mbs = nullptr; s.h_coef = nullptr; s.h_mvs = nullptr;
-        s.d_sparse = nullptr; s.h_dcs = nullptr;
+        s.d_sparse = nullptr; s.h_dcs = nullptr; s.packed = false;
         memset(&s.hdr_copy, 0, sizeof s.hdr_copy);
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -459,6 +509,7 @@ extern "C" int vp8hip_ir_upload(vp8hip_ctx *c, int slot)
                     h.mb_rows, c->dg.mb_cols, c->dg.mb_rows);
     HIPCHK(c, hipSetDevice(c->device));
     s.hdr_copy = h;
+    s.packed = false;
     HIPCHK(c, hipMemcpyAsync(s.d_mbs, s.h_mbs, (size_t)c->nmb * sizeof(vp8ir_mb), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(s.d_coef, s.h_coef, (size_t)c->nmb * VP8IR_COEF_PER_MB * sizeof(int16_t),
                              hipMemcpyHostToDevice, c->stream));
@@ -497,6 +548,7 @@ extern "C" int vp8hip_ir_upload_sparse(vp8hip_ctx *c, int slot, size_t nblocks, 
     memcpy((char *)s.h_mbs + o_dcs, s.h_dcs, ndcs * 2);
     const int16_t *d_blocks = (const int16_t *)(s.d_sparse + o_blocks), *d_dcs = (const int16_t *)(s.d_sparse + o_dcs);
     s.hdr_copy = h;
+    s.packed = false;
     HIPCHK(c, hipMemcpyAsync(s.d_sparse, s.h_mbs, used, hipMemcpyHostToDevice, c->stream));
     if (h.frame_type != 0)
         HIPCHK(c, hipMemcpyAsync(s.d_mvs, s.h_mvs, (size_t)c->nmb * 16 * sizeof(vp8ir_mv), hipMemcpyHostToDevice, c->stream));
@@ -515,6 +567,7 @@ extern "C" int vp8hip_ir_copy(vp8hip_ctx *c, int dst, int src)
     Slot &d = c->slots[dst], &s = c->slots[src];
     HIPCHK(c, hipSetDevice(c->device));
     d.hdr_copy = s.hdr_copy;
+    d.packed = s.packed;
     HIPCHK(c, hipMemcpyAsync(d.d_mbs, s.d_mbs, (size_t)c->nmb * sizeof(vp8ir_mb), hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(d.d_coef, s.d_coef, (size_t)c->nmb * VP8IR_COEF_PER_MB * sizeof(int16_t),
                              hipMemcpyDeviceToDevice, c->stream));
@@ -703,6 +756,32 @@ extern "C" int vp8hip_decode(vp8hip_ctx *c, const vp8hip_job *jobs, int njobs, i
     HIPCHK(c, hipMemcpyAsync(c->d_jobs, c->h_jobs, sizeof(DevJob) * njobs, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipEventRecord(c->ev_jobs, c->stream));
 
+    // ---- the coefficient form this launch's kernels read: packed for vp8_keyframe_kernel, dense for every other
+    if (stages & VP8HIP_STAGE_RECON) {
+        if (c->pack_cap < njobs) {
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            if (c->d_pack) (void)hipFree(c->d_pack);
+            if (c->h_pack) (void)hipHostFree(c->h_pack);
+            c->d_pack = nullptr; c->h_pack = nullptr; c->pack_cap = 0;
+            HIPCHK(c, hipMalloc((void **)&c->d_pack, sizeof(int) * (size_t)(njobs < 64 ? 64 : njobs)));
+            HIPCHK(c, hipHostMalloc((void **)&c->h_pack, sizeof(int) * (size_t)(njobs < 64 ? 64 : njobs), hipHostMallocDefault));
+            c->pack_cap = njobs < 64 ? 64 : njobs;
+        }
+        int n = 0;
+        for (int i = 0; i < njobs; i++) {
+            Slot &sl = c->slots[jobs[i].ir_slot];
+            if (sl.packed != fused) { sl.packed = fused; c->h_pack[n++] = jobs[i].ir_slot; }     // (a slot named twice converts once)
+        }
+        if (n) {
+            // (h_pack is reused by the next call: the copy below is waited for through ev_jobs, recorded after it)
+            HIPCHK(c, hipMemcpyAsync(c->d_pack, c->h_pack, sizeof(int) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, hipEventRecord(c->ev_jobs, c->stream));
+            const long threads = (long)n * c->nmb;
+            hipLaunchKernelGGL(vp8_ir_pack_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, c->stream, c->slot_block_dev,
+                               c->slot_bytes, c->o_mbs, c->o_coef, (const int *)c->d_pack, n, c->nmb, fused ? 0 : 1);
+            HIPCHK(c, hipGetLastError());
+        }
+    }
     const int wg_per_cu = K.wg_per_cu >= 1 && K.wg_per_cu <= 8 ? K.wg_per_cu : 1;
     const int grid = njobs < c->num_cu * wg_per_cu ? njobs : c->num_cu * wg_per_cu;
     c->stats.workgroups = grid;
