@@ -261,10 +261,8 @@ static void free_pools(vp8hip_ctx *c)
     if (c->slot_block_dev) (void)hipFree(c->slot_block_dev);
     if (c->gran_recon) (void)hipFree(c->gran_recon);
     if (c->gran_lf) (void)hipFree(c->gran_lf);
-    if (c->d_pp) { (void)hipFree(c->d_pp); (void)hipHostFree(c->h_pp); (void)hipEventDestroy(c->ev_pp); c->h_pp = nullptr; }
     if (c->d_intra_flags) (void)hipFree(c->d_intra_flags);
     c->d_intra_flags = nullptr; c->intra_flags_cap = 0;
-    c->d_pp = nullptr; c->pp_rv_loaded = false;
     c->gran_recon = c->gran_lf = nullptr; c->gran_recon_cap = c->gran_lf_cap = 0;
     for (Slot &s : c->slots) {
         if (s.h_block) (void)hipHostFree(s.h_block);
@@ -372,6 +370,11 @@ extern "C" void vp8hip_destroy(vp8hip_ctx *c)
     if (c->h_jobs) (void)hipHostFree(c->h_jobs);
     if (c->h_status) (void)hipHostFree(c->h_status);
     if (c->d_sched) (void)hipFree(c->d_sched);
+    // the post-processing tables outlive reconfigurations: the caller's noise state does too (vp8/common/postproc.c keeps
+    // postproc_state.noise across vp8_alloc_frame_buffers) and only sends the noise table again when q changes
+    if (c->d_pp) (void)hipFree(c->d_pp);
+    if (c->h_pp) (void)hipHostFree(c->h_pp);
+    if (c->ev_pp) (void)hipEventDestroy(c->ev_pp);
     if (c->d_pack) (void)hipFree(c->d_pack);
     if (c->h_pack) (void)hipHostFree(c->h_pack);
     destroy_events(c);
@@ -1105,11 +1108,15 @@ extern "C" int vp8hip_postproc(vp8hip_ctx *c, int src_fb, int dst_fb, int tmp_fb
     HIPCHK(c, hipSetDevice(c->device));
     if (join_detile(c)) return -1;
     if (c->d2h_count) { HIPCHK(c, hipEventSynchronize(c->ev_d2h_done)); c->d2h_count = 0; }   // a batch download may be reading dst
-    if (!c->d_pp) {
-        HIPCHK(c, hipMalloc((void **)&c->d_pp, 1024 + 3072 + 16384));
+    if (!c->d_pp || !c->h_pp || !c->ev_pp) {
+        // (each piece on its own: a failure half way leaves what exists for the next call, never a null event to wait on)
+        if (!c->d_pp) {
+            HIPCHK(c, hipMalloc((void **)&c->d_pp, 1024 + 3072 + 16384));
+            HIPCHK(c, hipMemsetAsync(c->d_pp, 0, 1024 + 3072 + 16384, c->stream));     // a noise table never sent is all zeros, as the reference's
+        }
         // the caller's tables go through a pinned copy of our own, so that they may be reused the moment the call returns
-        HIPCHK(c, hipHostMalloc((void **)&c->h_pp, 1024 + 3072 + 16384, hipHostMallocDefault));
-        HIPCHK(c, hipEventCreateWithFlags(&c->ev_pp, hipEventDisableTiming));
+        if (!c->h_pp) HIPCHK(c, hipHostMalloc((void **)&c->h_pp, 1024 + 3072 + 16384, hipHostMallocDefault));
+        if (!c->ev_pp) HIPCHK(c, hipEventCreateWithFlags(&c->ev_pp, hipEventDisableTiming));
     } else
         HIPCHK(c, hipEventSynchronize(c->ev_pp));       // the previous call's copies have left the pinned staging
     const short *d_rv = (const short *)c->d_pp;

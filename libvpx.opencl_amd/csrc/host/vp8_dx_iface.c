@@ -273,6 +273,11 @@ static vpx_codec_err_t vp8_decode(vpx_codec_alg_priv_t *p, const uint8_t *data, 
     if (p->ref_used & VP8_ALTR_FRAME) corrupt |= p->fb_corrupted[p->refs.alt_idx];
     p->fb_corrupted[p->refs.new_idx] = corrupt;
 
+    /* (allocated before anything is decoded: a failure here must not drop a frame that has been decoded and swapped in) */
+    if ((p->base.init_flags & VPX_CODEC_USE_POSTPROC) && !p->pp && !(p->pp = (vp8_pp_state *)calloc(1, sizeof *p->pp))) {
+        vp8_refs_release_new(&p->refs);
+        return VPX_CODEC_MEM_ERROR;
+    }
     t1 = now_s();
     if (vp8hip_ir_upload_sparse(p->hip, 0, nblocks, ndcs)) { vp8_refs_release_new(&p->refs); return gpu_error(p, "vp8hip_ir_upload_sparse"); }
     job.ir_slot = 0;
@@ -300,7 +305,6 @@ static vpx_codec_err_t vp8_decode(vpx_codec_alg_priv_t *p, const uint8_t *data, 
                 p->postproc_cfg.noise_level = 0;
                 p->postproc_cfg_set = 1;
             }
-            if (!p->pp && !(p->pp = (vp8_pp_state *)calloc(1, sizeof *p->pp))) return VPX_CODEC_MEM_ERROR;
             if (vp8_pp_prepare(p->pp, &p->postproc_cfg, hdr.filter_level, p->geom.aligned_h, &pp)) {
                 if (vp8hip_postproc(p->hip, show_fb, FB_POST, FB_PPTMP, &pp)) return gpu_error(p, "vp8hip_postproc");
                 show_fb = FB_POST;

@@ -15,6 +15,16 @@
 #include "vp8_boolreader.h"
 #include "vp8_tables.h"
 
+/* a polite spin: the x86 PAUSE hint where there is one, a compiler barrier elsewhere (the caller yields after a while) */
+static inline void cpu_relax(void)
+{
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#else
+    __asm__ __volatile__("" ::: "memory");
+#endif
+}
+
 /* ------------------------------------------------------------------------------------------
  * persistent per-MB state (the reference's MODE_INFO, vp8/common/blockd.h:168-184), kept with a
  * one-entry border on the top and left so neighbour look-ups need no edge tests
@@ -869,7 +879,7 @@ typedef struct tok_job {
     vp8ir_mv *mvs;
     int nthreads;
     volatile int *progress;          /* per row: macroblocks finished */
-    volatile int overflow;
+    int overflow;                 /* set by any thread (atomically): a sparse stream ran out of room */
 } tok_job;
 
 typedef struct tok_worker { tok_job *job; int id; tok_stream out; int bad; pthread_t thread; } tok_worker;
@@ -893,8 +903,8 @@ static int decode_row(tok_job *j, tok_stream *out, int r, vp8_boolreader *br)
             const int need = c + 4 < p->mb_cols ? c + 4 : p->mb_cols;
             int spins = 0;
             while (__atomic_load_n(&j->progress[(r - 1) * PROGRESS_STRIDE], __ATOMIC_ACQUIRE) < need) {
-                if (j->overflow) return 1;
-                if (++spins < 2000) __builtin_ia32_pause(); else sched_yield();
+                if (__atomic_load_n(&j->overflow, __ATOMIC_ACQUIRE)) return 1;
+                if (++spins < 2000) cpu_relax(); else sched_yield();
             }
         }
         memset(o, 0, sizeof *o);
@@ -917,7 +927,7 @@ static int decode_row(tok_job *j, tok_stream *out, int r, vp8_boolreader *br)
                 for (k = 0; k < 25; k++) {
                     if (k == 24 && !has_y2) break;
                     if (o->eobs[k] > 1) {
-                        if (out->nb >= out->cap_blocks) { j->overflow = 1; return 1; }
+                        if (out->nb >= out->cap_blocks) { __atomic_store_n(&j->overflow, 1, __ATOMIC_RELEASE); return 1; }
                         memcpy(out->blocks + (out->first_block + out->nb) * 16, q + k * 16, 32);
                         out->nb++;
                     } else if (o->eobs[k] == 1 && !(has_y2 && k < 16))
@@ -1030,13 +1040,13 @@ static int decode_mbs(vp8_parser *p, vp8ir_mb *mbs, int16_t *coef, int16_t *bloc
             started = t;
         }
         if (started != nthreads - 1) {                    /* could not start them all: nobody may wait for a missing row */
-            job.overflow = 1;
+            __atomic_store_n(&job.overflow, 1, __ATOMIC_RELEASE);
             for (t = 1; t <= started; t++) pthread_join(w[t].thread, NULL);
             return fail(p, VP8P_MEM_ERROR, "cannot start the token partition threads");
         }
         tok_worker_main(&w[0]);
         for (t = 1; t < nthreads; t++) pthread_join(w[t].thread, NULL);
-        if (job.overflow) return fail(p, VP8P_MEM_ERROR, "sparse coefficient stream overflow");
+        if (__atomic_load_n(&job.overflow, __ATOMIC_ACQUIRE)) return fail(p, VP8P_MEM_ERROR, "sparse coefficient stream overflow");
         for (t = 0; t < nthreads; t++) bad |= w[t].bad;
         if (!coef) {
             /* close the gaps: thread t's entries follow thread t-1's, and its macroblocks' indices move with them.

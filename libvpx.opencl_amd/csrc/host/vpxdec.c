@@ -4,8 +4,8 @@
  * benchmarks use (vpxdec.c:66-135 option table, :1034-1124 main loop): IVF input, --i420 / --yv12,
  * --md5 (one digest over all output, printed as "<md5>  <outfile>"), -o/--output, --noblit,
  * --summary / --progress (frames, microseconds inside vpx_codec_decode only, fps -- the same
- * bracket as vpxdec.c:1041-1055), --limit, --skip, -t/--threads (accepted, ignored: the GPU path has
- * no CPU worker threads), --codec=vp8, -v, and the VP8 post-processing options --postproc, --deblock,
+ * bracket as vpxdec.c:1041-1055), --limit, --skip, -t/--threads (host threads for the token partitions of a frame: the
+ * entropy decode is the CPU side of this decoder, vp8_parser_set_threads), --codec=vp8, -v, and the VP8 post-processing options --postproc, --deblock,
  * --demacroblock-level=<n>, --noise-level=<n>, --mfqe (vpxdec.c:111-133, 779-812, 983-1002; MFQE is accepted and has no effect).
  * Input: IVF or WebM, probed in that order like vpxdec.c:573-587 (webm.h; the reference reads WebM through its bundled
  * nestegg).  Headerless raw input is not provided.
@@ -41,7 +41,7 @@ static void usage_exit(void)
             "      --skip=<arg>      Skip the first n input frames\n"
             "      --summary         Show timing summary\n"
             "  -o, --output=<arg>    Output file name\n"
-            "  -t, --threads=<arg>   Max threads to use (accepted, unused)\n"
+            "  -t, --threads=<arg>   Max threads to use (token partitions of a frame are decoded in parallel)\n"
             "  -v, --verbose         Show version string\n"
             "      --md5             Compute the MD5 sum of the decoded frames\n\n"
             "Included decoders:\n\n    vp8    - %s\n", exec_name, vpx_codec_iface_name(vpx_codec_vp8_dx()));

@@ -62,3 +62,46 @@ def test_every_launch_size_regime_gives_the_reference_frame(decoded, monkeypatch
         if whole is None:
             whole = full
         assert np.array_equal(full, whole), n                # borders included, bit for bit the same on every path
+
+
+@pytest.mark.parametrize("knobs", [{"VP8HIP_RECON": "simt"},                                    # key frames: the fused kernel, its pass on stream 2
+                                   {"VP8HIP_RECON": "simt", "VP8HIP_FUSED": "0", "VP8HIP_LF_RASTER": "0"},   # ... the deferred pass
+                                   {"VP8HIP_RECON": "simt", "VP8HIP_INTER_TILED": "1", "VP8HIP_LF_RASTER": "0"}])
+def test_launches_chained_without_sync_wait_for_the_raster_pass(pkg, monkeypatch, knobs):
+    """A launch whose tiled -> raster pass still runs (or has not even been launched) on the second stream, followed at once --
+    no sync, no download -- by launches of inter frames that read those frame buffers as references: the library has to join
+    the pass first (vp8hip.hip: `!all_key` in the join condition).  Eight streams side by side, three frames each."""
+    P = pkg
+    for k in ("VP8HIP_RECON", "VP8HIP_FUSED", "VP8HIP_LF_RASTER", "VP8HIP_INTER_TILED", "VP8HIP_INTER_SPLIT"):
+        monkeypatch.delenv(k, raising=False)
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
+    name, n = "p_dense_1920x1080", 8
+    w, h, frames = P.read_ivf(ivf_path(name))
+    gold = golden_md5(name)
+    ctx = P.Vp8Hip(0)
+    try:
+        ctx.configure(w, h, 4 * n, 3)
+        parser = P.Parser()
+        launches = []
+        for f in range(3):
+            hdr = ctx.parse_into_slot(parser, frames[f], f)
+            ctx.upload(f)
+            r = parser.refs
+            launches.append((f, hdr.frame_type, r.new_idx, (r.lst_idx, r.gld_idx, r.alt_idx)))
+            parser.swap(hdr)
+        show = parser.refs.show_idx if hasattr(parser.refs, "show_idx") else launches[-1][2]
+        for f, ftype, new_idx, refs in launches:                # back to back: nothing waits in between
+            jobs = (P.Job * n)()
+            for i in range(n):
+                jobs[i].ir_slot, jobs[i].dst_fb = f, 4 * i + new_idx
+                for q in range(3):
+                    jobs[i].ref_fb[1 + q] = 4 * i + refs[q] if ftype else -1
+            ctx.decode_array(jobs, n, P.STAGE_ALL)
+        ctx.sync()
+        last_new = launches[-1][2]
+        for i in range(n):
+            assert P.planes_md5(*ctx.download_planes(4 * i + last_new)) == gold[2], (knobs, i)
+        parser.close()
+    finally:
+        ctx.close()
