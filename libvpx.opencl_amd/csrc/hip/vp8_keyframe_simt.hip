@@ -222,7 +222,7 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
     for (int j = 0; j < 4; j++) { pb[j][0] = pb[j][1] = pb[j][2] = 0; hF[j][0] = hF[j][1] = hF[j][2] = hF[j][3] = 0; }
     // ---- the macroblock after the current one, prepared at the end of the step before: descriptor words 0, 1, sub-block modes;
     // which of its blocks have a residual, whether the luma DCs come out of the Y2 block
-    u32 nx_w0 = 0, nx_w1 = 0, nx_jm = 0, nx_dcg = 0;
+    u32 nx_w0 = 0, nx_w1 = 0, nx_jm = 0, nx_dcg = 0, nx_dq = 0;
     u32x4 nx_bm = { 0, 0, 0, 0 };
     bool p_more = false;
 
@@ -234,10 +234,13 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
     // start of its 800 bytes, in block order -- vp8_ir_pack_kernel --, so that what is fetched is what is used: with a third of
     // the blocks coded, the dense form touches four of every five 128-byte lines.  rank0: coded blocks of the macroblock in
     // front of this phase's.)
-    auto queue = [&](g_cs16p cf_mb, const int rank0, const u32 m4, const u32 dcg, const int n0) {
+    // m4: the phase's coded blocks; f4: those of them with more than a DC (only these are queued for the transform: the owner adds
+    // a lone DC itself -- vp8_dc_only_idct_add_c, idctllm.c:112-137 -- from the block's first coefficient in its slot, or, with a
+    // Y2 block, from the Walsh transform's output, for which nothing is fetched at all)
+    auto queue = [&](g_cs16p cf_mb, const int rank0, const u32 m4, const u32 f4, const u32 dcg, const int n0) {
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            if ((m4 >> i) & 1) {
+            if (((m4 >> i) & 1) && (((f4 >> i) & 1) || !dcg)) {
                 g_cs16p cfb = cf_mb + (rank0 + __builtin_popcount(m4 & ((1u << i) - 1))) * 16;
                 __builtin_amdgcn_global_load_lds((g_cvp)cfb, (lds_vp)(s_stage + i * 512), 16, 0, 0);
                 __builtin_amdgcn_global_load_lds((g_cvp)(cfb + 8), (lds_vp)(s_stage + i * 512 + 256), 16, 0, 0);
@@ -247,7 +250,7 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
         int n = n0;
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            const bool b = (m4 >> i) & 1;
+            const bool b = (f4 >> i) & 1;
             const unsigned long long bal = __builtin_amdgcn_ballot_w64(b);
             const u32 at = __builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, (u32)n));
             if (b) s_queue[at] = (unsigned short)((u32)lane | ((u32)i << 6) | (dcg << 8));
@@ -306,7 +309,7 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
     // ---- what the transform needs to know about a macroblock, from its descriptor words (m0: words 0-3, m1: words 4-7) and, luma,
     // its Y2 block: which of its blocks (luma: 16 bits, chroma: 8) have a residual (`jm`), whether the luma DCs come out of the Y2
     // block (`dcg`); the lane's entry of s_tab (coefficient pointer, quantiser) and, with a Y2 block, of s_y2dc
-    auto prepare_mb = [&](const u32x4 m0, const u32x4 m1, const u32x4 y2a, const u32x4 y2b, g_cs16p cf, u32 &jm, u32 &dcg) {
+    auto prepare_mb = [&](const u32x4 m0, const u32x4 m1, const u32x4 y2a, const u32x4 y2b, g_cs16p cf, u32 &jm, u32 &dcg, u32 &dq_out) {
         const u32 w0 = m0.x, w1 = m0.y;
         const int y_mode = w0 & 0xff;
         const bool skip = (w0 >> 24) & VP8IR_MB_SKIP;
@@ -319,13 +322,16 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
         const u32 dq1 = seg == 0 ? s01 : seg == 1 ? s11 : seg == 2 ? s21 : s31;
         // eobs (detokenize.c:363), a byte per block, 0..16: which blocks have a token at all.  A luma block of a macroblock with
         // Y2 always has its DC (idct_blk.c:20-44, decodframe.c:262-296).
+        // Bits 16.. of the result: the blocks with more than a DC (eob >= 2), which alone go through the transform.
         u32 m = 0;
         if constexpr (LUMA) {
             const u32 e[4] = { m0.z, m0.w, m1.x, m1.y };
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 const u32 ge1 = ((e[q] + 0x7f7f7f7fu) & 0x80808080u) >> 7;        // bit 0 of each byte: eob >= 1
+                const u32 ge2 = ((e[q] + 0x7e7e7e7eu) & 0x80808080u) >> 7;        // eob >= 2
                 m |= (((ge1 * 0x00204081u) >> 21) & 0xfu) << (4 * q);
+                m |= (((ge2 * 0x00204081u) >> 21) & 0xfu) << (16 + 4 * q);
             }
             if (has_y2) m |= 0xffffu;
         } else {
@@ -333,7 +339,9 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
 #pragma unroll
             for (int q = 0; q < 2; q++) {
                 const u32 ge1 = ((e[q] + 0x7f7f7f7fu) & 0x80808080u) >> 7;
+                const u32 ge2 = ((e[q] + 0x7e7e7e7eu) & 0x80808080u) >> 7;
                 m |= (((ge1 * 0x00204081u) >> 21) & 0xfu) << (4 * q);
+                m |= (((ge2 * 0x00204081u) >> 21) & 0xfu) << (16 + 4 * q);
             }
             // the coded luma blocks in front of the chroma ones, counted into bits 8..12
             const u32 el[4] = { m0.z, m0.w, m1.x, m1.y };
@@ -346,6 +354,7 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
         jm = m;
         dcg = LUMA && has_y2 && !skip;
         s_tab[lane] = dq0;
+        dq_out = dq0;
         if constexpr (LUMA) {
             // Y2: vp8_dequantize_b + vp8_short_inv_walsh4x4_c (idctllm.c:140-192) -> the 16 luma DCs.  With nothing but a DC
             // coefficient the full transform gives what vp8_short_inv_walsh4x4_1_c gives (decodframe.c:282-285).
@@ -413,7 +422,7 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
         }
         const bool act = c >= 0 && c < cols && V < Vmax;
         const bool late = act && !p_more;        // first macroblock of a row: nothing was prepared a step ahead
-        u32 jm = nx_jm, dc_given = nx_dcg;
+        u32 jm = nx_jm, dc_given = nx_dcg, cur_dq = nx_dq;
         u32 cur_w0 = nx_w0, cur_w1 = nx_w1;
         u32x4 bm = nx_bm;
         if (late) {
@@ -441,13 +450,13 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
             // consumed here, so that no pending load leaves the branch
             asm volatile("" : "+v"(m0), "+v"(m1), "+v"(b0), "+v"(y2a), "+v"(y2b));
             cur_w0 = m0.x; cur_w1 = m0.y; bm = b0;
-            prepare_mb(m0, m1, y2a, y2b, cfp, jm, dc_given);
+            prepare_mb(m0, m1, y2a, y2b, cfp, jm, dc_given, cur_dq);
         }
         if (!act) { jm = 0; dc_given = 0; }
         // the row starters' first phase joins the queue behind the blocks the others had transformed at the end of the last step
         if (__builtin_amdgcn_ballot_w64(late) != 0) {
             const int n0 = q_n;
-            queue(cfp, LUMA ? 0 : (int)(jm >> 8), late ? jm & 0xf : 0, dc_given, n0);
+            queue(cfp, LUMA ? 0 : (int)((jm >> 8) & 0x1f), late ? jm & 0xf : 0, late ? (jm >> 16) & 0xf : 0, dc_given, n0);
             drain(LUMA ? 0 : 16, n0, 0);
         }
         // the descriptor of the macroblock after this one: on its way from here (a lane at the end of its row, or idle, fetches
@@ -535,11 +544,13 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
                 // ---- the block row's residuals; then the next phase's coefficients are requested (the next block row's, or the next
                 // macroblock's first, whose descriptor has arrived by now: at least the 12 row stores below are younger)
                 u32x4 rr[8];
-                const u32 rmg = jm >> (by * 4);
+                const u32 rmg = jm >> (by * 4), rmf = jm >> (16 + by * 4);
+                // the block row's four DCs out of the Y2 block, for the blocks that have nothing else
+                const u32 y2w0 = s_y2dc[lane * 8 + 2 * by], y2w1 = s_y2dc[lane * 8 + 2 * by + 1];
                 if (by < 3) {
                     fetch(rr);
                     STAMP(8)
-                    queue(cfp, __builtin_popcount(jm & ((16u << (4 * by)) - 1)), (jm >> (4 * by + 4)) & 0xf, dc_given, 0);
+                    queue(cfp, __builtin_popcount(jm & 0xffffu & ((16u << (4 * by)) - 1)), (jm >> (4 * by + 4)) & 0xf, (jm >> (4 * by + 20)) & 0xf, dc_given, 0);
                 } else {
                     // (all of this macroblock's phases have been transformed: its entries of s_tab / s_y2dc are free)
                     u32 n_jm = 0, n_dcg = 0;
@@ -549,14 +560,15 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
                         asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:1024\n\t"
                                      "ds_read_b128 %2, %4 offset:3072\n\tds_read_b128 %3, %4 offset:4096\n\ts_waitcnt lgkmcnt(0)"
                                      : "=&v"(m0), "=&v"(m1), "=&v"(y2a), "=&v"(y2b) : "v"(desc_lane) : "memory");
-                        if (more) prepare_mb(m0, m1, y2a, y2b, cfp + VP8IR_COEF_PER_MB, n_jm, n_dcg);
-                        nx_w0 = m0.x; nx_w1 = m0.y; nx_jm = n_jm; nx_dcg = n_dcg;
+                        u32 n_dq = 0;
+                        if (more) prepare_mb(m0, m1, y2a, y2b, cfp + VP8IR_COEF_PER_MB, n_jm, n_dcg, n_dq);
+                        nx_w0 = m0.x; nx_w1 = m0.y; nx_jm = n_jm; nx_dcg = n_dcg; nx_dq = n_dq;
                     }
                     asm volatile("ds_read_b128 %0, %1 offset:2048\n\ts_waitcnt lgkmcnt(0)" : "=&v"(nx_bm) : "v"(desc_lane) : "memory");
                     STAMP(9)
                     fetch(rr);
                     STAMP(8)
-                    queue(cfp + VP8IR_COEF_PER_MB, 0, n_jm & 0xf, n_dcg, 0);
+                    queue(cfp + VP8IR_COEF_PER_MB, 0, n_jm & 0xf, (n_jm >> 16) & 0xf, n_dcg, 0);
                 }
                 STAMP(3)
                 const u32 lcur = l0[0];
@@ -578,7 +590,14 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
                     const bool hasr = (rmg >> k) & 1;
                     if (__builtin_amdgcn_ballot_w64(hasr) != 0) {
                         if (hasr) {
-                            const u32x4 ra = rr[2 * k], rb = rr[2 * k + 1];
+                            u32x4 ra = rr[2 * k], rb = rr[2 * k + 1];
+                            if (!((rmf >> k) & 1)) {
+                                // a lone DC: (short)(q[0] * dq[0]) (idct_blk.c:34), or the Y2 block's; a1 = (dc + 4) >> 3 on every pixel
+                                const u32 y2w = k < 2 ? y2w0 : y2w1;
+                                const int dc = dc_given ? (short)(y2w >> (16 * (k & 1))) : (short)((short)ra.x * (short)(cur_dq & 0xffff));
+                                const u32 a1 = (u32)((dc + 4) >> 3) & 0xffffu, a2 = a1 | (a1 << 16);
+                                ra = rb = (u32x4){ a2, a2, a2, a2 };
+                            }
                             o[0] = add_clamp_pack(p[0], ra.x, ra.y); o[1] = add_clamp_pack(p[1], ra.z, ra.w);
                             o[2] = add_clamp_pack(p[2], rb.x, rb.y); o[3] = add_clamp_pack(p[3], rb.z, rb.w);
                         }
@@ -655,8 +674,8 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
             for (int pl = 0; pl < 2; pl++) {
                 u32x4 rr[8];
                 fetch(rr);
-                const u32 rmg = jm >> (4 * pl);
-                if (pl == 0) queue(cfp, (int)(jm >> 8) + __builtin_popcount(jm & 0xf), (jm >> 4) & 0xf, 0, 0);
+                const u32 rmg = jm >> (4 * pl), rmf = jm >> (16 + 4 * pl);
+                if (pl == 0) queue(cfp, (int)((jm >> 8) & 0x1f) + __builtin_popcount(jm & 0xf), (jm >> 4) & 0xf, (jm >> 20) & 0xf, 0, 0);
                 else {
                     u32 n_jm = 0, n_dcg = 0;
                     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
@@ -664,9 +683,10 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
                     asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024\n\ts_waitcnt lgkmcnt(0)"
                                  : "=&v"(m0), "=&v"(m1) : "v"(desc_lane) : "memory");
                     const u32x4 z = { 0, 0, 0, 0 };
-                    if (more) prepare_mb(m0, m1, z, z, cfp + VP8IR_COEF_PER_MB, n_jm, n_dcg);
-                    nx_w0 = m0.x; nx_w1 = m0.y; nx_jm = n_jm; nx_dcg = 0;
-                    queue(cfp + VP8IR_COEF_PER_MB, (int)(n_jm >> 8), n_jm & 0xf, 0, 0);
+                    u32 n_dq = 0;
+                    if (more) prepare_mb(m0, m1, z, z, cfp + VP8IR_COEF_PER_MB, n_jm, n_dcg, n_dq);
+                    nx_w0 = m0.x; nx_w1 = m0.y; nx_jm = n_jm; nx_dcg = 0; nx_dq = n_dq;
+                    queue(cfp + VP8IR_COEF_PER_MB, (int)((n_jm >> 8) & 0x1f), n_jm & 0xf, (n_jm >> 16) & 0xf, 0, 0);
                 }
                 STAMP(3)
                 const u32 aC0 = aA[0], aC1 = aA[1], lC0 = l0[0], lC1 = l0[1];
@@ -687,7 +707,12 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
                     const bool hasr = (rmg >> k) & 1;
                     if (__builtin_amdgcn_ballot_w64(hasr) != 0) {
                         if (hasr) {
-                            const u32x4 ra = rr[2 * k], rb = rr[2 * k + 1];
+                            u32x4 ra = rr[2 * k], rb = rr[2 * k + 1];
+                            if (!((rmf >> k) & 1)) {          // a lone DC
+                                const int dc = (short)((short)ra.x * (short)(cur_dq & 0xffff));
+                                const u32 a1 = (u32)((dc + 4) >> 3) & 0xffffu, a2 = a1 | (a1 << 16);
+                                ra = rb = (u32x4){ a2, a2, a2, a2 };
+                            }
                             o[0] = add_clamp_pack(p[0], ra.x, ra.y); o[1] = add_clamp_pack(p[1], ra.z, ra.w);
                             o[2] = add_clamp_pack(p[2], rb.x, rb.y); o[3] = add_clamp_pack(p[3], rb.z, rb.w);
                         }

@@ -90,7 +90,6 @@ def test_launches_chained_without_sync_wait_for_the_raster_pass(pkg, monkeypatch
             r = parser.refs
             launches.append((f, hdr.frame_type, r.new_idx, (r.lst_idx, r.gld_idx, r.alt_idx)))
             parser.swap(hdr)
-        show = parser.refs.show_idx if hasattr(parser.refs, "show_idx") else launches[-1][2]
         for f, ftype, new_idx, refs in launches:                # back to back: nothing waits in between
             jobs = (P.Job * n)()
             for i in range(n):
