@@ -171,6 +171,19 @@ int  vp8hip_get_stats_at(vp8hip_ctx *ctx, int back, vp8hip_stats *st);
 void *vp8hip_stream(vp8hip_ctx *ctx);
 int  vp8hip_join(vp8hip_ctx *ctx);
 
+/* ---- per-block test surface of the lane-per-row arithmetic (csrc/hip/vp8_lane_blocks.hip): the per-lane code the large-launch
+ * kernels are made of, one block / macroblock per lane, on the current HIP device.  Each call is a launch and a synchronisation;
+ * returns 0 or a negative error.  Counterparts in the reference: vp8_loop_filter_frame's per-macroblock calls
+ * (vp8/common/loopfilter.c:259-299: vp8_loop_filter_{mbv,bv,mbh,bh}[_simple]), vp8_intra4x4_predict (reconintra4x4.c:16),
+ * vp8_dequant_idct_add_c (dequantize.c:29). */
+/* in / out: n x 400 bytes = rows and columns -4..15 of a luma macroblock (20 x 20); par: n x 8 bytes = mblim, blim, lim, hev_thr,
+ * left edge filtered, inner edges filtered, top edge filtered, filter type (0 normal, 1 simple) */
+int  vp8hip_lane_loop_filter_mbs(const uint8_t *in, uint8_t *out, const uint8_t *par, int n);
+/* mode: n B_PREDICTION_MODEs; ctx: n x 16 bytes = above[0..7], left[0..3], top_left, 3 bytes of padding; out: n x 16 bytes, row-major */
+int  vp8hip_lane_intra4x4(const uint8_t *mode, const uint8_t *ctx, uint8_t *out, int n);
+/* coef: n x 16 in IR order (column-major, vp8_ir.h); dq: n x (dc, ac); pred / out: n x 16 bytes, row-major */
+int  vp8hip_lane_dequant_idct_add(const int16_t *coef, const int16_t *dq, const uint8_t *pred, uint8_t *out, int n);
+
 #ifdef __cplusplus
 }
 #endif

@@ -40,11 +40,6 @@ typedef u32x2 u32x2_u __attribute__((aligned(4)));
 typedef GLOBAL_AS u32x4_u *g_u32x4up;
 typedef GLOBAL_AS u32x2_u *g_u32x2up;
 
-// one biased row dword (four pixels) <-> two column pairs: (x, x+1) and (x+2, x+3) in the two 16-bit halves
-__device__ __forceinline__ v2u col_lo(u32 D) { return as_v2u(perm(D, D, 0x010c000cu)); }
-__device__ __forceinline__ v2u col_hi(u32 D) { return as_v2u(perm(D, D, 0x030c020cu)); }
-__device__ __forceinline__ u32 col_pack(v2u lo, v2u hi) { return perm(as_u32(hi), as_u32(lo), 0x07050301u); }
-
 // The output: one 384-byte tile per macroblock in the job's scratch (DevJob::tile), rows x (cols + 1) of them, laid out by who
 // knows which pixels when, so that every 64-byte half of a tile's three 128-byte lines is written whole, by one lane, within
 // one step (the L2 merges the 16- and 8-byte stores of a step; what leaves it are full sectors -- 16-byte pieces of raster
@@ -64,62 +59,6 @@ enum {
     // left them unfinished)
     KH_Y = 0, KH_U = 16, KH_V = 24, KH_BYTES = 32
 };
-
-// One block row (four pixel rows) of one plane through the loop filter.  W4: dwords per row (4 luma, 2 chroma).
-//   o[j][x]   in:  rows j = 0..3 of the block row as reconstructed (plain pixels)
-//   s[j]      in:  the last four pixels of the macroblock to the left in these rows (biased), as its own filtering left
-//                  them; out: after this macroblock's left edge
-//   P[j][x]   in:  the four rows above (biased dwords), vertical edges done; out: these four rows, vertical edges and the
-//                  edge above them done
-//   top_mb         the edge above is the macroblock's top edge (first block row)
-//   d[j][x]   out: the four rows above, final (biased dwords) -- but for their last dword, which the macroblock to the
-//                  right may still change
-// gv / gh: gates of the vertical-edge and of the horizontal-edge pass (loopfilter.c:265-299).
-// The rows travel as packed dwords between the stages and are widened to 16-bit pairs one dword column at a time: the
-// widened form of a whole block row and of the rows above it (2 x 32 registers for luma) is what decided whether a luma and
-// a chroma wave fit one SIMD together.
-template <int W4>
-__device__ __forceinline__ void lf_block_row(const u32 (&o)[4][W4], u32 (&s)[4], u32 (&P)[4][W4], const bool top_mb,
-                                             const Gates &gv, const Gates &gh, const Lim &L, u32 (&d)[4][W4])
-{
-    constexpr int NX = W4 + 1;
-    v2u a[4 * NX], b[4 * NX];             // rows (0, 1) and (2, 3): positions -4 .. 4*W4-1
-#pragma unroll
-    for (int x = 0; x < NX; x++) {
-        const u32 A0 = x ? o[0][x - 1] ^ VP8_LF_BIAS : s[0], A1 = x ? o[1][x - 1] ^ VP8_LF_BIAS : s[1];
-        const u32 A2 = x ? o[2][x - 1] ^ VP8_LF_BIAS : s[2], A3 = x ? o[3][x - 1] ^ VP8_LF_BIAS : s[3];
-        a[4 * x + 0] = as_v2u(perm(A1, A0, 0x040c000cu)); a[4 * x + 1] = as_v2u(perm(A1, A0, 0x050c010cu));
-        a[4 * x + 2] = as_v2u(perm(A1, A0, 0x060c020cu)); a[4 * x + 3] = as_v2u(perm(A1, A0, 0x070c030cu));
-        b[4 * x + 0] = as_v2u(perm(A3, A2, 0x040c000cu)); b[4 * x + 1] = as_v2u(perm(A3, A2, 0x050c010cu));
-        b[4 * x + 2] = as_v2u(perm(A3, A2, 0x060c020cu)); b[4 * x + 3] = as_v2u(perm(A3, A2, 0x070c030cu));
-    }
-    filter_lines2<W4>(a, b, gv, L);
-    {   // the left neighbour's last dword, back as rows
-        const u32 t01 = perm(as_u32(a[1]), as_u32(a[0]), 0x07030501u), t23 = perm(as_u32(a[3]), as_u32(a[2]), 0x07030501u);
-        const u32 u01 = perm(as_u32(b[1]), as_u32(b[0]), 0x07030501u), u23 = perm(as_u32(b[3]), as_u32(b[2]), 0x07030501u);
-        s[0] = perm(t23, t01, 0x05040100u); s[1] = perm(t23, t01, 0x07060302u);
-        s[2] = perm(u23, u01, 0x05040100u); s[3] = perm(u23, u01, 0x07060302u);
-    }
-    // the horizontal edge between the rows above (p3..p0) and this block row (q0..q3), one dword column -- two column pairs --
-    // at a time.  (Not skipped when no lane of the wave wants the normal filter: the gates switch it off lane by lane.)
-    const v2u elim_s = top_mb ? L.mblim : L.blim, gate_s = top_mb ? gh.mb_s : gh.inner_s;
-#pragma unroll
-    for (int x = 0; x < W4; x++) {
-        const u32 a0 = as_u32(a[4 * x + 4]), a1 = as_u32(a[4 * x + 5]), a2 = as_u32(a[4 * x + 6]), a3 = as_u32(a[4 * x + 7]);
-        const u32 b0 = as_u32(b[4 * x + 4]), b1 = as_u32(b[4 * x + 5]), b2 = as_u32(b[4 * x + 6]), b3 = as_u32(b[4 * x + 7]);
-        v2u p[8] = { col_lo(P[0][x]), col_lo(P[1][x]), col_lo(P[2][x]), col_lo(P[3][x]),
-                     as_v2u(perm(a1, a0, 0x050c010cu)), as_v2u(perm(a1, a0, 0x070c030cu)), as_v2u(perm(b1, b0, 0x050c010cu)), as_v2u(perm(b1, b0, 0x070c030cu)) };
-        v2u q[8] = { col_hi(P[0][x]), col_hi(P[1][x]), col_hi(P[2][x]), col_hi(P[3][x]),
-                     as_v2u(perm(a3, a2, 0x050c010cu)), as_v2u(perm(a3, a2, 0x070c030cu)), as_v2u(perm(b3, b2, 0x050c010cu)), as_v2u(perm(b3, b2, 0x070c030cu)) };
-        if (top_mb) { lf_mbedge(p, L, gh.mb); lf_mbedge(q, L, gh.mb); }
-        else { lf_inner(p, L, gh.inner); lf_inner(q, L, gh.inner); }
-        if (gh.any_simple) { lf_simple(p, elim_s, L.one, gate_s); lf_simple(q, elim_s, L.one, gate_s); }
-        // the rows above are done; this block row takes their place
-#pragma unroll
-        for (int j = 0; j < 4; j++) { d[j][x] = col_pack(p[j], q[j]); P[j][x] = col_pack(p[4 + j], q[4 + j]); }
-        __builtin_amdgcn_sched_barrier(0);      // two lines' worth of temporaries at a time, not 2 * W4
-    }
-}
 
 // loop-filter levels of a frame for its four segments, a byte each: macroblocks with a 16x16 mode / B_PRED macroblocks
 // (vp8_loop_filter_frame_init, loopfilter.c:117-201, for intra frames); all zero when the frame is not filtered (onyxd_if.c:576)
