@@ -21,6 +21,18 @@ typedef struct vp8_boolreader {
 
 static inline void vp8br_refill(vp8_boolreader *br)
 {
+    /* the bulk of a partition: up to seven bytes with one load (cf. the reference's VP8DX_BOOL_DECODER_FILL, dboolhuff.h:51-76,
+       which also shifts in as many whole bytes as fit) */
+    if (br->end - br->cur >= 8 && br->bits <= 0) {
+        uint64_t v;
+        int take = (56 - br->bits) >> 3;            /* whole bytes that fit below the valid bits: 7 at bits <= 0 */
+        __builtin_memcpy(&v, br->cur, 8);
+        v = __builtin_bswap64(v) >> (64 - 8 * take);      /* the first `take` bytes, first byte on top */
+        br->window |= v << (56 - br->bits - 8 * take);
+        br->cur += take;
+        br->bits += 8 * take;
+        return;
+    }
     while (br->bits <= 48) {
         uint64_t byte = 0;
         if (br->cur < br->end)

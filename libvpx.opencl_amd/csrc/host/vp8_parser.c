@@ -809,9 +809,12 @@ static int read_block_tokens(vp8_boolreader *br, const uint8_t (*probs)[3][11], 
     }
 }
 
-static int read_mb_tokens(vp8_parser *p, vp8_boolreader *br, const mbinfo *m, entropy_ctx *A, entropy_ctx *L,
+static int read_mb_tokens(vp8_parser *p, vp8_boolreader *brp, const mbinfo *m, entropy_ctx *A, entropy_ctx *L,
                           int16_t *coef, uint8_t *eobs)
 {
+    /* the decoder state in locals for the macroblock (a few hundred to a few thousand bool decodes): in registers, not behind a
+       pointer the coefficient stores might alias */
+    vp8_boolreader local = *brp, *br = &local;
     int total = 0, i, nz, first = 0, ytype = 3;
     if (m->y_mode != VP8IR_B_PRED && m->y_mode != VP8IR_SPLITMV) {
         int e = read_block_tokens(br, p->fc.coef[1], A->y2 + L->y2, 0, coef + 24 * 16, &nz);
@@ -837,6 +840,7 @@ static int read_mb_tokens(vp8_parser *p, vp8_boolreader *br, const mbinfo *m, en
         eobs[i] = (uint8_t)e;
         total += e;
     }
+    *brp = local;
     return total;
 }
 
