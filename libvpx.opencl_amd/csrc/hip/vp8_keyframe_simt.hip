@@ -165,6 +165,7 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
     u32x4 nx_bm = { 0, 0, 0, 0 };
     bool p_more = false;
 
+    STAMP_DECL
     int q_n = 0;                                                     // blocks queued (wave-uniform)
     // The owner requests the coefficients of the blocks cfb[0..3] of its macroblock that have any (`m4`) into ITS OWN four staging
     // slots (s_stage[block][half][lane]: no look-up stands between knowing the macroblock and the request), and the lanes
@@ -204,6 +205,7 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
         else if (younger >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         else if (younger >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        STAMP(14)
         wave_lds_sync();
         const int R = (q_n + 63) >> 6;
 #pragma unroll 1
@@ -341,7 +343,6 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
     };
 
     int c = -2 * pos - 1, V = pos;
-    STAMP_DECL
 #pragma unroll 1
     for (int t = 0; t < T; ++t) {
         STAMP(0)

@@ -20,7 +20,7 @@ ctx.decode_array(jobs, n, 7); ctx.sync()
 L.vp8hip_debug_stamps(ctx.h, 0, buf)
 ctx.decode_array(jobs, n, 7); ctx.sync(); st = ctx.stats()
 names = ["loop overhead", "row start, late phase 0, descriptor request", "step setup (gates, line above, read-back)", "fetch residuals + queue next phase (+ prepare next MB)",
-         "prediction + add", "loop filter (+ row stores, chroma)", "drain next phase (luma) / stores+rotate+drain (chroma)", "bottom rows, context, end of step", "fetch residuals", "prepare next MB (luma)", "row stores + rotate (luma)", "chroma: lf_block_row", "chroma: row stores"]
+         "prediction + add", "loop filter (+ row stores, chroma)", "drain next phase (luma) / stores+rotate+drain (chroma)", "bottom rows, context, end of step", "fetch residuals", "prepare next MB (luma)", "row stores + rotate (luma)", "chroma: lf_block_row", "chroma: row stores", "", "drain: waiting for the coefficients (vmcnt)"]
 for which, kn in ((0, "luma kernel"), (1, "chroma kernel")):
     L.vp8hip_debug_stamps(ctx.h, which, buf)
     tot = sum(buf)
