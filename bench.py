@@ -52,11 +52,11 @@ PMC_TRAFFIC_B_PER_MB = {        # the loop filter (luma + chroma kernels) writes
     # profiles/r02_a_pmc_{FETCH,WRITE}_SIZE_1024frames_G8.csv.  The loop filter's 1014 B/MB of writes against 384 B/MB of pixels are
     # the 32-byte (luma) and 16-byte (chroma) pieces of frame rows a lane has to give at a time
     "recon": 2 * 529.5 + 385.7, "loopfilter": 2 * (168.1 + 104.1) + 535.6 + 478.8, "extend": 2 * 27.5 + 40.4}
-# vp8_keyframe_kernel (reconstruction + loop filter in one pass, macroblock-window tiles out) and its tiled -> raster pass + border
-# extension: profiles/r03_a_pmc_{fetch,write}_1024_G8.csv (1024 frames per launch, 8 lanes per strand as at the default launch size;
-# FETCH_SIZE doubled as above).  At 64 lanes per strand -- every SIMD busy, most lanes idle -- the kernel fetches 1390 B/MB
-# (profiles/r03_a_pmc_fetch_1024_G64.csv); its writes at 8192 frames per launch: 484 B/MB (r03_a_pmc_write_8192_sharedIR.csv).
-PMC_TRAFFIC_B_PER_MB_FUSED = {"recon": 2 * 511.1 + 468.0, "loopfilter": 0.0, "extend": 2 * 193.8 + 396.5 + 2 * 27.5 + 40.4}
+# vp8_keyframe_kernel (reconstruction + loop filter in one pass, packed coefficients in, macroblock-window tiles out) and its tiled ->
+# raster pass + border extension: profiles/r03_b_pmc_{fetch,write}_1024_G8.csv (1024 frames per launch, 8 lanes per strand as at the
+# default launch size; FETCH_SIZE doubled as above).  At 64 lanes per strand -- every SIMD busy, most lanes idle -- the kernel fetches
+# 1270 B/MB (r03_b_pmc_fetch_1024_G64.csv); its writes at 8192 frames per launch: 495 B/MB (r03_b_pmc_write_8192_sharedIR.csv).
+PMC_TRAFFIC_B_PER_MB_FUSED = {"recon": 2 * 406.1 + 467.7, "loopfilter": 0.0, "extend": 2 * 193.8 + 396.5 + 2 * 27.5 + 40.4}
 PMC_TRAFFIC_B_PER_MB_DETILE = { # tiled -> raster pass (vp8_detile_kernel) after the loop filter
     "recon": 2 * 448.68 + 385.22, "loopfilter": 2 * 239.63 + 414.12, "extend": 2 * 192.08 + 466.87}
 
