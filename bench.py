@@ -404,8 +404,7 @@ def main():
             bytes_per_launch["recon"] = (B_RECON + B_LF) * nmb * F
             bytes_per_launch["loopfilter"] = 0
         names = ({"recon": "vp8_recon_simt_kernel",
-                  "loopfilter": "vp8_loopfilter_simt_luma_kernel (with vp8_loopfilter_simt_chroma_kernel beside it)" if split
-                                else "vp8_loopfilter_simt_kernel",
+                  "loopfilter": "vp8_loopfilter_simt_luma_kernel (with vp8_loopfilter_simt_chroma_kernel beside it)",
                   "extend": "vp8_detile_kernel (tiled -> raster + border extension)" if detile else "vp8_extend_kernel"} if lane else
                  {"recon": "vp8_recon_kernel", "loopfilter": "vp8_loopfilter_kernel", "extend": "vp8_extend_kernel"})
         if fused:

@@ -327,11 +327,7 @@ __device__ __forceinline__ void lf_simt_body(const DevJob *__restrict__ jobs, in
     STAMP_FLUSH(vp8_stamps_lf)
 }
 
-extern "C" __global__ void __launch_bounds__(64)
-vp8_loopfilter_simt_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g, int lgG, int P, int nstrands, int raster)
-{
-    lf_simt_body<LF_BOTH>(jobs, njobs, g, lgG, P, nstrands, raster);
-}
+// (Round 2 also built lf_simt_body<LF_BOTH>, one wave for all three planes: 402 registers, never faster than the pair; gone.)
 extern "C" __global__ void __launch_bounds__(64)
 vp8_loopfilter_simt_luma_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g, int lgG, int P, int nstrands, int raster)
 {

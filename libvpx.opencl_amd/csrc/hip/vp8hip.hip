@@ -31,7 +31,6 @@ extern "C" __global__ void vp8_keyframe_kernel(const DevJob *jobs, int njobs, De
 #define VP8HIP_SCHED_WORDS (16 + 16384)     // vp8_keyframe_kernel: two work counters, one arrival counter per SIMD of the device
 #endif
 extern "C" __global__ void vp8_recon_simt_kernel(const DevJob *jobs, int njobs, DevGeom g, int lgG, int P, int nstrands, uint8_t *dummy);
-extern "C" __global__ void vp8_loopfilter_simt_kernel(const DevJob *jobs, int njobs, DevGeom g, int lgG, int P, int nstrands, int raster);
 extern "C" __global__ void vp8_loopfilter_simt_luma_kernel(const DevJob *jobs, int njobs, DevGeom g, int lgG, int P, int nstrands, int raster);
 extern "C" __global__ void vp8_loopfilter_simt_chroma_kernel(const DevJob *jobs, int njobs, DevGeom g, int lgG, int P, int nstrands, int raster);
 extern "C" __global__ void vp8_loopfilter_kernel(const DevJob *jobs, int njobs, DevGeom g);
@@ -145,9 +144,6 @@ struct Knobs {
                       // filter through the tiled scratch frames (default 640; 0: never).  1080p P frames, recon + loop filter per launch:
                       // 512 frames 6.5 -> 7.4 ms, 768: 11.5 -> 10.6, 1024: 13.2 -> 10.9, 8192: 101.8 -> 73.2 (the recon's 4-byte stores
                       // complete 128-byte tile lines, which they never do in a raster frame)
-    // VP8HIP_LF_SPLIT=0: the lane-per-row loop filter (launches with inter frames from VP8HIP_INTER_TILED frames on; key-frame launches
-    // with VP8HIP_FUSED=0) as one kernel for all three planes instead of luma and chroma kernels side by side
-    int lf_split;
     // VP8HIP_FUSED=0: all-key-frame launches of the lane-per-row family run reconstruction and loop filter as two kernels with the
     // tiled scratch frames between them (the round-1/2 pipeline) instead of vp8_keyframe_simt_kernel
     int fused;
@@ -165,7 +161,6 @@ static void read_knobs(Knobs &k)
     k.wg_per_cu = env_int("VP8HIP_WG_PER_CU", 1);
     k.xcu = env_int("VP8HIP_XCU", 1) != 0;
     k.xcu_S = env_int("VP8HIP_XCU_S", 0);
-    k.lf_split = env_int("VP8HIP_LF_SPLIT", 1);
     k.fused = env_int("VP8HIP_FUSED", 1) != 0;
     k.detile_blocks = env_int("VP8HIP_DETILE_BLOCKS", 0);
     k.inter_split = env_int("VP8HIP_INTER_SPLIT", 384);
@@ -934,10 +929,8 @@ extern "C" int vp8hip_decode(vp8hip_ctx *c, const vp8hip_job *jobs, int njobs, i
     c->stats.fused = fused;
     if (fused) c->stats.lf_kernels = 0;
     if ((stages & VP8HIP_STAGE_LF) && any_lf && !fused) {
-        // one kernel (VP8HIP_LF_SPLIT=0), or luma + chroma kernels side by side (default)
-        const bool lf_pair = K.lf_split != 0;
-        c->stats.lf_kernels = tiled ? (lf_pair ? 2 : 1) : 1;
-        if (tiled && lf_pair) {
+        c->stats.lf_kernels = tiled ? 2 : 1;
+        if (tiled) {
             // luma and chroma as two kernels side by side: a luma wave (268 registers, 25.6 KB of LDS) and a chroma wave (187,
             // 9.2 KB) share a SIMD, so every SIMD has two instruction streams to issue from.  The chroma kernel goes out on
             // a stream of its own behind the recon, and the main stream takes it back in before anything reads the frames.
@@ -950,9 +943,6 @@ extern "C" int vp8hip_decode(vp8hip_ctx *c, const vp8hip_job *jobs, int njobs, i
                                njobs, c->dg, lgG, simtP, simt_waves * spw, lf_raster ? 1 : 0);
             HIPCHK(c, hipEventRecord(c->ev_split_done, c->stream3));
             HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_split_done, 0));
-        } else if (tiled) {
-            hipLaunchKernelGGL(vp8_loopfilter_simt_kernel, dim3(simt_waves), dim3(64), 0, c->stream, (const DevJob *)c->d_jobs,
-                               njobs, c->dg, lgG, simtP, simt_waves * spw, lf_raster ? 1 : 0);
         } else {
             const int npairs = (njobs + 1) / 2;          // the loop filter works on two frames per wave
             if (xcu_S > 1) {

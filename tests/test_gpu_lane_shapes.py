@@ -34,15 +34,13 @@ def lgG(request):
     return request.param
 
 
-@pytest.fixture(params=["fused", "raster", "detile", "raster_onekernel"])
+@pytest.fixture(params=["fused", "raster", "detile"])
 def lane_shape(request, lgG, monkeypatch):
     """fused: reconstruction and loop filter in one kernel (vp8_keyframe_simt_kernel), what all-key-frame launches run by default.
     The others are the two-kernel pipeline (VP8HIP_FUSED=0).  raster / detile: the loop filter writes the frame buffers itself / a tiled -> raster pass does; the loop filter runs as
-    luma + chroma kernels side by side, except "raster_onekernel": one kernel for all three planes (what large launches fall
-    back to when that is the faster one in the process at hand, VP8HIP_LF_SPLIT in vp8hip.hip)."""
+    luma + chroma kernels side by side."""
     monkeypatch.setenv("VP8HIP_RECON", "simt")
     monkeypatch.setenv("VP8HIP_SIMT_LGG", str(lgG))
-    monkeypatch.setenv("VP8HIP_LF_SPLIT", "0" if request.param == "raster_onekernel" else "2")
     monkeypatch.setenv("VP8HIP_FUSED", "1" if request.param == "fused" else "0")
     if request.param == "detile":
         monkeypatch.setenv("VP8HIP_LF_RASTER", "0")
@@ -107,7 +105,7 @@ def test_benchmark_shape_full_size(pkg, monkeypatch):
     kernel and shape choice.  Frames i and i + 10k decode copies of the same IR on different strands, waves and scratch
     sets: >= 64 of them, spread over the launch, must equal the reference MD5 and each other byte for byte (borders
     included); three launches back to back rotate the scratch sets and job tables."""
-    for k in ("VP8HIP_RECON", "VP8HIP_SIMT_LGG", "VP8HIP_SIMT_WAVES", "VP8HIP_LF_RASTER", "VP8HIP_LF_SPLIT", "VP8HIP_FUSED"):
+    for k in ("VP8HIP_RECON", "VP8HIP_SIMT_LGG", "VP8HIP_SIMT_WAVES", "VP8HIP_LF_RASTER", "VP8HIP_FUSED"):
         monkeypatch.delenv(k, raising=False)
     import torch
     free, _total = torch.cuda.mem_get_info(0)
