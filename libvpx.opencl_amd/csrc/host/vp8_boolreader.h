@@ -88,12 +88,14 @@ static inline int vp8br_literal(vp8_boolreader *br, int nbits)
     return v;
 }
 
-/* Bits consumed beyond the real end of the partition (with two bytes of slack for the
- * decoder's look-ahead): the partition was truncated (cf. vp8dx_bool_error,
- * dboolhuff.h:131-153). */
-static inline int vp8br_overrun(const vp8_boolreader *br)
+/* vp8dx_bool_error (vp8/decoder/dboolhuff.h:131-153): the decoder has shifted bits that were never in the partition into its
+ * top byte.  The reference keeps `count` = buffered bits below the top byte and adds VP8_LOTS_OF_BITS once a fill finds the
+ * partition exhausted; its test `count > VP8_BD_VALUE_SIZE && count < VP8_LOTS_OF_BITS` then says: fewer than zero REAL bits
+ * below the top byte.  Here the zero bytes of the refill are counted, so that is bits - 8 * zero_fill < 0, once the end has
+ * been met (a window that merely waits for its next refill is not an error). */
+static inline int vp8br_error(const vp8_boolreader *br)
 {
-    return br->zero_fill * 8 - (8 + br->bits) > 16;
+    return br->zero_fill > 0 && br->bits - 8 * br->zero_fill < 0;
 }
 
 #endif

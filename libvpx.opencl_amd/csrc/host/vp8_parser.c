@@ -917,6 +917,12 @@ static int decode_row(tok_job *j, tok_stream *out, int r, vp8_boolreader *br)
             memset(A, 0, sizeof *A);
             memset(&left, 0, sizeof left);
             if (!has_y2) { A->y2 = ay2; left.y2 = ly2; }
+        } else if (vp8br_error(br)) {
+            /* decode_macroblock, decodframe.c:119-130: once the partition has run out no tokens are read -- the macroblock is
+               neither reset nor marked skipped (its inner edges are loop-filtered), it gets no residual: the reference adds
+               the all-zero qcoeff through whatever eobs the macroblock before left behind, which is the prediction unchanged */
+            if (coef) memset(coef + n * VP8IR_COEF_PER_MB, 0, VP8IR_COEF_PER_MB * sizeof(int16_t));
+            else { o->sparse_first = (uint32_t)(out->first_block + out->nb); o->dc_first = (uint32_t)(out->first_dc + out->nd); }
         } else {
             int16_t local[VP8IR_COEF_PER_MB];
             int16_t *q = coef ? coef + n * VP8IR_COEF_PER_MB : local;
@@ -976,7 +982,7 @@ static void *tok_worker_main(void *arg)
         vp8_boolreader *br = &p->tok[r & (p->num_tok - 1)];
         if (row_owner(p, r, j->nthreads) != w->id) continue;
         if (decode_row(j, &w->out, r, br)) break;
-        w->bad |= vp8br_overrun(br);
+        w->bad |= vp8br_error(br);
     }
     return NULL;
 }
@@ -1002,7 +1008,7 @@ static int decode_mbs(vp8_parser *p, vp8ir_mb *mbs, int16_t *coef, int16_t *bloc
         return fail(p, VP8P_INVALID_PARAM, "inter frame needs an mv array");
 
     read_modes(p);
-    bad |= vp8br_overrun(&p->first);
+    bad |= vp8br_error(&p->first);
 
     memset(p->above, 0, (size_t)p->mb_cols * sizeof(entropy_ctx));
     memset(&job, 0, sizeof job);
@@ -1021,7 +1027,7 @@ static int decode_mbs(vp8_parser *p, vp8ir_mb *mbs, int16_t *coef, int16_t *bloc
         for (r = 0; r < p->mb_rows; r++) {
             vp8_boolreader *br = &p->tok[r & (p->num_tok - 1)];   /* round-robin, decodframe.c:1116-1129 */
             if (decode_row(&job, &w[0].out, r, br)) return fail(p, VP8P_MEM_ERROR, "sparse coefficient stream overflow");
-            bad |= vp8br_overrun(br);
+            bad |= vp8br_error(br);
         }
         nb = w[0].out.nb; nd = w[0].out.nd;
     } else {
