@@ -148,7 +148,9 @@ def inter_frame_probe(P, device, n=4096, name="p_dense_1920x1080", k=2):
         ctx.L.vp8hip_frame_copy(ctx.h, 4 + 2 * i, r.lst_idx)
         jobs[i].ir_slot, jobs[i].dst_fb = 2 + i, 5 + 2 * i
         jobs[i].ref_fb[1], jobs[i].ref_fb[2], jobs[i].ref_fb[3] = 4 + 2 * i, r.gld_idx, r.alt_idx
-    ctx.decode_array(jobs, n, P.STAGE_ALL); ctx.sync()
+    for _ in range(3):              # (the library's three scratch sets are allocated by the first three launches that rotate them)
+        ctx.decode_array(jobs, n, P.STAGE_ALL)
+    ctx.sync()
     ok = P.planes_md5(*ctx.download_planes(5 + 2 * (n // 2))) == gold[k]
     reps = 5
     t0 = time.perf_counter()

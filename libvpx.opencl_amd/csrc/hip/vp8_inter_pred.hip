@@ -1,0 +1,311 @@
+// Inter prediction of a launch's inter macroblocks, every one on its own, for gfx950: the first of the two kernels that decode
+// large launches with inter frames (vp8_interframe_kernel, vp8_keyframe_simt.hip, is the second).
+//
+// What it replaces (paths relative to the reference tree): vp8_build_inter_predictors_mb (vp8/common/reconinter.c:560-606) --
+// vp8_build_inter16x16_predictors_mb (:384-441), build_inter4x4_predictors_mb (:443-518), build_4x4uvmvs (:520-558), the MV
+// clamps (:348-382) -- and behind them the sub-pixel filters of vp8/common/filter.c (six-tap :41-128, bilinear :376-397) as
+// decode_macroblock (vp8/decoder/decodframe.c:112-296) calls them for a macroblock with ref_frame != INTRA_FRAME.
+//
+// An inter macroblock's prediction needs nothing of the frame being decoded, only the (finished, border-extended) reference
+// frames, so this kernel is order-free and its lanes are cut to the filter, not to the macroblock order:
+//   * a lane owns a COLUMN STRIP four pixels wide -- 16 rows of a luma macroblock, 8 rows of a chroma plane, or one 4x4 block of
+//     a SPLITMV macroblock -- and streams down the source rows: one global_load_dwordx3 per row (the nine pixels the six taps
+//     need, as three aligned dwords shifted into place), the horizontal pass two pixels per instruction on 16-bit lanes, a ring
+//     of the last six filtered rows in registers, the vertical pass, one dword stored.  21 source rows for 16 output rows (the
+//     wave-per-row kernels' 4-row segments need 9 for 4), no LDS, no exchange between lanes;
+//   * both passes always run, as in the reference's C filters (filter.c:95-128): a whole-pixel offset has the taps {0,0,128,0,0,0},
+//     which make a pass the identity, and the bilinear filters of versions 1-3 are the six-tap arithmetic with the taps
+//     {0,0,128-16f,16f,0,0} (the same sums, the same rounding; the clamp never binds) -- one code path for every profile;
+//   * a wave takes 64 consecutive macroblocks of a frame, sorts them by ballot into those with one motion vector and the
+//     SPLITMV ones (intra macroblocks drop out), and works through the two lists 16 (luma strips; then chroma strips) resp.
+//     4 / 8 macroblocks (luma / chroma 4x4 blocks) at a time, all lanes busy on the same code.
+//
+// Output: the prediction of macroblock (r, c) in ITS tile of the job's scratch frame (DevJob::tile, the key-frame kernels'
+// rows x (cols + 1) tiles of VP8_TILE_BYTES): luma rows at 16 y; chroma in the arrangement the tiles' chroma has -- U rows 0..3
+// at 256 + 8 y, V rows 0..3 at 288 + 8 y, U rows 4..7 at 320 + 8 (y - 4), V rows 4..7 at 352 + 8 (y - 4) -- so that
+// vp8_interframe_kernel, which reads a block row's prediction right before it writes finished pixels into the same tile, never
+// overwrites what it has not read yet.  Integer only; no MFMA by design.
+#include "vp8_block_prims.hip.h"
+
+namespace {
+
+typedef GLOBAL_AS const unsigned int *g_cmvp;       // vp8ir_mv {int16 row, col} read as one dword
+typedef u32 u32x3 __attribute__((ext_vector_type(3)));
+typedef GLOBAL_AS const u32x3 *g_cu32x3p;
+typedef u32 u32x2 __attribute__((ext_vector_type(2)));
+typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+typedef u32x4 u32x4_u __attribute__((aligned(4)));          // sixteen bytes at a four-byte boundary
+typedef GLOBAL_AS const u32x4_u *g_cu32x4up;
+
+// filter taps as (t, t) pairs of 16-bit lanes: [0] six-tap (filter.c:27-39), [1] bilinear (filter.c:16-26) on the six-tap grid
+#define T2_(a) (((u32)(unsigned short)(a)) * 0x10001u)
+#define BIL_(f) { 0u, 0u, T2_(128 - 16 * (f)), T2_(16 * (f)), 0u, 0u }
+__constant__ static const u32 k_taps2[2][8][6] = {
+    { { T2_(0), T2_(0), T2_(128), T2_(0), T2_(0), T2_(0) }, { T2_(0), T2_(-6), T2_(123), T2_(12), T2_(-1), T2_(0) },
+      { T2_(2), T2_(-11), T2_(108), T2_(36), T2_(-8), T2_(1) }, { T2_(0), T2_(-9), T2_(93), T2_(50), T2_(-6), T2_(0) },
+      { T2_(3), T2_(-16), T2_(77), T2_(77), T2_(-16), T2_(3) }, { T2_(0), T2_(-6), T2_(50), T2_(93), T2_(-9), T2_(0) },
+      { T2_(1), T2_(-8), T2_(36), T2_(108), T2_(-11), T2_(2) }, { T2_(0), T2_(-1), T2_(12), T2_(123), T2_(-6), T2_(0) } },
+    { BIL_(0), BIL_(1), BIL_(2), BIL_(3), BIL_(4), BIL_(5), BIL_(6), BIL_(7) }
+};
+#undef BIL_
+#undef T2_
+
+struct Taps { v2u16 t[6]; };
+__device__ __forceinline__ Taps load_taps(int bil, int f)
+{
+    Taps r;
+    const u32 *p = k_taps2[bil][f];
+#pragma unroll
+    for (int k = 0; k < 6; k++) r.t[k] = __builtin_bit_cast(v2u16, p[k]);
+    return r;
+}
+
+// four pixels of a filtered row as two pairs of 16-bit lanes, clamped to 0..255
+struct Row4 { v2u16 a, b; };
+// A pass's sum lies in -8160 .. 40864: biased by 8192 it is an unsigned 16-bit number, v_pk_mad_u16 wraps exactly, and
+// (t + 8192) >> 7 == (t >> 7) + 64; a saturating -64 and a min 255 are the clamp (vp8_block_prims.hip.h).
+__device__ __forceinline__ v2u16 finish2(v2u16 acc)
+{
+    const v2u16 c64 = { 64, 64 }, c255 = { 255, 255 };
+    return __builtin_elementwise_min(__builtin_elementwise_sub_sat(acc >> 7, c64), c255);
+}
+// first pass (filter_block2d_first_pass, filter.c:41-79) for four output pixels: d = the three aligned dwords that hold the
+// nine pixels from two left of the first output pixel on, sh = the byte offset of that pixel in d.x
+__device__ __forceinline__ Row4 h_pass(u32x3 d, u32 sh, const Taps &tx)
+{
+    auto asv = [](u32 v) { return __builtin_bit_cast(v2u16, v); };
+    const u32 w0 = __builtin_amdgcn_alignbyte(d.y, d.x, sh), w1 = __builtin_amdgcn_alignbyte(d.z, d.y, sh);
+    const u32 w2 = __builtin_amdgcn_alignbyte(0u, d.z, sh);
+    // P[k] = pixels (k, k+1) of the row, one per 16-bit lane
+    const v2u16 P[8] = { asv(perm(w0, w0, 0x0c010c00u)), asv(perm(w0, w0, 0x0c020c01u)), asv(perm(w0, w0, 0x0c030c02u)),
+                         asv(perm(w1, w0, 0x0c040c03u)), asv(perm(w1, w1, 0x0c010c00u)), asv(perm(w1, w1, 0x0c020c01u)),
+                         asv(perm(w1, w1, 0x0c030c02u)), asv(perm(w2, w1, 0x0c040c03u)) };
+    const v2u16 bias = { 64 + 8192, 64 + 8192 };
+    v2u16 a01 = bias, a23 = bias;
+#pragma unroll
+    for (int k = 0; k < 6; k++) { a01 += P[k] * tx.t[k]; a23 += P[k + 2] * tx.t[k]; }
+    return { finish2(a01), finish2(a23) };
+}
+// second pass (filter_block2d_second_pass, filter.c:81-128): H[0..5] = the filtered source rows -2 .. +3 of the output row
+__device__ __forceinline__ u32 v_pass(const Row4 &h0, const Row4 &h1, const Row4 &h2, const Row4 &h3, const Row4 &h4, const Row4 &h5,
+                                      const Taps &ty)
+{
+    const v2u16 bias = { 64 + 8192, 64 + 8192 };
+    const v2u16 a01 = bias + h0.a * ty.t[0] + h1.a * ty.t[1] + h2.a * ty.t[2] + h3.a * ty.t[3] + h4.a * ty.t[4] + h5.a * ty.t[5];
+    const v2u16 a23 = bias + h0.b * ty.t[0] + h1.b * ty.t[1] + h2.b * ty.t[2] + h3.b * ty.t[3] + h4.b * ty.t[4] + h5.b * ty.t[5];
+    return perm(__builtin_bit_cast(u32, finish2(a23)), __builtin_bit_cast(u32, finish2(a01)), 0x06040200u);
+}
+
+// A column strip of NOUT rows: src = the pixel two left of and two above the strip's first one in the reference plane,
+// dst / dstride = where output row y goes (rows 4.. of an 8-row strip at dst + dhalf + dstride * (y - 4): the chroma layout)
+template <int NOUT>
+__device__ __forceinline__ void strip(g_cu8p src, int stride, const Taps &tx, const Taps &ty, g_u8p dst, int dstride, int dhalf)
+{
+    const u32 sh = (u32)(unsigned long)src & 3u;
+    g_cu8p rp = src - sh;
+    // the source rows are requested AHEAD rows before they are filtered (the compiler would not move a load above the store of
+    // the output row before it -- for all it knows they alias -- and one row in flight at a time is a latency chain)
+    constexpr int NIN = NOUT + 5, AHEAD = NIN < 8 ? NIN : 8;
+    u32x3 q[AHEAD];
+#pragma unroll
+    for (int i = 0; i < AHEAD; i++) q[i] = *(g_cu32x3p)(rp + (long)i * stride);
+    Row4 H[6];
+#pragma unroll
+    for (int i = 0; i < NIN; i++) {
+        const u32x3 d = q[i % AHEAD];
+        if (i + AHEAD < NIN) q[i % AHEAD] = *(g_cu32x3p)(rp + (long)(i + AHEAD) * stride);
+        H[i % 6] = h_pass(d, sh, tx);
+        if (i >= 5) {
+            const int y = i - 5;
+            const u32 o = v_pass(H[(i + 1) % 6], H[(i + 2) % 6], H[(i + 3) % 6], H[(i + 4) % 6], H[(i + 5) % 6], H[i % 6], ty);
+            g_u8p qd = (NOUT == 8 && y >= 4) ? dst + dhalf + dstride * (y - 4) : dst + dstride * y;
+            *(GLOBAL_AS u32 *)qd = o;
+        }
+    }
+}
+
+// The same for a strip EIGHT pixels wide (the texture addresser is what bounds this kernel, and it works by the instruction:
+// half as many loads and stores per macroblock): the 13 pixels a row needs lie in four aligned dwords
+struct Row8 { Row4 l, r; };
+__device__ __forceinline__ Row8 h_pass8(u32x4 d, u32 sh, const Taps &tx)
+{
+    auto asv = [](u32 v) { return __builtin_bit_cast(v2u16, v); };
+    const u32 w0 = __builtin_amdgcn_alignbyte(d.y, d.x, sh), w1 = __builtin_amdgcn_alignbyte(d.z, d.y, sh);
+    const u32 w2 = __builtin_amdgcn_alignbyte(d.w, d.z, sh), w3 = __builtin_amdgcn_alignbyte(0u, d.w, sh);
+    const v2u16 P[12] = { asv(perm(w0, w0, 0x0c010c00u)), asv(perm(w0, w0, 0x0c020c01u)), asv(perm(w0, w0, 0x0c030c02u)),
+                          asv(perm(w1, w0, 0x0c040c03u)), asv(perm(w1, w1, 0x0c010c00u)), asv(perm(w1, w1, 0x0c020c01u)),
+                          asv(perm(w1, w1, 0x0c030c02u)), asv(perm(w2, w1, 0x0c040c03u)), asv(perm(w2, w2, 0x0c010c00u)),
+                          asv(perm(w2, w2, 0x0c020c01u)), asv(perm(w2, w2, 0x0c030c02u)), asv(perm(w3, w2, 0x0c040c03u)) };
+    const v2u16 bias = { 64 + 8192, 64 + 8192 };
+    v2u16 a01 = bias, a23 = bias, a45 = bias, a67 = bias;
+#pragma unroll
+    for (int k = 0; k < 6; k++) { a01 += P[k] * tx.t[k]; a23 += P[k + 2] * tx.t[k]; a45 += P[k + 4] * tx.t[k]; a67 += P[k + 6] * tx.t[k]; }
+    return { { finish2(a01), finish2(a23) }, { finish2(a45), finish2(a67) } };
+}
+template <int NOUT>
+__device__ __forceinline__ void strip8(g_cu8p src, int stride, const Taps &tx, const Taps &ty, g_u8p dst, int dstride, int dhalf)
+{
+    const u32 sh = (u32)(unsigned long)src & 3u;
+    g_cu8p rp = src - sh;
+    constexpr int NIN = NOUT + 5, AHEAD = 6;
+    u32x4_u q[AHEAD];
+#pragma unroll
+    for (int i = 0; i < AHEAD; i++) q[i] = *(g_cu32x4up)(rp + (long)i * stride);
+    Row8 H[6];
+#pragma unroll
+    for (int i = 0; i < NIN; i++) {
+        const u32x4 d = q[i % AHEAD];
+        if (i + AHEAD < NIN) q[i % AHEAD] = *(g_cu32x4up)(rp + (long)(i + AHEAD) * stride);
+        H[i % 6] = h_pass8(d, sh, tx);
+        if (i >= 5) {
+            const int y = i - 5;
+            const Row8 &h0 = H[(i + 1) % 6], &h1 = H[(i + 2) % 6], &h2 = H[(i + 3) % 6], &h3 = H[(i + 4) % 6], &h4 = H[(i + 5) % 6], &h5 = H[i % 6];
+            u32x2 o;
+            o.x = v_pass(h0.l, h1.l, h2.l, h3.l, h4.l, h5.l, ty);
+            o.y = v_pass(h0.r, h1.r, h2.r, h3.r, h4.r, h5.r, ty);
+            g_u8p qd = (NOUT == 8 && y >= 4) ? dst + dhalf + dstride * (y - 4) : dst + dstride * y;
+            *(GLOBAL_AS u32x2 *)qd = o;
+        }
+    }
+}
+
+// clamp_mv_to_umv_border (reconinter.c:348-368)
+__device__ __forceinline__ void clamp_luma_mv(int &row, int &col, int e_left, int e_right, int e_top, int e_bottom)
+{
+    if (col < e_left - (19 << 3)) col = e_left - (16 << 3);
+    else if (col > e_right + (18 << 3)) col = e_right + (16 << 3);
+    if (row < e_top - (19 << 3)) row = e_top - (16 << 3);
+    else if (row > e_bottom + (18 << 3)) row = e_bottom + (16 << 3);
+}
+// clamp_uvmv_to_umv_border (reconinter.c:371-382)
+__device__ __forceinline__ void clamp_chroma_mv(int &row, int &col, int e_left, int e_right, int e_top, int e_bottom)
+{
+    if (2 * col < e_left - (19 << 3)) col = (e_left - (16 << 3)) >> 1;
+    if (2 * col > e_right + (18 << 3)) col = (e_right + (16 << 3)) >> 1;
+    if (2 * row < e_top - (19 << 3)) row = (e_top - (16 << 3)) >> 1;
+    if (2 * row > e_bottom + (18 << 3)) row = (e_bottom + (16 << 3)) >> 1;
+}
+
+} // namespace
+
+// grid: any number of blocks of four waves (a wave takes units unit, unit + waves, ...); upf = units (64 macroblocks) per frame
+extern "C" __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8)))
+vp8_inter_pred_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g, int upf)
+{
+    __shared__ u32 s_w0a[4][64];
+    __shared__ unsigned char s_plaina[4][64], s_splita[4][64];
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    u32 *const s_w0 = s_w0a[wv];
+    unsigned char *const s_plain = s_plaina[wv], *const s_split = s_splita[wv];
+    const int cols = g.mb_cols, rows = g.mb_rows, nmb = cols * rows;
+    const long nunits = (long)njobs * upf;
+    for (long unit = (long)blockIdx.x * 4 + wv; unit < nunits; unit += (long)gridDim.x * 4) {
+        const int j = (int)(unit / upf), u = (int)(unit - (long)j * upf);
+        const DevJob &job = jobs[j];
+        if (job.hdr.frame_type == 0) continue;
+        const bool bil = job.hdr.version != 0, fullpix = job.hdr.version == 3;
+        g_cu32p mbs = (g_cu32p)job.mbs;
+        g_cmvp mvs = (g_cmvp)job.mvs;
+        const g_u8p tiles = (g_u8p)job.tile;
+        const int mb_l = u * 64 + lane;
+        const u32 w0_l = mb_l < nmb ? mbs[(long)mb_l * 16] : 0u;
+        const bool inter_l = ((w0_l >> 16) & 0xff) != VP8IR_INTRA_FRAME;
+        const bool split_l = inter_l && (w0_l & 0xff) == VP8IR_SPLITMV;
+        const unsigned long long balP = __builtin_amdgcn_ballot_w64(inter_l && !split_l), balS = __builtin_amdgcn_ballot_w64(split_l);
+        const int nP = __builtin_popcountll(balP), nS = __builtin_popcountll(balS);
+        wave_lds_sync();                                    // the previous unit's readers are done
+        s_w0[lane] = w0_l;
+        if (inter_l && !split_l) s_plain[__builtin_amdgcn_mbcnt_hi((u32)(balP >> 32), __builtin_amdgcn_mbcnt_lo((u32)balP, 0u))] = (unsigned char)lane;
+        if (split_l) s_split[__builtin_amdgcn_mbcnt_hi((u32)(balS >> 32), __builtin_amdgcn_mbcnt_lo((u32)balS, 0u))] = (unsigned char)lane;
+        wave_lds_sync();
+
+        // what a lane needs to know about macroblock `li` of the unit
+        struct Mb { int r, c; u32 w0; long idx; int e_left, e_right, e_top, e_bottom; g_cu8p ref; g_u8p tile; };
+        auto mb_of = [&](int li) {
+            Mb m;
+            m.idx = (long)u * 64 + li;
+            m.r = (int)(m.idx / cols); m.c = (int)(m.idx - (long)m.r * cols);
+            m.w0 = s_w0[li];
+            m.e_left = -((m.c * 16) << 3); m.e_right = ((cols - 1 - m.c) * 16) << 3;
+            m.e_top = -((m.r * 16) << 3); m.e_bottom = ((rows - 1 - m.r) * 16) << 3;
+            const int rf = (m.w0 >> 16) & 3;
+            m.ref = (g_cu8p)(rf == 1 ? job.ref[1] : rf == 2 ? job.ref[2] : job.ref[3]);
+            m.tile = tiles + ((long)m.r * (cols + 1) + m.c) * VP8_TILE_BYTES;
+            return m;
+        };
+
+        // ---- one motion vector: vp8_build_inter16x16_predictors_mb.  Luma: 16 macroblocks x 4 strips
+        for (int i0 = 0; i0 < nP; i0 += 32) {
+            const int mi = i0 + (lane >> 1), s = lane & 1;
+            if (mi < nP) {
+                const Mb m = mb_of(s_plain[mi]);
+                const u32 mvw = mvs[m.idx * 16];
+                int mrow = sext16(mvw), mcol = hi16(mvw);
+                if ((m.w0 >> 24) & VP8IR_MB_CLAMP) clamp_luma_mv(mrow, mcol, m.e_left, m.e_right, m.e_top, m.e_bottom);
+                // memory safety only (a conforming stream never triggers these): every tap inside the plane and its border
+                const int sx = max(-32 + 2, min(m.c * 16 + (mcol >> 3), g.aligned_w + 32 - 22));
+                const int sy = max(-32 + 2, min(m.r * 16 + (mrow >> 3), g.aligned_h + 32 - 19));
+                const Taps tx = load_taps(bil, mcol & 7), ty = load_taps(bil, mrow & 7);
+                strip8<16>(m.ref + g.y_off + (long)(sy - 2) * g.y_stride + (sx - 2 + 8 * s), g.y_stride, tx, ty, m.tile + 8 * s, 16, 0);
+            }
+        }
+        // chroma: 32 macroblocks x 2 planes; the MV from the CLAMPED luma MV (reconinter.c:419-424)
+        for (int i0 = 0; i0 < nP; i0 += 32) {
+            const int mi = i0 + (lane >> 1), pl = lane & 1;
+            if (mi < nP) {
+                const Mb m = mb_of(s_plain[mi]);
+                const u32 mvw = mvs[m.idx * 16];
+                int mrow = sext16(mvw), mcol = hi16(mvw);
+                if ((m.w0 >> 24) & VP8IR_MB_CLAMP) clamp_luma_mv(mrow, mcol, m.e_left, m.e_right, m.e_top, m.e_bottom);
+                mrow = (short)(mrow + (1 | (mrow >> 31)));
+                mcol = (short)(mcol + (1 | (mcol >> 31)));
+                mrow /= 2; mcol /= 2;
+                if (fullpix) { mrow &= ~7; mcol &= ~7; }
+                const int sx = max(-16 + 2, min(m.c * 8 + (mcol >> 3), g.aligned_w / 2 + 16 - 14));
+                const int sy = max(-16 + 2, min(m.r * 8 + (mrow >> 3), g.aligned_h / 2 + 16 - 11));
+                const Taps tx = load_taps(bil, mcol & 7), ty = load_taps(bil, mrow & 7);
+                strip8<8>(m.ref + (pl ? g.v_off : g.u_off) + (long)(sy - 2) * g.uv_stride + (sx - 2), g.uv_stride, tx, ty,
+                          m.tile + 256 + 32 * pl, 8, 64);
+            }
+        }
+        // ---- SPLITMV: build_inter4x4_predictors_mb, a 4x4 block per lane (partitions of 8x8 / 16x8 / 8x16 carry their MV in every
+        // block they cover: the filters are the same per pixel).  Luma: 4 macroblocks x 16 blocks
+        for (int i0 = 0; i0 < nS; i0 += 4) {
+            const int mi = i0 + (lane >> 4), b = lane & 15;
+            if (mi < nS) {
+                const Mb m = mb_of(s_split[mi]);
+                const u32 mvw = mvs[m.idx * 16 + b];
+                int mrow = sext16(mvw), mcol = hi16(mvw);
+                if ((m.w0 >> 24) & VP8IR_MB_CLAMP) clamp_luma_mv(mrow, mcol, m.e_left, m.e_right, m.e_top, m.e_bottom);
+                const int sx = max(-32 + 2, min(m.c * 16 + 4 * (b & 3) + (mcol >> 3), g.aligned_w + 32 - 10));
+                const int sy = max(-32 + 2, min(m.r * 16 + 4 * (b >> 2) + (mrow >> 3), g.aligned_h + 32 - 7));
+                const Taps tx = load_taps(bil, mcol & 7), ty = load_taps(bil, mrow & 7);
+                strip<4>(m.ref + g.y_off + (long)(sy - 2) * g.y_stride + (sx - 2), g.y_stride, tx, ty,
+                         m.tile + 64 * (b >> 2) + 4 * (b & 3), 16, 0);
+            }
+        }
+        // chroma: 8 macroblocks x 2 planes x 4 blocks; build_4x4uvmvs (reconinter.c:520-558): the UNclamped MVs of the four luma
+        // blocks above a chroma block, averaged
+        for (int i0 = 0; i0 < nS; i0 += 8) {
+            const int mi = i0 + (lane >> 3), pl = (lane >> 2) & 1, blk = lane & 3;
+            if (mi < nS) {
+                const Mb m = mb_of(s_split[mi]);
+                const int kq = (blk >> 1) * 8 + (blk & 1) * 2;
+                g_cmvp mv = mvs + m.idx * 16;
+                const u32 m0 = mv[kq], m1 = mv[kq + 1], m4 = mv[kq + 4], m5 = mv[kq + 5];
+                int mrow = sext16(m0) + sext16(m1) + sext16(m4) + sext16(m5);
+                int mcol = hi16(m0) + hi16(m1) + hi16(m4) + hi16(m5);
+                mrow += 4 + ((mrow >> 31) << 3);
+                mcol += 4 + ((mcol >> 31) << 3);
+                mrow /= 8; mcol /= 8;
+                if (fullpix) { mrow &= ~7; mcol &= ~7; }
+                if ((m.w0 >> 24) & VP8IR_MB_CLAMP) clamp_chroma_mv(mrow, mcol, m.e_left, m.e_right, m.e_top, m.e_bottom);
+                const int sx = max(-16 + 2, min(m.c * 8 + 4 * (blk & 1) + (mcol >> 3), g.aligned_w / 2 + 16 - 10));
+                const int sy = max(-16 + 2, min(m.r * 8 + 4 * (blk >> 1) + (mrow >> 3), g.aligned_h / 2 + 16 - 7));
+                const Taps tx = load_taps(bil, mcol & 7), ty = load_taps(bil, mrow & 7);
+                strip<4>(m.ref + (pl ? g.v_off : g.u_off) + (long)(sy - 2) * g.uv_stride + (sx - 2), g.uv_stride, tx, ty,
+                         m.tile + 256 + 32 * pl + 64 * (blk >> 1) + 4 * (blk & 1), 8, 0);
+            }
+        }
+    }
+}

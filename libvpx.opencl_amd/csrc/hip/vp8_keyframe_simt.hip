@@ -73,6 +73,29 @@ __device__ __forceinline__ void frame_levels(const vp8ir_frame_hdr &h, u32 &plai
     }
 }
 
+// ... for launches with inter frames: the segments' base levels, and the deltas a macroblock's reference frame and mode add
+// (mb_level, vp8_simt_prims.hip.h, is the same arithmetic per macroblock)
+__device__ __forceinline__ void frame_levels_inter(const vp8ir_frame_hdr &h, u32 &base, u32 &refd, u32 &moded)
+{
+    base = refd = moded = 0;
+    if (!h.filter_level) return;
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+        int b = h.filter_level;
+        if (h.segmentation_enabled) {
+            if (h.mb_segment_abs_delta) b = h.segment_lf[s];
+            else { b += h.segment_lf[s]; b = b < 0 ? 0 : (b > 63 ? 63 : b); }
+        }
+        base |= (u32)(b & 0xff) << (8 * s);
+    }
+    if (!h.mode_ref_lf_delta_enabled) return;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        refd |= (u32)(unsigned char)h.ref_lf_deltas[k] << (8 * k);
+        moded |= (u32)(unsigned char)h.mode_lf_deltas[k] << (8 * k);
+    }
+}
+
 #ifdef KF_NOSTORE          // (timing experiments only: the row stores of active lanes go to the dummy scratch too)
 #define KF_ACT(a) false
 #else
@@ -112,7 +135,7 @@ __device__ __forceinline__ void frame_levels(const vp8ir_frame_hdr &h, u32 &plai
 //   s_sf     [row][lane]: the last four pixels (filtered, biased) of pixel rows of the macroblock to the left -- luma rows 0..11,
 //            chroma U rows 0..3, V rows 0..3 (the bottom four rows' are in registers: they double as the lane below's context).
 //            Per-lane state read and written once per step and indexed by the block row: in LDS it costs no registers    3072 B
-template <bool LUMA>
+template <bool LUMA, bool INTER>
 __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njobs, DevGeom g, int lgG, int P, int nstrands, uint8_t *dummy,
                                         const int wave, u32 *s_stage, unsigned short *s_queue, u32 *s_tab,
                                         u32 *s_y2dc, u32 *s_desc, u32 *s_sf)
@@ -142,8 +165,11 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
     u32 dqs[4][2];                              // luma: y1, y2 quantisers per segment (dc | ac << 16); chroma: uv in [s][0]
 #pragma unroll
     for (int s = 0; s < 4; s++) dqs[s][0] = dqs[s][1] = 0;
-    u32 lv_plain = 0, lv_bpred = 0;
-    int sharp = 0; bool simple = false;
+    // loop-filter levels.  Key-frame launches: lv_plain / lv_bpred = the level per segment, a byte each, for 16x16 modes / B_PRED.
+    // Launches with inter frames: lv_plain = the segments' base levels, lv_bpred = ref_lf_deltas[0..3], lv_mode = mode_lf_deltas[0..3]
+    // (signed bytes; both zero without mode_ref_lf_delta_enabled), ftype = the frame's type (the hev threshold depends on it)
+    u32 lv_plain = 0, lv_bpred = 0, lv_mode = 0;
+    int sharp = 0, ftype = 0; bool simple = false, lv_delta = false;
     s_tab[lane] = 0;
     // ---- prediction context (unfiltered).  Luma: l0[0..3] left column, h1/h2[0..3] bottom lines of the macroblocks finished one
     // and two steps ago.  Chroma: U in [0..1], V in [2..3].
@@ -378,7 +404,12 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
                 else { d[0] = dqs[0][0]; d[1] = dqs[0][1]; d[2] = dqs[0][0]; }
                 dqs[s][0] = LUMA ? d[0] : d[2]; dqs[s][1] = d[1];
             }
-            frame_levels(h, lv_plain, lv_bpred);
+            if constexpr (INTER) {
+                frame_levels_inter(h, lv_plain, lv_bpred, lv_mode);
+                lv_delta = h.filter_level && h.mode_ref_lf_delta_enabled;
+                ftype = h.frame_type;
+            } else
+                frame_levels(h, lv_plain, lv_bpred);
             sharp = h.sharpness_level; simple = h.filter_type == 1;
             mbp = (g_cu32p)(job->mbs + (long)r * cols);
             cfp = (g_cs16p)(job->coef + (long)r * cols * VP8IR_COEF_PER_MB);
@@ -415,8 +446,22 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
         // ---- macroblock descriptor; loop-filter parameters (vp8_loop_filter_frame, loopfilter.c:245-299)
         const int y_mode = cur_w0 & 0xff, uv_mode = (cur_w0 >> 8) & 0xff;
         const bool bpred = y_mode == VP8IR_B_PRED;
-        const int level = act ? (int)(((bpred ? lv_bpred : lv_plain) >> (8 * (cur_w1 & 3))) & 0xff) : 0;
-        const Lim L = mb_limits(sharp, level, 0, one);
+        const int ref_frame = INTER ? (int)((cur_w0 >> 16) & 3) : 0;
+        const bool is_inter = INTER && act && ref_frame != VP8IR_INTRA_FRAME;
+        int level;
+        if constexpr (INTER) {
+            // vp8_loop_filter_frame_init (loopfilter.c:117-201) for this macroblock's segment, reference frame and mode class
+            level = (int)((lv_plain >> (8 * (cur_w1 & 3))) & 0xff);
+            if (lv_delta) {
+                const int m = ref_frame == VP8IR_INTRA_FRAME ? (bpred ? 0 : -1)
+                                                             : (y_mode == VP8IR_ZEROMV ? 1 : (y_mode == VP8IR_SPLITMV ? 3 : 2));
+                level += (int)(signed char)(lv_bpred >> (8 * ref_frame)) + (m >= 0 ? (int)(signed char)(lv_mode >> (8 * m)) : 0);
+                level = level < 0 ? 0 : (level > 63 ? 63 : level);
+            }
+            if (!act) level = 0;
+        } else
+            level = act ? (int)(((bpred ? lv_bpred : lv_plain) >> (8 * (cur_w1 & 3))) & 0xff) : 0;
+        const Lim L = mb_limits(sharp, level, INTER ? ftype : 0, one);
         const bool on = level != 0;
         const bool skip_lf = !bpred && y_mode != VP8IR_SPLITMV && ((cur_w0 >> 24) & VP8IR_MB_SKIP);
         const bool mbv = on && c > 0, inner = on && !skip_lf, mbh = on && !top;
@@ -479,8 +524,19 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
             // where the rows above the current block row go: first the bottom rows of the macroblock above, then this one's window
             g_u8p prow = KF_ACT(act && !top) ? tpc - rowbytes + KT_Y_BOT : (g_u8p)dummy;
             int pstride = KF_ACT(act && !top) ? 16 : 0;
+            // inter macroblocks: the prediction vp8_inter_pred_kernel left in the macroblock's tile (luma row y at 16 y), a block row at
+            // a time; the next block row's is requested behind this one's row stores and arrives during the transform
+            u32x4 pr[4] = { { 0, 0, 0, 0 }, { 0, 0, 0, 0 }, { 0, 0, 0, 0 }, { 0, 0, 0, 0 } };
+            if constexpr (INTER) {
+                if (is_inter) {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) pr[j] = *(g_cu32x4p)(tpc + 16 * j);
+                }
+            }
 #pragma unroll 1
             for (int by = 0; by < 4; by++) {
+                // (landed before the next phase's coefficients are requested: nothing older than those may be waited for later)
+                if constexpr (INTER) asm volatile("" : "+v"(pr[0]), "+v"(pr[1]), "+v"(pr[2]), "+v"(pr[3]));
                 // ---- the block row's residuals; then the next phase's coefficients are requested (the next block row's, or the next
                 // macroblock's first, whose descriptor has arrived by now: at least the 12 row stores below are younger)
                 u32x4 rr[8];
@@ -519,7 +575,10 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     u32 p[4];
-                    if (bpred) {
+                    if (INTER && is_inter) {
+#pragma unroll
+                        for (int jj = 0; jj < 4; jj++) p[jj] = k == 0 ? pr[jj].x : k == 1 ? pr[jj].y : k == 2 ? pr[jj].z : pr[jj].w;
+                    } else if (bpred) {
                         // decodframe.c:200-236; above-right of the right-hand block column is the macroblock's own
                         // above-right for every block row (reconintra4x4.c:305-317)
                         bpred4x4((bmw >> (8 * k)) & 0xff, abv[k], k < 3 ? abv[k + 1] : arY, left, tl, p);
@@ -569,6 +628,12 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
                 for (int j = 0; j < 4; j++) { if (act && !first) sF[(4 * by - 4 + j) * 64] = d[j][3]; sfix[j] = sb[j]; }
                 prow = KF_ACT(act) ? (first ? tpc + KT_Y_WIN : prow + 64) : (g_u8p)dummy;
                 pstride = KF_ACT(act) ? 16 : 0;
+                if constexpr (INTER) {
+                    if (is_inter && by < 3) {
+#pragma unroll
+                        for (int j = 0; j < 4; j++) pr[j] = *(g_cu32x4p)(tpc + 64 * (by + 1) + 16 * j);
+                    }
+                }
                 STAMP(10)
                 // ---- the next phase's residuals (its coefficients have landed: the four row stores above are younger)
                 drain(by < 3 ? 4 * by + 4 : 0, 0, 4);
@@ -610,8 +675,18 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
             int tlA = top ? 127 : (c == 0 ? 129 : prevLast), tlB = top ? 127 : (c == 0 ? 129 : prevLast2);
             const int lastU = aA[1] >> 24, lastV = aA[3] >> 24;
             u32 bA[2] = { 0, 0 }, bB[2] = { 0, 0 };           // unfiltered bottom lines of the two planes
+            // inter macroblocks: the plane's prediction out of the macroblock's tile, rows (0,1) (2,3) (4,5) (6,7); V's is requested
+            // behind U's row stores
+            u32x4 pr[4] = { { 0, 0, 0, 0 }, { 0, 0, 0, 0 }, { 0, 0, 0, 0 }, { 0, 0, 0, 0 } };
+            if constexpr (INTER) {
+                if (is_inter) {
+                    pr[0] = *(g_cu32x4p)(tpc + 256); pr[1] = *(g_cu32x4p)(tpc + 272);
+                    pr[2] = *(g_cu32x4p)(tpc + 320); pr[3] = *(g_cu32x4p)(tpc + 336);
+                }
+            }
 #pragma unroll 1
             for (int pl = 0; pl < 2; pl++) {
+                if constexpr (INTER) asm volatile("" : "+v"(pr[0]), "+v"(pr[1]), "+v"(pr[2]), "+v"(pr[3]));
                 u32x4 rr[8];
                 fetch(rr);
                 const u32 rmg = jm >> (4 * pl), rmf = jm >> (16 + 4 * pl);
@@ -642,7 +717,11 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
                 for (int k = 0; k < 4; k++) {
                     const int bx = k & 1, byc = k >> 1;
                     u32 p[4];
-                    mb_mode_pred(uv_mode, bx ? aC1 : aC0, byc ? lC1 : lC0, tlA, dcC, p);
+                    if (INTER && is_inter) {
+                        const u32x4 ra = byc ? pr[2] : pr[0], rb = byc ? pr[3] : pr[1];
+                        p[0] = bx ? ra.y : ra.x; p[1] = bx ? ra.w : ra.z; p[2] = bx ? rb.y : rb.x; p[3] = bx ? rb.w : rb.z;
+                    } else
+                        mb_mode_pred(uv_mode, bx ? aC1 : aC0, byc ? lC1 : lC0, tlA, dcC, p);
                     u32 o[4] = { p[0], p[1], p[2], p[3] };
                     const bool hasr = (rmg >> k) & 1;
                     if (__builtin_amdgcn_ballot_w64(hasr) != 0) {
@@ -713,6 +792,12 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
                         }
                     }
                 }
+                if constexpr (INTER) {
+                    if (is_inter && pl == 0) {
+                        pr[0] = *(g_cu32x4p)(tpc + 288); pr[1] = *(g_cu32x4p)(tpc + 304);
+                        pr[2] = *(g_cu32x4p)(tpc + 352); pr[3] = *(g_cu32x4p)(tpc + 368);
+                    }
+                }
                 // ---- the other plane's residuals (or the next macroblock's first): the eight row stores above are younger
                 drain(pl == 0 ? 20 : 16, 0, 8);
                 STAMP(6)
@@ -748,9 +833,9 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
 // from one counter per role (if its role has run out of work it takes the other).  grid = 2 * nwaves.
 //   sched[0], sched[1]: next luma / chroma work item (zeroed before every launch); sched[16 + simd]: waves seen (never reset:
 //   only the parity matters).
-extern "C" __global__ void __launch_bounds__(64, 2)
-vp8_keyframe_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g, int lgG, int P, int nstrands, uint8_t *dummy,
-                    unsigned int *sched, int nwaves)
+template <bool INTER>
+__device__ __forceinline__ void kf_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g, int lgG, int P, int nstrands, uint8_t *dummy,
+                                          unsigned int *sched, int nwaves)
 {
     __shared__ __attribute__((aligned(16))) u32 s_stage[4 * 2 * 64 * 4];
     __shared__ unsigned short s_queue[256];
@@ -776,6 +861,24 @@ vp8_keyframe_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g, int l
     role = __builtin_amdgcn_readfirstlane(role);
     item = __builtin_amdgcn_readfirstlane(item);
     if (item >= nwaves) return;         // (cannot happen with grid = 2 * nwaves)
-    if (role == 0) kf_body<true>(jobs, njobs, g, lgG, P, nstrands, dummy, item, s_stage, s_queue, s_tab, s_y2dc, s_desc, s_sf);
-    else kf_body<false>(jobs, njobs, g, lgG, P, nstrands, dummy + 1024, item, s_stage, s_queue, s_tab, s_y2dc, s_desc, s_sf);
+    if (role == 0) kf_body<true, INTER>(jobs, njobs, g, lgG, P, nstrands, dummy, item, s_stage, s_queue, s_tab, s_y2dc, s_desc, s_sf);
+    else kf_body<false, INTER>(jobs, njobs, g, lgG, P, nstrands, dummy + 1024, item, s_stage, s_queue, s_tab, s_y2dc, s_desc, s_sf);
+}
+
+extern "C" __global__ void __launch_bounds__(64, 2)
+vp8_keyframe_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g, int lgG, int P, int nstrands, uint8_t *dummy,
+                    unsigned int *sched, int nwaves)
+{
+    kf_kernel<false>(jobs, njobs, g, lgG, P, nstrands, dummy, sched, nwaves);
+}
+
+// The same for launches with inter frames among them: a macroblock with a reference frame takes its prediction from its tile, where
+// vp8_inter_pred_kernel (vp8_inter_pred.hip; launched in front of this kernel) left it, instead of predicting from its neighbours;
+// residual, loop filter (levels by reference frame and mode, the inter frames' hev thresholds) and output are the key frames'.
+// Intra macroblocks of inter frames, and whole key frames in such a launch, go the key-frame way.
+extern "C" __global__ void __launch_bounds__(64, 2)
+vp8_interframe_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g, int lgG, int P, int nstrands, uint8_t *dummy,
+                      unsigned int *sched, int nwaves)
+{
+    kf_kernel<true>(jobs, njobs, g, lgG, P, nstrands, dummy, sched, nwaves);
 }

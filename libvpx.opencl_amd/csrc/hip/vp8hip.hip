@@ -25,6 +25,9 @@ extern "C" __global__ void vp8_recon_intra_xcu_kernel(const DevJob *jobs, int nj
 extern "C" __global__ void vp8_inter_mb_kernel(const DevJob *jobs, int njobs, DevGeom g, unsigned int *intra_flags);
 extern "C" __global__ void vp8_keyframe_kernel(const DevJob *jobs, int njobs, DevGeom g, int lgG, int P, int nstrands, uint8_t *dummy,
                                                unsigned int *sched, int nwaves);
+extern "C" __global__ void vp8_interframe_kernel(const DevJob *jobs, int njobs, DevGeom g, int lgG, int P, int nstrands, uint8_t *dummy,
+                                               unsigned int *sched, int nwaves);
+extern "C" __global__ void vp8_inter_pred_kernel(const DevJob *jobs, int njobs, DevGeom g, int upf);
 #ifdef VP8_STAMPS
 #define VP8HIP_SCHED_WORDS (16 + 16384 + 4 * 4096)     // + the diagnostic builds' log: four words per wave
 #else
@@ -147,6 +150,11 @@ struct Knobs {
     // VP8HIP_FUSED=0: all-key-frame launches of the lane-per-row family run reconstruction and loop filter as two kernels with the
     // tiled scratch frames between them (the round-1/2 pipeline) instead of vp8_keyframe_simt_kernel
     int fused;
+    // VP8HIP_INTER_FUSED=N: launches of N or more frames with inter frames among them, both stages wanted, go the key frames' way --
+    // vp8_inter_pred_kernel (every inter macroblock's prediction, order-free) + vp8_interframe_kernel (residual + loop filter, one
+    // macroblock row per lane) -- instead of the wave-per-row recon + the lane-per-row loop filter.  Default -1: launches of more
+    // than two frames per CU, as for key frames; 0: never.  VP8HIP_RECON=simt forces it at every size.
+    int inter_fused;
     int detile_blocks;     // VP8HIP_DETILE_BLOCKS=n: workgroups of the key-frame kernel's tiled -> raster pass (default: two per CU)
     int lf_raster, lgG, simt_waves, wg_per_cu, xcu, xcu_S, xcu_NW, recon_nw, lf_nw, detile_stream, detile_defer;
 };
@@ -165,6 +173,7 @@ static void read_knobs(Knobs &k)
     k.detile_blocks = env_int("VP8HIP_DETILE_BLOCKS", 0);
     k.inter_split = env_int("VP8HIP_INTER_SPLIT", 384);
     k.inter_tiled = env_int("VP8HIP_INTER_TILED", 640);
+    k.inter_fused = env_int("VP8HIP_INTER_FUSED", -1);
     k.xcu_NW = env_int("VP8HIP_XCU_NW", 0);
     k.recon_nw = env_int("VP8HIP_RECON_NW", 0);
     k.lf_nw = env_int("VP8HIP_LF_NW", 0);
@@ -202,6 +211,11 @@ struct vp8hip_ctx {
     int nmb;
     // pools
     std::vector<uint8_t *> fb;
+    // which tiled -> raster pass writes a frame buffer's raster: passes are numbered as they are issued (detile_gen); passes up to
+    // detile_joined have been waited for by the main stream.  A launch that reads reference frames only has to join if one of
+    // them is still to be written by a pass it has not waited for
+    std::vector<unsigned> fb_detile_gen;
+    unsigned detile_gen, detile_joined;
     std::vector<Slot> slots;
     uint8_t *fb_block; char *slot_block_dev;
     uint8_t *tile_block[VP8HIP_NBUF]; size_t tile_cap[VP8HIP_NBUF];   // macroblock-tiled scratch frames of the lane-per-row pipeline
@@ -308,6 +322,7 @@ extern "C" int vp8hip_create(int device, vp8hip_ctx **out)
     for (int k = 0; k < VP8HIP_NBUF; k++) c->d_jobs2[k] = nullptr;
     for (int k = 0; k < VP8HIP_NBUF; k++) c->detile_used[k] = false;
     c->detile_pending = false; c->parity = 0; c->last_par = 0;
+    c->detile_gen = c->detile_joined = 0;
     c->deferred.valid = false;
     c->width = c->height = 0;
     c->ncalls = 0;
@@ -445,6 +460,7 @@ static int configure_pools(vp8hip_ctx *c, int width, int height, int num_fb, int
     HIPCHK(c, hipMalloc((void **)&c->fb_block, fbsz * num_fb));
     HIPCHK(c, hipMemsetAsync(c->fb_block, 0, fbsz * num_fb, c->stream));
     for (int i = 0; i < num_fb; i++) c->fb.push_back(c->fb_block + fbsz * i);
+    c->fb_detile_gen.assign((size_t)num_fb, 0u); c->detile_gen = c->detile_joined = 0;
     c->fb_stride = fbsz;
     if (c->stream_d2h) HIPCHK(c, hipStreamSynchronize(c->stream_d2h));
     c->d2h_count = 0;
@@ -625,6 +641,7 @@ static int join_detile(vp8hip_ctx *c)
         HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_detile_done[c->last_par], 0));
         c->detile_pending = false;
     }
+    c->detile_joined = c->detile_gen;
     return 0;
 }
 extern "C" int vp8hip_join(vp8hip_ctx *c)
@@ -682,12 +699,17 @@ extern "C" int vp8hip_decode(vp8hip_ctx *c, const vp8hip_job *jobs, int njobs, i
     // Large launches with inter frames: the wave-per-row recon (inter prediction is its business) writes the tiled scratch
     // frames too, and the loop filter is the lane-per-row one, at half the time per frame of the wave-per-row filter once the
     // launch fills the chip
+    // ... or, larger still, the key frames' way: all inter predictions first, then residual + loop filter in one pass
+    bool inter_fused = (stages & VP8HIP_STAGE_RECON) && (stages & VP8HIP_STAGE_LF) && !all_key && K.fused
+                       && (K.inter_fused < 0 ? njobs > 2 * c->num_cu : K.inter_fused > 0 && njobs >= K.inter_fused);
+    if (K.recon_force)
+        inter_fused = (stages & VP8HIP_STAGE_RECON) && (stages & VP8HIP_STAGE_LF) && !all_key && K.fused && K.recon_force == 1;
     const bool inter_tiled = (stages & VP8HIP_STAGE_RECON) && (stages & VP8HIP_STAGE_LF) && !all_key && K.inter_tiled > 0
-                             && njobs >= K.inter_tiled;
+                             && njobs >= K.inter_tiled && !inter_fused;
     // the lane-per-row kernels work on macroblock-tiled scratch frames; vp8_detile_kernel converts at the end
-    const bool tiled = simt_recon || inter_tiled;
-    // key frames only, both stages wanted: one kernel reconstructs and filters, and writes the raster frame buffers itself
-    const bool fused = simt_recon && (stages & VP8HIP_STAGE_LF) && K.fused;
+    const bool tiled = simt_recon || inter_tiled || inter_fused;
+    // both stages wanted: one kernel reconstructs and filters, and writes the raster frame buffers itself
+    const bool fused = (simt_recon && (stages & VP8HIP_STAGE_LF) && K.fused) || inter_fused;
     // When the loop filter runs at all (some frame of the launch has filter_level != 0), it writes its finished lines
     // straight into the raster frame buffers -- unfiltered frames are carried through with the filter gated off -- (rows of two neighbouring macroblocks back to back: 32-byte pieces) and the tiled -> raster
     // pass is skipped; only the border extension is left.  +6..10 % from 1536 frames per launch up (1080p), a tie at 2048,
@@ -700,9 +722,18 @@ extern "C" int vp8hip_decode(vp8hip_ctx *c, const vp8hip_job *jobs, int njobs, i
     // unfiltered line per tile behind them (vp8_keyframe_simt.hip)
     const size_t tile_frame = align_up((size_t)c->dg.mb_rows * (c->dg.mb_cols + 1) * (VP8_TILE_BYTES + 32), 256);
     const int par = c->parity;
-    if (!tiled || lf_raster || !all_key) {
+    bool reads_pending = false;
+    if (!all_key)
+        for (int i = 0; i < njobs && !reads_pending; i++) {
+            if (jobs[i].ir_slot < 0 || jobs[i].ir_slot >= nsl || c->slots[jobs[i].ir_slot].hdr_copy.frame_type == 0) continue;
+            for (int k = 1; k < 4; k++) {
+                const int f = jobs[i].ref_fb[k];
+                if (f >= 0 && f < nfb && c->fb_detile_gen[f] > c->detile_joined) reads_pending = true;
+            }
+        }
+    if (!tiled || lf_raster || reads_pending) {
         // this launch touches the raster frame buffers directly: it writes them, or (inter frames) reads reference frames a
-        // tiled -> raster pass of an earlier launch may still be producing
+        // tiled -> raster pass of an earlier launch is still to produce
         if (join_detile(c)) return -1;
     }
     if (tiled) {
@@ -866,7 +897,7 @@ extern "C" int vp8hip_decode(vp8hip_ctx *c, const vp8hip_job *jobs, int njobs, i
         if (K.simt_waves >= 1) maxw = K.simt_waves;
         if (simt_waves > maxw) simt_waves = maxw;
     }
-    if (tiled) { c->stats.workgroups = simt_waves; c->stats.recon_waves = simt_recon ? 1 : c->recon_nw; c->stats.lf_waves = 1; }
+    if (tiled) { c->stats.workgroups = simt_waves; c->stats.recon_waves = simt_recon || inter_fused ? 1 : c->recon_nw; c->stats.lf_waves = 1; }
     c->stats.detile_pass = tiled && !lf_raster;
     if (stages & VP8HIP_STAGE_RECON) {
         if (fused) {
@@ -876,6 +907,23 @@ extern "C" int vp8hip_decode(vp8hip_ctx *c, const vp8hip_job *jobs, int njobs, i
                 HIPCHK(c, hipMemsetAsync(c->d_sched, 0, sizeof(unsigned int) * VP8HIP_SCHED_WORDS, c->stream));
             }
             HIPCHK(c, hipMemsetAsync(c->d_sched, 0, 2 * sizeof(unsigned int), c->stream));
+            if (inter_fused) {
+                // the inter macroblocks' predictions into their tiles: a wave per 64 macroblocks, at most 8 waves per SIMD's worth
+                const int upf = (c->nmb + 63) / 64;
+                long pgrid = ((long)njobs * upf + 3) / 4;
+                if (pgrid > (long)c->num_cu * 8) pgrid = (long)c->num_cu * 8;
+                hipLaunchKernelGGL(vp8_inter_pred_kernel, dim3((unsigned)pgrid), dim3(256), 0, c->stream, (const DevJob *)c->d_jobs, njobs,
+                                   c->dg, upf);
+                // the previous launch's tiled -> raster pass, if it was held back: beside vp8_interframe_kernel, which is bound by
+                // arithmetic, not beside the prediction kernel, which is bound by memory bandwidth as the pass is
+                if (c->deferred.valid) {
+                    HIPCHK(c, hipEventRecord(c->ev_recon_done, c->stream));
+                    if (launch_deferred(c, c->ev_recon_done)) return -1;
+                }
+                hipLaunchKernelGGL(vp8_interframe_kernel, dim3(2 * simt_waves), dim3(64), 0, c->stream, (const DevJob *)c->d_jobs, njobs,
+                                   c->dg, lgG, simtP, simt_waves * spw, c->tile_block[par] + tile_frame * njobs + 4096,
+                                   c->d_sched, simt_waves);
+            } else
             hipLaunchKernelGGL(vp8_keyframe_kernel, dim3(2 * simt_waves), dim3(64), 0, c->stream, (const DevJob *)c->d_jobs, njobs,
                                c->dg, lgG, simtP, simt_waves * spw, c->tile_block[par] + tile_frame * njobs + 4096,
                                c->d_sched, simt_waves);
@@ -980,8 +1028,8 @@ extern "C" int vp8hip_decode(vp8hip_ctx *c, const vp8hip_job *jobs, int njobs, i
         // deferred by default: the pass is launched with the NEXT lane-per-row launch, right after its recon, so
         // that it runs beside that launch's loop filter (which it disturbs less than the recon), or at the next join
         // (the key-frame kernel's pass goes out at once: its waves are small enough -- 16 registers -- to run in the gaps the next
-        // launch's kernel leaves on every SIMD)
-        const bool defer = own_stream && K.detile_defer && !fused;
+        // launch's kernel leaves on every SIMD; after a launch with inter frames it waits for the next launch's prediction kernel)
+        const bool defer = own_stream && K.detile_defer && (!fused || inter_fused);
         hipStream_t ds = own_stream ? c->stream2 : c->stream;
         if (defer) {
             c->deferred.valid = true; c->deferred.kf = fused; c->deferred.jobs = c->d_jobs; c->deferred.njobs = njobs;
@@ -997,6 +1045,8 @@ extern "C" int vp8hip_decode(vp8hip_ctx *c, const vp8hip_job *jobs, int njobs, i
         HIPCHK(c, hipEventRecord(c->ev_detile_done[par], ds));
         }
         c->detile_used[par] = true; c->detile_pending = true; c->last_par = par; c->parity = (par + 1) % VP8HIP_NBUF;
+        ++c->detile_gen;
+        for (int i = 0; i < njobs; i++) c->fb_detile_gen[jobs[i].dst_fb] = c->detile_gen;
     } else if (stages & VP8HIP_STAGE_EXTEND) {
         int bx = (c->geom.aligned_h + 64) / 4;
         if (bx < 1) bx = 1;
