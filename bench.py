@@ -159,6 +159,19 @@ def inter_frame_probe(P, device, n=4096, name="p_dense_1920x1080", k=2):
     ctx.sync()
     dt = (time.perf_counter() - t0) / reps
     st = ctx.stats()
+    # the same launches CHAINED: every launch predicts from the frames the launch before it wrote (n streams in lock step, as a
+    # decoder runs them), so nothing of a launch -- its tiled -> raster pass neither -- can run beside the next one
+    back = (P.Job * n)()
+    for i in range(n):
+        back[i].ir_slot, back[i].dst_fb = 2 + i, 4 + 2 * i
+        back[i].ref_fb[1], back[i].ref_fb[2], back[i].ref_fb[3] = 5 + 2 * i, r.gld_idx, r.alt_idx
+    ctx.decode_array(back, n, P.STAGE_ALL); ctx.decode_array(jobs, n, P.STAGE_ALL); ctx.sync()
+    t0 = time.perf_counter()
+    for _ in range(2):
+        ctx.decode_array(back, n, P.STAGE_ALL)
+        ctx.decode_array(jobs, n, P.STAGE_ALL)
+    ctx.sync()
+    dt_chained = (time.perf_counter() - t0) / 4
     nmb = ctx.nmb
     parser.close()
     ctx.close()
@@ -167,8 +180,14 @@ def inter_frame_probe(P, device, n=4096, name="p_dense_1920x1080", k=2):
                         f"launch, each with its own IR slot, reference buffer and destination",
             "md5_ok": bool(ok),
             "Mpix_s": round(n * w * h / dt / 1e6, 1), "ms_per_launch": round(dt * 1e3, 3),
+            "chained": {"ms_per_launch": round(dt_chained * 1e3, 3), "Mpix_s": round(n * w * h / dt_chained / 1e6, 1),
+                        "note": "every launch reads the frames the previous launch wrote"},
             "kernel_ms": {"recon": round(st.recon_ms, 3), "loopfilter": round(st.lf_ms, 3), "extend": round(st.extend_ms, 3)},
-            "kernel_family": ("wave-per-row recon into the tiled scratch frames, lane-per-row loop filter (luma + chroma kernels)"
+            "kernel_family": ("vp8_inter_pred_kernel (every inter macroblock's six-tap prediction, order-free, into the macroblock's tile) + "
+                              "vp8_interframe_kernel (residual + loop filter, one macroblock row per lane, luma and chroma waves paired "
+                              "on every SIMD: kernel_ms.recon is both) + vp8_detile_kf_kernel / vp8_extend_kernel beside the next launch"
+                              if st.fused else
+                              "wave-per-row recon into the tiled scratch frames, lane-per-row loop filter (luma + chroma kernels)"
                               if st.lf_waves == 1 else "one wave per macroblock row"),
             "roofline": {"bound": "hbm", "achieved": round(gbps, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(gbps / HBM_PEAK_GBPS, 5),

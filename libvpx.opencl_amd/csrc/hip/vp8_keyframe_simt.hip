@@ -191,6 +191,10 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
     u32x4 nx_bm = { 0, 0, 0, 0 };
     bool p_more = false;
 
+    // inter macroblocks: the part of the prediction (vp8_inter_pred_kernel left it in the macroblock's tile) the lane consumes next
+    // -- luma: a block row, rows at 16 y; chroma: a plane, rows (0,1) (2,3) (4,5) (6,7) --, requested behind the row stores of the
+    // part before it (for a macroblock's first part: of the macroblock before it), so that it arrives during the transform
+    u32x4 pr[4] = { { 0, 0, 0, 0 }, { 0, 0, 0, 0 }, { 0, 0, 0, 0 }, { 0, 0, 0, 0 } };
     STAMP_DECL
     int q_n = 0;                                                     // blocks queued (wave-uniform)
     // The owner requests the coefficients of the blocks cfb[0..3] of its macroblock that have any (`m4`) into ITS OWN four staging
@@ -524,11 +528,8 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
             // where the rows above the current block row go: first the bottom rows of the macroblock above, then this one's window
             g_u8p prow = KF_ACT(act && !top) ? tpc - rowbytes + KT_Y_BOT : (g_u8p)dummy;
             int pstride = KF_ACT(act && !top) ? 16 : 0;
-            // inter macroblocks: the prediction vp8_inter_pred_kernel left in the macroblock's tile (luma row y at 16 y), a block row at
-            // a time; the next block row's is requested behind this one's row stores and arrives during the transform
-            u32x4 pr[4] = { { 0, 0, 0, 0 }, { 0, 0, 0, 0 }, { 0, 0, 0, 0 }, { 0, 0, 0, 0 } };
             if constexpr (INTER) {
-                if (is_inter) {
+                if (is_inter && late) {          // first macroblock of a row: nobody asked ahead
 #pragma unroll
                     for (int j = 0; j < 4; j++) pr[j] = *(g_cu32x4p)(tpc + 16 * j);
                 }
@@ -629,9 +630,11 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
                 prow = KF_ACT(act) ? (first ? tpc + KT_Y_WIN : prow + 64) : (g_u8p)dummy;
                 pstride = KF_ACT(act) ? 16 : 0;
                 if constexpr (INTER) {
-                    if (is_inter && by < 3) {
+                    const bool nx_inter = more && ((nx_w0 >> 16) & 3) != VP8IR_INTRA_FRAME;        // (by == 3: nx_w0 is the next macroblock's)
+                    if (by < 3 ? is_inter : nx_inter) {
+                        const g_u8p pp = by < 3 ? tpc + 64 * (by + 1) : tpc + VP8_TILE_BYTES;
 #pragma unroll
-                        for (int j = 0; j < 4; j++) pr[j] = *(g_cu32x4p)(tpc + 64 * (by + 1) + 16 * j);
+                        for (int j = 0; j < 4; j++) pr[j] = *(g_cu32x4p)(pp + 16 * j);
                     }
                 }
                 STAMP(10)
@@ -675,11 +678,8 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
             int tlA = top ? 127 : (c == 0 ? 129 : prevLast), tlB = top ? 127 : (c == 0 ? 129 : prevLast2);
             const int lastU = aA[1] >> 24, lastV = aA[3] >> 24;
             u32 bA[2] = { 0, 0 }, bB[2] = { 0, 0 };           // unfiltered bottom lines of the two planes
-            // inter macroblocks: the plane's prediction out of the macroblock's tile, rows (0,1) (2,3) (4,5) (6,7); V's is requested
-            // behind U's row stores
-            u32x4 pr[4] = { { 0, 0, 0, 0 }, { 0, 0, 0, 0 }, { 0, 0, 0, 0 }, { 0, 0, 0, 0 } };
             if constexpr (INTER) {
-                if (is_inter) {
+                if (is_inter && late) {
                     pr[0] = *(g_cu32x4p)(tpc + 256); pr[1] = *(g_cu32x4p)(tpc + 272);
                     pr[2] = *(g_cu32x4p)(tpc + 320); pr[3] = *(g_cu32x4p)(tpc + 336);
                 }
@@ -793,9 +793,11 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
                     }
                 }
                 if constexpr (INTER) {
-                    if (is_inter && pl == 0) {
-                        pr[0] = *(g_cu32x4p)(tpc + 288); pr[1] = *(g_cu32x4p)(tpc + 304);
-                        pr[2] = *(g_cu32x4p)(tpc + 352); pr[3] = *(g_cu32x4p)(tpc + 368);
+                    const bool nx_inter = more && ((nx_w0 >> 16) & 3) != VP8IR_INTRA_FRAME;        // (pl == 1: nx_w0 is the next macroblock's)
+                    if (pl == 0 ? is_inter : nx_inter) {
+                        const g_u8p pp = pl == 0 ? tpc + 288 : tpc + VP8_TILE_BYTES + 256;
+                        pr[0] = *(g_cu32x4p)pp; pr[1] = *(g_cu32x4p)(pp + 16);
+                        pr[2] = *(g_cu32x4p)(pp + 64); pr[3] = *(g_cu32x4p)(pp + 80);
                     }
                 }
                 // ---- the other plane's residuals (or the next macroblock's first): the eight row stores above are younger

@@ -1,6 +1,6 @@
 """GPU: launches with inter frames at the sizes where vp8hip_decode changes its kernels by itself (no knobs set): up to 384
-frames -- inter macroblocks by vp8_inter_mb_kernel first --, 385..639 -- the row-ordered kernels alone --, 640 and more -- through
-the macroblock-tiled scratch frames to the lane-per-row loop filter.  Real 1080p P frames (dense fixture), every job decoding
+frames -- inter macroblocks by vp8_inter_mb_kernel first --, 385..512 -- the row-ordered kernels alone --, more than two frames per
+CU -- all inter predictions by vp8_inter_pred_kernel, then residual + loop filter one macroblock row per lane.  Real 1080p P frames (dense fixture), every job decoding
 the same frame from the same references into its own buffer: all outputs equal the reference decoder's MD5 and each other,
 whole buffers (borders included) are the same on every path."""
 import numpy as np
@@ -55,7 +55,8 @@ def test_every_launch_size_regime_gives_the_reference_frame(decoded, monkeypatch
         for i in range(n):                                   # nothing left over from the previous launch
             ctx.upload_frame(4 + i, np.zeros(ctx.g.frame_size, np.uint8)) if i in (0, n // 2, n - 1) else None
         st = _launch(P, ctx, refs, n)
-        assert (st.lf_waves == 1) == lane_lf, (n, st.lf_waves)       # 640 and more: the lane-per-row loop filter ran
+        assert (st.lf_waves == 1) == lane_lf, (n, st.lf_waves)       # 640 and more: one macroblock row per lane ...
+        assert st.fused == int(lane_lf), (n, st.fused)               # ... prediction kernel + vp8_interframe_kernel
         for i in sorted({0, n // 2, n - 1}):
             assert P.planes_md5(*ctx.download_planes(4 + i)) == gold, (n, i)
         full = ctx.download_full(4 + n - 1)
@@ -101,6 +102,55 @@ def test_launches_chained_without_sync_wait_for_the_raster_pass(pkg, monkeypatch
         last_new = launches[-1][2]
         for i in range(n):
             assert P.planes_md5(*ctx.download_planes(4 * i + last_new)) == gold[2], (knobs, i)
+        parser.close()
+    finally:
+        ctx.close()
+
+
+def test_independent_launches_run_past_the_raster_pass_dependent_ones_wait(pkg, monkeypatch):
+    """Launches with inter frames by the prediction kernel + vp8_interframe_kernel (forced at this size), back to back without a
+    sync: frame 2 of eight streams into their decoder buffers, frame 2 AGAIN into spare buffers -- reads only frames decoded
+    long ago: the library lets it start while the first launch's tiled -> raster pass still runs --, then frame 3, which
+    predicts from what the first launch wrote and has to wait for that pass.  Everything equals the reference decoder's frames."""
+    P = pkg
+    for k in ("VP8HIP_FUSED", "VP8HIP_LF_RASTER", "VP8HIP_INTER_TILED", "VP8HIP_INTER_SPLIT", "VP8HIP_INTER_FUSED"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv("VP8HIP_RECON", "simt")
+    name, n = "p_dense_1920x1080", 8
+    w, h, frames = P.read_ivf(ivf_path(name))
+    gold = golden_md5(name)
+    ctx = P.Vp8Hip(0)
+    try:
+        ctx.configure(w, h, 5 * n, 4)
+        parser = P.Parser()
+        plan = []
+        for f in range(4):
+            hdr = ctx.parse_into_slot(parser, frames[f], f)
+            ctx.upload(f)
+            r = parser.refs
+            plan.append((f, hdr.frame_type, r.new_idx, (r.lst_idx, r.gld_idx, r.alt_idx)))
+            parser.swap(hdr)
+
+        def launch(f, spare=False):
+            _, ftype, new_idx, refs = plan[f]
+            jobs = (P.Job * n)()
+            for i in range(n):
+                jobs[i].ir_slot, jobs[i].dst_fb = f, (4 * n + i) if spare else 4 * i + new_idx
+                for q in range(3):
+                    jobs[i].ref_fb[1 + q] = 4 * i + refs[q] if ftype else -1
+            ctx.decode_array(jobs, n, P.STAGE_ALL)
+            return ctx.stats()
+
+        launch(0); launch(1)
+        ctx.sync()
+        assert launch(2).fused == 1
+        launch(2, spare=True)
+        launch(3)
+        ctx.sync()
+        for i in range(n):
+            assert P.planes_md5(*ctx.download_planes(4 * n + i)) == gold[2], i
+            assert P.planes_md5(*ctx.download_planes(4 * i + plan[3][2])) == gold[3], i
+            assert P.planes_md5(*ctx.download_planes(4 * i + plan[2][2])) == gold[2], i
         parser.close()
     finally:
         ctx.close()
