@@ -534,7 +534,7 @@ def main():
             try:
                 sys.path.insert(0, os.path.join(ROOT, "tools"))
                 import e2e
-                out["config"]["end_to_end"] = e2e.run(P, local_rank, fixture=fixture)
+                out["config"]["end_to_end"] = e2e.run(P, local_rank, fixture=fixture, nframes=2048)
             except Exception as ex:      # a probe, not the benchmark: report, do not fail the line
                 out["config"]["end_to_end"] = {"error": repr(ex)}
         if not args.no_cpu_baseline and world == 1:      # the contract: rank 0 at N = 1 only

@@ -142,6 +142,12 @@ int  vp8hip_postproc(vp8hip_ctx *ctx, int src_fb, int dst_fb, int tmp_fb, const 
 size_t vp8hip_frame_stride(const vp8hip_ctx *ctx);
 int  vp8hip_frames_download_async(vp8hip_ctx *ctx, int first_fb, int count, uint8_t *dst);
 int  vp8hip_download_wait(vp8hip_ctx *ctx);
+/* The same with the frames' MD5s computed on the device: what `vpxdec --md5` (vpxdec.c:1080-1101) and examples/decode_to_md5
+ * (decode_to_md5.txt) hash on the host -- the visible rows of the Y, U and V planes, vpx_image_t d_w x d_h -- one 16-byte digest
+ * per frame into digests[16 * i], a frame per lane (csrc/hip/vp8_md5.hip).  dst and digests may each be NULL (not both); both
+ * have landed when vp8hip_download_wait returns.  Display widths that are not a multiple of 128 are refused with -3 (rows have
+ * to be whole MD5 blocks): the caller hashes those frames on the host. */
+int  vp8hip_frames_fetch_async(vp8hip_ctx *ctx, int first_fb, int count, uint8_t *dst, uint8_t *digests);
 /* Upload a whole frame buffer (frame_size bytes) -- tests and VP8_SET_REFERENCE. */
 int  vp8hip_frame_upload(vp8hip_ctx *ctx, int fb, const uint8_t *buf);
 int  vp8hip_frame_copy(vp8hip_ctx *ctx, int dst_fb, int src_fb);

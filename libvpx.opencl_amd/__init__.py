@@ -396,6 +396,15 @@ class Vp8Hip:
                   "download")
         return y, u, v
 
+    def frames_md5(self, first_fb, count):
+        """MD5s of `count` consecutive frame buffers computed on the device (vp8hip_frames_fetch_async): list of hex digests."""
+        out = np.zeros(16 * count, np.uint8)
+        self.L.vp8hip_frames_fetch_async.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+        self.L.vp8hip_download_wait.argtypes = [ctypes.c_void_p]
+        self._chk(self.L.vp8hip_frames_fetch_async(self.h, first_fb, count, None, out.ctypes.data), "vp8hip_frames_fetch_async")
+        self._chk(self.L.vp8hip_download_wait(self.h), "vp8hip_download_wait")
+        return [out[16 * i: 16 * i + 16].tobytes().hex() for i in range(count)]
+
     def upload_frame(self, fb, buf):
         assert buf.nbytes == self.g.frame_size
         self._chk(self.L.vp8hip_frame_upload(self.h, fb, buf.ctypes.data), "upload")

@@ -28,6 +28,7 @@ extern "C" __global__ void vp8_keyframe_kernel(const DevJob *jobs, int njobs, De
 extern "C" __global__ void vp8_interframe_kernel(const DevJob *jobs, int njobs, DevGeom g, int lgG, int P, int nstrands, uint8_t *dummy,
                                                unsigned int *sched, int nwaves);
 extern "C" __global__ void vp8_inter_pred_kernel(const DevJob *jobs, int njobs, DevGeom g, int upf);
+extern "C" __global__ void vp8_md5_kernel(const uint8_t *frames, size_t fstride, int count, DevGeom g, int w, int h, uint8_t *out);
 #ifdef VP8_STAMPS
 #define VP8HIP_SCHED_WORDS (16 + 16384 + 4 * 4096)     // + the diagnostic builds' log: four words per wave
 #else
@@ -238,6 +239,7 @@ struct vp8hip_ctx {
     hipStream_t stream_d2h;
     hipEvent_t ev_d2h_from, ev_d2h_done;
     int d2h_first, d2h_count;      // frame buffers of the copy in flight (count 0: none)
+    uint8_t *d_md5; int md5_cap;   // vp8hip_frames_fetch_async: the batch's digests on the device
     size_t fb_stride;
     unsigned int *d_intra_flags; int intra_flags_cap;       // per job of a launch: the frame has intra macroblocks (vp8_inter_mb_kernel)
     hipStream_t stream3; hipEvent_t ev_split_from, ev_split_done;     // chroma half of the split lane-per-row loop filter
@@ -323,6 +325,7 @@ extern "C" int vp8hip_create(int device, vp8hip_ctx **out)
     for (int k = 0; k < VP8HIP_NBUF; k++) c->detile_used[k] = false;
     c->detile_pending = false; c->parity = 0; c->last_par = 0;
     c->detile_gen = c->detile_joined = 0;
+    c->d_md5 = nullptr; c->md5_cap = 0;
     c->deferred.valid = false;
     c->width = c->height = 0;
     c->ncalls = 0;
@@ -383,6 +386,7 @@ extern "C" void vp8hip_destroy(vp8hip_ctx *c)
     // the post-processing tables outlive reconfigurations: the caller's noise state does too (vp8/common/postproc.c keeps
     // postproc_state.noise across vp8_alloc_frame_buffers) and only sends the noise table again when q changes
     if (c->d_pp) (void)hipFree(c->d_pp);
+    if (c->d_md5) (void)hipFree(c->d_md5);
     if (c->h_pp) (void)hipHostFree(c->h_pp);
     if (c->ev_pp) (void)hipEventDestroy(c->ev_pp);
     if (c->d_pack) (void)hipFree(c->d_pack);
@@ -1198,10 +1202,12 @@ extern "C" int vp8hip_postproc(vp8hip_ctx *c, int src_fb, int dst_fb, int tmp_fb
 
 extern "C" size_t vp8hip_frame_stride(const vp8hip_ctx *c) { return c ? c->fb_stride : 0; }
 
-extern "C" int vp8hip_frames_download_async(vp8hip_ctx *c, int first_fb, int count, uint8_t *dst)
+extern "C" int vp8hip_frames_fetch_async(vp8hip_ctx *c, int first_fb, int count, uint8_t *dst, uint8_t *digests)
 {
-    if (!c || first_fb < 0 || count < 1 || first_fb + count > (int)c->fb.size() || !dst)
-        return fail(c, -2, "vp8hip_frames_download_async: bad arguments");
+    if (!c || first_fb < 0 || count < 1 || first_fb + count > (int)c->fb.size() || (!dst && !digests))
+        return fail(c, -2, "vp8hip_frames_fetch_async: bad arguments");
+    if (digests && (c->width & 127))
+        return fail(c, -3, "vp8hip_frames_fetch_async: digests on the device need a display width that is a multiple of 128 (%d)", c->width);
     HIPCHK(c, hipSetDevice(c->device));
     if (join_detile(c)) return -1;
     if (!c->stream_d2h) {
@@ -1212,10 +1218,30 @@ extern "C" int vp8hip_frames_download_async(vp8hip_ctx *c, int first_fb, int cou
     if (c->d2h_count) HIPCHK(c, hipEventSynchronize(c->ev_d2h_done));  // one copy in flight at a time
     HIPCHK(c, hipEventRecord(c->ev_d2h_from, c->stream));             // everything queued so far: the frames' kernels
     HIPCHK(c, hipStreamWaitEvent(c->stream_d2h, c->ev_d2h_from, 0));
-    HIPCHK(c, hipMemcpyAsync(dst, c->fb[first_fb], c->fb_stride * (size_t)count, hipMemcpyDeviceToHost, c->stream_d2h));
+    if (dst) HIPCHK(c, hipMemcpyAsync(dst, c->fb[first_fb], c->fb_stride * (size_t)count, hipMemcpyDeviceToHost, c->stream_d2h));
+    if (digests) {
+        if (c->md5_cap < count) {
+            HIPCHK(c, hipStreamSynchronize(c->stream_d2h));
+            if (c->d_md5) (void)hipFree(c->d_md5);
+            c->d_md5 = nullptr; c->md5_cap = 0;
+            HIPCHK(c, hipMalloc((void **)&c->d_md5, 16 * (size_t)(count < 64 ? 64 : count)));
+            c->md5_cap = count < 64 ? 64 : count;
+        }
+        // a frame per lane: the frames' hashes run side by side, behind the copy of the frames themselves (if asked for)
+        hipLaunchKernelGGL(vp8_md5_kernel, dim3((unsigned)((count + 63) / 64)), dim3(64), 0, c->stream_d2h, (const uint8_t *)c->fb[first_fb],
+                           c->fb_stride, count, c->dg, c->width, c->height, c->d_md5);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipMemcpyAsync(digests, c->d_md5, 16 * (size_t)count, hipMemcpyDeviceToHost, c->stream_d2h));
+    }
     HIPCHK(c, hipEventRecord(c->ev_d2h_done, c->stream_d2h));
     c->d2h_first = first_fb; c->d2h_count = count;
     return 0;
+}
+
+extern "C" int vp8hip_frames_download_async(vp8hip_ctx *c, int first_fb, int count, uint8_t *dst)
+{
+    if (!dst) return fail(c, -2, "vp8hip_frames_download_async: bad arguments");
+    return vp8hip_frames_fetch_async(c, first_fb, count, dst, nullptr);
 }
 
 extern "C" int vp8hip_download_wait(vp8hip_ctx *c)

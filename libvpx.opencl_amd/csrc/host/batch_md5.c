@@ -1,4 +1,4 @@
-/* batch_md5 [--threads T] [--batch B] [--loop N] <in.ivf> <out.md5>
+/* batch_md5 [--threads T] [--batch B] [--loop N] [--host-md5] <in.ivf> <out.md5>
  *
  * decode_to_md5 for streams of independently decodable frames (all key frames), at the rate the host can feed the
  * GPU: SURVEY.md 8(f)1.  The output file has decode_to_md5's lines ("<md5>  img-<w>x<h>-<%04d>.i420", one per frame,
@@ -88,6 +88,9 @@ static struct { vp8ir_frame_hdr *hdr; vp8ir_mb *mbs; int16_t *blocks, *dcs; size
 static uint8_t *g_host[2];                          /* 2 x batch pinned frame buffers: one being filled by the GPU, one being hashed */
 static size_t g_stride;                             /* bytes from one frame buffer to the next */
 static unsigned char (*g_digest)[16];               /* one per frame of the whole run */
+static uint8_t *g_dig[2];                           /* the digests of a batch as the device computed them (pinned), beside g_host[] */
+static int g_dev_md5;                               /* hash on the device (vp8hip_frames_fetch_async: widths that are multiples of 128),
+                                                       the feeder keeps the host's cores */
 static volatile int g_failed;
 
 typedef struct batch_ref { int b, n; long first; } batch_ref;     /* batch number, frames in it, index of its first frame */
@@ -126,6 +129,7 @@ static void hash_one(void *arg, int i, int worker)
     }
     md5_final(&md5, g_digest[br->first + i]);
 }
+static void take_digests(const batch_ref *br) { memcpy(g_digest[br->first], g_dig[br->b & 1], 16 * (size_t)br->n); }
 
 static double now_s(void)
 {
@@ -139,16 +143,17 @@ static double now_s(void)
 
 int main(int argc, char **argv)
 {
-    int threads = 0, loop = 1, a = 1;
+    int threads = 0, loop = 1, a = 1, host_md5 = 0;
     g_batch = 128;
     for (; a < argc && argv[a][0] == '-' && argv[a][1] == '-'; a++) {
         if (!strcmp(argv[a], "--threads") && a + 1 < argc) threads = atoi(argv[++a]);
+        else if (!strcmp(argv[a], "--host-md5")) host_md5 = 1;          /* hash on the host whatever the frame size */
         else if (!strcmp(argv[a], "--batch") && a + 1 < argc) g_batch = atoi(argv[++a]);
         else if (!strcmp(argv[a], "--loop") && a + 1 < argc) loop = atoi(argv[++a]);
-        else DIE("Usage: %s [--threads T] [--batch B] [--loop N] <in.ivf> <out.md5>", argv[0]);
+        else DIE("Usage: %s [--threads T] [--batch B] [--loop N] [--host-md5] <in.ivf> <out.md5>", argv[0]);
     }
     if (argc - a != 2 || g_batch < 1 || loop < 1)
-        DIE("Usage: %s [--threads T] [--batch B] [--loop N] <in.ivf> <out.md5>", argv[0]);
+        DIE("Usage: %s [--threads T] [--batch B] [--loop N] [--host-md5] <in.ivf> <out.md5>", argv[0]);
     if (threads < 1) {
         long n = sysconf(_SC_NPROCESSORS_ONLN);
         threads = n > 33 ? 32 : (n > 2 ? (int)n - 1 : 1);      /* more than ~32 feeders gain nothing: the host memory system is the limit */
@@ -185,9 +190,12 @@ int main(int argc, char **argv)
     for (int s = 0; s < 3 * g_batch; s++)
         HIP(vp8hip_ir_map_sparse(g_hip, s, &g_maps[s].hdr, &g_maps[s].mbs, &g_maps[s].blocks, &g_maps[s].cap, &g_maps[s].dcs, &g_maps[s].mvs));
     g_stride = vp8hip_frame_stride(g_hip);
-    for (int k = 0; k < 2; k++)
+    for (int k = 0; k < 2; k++) {
         if (!(g_host[k] = (uint8_t *)vp8hip_host_alloc(g_hip, (size_t)g_batch * g_stride))) DIE("vp8hip_host_alloc: %s", vp8hip_last_error(g_hip));
+        if (!(g_dig[k] = (uint8_t *)vp8hip_host_alloc(g_hip, (size_t)g_batch * 16))) DIE("vp8hip_host_alloc: %s", vp8hip_last_error(g_hip));
+    }
     g_digest = calloc((size_t)total, 16);
+    g_dev_md5 = !host_md5 && g_width % 128 == 0;
     g_parsers = calloc((size_t)threads, sizeof *g_parsers);
     pthread_t *tid = calloc((size_t)threads, sizeof *tid);
     for (int t = 0; t < threads; t++) {
@@ -223,18 +231,24 @@ int main(int argc, char **argv)
         HIP(vp8hip_decode(g_hip, jobs, now.n, VP8HIP_STAGE_ALL));
         if (prev.b >= 0) {
             HIP(vp8hip_download_wait(g_hip));                               /* batch b-1 is in host set (b-1)&1 */
-            if (hashing.b >= 0) task_wait(&hash_t, 1);                      /* batch b-2 hashed: host set b&1 is free again */
-            hashing = prev;
-            task_start(&hash_t, 1, hash_one, &hashing, hashing.n);
+            if (g_dev_md5) take_digests(&prev);
+            else {
+                if (hashing.b >= 0) task_wait(&hash_t, 1);                  /* batch b-2 hashed: host set b&1 is free again */
+                hashing = prev;
+                task_start(&hash_t, 1, hash_one, &hashing, hashing.n);
+            }
         }
-        HIP(vp8hip_frames_download_async(g_hip, (now.b % 3) * g_batch, now.n, g_host[now.b & 1]));
+        HIP(vp8hip_frames_fetch_async(g_hip, (now.b % 3) * g_batch, now.n, g_host[now.b & 1], g_dev_md5 ? g_dig[now.b & 1] : NULL));
         prev = now;
     }
     HIP(vp8hip_download_wait(g_hip));
-    if (hashing.b >= 0) task_wait(&hash_t, 1);
-    hashing = prev;
-    task_start(&hash_t, 1, hash_one, &hashing, hashing.n);
-    task_wait(&hash_t, 1);
+    if (g_dev_md5) take_digests(&prev);
+    else {
+        if (hashing.b >= 0) task_wait(&hash_t, 1);
+        hashing = prev;
+        task_start(&hash_t, 1, hash_one, &hashing, hashing.n);
+        task_wait(&hash_t, 1);
+    }
     const double dt = now_s() - t0;
 
     /* ---- the listing */
@@ -245,8 +259,8 @@ int main(int argc, char **argv)
         fprintf(out, "  img-%dx%d-%04ld.i420\n", g_width, g_height, f + 1);
     }
     fclose(out);
-    fprintf(stderr, "%ld frames in %.3f s: %.1f frames/s, %.1f Mpix/s (%d feeder threads, %d frames per launch)\n", total, dt,
-            total / dt, total / dt * g_width * g_height / 1e6, threads, g_batch);
+    fprintf(stderr, "%ld frames in %.3f s: %.1f frames/s, %.1f Mpix/s (%d feeder threads, %d frames per launch, MD5 on the %s)\n", total, dt,
+            total / dt, total / dt * g_width * g_height / 1e6, threads, g_batch, g_dev_md5 ? "device" : "host");
 
     pthread_mutex_lock(&pool.mu);
     pool.stop = 1;
@@ -255,6 +269,8 @@ int main(int argc, char **argv)
     for (int t = 0; t < threads; t++) { pthread_join(tid[t], NULL); vp8_parser_destroy(g_parsers[t]); }
     vp8hip_host_free(g_hip, g_host[0]);
     vp8hip_host_free(g_hip, g_host[1]);
+    vp8hip_host_free(g_hip, g_dig[0]);
+    vp8hip_host_free(g_hip, g_dig[1]);
     vp8hip_destroy(g_hip);
     return EXIT_SUCCESS;
 }

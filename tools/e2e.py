@@ -8,7 +8,7 @@ launches the pixel path, and while the next batch is being parsed downloads the 
 pool hashes.  Everything the kernel-only number leaves out is in here: entropy decode, H2D of the dense IR
 (3.3 B/px), D2H of the visible planes (1.5 B/px), MD5.
 
-    python tools/e2e.py [frames] [batch] [threads]
+    python tools/e2e.py [frames] [batch] [threads] [MD5 on the device: 1 / 0]
 """
 import hashlib
 import os
@@ -20,12 +20,12 @@ ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
-def run(P, device=0, fixture="kf_1920x1080", nframes=1024, batch=128, threads=None):
+def run(P, device=0, fixture="kf_1920x1080", nframes=1024, batch=128, threads=None, device_md5=None):
     from vp8_testlib import ivf_path, golden_md5
     w, h, frames = P.read_ivf(ivf_path(fixture))
     gold = golden_md5(fixture)
     nsrc = len(frames)
-    threads = threads or max(1, min(64, (os.cpu_count() or 2) - 1))
+    threads = threads or max(1, min(32, (os.cpu_count() or 2) - 1))      # (more than 32 feeders gain nothing, 64 lose: the box runs under a 16-CPU quota)
     nbatch = (nframes + batch - 1) // batch
     ctx = P.Vp8Hip(device)
     # three sets of slots and frame buffers: batch k+1 is parsed while k is decoded and k-1 is downloaded and hashed
@@ -63,11 +63,17 @@ def run(P, device=0, fixture="kf_1920x1080", nframes=1024, batch=128, threads=No
     L = ctx.L
     L.vp8hip_frame_stride.restype = ctypes.c_size_t
     L.vp8hip_frame_stride.argtypes = [c_void_p]
-    L.vp8hip_frames_download_async.argtypes = [c_void_p, ctypes.c_int, ctypes.c_int, c_void_p]
+    L.vp8hip_frames_fetch_async.argtypes = [c_void_p, ctypes.c_int, ctypes.c_int, c_void_p, c_void_p]
     L.vp8hip_download_wait.argtypes = [c_void_p]
     stride = L.vp8hip_frame_stride(ctx.h)
     pinned = torch.empty((2, batch, stride), dtype=torch.uint8, pin_memory=True)
     host = pinned.numpy()
+    # the digests come with the frames, computed on the device (a frame per lane, vp8_md5.hip), where a row is a whole number of
+    # MD5 blocks; the host's cores are the feeder's then
+    if device_md5 is None:
+        device_md5 = w % 128 == 0
+    pinned_dig = torch.zeros((2, batch, 16), dtype=torch.uint8, pin_memory=True)
+    dig = pinned_dig.numpy()
 
     def md5_frame(k, i):
         return P.frame_md5(host[k, i], ctx.g, w, h)
@@ -103,10 +109,15 @@ def run(P, device=0, fixture="kf_1920x1080", nframes=1024, batch=128, threads=No
 
     def arrived(b, n):
         """Batch b's copy has landed in host set b & 1: hash it (after the digests of batch b-1... of the set's previous user are in)."""
-        nonlocal hashing
+        nonlocal hashing, bad
         ctx._chk(L.vp8hip_download_wait(ctx.h), "vp8hip_download_wait")
         collect()
-        hashing = (b, [hpool.submit(md5_frame, b & 1, i) for i in range(n)])
+        if device_md5:
+            for i in range(n):
+                if dig[b & 1, i].tobytes().hex() != gold[(b * batch + i) % nsrc]:
+                    bad += 1
+        else:
+            hashing = (b, [hpool.submit(md5_frame, b & 1, i) for i in range(n)])
 
     t0 = time.perf_counter()
     pending = submit_parse(0)
@@ -125,7 +136,8 @@ def run(P, device=0, fixture="kf_1920x1080", nframes=1024, batch=128, threads=No
         tc = time.perf_counter()
         if prev is not None:
             arrived(*prev)                             # (its copy ran beside this batch's uploads)
-        ctx._chk(L.vp8hip_frames_download_async(ctx.h, (b % 3) * batch, n, host[b & 1].ctypes.data), "vp8hip_frames_download_async")
+        ctx._chk(L.vp8hip_frames_fetch_async(ctx.h, (b % 3) * batch, n, host[b & 1].ctypes.data,
+                                             dig[b & 1].ctypes.data if device_md5 else None), "vp8hip_frames_fetch_async")
         prev = (b, n)
         td = time.perf_counter()
         t_parse += tb - ta; t_gpu += tc - tb; t_out += td - tc
@@ -139,7 +151,9 @@ def run(P, device=0, fixture="kf_1920x1080", nframes=1024, batch=128, threads=No
     ctx_nmb = ctx.nmb
     ctx.close()
     return {"workload": f"{fixture}.ivf looped to {nframes} key frames, compressed input in host memory -> per-frame MD5 "
-                        f"(entropy decode on {threads} host threads, H2D of the IR, pixel path, D2H, MD5)",
+                        f"(entropy decode on {threads} host threads, H2D of the IR, pixel path, D2H of the frames, MD5 "
+                        f"{'on the device, a frame per lane' if device_md5 else 'on the host'})",
+            "md5_on": "device" if device_md5 else "host",
             "Mpix_s": round(nframes * w * h / elapsed / 1e6, 1), "frames_per_s": round(nframes / elapsed, 1),
             "host_threads": threads, "frames": nframes, "frames_per_launch": batch, "md5_mismatches": bad,
             "h2d_bytes_per_pixel": round(h2d_bytes[0] / (nframes * w * h), 3),
@@ -152,6 +166,6 @@ if __name__ == "__main__":
     from vp8_testlib import load_package
     a = [int(x) for x in sys.argv[1:]]
     out = run(load_package(), 0, nframes=a[0] if a else 1024, batch=a[1] if len(a) > 1 else 128,
-              threads=a[2] if len(a) > 2 else None)
+              threads=a[2] if len(a) > 2 else None, device_md5=bool(a[3]) if len(a) > 3 else None)
     import json
     print(json.dumps(out))
