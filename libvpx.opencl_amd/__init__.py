@@ -151,6 +151,8 @@ def load_host():
         L.vp8_parser_create.restype = c_void_p
         L.vp8_parser_destroy.argtypes = [c_void_p]
         L.vp8_parser_set_threads.argtypes = [c_void_p, c_int]
+        L.vp8_parser_set_error_concealment.argtypes = [c_void_p, c_int]
+        L.vp8_parser_conceals.argtypes = [c_void_p]
         L.vp8_parser_begin_frame.argtypes = [c_void_p, ctypes.c_char_p, c_size_t, c_void_p]
         L.vp8_parser_decode_mbs.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
         L.vp8_parser_decode_mbs_sparse.argtypes = [c_void_p, c_void_p, c_void_p, c_size_t, ctypes.POINTER(c_size_t), c_void_p,
@@ -183,6 +185,10 @@ class Parser:
     def set_threads(self, n):
         """token partitions of a frame on up to n threads (vp8_parser_set_threads)"""
         self.L.vp8_parser_set_threads(self.p, n)
+
+    def set_error_concealment(self, on=True):
+        """before the first frame: conceal lost frames and lost residuals (vp8_parser_set_error_concealment)"""
+        self.L.vp8_parser_set_error_concealment(self.p, int(on))
 
     def begin(self, data):
         """-> (hdr, dims_changed).  Acquires refs.new_idx like the reference's get_free_fb."""

@@ -181,6 +181,8 @@ static vpx_codec_err_t vp8_decode(vpx_codec_alg_priv_t *p, const uint8_t *data, 
         p->parser = vp8_parser_create();
         if (!p->parser) return VPX_CODEC_MEM_ERROR;
         vp8_parser_set_threads(p->parser, (int)p->cfg.threads);   /* oxcf.max_threads = ctx->cfg.threads, vp8_dx_iface.c:413 */
+        /* oxcf.error_concealment (vp8_dx_iface.c:414-415) */
+        vp8_parser_set_error_concealment(p->parser, (p->base.init_flags & VPX_CODEC_USE_ERROR_CONCEALMENT) != 0);
         vp8_refs_init(&p->refs);
         p->decoder_init = 1;
         if (vp8hip_create(device, &p->hip)) {
@@ -207,10 +209,16 @@ static vpx_codec_err_t vp8_decode(vpx_codec_alg_priv_t *p, const uint8_t *data, 
         p->num_frags = data ? 1 : 0;
     }
     if (p->num_frags == 0 || (p->num_frags == 1 && p->frag_sz[0] == 0)) {
-        /* missing frame (onyxd_if.c:375-407): mark the last reference corrupt, nothing to show */
-        p->fb_corrupted[p->refs.lst_idx] = 1;
-        p->num_frags = 0;
-        return VPX_CODEC_OK;
+        if (!vp8_parser_conceals(p->parser) || !p->width) {
+            /* missing frame (onyxd_if.c:375-407): mark the last reference corrupt, nothing to show */
+            p->fb_corrupted[p->refs.lst_idx] = 1;
+            p->num_frags = 0;
+            return VPX_CODEC_OK;
+        }
+        /* with error concealment at work the lost frame is decoded: an inter frame out of estimated motion vectors */
+        p->frag[0] = NULL;
+        p->frag_sz[0] = 0;
+        p->num_frags = 1;
     }
     nfrags = p->num_frags;
     p->num_frags = 0;                                 /* whatever happens below, the next call starts a new frame */
@@ -444,7 +452,7 @@ static vpx_codec_ctrl_fn_map_t vp8_ctf_maps[] = {
 const struct vpx_codec_iface vpx_codec_vp8_dx_algo = {
     "MI355X HIP VP8 Decoder (gfx950) " "v1.0.0",
     VPX_CODEC_INTERNAL_ABI_VERSION,
-    VPX_CODEC_CAP_DECODER | VP8_CAP_POSTPROC | VPX_CODEC_CAP_INPUT_FRAGMENTS,
+    VPX_CODEC_CAP_DECODER | VP8_CAP_POSTPROC | VPX_CODEC_CAP_ERROR_CONCEALMENT | VPX_CODEC_CAP_INPUT_FRAGMENTS,
     vp8_init,
     vp8_destroy,
     vp8_ctf_maps,

@@ -42,6 +42,8 @@ typedef struct mbinfo {
     bslot   b[16];
 } mbinfo;
 
+#include "vp8_ec.h"              /* error concealment: motion vectors for macroblocks whose modes were lost */
+
 typedef struct entropy_ctx {     /* ENTROPY_CONTEXT_PLANES (blockd.h:44-50) */
     uint8_t y[4], u[2], v[2], y2;
 } entropy_ctx;
@@ -83,6 +85,18 @@ struct vp8_parser {
     entropy_ctx *above;
     int threads;                 /* vp8_parser_set_threads */
     int *progress;               /* per macroblock row, threaded token decode */
+
+    /* error concealment (a reference build with CONFIG_ERROR_CONCEALMENT, decoder created with oxcf.error_concealment) */
+    int ec_enabled;              /* vp8_parser_set_error_concealment */
+    int ec_active;               /* from the first inter frame after a complete key frame on (init_frame, decodframe.c:672-673) */
+    int corrupted;               /* xd->corrupted of the frame being decoded */
+    unsigned mvs_corrupt_from_mb;/* first macroblock whose modes the first partition no longer held (decodemv.c:639-655) */
+    int frame_corrupt_residual;  /* a macroblock of this frame has lost its residual already */
+    int independent_partitions, prev_independent;    /* decodframe.c:1036-1054, :1162-1166 */
+    uint8_t prev_version;        /* what a lost frame inherits: vp8_setup_version is not run for it */
+    int prev_log2n;              /* ... and the number of token partitions, when the bits that carry it are lost */
+    mbinfo *prev_alloc, *prev_mi;/* the frame before's mode info (pc->prev_mi; the two arrays change places after every frame) */
+    ec_block *overlaps;
     char err[96];
 };
 
@@ -118,6 +132,8 @@ void vp8_parser_destroy(vp8_parser *p)
 {
     if (!p) return;
     free(p->mi_alloc);
+    free(p->prev_alloc);
+    free(p->overlaps);
     free(p->above);
     free(p->progress);
     free(p);
@@ -147,11 +163,20 @@ static int resize(vp8_parser *p, int w, int h)
     int cols = (w + 15) >> 4, rows = (h + 15) >> 4;
     free(p->mi_alloc);
     free(p->above);
+    free(p->prev_alloc);
+    free(p->overlaps);
+    p->prev_alloc = NULL; p->prev_mi = NULL; p->overlaps = NULL;
     p->mi_alloc = (mbinfo *)calloc((size_t)(cols + 1) * (rows + 1), sizeof(mbinfo));
     p->above = (entropy_ctx *)calloc((size_t)cols, sizeof(entropy_ctx));
     if (!p->mi_alloc || !p->above) return -1;
     p->mi_stride = cols + 1;
     p->mi = p->mi_alloc + p->mi_stride + 1;
+    if (p->ec_enabled) {         /* vp8_alloc_frame_buffers (prev_mip, alloccommon.c) + vp8_alloc_overlap_lists (decodframe.c:793-802) */
+        p->prev_alloc = (mbinfo *)calloc((size_t)(cols + 1) * (rows + 1), sizeof(mbinfo));
+        p->overlaps = (ec_block *)calloc((size_t)cols * rows * 16, sizeof(ec_block));
+        if (!p->prev_alloc || !p->overlaps) return -1;
+        p->prev_mi = p->prev_alloc + p->mi_stride + 1;
+    }
     p->width = w;
     p->height = h;
     p->mb_cols = cols;
@@ -192,28 +217,43 @@ int vp8_parser_begin_frame_fragments(vp8_parser *p, const uint8_t *const *frags,
     vp8ir_frame_hdr *h = &p->hdr;
     vp8_boolreader *br = &p->first;
     /* the frame header and the first partition are read from the first fragment only (decodframe.c:695-697) */
-    const uint8_t *data = nfrags > 0 ? frags[0] : NULL;
-    const size_t size = nfrags > 0 ? frag_sizes[0] : 0;
+    static const uint8_t nothing[8] = { 0 };
+    const uint8_t *data = nfrags > 0 && frags[0] ? frags[0] : nothing;
+    const size_t size = nfrags > 0 && frags[0] ? frag_sizes[0] : 0;
     const uint8_t *end = data + size;
     const uint8_t *cur = data;
     size_t first_len;
-    int is_key, i, j;
+    int is_key, i, j, lost = 0;
+    /* error concealment is for whole buffers; with VPX_CODEC_USE_INPUT_FRAGMENTS the strict rules stay */
+#define EC_ON (p->ec_active && nfrags <= 1)
 
     p->frame_open = 0;
     p->err[0] = 0;
-    if (!data || size < 3)
-        return fail(p, VP8P_CORRUPT_FRAME, "Truncated packet");
-
-    /* 3-byte frame tag (decodframe.c:727-731) */
     memset(h, 0, sizeof *h);
+    if (size < 3) {
+        /* decodframe.c:709-724: a frame that never came is, with concealment, an inter frame whose every bit reads as zero and
+           whose motion vectors are estimated; everything vp8_setup_version derives stays as the frame before left it */
+        if (!EC_ON)
+            return fail(p, VP8P_CORRUPT_FRAME, "Truncated packet");
+        lost = 1;
+        is_key = 0;
+        h->frame_type = 1;
+        h->version = p->prev_version;
+        h->show_frame = 1;
+        first_len = 0;
+    } else {
+    /* 3-byte frame tag (decodframe.c:727-731) */
     is_key = !(cur[0] & 1);
     h->frame_type = (uint8_t)(cur[0] & 1);
     h->version = (cur[0] >> 1) & 7;
     h->show_frame = (cur[0] >> 4) & 1;
     first_len = (size_t)((cur[0] | (cur[1] << 8) | (cur[2] << 16)) >> 5);
     cur += 3;
+    /* (with concealment the reference goes on here and, the first partition being short, sets its token decoders up over
+       memory behind the buffer, decodframe.c:533-541: not followed -- an error with or without concealment) */
     if (first_len > (size_t)(end - (data)))   /* reference checks data + len against data_end */
         return fail(p, VP8P_CORRUPT_FRAME, "Truncated packet or corrupt partition 0 length");
+    }
 
     if (is_key) {
         int w, hgt;
@@ -240,6 +280,9 @@ int vp8_parser_begin_frame_fragments(vp8_parser *p, const uint8_t *const *frags,
     h->mb_rows = (uint16_t)p->mb_rows;
 
     /* init_frame (decodframe.c:605-687): key frames reset all adaptive state */
+    p->corrupted = 0;
+    p->prev_independent = p->independent_partitions;
+    if (!is_key && p->have_key_frame && p->ec_enabled) p->ec_active = 1;
     if (is_key) {
         memcpy(p->fc.mvc, vp8t_default_mv_context, sizeof p->fc.mvc);
         memcpy(p->fc.ymode, default_ymode_prob, 4);
@@ -309,8 +352,11 @@ int vp8_parser_begin_frame_fragments(vp8_parser *p, const uint8_t *const *frags,
        the last come from the table, every one is checked against the end of the fragment it lies in */
     {
         int log2n = vp8br_literal(br, 2);
-        int n = 1 << log2n, fi;
-        const uint8_t *sizes = data + 3 + (is_key ? 7 : 0) + first_len;
+        int n, fi, none = 0;
+        const uint8_t *sizes = lost ? data : data + 3 + (is_key ? 7 : 0) + first_len;
+        /* (decodframe.c:510-514: the count only changes when the bits that carry it were really there) */
+        if (!vp8br_error(br)) p->prev_log2n = log2n; else log2n = p->prev_log2n;
+        n = 1 << log2n;
         const uint8_t *F[10];
         size_t S[10];
         if (nfrags > 9)
@@ -318,13 +364,18 @@ int vp8_parser_begin_frame_fragments(vp8_parser *p, const uint8_t *const *frags,
         memset(F, 0, sizeof F);
         memset(S, 0, sizeof S);
         for (i = 0; i < nfrags; i++) { F[i] = frags[i]; S[i] = frag_sizes[i]; }
+        if (lost) { F[0] = data; S[0] = size; }
         for (fi = 0; fi < nfrags && fi <= n; fi++) {
             size_t left = S[fi];
             const uint8_t *fend = F[fi] + left;
             if (fi == 0) {
                 const size_t ext_first = (size_t)(sizes - F[0]) + (size_t)(3 * (n - 1));   /* first partition + the size table */
-                if (sizes > end || ext_first > left)
-                    return fail(p, VP8P_CORRUPT_FRAME, "Truncated partition size data");
+                if (sizes > end || ext_first > left) {
+                    if (!(EC_ON && lost))
+                        return fail(p, VP8P_CORRUPT_FRAME, "Truncated partition size data");
+                    none = 1;               /* a lost frame has no token partitions (every residual is thrown away anyway) */
+                    break;
+                }
                 left -= ext_first;
                 if (left > 0) {                 /* the fragment goes on with token partitions */
                     S[0] = ext_first;
@@ -337,12 +388,17 @@ int vp8_parser_begin_frame_fragments(vp8_parser *p, const uint8_t *const *frags,
                 const int k = fi - 1;
                 size_t len = (size_t)(fend - F[fi]);
                 if (k < n - 1) {
-                    if (!span_ok(sizes + 3 * k, 3, end))
+                    if (span_ok(sizes + 3 * k, 3, end))
+                        len = (size_t)(sizes[3 * k] | (sizes[3 * k + 1] << 8) | (sizes[3 * k + 2] << 16));
+                    else if (!EC_ON)
                         return fail(p, VP8P_CORRUPT_FRAME, "Truncated partition size data");
-                    len = (size_t)(sizes[3 * k] | (sizes[3 * k + 1] << 8) | (sizes[3 * k + 2] << 16));
                 }
-                if (!span_ok(F[fi], len, fend))
-                    return fail(p, VP8P_CORRUPT_FRAME, "Truncated packet or corrupt partition length");
+                if (!span_ok(F[fi], len, fend)) {
+                    /* with concealment a partition is what is left of it (read_available_partition_size, decodframe.c:456-497) */
+                    if (!EC_ON)
+                        return fail(p, VP8P_CORRUPT_FRAME, "Truncated packet or corrupt partition length");
+                    len = (size_t)(fend - F[fi]);
+                }
                 S[fi] = len;
                 left -= len;
                 if (left > 0) {
@@ -353,7 +409,10 @@ int vp8_parser_begin_frame_fragments(vp8_parser *p, const uint8_t *const *frags,
                 }
             }
         }
-        for (i = 0; i < n; i++) vp8br_init(&p->tok[i], F[i + 1], S[i + 1]);     /* (a partition that never came: empty, the frame turns out corrupt) */
+        for (i = 0; i < n; i++) {     /* (a partition that never came: empty, the frame turns out corrupt) */
+            if (none || !F[i + 1]) vp8br_init(&p->tok[i], nothing, 0);
+            else vp8br_init(&p->tok[i], F[i + 1], S[i + 1]);
+        }
         p->num_tok = n;
         h->num_token_partitions = (uint8_t)n;
     }
@@ -373,12 +432,22 @@ int vp8_parser_begin_frame_fragments(vp8_parser *p, const uint8_t *const *frags,
         h->copy_buffer_to_gf = 0;
         h->copy_buffer_to_arf = 0;
     } else {
+        /* with concealment, a flag whose bit was not there takes the harmless value (decodframe.c:951-992): no golden / alt-ref
+           refresh, no buffer copies */
         h->refresh_golden = (uint8_t)vp8br_bit(br);
+        if (p->ec_enabled) p->corrupted |= vp8br_error(br);
+        if (EC_ON && p->corrupted) h->refresh_golden = 0;
         h->refresh_alt = (uint8_t)vp8br_bit(br);
+        if (p->ec_enabled) p->corrupted |= vp8br_error(br);
+        if (EC_ON && p->corrupted) h->refresh_alt = 0;
         h->copy_buffer_to_gf = 0;
         if (!h->refresh_golden) h->copy_buffer_to_gf = (uint8_t)vp8br_literal(br, 2);
+        if (p->ec_enabled) p->corrupted |= vp8br_error(br);
+        if (EC_ON && p->corrupted) h->copy_buffer_to_gf = 0;
         h->copy_buffer_to_arf = 0;
         if (!h->refresh_alt) h->copy_buffer_to_arf = (uint8_t)vp8br_literal(br, 2);
+        if (p->ec_enabled) p->corrupted |= vp8br_error(br);
+        if (EC_ON && p->corrupted) h->copy_buffer_to_arf = 0;
         p->sign_bias[VP8IR_GOLDEN_FRAME] = vp8br_bit(br);
         p->sign_bias[VP8IR_ALTREF_FRAME] = vp8br_bit(br);
     }
@@ -386,16 +455,24 @@ int vp8_parser_begin_frame_fragments(vp8_parser *p, const uint8_t *const *frags,
     h->sign_bias_alt = (uint8_t)p->sign_bias[VP8IR_ALTREF_FRAME];
 
     p->restore_probs = !vp8br_bit(br);          /* refresh_entropy_probs == 0 */
+    if (p->ec_enabled) p->corrupted |= vp8br_error(br);
+    if (EC_ON && p->corrupted) p->restore_probs = 1;          /* (decodframe.c:998-1005) probabilities of a damaged frame do not stay */
     if (p->restore_probs)
         p->saved_fc = p->fc;
     h->refresh_last = (uint8_t)(is_key || vp8br_bit(br));
+    if (p->ec_enabled) p->corrupted |= vp8br_error(br);
+    if (EC_ON && p->corrupted) h->refresh_last = 1;           /* (:1013-1018) ... but the frame itself becomes the last frame */
 
-    /* coefficient probability updates (decodframe.c:1036-1054) */
+    /* coefficient probability updates (decodframe.c:1036-1054); the token partitions are independent of each other's contexts
+       when no probability depends on the context of the block before (what lets concealment keep the residual of intact partitions) */
     {
         uint8_t *cp = &p->fc.coef[0][0][0][0];
-        for (i = 0; i < 1056; i++)
+        p->independent_partitions = 1;
+        for (i = 0; i < 1056; i++) {
             if (vp8br_get(br, vp8t_coef_update_probs[i]))
                 cp[i] = (uint8_t)vp8br_literal(br, 8);
+            if ((i / 11) % 3 > 0 && cp[i] != cp[i - 11]) p->independent_partitions = 0;
+        }
     }
 
     p->mb_no_coeff_skip = vp8br_bit(br);
@@ -429,10 +506,14 @@ int vp8_parser_begin_frame_fragments(vp8_parser *p, const uint8_t *const *frags,
     memcpy(h->ref_lf_deltas, p->ref_lf_deltas, 4);
     memcpy(h->mode_lf_deltas, p->mode_lf_deltas, 4);
 
+    if (!lost) p->prev_version = h->version;
     *out = *h;
     p->frame_open = 1;
     return VP8P_OK;
+#undef EC_ON
 }
+
+int vp8_parser_conceals(const vp8_parser *p) { return p && p->ec_active; }
 
 /* ------------------------------------------------------------------------------------------
  * modes and motion vectors
@@ -731,6 +812,7 @@ static void read_modes(vp8_parser *p)           /* vp8_decode_mode_mvs, decodemv
     vp8_boolreader *br = &p->first;
     int is_key = p->hdr.frame_type == 0;
     int r, c;
+    p->mvs_corrupt_from_mb = ~0u;
     for (r = 0; r < p->mb_rows; r++) {
         mbinfo *m = p->mi + r * p->mi_stride;
         for (c = 0; c < p->mb_cols; c++, m++) {
@@ -748,6 +830,18 @@ static void read_modes(vp8_parser *p)           /* vp8_decode_mode_mvs, decodemv
                 read_kf_modes(p, m);
             else
                 read_inter_modes(p, m, r, c);
+            if (p->ec_enabled) {
+                /* a build with concealment keeps every inter macroblock's vector per block too (decodemv.c:538-557), and stops at
+                   the macroblock where the first partition ran out (:639-655): the modes from there on are the estimator's */
+                if (!is_key && m->ref_frame != VP8IR_INTRA_FRAME && m->y_mode != VP8IR_SPLITMV) {
+                    int k;
+                    for (k = 0; k < 16; k++) m->b[k].mv = m->mv;
+                }
+                if (vp8br_error(br)) {
+                    p->mvs_corrupt_from_mb = (unsigned)(r * p->mb_cols + c);
+                    return;
+                }
+            }
         }
     }
 }
@@ -902,7 +996,15 @@ static int decode_row(tok_job *j, tok_stream *out, int r, vp8_boolreader *br)
         size_t n = (size_t)r * p->mb_cols + c;
         vp8ir_mb *o = &j->mbs[n];
         entropy_ctx *A = &p->above[c];
-        int has_y2 = m->y_mode != VP8IR_B_PRED && m->y_mode != VP8IR_SPLITMV;
+        const unsigned mb_idx = (unsigned)n;
+        int has_y2;
+        if (p->ec_active && m->ref_frame == VP8IR_INTRA_FRAME && p->hdr.frame_type != 0
+            && ((!p->independent_partitions && p->frame_corrupt_residual) || vp8br_error(br)))
+            /* decode_mb_row, decodframe.c:365-392: an intra macroblock whose residual is lost is better predicted from the last
+               frame with vectors interpolated from its neighbours.  (The first macroblock to lose its residual finds out too
+               late for that, as there.  Key frames are not concealed this way here: their macroblocks stay intra.) */
+            ec_interpolate_motion(m, p->mi_stride, r, c, p->mb_rows, p->mb_cols);
+        has_y2 = m->y_mode != VP8IR_B_PRED && m->y_mode != VP8IR_SPLITMV;
         if (j->progress && r > 0 && (c & 3) == 0) {   /* the four macroblocks above have left their context in p->above[] */
             const int need = c + 4 < p->mb_cols ? c + 4 : p->mb_cols;
             int spins = 0;
@@ -930,6 +1032,14 @@ static int decode_row(tok_job *j, tok_stream *out, int r, vp8_boolreader *br)
             if (read_mb_tokens(p, br, m, A, &left, q, o->eobs) == 0) {
                 m->skip = 1;                 /* decodframe.c:129: eobtotal==0 forces skip */
                 memset(o->eobs, 0, 25);
+            } else if (p->ec_active && (mb_idx >= p->mvs_corrupt_from_mb || vp8br_error(br)
+                                        || (!p->independent_partitions && p->frame_corrupt_residual))) {
+                /* decode_macroblock, decodframe.c:158-187: with concealment, a macroblock whose modes were estimated, whose
+                   partition has just run out or -- unless the partitions are independent -- that follows one that lost its
+                   residual keeps the prediction alone; its skip flag stays what the tokens said */
+                memset(o->eobs, 0, 25);
+                if (coef) memset(q, 0, VP8IR_COEF_PER_MB * sizeof(int16_t));
+                else { o->sparse_first = (uint32_t)(out->first_block + out->nb); o->dc_first = (uint32_t)(out->first_dc + out->nd); }
             } else if (!coef) {              /* sparse streams: full blocks and lone DCs, in block order (vp8_ir.h) */
                 int k;
                 o->sparse_first = (uint32_t)(out->first_block + out->nb);
@@ -945,6 +1055,8 @@ static int decode_row(tok_job *j, tok_stream *out, int r, vp8_boolreader *br)
                 }
             }
         }
+        if (p->ec_active && (mb_idx >= p->mvs_corrupt_from_mb || vp8br_error(br) || (!p->independent_partitions && p->frame_corrupt_residual)))
+            p->frame_corrupt_residual = 1;       /* (whether or not this macroblock had a residual to lose) */
         if (j->progress && ((c & 3) == 3 || c == p->mb_cols - 1)) __atomic_store_n(&j->progress[r * PROGRESS_STRIDE], c + 1, __ATOMIC_RELEASE);
         o->y_mode = m->y_mode;
         o->uv_mode = m->uv_mode;
@@ -987,6 +1099,11 @@ static void *tok_worker_main(void *arg)
     return NULL;
 }
 
+void vp8_parser_set_error_concealment(vp8_parser *p, int on)
+{
+    if (p && !p->width) p->ec_enabled = on != 0;      /* before the first frame only: the mode-info arrays are allocated with it */
+}
+
 void vp8_parser_set_threads(vp8_parser *p, int threads)
 {
     if (p) p->threads = threads < 1 ? 1 : (threads > 8 ? 8 : threads);
@@ -1008,7 +1125,11 @@ static int decode_mbs(vp8_parser *p, vp8ir_mb *mbs, int16_t *coef, int16_t *bloc
         return fail(p, VP8P_INVALID_PARAM, "inter frame needs an mv array");
 
     read_modes(p);
-    bad |= vp8br_error(&p->first);
+    bad |= vp8br_error(&p->first) | p->corrupted;
+    if (p->ec_active && p->mvs_corrupt_from_mb < (unsigned)(p->mb_rows * p->mb_cols) && p->prev_mi)
+        /* decodframe.c:1079-1086: the modes that did not arrive are estimated from the frame before */
+        ec_estimate_missing_mvs(p->overlaps, p->mi, p->prev_mi, p->mi_stride, p->mb_rows, p->mb_cols, p->mvs_corrupt_from_mb);
+    p->frame_corrupt_residual = 0;
 
     memset(p->above, 0, (size_t)p->mb_cols * sizeof(entropy_ctx));
     memset(&job, 0, sizeof job);
@@ -1016,6 +1137,7 @@ static int decode_mbs(vp8_parser *p, vp8ir_mb *mbs, int16_t *coef, int16_t *bloc
     job.p = p; job.mbs = mbs; job.coef = coef; job.mvs = mvs;
     nthreads = p->threads < p->num_tok ? p->threads : p->num_tok;
     if (nthreads > p->mb_rows) nthreads = p->mb_rows;
+    if (p->ec_active) nthreads = 1;              /* what a lost residual does to the macroblocks after it is decided in frame order */
     /* a thread's sparse region has to hold the worst case of its rows; with a smaller array the frame is decoded serially */
     if (nthreads > 1 && !coef && cap_blocks < (size_t)p->mb_rows * p->mb_cols * 25) nthreads = 1;
     if (nthreads > 1) {
@@ -1081,8 +1203,21 @@ static int decode_mbs(vp8_parser *p, vp8ir_mb *mbs, int16_t *coef, int16_t *bloc
     if (is_key && !bad) p->have_key_frame = 1;
     if (!p->have_key_frame)
         return fail(p, VP8P_CORRUPT_FRAME, "A stream must start with a complete key frame");
-    if (p->restore_probs)
+    if (p->restore_probs) {
         p->fc = p->saved_fc;
+        p->independent_partitions = p->prev_independent;
+    }
+    if (p->ec_enabled && p->prev_mi) {
+        /* onyxd_if.c:622-640: this frame's mode info is what the next frame's concealment looks back on; the array it gets
+           to fill starts out with this frame's segment ids (a segment map that is not updated persists) */
+        mbinfo *t = p->prev_mi, *ta = p->prev_alloc;
+        p->prev_mi = p->mi; p->prev_alloc = p->mi_alloc;
+        p->mi = t; p->mi_alloc = ta;
+        for (r = 0; r < p->mb_rows; r++) {
+            int c;
+            for (c = 0; c < p->mb_cols; c++) p->mi[r * p->mi_stride + c].segment_id = p->prev_mi[r * p->mi_stride + c].segment_id;
+        }
+    }
     if (corrupt) *corrupt = bad;
     if (nblocks) *nblocks = nb;
     if (ndcs) *ndcs = nd;

@@ -36,6 +36,16 @@ vp8_parser *vp8_parser_create(void);
  * vpx_codec_dec_cfg_t::threads asks for (vpx/vpx_decoder.h:101-106; the reference's vp8/decoder/threading.c). */
 void vp8_parser_set_threads(vp8_parser *p, int threads);
 void vp8_parser_destroy(vp8_parser *p);
+/* Error concealment (VPX_CODEC_USE_ERROR_CONCEALMENT; a reference build configured --enable-error-concealment, decoder created
+ * with oxcf.error_concealment, onyxd_if.c:111-113).  To be set before the first frame.  Once a key frame has been decoded
+ * completely, from the first inter frame on (vp8_parser_conceals): a frame that never came -- vp8_parser_begin_frame with size 0
+ * -- is decoded as an inter frame whose motion vectors are extrapolated from the frame before (vp8_estimate_missing_mvs,
+ * error_concealment.c:408); a frame whose token partitions end early keeps the prediction, without residual, from the macroblock
+ * where they end, intra macroblocks among those predicted from the last frame with vectors interpolated from their neighbours
+ * (vp8_interpolate_motion, :555); reference-refresh flags whose bits are missing take their harmless values.  A short FIRST
+ * partition stays an error (the reference reads behind the buffer there), and key frames keep their intra macroblocks. */
+void vp8_parser_set_error_concealment(vp8_parser *p, int on);
+int  vp8_parser_conceals(const vp8_parser *p);
 
 /* vp8_peek_si (vp8/vp8_dx_iface.c:245-285): key-frame start code + 14-bit dimensions. */
 int vp8_parser_peek(const uint8_t *data, size_t size, int *is_key, int *width, int *height);
