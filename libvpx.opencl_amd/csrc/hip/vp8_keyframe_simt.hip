@@ -440,7 +440,12 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
         STAMP(1)
         const bool top = r == 0;
         const bool more = act && c + 1 < cols;
+#ifdef KF_NO_READBACK      // (timing experiments only: what the L2 round trip below costs -- 4-5 % of the kernel; asking a step ahead
+                           // costs 21 registers the luma wave does not have: +2 % key frames, +12 % inter frames with the spills)
+        const bool readback = false;
+#else
         const bool readback = act && pos == 0 && !top;          // first lane of a strand: its context comes from the hand-over tile
+#endif
         const bool last_col = act && c == cols - 1, last_row = r == rows - 1;
         // bottom rows that no lane below takes over are written here: to the frame (last row), or to the hand-over tile
         const bool write_bottom = pos == G - 1 || last_row;
@@ -863,8 +868,22 @@ __device__ __forceinline__ void kf_kernel(const DevJob *__restrict__ jobs, int n
     role = __builtin_amdgcn_readfirstlane(role);
     item = __builtin_amdgcn_readfirstlane(item);
     if (item >= nwaves) return;         // (cannot happen with grid = 2 * nwaves)
+#ifdef VP8_STAMPS
+    const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
+#endif
+    // The luma wave of a SIMD is the longer one (twice the pixels: 80 M cycles against the chroma wave's 64 M per 8192 key frames,
+    // 50 M against 31 M in launches with inter frames; tools/wave_times.py) and so is what the kernel takes: where the two compete
+    // for an issue slot it goes first.  -4 % (key frames) / -6 % (inter frames) of the kernel's time, mostly off the slowest
+    // luma waves.
+#ifndef KF_LUMA_PRIO
+#define KF_LUMA_PRIO 3
+#endif
+    if (role == 0) __builtin_amdgcn_s_setprio(KF_LUMA_PRIO);
     if (role == 0) kf_body<true, INTER>(jobs, njobs, g, lgG, P, nstrands, dummy, item, s_stage, s_queue, s_tab, s_y2dc, s_desc, s_sf);
     else kf_body<false, INTER>(jobs, njobs, g, lgG, P, nstrands, dummy + 1024, item, s_stage, s_queue, s_tab, s_y2dc, s_desc, s_sf);
+#ifdef VP8_STAMPS       // ... and for how long (units of 1024 cycles, above the work item's ten bits)
+    if (threadIdx.x == 0) sched[16 + 16384 + 4 * blockIdx.x + 3] = (u32)item | ((u32)((__builtin_amdgcn_s_memtime() - t_begin) >> 10) << 10);
+#endif
 }
 
 extern "C" __global__ void __launch_bounds__(64, 2)
