@@ -51,8 +51,8 @@ static void ec_spread_block(ec_block *blocks, int mb_rows, int mb_cols, int32_t 
     end_row = ec_min(mb_rows - om_row, 2);
     end_col = ec_min(mb_cols - om_col, 2);
     /* a second macroblock is only reached from the last block row / column of the first */
-    if (abs(new_row - ((16 * om_row) << 3)) < ((3 * 4) << 3)) end_row = 1;
-    if (abs(new_col - ((16 * om_col) << 3)) < ((3 * 4) << 3)) end_col = 1;
+    if (abs(new_row - 16 * om_row * 8) < ((3 * 4) << 3)) end_row = 1;
+    if (abs(new_col - 16 * om_col * 8) < ((3 * 4) << 3)) end_col = 1;
     for (rr = 0; rr < end_row; rr++)
         for (rc = 0; rc < end_col; rc++) {
             const int m_row = om_row + rr, m_col = om_col + rc;
@@ -68,11 +68,11 @@ static void ec_spread_block(ec_block *blocks, int mb_rows, int mb_cols, int32_t 
             e_col = ec_min(4 + m_col * 4 - fb_col, 2);
             if (new_row >= 0 && (new_row & 0x1F) == 0) e_row = 1;        /* block-aligned: no second block */
             if (new_col >= 0 && (new_col & 0x1F) == 0) e_col = 1;
-            if (new_row < ((m_row * 16) << 3)) e_row = 1;                /* started in the macroblock before */
-            if (new_col < ((m_col * 16) << 3)) e_col = 1;
+            if (new_row < m_row * 16 * 8) e_row = 1;                /* started in the macroblock before */
+            if (new_col < m_col * 16 * 8) e_col = 1;
             for (r = 0; r < e_row; r++)
                 for (c = 0; c < e_col; c++) {
-                    const int b2_row = ((fb_row + r) * 4) << 3, b2_col = ((fb_col + c) * 4) << 3;
+                    const int b2_row = (fb_row + r) * 4 * 8, b2_col = (fb_col + c) * 4 * 8;
                     const int top = ec_max(new_row, b2_row), left = ec_max(new_col, b2_col);
                     const int right = ec_min(new_col + (4 << 3), b2_col + (4 << 3)), bottom = ec_min(new_row + (4 << 3), b2_row + (4 << 3));
                     const int area = (bottom - top) * (right - left);            /* Q6 */

@@ -611,8 +611,8 @@ static int read_mv_component(vp8_boolreader *br, const uint8_t *pr)   /* decodem
 static mv16 read_mv(vp8_parser *p)
 {
     mv16 v;
-    v.row = (int16_t)(read_mv_component(&p->first, p->fc.mvc[0]) << 1);
-    v.col = (int16_t)(read_mv_component(&p->first, p->fc.mvc[1]) << 1);
+    v.row = (int16_t)(read_mv_component(&p->first, p->fc.mvc[0]) * 2);
+    v.col = (int16_t)(read_mv_component(&p->first, p->fc.mvc[1]) * 2);
     return v;
 }
 
