@@ -154,3 +154,50 @@ def test_independent_launches_run_past_the_raster_pass_dependent_ones_wait(pkg, 
         parser.close()
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("sizes", [(520, 3, 700, 520), (700, 700, 1, 600), (2, 640, 640, 640), (600, 8, 8, 520)])
+def test_mixed_launch_sizes_chained_without_sync(pkg, monkeypatch, sizes):
+    """Four frames of the dense P stream, each decoded for as many of the streams as `sizes` says (the first sizes[f] streams), back
+    to back without a sync, with no knob set: every launch picks its kernels by its own size -- wave-per-row with and without the
+    order-free inter kernel, prediction kernel + vp8_interframe_kernel with the raster pass held back -- and every one reads what
+    some launch before it wrote.  A stream's frame f is only launched where its frame f - 1 was; all of them must be the
+    reference decoder's."""
+    P = pkg
+    for k in ("VP8HIP_RECON", "VP8HIP_FUSED", "VP8HIP_LF_RASTER", "VP8HIP_INTER_TILED", "VP8HIP_INTER_SPLIT", "VP8HIP_INTER_FUSED"):
+        monkeypatch.delenv(k, raising=False)
+    name = "p_dense_1920x1080"
+    w, h, frames = P.read_ivf(ivf_path(name))
+    gold = golden_md5(name)
+    n = max(sizes)
+    ctx = P.Vp8Hip(0)
+    try:
+        ctx.configure(w, h, 4 * n, 4)
+        parser = P.Parser()
+        plan = []
+        for f in range(4):
+            hdr = ctx.parse_into_slot(parser, frames[f], f)
+            ctx.upload(f)
+            r = parser.refs
+            plan.append((hdr.frame_type, r.new_idx, (r.lst_idx, r.gld_idx, r.alt_idx)))
+            parser.swap(hdr)
+        count = n
+        done = []
+        for f, (ftype, new_idx, refs) in enumerate(plan):
+            count = min(count, sizes[f])
+            jobs = (P.Job * count)()
+            for i in range(count):
+                jobs[i].ir_slot, jobs[i].dst_fb = f, 4 * i + new_idx
+                for q in range(3):
+                    jobs[i].ref_fb[1 + q] = 4 * i + refs[q] if ftype else -1
+            ctx.decode_array(jobs, count, P.STAGE_ALL)
+            done.append(count)
+        ctx.sync()
+        for i in sorted({0, done[-1] // 2, done[-1] - 1}):
+            assert P.planes_md5(*ctx.download_planes(4 * i + plan[3][1])) == gold[3], (sizes, i)
+        if done[2] > done[3]:            # streams that stopped after frame 2
+            i = done[2] - 1
+            assert P.planes_md5(*ctx.download_planes(4 * i + plan[2][1])) == gold[2], (sizes, i)
+        parser.close()
+    finally:
+        ctx.close()
