@@ -110,7 +110,10 @@ typedef struct vp8ir_frame_hdr { /* 64 bytes */
     uint8_t  sign_bias_golden, sign_bias_alt;
     uint8_t  color_space, clamping_type;
     uint8_t  num_token_partitions;
-    uint8_t  rsv[15];
+    uint8_t  lf_key_frame;       /* 1: a KEY frame some of whose macroblocks error concealment turned into inter macroblocks
+                                    (decodframe.c:365-392): frame_type says inter -- the frame reads references --, the loop filter's
+                                    hev thresholds stay a key frame's (cm->frame_type, loopfilter.c:24-50).  See vp8ir_lf_frame_type */
+    uint8_t  rsv[14];
 } vp8ir_frame_hdr;
 
 #if defined(__HIPCC__)
@@ -118,6 +121,9 @@ typedef struct vp8ir_frame_hdr { /* 64 bytes */
 #else
 #define VP8IR_INLINE static inline
 #endif
+/* the frame type the loop filter's hev threshold goes by */
+VP8IR_INLINE int vp8ir_lf_frame_type(const vp8ir_frame_hdr *h) { return h->frame_type && !h->lf_key_frame; }
+
 /* 0: block k of the macroblock has no coefficients, 1: only its first (in `dcs`), 2: a full block (in `blocks`) */
 VP8IR_INLINE int vp8ir_block_kind(const vp8ir_mb *m, int k)
 {

@@ -56,7 +56,7 @@ class FrameHdr(ctypes.Structure):
                 ("copy_buffer_to_gf", ctypes.c_uint8), ("copy_buffer_to_arf", ctypes.c_uint8),
                 ("sign_bias_golden", ctypes.c_uint8), ("sign_bias_alt", ctypes.c_uint8),
                 ("color_space", ctypes.c_uint8), ("clamping_type", ctypes.c_uint8),
-                ("num_token_partitions", ctypes.c_uint8), ("rsv", ctypes.c_uint8 * 15)]
+                ("num_token_partitions", ctypes.c_uint8), ("lf_key_frame", ctypes.c_uint8), ("rsv", ctypes.c_uint8 * 14)]
 
 
 assert ctypes.sizeof(FrameHdr) == 64
@@ -153,6 +153,7 @@ def load_host():
         L.vp8_parser_set_threads.argtypes = [c_void_p, c_int]
         L.vp8_parser_set_error_concealment.argtypes = [c_void_p, c_int]
         L.vp8_parser_conceals.argtypes = [c_void_p]
+        L.vp8_parser_frame_hdr.argtypes = [c_void_p, c_void_p]
         L.vp8_parser_begin_frame.argtypes = [c_void_p, ctypes.c_char_p, c_size_t, c_void_p]
         L.vp8_parser_decode_mbs.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
         L.vp8_parser_decode_mbs_sparse.argtypes = [c_void_p, c_void_p, c_void_p, c_size_t, ctypes.POINTER(c_size_t), c_void_p,
@@ -185,6 +186,11 @@ class Parser:
     def set_threads(self, n):
         """token partitions of a frame on up to n threads (vp8_parser_set_threads)"""
         self.L.vp8_parser_set_threads(self.p, n)
+
+    def final_hdr(self, hdr):
+        """after decode_mbs: the header as the pixel path is to see it (vp8_parser_frame_hdr)"""
+        self.L.vp8_parser_frame_hdr(self.p, ctypes.byref(hdr))
+        return hdr
 
     def set_error_concealment(self, on=True):
         """before the first frame: conceal lost frames and lost residuals (vp8_parser_set_error_concealment)"""

@@ -411,7 +411,7 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
             if constexpr (INTER) {
                 frame_levels_inter(h, lv_plain, lv_bpred, lv_mode);
                 lv_delta = h.filter_level && h.mode_ref_lf_delta_enabled;
-                ftype = h.frame_type;
+                ftype = vp8ir_lf_frame_type(&h);
             } else
                 frame_levels(h, lv_plain, lv_bpred);
             sharp = h.sharpness_level; simple = h.filter_type == 1;

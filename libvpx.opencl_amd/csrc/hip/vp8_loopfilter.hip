@@ -182,7 +182,7 @@ __device__ __forceinline__ void lf_body(const DevJob *__restrict__ jobs, int njo
         const int lvlA = build_level(hA, lane), lvlB = build_level(hB, lane);
         const bool simple = (half ? hB.filter_type : hA.filter_type) != 0;
         const int sharp = half ? hB.sharpness_level : hA.sharpness_level;
-        const int ftype = half ? hB.frame_type : hA.frame_type;
+        const int ftype = half ? vp8ir_lf_frame_type(&hB) : vp8ir_lf_frame_type(&hA);
         const vp8ir_mb *mbs = half ? jobB.mbs : jobA.mbs;
         uint8_t *dst = half ? jobB.dst : jobA.dst;
         g_cu32p mbrow = (g_cu32p)(mbs + (long)r * cols);              // 16 dwords per MB

@@ -143,7 +143,7 @@ __device__ __forceinline__ void lf_simt_body(const DevJob *__restrict__ jobs, in
             const int y_mode = w0 & 0xff, ref_frame = (w0 >> 16) & 0xff;
             const u32 flags = w0 >> 24;
             const int level = mb_level(h, w1 & 3, ref_frame & 3, y_mode);
-            const Lim L = mb_limits(h.sharpness_level, level, h.frame_type, one);
+            const Lim L = mb_limits(h.sharpness_level, level, vp8ir_lf_frame_type(&h), one);
             const bool on = lf_on && level != 0;
             const bool skip_lf = y_mode != VP8IR_B_PRED && y_mode != VP8IR_SPLITMV && (flags & VP8IR_MB_SKIP);
             const bool mbv = on && c > 0, inner = on && !skip_lf, mbh = on && r > 0;

@@ -262,6 +262,7 @@ static vpx_codec_err_t vp8_decode(vpx_codec_alg_priv_t *p, const uint8_t *data, 
         vp8_refs_release_new(&p->refs);
         return set_detail(p, (vpx_codec_err_t)rc, vp8_parser_error(p->parser));
     }
+    vp8_parser_frame_hdr(p->parser, &hdr);          /* (a concealed key frame reads references: frame_type 1, lf_key_frame 1) */
     *h_hdr = hdr;
 
     /* which references does this frame read (vp8dx_references_buffer, onyxd_if.c:711-760) */

@@ -88,6 +88,7 @@ struct vp8_parser {
 
     /* error concealment (a reference build with CONFIG_ERROR_CONCEALMENT, decoder created with oxcf.error_concealment) */
     int ec_enabled;              /* vp8_parser_set_error_concealment */
+    int key_concealed;           /* the key frame being decoded got inter macroblocks from vp8_interpolate_motion */
     int ec_active;               /* from the first inter frame after a complete key frame on (init_frame, decodframe.c:672-673) */
     int corrupted;               /* xd->corrupted of the frame being decoded */
     unsigned mvs_corrupt_from_mb;/* first macroblock whose modes the first partition no longer held (decodemv.c:639-655) */
@@ -514,6 +515,12 @@ int vp8_parser_begin_frame_fragments(vp8_parser *p, const uint8_t *const *frags,
 }
 
 int vp8_parser_conceals(const vp8_parser *p) { return p && p->ec_active; }
+
+void vp8_parser_frame_hdr(const vp8_parser *p, vp8ir_frame_hdr *out)
+{
+    *out = p->hdr;
+    if (p->key_concealed) { out->frame_type = 1; out->lf_key_frame = 1; }
+}
 
 /* ------------------------------------------------------------------------------------------
  * modes and motion vectors
@@ -998,12 +1005,15 @@ static int decode_row(tok_job *j, tok_stream *out, int r, vp8_boolreader *br)
         entropy_ctx *A = &p->above[c];
         const unsigned mb_idx = (unsigned)n;
         int has_y2;
-        if (p->ec_active && m->ref_frame == VP8IR_INTRA_FRAME && p->hdr.frame_type != 0
-            && ((!p->independent_partitions && p->frame_corrupt_residual) || vp8br_error(br)))
+        if (p->ec_active && m->ref_frame == VP8IR_INTRA_FRAME && (p->hdr.frame_type != 0 || mvs)
+            && ((!p->independent_partitions && p->frame_corrupt_residual) || vp8br_error(br))) {
             /* decode_mb_row, decodframe.c:365-392: an intra macroblock whose residual is lost is better predicted from the last
                frame with vectors interpolated from its neighbours.  (The first macroblock to lose its residual finds out too
-               late for that, as there.  Key frames are not concealed this way here: their macroblocks stay intra.) */
+               late for that, as there.)  In a KEY frame too: the frame then reads a reference like an inter frame, which is what
+               its header says to the pixel path afterwards (vp8_parser_frame_hdr), with lf_key_frame for the loop filter */
             ec_interpolate_motion(m, p->mi_stride, r, c, p->mb_rows, p->mb_cols);
+            if (p->hdr.frame_type == 0) p->key_concealed = 1;
+        }
         has_y2 = m->y_mode != VP8IR_B_PRED && m->y_mode != VP8IR_SPLITMV;
         if (j->progress && r > 0 && (c & 3) == 0) {   /* the four macroblocks above have left their context in p->above[] */
             const int need = c + 4 < p->mb_cols ? c + 4 : p->mb_cols;
@@ -1130,6 +1140,7 @@ static int decode_mbs(vp8_parser *p, vp8ir_mb *mbs, int16_t *coef, int16_t *bloc
         /* decodframe.c:1079-1086: the modes that did not arrive are estimated from the frame before */
         ec_estimate_missing_mvs(p->overlaps, p->mi, p->prev_mi, p->mi_stride, p->mb_rows, p->mb_cols, p->mvs_corrupt_from_mb);
     p->frame_corrupt_residual = 0;
+    p->key_concealed = 0;
 
     memset(p->above, 0, (size_t)p->mb_cols * sizeof(entropy_ctx));
     memset(&job, 0, sizeof job);

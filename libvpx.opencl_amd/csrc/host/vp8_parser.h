@@ -42,10 +42,14 @@ void vp8_parser_destroy(vp8_parser *p);
  * -- is decoded as an inter frame whose motion vectors are extrapolated from the frame before (vp8_estimate_missing_mvs,
  * error_concealment.c:408); a frame whose token partitions end early keeps the prediction, without residual, from the macroblock
  * where they end, intra macroblocks among those predicted from the last frame with vectors interpolated from their neighbours
- * (vp8_interpolate_motion, :555); reference-refresh flags whose bits are missing take their harmless values.  A short FIRST
- * partition stays an error (the reference reads behind the buffer there), and key frames keep their intra macroblocks. */
+ * (vp8_interpolate_motion, :555), in key frames too (vp8_parser_frame_hdr); reference-refresh flags whose bits are missing take
+ * their harmless values.  A short FIRST partition stays an error (the reference reads behind the buffer there). */
 void vp8_parser_set_error_concealment(vp8_parser *p, int on);
 int  vp8_parser_conceals(const vp8_parser *p);
+/* The header of the frame vp8_parser_decode_mbs[_sparse] has just decoded, as the pixel path is to see it: what begin_frame
+ * returned, except for a key frame in which concealment replaced intra macroblocks by inter ones (frame_type 1, lf_key_frame 1:
+ * vp8_ir.h).  Callers that enable concealment pass THIS header on; key frames then need the mv array too. */
+void vp8_parser_frame_hdr(const vp8_parser *p, vp8ir_frame_hdr *out);
 
 /* vp8_peek_si (vp8/vp8_dx_iface.c:245-285): key-frame start code + 14-bit dimensions. */
 int vp8_parser_peek(const uint8_t *data, size_t size, int *is_key, int *width, int *height);

@@ -613,7 +613,7 @@ static void loop_filter_frame(const vp8ir_frame_hdr *h, const vp8ir_geom *g, con
             unsigned char *v = frame + g->v_off + r * 8 * g->uv_stride + c * 8;
             vp8o_lf_info l;
             if (!level) continue;
-            vp8o_lf_limits(h->sharpness_level, level, h->frame_type, &l);
+            vp8o_lf_limits(h->sharpness_level, level, vp8ir_lf_frame_type(h), &l);
             if (h->filter_type == 0) {
                 if (c > 0) vp8o_loop_filter_mbv(y, u, v, g->y_stride, g->uv_stride, &l);
                 if (!skip_lf) vp8o_loop_filter_bv(y, u, v, g->y_stride, g->uv_stride, &l);

@@ -4,13 +4,21 @@ damaged stream against the reference decoder built with error concealment.
     python3 tests/debug/ec_cpu.py <fixture> [--lose 3,4] [--cut 5:700,...] [--no-ec]"""
 import os, subprocess, sys, tempfile
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import numpy as np
 from vp8_testlib import ROOT, load_package, ivf_path, oracle_decode
 
 
+def _stream(name, tmp):
+    from ec_cases import materialize
+    from vp8_testlib import GOLDEN
+    return materialize(name, GOLDEN, tmp)
+
+
 def damaged_listing(name, lose=(), cut=(), ec=True):
     P = load_package()
-    w, h, frames = P.read_ivf(ivf_path(name))
+    with tempfile.TemporaryDirectory() as tmp:
+        w, h, frames = P.read_ivf(_stream(name, tmp))
     parser = P.Parser()
     if ec:
         parser.set_error_concealment(True)
@@ -35,6 +43,7 @@ def damaged_listing(name, lose=(), cut=(), ec=True):
         except ValueError:
             out.append(f"decode-error {k:04d}")
             continue
+        parser.final_hdr(hdr)
         if changed:
             g = P.geom(hdr.width, hdr.height)
             bufs = [np.zeros(g.frame_size, np.uint8) for _ in range(4)]
@@ -54,7 +63,7 @@ def reference_listing(name, lose=(), cut=(), ec=True):
         args = [tool, "--damage"] + (["--ec"] if ec else [])
         if lose: args += ["--lose", ",".join(map(str, lose))]
         if cut: args += ["--cut", ",".join(f"{a}:{b}" for a, b in cut)]
-        r = subprocess.run(args + [ivf_path(name), o], capture_output=True, text=True)
+        r = subprocess.run(args + [_stream(name, d), o], capture_output=True, text=True)
         assert r.returncode == 0, r.stderr
         return open(o).read().splitlines()
 

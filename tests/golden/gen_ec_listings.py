@@ -4,10 +4,12 @@
 import os, subprocess, sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(HERE, ".."))
-from ec_cases import CASES, tool_args
+import tempfile
+from ec_cases import CASES, materialize, tool_args
 TOOL = os.path.join(HERE, "..", "..", "oracle", "_ref", "ref_md5_ec")
 for name, (fixture, lose, cut) in CASES.items():
     out = os.path.join(HERE, f"ec_{name}.md5")
-    subprocess.run([TOOL, "--damage"] + tool_args(lose, cut) + [os.path.join(HERE, fixture + ".ivf"), out], check=True,
-                   stderr=subprocess.DEVNULL)
+    with tempfile.TemporaryDirectory() as tmp:
+        subprocess.run([TOOL, "--damage"] + tool_args(lose, cut) + [materialize(fixture, HERE, tmp), out], check=True,
+                       stderr=subprocess.DEVNULL)
     print(name, len(open(out).read().splitlines()), "lines")

@@ -7,7 +7,7 @@ import subprocess
 
 import pytest
 
-from ec_cases import CASES, tool_args
+from ec_cases import CASES, materialize, tool_args
 from vp8_testlib import GOLDEN, ROOT, ivf_path
 
 pytestmark = pytest.mark.gpu
@@ -19,13 +19,14 @@ REF = os.path.join(ROOT, "oracle", "_ref", "ref_md5_ec")
 def test_damaged_stream_with_concealment_equals_the_reference(tmp_path, name):
     fixture, lose, cut = CASES[name]
     got = tmp_path / "hip.md5"
-    r = subprocess.run([BIN] + tool_args(lose, cut) + [ivf_path(fixture), str(got)], capture_output=True, text=True)
+    stream = materialize(fixture, GOLDEN, tmp_path)
+    r = subprocess.run([BIN] + tool_args(lose, cut) + [stream, str(got)], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     listing = open(got).read()
     assert listing == open(os.path.join(GOLDEN, f"ec_{name}.md5")).read()
     if os.path.exists(REF):
         want = tmp_path / "ref.md5"
-        subprocess.run([REF, "--damage"] + tool_args(lose, cut) + [ivf_path(fixture), str(want)], check=True, capture_output=True)
+        subprocess.run([REF, "--damage"] + tool_args(lose, cut) + [stream, str(want)], check=True, capture_output=True)
         assert listing == open(want).read()
 
 
