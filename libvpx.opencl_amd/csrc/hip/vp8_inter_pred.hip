@@ -8,16 +8,18 @@
 //
 // An inter macroblock's prediction needs nothing of the frame being decoded, only the (finished, border-extended) reference
 // frames, so this kernel is order-free and its lanes are cut to the filter, not to the macroblock order:
-//   * a lane owns a COLUMN STRIP four pixels wide -- 16 rows of a luma macroblock, 8 rows of a chroma plane, or one 4x4 block of
-//     a SPLITMV macroblock -- and streams down the source rows: one global_load_dwordx3 per row (the nine pixels the six taps
-//     need, as three aligned dwords shifted into place), the horizontal pass two pixels per instruction on 16-bit lanes, a ring
-//     of the last six filtered rows in registers, the vertical pass, one dword stored.  21 source rows for 16 output rows (the
-//     wave-per-row kernels' 4-row segments need 9 for 4), no LDS, no exchange between lanes;
+//   * a lane owns a COLUMN STRIP eight pixels wide -- half of a luma macroblock's 16 rows, a chroma plane's 8 rows -- or one 4x4
+//     block of a SPLITMV macroblock, and streams down the source rows: one global_load_dwordx4 (4x4 blocks: dwordx3) per row (the
+//     13 / 9 pixels the six taps need, as aligned dwords shifted into place), requested six rows ahead; the horizontal pass two
+//     pixels per instruction on 16-bit lanes; a ring of the last six filtered rows in registers; the vertical pass.  21 source
+//     rows for 16 output rows (the wave-per-row kernels' 4-row segments need 9 for 4), no LDS.  Output goes out in 16-byte
+//     stores -- the two lanes of a luma macroblock swap half rows by DPP and store a whole row each, a chroma lane stores two
+//     rows at once: as 8-byte stores (19 write requests per macroblock at the L2 instead of 6) they were 39 % of the kernel;
 //   * both passes always run, as in the reference's C filters (filter.c:95-128): a whole-pixel offset has the taps {0,0,128,0,0,0},
 //     which make a pass the identity, and the bilinear filters of versions 1-3 are the six-tap arithmetic with the taps
 //     {0,0,128-16f,16f,0,0} (the same sums, the same rounding; the clamp never binds) -- one code path for every profile;
 //   * a wave takes 64 consecutive macroblocks of a frame, sorts them by ballot into those with one motion vector and the
-//     SPLITMV ones (intra macroblocks drop out), and works through the two lists 16 (luma strips; then chroma strips) resp.
+//     SPLITMV ones (intra macroblocks drop out), and works through the two lists 32 (luma strips; then chroma strips) resp.
 //     4 / 8 macroblocks (luma / chroma 4x4 blocks) at a time, all lanes busy on the same code.
 //
 // Output: the prediction of macroblock (r, c) in ITS tile of the job's scratch frame (DevJob::tile, the key-frame kernels'
@@ -26,6 +28,9 @@
 // vp8_interframe_kernel, which reads a block row's prediction right before it writes finished pixels into the same tile, never
 // overwrites what it has not read yet.  Integer only; no MFMA by design.
 #include "vp8_block_prims.hip.h"
+#ifndef IP_WAVES
+#define IP_WAVES 4        // (five or six waves per SIMD only fit with spills: 9.9 / 10.0 ms against 9.1-9.6)
+#endif
 
 namespace {
 
@@ -143,8 +148,13 @@ __device__ __forceinline__ Row8 h_pass8(u32x4 d, u32 sh, const Taps &tx)
     return { { finish2(a01), finish2(a23) }, { finish2(a45), finish2(a67) } };
 }
 template <int NOUT>
-__device__ __forceinline__ void strip8(g_cu8p src, int stride, const Taps &tx, const Taps &ty, g_u8p dst, int dstride, int dhalf)
+__device__ __forceinline__ void strip8(g_cu8p src, int stride, const Taps &tx, const Taps &ty, g_u8p dst, int s)
 {
+    // Output in 16-byte stores (8-byte ones -- 19 write requests per macroblock at the L2 instead of 6 -- cost this kernel 39 % of
+    // its time).  NOUT == 16, luma: dst = the macroblock's tile, lanes s = 0 / 1 hold the left / right half of its rows; after
+    // every second row they swap a half row (DPP), lane 0 stores the whole row y - 1 and lane 1 the whole row y.  NOUT == 8,
+    // chroma: dst = the plane's rows 0..3 (rows 4..7 64 bytes on), a lane has whole rows: two of them are one store.
+    u32x2 prev = { 0, 0 };
     const u32 sh = (u32)(unsigned long)src & 3u;
     g_cu8p rp = src - sh;
     constexpr int NIN = NOUT + 5, AHEAD = 6;
@@ -163,8 +173,16 @@ __device__ __forceinline__ void strip8(g_cu8p src, int stride, const Taps &tx, c
             u32x2 o;
             o.x = v_pass(h0.l, h1.l, h2.l, h3.l, h4.l, h5.l, ty);
             o.y = v_pass(h0.r, h1.r, h2.r, h3.r, h4.r, h5.r, ty);
-            g_u8p qd = (NOUT == 8 && y >= 4) ? dst + dhalf + dstride * (y - 4) : dst + dstride * y;
-            *(GLOBAL_AS u32x2 *)qd = o;
+            if (!(y & 1)) prev = o;
+            else if (NOUT == 16) {
+                const u32x2 give = s ? prev : o;
+                const u32 tx_ = dpp_xor1(give.x), ty_ = dpp_xor1(give.y);
+                const u32x4 v = s ? (u32x4){ tx_, ty_, o.x, o.y } : (u32x4){ prev.x, prev.y, tx_, ty_ };
+                *(GLOBAL_AS u32x4 *)(dst + 16 * (y - 1 + s)) = v;
+            } else {
+                g_u8p qd = y - 1 >= 4 ? dst + 64 + 8 * (y - 1 - 4) : dst + 8 * (y - 1);
+                *(GLOBAL_AS u32x4 *)qd = (u32x4){ prev.x, prev.y, o.x, o.y };
+            }
         }
     }
 }
@@ -189,7 +207,7 @@ __device__ __forceinline__ void clamp_chroma_mv(int &row, int &col, int e_left, 
 } // namespace
 
 // grid: any number of blocks of four waves (a wave takes units unit, unit + waves, ...); upf = units (64 macroblocks) per frame
-extern "C" __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8)))
+extern "C" __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(IP_WAVES, 8)))
 vp8_inter_pred_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g, int upf)
 {
     __shared__ u32 s_w0a[4][64];
@@ -246,7 +264,7 @@ vp8_inter_pred_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g, int
                 const int sx = max(-32 + 2, min(m.c * 16 + (mcol >> 3), g.aligned_w + 32 - 22));
                 const int sy = max(-32 + 2, min(m.r * 16 + (mrow >> 3), g.aligned_h + 32 - 19));
                 const Taps tx = load_taps(bil, mcol & 7), ty = load_taps(bil, mrow & 7);
-                strip8<16>(m.ref + g.y_off + (long)(sy - 2) * g.y_stride + (sx - 2 + 8 * s), g.y_stride, tx, ty, m.tile + 8 * s, 16, 0);
+                strip8<16>(m.ref + g.y_off + (long)(sy - 2) * g.y_stride + (sx - 2 + 8 * s), g.y_stride, tx, ty, m.tile, s);
             }
         }
         // chroma: 32 macroblocks x 2 planes; the MV from the CLAMPED luma MV (reconinter.c:419-424)
@@ -265,7 +283,7 @@ vp8_inter_pred_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g, int
                 const int sy = max(-16 + 2, min(m.r * 8 + (mrow >> 3), g.aligned_h / 2 + 16 - 11));
                 const Taps tx = load_taps(bil, mcol & 7), ty = load_taps(bil, mrow & 7);
                 strip8<8>(m.ref + (pl ? g.v_off : g.u_off) + (long)(sy - 2) * g.uv_stride + (sx - 2), g.uv_stride, tx, ty,
-                          m.tile + 256 + 32 * pl, 8, 64);
+                          m.tile + 256 + 32 * pl, 0);
             }
         }
         // ---- SPLITMV: build_inter4x4_predictors_mb, a 4x4 block per lane (partitions of 8x8 / 16x8 / 8x16 carry their MV in every
