@@ -28,6 +28,9 @@
 // vp8_interframe_kernel, which reads a block row's prediction right before it writes finished pixels into the same tile, never
 // overwrites what it has not read yet.  Integer only; no MFMA by design.
 #include "vp8_block_prims.hip.h"
+#ifndef IP_AHEAD
+#define IP_AHEAD 6
+#endif
 #ifndef IP_WAVES
 #define IP_WAVES 4        // (five or six waves per SIMD only fit with spills: 9.9 / 10.0 ms against 9.1-9.6)
 #endif
@@ -157,7 +160,7 @@ __device__ __forceinline__ void strip8(g_cu8p src, int stride, const Taps &tx, c
     u32x2 prev = { 0, 0 };
     const u32 sh = (u32)(unsigned long)src & 3u;
     g_cu8p rp = src - sh;
-    constexpr int NIN = NOUT + 5, AHEAD = 6;
+    constexpr int NIN = NOUT + 5, AHEAD = IP_AHEAD < NIN ? IP_AHEAD : NIN;
     u32x4_u q[AHEAD];
 #pragma unroll
     for (int i = 0; i < AHEAD; i++) q[i] = *(g_cu32x4up)(rp + (long)i * stride);
