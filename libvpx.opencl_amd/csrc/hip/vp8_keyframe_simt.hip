@@ -698,7 +698,7 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
                 if (pl == 0) queue(cfp, (int)((jm >> 8) & 0x1f) + __builtin_popcount(jm & 0xf), (jm >> 4) & 0xf, (jm >> 20) & 0xf, 0, 0);
                 else {
                     u32 n_jm = 0, n_dcg = 0;
-                    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");          // (the descriptor: U's four row stores are younger)
                     u32x4 m0, m1;
                     asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024\n\ts_waitcnt lgkmcnt(0)"
                                  : "=&v"(m0), "=&v"(m1) : "v"(desc_lane) : "memory");
@@ -760,20 +760,20 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
                 STAMP(11)
                 {   // rows 4..7 of the macroblock above: final
                     g_u8p pa = KF_ACT(act && !top) ? tpc - rowbytes + KT_U_BOT + poff : (g_u8p)dummy;
-                    const int st = KF_ACT(act && !top) ? 8 : 0;
+                    const int st = KF_ACT(act && !top) ? 16 : 0;          // (two 8-byte rows per store)
 #pragma unroll
-                    for (int j = 0; j < 4; j++)
-                        *(g_u32x2p)(pa + j * st) = (u32x2){ d0[j][0] ^ VP8_LF_BIAS, d0[j][1] ^ VP8_LF_BIAS };
+                    for (int j = 0; j < 4; j += 2)
+                        *(g_u32x4p)(pa + (j >> 1) * st) = (u32x4){ d0[j][0], d0[j][1], d0[j + 1][0], d0[j + 1][1] } ^ VP8_LF_BIAS;
                 }
                 STAMP(12)
                 lf_block_row<2>(o1, s1, Pc, false, gv, gh, L, d1);
                 STAMP(11)
                 {   // rows 0..3: the left neighbour's last dword and this macroblock's first
                     g_u8p po = KF_ACT(act) ? tpc + KT_U_WIN + poff : (g_u8p)dummy;
-                    const int st = KF_ACT(act) ? 8 : 0;
+                    const int st = KF_ACT(act) ? 16 : 0;
 #pragma unroll
-                    for (int j = 0; j < 4; j++)
-                        *(g_u32x2p)(po + j * st) = (u32x2){ s0[j] ^ VP8_LF_BIAS, d1[j][0] ^ VP8_LF_BIAS };
+                    for (int j = 0; j < 4; j += 2)
+                        *(g_u32x4p)(po + (j >> 1) * st) = (u32x4){ s0[j], d1[j][0], s0[j + 1], d1[j + 1][0] } ^ VP8_LF_BIAS;
                 }
                 STAMP(12)
                 u32 (&e)[4][2] = Pc;             // rows 4..7 as the second block row left them
@@ -784,7 +784,7 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
                     if (write_bottom && c > 0) {       // nobody below takes the left neighbour's bottom rows over
                         g_u8p pbo = tpc - VP8_TILE_BYTES + KT_U_BOT + poff;
 #pragma unroll
-                        for (int j = 0; j < 4; j++) *(g_u32x2p)(pbo + j * 8) = (u32x2){ hF[j][0] ^ VP8_LF_BIAS, hF[j][1] ^ VP8_LF_BIAS };
+                        for (int j = 0; j < 4; j += 2) *(g_u32x4p)(pbo + j * 8) = (u32x4){ hF[j][0], hF[j][1], hF[j + 1][0], hF[j + 1][1] } ^ VP8_LF_BIAS;
                     }
 #pragma unroll
                     for (int j = 0; j < 4; j++) { sP[j * 64] = d1[j][1]; sB[j] = e[j][1]; pb[j][0] = e[j][0]; }
@@ -793,7 +793,7 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
                         for (int j = 0; j < 4; j++) *(GLOBAL_AS u32 *)(tpc + VP8_TILE_BYTES + KT_U_WIN + poff + 8 * j) = d1[j][1] ^ VP8_LF_BIAS;
                         if (write_bottom) {
 #pragma unroll
-                            for (int j = 0; j < 4; j++) *(g_u32x2p)(tpc + KT_U_BOT + poff + j * 8) = (u32x2){ e[j][0] ^ VP8_LF_BIAS, e[j][1] ^ VP8_LF_BIAS };
+                            for (int j = 0; j < 4; j += 2) *(g_u32x4p)(tpc + KT_U_BOT + poff + j * 8) = (u32x4){ e[j][0], e[j][1], e[j + 1][0], e[j + 1][1] } ^ VP8_LF_BIAS;
                         }
                     }
                 }
@@ -805,8 +805,8 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
                         pr[2] = *(g_cu32x4p)(pp + 64); pr[3] = *(g_cu32x4p)(pp + 80);
                     }
                 }
-                // ---- the other plane's residuals (or the next macroblock's first): the eight row stores above are younger
-                drain(pl == 0 ? 20 : 16, 0, 8);
+                // ---- the other plane's residuals (or the next macroblock's first): the four row stores above are younger
+                drain(pl == 0 ? 20 : 16, 0, 4);
                 STAMP(6)
                 // ---- the planes change places
                 SWAP_U32(bA[0], bB[0]) SWAP_U32(bA[1], bB[1]) SWAP_U32(l0[0], l0[2]) SWAP_U32(l0[1], l0[3])
