@@ -492,22 +492,41 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
         if (readback) {
             const unsigned char *pa = (const unsigned char *)tpc - rowbytes, *ha = (const unsigned char *)hpc - hrow;
             if constexpr (LUMA) {
-#pragma unroll
-                for (int i = 0; i < 4; i++) aA[i] = load_l2(ha + KH_Y + 4 * i);
-                arY = load_l2(ha + KH_BYTES + KH_Y);
+                // (agent-scope loads -- served by the L2, see load_l2 --, six wide ones instead of 21 dwords)
+                u32x4 va, v0, v1, v2, v3;
+                u32 vr;
+                asm volatile("global_load_dwordx4 %0, %6, off sc1\n\t"
+                             "global_load_dword %5, %6, off offset:32 sc1\n\t"
+                             "global_load_dwordx4 %1, %7, off offset:192 sc1\n\t"
+                             "global_load_dwordx4 %2, %7, off offset:208 sc1\n\t"
+                             "global_load_dwordx4 %3, %7, off offset:224 sc1\n\t"
+                             "global_load_dwordx4 %4, %7, off offset:240 sc1\n\t"
+                             "s_waitcnt vmcnt(0)"
+                             : "=&v"(va), "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3), "=&v"(vr) : "v"(ha), "v"(pa) : "memory");
+                static_assert(KH_Y == 0 && KH_BYTES == 32 && KT_Y_BOT == 192, "offsets in the asm above");
+                aA[0] = va.x; aA[1] = va.y; aA[2] = va.z; aA[3] = va.w;
+                arY = vr;
+                const u32x4 vv[4] = { v0, v1, v2, v3 };
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
-#pragma unroll
-                    for (int i = 0; i < 4; i++) tF[j][i] = load_l2(pa + KT_Y_BOT + 16 * j + 4 * i) ^ VP8_LF_BIAS;
+                    tF[j][0] = vv[j].x ^ VP8_LF_BIAS; tF[j][1] = vv[j].y ^ VP8_LF_BIAS;
+                    tF[j][2] = vv[j].z ^ VP8_LF_BIAS; tF[j][3] = vv[j].w ^ VP8_LF_BIAS;
                 }
             } else {
-                aA[0] = load_l2(ha + KH_U); aA[1] = load_l2(ha + KH_U + 4);
-                aA[2] = load_l2(ha + KH_V); aA[3] = load_l2(ha + KH_V + 4);
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    tF[j][0] = load_l2(pa + KT_U_BOT + 8 * j) ^ VP8_LF_BIAS; tF[j][1] = load_l2(pa + KT_U_BOT + 8 * j + 4) ^ VP8_LF_BIAS;
-                    tF[j][2] = load_l2(pa + KT_U_BOT + 32 + 8 * j) ^ VP8_LF_BIAS; tF[j][3] = load_l2(pa + KT_U_BOT + 32 + 8 * j + 4) ^ VP8_LF_BIAS;
-                }
+                u32x4 va, u0, u1, w0, w1;            // U rows (4,5) (6,7), V rows (4,5) (6,7): 64 contiguous bytes
+                asm volatile("global_load_dwordx4 %0, %5, off offset:16 sc1\n\t"
+                             "global_load_dwordx4 %1, %6, off offset:320 sc1\n\t"
+                             "global_load_dwordx4 %2, %6, off offset:336 sc1\n\t"
+                             "global_load_dwordx4 %3, %6, off offset:352 sc1\n\t"
+                             "global_load_dwordx4 %4, %6, off offset:368 sc1\n\t"
+                             "s_waitcnt vmcnt(0)"
+                             : "=&v"(va), "=&v"(u0), "=&v"(u1), "=&v"(w0), "=&v"(w1) : "v"(ha), "v"(pa) : "memory");
+                static_assert(KH_U == 16 && KH_V == 24 && KT_U_BOT == 320, "offsets in the asm above");
+                aA[0] = va.x; aA[1] = va.y; aA[2] = va.z; aA[3] = va.w;
+                tF[0][0] = u0.x ^ VP8_LF_BIAS; tF[0][1] = u0.y ^ VP8_LF_BIAS; tF[1][0] = u0.z ^ VP8_LF_BIAS; tF[1][1] = u0.w ^ VP8_LF_BIAS;
+                tF[2][0] = u1.x ^ VP8_LF_BIAS; tF[2][1] = u1.y ^ VP8_LF_BIAS; tF[3][0] = u1.z ^ VP8_LF_BIAS; tF[3][1] = u1.w ^ VP8_LF_BIAS;
+                tF[0][2] = w0.x ^ VP8_LF_BIAS; tF[0][3] = w0.y ^ VP8_LF_BIAS; tF[1][2] = w0.z ^ VP8_LF_BIAS; tF[1][3] = w0.w ^ VP8_LF_BIAS;
+                tF[2][2] = w1.x ^ VP8_LF_BIAS; tF[2][3] = w1.y ^ VP8_LF_BIAS; tF[3][2] = w1.z ^ VP8_LF_BIAS; tF[3][3] = w1.w ^ VP8_LF_BIAS;
             }
         }
         const int up = !top, lf = c > 0;
