@@ -194,6 +194,29 @@ def inter_frame_probe(P, device, n=4096, name="p_dense_1920x1080", k=2):
                          "note": "SURVEY 8(d) full inter path 2407 B/MB x macroblocks per launch / wall time per launch"}}
 
 
+def batch_md5_probe(fixture, device, loops=205):
+    """The same end-to-end pipeline with the C host side (bin/batch_md5: feeder threads, batched launches, MD5 on the device where the
+    frame size allows): the fixture looped, listing checked line by line against the reference decoder's digests."""
+    import tempfile
+    tool = os.path.join(ROOT, "libvpx.opencl_amd", "bin", "batch_md5")
+    ivf = os.path.join(ROOT, "tests", "golden", fixture + ".ivf")
+    gold = [l.split()[0] for l in open(os.path.join(ROOT, "tests", "golden", fixture + ".md5")).read().splitlines()]
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "o.md5")
+        env = dict(os.environ, VP8HIP_DEVICE=str(device))
+        r = subprocess.run([tool, "--loop", str(loops), ivf, out], capture_output=True, text=True, env=env, timeout=300)
+        if r.returncode:
+            return {"error": r.stderr[-300:]}
+        got = [l.split()[0] for l in open(out).read().splitlines()]
+    bad = sum(1 for i, g in enumerate(got) if g != gold[i % len(gold)]) + abs(len(got) - loops * len(gold))
+    import re
+    m = re.search(r"(\d+) frames in ([0-9.]+) s: ([0-9.]+) frames/s, ([0-9.]+) Mpix/s \((\d+) feeder threads, (\d+) frames per launch, MD5 on the (\w+)\)", r.stderr)
+    if not m:
+        return {"error": "unparsed: " + r.stderr[-200:]}
+    return {"tool": "bin/batch_md5 --loop %d" % loops, "frames": int(m.group(1)), "frames_per_s": float(m.group(3)), "Mpix_s": float(m.group(4)),
+            "host_threads": int(m.group(5)), "frames_per_launch": int(m.group(6)), "md5_on": m.group(7), "md5_mismatches": bad}
+
+
 def load_stream(P, ctx, fixture, F, lo):
     """Slots 0 .. F-1 of `ctx` <- frames lo .. lo+F-1 of the looped stream (frame i of the stream is source frame i mod nsrc;
     every key frame is independently decodable).  Host feeder once per source frame, device-to-device copies for the rest."""
@@ -535,6 +558,7 @@ def main():
                 sys.path.insert(0, os.path.join(ROOT, "tools"))
                 import e2e
                 out["config"]["end_to_end"] = e2e.run(P, local_rank, fixture=fixture, nframes=2048)
+                out["config"]["end_to_end"]["c_host"] = batch_md5_probe(fixture, local_rank)
             except Exception as ex:      # a probe, not the benchmark: report, do not fail the line
                 out["config"]["end_to_end"] = {"error": repr(ex)}
         if not args.no_cpu_baseline and world == 1:      # the contract: rank 0 at N = 1 only
