@@ -208,10 +208,14 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
     // a lone DC itself -- vp8_dc_only_idct_add_c, idctllm.c:112-137 -- from the block's first coefficient in its slot, or, with a
     // Y2 block, from the Walsh transform's output, for which nothing is fetched at all)
     auto queue = [&](g_cs16p cf_mb, const int rank0, const u32 m4, const u32 f4, const u32 dcg, const int n0) {
+        // what is fetched, and where it stands (vp8_ir_pack_kernel): luma -- the blocks with more than a DC, among all four blocks of the
+        // phase in a macroblock with a Y2 block, among themselves otherwise (a lone DC came with the descriptor); chroma -- the blocks
+        // with any coefficient
+        const u32 get4 = LUMA ? f4 : m4, s4 = LUMA ? (dcg ? 0xfu : f4) : m4;
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            if (((m4 >> i) & 1) && (((f4 >> i) & 1) || !dcg)) {
-                g_cs16p cfb = cf_mb + (rank0 + __builtin_popcount(m4 & ((1u << i) - 1))) * 16;
+            if ((get4 >> i) & 1) {
+                g_cs16p cfb = cf_mb + (rank0 + __builtin_popcount(s4 & ((1u << i) - 1))) * 16;
                 __builtin_amdgcn_global_load_lds((g_cvp)cfb, (lds_vp)(s_stage + i * 512), 16, 0, 0);
                 __builtin_amdgcn_global_load_lds((g_cvp)(cfb + 8), (lds_vp)(s_stage + i * 512 + 256), 16, 0, 0);
             }
@@ -314,11 +318,11 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
                 m |= (((ge1 * 0x00204081u) >> 21) & 0xfu) << (4 * q);
                 m |= (((ge2 * 0x00204081u) >> 21) & 0xfu) << (16 + 4 * q);
             }
-            // the coded luma blocks in front of the chroma ones, counted into bits 8..12
+            // the luma blocks stored in front of the chroma ones, counted into bits 8..12
             const u32 el[4] = { m0.z, m0.w, m1.x, m1.y };
             u32 nl = 0;
 #pragma unroll
-            for (int q = 0; q < 4; q++) nl += __builtin_popcount((el[q] + 0x7f7f7f7fu) & 0x80808080u);
+            for (int q = 0; q < 4; q++) nl += __builtin_popcount((el[q] + 0x7e7e7e7eu) & 0x80808080u);       // (eob >= 2: see vp8_ir_pack_kernel)
             m |= (has_y2 ? 16u : nl) << 8;
         }
         if (skip) m = 0;
@@ -358,6 +362,12 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
                     dst[0] = (u32x4){ o[0], o[1], o[2], o[3] };
                     dst[1] = (u32x4){ o[4], o[5], o[6], o[7] };
                 }
+            }
+            // without a Y2 block: block 24's place holds the sixteen luma blocks' first coefficients (vp8_ir_pack_kernel) -- the lone DCs
+            if (!has_y2 && !skip) {
+                u32x4 *dst = (u32x4 *)(s_y2dc + lane * 8);
+                dst[0] = y2a;
+                dst[1] = y2b;
             }
         }
     };
@@ -571,7 +581,8 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
                 if (by < 3) {
                     fetch(rr);
                     STAMP(8)
-                    queue(cfp, __builtin_popcount(jm & 0xffffu & ((16u << (4 * by)) - 1)), (jm >> (4 * by + 4)) & 0xf, (jm >> (4 * by + 20)) & 0xf, dc_given, 0);
+                    queue(cfp, __builtin_popcount((dc_given ? 0xffffu : jm >> 16) & 0xffffu & ((16u << (4 * by)) - 1)), (jm >> (4 * by + 4)) & 0xf,
+                          (jm >> (4 * by + 20)) & 0xf, dc_given, 0);
                 } else {
                     // (all of this macroblock's phases have been transformed: its entries of s_tab / s_y2dc are free)
                     u32 n_jm = 0, n_dcg = 0;
@@ -618,7 +629,8 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
                             if (!((rmf >> k) & 1)) {
                                 // a lone DC: (short)(q[0] * dq[0]) (idct_blk.c:34), or the Y2 block's; a1 = (dc + 4) >> 3 on every pixel
                                 const u32 y2w = k < 2 ? y2w0 : y2w1;
-                                const int dc = dc_given ? (short)(y2w >> (16 * (k & 1))) : (short)((short)ra.x * (short)(cur_dq & 0xffff));
+                                const int raw = (short)(y2w >> (16 * (k & 1)));
+                                const int dc = dc_given ? raw : (short)(raw * (short)(cur_dq & 0xffff));
                                 const u32 a1 = (u32)((dc + 4) >> 3) & 0xffffu, a2 = a1 | (a1 << 16);
                                 ra = rb = (u32x4){ a2, a2, a2, a2 };
                             }

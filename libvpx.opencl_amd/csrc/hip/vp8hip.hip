@@ -72,18 +72,24 @@ vp8_ir_expand_kernel(const vp8ir_mb *__restrict__ mbs, const int16_t *__restrict
     *(u32x4 *)(coef + (size_t)mb * VP8IR_COEF_PER_MB + k * 16 + (ch & 1) * 8) = v;
 }
 
-// Packed coefficients: the form vp8_keyframe_kernel reads a key frame's slot in.  The blocks 0..23 of a macroblock that have
-// coefficients (eob >= 1; every luma block of a macroblock with a Y2 block: their DCs come out of it, decodframe.c:262-296) move
-// to the front of its 800 bytes, in block order; the Y2 block stays where it is.  With a third of the blocks coded the dense
-// form makes a kernel fetch four of every five 128-byte lines of the array; packed, it fetches what it uses.  In place, one
-// thread per macroblock: a block only ever moves towards the front, past blocks that have moved already.  `unpack` restores the
-// dense form (zeros where a block has no coefficients) for the kernels that read that.  slots: indices into the slot pool.
-static __device__ __forceinline__ unsigned int vp8_coded_blocks(const vp8ir_mb &m)
+// Packed coefficients: the form vp8_keyframe_kernel / vp8_interframe_kernel read a slot in.  Of a macroblock's blocks 0..23 those a
+// kernel FETCHES move to the front of its 800 bytes, in block order: every luma block of a macroblock with a Y2 block (their DCs
+// come out of it, decodframe.c:262-296), otherwise the luma blocks with more than a DC; the chroma blocks with any coefficient.
+// The Y2 block stays where it is (block 24); in a macroblock WITHOUT one, block 24's place holds the first coefficients of the
+// sixteen luma blocks instead (eob == 1: the lone DC; else 0), which the luma wave gets with the macroblock's descriptor anyway:
+// a lone DC costs two bytes there, not a 32-byte block and its two requests.  With a third of the blocks coded the dense form
+// makes a kernel fetch four of every five 128-byte lines of the array; packed, it fetches what it uses.  In place, one thread per
+// macroblock: a block only ever moves towards the front, past blocks that have moved already.  `unpack` restores the dense form
+// (zeros where a block has no coefficients) for the kernels that read that.  slots: indices into the slot pool.
+static __device__ __forceinline__ unsigned int vp8_stored_blocks(const vp8ir_mb &m, bool &lone_dcs)
 {
+    lone_dcs = false;
     if (m.flags & VP8IR_MB_SKIP) return 0;
+    const bool has_y2 = m.y_mode != VP8IR_B_PRED && m.y_mode != VP8IR_SPLITMV;
     unsigned int mask = 0;
-    for (int k = 0; k < 24; k++) mask |= (unsigned int)(m.eobs[k] >= 1) << k;
-    if (m.y_mode != VP8IR_B_PRED && m.y_mode != VP8IR_SPLITMV) mask |= 0xffffu;
+    for (int k = 0; k < 16; k++) mask |= (unsigned int)(has_y2 || m.eobs[k] >= 2) << k;
+    for (int k = 16; k < 24; k++) mask |= (unsigned int)(m.eobs[k] >= 1) << k;
+    lone_dcs = !has_y2;
     return mask;
 }
 __global__ void __launch_bounds__(256)
@@ -95,17 +101,27 @@ vp8_ir_pack_kernel(char *slot_base, size_t slot_bytes, size_t o_mbs, size_t o_co
     if (si >= nslots) return;
     char *slot = slot_base + slot_bytes * (size_t)slots[si];
     const vp8ir_mb &m = ((const vp8ir_mb *)(slot + o_mbs))[mb];
-    u32x4 *cf = (u32x4 *)((int16_t *)(slot + o_coef) + (size_t)mb * VP8IR_COEF_PER_MB);      // two per block
-    const unsigned int mask = vp8_coded_blocks(m);
+    int16_t *c16 = (int16_t *)(slot + o_coef) + (size_t)mb * VP8IR_COEF_PER_MB;
+    u32x4 *cf = (u32x4 *)c16;      // two per block
+    bool lone;
+    const unsigned int mask = vp8_stored_blocks(m, lone);
     if (!unpack) {
+        int16_t dc[16];
+        if (lone)
+            for (int k = 0; k < 16; k++) dc[k] = m.eobs[k] == 1 ? c16[k * 16] : (int16_t)0;
         int r = 0;
         for (int k = 0; k < 24; k++) {
             if (!((mask >> k) & 1)) continue;
             if (r != k) { const u32x4 a = cf[2 * k], b = cf[2 * k + 1]; cf[2 * r] = a; cf[2 * r + 1] = b; }
             r++;
         }
+        if (lone)
+            for (int k = 0; k < 16; k++) c16[384 + k] = dc[k];
     } else {
         if (m.flags & VP8IR_MB_SKIP) return;
+        int16_t dc[16];
+        if (lone)
+            for (int k = 0; k < 16; k++) dc[k] = c16[384 + k];
         int r = __builtin_popcount(mask);
         for (int k = 23; k >= 0; k--) {
             if (!((mask >> k) & 1)) continue;
@@ -115,6 +131,11 @@ vp8_ir_pack_kernel(char *slot_base, size_t slot_bytes, size_t o_mbs, size_t o_co
         const u32x4 z = { 0, 0, 0, 0 };
         for (int k = 0; k < 24; k++)
             if (!((mask >> k) & 1)) { cf[2 * k] = z; cf[2 * k + 1] = z; }
+        if (lone) {
+            for (int k = 0; k < 16; k++)
+                if (m.eobs[k] == 1) c16[k * 16] = dc[k];
+            cf[48] = z; cf[49] = z;
+        }
     }
 }
 
