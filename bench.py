@@ -56,7 +56,8 @@ PMC_TRAFFIC_B_PER_MB = {        # the loop filter (luma + chroma kernels) writes
 # raster pass + border extension: profiles/r03_b_pmc_{fetch,write}_1024_G8.csv (1024 frames per launch, 8 lanes per strand as at the
 # default launch size; FETCH_SIZE doubled as above).  At 64 lanes per strand -- every SIMD busy, most lanes idle -- the kernel fetches
 # 1270 B/MB (r03_b_pmc_fetch_1024_G64.csv); its writes at 8192 frames per launch: 495 B/MB (r03_b_pmc_write_8192_sharedIR.csv).
-PMC_TRAFFIC_B_PER_MB_FUSED = {"recon": 2 * 406.1 + 467.7, "loopfilter": 0.0, "extend": 2 * 193.8 + 396.5 + 2 * 27.5 + 40.4}
+# End of round 3 (lone luma DCs with the descriptor, 16-byte chroma stores): profiles/r03_g_pmc_{fetch,write}_1024_G8.*
+PMC_TRAFFIC_B_PER_MB_FUSED = {"recon": 2 * 369.5 + 462.3, "loopfilter": 0.0, "extend": 2 * 193.8 + 396.5 + 2 * 27.5 + 40.4}
 PMC_TRAFFIC_B_PER_MB_DETILE = { # tiled -> raster pass (vp8_detile_kernel) after the loop filter
     "recon": 2 * 448.68 + 385.22, "loopfilter": 2 * 239.63 + 414.12, "extend": 2 * 192.08 + 466.87}
 
