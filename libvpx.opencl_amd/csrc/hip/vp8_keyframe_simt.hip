@@ -208,10 +208,9 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
     // a lone DC itself -- vp8_dc_only_idct_add_c, idctllm.c:112-137 -- from the block's first coefficient in its slot, or, with a
     // Y2 block, from the Walsh transform's output, for which nothing is fetched at all)
     auto queue = [&](g_cs16p cf_mb, const int rank0, const u32 m4, const u32 f4, const u32 dcg, const int n0) {
-        // what is fetched, and where it stands (vp8_ir_pack_kernel): luma -- the blocks with more than a DC, among all four blocks of the
-        // phase in a macroblock with a Y2 block, among themselves otherwise (a lone DC came with the descriptor); chroma -- the blocks
-        // with any coefficient
-        const u32 get4 = LUMA ? f4 : m4, s4 = LUMA ? (dcg ? 0xfu : f4) : m4;
+        // what is fetched, and where it stands (vp8_ir_pack_kernel): luma -- the blocks with more than a DC (a lone DC comes out of the Y2
+        // block or came with the descriptor); chroma -- the blocks with any coefficient
+        const u32 get4 = LUMA ? f4 : m4, s4 = get4;
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             if ((get4 >> i) & 1) {
@@ -323,7 +322,7 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
             u32 nl = 0;
 #pragma unroll
             for (int q = 0; q < 4; q++) nl += __builtin_popcount((el[q] + 0x7e7e7e7eu) & 0x80808080u);       // (eob >= 2: see vp8_ir_pack_kernel)
-            m |= (has_y2 ? 16u : nl) << 8;
+            m |= nl << 8;
         }
         if (skip) m = 0;
         jm = m;
@@ -581,7 +580,7 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
                 if (by < 3) {
                     fetch(rr);
                     STAMP(8)
-                    queue(cfp, __builtin_popcount((dc_given ? 0xffffu : jm >> 16) & 0xffffu & ((16u << (4 * by)) - 1)), (jm >> (4 * by + 4)) & 0xf,
+                    queue(cfp, __builtin_popcount((jm >> 16) & 0xffffu & ((16u << (4 * by)) - 1)), (jm >> (4 * by + 4)) & 0xf,
                           (jm >> (4 * by + 20)) & 0xf, dc_given, 0);
                 } else {
                     // (all of this macroblock's phases have been transformed: its entries of s_tab / s_y2dc are free)

@@ -73,8 +73,8 @@ vp8_ir_expand_kernel(const vp8ir_mb *__restrict__ mbs, const int16_t *__restrict
 }
 
 // Packed coefficients: the form vp8_keyframe_kernel / vp8_interframe_kernel read a slot in.  Of a macroblock's blocks 0..23 those a
-// kernel FETCHES move to the front of its 800 bytes, in block order: every luma block of a macroblock with a Y2 block (their DCs
-// come out of it, decodframe.c:262-296), otherwise the luma blocks with more than a DC; the chroma blocks with any coefficient.
+// kernel FETCHES move to the front of its 800 bytes, in block order: the luma blocks with more than a DC (a lone DC comes out of the
+// Y2 block, decodframe.c:262-296, or -- below -- with the descriptor); the chroma blocks with any coefficient.
 // The Y2 block stays where it is (block 24); in a macroblock WITHOUT one, block 24's place holds the first coefficients of the
 // sixteen luma blocks instead (eob == 1: the lone DC; else 0), which the luma wave gets with the macroblock's descriptor anyway:
 // a lone DC costs two bytes there, not a 32-byte block and its two requests.  With a third of the blocks coded the dense form
@@ -87,7 +87,7 @@ static __device__ __forceinline__ unsigned int vp8_stored_blocks(const vp8ir_mb 
     if (m.flags & VP8IR_MB_SKIP) return 0;
     const bool has_y2 = m.y_mode != VP8IR_B_PRED && m.y_mode != VP8IR_SPLITMV;
     unsigned int mask = 0;
-    for (int k = 0; k < 16; k++) mask |= (unsigned int)(has_y2 || m.eobs[k] >= 2) << k;
+    for (int k = 0; k < 16; k++) mask |= (unsigned int)(m.eobs[k] >= 2) << k;
     for (int k = 16; k < 24; k++) mask |= (unsigned int)(m.eobs[k] >= 1) << k;
     lone_dcs = !has_y2;
     return mask;
