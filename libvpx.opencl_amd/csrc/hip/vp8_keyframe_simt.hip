@@ -1,12 +1,14 @@
-// VP8 key frames in ONE pass: reconstruction and in-loop deblocking fused, "one macroblock row per LANE", for gfx950.
+// VP8 frames in ONE pass: reconstruction and in-loop deblocking fused, "one macroblock row per LANE", for gfx950 -- key frames
+// (vp8_keyframe_kernel) and, with the inter macroblocks' prediction taken from where vp8_inter_pred_kernel left it, launches with
+// inter frames (vp8_interframe_kernel).
 //
 // What it replaces (all paths relative to the reference tree): the macroblock loop of vp8_decode_frame
 // (vp8/decoder/decodframe.c:1116-1129 -> decode_mb_row :334 -> decode_macroblock :112, with reconintra.c, reconintra4x4.c,
 // dequantize.c, idctllm.c, idct_blk.c behind it) AND vp8_loop_filter_frame (vp8/common/loopfilter.c:203-316, filters of
 // loopfilter_filters.c) for frames whose macroblocks are all intra.  vp8_recon_simt.hip and vp8_loopfilter_simt.hip do the
 // same work as two kernels with a macroblock-tiled scratch frame between them; here a lane reconstructs a macroblock and
-// filters it in the same step, the pixels never leave its registers in between, and the finished rows go straight to the
-// raster frame buffer:
+// filters it in the same step, the pixels never leave its registers in between, and the finished rows go out once, into
+// macroblock-window tiles (below) that a small pass turns into the raster frame buffer:
 //
 //   * the schedule is that of the two kernels (they already shared it): lane p owns macroblock rows p, p+G, ... of a
 //     strand of frames and runs two macroblocks behind lane p-1, so that prediction (left, above, above-right, all
@@ -107,17 +109,18 @@ __device__ __forceinline__ void frame_levels_inter(const vp8ir_frame_hdr &h, u32
 
 
 // ---------------------------------------------------------------------------------------------------------------------
-// The two kernels: vp8_keyframe_luma_kernel and vp8_keyframe_chroma_kernel, launched side by side on two streams.  Luma and
-// chroma of an intra frame share nothing but the macroblock descriptors (separate planes of the frame buffer, separate
-// lines of the hand-over tile), and a luma wave and a chroma wave together fit one SIMD -- registers (VGPRs + AGPRs of both
-// <= 512) and LDS (both <= 40 KB) --, so every SIMD has two instruction streams to issue from: what one stalls on (LDS and
-// memory round trips, scalar / branch bubbles; a lone wave of this kind of code keeps the vector ALU busy less than half
-// the time) the other fills.
+// The two ROLES of a wave of vp8_keyframe_kernel / vp8_interframe_kernel (kf_body<LUMA, INTER>; the kernels at the end of the file
+// deal them out, a luma and a chroma wave to every SIMD).  Luma and chroma of a frame share nothing but the macroblock descriptors
+// (separate rows of the macroblock's tile, separate lines of the hand-over tile), and a luma wave and a chroma wave together fit one
+// SIMD -- registers (256 each) and LDS (19 KB each) --, so every SIMD has two instruction streams to issue from: what one stalls
+// on (LDS and memory round trips, scalar / branch bubbles; a lone wave of this kind of code keeps the vector ALU busy less than
+// half the time) the other fills.
 //
-// grid = waves (one wave per block); lgG, P, nstrands as in vp8_recon_simt_kernel.  Every job must be a key frame.  The frames
-// go to the jobs' raster frame buffers (DevJob::dst, borders not included: vp8_extend_kernel); DevJob::tile is the hand-over
-// scratch of the strands' last lanes.  `dummy`: 512 bytes of scratch nobody reads (idle lanes store there: the stores of the
-// step loop are unconditional, see vp8_recon_simt.hip on s_waitcnt).
+// lgG, P, nstrands as in vp8_recon_simt_kernel.  The frames go to the jobs' macroblock-window tiles (DevJob::tile, layout above;
+// vp8_detile_kf_kernel + vp8_extend_kernel make the raster frame buffers of them), which are the hand-over scratch of the strands'
+// last lanes too.  `dummy`: scratch nobody reads (idle lanes store there: the stores of the step loop are unconditional, see
+// vp8_recon_simt.hip on s_waitcnt).  INTER: launches with inter frames -- a macroblock with a reference frame takes its prediction
+// out of its own tile, where vp8_inter_pred_kernel left it (see vp8_interframe_kernel below).
 //
 // The residual transform is the cooperative one of vp8_recon_simt.hip on a diet, so that two waves' worth fits: a PHASE is
 // the four blocks the owner consumes next (luma: a block row; chroma: a plane); the lanes queue their blocks with
@@ -130,7 +133,7 @@ __device__ __forceinline__ void frame_levels_inter(const vp8ir_frame_hdr &h, u32
 //   s_stage  [block of the phase][half][lane] 16 B: the owner's coefficients in, residuals out     8192 B
 //   s_queue  owner lane | block in phase << 6 | DC given << 8                 512 B
 //   s_tab    per owner: quantiser (dc | ac << 16)                             256 B
-//   s_y2dc   per owner: the sixteen luma DCs out of the Y2 block (luma)      2048 B
+//   s_y2dc   per owner: the sixteen luma DCs out of the Y2 block, or -- no Y2 block -- the luma blocks' first coefficients (luma)   2048 B
 //   s_desc   [piece][lane] 16 B: the next macroblock's descriptor (luma 5 pieces, chroma 2)   5120 B
 //   s_sf     [row][lane]: the last four pixels (filtered, biased) of pixel rows of the macroblock to the left -- luma rows 0..11,
 //            chroma U rows 0..3, V rows 0..3 (the bottom four rows' are in registers: they double as the lane below's context).
