@@ -201,3 +201,51 @@ def test_mixed_launch_sizes_chained_without_sync(pkg, monkeypatch, sizes):
         parser.close()
     finally:
         ctx.close()
+
+
+def test_key_and_inter_frames_in_one_launch(pkg, monkeypatch):
+    """One launch of the prediction kernel + vp8_interframe_kernel with key frames AND inter frames among its jobs (streams at
+    different points: some start over with their key frame while the others decode a P frame): the key frames go the key-frame way
+    inside the inter-frame kernel, nobody's tiles or references get mixed up."""
+    P = pkg
+    for k in ("VP8HIP_FUSED", "VP8HIP_LF_RASTER", "VP8HIP_INTER_TILED", "VP8HIP_INTER_SPLIT", "VP8HIP_INTER_FUSED"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv("VP8HIP_RECON", "simt")
+    name, n = "p_dense_1920x1080", 12
+    w, h, frames = P.read_ivf(ivf_path(name))
+    gold = golden_md5(name)
+    ctx = P.Vp8Hip(0)
+    try:
+        ctx.configure(w, h, 4 * n, 3)
+        parser = P.Parser()
+        plan = []
+        for f in range(3):
+            hdr = ctx.parse_into_slot(parser, frames[f], f)
+            ctx.upload(f)
+            r = parser.refs
+            plan.append((hdr.frame_type, r.new_idx, (r.lst_idx, r.gld_idx, r.alt_idx)))
+            parser.swap(hdr)
+
+        def job(j, i, f):
+            ftype, new_idx, refs = plan[f]
+            j.ir_slot, j.dst_fb = f, 4 * i + new_idx
+            for q in range(3):
+                j.ref_fb[1 + q] = 4 * i + refs[q] if ftype else -1
+
+        for f in (0, 1):                                      # all streams up to frame 1
+            jobs = (P.Job * n)()
+            for i in range(n):
+                job(jobs[i], i, f)
+            ctx.decode_array(jobs, n, P.STAGE_ALL)
+        jobs = (P.Job * n)()                                  # odd streams: frame 2 (inter); even streams: frame 0 again (key)
+        for i in range(n):
+            job(jobs[i], i, 2 if i & 1 else 0)
+        ctx.decode_array(jobs, n, P.STAGE_ALL)
+        assert ctx.stats().fused == 1
+        ctx.sync()
+        for i in range(n):
+            f = 2 if i & 1 else 0
+            assert P.planes_md5(*ctx.download_planes(4 * i + plan[f][1])) == gold[f], i
+        parser.close()
+    finally:
+        ctx.close()
