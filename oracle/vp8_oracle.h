@@ -88,6 +88,8 @@ void vp8o_plane_add_noise(unsigned char *plane, const signed char *noise, int cl
                           const unsigned char *row_offset);
 void vp8o_pp_strengths(int filter_level, int deblocking_level, int *q, int *ppl, int *ppl_demacro, int *mb_flimit);
 void vp8o_pp_noise_table(int q, int a, const unsigned char *r, signed char noise[3072], int *clamp);
+void vp8o_mfqe(const vp8ir_frame_hdr *hdr, const vp8ir_geom *g, const vp8ir_mb *mbs, const vp8ir_mv *mvs,
+               const unsigned char *show, unsigned char *dest, int qcurr, int qprev);
 
 void vp8o_mb_dequant(const vp8ir_frame_hdr *h, int segment_id, vp8o_dequant *dq);
 void vp8o_lf_levels(const vp8ir_frame_hdr *h, unsigned char lvl[4][4][4]);

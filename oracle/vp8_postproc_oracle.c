@@ -142,3 +142,99 @@ void vp8o_pp_noise_table(int q, int a, const unsigned char *r, signed char noise
     for (int i = 0; i < 3072; i++) noise[i] = dist[r[i]];
     *clamp = -dist[0];
 }
+
+/* ---- multiframe quality enhancement (VP8_MFQE) ------------------------------------------------------------------------------
+ * postproc.c:696-800 (multiframe_quality_enhance_block) for one luma block of `bs` x `bs` pixels (16 or 8) and the chroma
+ * blocks of half that size under it: `y`, `u`, `v` the frame about to be shown, `yd`, `ud`, `vd` the post-processing buffer,
+ * which still holds what was shown before.  Where the two differ little for the activity of the old picture and the step in
+ * quantiser, the old picture is kept or blended with the new one; elsewhere the new one is copied.
+ * The activity is vp8_variance16x16 / 8x8 against a row of zeros (encoder/variance_c.c:34-79,115-127): sum of squares minus
+ * sum * sum >> 8 (>> 6), and the reference forms sum * sum in a signed int.  A 16x16 block brighter than 181 on average
+ * overflows it; the reference build wraps (two's complement imul, arithmetic shift), which is restated here and what the
+ * listings printed by that build pin. */
+static void mfqe_block(int bs, int qcurr, int qprev, const unsigned char *y, const unsigned char *u, const unsigned char *v,
+                       int y_stride, int uv_stride, unsigned char *yd, unsigned char *ud, unsigned char *vd, int yd_stride,
+                       int uvd_stride)
+{
+    const int half = bs >> 1, qdiff = qcurr - qprev;
+    const int sh = bs == 16 ? 8 : 6, rnd = 1 << (sh - 1);
+    unsigned int sse = 0, sad = 0, act, thr;
+    int sum = 0;
+    for (int i = 0; i < bs; i++)
+        for (int j = 0; j < bs; j++) {
+            const int d = yd[i * yd_stride + j];
+            sum += d;
+            sse += (unsigned)(d * d);
+            sad += (unsigned)iabs(y[i * y_stride + j] - d);
+        }
+    {
+        const int sq = (int)((unsigned)sum * (unsigned)sum);         /* avg * avg in an int: wraps for sum >= 46341 */
+        const int sq_sh = sq >= 0 ? sq >> sh : -((-(long)sq + (1L << sh) - 1) >> sh);     /* arithmetic shift, spelled out */
+        act = (sse - (unsigned)sq_sh + (unsigned)rnd) >> sh;
+    }
+    sad = (sad + (unsigned)rnd) >> sh;
+    thr = (unsigned)(qdiff >> 3);                                    /* thr = qdiff / 8 + log2(act) + log4(qprev) */
+    while (act >>= 1) thr++;
+    while (qprev >>= 2) thr++;
+    if (sad < thr) {
+        int ifactor = (int)((sad << 4) / thr);
+        ifactor >>= (qdiff >> 5);
+        if (ifactor) {
+            const int ic = 16 - ifactor;
+            for (int i = 0; i < bs; i++)
+                for (int j = 0; j < bs; j++)
+                    yd[i * yd_stride + j] = (unsigned char)((y[i * y_stride + j] * ifactor + yd[i * yd_stride + j] * ic + 8) >> 4);
+            for (int i = 0; i < half; i++)
+                for (int j = 0; j < half; j++) {
+                    ud[i * uvd_stride + j] = (unsigned char)((u[i * uv_stride + j] * ifactor + ud[i * uvd_stride + j] * ic + 8) >> 4);
+                    vd[i * uvd_stride + j] = (unsigned char)((v[i * uv_stride + j] * ifactor + vd[i * uvd_stride + j] * ic + 8) >> 4);
+                }
+        }                                                            /* ifactor 0: the old picture stays */
+    } else {
+        for (int i = 0; i < bs; i++)
+            for (int j = 0; j < bs; j++) yd[i * yd_stride + j] = y[i * y_stride + j];
+        for (int i = 0; i < half; i++)
+            for (int j = 0; j < half; j++) {
+                ud[i * uvd_stride + j] = u[i * uv_stride + j];
+                vd[i * uvd_stride + j] = v[i * uv_stride + j];
+            }
+    }
+}
+
+/* vp8_multiframe_quality_enhance (postproc.c:802-900) over frame buffers laid out by vp8ir_geom: `show` the decoded frame,
+ * `dest` the post-processing buffer (in place).  Per macroblock: key frames and macroblocks that moved by at most 10 (in the
+ * units the vectors are stored in) in both directions are enhanced -- B_PRED and SPLITMV macroblocks as four 8x8 blocks, the
+ * others whole -- the rest is copied.  mbs / mvs: the frame's IR (mvs may be NULL on key frames; the macroblock's vector is
+ * that of its last block: decodemv.c:490, and zero for intra macroblocks, :563). */
+void vp8o_mfqe(const vp8ir_frame_hdr *hdr, const vp8ir_geom *g, const vp8ir_mb *mbs, const vp8ir_mv *mvs,
+               const unsigned char *show, unsigned char *dest, int qcurr, int qprev)
+{
+    for (int r = 0; r < hdr->mb_rows; r++)
+        for (int c = 0; c < hdr->mb_cols; c++) {
+            const int n = r * hdr->mb_cols + c;
+            const long yo = g->y_off + (long)16 * r * g->y_stride + 16 * c, uo = (long)8 * r * g->uv_stride + 8 * c;
+            const unsigned char *y = show + yo, *u = show + g->u_off + uo, *v = show + g->v_off + uo;
+            unsigned char *yd = dest + yo, *ud = dest + g->u_off + uo, *vd = dest + g->v_off + uo;
+            int still = hdr->frame_type == 0;
+            if (!still) {
+                const int mr = mbs[n].ref_frame == VP8IR_INTRA_FRAME ? 0 : mvs[n * 16 + 15].row;
+                const int mc = mbs[n].ref_frame == VP8IR_INTRA_FRAME ? 0 : mvs[n * 16 + 15].col;
+                still = iabs(mr) <= 10 && iabs(mc) <= 10;
+            }
+            if (!still) {
+                for (int i = 0; i < 16; i++) for (int j = 0; j < 16; j++) yd[i * g->y_stride + j] = y[i * g->y_stride + j];
+                for (int i = 0; i < 8; i++)
+                    for (int j = 0; j < 8; j++) {
+                        ud[i * g->uv_stride + j] = u[i * g->uv_stride + j];
+                        vd[i * g->uv_stride + j] = v[i * g->uv_stride + j];
+                    }
+            } else if (mbs[n].y_mode == VP8IR_B_PRED || mbs[n].y_mode == VP8IR_SPLITMV) {
+                for (int i = 0; i < 2; i++)
+                    for (int j = 0; j < 2; j++)
+                        mfqe_block(8, qcurr, qprev, y + 8 * (i * g->y_stride + j), u + 4 * (i * g->uv_stride + j),
+                                   v + 4 * (i * g->uv_stride + j), g->y_stride, g->uv_stride, yd + 8 * (i * g->y_stride + j),
+                                   ud + 4 * (i * g->uv_stride + j), vd + 4 * (i * g->uv_stride + j), g->y_stride, g->uv_stride);
+            } else
+                mfqe_block(16, qcurr, qprev, y, u, v, g->y_stride, g->uv_stride, yd, ud, vd, g->y_stride, g->uv_stride);
+        }
+}

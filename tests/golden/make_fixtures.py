@@ -181,9 +181,11 @@ def ref_controls(name):
 # vp8_postproc_cfg_t {post_proc_flag, deblocking_level, noise_level} handed to the REFERENCE decoder by oracle/ref_md5 --pp
 # (flags: VP8_DEBLOCK 1, VP8_DEMACROBLOCK 2, VP8_ADDNOISE 4, vpx/vp8.h:55-66).  The dither and noise phases come from the C
 # library's unseeded rand(), which every run of the reference binary sees in the same state.
-# Not recorded: VP8_MFQE, which is also part of the reference's default configuration (vp8_dx_iface.c:421-431).  The
-# reference dies with SIGSEGV in that path on four of these six streams (`vpxdec --postproc` as well as ref_md5 --pp -1 0 0),
-# so there is nothing to pin a restatement to.
+# VP8_MFQE (1024; also part of the reference's default configuration, vp8_dx_iface.c:421-431): alone it works on every
+# stream; together with VP8_DEBLOCK / VP8_DEMACROBLOCK the reference dies with SIGSEGV on the first shown frame of every stream
+# whose width or height is not a multiple of 16 (the intermediate buffer is allocated with the display size, which
+# vp8_yv12_alloc_frame_buffer refuses, and then cleared through its null pointer: postproc.c:929-941), `vpxdec --postproc`
+# included -- so those combinations are recorded for the 16-aligned streams only (MFQE_FILTER_STREAMS).
 PP_CONFIGS = {
     "deblock": (1, 0, 0),
     "demacro4": (2, 4, 0),
@@ -194,16 +196,23 @@ PP_CONFIGS = {
     "demacro6_noise2": (6, 6, 2),
 }
 PP_STREAMS = ("p_arf_176x144", "p_lowrate_640x360", "kf_odd_67x45", "p_odd_130x98", "p_sharp_320x240", "kf_640x360")
+MFQE_CONFIGS = {"mfqe": (1024, 0, 0), "mfqe_noise3": (1028, 0, 3)}
+MFQE_STREAMS = PP_STREAMS + ("p_split_352x288", "p_prof1_640x360", "kf_1920x1080")
+MFQE_FILTER_CONFIGS = {"default": (1027, 4, 0), "mfqe_deblock": (1025, 0, 0), "mfqe_demacro4": (1026, 4, 0),
+                       "mfqe_deblock_noise1": (1029, 0, 1), "mfqe_demacro6_noise2": (1030, 6, 2)}
+MFQE_FILTER_STREAMS = ("p_arf_176x144", "p_sharp_320x240", "p_split_352x288")
 
 
-def postproc_md5(name):
-    for tag, (flags, level, noise) in PP_CONFIGS.items():
+def postproc_md5(name, configs=PP_CONFIGS):
+    for tag, (flags, level, noise) in configs.items():
         out = os.path.join(HERE, f"{name}.pp_{tag}.md5")
         run([REFMD5, "--pp", str(flags), str(level), str(noise), os.path.join(HERE, name + ".ivf"), out])
 
 
 PP_CLI = (("p_arf_176x144", ["--deblock"]), ("p_arf_176x144", ["--demacroblock-level=6", "--noise-level=2"]),
-          ("p_lowrate_640x360", ["--demacroblock-level=3"]), ("p_odd_130x98", ["--noise-level=4", "--deblock"]))
+          ("p_lowrate_640x360", ["--demacroblock-level=3"]), ("p_odd_130x98", ["--noise-level=4", "--deblock"]),
+          ("p_arf_176x144", ["--postproc"]), ("p_split_352x288", ["--mfqe", "--deblock"]), ("p_odd_130x98", ["--mfqe"]),
+          ("p_lowrate_640x360", ["--mfqe", "--noise-level=2"]))
 
 
 def webm_fixture():
@@ -229,6 +238,10 @@ def main():
     if "--postproc" in sys.argv:
         for name in PP_STREAMS:
             postproc_md5(name)
+        for name in MFQE_STREAMS:
+            postproc_md5(name, MFQE_CONFIGS)
+        for name in MFQE_FILTER_STREAMS:
+            postproc_md5(name, MFQE_FILTER_CONFIGS)
         # the reference's vpxdec with its own option names: one digest over all post-processed frames
         with open(os.path.join(HERE, "postproc.pp_vpxdec_md5"), "w") as f:
             for name, args in PP_CLI:

@@ -51,6 +51,15 @@ def test_fixture_matrix_covers_the_paths(pkg):
 PP_CONFIGS = {"deblock": (1, 0, 0), "demacro4": (2, 4, 0), "demacro9": (2, 9, 0), "demacro0": (3, 0, 0), "noise3": (4, 0, 3),
               "deblock_noise1": (5, 0, 1), "demacro6_noise2": (6, 6, 2)}
 PP_STREAMS = ("p_arf_176x144", "p_lowrate_640x360", "kf_odd_67x45", "p_odd_130x98", "p_sharp_320x240", "kf_640x360")
+# VP8_MFQE (1024): alone on any stream; with the deblocking filters the reference only survives 16-aligned sizes
+# (tests/golden/make_fixtures.py)
+MFQE_CONFIGS = {"mfqe": (1024, 0, 0), "mfqe_noise3": (1028, 0, 3)}
+MFQE_STREAMS = PP_STREAMS + ("p_split_352x288", "p_prof1_640x360", "kf_1920x1080")
+MFQE_FILTER_CONFIGS = {"default": (1027, 4, 0), "mfqe_deblock": (1025, 0, 0), "mfqe_demacro4": (1026, 4, 0),
+                       "mfqe_deblock_noise1": (1029, 0, 1), "mfqe_demacro6_noise2": (1030, 6, 2)}
+MFQE_FILTER_STREAMS = ("p_arf_176x144", "p_sharp_320x240", "p_split_352x288")
+MFQE_CASES = [(n, t, MFQE_CONFIGS[t]) for n in MFQE_STREAMS for t in MFQE_CONFIGS] + \
+             [(n, t, MFQE_FILTER_CONFIGS[t]) for n in MFQE_FILTER_STREAMS for t in MFQE_FILTER_CONFIGS]
 
 
 def golden_pp_md5(name, tag):
@@ -64,3 +73,15 @@ def golden_pp_md5(name, tag):
 def test_postproc_fixture_md5(name, tag):
     from vp8_testlib import oracle_postproc_ivf
     assert oracle_postproc_ivf(name, *PP_CONFIGS[tag]) == golden_pp_md5(name, tag)
+
+
+@pytest.mark.parametrize("name,tag,cfg", MFQE_CASES, ids=[f"{n}-{t}" for n, t, _ in MFQE_CASES])
+def test_mfqe_fixture_md5(name, tag, cfg):
+    """vp8_multiframe_quality_enhance and vp8_post_proc_frame's use of it (postproc.c:802-900, 929-969), restated in
+    oracle/vp8_postproc_oracle.c and tests/vp8_testlib.py, against what the reference decoder showed."""
+    from vp8_testlib import oracle_postproc_ivf
+    gold = golden_pp_md5(name, tag)
+    assert oracle_postproc_ivf(name, *cfg) == gold
+    if tag == "mfqe" and name != "kf_odd_67x45":     # the fixtures do exercise the path (all but the one whose quantiser never rises)
+        from vp8_testlib import golden_md5
+        assert gold != golden_md5(name)

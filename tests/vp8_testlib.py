@@ -233,13 +233,15 @@ def random_frame(g, seed):
 # ------------------------------------------------------------------------------------------
 # output-side post-processing: vp8_post_proc_frame (vp8/common/postproc.c:903-1000) over the oracle's filters
 # ------------------------------------------------------------------------------------------
-PP_DEBLOCK, PP_DEMACROBLOCK, PP_ADDNOISE = 1, 2, 4
+PP_DEBLOCK, PP_DEMACROBLOCK, PP_ADDNOISE, PP_MFQE = 1, 2, 4, 1024
 
 
 class OraclePostproc:
-    """One decoder's post-processing state.  rand() is the C library's, drawn in the reference's order: once per
-    demacroblocked frame (postproc.c:286), 3072 times per noise table (:456) and once per noisy row (:499).  Call
-    libc.srand(1) first to be in the state a fresh process (the reference's vpxdec) is in."""
+    """One decoder's post-processing state (vp8_post_proc_frame, postproc.c:903-1000).  rand() is the C library's, drawn in the
+    reference's order: once per demacroblocked frame (postproc.c:286), 3072 times per noise table (:456) and once per noisy row
+    (:499).  Call libc.srand(1) first to be in the state a fresh process (the reference's vpxdec) is in.  With PP_MFQE the
+    caller passes the frame's header and IR as well: the buffer that was shown before is blended into frames whose quantiser
+    index is 10 or more above the running one (:948-969)."""
 
     def __init__(self, flags, deblocking_level, noise_level):
         self.flags, self.level, self.noise_level = flags, deblocking_level, noise_level
@@ -247,27 +249,59 @@ class OraclePostproc:
         self.noise = np.zeros(3072, np.int8)
         self.clamp = 0
         self.libc = ctypes.CDLL(None)
+        self.shown = 0                   # cm->current_video_frame when the frame is post-processed (onyxd_if.c:646-647)
+        self.last_base_qindex = 0        # postproc_state.last_base_qindex
+        self.post = None                 # post_proc_buffer
+        self.mfqe_frames = 0
 
-    def frame(self, buf, g, filter_level):
+    def _filters(self, src, post, g, ppl, ppl_dm, mbl):
+        O = oracle()
+        ci, vp = ctypes.c_int, ctypes.c_void_p
+        planes = _pp_planes(g)
+        lim = ppl_dm if self.flags & PP_DEMACROBLOCK else ppl
+        for off, stride, rows, cols in planes:
+            O.vp8o_post_proc_down_and_across(vp(src.ctypes.data + off), vp(post.ctypes.data + off), ci(stride), ci(stride),
+                                             ci(rows), ci(cols), ci(lim))
+        if self.flags & PP_DEMACROBLOCK:
+            off, stride, rows, cols = planes[0]
+            tmp = post.copy()
+            O.vp8o_mbpost_proc_across(vp(post.ctypes.data + off), vp(tmp.ctypes.data + off), ci(stride), ci(rows), ci(cols), ci(mbl))
+            rv = self.libc.rand() & 63
+            O.vp8o_mbpost_proc_down(vp(tmp.ctypes.data + off), vp(post.ctypes.data + off), ci(stride), ci(rows), ci(cols),
+                                    ci(mbl), ci(rv))
+
+    def frame(self, buf, g, filter_level, hdr=None, mbs=None, mvs=None):
         O = oracle()
         ci, vp = ctypes.c_int, ctypes.c_void_p
         q, ppl, ppl_dm, mbl = (ctypes.c_int() for _ in range(4))
         O.vp8o_pp_strengths(ci(filter_level), ci(self.level), ctypes.byref(q), ctypes.byref(ppl), ctypes.byref(ppl_dm), ctypes.byref(mbl))
-        post = buf.copy()
-        planes = ((g.y_off, g.y_stride, g.aligned_h, g.aligned_w), (g.u_off, g.uv_stride, g.aligned_h // 2, g.aligned_w // 2),
-                  (g.v_off, g.uv_stride, g.aligned_h // 2, g.aligned_w // 2))
-        if self.flags & (PP_DEBLOCK | PP_DEMACROBLOCK):
-            lim = ppl_dm.value if self.flags & PP_DEMACROBLOCK else ppl.value
-            for off, stride, rows, cols in planes:
-                O.vp8o_post_proc_down_and_across(vp(buf.ctypes.data + off), vp(post.ctypes.data + off), ci(stride), ci(stride),
-                                                 ci(rows), ci(cols), ci(lim))
-            if self.flags & PP_DEMACROBLOCK:
-                off, stride, rows, cols = planes[0]
-                tmp = post.copy()
-                O.vp8o_mbpost_proc_across(vp(post.ctypes.data + off), vp(tmp.ctypes.data + off), ci(stride), ci(rows), ci(cols), ci(mbl.value))
-                rv = self.libc.rand() & 63
-                O.vp8o_mbpost_proc_down(vp(tmp.ctypes.data + off), vp(post.ctypes.data + off), ci(stride), ci(rows), ci(cols),
-                                        ci(mbl.value), ci(rv))
+        planes = _pp_planes(g)
+        self.shown += 1
+        if self.post is None or self.post.size != buf.size:
+            self.post = np.zeros(buf.size, np.uint8)
+        post = self.post
+        base_q = hdr.base_qindex if hdr is not None else 0
+        filtering = self.flags & (PP_DEBLOCK | PP_DEMACROBLOCK)
+        if (self.flags & PP_MFQE) and hdr is not None and self.shown >= 2 and base_q - self.last_base_qindex >= 10:
+            G = (ctypes.c_int * 10)(*[getattr(g, n) for n, _ in g._fields_])
+            O.vp8o_mfqe(ctypes.byref(hdr), G, vp(mbs.ctypes.data), vp(mvs.ctypes.data if mvs is not None else None),
+                        vp(buf.ctypes.data), vp(post.ctypes.data), ci(base_q), ci(self.last_base_qindex))
+            self.mfqe_frames += 1
+            if filtering:                # post_proc_buffer -> post_proc_buffer_int (with borders, yv12extend.c:224-260) -> filters
+                mid = post.copy()
+                for off, stride, rows, cols in planes:
+                    for k in (1, 2):
+                        mid[off - k * stride:off - k * stride + cols] = mid[off:off + cols]
+                        e = off + (rows - 1) * stride
+                        mid[e + k * stride:e + k * stride + cols] = mid[e:e + cols]
+                self._filters(mid, post, g, ppl.value, ppl_dm.value, mbl.value)
+            self.last_base_qindex = (3 * self.last_base_qindex + base_q) >> 2
+        else:
+            if filtering:
+                self._filters(buf, post, g, ppl.value, ppl_dm.value, mbl.value)
+            else:
+                post[:] = buf
+            self.last_base_qindex = base_q
         if self.flags & PP_ADDNOISE:
             if self.last_q != q.value or self.last_noise != self.noise_level:      # :988-993; fillrd stores ITS q = 63 - q
                 r = np.array([self.libc.rand() & 0xff for _ in range(3072)], np.uint8)
@@ -279,7 +313,12 @@ class OraclePostproc:
             offs = np.array([self.libc.rand() & 0xff for _ in range(rows)], np.uint8)
             O.vp8o_plane_add_noise(vp(post.ctypes.data + off), vp(self.noise.ctypes.data), ci(self.clamp), ci(cols), ci(rows), ci(stride),
                                    vp(offs.ctypes.data))
-        return post
+        return post.copy()
+
+
+def _pp_planes(g):
+    return ((g.y_off, g.y_stride, g.aligned_h, g.aligned_w), (g.u_off, g.uv_stride, g.aligned_h // 2, g.aligned_w // 2),
+            (g.v_off, g.uv_stride, g.aligned_h // 2, g.aligned_w // 2))
 
 
 def oracle_postproc_ivf(name, flags, level, noise):
@@ -292,5 +331,5 @@ def oracle_postproc_ivf(name, flags, level, noise):
     for hdr, mbs, coef, mvs, frame in kept:
         if hdr.show_frame:
             g = P.geom(hdr.width, hdr.height)
-            out.append(P.frame_md5(pp.frame(frame, g, hdr.filter_level), g, hdr.width, hdr.height))
+            out.append(P.frame_md5(pp.frame(frame, g, hdr.filter_level, hdr, mbs, mvs), g, hdr.width, hdr.height))
     return out
