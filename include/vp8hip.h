@@ -117,7 +117,9 @@ int  vp8hip_frame_download(vp8hip_ctx *ctx, int fb, int full, uint8_t *y, uint8_
  *                           unchanged since the previous call), noise_clamp = its blackclamp[0], noise_rows[r] = rand() & 0xff
  *                           per row of the 16-aligned height.  Frames wider than 2816 are refused: the reference indexes
  *                           past the end of its table for them.
- * With neither of the first two flags dst_fb becomes a copy of src_fb (:982).  Asynchronous on the context's stream like
+ * With neither of the first two flags dst_fb becomes a copy of src_fb (:982), or, with dst_fb == src_fb, stays what it is (the
+ * noise alone, in place: after vp8hip_mfqe).  The filters read nothing outside the pictures' coded area (rows above and below
+ * are the edge rows, as a frame's borders would say).  Asynchronous on the context's stream like
  * vp8hip_decode; the host arrays may be reused when the call returns. */
 #define VP8HIP_PP_DEBLOCK       1
 #define VP8HIP_PP_DEMACROBLOCK  2
@@ -133,6 +135,16 @@ typedef struct vp8hip_pp {
     const uint8_t *noise_rows;
 } vp8hip_pp;
 int  vp8hip_postproc(vp8hip_ctx *ctx, int src_fb, int dst_fb, int tmp_fb, const vp8hip_pp *pp);
+/* VP8_MFQE, vp8_multiframe_quality_enhance (postproc.c:802-900): the frame about to be shown (show_fb) against the picture that
+ * was shown before it (prev_fb: the output of the previous call chain, noise and all), macroblock by macroblock -- where the two
+ * differ little for the old picture's activity and the step from qprev to qcurr the old picture is kept or blended in (it was
+ * coded with the finer quantiser), elsewhere the new one is copied -- into dst_fb, which may be prev_fb.  mb_class: a byte per
+ * macroblock in raster order, 0 = copy (inter frame, a vector component above 10: :836-841), 1 = one 16x16 block, 2 = four 8x8
+ * blocks (B_PRED, SPLITMV: :843).  When to call it is the caller's policy, as for the filters (vp8_post_proc_frame :948-969:
+ * from the second shown frame on, when base_qindex is 10 or more above the running last_base_qindex; the filters then run on
+ * its output: vp8hip_postproc(dst_fb -> prev_fb), or with src_fb == dst_fb for the noise alone).  qprev <= qcurr <= 127.
+ * Asynchronous on the context's stream; mb_class may be reused when the call returns. */
+int  vp8hip_mfqe(vp8hip_ctx *ctx, int show_fb, int prev_fb, int dst_fb, const uint8_t *mb_class, int qcurr, int qprev);
 
 /* Batch form for pipelines (tools/e2e.py, bin/batch_md5): `count` consecutive frame buffers, whole, as ONE asynchronous copy on
  * a stream of its own -- it starts when everything queued on the context's stream so far has finished and runs beside later

@@ -288,6 +288,7 @@ def load_hip():
         L.vp8hip_stream.argtypes = [c_void_p]
         L.vp8hip_stream.restype = c_void_p
         L.vp8hip_postproc.argtypes = [c_void_p, c_int, c_int, c_int, ctypes.POINTER(PostprocParams)]
+        L.vp8hip_mfqe.argtypes = [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int]
         _hip = L
     return _hip
 
@@ -429,6 +430,15 @@ class Vp8Hip:
                             noise.ctypes.data if noise is not None else None,
                             noise_rows.ctypes.data if noise_rows is not None else None)
         self._chk(self.L.vp8hip_postproc(self.h, src_fb, dst_fb, tmp_fb, ctypes.byref(pp)), "postproc")
+
+    def mfqe(self, show_fb, prev_fb, dst_fb, mb_class, qcurr, qprev):
+        """vp8_multiframe_quality_enhance (postproc.c:802-900; include/vp8hip.h): mb_class a uint8 array, a byte per macroblock."""
+        mb_class = np.ascontiguousarray(mb_class, np.uint8)
+        assert mb_class.size == self.g_mbs()
+        self._chk(self.L.vp8hip_mfqe(self.h, show_fb, prev_fb, dst_fb, mb_class.ctypes.data, qcurr, qprev), "mfqe")
+
+    def g_mbs(self):
+        return (self.g.aligned_w // 16) * (self.g.aligned_h // 16)
 
 
 def decode_ivf_gpu(path, device=-1, stages=STAGE_ALL):

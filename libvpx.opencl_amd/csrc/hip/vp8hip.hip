@@ -45,6 +45,8 @@ extern "C" __global__ void vp8_detile_kf_kernel(const DevJob *jobs, int njobs, D
 void vp8pp_down_and_across(hipStream_t st, const uint8_t *src, uint8_t *dst, int stride, int rows, int cols, int flimit);
 void vp8pp_mb_across(hipStream_t st, const uint8_t *src, uint8_t *dst, int stride, int rows, int cols, int flimit);
 void vp8pp_mb_down(hipStream_t st, const uint8_t *src, uint8_t *dst, int stride, int rows, int cols, int flimit, const short *rv);
+void vp8pp_mfqe(hipStream_t st, const uint8_t *show, const uint8_t *prev, uint8_t *out, const DevGeom &g, const uint8_t *cls,
+                int qcurr, int qprev);
 void vp8pp_add_noise(hipStream_t st, uint8_t *plane, int stride, int rows, int cols, int clamp, const signed char *noise,
                      const uint8_t *row_offset);
 
@@ -266,6 +268,7 @@ struct vp8hip_ctx {
     hipStream_t stream3; hipEvent_t ev_split_from, ev_split_done;     // chroma half of the split lane-per-row loop filter
     // vp8hip_postproc: dither table (440 shorts), noise table (3072) and per-row noise phases (16384) on the device
     char *d_pp, *h_pp; bool pp_rv_loaded; hipEvent_t ev_pp;
+    uint8_t *d_mfqe, *h_mfqe; int mfqe_cap; hipEvent_t ev_mfqe;     // vp8hip_mfqe: the macroblock classes of the frame
     unsigned int *d_sched;         // vp8_keyframe_kernel's role / work counters
     int *h_pack, *d_pack; int pack_cap;      // slots whose coefficients a launch has to pack / unpack first
 };
@@ -410,6 +413,9 @@ extern "C" void vp8hip_destroy(vp8hip_ctx *c)
     if (c->d_md5) (void)hipFree(c->d_md5);
     if (c->h_pp) (void)hipHostFree(c->h_pp);
     if (c->ev_pp) (void)hipEventDestroy(c->ev_pp);
+    if (c->d_mfqe) (void)hipFree(c->d_mfqe);
+    if (c->h_mfqe) (void)hipHostFree(c->h_mfqe);
+    if (c->ev_mfqe) (void)hipEventDestroy(c->ev_mfqe);
     if (c->d_pack) (void)hipFree(c->d_pack);
     if (c->h_pack) (void)hipHostFree(c->h_pack);
     destroy_events(c);
@@ -1159,9 +1165,11 @@ extern "C" int vp8hip_frame_download(vp8hip_ctx *c, int fb, int full, uint8_t *y
 extern "C" int vp8hip_postproc(vp8hip_ctx *c, int src_fb, int dst_fb, int tmp_fb, const vp8hip_pp *pp)
 {
     const int nfb = c ? (int)c->fb.size() : 0;
-    if (!c || !pp || src_fb < 0 || src_fb >= nfb || dst_fb < 0 || dst_fb >= nfb || dst_fb == src_fb)
+    if (!c || !pp || src_fb < 0 || src_fb >= nfb || dst_fb < 0 || dst_fb >= nfb)
         return fail(c, -2, "vp8hip_postproc: bad arguments");
     const bool demacro = pp->flags & VP8HIP_PP_DEMACROBLOCK, deblock = demacro || (pp->flags & VP8HIP_PP_DEBLOCK);
+    if (dst_fb == src_fb && deblock)                     // (in place: the noise alone, on a picture vp8hip_mfqe left in dst_fb)
+        return fail(c, -2, "vp8hip_postproc: the deblocking filters cannot run in place");
     const bool noise = pp->flags & VP8HIP_PP_ADDNOISE;
     if (demacro && (tmp_fb < 0 || tmp_fb >= nfb || tmp_fb == src_fb || tmp_fb == dst_fb || !pp->rv || pp->rv_offset < 0 || pp->rv_offset > 63))
         return fail(c, -2, "vp8hip_postproc: demacroblocking needs a third frame buffer and the dither table");
@@ -1205,7 +1213,7 @@ extern "C" int vp8hip_postproc(vp8hip_ctx *c, int src_fb, int dst_fb, int tmp_fb
             vp8pp_mb_down(c->stream, tmp + pl[0].off, dst + pl[0].off, pl[0].stride, pl[0].rows, pl[0].cols, pp->mb_flimit,
                           d_rv + pp->rv_offset);
         }
-    } else       // vp8_yv12_copy_frame_ptr (postproc.c:982)
+    } else if (dst != src)      // vp8_yv12_copy_frame_ptr (postproc.c:982)
         HIPCHK(c, hipMemcpyAsync(dst, src, (size_t)g.frame_size, hipMemcpyDeviceToDevice, c->stream));
     if (noise) {
         if (pp->noise) {
@@ -1218,6 +1226,35 @@ extern "C" int vp8hip_postproc(vp8hip_ctx *c, int src_fb, int dst_fb, int tmp_fb
     }
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(c->ev_pp, c->stream));
+    return 0;
+}
+
+extern "C" int vp8hip_mfqe(vp8hip_ctx *c, int show_fb, int prev_fb, int dst_fb, const uint8_t *mb_class, int qcurr, int qprev)
+{
+    const int nfb = c ? (int)c->fb.size() : 0;
+    if (!c || !mb_class || show_fb < 0 || show_fb >= nfb || prev_fb < 0 || prev_fb >= nfb || dst_fb < 0 || dst_fb >= nfb ||
+        show_fb == prev_fb || show_fb == dst_fb || qcurr < 0 || qcurr > 127 || qprev < 0 || qprev > qcurr)
+        return fail(c, -2, "vp8hip_mfqe: bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (join_detile(c)) return -1;
+    if (c->d2h_count) { HIPCHK(c, hipEventSynchronize(c->ev_d2h_done)); c->d2h_count = 0; }   // a batch download may be reading dst
+    const int nmb = c->dg.mb_cols * c->dg.mb_rows;
+    if (nmb > c->mfqe_cap) {
+        if (c->ev_mfqe) HIPCHK(c, hipEventSynchronize(c->ev_mfqe));
+        if (c->d_mfqe) (void)hipFree(c->d_mfqe);
+        if (c->h_mfqe) (void)hipHostFree(c->h_mfqe);
+        c->d_mfqe = c->h_mfqe = nullptr; c->mfqe_cap = 0;
+        HIPCHK(c, hipMalloc((void **)&c->d_mfqe, (size_t)nmb));
+        HIPCHK(c, hipHostMalloc((void **)&c->h_mfqe, (size_t)nmb, hipHostMallocDefault));
+        c->mfqe_cap = nmb;
+    }
+    if (!c->ev_mfqe) HIPCHK(c, hipEventCreateWithFlags(&c->ev_mfqe, hipEventDisableTiming));
+    else HIPCHK(c, hipEventSynchronize(c->ev_mfqe));    // the previous call's copy has left the pinned staging
+    memcpy(c->h_mfqe, mb_class, (size_t)nmb);
+    HIPCHK(c, hipMemcpyAsync(c->d_mfqe, c->h_mfqe, (size_t)nmb, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipEventRecord(c->ev_mfqe, c->stream));
+    vp8pp_mfqe(c->stream, c->fb[show_fb], c->fb[prev_fb], c->fb[dst_fb], c->dg, c->d_mfqe, qcurr, qprev);
+    HIPCHK(c, hipGetLastError());
     return 0;
 }
 

@@ -27,6 +27,7 @@
 #define FB_DECODE 4
 #define FB_POST   4
 #define FB_PPTMP  5
+#define FB_PPINT  6         /* post_proc_buffer_int: what VP8_MFQE hands to the deblocking filters */
 
 struct vpx_codec_alg_priv {
     vpx_codec_priv_t        base;
@@ -53,6 +54,8 @@ struct vpx_codec_alg_priv {
     int                     postproc_cfg_set;
     vp8_postproc_cfg_t      postproc_cfg;
     vp8_pp_state           *pp;
+    uint8_t                *mb_class;        /* VP8_MFQE: a byte per macroblock (vp8_pp_mfqe_classes) */
+    size_t                  mb_class_cap;
     char                    detail[160];
     double                  t_parse, t_launch, t_down;   /* VP8HIP_TRACE: seconds per phase of vp8_decode */
     long                    t_frames;
@@ -100,6 +103,7 @@ static vpx_codec_err_t vp8_destroy(vpx_codec_alg_priv_t *p)
     if (p->hip) { vp8hip_host_free(p->hip, p->host_frame); vp8hip_destroy(p->hip); }
     vp8_parser_destroy(p->parser);
     free(p->pp);
+    free(p->mb_class);
     free(p);
     return VPX_CODEC_OK;
 }
@@ -232,7 +236,7 @@ static vpx_codec_err_t vp8_decode(vpx_codec_alg_priv_t *p, const uint8_t *data, 
     }
     if (hdr.width != p->width || hdr.height != p->height) {       /* vp8_alloc_frame_buffers */
         if (vp8hip_configure(p->hip, hdr.width, hdr.height,
-                             (p->base.init_flags & VPX_CODEC_USE_POSTPROC) ? FB_DECODE + 2 : FB_DECODE, 1)) {
+                             (p->base.init_flags & VPX_CODEC_USE_POSTPROC) ? FB_DECODE + 3 : FB_DECODE, 1)) {
             vp8_refs_release_new(&p->refs);
             p->width = p->height = 0;
             return gpu_error(p, "vp8hip_configure");
@@ -314,9 +318,37 @@ static vpx_codec_err_t vp8_decode(vpx_codec_alg_priv_t *p, const uint8_t *data, 
                 p->postproc_cfg.noise_level = 0;
                 p->postproc_cfg_set = 1;
             }
-            if (vp8_pp_prepare(p->pp, &p->postproc_cfg, hdr.filter_level, p->geom.aligned_h, &pp)) {
-                if (vp8hip_postproc(p->hip, show_fb, FB_POST, FB_PPTMP, &pp)) return gpu_error(p, "vp8hip_postproc");
-                show_fb = FB_POST;
+            {
+                int qprev = 0;
+                const int mfqe = vp8_pp_mfqe_step(p->pp, &p->postproc_cfg, hdr.base_qindex, &qprev);
+                const int filters = vp8_pp_prepare(p->pp, &p->postproc_cfg, hdr.filter_level, p->geom.aligned_h, &pp);
+                if (mfqe) {
+                    /* postproc.c:948-969: the picture shown before, still in post_proc_buffer, is kept or blended in where the
+                       new frame (coarser by 10 quantiser steps or more) differs little from it; the deblocking filters then
+                       run on the result.  (Sizes that are not multiples of 16 included: the reference dies on those when both
+                       are asked for -- its intermediate buffer is never allocated, :929-941 -- so that combination is the one
+                       piece here no listing pins.) */
+                    const int deblocking = filters & (VP8HIP_PP_DEBLOCK | VP8HIP_PP_DEMACROBLOCK);
+                    const size_t n = (size_t)hdr.mb_cols * hdr.mb_rows;
+                    if (n > p->mb_class_cap) {
+                        uint8_t *m = (uint8_t *)realloc(p->mb_class, n);
+                        if (!m) return VPX_CODEC_MEM_ERROR;
+                        p->mb_class = m;
+                        p->mb_class_cap = n;
+                    }
+                    vp8_pp_mfqe_classes(&hdr, h_mbs, h_mvs, p->mb_class);
+                    if (vp8hip_mfqe(p->hip, show_fb, FB_POST, deblocking ? FB_PPINT : FB_POST, p->mb_class, hdr.base_qindex, qprev))
+                        return gpu_error(p, "vp8hip_mfqe");
+                    if (deblocking) {
+                        if (vp8hip_postproc(p->hip, FB_PPINT, FB_POST, FB_PPTMP, &pp)) return gpu_error(p, "vp8hip_postproc");
+                    } else if (filters && vp8hip_postproc(p->hip, FB_POST, FB_POST, FB_PPTMP, &pp))
+                        return gpu_error(p, "vp8hip_postproc");
+                    show_fb = FB_POST;
+                } else if (filters || (p->postproc_cfg.post_proc_flag & VP8_MFQE)) {
+                    /* (with VP8_MFQE the buffer holds every shown frame, filtered or not: :982-986) */
+                    if (vp8hip_postproc(p->hip, show_fb, FB_POST, FB_PPTMP, &pp)) return gpu_error(p, "vp8hip_postproc");
+                    show_fb = FB_POST;
+                }
             }
         }
         /* the whole frame buffer, borders included, in one linear copy into the pinned mirror (same vp8ir_geom layout) */

@@ -68,8 +68,7 @@ static void build_noise(vp8_pp_state *st, int q, int a)
 
 int vp8_pp_prepare(vp8_pp_state *st, const vp8_postproc_cfg_t *cfg, int filter_level, int rows, vp8hip_pp *pp)
 {
-    /* VP8_MFQE and the VP8_DEBUG_* overlays are not implemented: the flags are accepted and have no effect
-       (the reference's own MFQE path does not survive most of the fixture streams) */
+    /* (VP8_MFQE: vp8_pp_mfqe_step; the VP8_DEBUG_* overlays are not implemented: the flags are accepted and have no effect) */
     const int flags = cfg->post_proc_flag & (VP8_DEBLOCK | VP8_DEMACROBLOCK | VP8_ADDNOISE);
     int q = filter_level * 10 / 6, r;
     memset(pp, 0, sizeof *pp);
@@ -99,4 +98,31 @@ int vp8_pp_prepare(vp8_pp_state *st, const vp8_postproc_cfg_t *cfg, int filter_l
         pp->noise_clamp = st->clamp;
     }
     return pp->flags;
+}
+
+int vp8_pp_mfqe_step(vp8_pp_state *st, const vp8_postproc_cfg_t *cfg, int base_qindex, int *qprev)
+{
+    st->shown++;
+    if ((cfg->post_proc_flag & VP8_MFQE) && st->shown >= 2 && base_qindex - st->last_base_qindex >= 10) {
+        *qprev = st->last_base_qindex;
+        st->last_base_qindex = (3 * st->last_base_qindex + base_qindex) >> 2;
+        return 1;
+    }
+    st->last_base_qindex = base_qindex;
+    return 0;
+}
+
+void vp8_pp_mfqe_classes(const vp8ir_frame_hdr *hdr, const vp8ir_mb *mbs, const vp8ir_mv *mvs, uint8_t *cls)
+{
+    const int n = hdr->mb_cols * hdr->mb_rows;
+    int i;
+    for (i = 0; i < n; i++) {
+        int still = hdr->frame_type == 0;
+        if (!still) {
+            const int intra = mbs[i].ref_frame == VP8IR_INTRA_FRAME || !mvs;
+            const int r = intra ? 0 : mvs[i * 16 + 15].row, c = intra ? 0 : mvs[i * 16 + 15].col;
+            still = abs(r) <= 10 && abs(c) <= 10;
+        }
+        cls[i] = !still ? 0 : (mbs[i].y_mode == VP8IR_B_PRED || mbs[i].y_mode == VP8IR_SPLITMV) ? 2 : 1;
+    }
 }

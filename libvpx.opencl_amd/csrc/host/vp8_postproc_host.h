@@ -12,6 +12,8 @@ typedef struct vp8_pp_state {           /* struct postproc_state, vp8/common/pos
     int    clamp;                       /* blackclamp[0] == whiteclamp[0] */
     int8_t noise[3072];
     uint8_t noise_rows[16384];
+    int    shown;                       /* frames shown so far: cm->current_video_frame as vp8_post_proc_frame sees it */
+    int    last_base_qindex;            /* the quantiser index the picture in the post-processing buffer stands for */
 } vp8_pp_state;
 
 /* The reference draws its dither and noise phases from the C library's rand() and never seeds it (postproc.c:286,456,499), so
@@ -25,5 +27,14 @@ int vp8_pp_rand(vp8_pp_state *st);
  * reference's order: once per demacroblocked frame, 3072 times per new noise table, once per noisy row.  Returns the
  * effective flags (0: show the frame as it is). */
 int vp8_pp_prepare(vp8_pp_state *st, const vp8_postproc_cfg_t *cfg, int filter_level, int rows, vp8hip_pp *pp);
+
+/* VP8_MFQE, the policy (vp8_post_proc_frame, postproc.c:911-925,948-986): to be called once for every SHOWN frame of a decoder
+ * created with VPX_CODEC_USE_POSTPROC, before vp8_pp_prepare.  Returns 1 when the frame goes through
+ * vp8_multiframe_quality_enhance -- VP8_MFQE set, at least the second frame shown, base_qindex 10 or more above the running
+ * index -- with *qprev = that index; the running index then moves a quarter of the way (:969), otherwise it becomes the frame's. */
+int vp8_pp_mfqe_step(vp8_pp_state *st, const vp8_postproc_cfg_t *cfg, int base_qindex, int *qprev);
+/* ... and the class of every macroblock for vp8hip_mfqe (postproc.c:834-843): cls[mb_rows * mb_cols]; mvs may be NULL on key
+ * frames.  A macroblock's vector is its last block's (decodemv.c:490), zero for intra macroblocks (:563). */
+void vp8_pp_mfqe_classes(const vp8ir_frame_hdr *hdr, const vp8ir_mb *mbs, const vp8ir_mv *mvs, uint8_t *cls);
 
 #endif

@@ -6,7 +6,7 @@
  * --summary / --progress (frames, microseconds inside vpx_codec_decode only, fps -- the same
  * bracket as vpxdec.c:1041-1055), --limit, --skip, -t/--threads (host threads for the token partitions of a frame: the
  * entropy decode is the CPU side of this decoder, vp8_parser_set_threads), --codec=vp8, -v, and the VP8 post-processing options --postproc, --deblock,
- * --demacroblock-level=<n>, --noise-level=<n>, --mfqe (vpxdec.c:111-133, 779-812, 983-1002; MFQE is accepted and has no effect).
+ * --demacroblock-level=<n>, --noise-level=<n>, --mfqe (vpxdec.c:111-133, 779-812, 983-1002).
  * Input: IVF or WebM, probed in that order like vpxdec.c:573-587 (webm.h; the reference reads WebM through its bundled
  * nestegg).  Headerless raw input is not provided.
  */

@@ -94,3 +94,43 @@ def test_postproc_phase_generator_is_the_c_librarys(pkg):
     libc.srand(1)
     st = ctypes.create_string_buffer(40000)
     assert all(H.vp8_pp_rand(st) == libc.rand() for _ in range(20000))
+
+
+def test_mfqe_policy(pkg):
+    """vp8_pp_mfqe_step / vp8_pp_mfqe_classes (vp8_postproc_host.h) against vp8_post_proc_frame's bookkeeping (postproc.c:948-986)
+    and vp8_multiframe_quality_enhance's per-macroblock choice (:834-843), spelled out here."""
+    import numpy as np
+    H = pkg.load_host()
+
+    class Cfg(ctypes.Structure):
+        _fields_ = [("post_proc_flag", ctypes.c_int), ("deblocking_level", ctypes.c_int), ("noise_level", ctypes.c_int)]
+
+    rng = np.random.default_rng(5)
+    for flag in (1024, 1027, 3):
+        st = ctypes.create_string_buffer(40000)
+        last, shown = 0, 0
+        for q in [int(x) for x in rng.integers(0, 128, size=200)]:
+            shown += 1
+            qprev = ctypes.c_int(-1)
+            got = H.vp8_pp_mfqe_step(st, ctypes.byref(Cfg(flag, 4, 0)), q, ctypes.byref(qprev))
+            want = bool(flag & 1024) and shown >= 2 and q - last >= 10
+            assert bool(got) == want
+            if want:
+                assert qprev.value == last
+                last = (3 * last + q) >> 2
+            else:
+                last = q
+    n = 500
+    mbs = np.zeros((n, 64), np.uint8)
+    mbs[:, 0] = rng.integers(0, 10, size=n)
+    mbs[:, 2] = np.where(mbs[:, 0] <= 4, 0, rng.integers(1, 4, size=n))
+    mvs = rng.integers(-13, 14, size=(n, 16, 2)).astype(np.int16)
+    for frame_type in (0, 1):
+        hdr = pkg.FrameHdr()
+        hdr.mb_cols, hdr.mb_rows, hdr.frame_type = 25, 20, frame_type
+        cls = np.zeros(n, np.uint8)
+        H.vp8_pp_mfqe_classes(ctypes.byref(hdr), ctypes.c_void_p(mbs.ctypes.data), ctypes.c_void_p(mvs.ctypes.data), ctypes.c_void_p(cls.ctypes.data))
+        for i in range(n):
+            mv = (0, 0) if mbs[i, 2] == 0 else tuple(int(v) for v in mvs[i, 15])
+            still = frame_type == 0 or (abs(mv[0]) <= 10 and abs(mv[1]) <= 10)
+            assert cls[i] == (0 if not still else 2 if mbs[i, 0] in (4, 9) else 1)
