@@ -146,6 +146,40 @@ int  vp8hip_postproc(vp8hip_ctx *ctx, int src_fb, int dst_fb, int tmp_fb, const 
  * Asynchronous on the context's stream; mb_class may be reused when the call returns. */
 int  vp8hip_mfqe(vp8hip_ctx *ctx, int show_fb, int prev_fb, int dst_fb, const uint8_t *mb_class, int qcurr, int qprev);
 
+/* Entropy decoding on the device (key frames).  What it replaces: the per-macroblock half of the host feeder -- the reference's
+ * vp8_kfread_modes (vp8/decoder/decodemv.c:50-173) and vp8_decode_mb_tokens (vp8/decoder/detokenize.c:183-405) driven by
+ * decode_mb_row (vp8/decoder/decodframe.c:293-470) -- which at ~10 ms per 1080p frame and core is what bounds a pipeline that
+ * starts from the compressed stream.  A bool decoder is a serial machine, so a frame is ONE LANE's work (its token partitions
+ * decoded in macroblock-row order like the reference's single thread does); the frames of a batch run side by side, 64 to a
+ * wave.  The frame header stays with the host (a few thousand bools: vp8_parser_begin_frame), which hands over what it leaves
+ * behind (vp8_parser_export_entropy, csrc/host/vp8_parser.h): the decoder state of the first partition where the per-macroblock
+ * data start, the token partitions' extents, the probabilities.  The kernel writes the dense IR of include/vp8_ir.h into the
+ * frames' slots -- descriptors and coefficients byte for byte what vp8_parser_decode_mbs writes -- and vp8hip_decode takes it
+ * from there.  Integer only. */
+typedef struct vp8hip_entropy_frame {
+    vp8ir_frame_hdr hdr;                /* as vp8_parser_begin_frame returned it; a key frame of the context's size */
+    uint32_t data_off;                  /* the frame's first byte in the buffer handed to vp8hip_entropy_decode */
+    uint32_t first_pos, first_end;      /* first partition, relative to data_off: the next byte the decoder takes, and its end */
+    uint32_t first_value;               /* ... its window (32 bits, the active byte on top), */
+    int32_t  first_bits;                /*     the valid bits below the top byte (negative: refill due), */
+    uint32_t first_range;               /*     and its range, 128..255 */
+    uint32_t num_tok;                   /* 1, 2, 4 or 8 token partitions */
+    uint32_t tok_pos[8], tok_end[8];    /* their extents, relative to data_off */
+    uint8_t  update_mb_segmentation_map, mb_no_coeff_skip, prob_skip_false, rsv0;
+    uint8_t  segment_tree_probs[3], rsv1;
+    uint8_t  coef_probs[1056];          /* [block type 4][band 8][context 3][node 11] */
+} vp8hip_entropy_frame;
+/* frames[i] -> IR slot first_slot + i.  `data`: the compressed frames (data_bytes in all; any host memory -- page-locked memory
+ * from vp8hip_host_alloc makes the copy asynchronous, and then `frames` and `data` have to stay untouched until the next
+ * vp8hip_sync).  Asynchronous on the context's stream. */
+int  vp8hip_entropy_decode(vp8hip_ctx *ctx, int first_slot, int count, const vp8hip_entropy_frame *frames, const uint8_t *data,
+                           size_t data_bytes);
+/* What became of the frames of the last vp8hip_entropy_decode, a word each: bit 0 = a partition of the frame ended early, the
+ * frame is corrupt (what vp8_parser_decode_mbs reports through *corrupt).  Synchronous. */
+int  vp8hip_entropy_status(vp8hip_ctx *ctx, int count, uint32_t *status);
+/* The IR of a slot as it stands on the device, dense form (tests, debugging): mbs[nmb], coef[nmb * 400].  Synchronous. */
+int  vp8hip_ir_fetch(vp8hip_ctx *ctx, int slot, vp8ir_mb *mbs, int16_t *coef);
+
 /* Batch form for pipelines (tools/e2e.py, bin/batch_md5): `count` consecutive frame buffers, whole, as ONE asynchronous copy on
  * a stream of its own -- it starts when everything queued on the context's stream so far has finished and runs beside later
  * uploads (PCIe is full duplex).  dst: page-locked memory (vp8hip_host_alloc), frame i at dst + i * vp8hip_frame_stride(ctx)

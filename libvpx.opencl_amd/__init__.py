@@ -62,6 +62,16 @@ class FrameHdr(ctypes.Structure):
 assert ctypes.sizeof(FrameHdr) == 64
 
 
+class EntropyFrame(ctypes.Structure):
+    """vp8hip_entropy_frame (include/vp8hip.h): what the host's header parse hands to the device's entropy decoder."""
+    _fields_ = [("hdr", FrameHdr), ("data_off", ctypes.c_uint32), ("first_pos", ctypes.c_uint32), ("first_end", ctypes.c_uint32),
+                ("first_value", ctypes.c_uint32), ("first_bits", ctypes.c_int32), ("first_range", ctypes.c_uint32),
+                ("num_tok", ctypes.c_uint32), ("tok_pos", ctypes.c_uint32 * 8), ("tok_end", ctypes.c_uint32 * 8),
+                ("update_mb_segmentation_map", ctypes.c_uint8), ("mb_no_coeff_skip", ctypes.c_uint8),
+                ("prob_skip_false", ctypes.c_uint8), ("rsv0", ctypes.c_uint8), ("segment_tree_probs", ctypes.c_uint8 * 3),
+                ("rsv1", ctypes.c_uint8), ("coef_probs", ctypes.c_uint8 * 1056)]
+
+
 class Geom(ctypes.Structure):
     _fields_ = [(n, c_int) for n in ("aligned_w", "aligned_h", "y_stride", "uv_stride", "y_plane_size",
                                      "uv_plane_size", "frame_size", "y_off", "u_off", "v_off")]
@@ -158,6 +168,7 @@ def load_host():
         L.vp8_parser_decode_mbs.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
         L.vp8_parser_decode_mbs_sparse.argtypes = [c_void_p, c_void_p, c_void_p, c_size_t, ctypes.POINTER(c_size_t), c_void_p,
                                                    ctypes.POINTER(c_size_t), c_void_p, c_void_p]
+        L.vp8_parser_export_entropy.argtypes = [c_void_p, c_void_p]
         L.vp8_parser_error.argtypes = [c_void_p]
         L.vp8_parser_error.restype = ctypes.c_char_p
         for f in ("vp8_refs_init", "vp8_refs_on_alloc", "vp8_refs_release_new"):
@@ -211,6 +222,18 @@ class Parser:
             self.dims = (hdr.width, hdr.height)
             self.L.vp8_refs_on_alloc(ctypes.byref(self.refs))
         return hdr, changed
+
+    def export_entropy(self):
+        """After begin() on a key frame: the frame's vp8hip_entropy_frame (offsets relative to the frame's first byte); the
+        parser is done with the frame.  None when the frame is not one the device decodes (it stays open for decode_mbs)."""
+        out = EntropyFrame()
+        rc = self.L.vp8_parser_export_entropy(self.p, ctypes.byref(out))
+        if rc == 5:
+            return None
+        if rc:
+            self.L.vp8_refs_release_new(ctypes.byref(self.refs))
+            raise ValueError(f"vp8 header error {rc}: {self.L.vp8_parser_error(self.p).decode()}")
+        return out
 
     def decode_mbs(self, mbs_ptr, coef_ptr, mvs_ptr):
         corrupt = c_int(0)
@@ -289,6 +312,9 @@ def load_hip():
         L.vp8hip_stream.restype = c_void_p
         L.vp8hip_postproc.argtypes = [c_void_p, c_int, c_int, c_int, ctypes.POINTER(PostprocParams)]
         L.vp8hip_mfqe.argtypes = [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int]
+        L.vp8hip_entropy_decode.argtypes = [c_void_p, c_int, c_int, c_void_p, c_void_p, c_size_t]
+        L.vp8hip_entropy_status.argtypes = [c_void_p, c_int, c_void_p]
+        L.vp8hip_ir_fetch.argtypes = [c_void_p, c_int, c_void_p, c_void_p]
         _hip = L
     return _hip
 
@@ -430,6 +456,30 @@ class Vp8Hip:
                             noise.ctypes.data if noise is not None else None,
                             noise_rows.ctypes.data if noise_rows is not None else None)
         self._chk(self.L.vp8hip_postproc(self.h, src_fb, dst_fb, tmp_fb, ctypes.byref(pp)), "postproc")
+
+    def entropy_decode(self, first_slot, frames, datas):
+        """vp8hip_entropy_decode: frames = EntropyFrame list (from Parser.export_entropy), datas = the frames' bytes; slot
+        first_slot + i receives frame i's IR.  Returns the per-frame status words (synchronises)."""
+        n = len(frames)
+        arr = (EntropyFrame * n)()
+        off = 0
+        for i, (f, d) in enumerate(zip(frames, datas)):
+            ctypes.memmove(ctypes.byref(arr[i]), ctypes.byref(f), ctypes.sizeof(EntropyFrame))
+            arr[i].data_off = off
+            off += len(d)
+        blob = b"".join(datas)
+        self._chk(self.L.vp8hip_entropy_decode(self.h, first_slot, n, ctypes.byref(arr), blob, len(blob)), "entropy_decode")
+        st = np.zeros(n, np.uint32)
+        self._chk(self.L.vp8hip_entropy_status(self.h, n, st.ctypes.data), "entropy_status")
+        return st
+
+    def ir_fetch(self, slot):
+        """The slot's IR as it stands on the device: (mbs uint8[n,64], coef int16[n,400])."""
+        n = self.g_mbs()
+        mbs = np.zeros((n, 64), np.uint8)
+        coef = np.zeros((n, 400), np.int16)
+        self._chk(self.L.vp8hip_ir_fetch(self.h, slot, mbs.ctypes.data, coef.ctypes.data), "ir_fetch")
+        return mbs, coef
 
     def mfqe(self, show_fb, prev_fb, dst_fb, mb_class, qcurr, qprev):
         """vp8_multiframe_quality_enhance (postproc.c:802-900; include/vp8hip.h): mb_class a uint8 array, a byte per macroblock."""

@@ -28,6 +28,9 @@ extern "C" __global__ void vp8_keyframe_kernel(const DevJob *jobs, int njobs, De
 extern "C" __global__ void vp8_interframe_kernel(const DevJob *jobs, int njobs, DevGeom g, int lgG, int P, int nstrands, uint8_t *dummy,
                                                unsigned int *sched, int nwaves);
 extern "C" __global__ void vp8_inter_pred_kernel(const DevJob *jobs, int njobs, DevGeom g, int upf);
+extern "C" __global__ void vp8_entropy_kernel(const vp8hip_entropy_frame *frames, int count, int lpw, const uint8_t *data, DevGeom g,
+                                              char *slot_base, size_t slot_bytes, size_t o_mbs, size_t o_coef, int first_slot,
+                                              unsigned int *scratch, unsigned int *status);
 extern "C" __global__ void vp8_md5_kernel(const uint8_t *frames, size_t fstride, int count, DevGeom g, int w, int h, uint8_t *out);
 #ifdef VP8_STAMPS
 #define VP8HIP_SCHED_WORDS (16 + 16384 + 4 * 4096)     // + the diagnostic builds' log: four words per wave
@@ -269,6 +272,9 @@ struct vp8hip_ctx {
     // vp8hip_postproc: dither table (440 shorts), noise table (3072) and per-row noise phases (16384) on the device
     char *d_pp, *h_pp; bool pp_rv_loaded; hipEvent_t ev_pp;
     uint8_t *d_mfqe, *h_mfqe; int mfqe_cap; hipEvent_t ev_mfqe;     // vp8hip_mfqe: the macroblock classes of the frame
+    // vp8hip_entropy_decode: the frames' descriptions, their bytes, per-frame scratch and status on the device
+    char *d_ent_frames, *d_ent_data; unsigned int *d_ent_scratch, *d_ent_status; size_t ent_frames_cap, ent_data_cap, ent_scratch_cap;
+    bool ent_tables_loaded; int ent_lpw;
     unsigned int *d_sched;         // vp8_keyframe_kernel's role / work counters
     int *h_pack, *d_pack; int pack_cap;      // slots whose coefficients a launch has to pack / unpack first
 };
@@ -413,6 +419,10 @@ extern "C" void vp8hip_destroy(vp8hip_ctx *c)
     if (c->d_md5) (void)hipFree(c->d_md5);
     if (c->h_pp) (void)hipHostFree(c->h_pp);
     if (c->ev_pp) (void)hipEventDestroy(c->ev_pp);
+    if (c->d_ent_frames) (void)hipFree(c->d_ent_frames);
+    if (c->d_ent_data) (void)hipFree(c->d_ent_data);
+    if (c->d_ent_scratch) (void)hipFree(c->d_ent_scratch);
+    if (c->d_ent_status) (void)hipFree(c->d_ent_status);
     if (c->d_mfqe) (void)hipFree(c->d_mfqe);
     if (c->h_mfqe) (void)hipHostFree(c->h_mfqe);
     if (c->ev_mfqe) (void)hipEventDestroy(c->ev_mfqe);
@@ -1255,6 +1265,97 @@ extern "C" int vp8hip_mfqe(vp8hip_ctx *c, int show_fb, int prev_fb, int dst_fb, 
     HIPCHK(c, hipEventRecord(c->ev_mfqe, c->stream));
     vp8pp_mfqe(c->stream, c->fb[show_fb], c->fb[prev_fb], c->fb[dst_fb], c->dg, c->d_mfqe, qcurr, qprev);
     HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
+extern "C" int vp8hip_entropy_decode(vp8hip_ctx *c, int first_slot, int count, const vp8hip_entropy_frame *frames, const uint8_t *data,
+                                     size_t data_bytes)
+{
+    if (!c || !frames || !data || count < 1 || first_slot < 0 || first_slot + count > (int)c->slots.size() || data_bytes >= (1ull << 32) - 16)
+        return fail(c, -2, "vp8hip_entropy_decode: bad arguments");
+    for (int i = 0; i < count; i++) {
+        const vp8hip_entropy_frame &f = frames[i];
+        const vp8ir_frame_hdr &h = f.hdr;
+        if (h.frame_type != 0) return fail(c, -2, "vp8hip_entropy_decode: frame %d is not a key frame", i);
+        if (h.mb_cols != c->dg.mb_cols || h.mb_rows != c->dg.mb_rows)
+            return fail(c, -2, "vp8hip_entropy_decode: frame %d is %dx%d MBs, context configured for %dx%d", i, h.mb_cols, h.mb_rows,
+                        c->dg.mb_cols, c->dg.mb_rows);
+        bool ok = (f.num_tok == 1 || f.num_tok == 2 || f.num_tok == 4 || f.num_tok == 8) && f.data_off <= data_bytes &&
+                  f.first_pos <= f.first_end && f.first_end <= data_bytes - f.data_off && f.first_range >= 128 && f.first_range <= 255 &&
+                  f.first_bits >= -8 && f.first_bits <= 24;
+        for (unsigned k = 0; ok && k < f.num_tok; k++) ok = f.tok_pos[k] <= f.tok_end[k] && f.tok_end[k] <= data_bytes - f.data_off;
+        if (!ok) return fail(c, -2, "vp8hip_entropy_decode: frame %d: partitions outside the data, or no decoder state", i);
+    }
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t fbytes = (size_t)count * sizeof(vp8hip_entropy_frame);
+    const size_t swords = (size_t)count * (2 * (size_t)c->dg.mb_cols + 64);
+    if (fbytes > c->ent_frames_cap) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (c->d_ent_frames) (void)hipFree(c->d_ent_frames);
+        if (c->d_ent_status) (void)hipFree(c->d_ent_status);
+        c->d_ent_frames = nullptr; c->d_ent_status = nullptr; c->ent_frames_cap = 0;
+        HIPCHK(c, hipMalloc((void **)&c->d_ent_frames, fbytes));
+        HIPCHK(c, hipMalloc((void **)&c->d_ent_status, (size_t)count * 4));
+        c->ent_frames_cap = fbytes;
+    }
+    if (data_bytes + 16 > c->ent_data_cap) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (c->d_ent_data) (void)hipFree(c->d_ent_data);
+        c->d_ent_data = nullptr; c->ent_data_cap = 0;
+        const size_t cap = data_bytes + data_bytes / 4 + 4096;
+        HIPCHK(c, hipMalloc((void **)&c->d_ent_data, cap));
+        c->ent_data_cap = cap;
+    }
+    if (swords > c->ent_scratch_cap) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (c->d_ent_scratch) (void)hipFree(c->d_ent_scratch);
+        c->d_ent_scratch = nullptr; c->ent_scratch_cap = 0;
+        HIPCHK(c, hipMalloc((void **)&c->d_ent_scratch, swords * 4));
+        c->ent_scratch_cap = swords;
+    }
+    if (!c->ent_tables_loaded) {
+        c->ent_tables_loaded = true;
+        const char *e = getenv("VP8HIP_ENTROPY_LANES");     // lanes of a wave that carry a frame (a tuning knob: read once)
+        c->ent_lpw = e ? atoi(e) : 0;
+        if (c->ent_lpw < 1 || c->ent_lpw > 64) c->ent_lpw = 0;
+    }
+    HIPCHK(c, hipMemcpyAsync(c->d_ent_frames, frames, fbytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_ent_data, data, data_bytes, hipMemcpyHostToDevice, c->stream));
+    for (int i = 0; i < count; i++) {
+        Slot &s = c->slots[first_slot + i];
+        s.hdr_copy = frames[i].hdr;
+        s.packed = false;
+    }
+    // lanes per wave: all 64 when there are frames enough to give every SIMD of the chip a wave that way, fewer otherwise (a
+    // wave's time per decision grows with the number of different paths its lanes are on)
+    int lpw = c->ent_lpw;
+    if (!lpw) { lpw = 64; while (lpw > 8 && (count + lpw - 1) / lpw < c->num_cu * 4) lpw >>= 1; }
+    hipLaunchKernelGGL(vp8_entropy_kernel, dim3((unsigned)((count + lpw - 1) / lpw)), dim3(64), 0, c->stream,
+                       (const vp8hip_entropy_frame *)c->d_ent_frames, count, lpw, (const uint8_t *)c->d_ent_data, c->dg, c->slot_block_dev,
+                       c->slot_bytes, c->o_mbs, c->o_coef, first_slot, c->d_ent_scratch, c->d_ent_status);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
+extern "C" int vp8hip_entropy_status(vp8hip_ctx *c, int count, uint32_t *status)
+{
+    if (!c || !status || count < 1 || (size_t)count * sizeof(vp8hip_entropy_frame) > c->ent_frames_cap)
+        return fail(c, -2, "vp8hip_entropy_status: bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(status, c->d_ent_status, (size_t)count * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int vp8hip_ir_fetch(vp8hip_ctx *c, int slot, vp8ir_mb *mbs, int16_t *coef)
+{
+    if (!c || slot < 0 || slot >= (int)c->slots.size()) return fail(c, -2, "vp8hip_ir_fetch: bad slot %d", slot);
+    Slot &s = c->slots[slot];
+    if (s.packed) return fail(c, -2, "vp8hip_ir_fetch: slot %d holds the packed form (a launch has consumed it)", slot);
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (mbs) HIPCHK(c, hipMemcpy(mbs, s.d_mbs, (size_t)c->nmb * sizeof(vp8ir_mb), hipMemcpyDeviceToHost));
+    if (coef) HIPCHK(c, hipMemcpy(coef, s.d_coef, (size_t)c->nmb * VP8IR_COEF_PER_MB * sizeof(int16_t), hipMemcpyDeviceToHost));
     return 0;
 }
 

@@ -291,6 +291,13 @@ static vpx_codec_err_t vp8_decode(vpx_codec_alg_priv_t *p, const uint8_t *data, 
         vp8_refs_release_new(&p->refs);
         return VPX_CODEC_MEM_ERROR;
     }
+    if ((p->base.init_flags & VPX_CODEC_USE_POSTPROC) && (size_t)hdr.mb_cols * hdr.mb_rows > p->mb_class_cap) {
+        const size_t n = (size_t)hdr.mb_cols * hdr.mb_rows;
+        uint8_t *m = (uint8_t *)realloc(p->mb_class, n);
+        if (!m) { vp8_refs_release_new(&p->refs); return VPX_CODEC_MEM_ERROR; }
+        p->mb_class = m;
+        p->mb_class_cap = n;
+    }
     t1 = now_s();
     if (vp8hip_ir_upload_sparse(p->hip, 0, nblocks, ndcs)) { vp8_refs_release_new(&p->refs); return gpu_error(p, "vp8hip_ir_upload_sparse"); }
     job.ir_slot = 0;
@@ -329,13 +336,6 @@ static vpx_codec_err_t vp8_decode(vpx_codec_alg_priv_t *p, const uint8_t *data, 
                        are asked for -- its intermediate buffer is never allocated, :929-941 -- so that combination is the one
                        piece here no listing pins.) */
                     const int deblocking = filters & (VP8HIP_PP_DEBLOCK | VP8HIP_PP_DEMACROBLOCK);
-                    const size_t n = (size_t)hdr.mb_cols * hdr.mb_rows;
-                    if (n > p->mb_class_cap) {
-                        uint8_t *m = (uint8_t *)realloc(p->mb_class, n);
-                        if (!m) return VPX_CODEC_MEM_ERROR;
-                        p->mb_class = m;
-                        p->mb_class_cap = n;
-                    }
                     vp8_pp_mfqe_classes(&hdr, h_mbs, h_mvs, p->mb_class);
                     if (vp8hip_mfqe(p->hip, show_fb, FB_POST, deblocking ? FB_PPINT : FB_POST, p->mb_class, hdr.base_qindex, qprev))
                         return gpu_error(p, "vp8hip_mfqe");

@@ -77,6 +77,8 @@ struct vp8_parser {
     int sign_bias[4];
     vp8_boolreader first;        /* first partition (modes) */
     vp8_boolreader tok[8];       /* token partitions */
+    const uint8_t *tok_start[8]; /* ... where each begins (vp8_parser_export_entropy) */
+    const uint8_t *frame_data;   /* the frame, when it came as one buffer */
     int num_tok;
     int frame_open;
 
@@ -226,6 +228,7 @@ int vp8_parser_begin_frame_fragments(vp8_parser *p, const uint8_t *const *frags,
     size_t first_len;
     int is_key, i, j, lost = 0;
     /* error concealment is for whole buffers; with VPX_CODEC_USE_INPUT_FRAGMENTS the strict rules stay */
+    p->frame_data = nfrags == 1 ? frags[0] : NULL;
 #define EC_ON (p->ec_active && nfrags <= 1)
 
     p->frame_open = 0;
@@ -411,8 +414,8 @@ int vp8_parser_begin_frame_fragments(vp8_parser *p, const uint8_t *const *frags,
             }
         }
         for (i = 0; i < n; i++) {     /* (a partition that never came: empty, the frame turns out corrupt) */
-            if (none || !F[i + 1]) vp8br_init(&p->tok[i], nothing, 0);
-            else vp8br_init(&p->tok[i], F[i + 1], S[i + 1]);
+            if (none || !F[i + 1]) { vp8br_init(&p->tok[i], nothing, 0); p->tok_start[i] = NULL; }
+            else { vp8br_init(&p->tok[i], F[i + 1], S[i + 1]); p->tok_start[i] = F[i + 1]; }
         }
         p->num_tok = n;
         h->num_token_partitions = (uint8_t)n;
@@ -515,6 +518,51 @@ int vp8_parser_begin_frame_fragments(vp8_parser *p, const uint8_t *const *frags,
 }
 
 int vp8_parser_conceals(const vp8_parser *p) { return p && p->ec_active; }
+
+/* See vp8_parser.h.  The decoder states handed over are the host's, cut down to the device's 32-bit window: the bytes the
+   64-bit window holds beyond that go back to the partition (the position moves back by whole bytes). */
+int vp8_parser_export_entropy(vp8_parser *p, vp8hip_entropy_frame *out)
+{
+    const vp8_boolreader *br = &p->first;
+    int i, bits, back;
+    if (!p->frame_open) return fail(p, VP8P_ERROR, "export_entropy without begin_frame");
+    if (p->hdr.frame_type != 0 || !p->frame_data || p->ec_enabled) {      /* (the frame stays open) */
+        snprintf(p->err, sizeof p->err, "%s", "the device decodes key frames given as one buffer, without concealment");
+        return VP8P_UNSUP_BITSTREAM;
+    }
+    if (br->zero_fill || p->corrupted) return fail(p, VP8P_CORRUPT_FRAME, "the frame header ran past the end of the data");
+    memset(out, 0, sizeof *out);
+    out->hdr = p->hdr;
+    bits = br->bits;
+    back = bits > 24 ? (bits - 24 + 7) >> 3 : 0;
+    bits -= 8 * back;
+    out->first_pos = (uint32_t)(br->cur - p->frame_data) - (uint32_t)back;
+    out->first_end = (uint32_t)(br->end - p->frame_data);
+    out->first_value = (uint32_t)(br->window >> 32) & ~((1u << (24 - (bits < 0 ? 0 : bits))) - 1u);
+    if (bits < 0) out->first_value = (uint32_t)(br->window >> 32);
+    out->first_bits = bits;
+    out->first_range = br->range;
+    out->num_tok = (uint32_t)p->num_tok;
+    for (i = 0; i < p->num_tok; i++) {
+        if (!p->tok_start[i]) return fail(p, VP8P_CORRUPT_FRAME, "a token partition is missing");
+        out->tok_pos[i] = (uint32_t)(p->tok_start[i] - p->frame_data);
+        out->tok_end[i] = (uint32_t)(p->tok[i].end - p->frame_data);
+    }
+    out->update_mb_segmentation_map = (uint8_t)(p->update_mb_segmentation_map && p->segmentation_enabled);
+    out->mb_no_coeff_skip = (uint8_t)p->mb_no_coeff_skip;
+    out->prob_skip_false = p->prob_skip_false;
+    memcpy(out->segment_tree_probs, p->segment_tree_probs, 3);
+    memcpy(out->coef_probs, p->fc.coef, 1056);
+    /* the frame is over for the parser (what vp8_parser_decode_mbs does at its end); the macroblocks' modes never came by here,
+       so nothing that leans on them -- an inter frame -- may follow before the next key frame decoded on the host */
+    if (p->restore_probs) {
+        p->fc = p->saved_fc;
+        p->independent_partitions = p->prev_independent;
+    }
+    p->have_key_frame = 0;
+    p->frame_open = 0;
+    return VP8P_OK;
+}
 
 void vp8_parser_frame_hdr(const vp8_parser *p, vp8ir_frame_hdr *out)
 {

@@ -13,6 +13,7 @@
 #include <stddef.h>
 #include <stdint.h>
 #include "vp8_ir.h"
+#include "vp8hip.h"
 
 #ifdef __cplusplus
 extern "C" {
@@ -79,6 +80,13 @@ int vp8_parser_decode_mbs(vp8_parser *p, vp8ir_mb *mbs, int16_t *coef, vp8ir_mv 
  * entries start. */
 int vp8_parser_decode_mbs_sparse(vp8_parser *p, vp8ir_mb *mbs, int16_t *blocks, size_t cap_blocks, size_t *nblocks,
                                  int16_t *dcs, size_t *ndcs, vp8ir_mv *mvs, int *corrupt);
+
+/* Step 2 on the device (include/vp8hip.h: vp8hip_entropy_decode): instead of decoding the macroblocks, hand over what the
+ * frame header left behind -- the first partition's decoder state at the first macroblock, the token partitions' extents (all
+ * relative to the start of the buffer begin_frame was given), the probabilities.  Key frames given as one buffer, without
+ * concealment (VP8P_UNSUP_BITSTREAM otherwise, and the frame stays open for vp8_parser_decode_mbs); a frame whose header ran
+ * past its data is VP8P_CORRUPT_FRAME.  Closes the frame; the next frame has to be a key frame. */
+int vp8_parser_export_entropy(vp8_parser *p, vp8hip_entropy_frame *out);
 
 const char *vp8_parser_error(const vp8_parser *p);
 

