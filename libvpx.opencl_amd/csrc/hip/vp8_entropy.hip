@@ -28,52 +28,64 @@ typedef unsigned int u32;
 typedef unsigned long long u64;
 typedef u32 u32x4 __attribute__((ext_vector_type(4)));
 typedef short __attribute__((may_alias)) coef_t;     // the block staged in LDS is zeroed and read back as words
+typedef u32 __attribute__((may_alias)) row_t;        // probability rows are written as bytes and read as words
 
-#define ENT_PROB_STRIDE 1060       // bytes per lane: 265 words, odd
-#define ENT_DESC_WORDS  17         // 64-byte descriptor + a word of padding
-#define ENT_BLK_WORDS   9          // 32-byte block + a word of padding
+// Probabilities live in LDS in ROWS of 12 bytes -- the 11 node probabilities of one (block type, band, context), the 9 of one
+// (above, left) pair of sub-block modes, the up to 11 of one extra-bits category -- so that what a token's decisions need comes
+// with one three-word read when the row is entered, not with a byte read in front of every decision.
+#define ENT_ROW 12
+#define ENT_PROB_WORDS 289         // per lane: 96 rows = 288 words, + 1 so that consecutive lanes start on different banks
+#define ENT_DESC_WORDS 17          // 64-byte descriptor + a word of padding
+#define ENT_BLK_WORDS  8           // the block being decoded
 
-__constant__ uint8_t vp8_ent_kf_bmode_probs[900] = {
+__constant__ uint8_t k_kf_bmode_probs[900] = {
 #include "../host/vp8_kf_bmode_probs.inc"
 };
 
-// Pcat1..Pcat6 (vp8/decoder/detokenize.c:52-64; RFC 6386 13.2), one after the other
-__constant__ uint8_t k_cat_probs[28] = { 159, 165, 145, 173, 148, 140, 176, 155, 140, 135, 180, 157, 141, 134, 130,
-                                         254, 254, 243, 230, 196, 177, 153, 140, 133, 130, 129, 0, 0 };
+// Pcat1..Pcat6 (vp8/decoder/detokenize.c:52-64; RFC 6386 13.2), a row each
+__constant__ uint8_t k_cat_rows[6 * ENT_ROW] = { 159, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0,   165, 145, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0,
+                                                 173, 148, 140, 0, 0, 0, 0, 0, 0, 0, 0, 0,   176, 155, 140, 135, 0, 0, 0, 0, 0, 0, 0, 0,
+                                                 180, 157, 141, 134, 130, 0, 0, 0, 0, 0, 0, 0,
+                                                 254, 254, 243, 230, 196, 177, 153, 140, 133, 130, 129, 0 };
+
+struct Row { u32 w0, w1, w2; };
+__device__ __forceinline__ Row row_at(const row_t *p) { Row r; r.w0 = p[0]; r.w1 = p[1]; r.w2 = p[2]; return r; }
+// node k of a row, k a constant: a bit-field extract
+#define RP(r, k) ((((k) < 4 ? (r).w0 : (k) < 8 ? (r).w1 : (r).w2) >> (8 * ((k) & 3))) & 255u)
 
 struct BD {
     u32 value;      // window: the active byte in bits 31..24
     int bits;       // valid bits below it; negative: refill before the next decision
     u32 range;      // 128..255
     u32 pos, end;   // next byte to request / end of the partition (offsets into the launch's data)
-    u32 nxt;        // bytes pos-3 .. pos-1 (requested at the refill before), first byte on top; zeros past the end
+    u32 n01, n2;    // bytes pos-3, pos-2 (a little-endian pair) and pos-1 as requested at the refill before (not looked at until the next refill takes them:
+                    // the requests have the decisions in between to land) ...
+    u32 nmask;      // ... and which of them exist (zeros from the partition's end on)
     u32 over;       // bytes taken from behind the end so far
 };
 
-__device__ __forceinline__ u32 fetch3(const uint8_t *__restrict__ data, u32 pos, u32 end)
+// Request the three bytes from pos on.  No branches: they are requested whatever pos is (the launch's data are followed by
+// padding, and `limit` keeps a decoder that runs on through a damaged partition inside it).
+__device__ __forceinline__ void request3(BD &b, const uint8_t *__restrict__ data, u32 pos, u32 limit)
 {
-    const u32 b0 = pos < end ? data[pos] : 0u, b1 = pos + 1 < end ? data[pos + 1] : 0u, b2 = pos + 2 < end ? data[pos + 2] : 0u;
-    return b0 << 16 | b1 << 8 | b2;
-}
-
-__device__ __forceinline__ void bd_start(BD &b, const uint8_t *__restrict__ data, u32 value, int bits, u32 range, u32 pos, u32 end)
-{
-    b.value = value; b.bits = bits; b.range = range; b.end = end; b.over = 0;
-    b.nxt = fetch3(data, pos, end);
-    b.pos = pos + 3;
+    const uint8_t *p = data + (pos < limit ? pos : limit);
+    typedef unsigned short __attribute__((aligned(1), may_alias)) u16u;
+    b.n01 = *(const u16u *)p; b.n2 = p[2];
+    const u32 rem = b.end > pos ? b.end - pos : 0u;
+    b.nmask = rem >= 3u ? 0xffffffu : ~(0xffffffu >> (8 * rem)) & 0xffffffu;
 }
 
 // vp8dx_decode_bool (dboolhuff.h:76-120): split = 1 + (((range - 1) * probability) >> 8), the decision is whether the window is
 // at or above split; range and window renormalised by the leading zeros of the new range
-__device__ __forceinline__ int bd_get(BD &b, const uint8_t *__restrict__ data, u32 prob)
+__device__ __forceinline__ int bd_get(BD &b, const uint8_t *__restrict__ data, u32 limit, u32 prob)
 {
-    const u32 split = 1u + (((b.range - 1u) * prob) >> 8);
+    const u32 split = 1u + (__umul24(b.range - 1u, prob) >> 8);
     if (b.bits < 0) {                                   // 1..8 bits of the top byte are spent: three more bytes under them
-        b.value |= b.nxt << (-b.bits);
+        const u32 nxt = ((b.n01 & 255u) << 16 | (b.n01 & 0xff00u) | b.n2) & b.nmask;
+        b.value |= nxt << (-b.bits);
         b.bits += 24;
-        const u32 past = b.pos > b.end ? (b.pos - b.end > 3u ? 3u : b.pos - b.end) : 0u;   // how many of those three were not there
-        b.over += past;
-        b.nxt = fetch3(data, b.pos, b.end);
+        b.over += b.pos > b.end ? (b.pos - b.end > 3u ? 3u : b.pos - b.end) : 0u;   // how many of those three were not there
+        request3(b, data, b.pos, limit);
         b.pos += 3;
     }
     const u32 big = split << 24;
@@ -86,71 +98,75 @@ __device__ __forceinline__ int bd_get(BD &b, const uint8_t *__restrict__ data, u
     b.bits -= shift;
     return bit ? 1 : 0;
 }
+#define GET(b, prob) bd_get(b, data, limit, prob)
 
 // vp8dx_bool_error (dboolhuff.h:131-153) as csrc/host/vp8_boolreader.h states it: zeros from behind the end of the partition have
 // reached the top byte
 __device__ __forceinline__ bool bd_error(const BD &b) { return b.over > 0 && b.bits - 8 * (int)b.over < 0; }
 
 // intra sub-block mode tree (vp8_bmode_tree, vp8/common/entropymode.c)
-__device__ __forceinline__ int read_bmode(BD &b, const uint8_t *__restrict__ data, const uint8_t *pr)
+__device__ __forceinline__ int read_bmode(BD &b, const uint8_t *__restrict__ data, u32 limit, const Row pr)
 {
-    if (!bd_get(b, data, pr[0])) return VP8IR_B_DC_PRED;
-    if (!bd_get(b, data, pr[1])) return VP8IR_B_TM_PRED;
-    if (!bd_get(b, data, pr[2])) return VP8IR_B_VE_PRED;
-    if (!bd_get(b, data, pr[3])) {
-        if (!bd_get(b, data, pr[4])) return VP8IR_B_HE_PRED;
-        return bd_get(b, data, pr[5]) ? VP8IR_B_VR_PRED : VP8IR_B_RD_PRED;
+    if (!GET(b, RP(pr, 0))) return VP8IR_B_DC_PRED;
+    if (!GET(b, RP(pr, 1))) return VP8IR_B_TM_PRED;
+    if (!GET(b, RP(pr, 2))) return VP8IR_B_VE_PRED;
+    if (!GET(b, RP(pr, 3))) {
+        if (!GET(b, RP(pr, 4))) return VP8IR_B_HE_PRED;
+        return GET(b, RP(pr, 5)) ? VP8IR_B_VR_PRED : VP8IR_B_RD_PRED;
     }
-    if (!bd_get(b, data, pr[6])) return VP8IR_B_LD_PRED;
-    if (!bd_get(b, data, pr[7])) return VP8IR_B_VL_PRED;
-    return bd_get(b, data, pr[8]) ? VP8IR_B_HU_PRED : VP8IR_B_HD_PRED;
+    if (!GET(b, RP(pr, 6))) return VP8IR_B_LD_PRED;
+    if (!GET(b, RP(pr, 7))) return VP8IR_B_VL_PRED;
+    return GET(b, RP(pr, 8)) ? VP8IR_B_HU_PRED : VP8IR_B_HD_PRED;
 }
 
-// One 4x4 block (the body of vp8_decode_mb_tokens, detokenize.c:262-378).  pr0: the lane's probabilities of the block type in
-// LDS ([band][context][node]); out: the lane's 16 coefficients in LDS, zeroed, in the IR's column-major order.  Returns the
-// reference's eob ("c" at BLOCK_FINISHED); nz = the first token was not EOB.
-__device__ __forceinline__ int read_block(BD &b, const uint8_t *__restrict__ data, const uint8_t *pr0, int ctx, int first, coef_t *out,
-                                          int &nz)
+// One 4x4 block (the body of vp8_decode_mb_tokens, detokenize.c:262-378).  pr0: the lane's rows of the block type in LDS
+// ([band][context]); cat: the extra-bits rows; out: the lane's 16 coefficients in LDS, zeroed, in the IR's column-major order.
+// Returns the reference's eob ("c" at BLOCK_FINISHED); nz = the first token was not EOB.
+__device__ __forceinline__ int read_block(BD &b, const uint8_t *__restrict__ data, u32 limit, const row_t *pr0, const row_t *cat, int ctx,
+                                          int first, coef_t *out, int &nz)
 {
     constexpr u64 BANDS = 0x7666666665463210ull;    // vp8_coef_bands (entropy.c), a nibble per position
     constexpr u64 ZIGZAG = 0xFBEDA7369C852140ull;   // vp8_default_zig_zag1d with raster index r * 4 + c mapped to c * 4 + r
     int c = first;
-    const uint8_t *pr = pr0 + ((int)((BANDS >> (4 * c)) & 15) * 3 + ctx) * 11;
+    Row pr = row_at(pr0 + ((int)((BANDS >> (4 * c)) & 15) * 3 + ctx) * 3);
     nz = 0;
-    if (!bd_get(b, data, pr[0])) return c;
+    if (!GET(b, RP(pr, 0))) return c;
     nz = 1;
     for (;;) {
         int v, next;
-        while (!bd_get(b, data, pr[1])) {           // DCT_0: no EOB test follows a zero
+        while (!GET(b, RP(pr, 1))) {                // DCT_0: no EOB test follows a zero
             if (c == 15) return 15;                 // (a stream that codes a zero in the last position: as the reference)
             c++;
-            pr = pr0 + (int)((BANDS >> (4 * c)) & 15) * 33;
+            pr = row_at(pr0 + (int)((BANDS >> (4 * c)) & 15) * 9);
         }
-        if (!bd_get(b, data, pr[2])) {
+        if (!GET(b, RP(pr, 2))) {
             v = 1; next = 1;
         } else {
             next = 2;
-            if (!bd_get(b, data, pr[3])) {
-                if (!bd_get(b, data, pr[4])) v = 2;
-                else v = 3 + bd_get(b, data, pr[5]);
+            if (!GET(b, RP(pr, 3))) {
+                if (!GET(b, RP(pr, 4))) v = 2;
+                else v = 3 + GET(b, RP(pr, 5));
             } else {
-                int cat;                            // DCT_VAL_CATEGORY1..6: base value, number of extra bits, their probabilities
-                if (!bd_get(b, data, pr[6])) cat = bd_get(b, data, pr[7]);
-                else if (!bd_get(b, data, pr[8])) cat = 2 + bd_get(b, data, pr[9]);
-                else cat = 4 + bd_get(b, data, pr[10]);
-                const int nbits = cat < 5 ? cat + 1 : 11;
-                const int off = (int)((0xFA6310u >> (4 * cat)) & 15);     // 0, 1, 3, 6, 10, 15
+                int k;                              // DCT_VAL_CATEGORY1..6: base value, number of extra bits, their probabilities
+                if (!GET(b, RP(pr, 6))) k = GET(b, RP(pr, 7));
+                else if (!GET(b, RP(pr, 8))) k = 2 + GET(b, RP(pr, 9));
+                else k = 4 + GET(b, RP(pr, 10));
+                const int nbits = k < 5 ? k + 1 : 11;
+                const Row cr = row_at(cat + 3 * k);
                 int x = 0;
-                for (int i = 0; i < nbits; i++) x = (x << 1) | bd_get(b, data, k_cat_probs[off + i]);
-                v = (cat < 5 ? 3 + (2 << cat) : 67) + x;                  // 5, 7, 11, 19, 35, 67
+                for (int i = 0; i < nbits; i++) {
+                    const u32 w = i < 4 ? cr.w0 : i < 8 ? cr.w1 : cr.w2;
+                    x = (x << 1) | GET(b, (w >> (8 * (i & 3))) & 255u);
+                }
+                v = (k < 5 ? 3 + (2 << k) : 67) + x;                      // 5, 7, 11, 19, 35, 67
             }
         }
-        if (bd_get(b, data, 128)) v = -v;
+        if (GET(b, 128)) v = -v;
         out[(int)((ZIGZAG >> (4 * c)) & 15)] = (coef_t)v;
         if (c == 15) return 15;                     // the reference leaves c at 15 here (detokenize.c:140-146)
         c++;
-        pr = pr0 + ((int)((BANDS >> (4 * c)) & 15) * 3 + next) * 11;
-        if (!bd_get(b, data, pr[0])) return c;
+        pr = row_at(pr0 + ((int)((BANDS >> (4 * c)) & 15) * 3 + next) * 3);
+        if (!GET(b, RP(pr, 0))) return c;
     }
 }
 
@@ -161,27 +177,36 @@ __device__ __forceinline__ int read_block(BD &b, const uint8_t *__restrict__ dat
 // (the row above's sub-block modes and non-zero flags per macroblock column, the token partitions' decoder states).
 extern "C" __global__ void __launch_bounds__(64)
 vp8_entropy_kernel(const vp8hip_entropy_frame *__restrict__ frames, int count, int lpw, const uint8_t *__restrict__ data, DevGeom g,
-                   char *slot_base, size_t slot_bytes, size_t o_mbs, size_t o_coef, int first_slot, u32 *__restrict__ scratch,
-                   u32 *__restrict__ status)
+                   u32 limit, char *slot_base, size_t slot_bytes, size_t o_mbs, size_t o_coef, int first_slot,
+                   u32 *__restrict__ scratch, u32 *__restrict__ status)
 {
-    __shared__ uint8_t s_probs[64 * ENT_PROB_STRIDE];
+    __shared__ row_t s_probs[64 * ENT_PROB_WORDS];
     __shared__ u32 s_desc[64 * ENT_DESC_WORDS];
     __shared__ u32 s_blk[64 * ENT_BLK_WORDS];
+    __shared__ row_t s_kfb[100 * 3];                    // kf_bmode_probs, a row per (above, left)
+    __shared__ row_t s_cat[6 * 3];
     const int lane = threadIdx.x;
     const int f = blockIdx.x * lpw + lane;
+    for (int i = lane; i < 100 * ENT_ROW; i += 64) {
+        const int row = i / ENT_ROW, k = i - row * ENT_ROW;
+        ((uint8_t *)s_kfb)[i] = k < 9 ? k_kf_bmode_probs[row * 9 + k] : (uint8_t)0;
+    }
+    for (int i = lane; i < 6 * ENT_ROW; i += 64) ((uint8_t *)s_cat)[i] = k_cat_rows[i];
+    __syncthreads();
     if (lane >= lpw || f >= count) return;
     const vp8hip_entropy_frame &F = frames[f];
     const int cols = g.mb_cols, rows = g.mb_rows;
     u32 *abm = scratch + (size_t)f * (2 * cols + 64);   // the row above: four sub-block modes per macroblock column, a nibble each
     u32 *anz = abm + cols;                              // ... and its non-zero flags: bits 0..3 Y, 4..5 U, 6..7 V, 8 Y2
     u32 *tst = anz + cols;                              // token partitions' states: 8 words each
-    uint8_t *probs = s_probs + lane * ENT_PROB_STRIDE;
+    row_t *probs = s_probs + lane * ENT_PROB_WORDS;
     u32 *desc = s_desc + lane * ENT_DESC_WORDS;
     u32 *blk = s_blk + lane * ENT_BLK_WORDS;
-    {
-        const u32 *src = (const u32 *)F.coef_probs;
-        u32 *dst = (u32 *)probs;
-        for (int i = 0; i < 264; i++) dst[i] = src[i];
+    for (int row = 0; row < 96; row++) {                               // [type][band][context] rows of 11 -> rows of 12
+        const uint8_t *src = F.coef_probs + row * 11;
+        uint8_t *dst = (uint8_t *)probs + row * ENT_ROW;
+        for (int k = 0; k < 11; k++) dst[k] = src[k];
+        dst[11] = 0;
     }
     for (int c = 0; c < cols; c++) { abm[c] = 0; anz[c] = 0; }         // outside the frame: B_DC_PRED, nothing coded
     const u32 base = F.data_off;
@@ -191,7 +216,9 @@ vp8_entropy_kernel(const vp8hip_entropy_frame *__restrict__ frames, int count, i
         t[0] = 0; t[1] = (u32)-8; t[2] = 255; t[3] = base + F.tok_pos[k]; t[4] = base + F.tok_end[k]; t[5] = 0;
     }
     BD fb;                                                             // first partition: where the host's header parse stopped
-    bd_start(fb, data, F.first_value, F.first_bits, F.first_range, base + F.first_pos, base + F.first_end);
+    fb.value = F.first_value; fb.bits = F.first_bits; fb.range = F.first_range; fb.end = base + F.first_end; fb.over = 0;
+    request3(fb, data, base + F.first_pos, limit);
+    fb.pos = base + F.first_pos + 3;
     const bool seg_map = F.update_mb_segmentation_map != 0, has_skip = F.mb_no_coeff_skip != 0;
     const u32 p_skip = F.prob_skip_false, tp0 = F.segment_tree_probs[0], tp1 = F.segment_tree_probs[1], tp2 = F.segment_tree_probs[2];
     char *slot = slot_base + slot_bytes * (size_t)(first_slot + f);
@@ -204,20 +231,20 @@ vp8_entropy_kernel(const vp8hip_entropy_frame *__restrict__ frames, int count, i
         {
             const u32 *t = tst + 8 * (r & (ntok - 1));                 // round robin by row (decodframe.c:1116-1129)
             tb.value = t[0]; tb.bits = (int)t[1]; tb.range = t[2]; tb.end = t[4]; tb.over = t[5];
-            if (r < ntok) { tb.nxt = fetch3(data, t[3], t[4]); tb.pos = t[3] + 3; }
-            else { tb.nxt = t[6]; tb.pos = t[3]; }
+            if (r < ntok) { request3(tb, data, t[3], limit); tb.pos = t[3] + 3; }
+            else { tb.n01 = (t[6] >> 16) | (t[6] & 0xff00u); tb.n2 = t[6] & 255u; tb.nmask = 0xffffffu; tb.pos = t[3]; }
         }
         u32 lbm = 0, lnz = 0;                                          // left of the row: B_DC_PRED, nothing coded
         for (int c = 0; c < cols; c++) {
             const long n = (long)r * cols + c;
             // ---- modes (vp8_kfread_modes, decodemv.c:50-173)
             int seg = 0;
-            if (seg_map) seg = bd_get(fb, data, tp0) ? 2 + bd_get(fb, data, tp2) : bd_get(fb, data, tp1);
-            int skip = has_skip ? bd_get(fb, data, p_skip) : 0;
+            if (seg_map) seg = GET(fb, tp0) ? 2 + GET(fb, tp2) : GET(fb, tp1);
+            int skip = has_skip ? GET(fb, p_skip) : 0;
             int ymode;
-            if (!bd_get(fb, data, 145)) ymode = VP8IR_B_PRED;
-            else if (!bd_get(fb, data, 156)) ymode = bd_get(fb, data, 163) ? VP8IR_V_PRED : VP8IR_DC_PRED;
-            else ymode = bd_get(fb, data, 128) ? VP8IR_TM_PRED : VP8IR_H_PRED;
+            if (!GET(fb, 145)) ymode = VP8IR_B_PRED;
+            else if (!GET(fb, 156)) ymode = GET(fb, 163) ? VP8IR_V_PRED : VP8IR_DC_PRED;
+            else ymode = GET(fb, 128) ? VP8IR_TM_PRED : VP8IR_H_PRED;
 #pragma unroll
             for (int i = 0; i < 16; i++) desc[i] = 0;
             const u32 above = abm[c];
@@ -226,7 +253,7 @@ vp8_entropy_kernel(const vp8hip_entropy_frame *__restrict__ frames, int count, i
                 for (int i = 0; i < 16; i++) {
                     const int A = i < 4 ? (int)((above >> (4 * i)) & 15) : (int)((bm >> (4 * (i - 4))) & 15);
                     const int L = (i & 3) == 0 ? (int)((lbm >> (i & 12)) & 15) : (int)((bm >> (4 * (i - 1))) & 15);
-                    const int m = read_bmode(fb, data, vp8_ent_kf_bmode_probs + (A * 10 + L) * 9);
+                    const int m = read_bmode(fb, data, limit, row_at(s_kfb + (A * 10 + L) * 3));
                     bm |= (u64)m << (4 * i);
                     ((uint8_t *)desc)[40 + i] = (uint8_t)m;
                 }
@@ -239,9 +266,9 @@ vp8_entropy_kernel(const vp8hip_entropy_frame *__restrict__ frames, int count, i
                 abm[c] = lbm = im * 0x1111u;
             }
             int uvmode;
-            if (!bd_get(fb, data, 142)) uvmode = VP8IR_DC_PRED;
-            else if (!bd_get(fb, data, 114)) uvmode = VP8IR_V_PRED;
-            else uvmode = bd_get(fb, data, 183) ? VP8IR_TM_PRED : VP8IR_H_PRED;
+            if (!GET(fb, 142)) uvmode = VP8IR_DC_PRED;
+            else if (!GET(fb, 114)) uvmode = VP8IR_V_PRED;
+            else uvmode = GET(fb, 183) ? VP8IR_TM_PRED : VP8IR_H_PRED;
 
             // ---- tokens (decode_macroblock, decodframe.c:100-130; vp8_decode_mb_tokens)
             const bool has_y2 = ymode != VP8IR_B_PRED;
@@ -266,7 +293,7 @@ vp8_entropy_kernel(const vp8hip_entropy_frame *__restrict__ frames, int count, i
                     for (int w = 0; w < 8; w++) blk[w] = 0;
                     int nz;
                     const int ctx = (int)((A >> abit) & 1) + (int)((lnz >> lbit) & 1);
-                    const int e = read_block(tb, data, probs + type * 264, ctx, first, (coef_t *)blk, nz);
+                    const int e = read_block(tb, data, limit, probs + type * 72, s_cat, ctx, first, (coef_t *)blk, nz);
                     A = (A & ~(1u << abit)) | (u32)nz << abit;
                     lnz = (lnz & ~(1u << lbit)) | (u32)nz << lbit;
                     ((uint8_t *)desc)[8 + k] = (uint8_t)e;
@@ -291,7 +318,7 @@ vp8_entropy_kernel(const vp8hip_entropy_frame *__restrict__ frames, int count, i
         bad |= bd_error(tb);
         {
             u32 *t = tst + 8 * (r & (ntok - 1));
-            t[0] = tb.value; t[1] = (u32)tb.bits; t[2] = tb.range; t[3] = tb.pos; t[5] = tb.over; t[6] = tb.nxt;
+            t[0] = tb.value; t[1] = (u32)tb.bits; t[2] = tb.range; t[3] = tb.pos; t[5] = tb.over; t[6] = ((tb.n01 & 255u) << 16 | (tb.n01 & 0xff00u) | tb.n2) & tb.nmask;
         }
     }
     bad |= bd_error(fb);

@@ -29,8 +29,8 @@ extern "C" __global__ void vp8_interframe_kernel(const DevJob *jobs, int njobs, 
                                                unsigned int *sched, int nwaves);
 extern "C" __global__ void vp8_inter_pred_kernel(const DevJob *jobs, int njobs, DevGeom g, int upf);
 extern "C" __global__ void vp8_entropy_kernel(const vp8hip_entropy_frame *frames, int count, int lpw, const uint8_t *data, DevGeom g,
-                                              char *slot_base, size_t slot_bytes, size_t o_mbs, size_t o_coef, int first_slot,
-                                              unsigned int *scratch, unsigned int *status);
+                                              unsigned int limit, char *slot_base, size_t slot_bytes, size_t o_mbs, size_t o_coef,
+                                              int first_slot, unsigned int *scratch, unsigned int *status);
 extern "C" __global__ void vp8_md5_kernel(const uint8_t *frames, size_t fstride, int count, DevGeom g, int w, int h, uint8_t *out);
 #ifdef VP8_STAMPS
 #define VP8HIP_SCHED_WORDS (16 + 16384 + 4 * 4096)     // + the diagnostic builds' log: four words per wave
@@ -1326,12 +1326,11 @@ extern "C" int vp8hip_entropy_decode(vp8hip_ctx *c, int first_slot, int count, c
         s.hdr_copy = frames[i].hdr;
         s.packed = false;
     }
-    // lanes per wave: all 64 when there are frames enough to give every SIMD of the chip a wave that way, fewer otherwise (a
-    // wave's time per decision grows with the number of different paths its lanes are on)
-    int lpw = c->ent_lpw;
-    if (!lpw) { lpw = 64; while (lpw > 8 && (count + lpw - 1) / lpw < c->num_cu * 4) lpw >>= 1; }
+    // (lanes per wave: a frame's time hardly depends on how many other frames share its wave -- 2048 1080p frames: 1.36 s at 64,
+    // 1.28 s at 4 -- so waves are filled)
+    const int lpw = c->ent_lpw ? c->ent_lpw : 64;
     hipLaunchKernelGGL(vp8_entropy_kernel, dim3((unsigned)((count + lpw - 1) / lpw)), dim3(64), 0, c->stream,
-                       (const vp8hip_entropy_frame *)c->d_ent_frames, count, lpw, (const uint8_t *)c->d_ent_data, c->dg, c->slot_block_dev,
+                       (const vp8hip_entropy_frame *)c->d_ent_frames, count, lpw, (const uint8_t *)c->d_ent_data, c->dg, (unsigned int)data_bytes, c->slot_block_dev,
                        c->slot_bytes, c->o_mbs, c->o_coef, first_slot, c->d_ent_scratch, c->d_ent_status);
     HIPCHK(c, hipGetLastError());
     return 0;

@@ -1,4 +1,4 @@
-/* batch_md5 [--threads T] [--batch B] [--loop N] [--host-md5] <in.ivf> <out.md5>
+/* batch_md5 [--threads T] [--batch B] [--loop N] [--host-md5] [--device-entropy [--no-download]] <in.ivf> <out.md5>
  *
  * decode_to_md5 for streams of independently decodable frames (all key frames), at the rate the host can feed the
  * GPU: SURVEY.md 8(f)1.  The output file has decode_to_md5's lines ("<md5>  img-<w>x<h>-<%04d>.i420", one per frame,
@@ -11,6 +11,12 @@
  * batch into pinned host memory, and the same pool hashes it.  Three slot / frame-buffer sets rotate: batch k+1 is
  * parsed while batch k is on the GPU and batch k-1 is downloaded and hashed.  --loop repeats the stream N times
  * (benchmarking; the listing then has N * frames lines).
+ *
+ * --device-entropy: the feeder threads only read the frame headers (vp8_parser_begin_frame, vp8_parser_export_entropy) and
+ * copy the compressed frames into page-locked memory; the macroblocks' modes and coefficient tokens are decoded on the GPU, a
+ * frame per lane (vp8hip_entropy_decode), straight into the IR slots the pixel path reads.  A lane takes about a second for a
+ * large 1080p key frame whatever the batch, so this mode wants batches of thousands (one set of IR slots, two sets of frame
+ * buffers).  --no-download: with the MD5s computed on the device the frames themselves stay there.
  *
  * Prints frames, seconds and frames/s for the region "first byte parsed .. last digest done" on stderr. */
 #include <pthread.h>
@@ -92,6 +98,10 @@ static uint8_t *g_dig[2];                           /* the digests of a batch as
 static int g_dev_md5;                               /* hash on the device (vp8hip_frames_fetch_async: widths that are multiples of 128),
                                                        the feeder keeps the host's cores */
 static volatile int g_failed;
+static int g_dev_entropy;                           /* --device-entropy */
+static vp8hip_entropy_frame *g_ent[2];              /* per set: the frames' descriptions for vp8hip_entropy_decode (pinned) */
+static uint8_t *g_ent_data[2];                      /* ... and their bytes, one after the other */
+static size_t g_ent_cap;
 
 typedef struct batch_ref { int b, n; long first; } batch_ref;     /* batch number, frames in it, index of its first frame */
 /* The pipeline, batch by batch (three slot / frame-buffer sets, two pinned host sets):
@@ -112,6 +122,32 @@ static void parse_one(void *arg, int i, int worker)
                                                &g_maps[slot].nblocks, g_maps[slot].dcs, &g_maps[slot].ndcs, g_maps[slot].mvs, NULL);
     if (rc) { g_failed = 1; return; }
     *g_maps[slot].hdr = hdr;
+}
+
+/* --device-entropy: the header on the host, the rest of the frame handed over as it is (data_off was set by the main thread) */
+static void export_one(void *arg, int i, int worker)
+{
+    const batch_ref *br = (const batch_ref *)arg;
+    const frame *f = &g_frames[(br->first + i) % g_nframes];
+    vp8hip_entropy_frame *e = &g_ent[br->b & 1][i];
+    const uint32_t off = e->data_off;
+    vp8ir_frame_hdr hdr;
+    int rc = vp8_parser_begin_frame(g_parsers[worker], f->data, f->size, &hdr);
+    if (!rc && (hdr.frame_type != 0 || hdr.width != g_width || hdr.height != g_height)) rc = VP8P_UNSUP_BITSTREAM;
+    if (!rc) rc = vp8_parser_export_entropy(g_parsers[worker], e);
+    if (rc) { g_failed = 1; return; }
+    e->data_off = off;
+    memcpy(g_ent_data[br->b & 1] + off, f->data, f->size);
+}
+/* where the frames of a batch go in the set's data buffer; returns the bytes in all */
+static size_t place_frames(const batch_ref *br)
+{
+    size_t off = 0;
+    for (int i = 0; i < br->n; i++) {
+        g_ent[br->b & 1][i].data_off = (uint32_t)off;
+        off += g_frames[(br->first + i) % g_nframes].size;
+    }
+    return off;
 }
 
 static void hash_one(void *arg, int i, int worker)
@@ -143,17 +179,19 @@ static double now_s(void)
 
 int main(int argc, char **argv)
 {
-    int threads = 0, loop = 1, a = 1, host_md5 = 0;
+    int threads = 0, loop = 1, a = 1, host_md5 = 0, no_download = 0;
     g_batch = 128;
     for (; a < argc && argv[a][0] == '-' && argv[a][1] == '-'; a++) {
         if (!strcmp(argv[a], "--threads") && a + 1 < argc) threads = atoi(argv[++a]);
         else if (!strcmp(argv[a], "--host-md5")) host_md5 = 1;          /* hash on the host whatever the frame size */
+        else if (!strcmp(argv[a], "--device-entropy")) g_dev_entropy = 1;
+        else if (!strcmp(argv[a], "--no-download")) no_download = 1;
         else if (!strcmp(argv[a], "--batch") && a + 1 < argc) g_batch = atoi(argv[++a]);
         else if (!strcmp(argv[a], "--loop") && a + 1 < argc) loop = atoi(argv[++a]);
-        else DIE("Usage: %s [--threads T] [--batch B] [--loop N] [--host-md5] <in.ivf> <out.md5>", argv[0]);
+        else DIE("Usage: %s [--threads T] [--batch B] [--loop N] [--host-md5] [--device-entropy [--no-download]] <in.ivf> <out.md5>", argv[0]);
     }
     if (argc - a != 2 || g_batch < 1 || loop < 1)
-        DIE("Usage: %s [--threads T] [--batch B] [--loop N] [--host-md5] <in.ivf> <out.md5>", argv[0]);
+        DIE("Usage: %s [--threads T] [--batch B] [--loop N] [--host-md5] [--device-entropy [--no-download]] <in.ivf> <out.md5>", argv[0]);
     if (threads < 1) {
         long n = sysconf(_SC_NPROCESSORS_ONLN);
         threads = n > 33 ? 32 : (n > 2 ? (int)n - 1 : 1);      /* more than ~32 feeders gain nothing: the host memory system is the limit */
@@ -184,18 +222,40 @@ int main(int argc, char **argv)
     int device = -1;
     if (getenv("VP8HIP_DEVICE")) device = atoi(getenv("VP8HIP_DEVICE"));
     if (vp8hip_create(device, &g_hip)) DIE("vp8hip_create: %s (no CPU fallback)", vp8hip_last_error(NULL));
-    HIP(vp8hip_configure(g_hip, g_width, g_height, 3 * g_batch, 3 * g_batch));
+    g_dev_md5 = !host_md5 && g_width % 128 == 0;
+    if (no_download && !g_dev_md5) DIE("--no-download needs the MD5s computed on the device (a width that is a multiple of 128, no --host-md5)");
+    /* slots and frame buffers: three sets for the host feeder (parsed / on the GPU / coming back); with the entropy decoder on
+       the device the IR is written and read on one stream, one set does, and the frame buffers alternate between two */
+    const int slot_sets = g_dev_entropy ? 1 : 3, fb_sets = g_dev_entropy ? 2 : 3;
+    HIP(vp8hip_configure(g_hip, g_width, g_height, fb_sets * g_batch, slot_sets * g_batch));
     HIP(vp8hip_geometry(g_hip, &g_geom));
-    g_maps = calloc((size_t)3 * g_batch, sizeof *g_maps);
-    for (int s = 0; s < 3 * g_batch; s++)
-        HIP(vp8hip_ir_map_sparse(g_hip, s, &g_maps[s].hdr, &g_maps[s].mbs, &g_maps[s].blocks, &g_maps[s].cap, &g_maps[s].dcs, &g_maps[s].mvs));
+    if (g_dev_entropy) {
+        {   /* the largest run of g_batch consecutive frames, the stream repeating */
+            size_t all = 0, best = 0;
+            const int rem = g_batch % g_nframes;
+            for (int i = 0; i < g_nframes; i++) all += g_frames[i].size;
+            for (int i = 0; i < g_nframes; i++) {
+                size_t run = 0;
+                for (int k = 0; k < rem; k++) run += g_frames[(i + k) % g_nframes].size;
+                if (run > best) best = run;
+            }
+            g_ent_cap = (size_t)(g_batch / g_nframes) * all + best;
+        }
+        for (int k = 0; k < 2; k++) {
+            if (!(g_ent[k] = (vp8hip_entropy_frame *)vp8hip_host_alloc(g_hip, (size_t)g_batch * sizeof(vp8hip_entropy_frame))) ||
+                !(g_ent_data[k] = (uint8_t *)vp8hip_host_alloc(g_hip, g_ent_cap + 16))) DIE("vp8hip_host_alloc: %s", vp8hip_last_error(g_hip));
+        }
+    } else {
+        g_maps = calloc((size_t)3 * g_batch, sizeof *g_maps);
+        for (int s = 0; s < 3 * g_batch; s++)
+            HIP(vp8hip_ir_map_sparse(g_hip, s, &g_maps[s].hdr, &g_maps[s].mbs, &g_maps[s].blocks, &g_maps[s].cap, &g_maps[s].dcs, &g_maps[s].mvs));
+    }
     g_stride = vp8hip_frame_stride(g_hip);
     for (int k = 0; k < 2; k++) {
-        if (!(g_host[k] = (uint8_t *)vp8hip_host_alloc(g_hip, (size_t)g_batch * g_stride))) DIE("vp8hip_host_alloc: %s", vp8hip_last_error(g_hip));
+        if (!no_download && !(g_host[k] = (uint8_t *)vp8hip_host_alloc(g_hip, (size_t)g_batch * g_stride))) DIE("vp8hip_host_alloc: %s", vp8hip_last_error(g_hip));
         if (!(g_dig[k] = (uint8_t *)vp8hip_host_alloc(g_hip, (size_t)g_batch * 16))) DIE("vp8hip_host_alloc: %s", vp8hip_last_error(g_hip));
     }
     g_digest = calloc((size_t)total, 16);
-    g_dev_md5 = !host_md5 && g_width % 128 == 0;
     g_parsers = calloc((size_t)threads, sizeof *g_parsers);
     pthread_t *tid = calloc((size_t)threads, sizeof *tid);
     for (int t = 0; t < threads; t++) {
@@ -208,24 +268,29 @@ int main(int argc, char **argv)
     const long nbatch = (total + g_batch - 1) / g_batch;
     task parse_t, hash_t;
     batch_ref cur = { 0, (int)(total < g_batch ? total : g_batch), 0 }, nxt, prev = { -1, 0, 0 }, hashing = { -1, 0, 0 };
+    const task_fn feed = g_dev_entropy ? export_one : parse_one;
+    size_t ent_bytes = 0;
     const double t0 = now_s();
-    task_start(&parse_t, 0, parse_one, &cur, cur.n);
+    if (g_dev_entropy) ent_bytes = place_frames(&cur);
+    task_start(&parse_t, 0, feed, &cur, cur.n);
     for (long b = 0; b < nbatch; b++) {
         task_wait(&parse_t, 0);
         if (g_failed) DIE("a frame of batch %ld failed to parse", b);
         const batch_ref now = cur;
-        if (b + 1 < nbatch) {
+        if (b + 1 < nbatch && !g_dev_entropy) {
             /* the feeder goes on with the next batch at once -- slot set (b+1)%3 was last used by batch b-2, which came back an
                iteration ago -- while this thread downloads batch b-1 and uploads and launches batch b */
             const long first = cur.first + cur.n;
             nxt.b = cur.b + 1; nxt.first = first; nxt.n = (int)(total - first < g_batch ? total - first : g_batch);
             cur = nxt;
-            task_start(&parse_t, 0, parse_one, &cur, cur.n);
+            task_start(&parse_t, 0, feed, &cur, cur.n);
         }
+        const int fb0 = g_dev_entropy ? (now.b & 1) * g_batch : (now.b % 3) * g_batch;
+        if (g_dev_entropy) HIP(vp8hip_entropy_decode(g_hip, 0, now.n, g_ent[now.b & 1], g_ent_data[now.b & 1], ent_bytes));
         for (int i = 0; i < now.n; i++) {
-            const int s = (now.b % 3) * g_batch + i;
-            HIP(vp8hip_ir_upload_sparse(g_hip, s, g_maps[s].nblocks, g_maps[s].ndcs));
-            jobs[i].ir_slot = s; jobs[i].dst_fb = s;
+            const int s = g_dev_entropy ? i : (now.b % 3) * g_batch + i;
+            if (!g_dev_entropy) HIP(vp8hip_ir_upload_sparse(g_hip, s, g_maps[s].nblocks, g_maps[s].ndcs));
+            jobs[i].ir_slot = s; jobs[i].dst_fb = fb0 + i;
             jobs[i].ref_fb[0] = jobs[i].ref_fb[1] = jobs[i].ref_fb[2] = jobs[i].ref_fb[3] = -1;
         }
         HIP(vp8hip_decode(g_hip, jobs, now.n, VP8HIP_STAGE_ALL));
@@ -238,7 +303,16 @@ int main(int argc, char **argv)
                 task_start(&hash_t, 1, hash_one, &hashing, hashing.n);
             }
         }
-        HIP(vp8hip_frames_fetch_async(g_hip, (now.b % 3) * g_batch, now.n, g_host[now.b & 1], g_dev_md5 ? g_dig[now.b & 1] : NULL));
+        if (b + 1 < nbatch && g_dev_entropy) {
+            /* the headers of the next batch (little work).  The pinned set it is written to was handed to the GPU two batches
+               ago, and that batch's digests have just come back: its copies are done */
+            const long first = cur.first + cur.n;
+            nxt.b = cur.b + 1; nxt.first = first; nxt.n = (int)(total - first < g_batch ? total - first : g_batch);
+            cur = nxt;
+            ent_bytes = place_frames(&cur);
+            task_start(&parse_t, 0, feed, &cur, cur.n);
+        }
+        HIP(vp8hip_frames_fetch_async(g_hip, fb0, now.n, no_download ? NULL : g_host[now.b & 1], g_dev_md5 ? g_dig[now.b & 1] : NULL));
         prev = now;
     }
     HIP(vp8hip_download_wait(g_hip));
@@ -259,16 +333,18 @@ int main(int argc, char **argv)
         fprintf(out, "  img-%dx%d-%04ld.i420\n", g_width, g_height, f + 1);
     }
     fclose(out);
-    fprintf(stderr, "%ld frames in %.3f s: %.1f frames/s, %.1f Mpix/s (%d feeder threads, %d frames per launch, MD5 on the %s)\n", total, dt,
-            total / dt, total / dt * g_width * g_height / 1e6, threads, g_batch, g_dev_md5 ? "device" : "host");
+    fprintf(stderr, "%ld frames in %.3f s: %.1f frames/s, %.1f Mpix/s (%d feeder threads, %d frames per launch, entropy decode on the %s, MD5 on the %s%s)\n",
+            total, dt, total / dt, total / dt * g_width * g_height / 1e6, threads, g_batch, g_dev_entropy ? "device" : "host",
+            g_dev_md5 ? "device" : "host", no_download ? ", frames not downloaded" : "");
 
     pthread_mutex_lock(&pool.mu);
     pool.stop = 1;
     pthread_cond_broadcast(&pool.work);
     pthread_mutex_unlock(&pool.mu);
     for (int t = 0; t < threads; t++) { pthread_join(tid[t], NULL); vp8_parser_destroy(g_parsers[t]); }
-    vp8hip_host_free(g_hip, g_host[0]);
-    vp8hip_host_free(g_hip, g_host[1]);
+    if (g_host[0]) vp8hip_host_free(g_hip, g_host[0]);
+    if (g_host[1]) vp8hip_host_free(g_hip, g_host[1]);
+    for (int k = 0; k < 2; k++) if (g_ent[k]) { vp8hip_host_free(g_hip, g_ent[k]); vp8hip_host_free(g_hip, g_ent_data[k]); }
     vp8hip_host_free(g_hip, g_dig[0]);
     vp8hip_host_free(g_hip, g_dig[1]);
     vp8hip_destroy(g_hip);

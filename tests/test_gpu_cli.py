@@ -46,7 +46,14 @@ def test_api_rejects_bad_streams():
 @pytest.mark.parametrize("name,args", [("kf_640x360", ["--threads", "4", "--batch", "3"]), ("kf_odd_67x45", ["--batch", "64"]),
                                        ("kf_640x360", ["--host-md5", "--batch", "7"]),
                                        ("kf_q0_176x144", ["--threads", "2", "--batch", "4", "--loop", "5"]),
-                                       ("kf_1920x1080", [])])
+                                       ("kf_1920x1080", []),
+                                       # the entropy decoder on the device (vp8hip_entropy_decode): batches that end unevenly, a stream
+                                       # shorter than the batch, eight token partitions, the host hashing, frames left on the device
+                                       ("kf_640x360", ["--device-entropy", "--batch", "7", "--loop", "3"]),
+                                       ("kf_odd_67x45", ["--device-entropy", "--batch", "64", "--loop", "30"]),
+                                       ("kf_8part_1920x1080", ["--device-entropy", "--batch", "4", "--loop", "4", "--no-download"]),
+                                       ("kf_640x360", ["--device-entropy", "--host-md5", "--batch", "16", "--loop", "4"]),
+                                       ("kf_1920x1080", ["--device-entropy", "--batch", "32", "--loop", "7"])])
 def test_batch_md5_listing_equals_decode_to_md5(name, args, tmp_path):
     """The threaded feeder + batched launches (batch_md5) write decode_to_md5's listing, line for line; looped, the
     digests repeat with continuing frame numbers."""
@@ -55,7 +62,8 @@ def test_batch_md5_listing_equals_decode_to_md5(name, args, tmp_path):
     assert r.returncode == 0, r.stderr
     assert "frames/s" in r.stderr
     # widths that are whole MD5 blocks per row (multiples of 128) are hashed on the device, a frame per lane (vp8_md5.hip)
-    assert ("MD5 on the device" in r.stderr) == (name in ("kf_640x360", "kf_1920x1080") and "--host-md5" not in args), r.stderr
+    assert ("MD5 on the device" in r.stderr) == (name in ("kf_640x360", "kf_1920x1080", "kf_8part_1920x1080") and "--host-md5" not in args), r.stderr
+    assert ("entropy decode on the device" in r.stderr) == ("--device-entropy" in args)
     loop = int(args[args.index("--loop") + 1]) if "--loop" in args else 1
     gold = open(os.path.join(GOLDEN, name + ".md5")).read().splitlines()
     got = open(out).read().splitlines()
