@@ -158,7 +158,7 @@ int  vp8hip_mfqe(vp8hip_ctx *ctx, int show_fb, int prev_fb, int dst_fb, const ui
  * from there.  Integer only. */
 typedef struct vp8hip_entropy_frame {
     vp8ir_frame_hdr hdr;                /* as vp8_parser_begin_frame returned it; a key frame of the context's size */
-    uint32_t data_off;                  /* the frame's first byte in the buffer handed to vp8hip_entropy_decode */
+    uint64_t data_off;                  /* the frame's first byte in the buffer handed to vp8hip_entropy_decode */
     uint32_t first_pos, first_end;      /* first partition, relative to data_off: the next byte the decoder takes, and its end */
     uint32_t first_value;               /* ... its window (32 bits, the active byte on top), */
     int32_t  first_bits;                /*     the valid bits below the top byte (negative: refill due), */

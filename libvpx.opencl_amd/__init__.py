@@ -64,7 +64,7 @@ assert ctypes.sizeof(FrameHdr) == 64
 
 class EntropyFrame(ctypes.Structure):
     """vp8hip_entropy_frame (include/vp8hip.h): what the host's header parse hands to the device's entropy decoder."""
-    _fields_ = [("hdr", FrameHdr), ("data_off", ctypes.c_uint32), ("first_pos", ctypes.c_uint32), ("first_end", ctypes.c_uint32),
+    _fields_ = [("hdr", FrameHdr), ("data_off", ctypes.c_uint64), ("first_pos", ctypes.c_uint32), ("first_end", ctypes.c_uint32),
                 ("first_value", ctypes.c_uint32), ("first_bits", ctypes.c_int32), ("first_range", ctypes.c_uint32),
                 ("num_tok", ctypes.c_uint32), ("tok_pos", ctypes.c_uint32 * 8), ("tok_end", ctypes.c_uint32 * 8),
                 ("update_mb_segmentation_map", ctypes.c_uint8), ("mb_no_coeff_skip", ctypes.c_uint8),

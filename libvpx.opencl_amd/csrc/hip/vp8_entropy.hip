@@ -62,6 +62,9 @@ struct BD {
                     // the requests have the decisions in between to land) ...
     u32 nmask;      // ... and which of them exist (zeros from the partition's end on)
     u32 over;       // bytes taken from behind the end so far
+#ifdef ENT_STATS
+    u32 count;      // (diagnostic builds: decisions taken)
+#endif
 };
 
 // Request the three bytes from pos on.  No branches: they are requested whatever pos is (the launch's data are followed by
@@ -80,6 +83,9 @@ __device__ __forceinline__ void request3(BD &b, const uint8_t *__restrict__ data
 __device__ __forceinline__ int bd_get(BD &b, const uint8_t *__restrict__ data, u32 limit, u32 prob)
 {
     const u32 split = 1u + (__umul24(b.range - 1u, prob) >> 8);
+#ifdef ENT_STATS
+    b.count++;
+#endif
     if (b.bits < 0) {                                   // 1..8 bits of the top byte are spent: three more bytes under them
         const u32 nxt = ((b.n01 & 255u) << 16 | (b.n01 & 0xff00u) | b.n2) & b.nmask;
         b.value |= nxt << (-b.bits);
@@ -176,8 +182,8 @@ __device__ __forceinline__ int read_block(BD &b, const uint8_t *__restrict__ dat
 // coefficients at o_coef).  lpw: lanes of each wave that carry a frame (1..64).  scratch: per frame (2 * mb_cols + 64) words
 // (the row above's sub-block modes and non-zero flags per macroblock column, the token partitions' decoder states).
 extern "C" __global__ void __launch_bounds__(64)
-vp8_entropy_kernel(const vp8hip_entropy_frame *__restrict__ frames, int count, int lpw, const uint8_t *__restrict__ data, DevGeom g,
-                   u32 limit, char *slot_base, size_t slot_bytes, size_t o_mbs, size_t o_coef, int first_slot,
+vp8_entropy_kernel(const vp8hip_entropy_frame *__restrict__ frames, int count, int lpw, const uint8_t *__restrict__ all_data, DevGeom g,
+                   size_t data_bytes, char *slot_base, size_t slot_bytes, size_t o_mbs, size_t o_coef, int first_slot,
                    u32 *__restrict__ scratch, u32 *__restrict__ status)
 {
     __shared__ row_t s_probs[64 * ENT_PROB_WORDS];
@@ -209,7 +215,10 @@ vp8_entropy_kernel(const vp8hip_entropy_frame *__restrict__ frames, int count, i
         dst[11] = 0;
     }
     for (int c = 0; c < cols; c++) { abm[c] = 0; anz[c] = 0; }         // outside the frame: B_DC_PRED, nothing coded
-    const u32 base = F.data_off;
+    // positions are relative to the frame's first byte; what may be read: to the end of the launch's data (followed by padding)
+    const uint8_t *__restrict__ data = all_data + F.data_off;
+    const u32 limit = data_bytes - F.data_off < 0xfffffff0ull ? (u32)(data_bytes - F.data_off) : 0xfffffff0u;
+    const u32 base = 0;
     const int ntok = (int)F.num_tok;
     for (int k = 0; k < ntok; k++) {                                   // a fresh decoder per partition (vp8dx_start_decode)
         u32 *t = tst + 8 * k;
@@ -217,6 +226,9 @@ vp8_entropy_kernel(const vp8hip_entropy_frame *__restrict__ frames, int count, i
     }
     BD fb;                                                             // first partition: where the host's header parse stopped
     fb.value = F.first_value; fb.bits = F.first_bits; fb.range = F.first_range; fb.end = base + F.first_end; fb.over = 0;
+#ifdef ENT_STATS
+    fb.count = 0; u32 tcount = 0;
+#endif
     request3(fb, data, base + F.first_pos, limit);
     fb.pos = base + F.first_pos + 3;
     const bool seg_map = F.update_mb_segmentation_map != 0, has_skip = F.mb_no_coeff_skip != 0;
@@ -231,6 +243,9 @@ vp8_entropy_kernel(const vp8hip_entropy_frame *__restrict__ frames, int count, i
         {
             const u32 *t = tst + 8 * (r & (ntok - 1));                 // round robin by row (decodframe.c:1116-1129)
             tb.value = t[0]; tb.bits = (int)t[1]; tb.range = t[2]; tb.end = t[4]; tb.over = t[5];
+#ifdef ENT_STATS
+            tb.count = 0;
+#endif
             if (r < ntok) { request3(tb, data, t[3], limit); tb.pos = t[3] + 3; }
             else { tb.n01 = (t[6] >> 16) | (t[6] & 0xff00u); tb.n2 = t[6] & 255u; tb.nmask = 0xffffffu; tb.pos = t[3]; }
         }
@@ -316,11 +331,18 @@ vp8_entropy_kernel(const vp8hip_entropy_frame *__restrict__ frames, int count, i
             for (int w = 0; w < 4; w++) out_mbs[n * 4 + w] = (u32x4){ desc[4 * w], desc[4 * w + 1], desc[4 * w + 2], desc[4 * w + 3] };
         }
         bad |= bd_error(tb);
+#ifdef ENT_STATS
+        tcount += tb.count;
+#endif
         {
             u32 *t = tst + 8 * (r & (ntok - 1));
             t[0] = tb.value; t[1] = (u32)tb.bits; t[2] = tb.range; t[3] = tb.pos; t[5] = tb.over; t[6] = ((tb.n01 & 255u) << 16 | (tb.n01 & 0xff00u) | tb.n2) & tb.nmask;
         }
     }
     bad |= bd_error(fb);
+#ifdef ENT_STATS      // decisions of the first partition in the low half, of the token partitions (the last row's) in the high half
+    if (status) status[f] = (fb.count >> 4 & 0xffffu) | tcount >> 8 << 16;
+#else
     if (status) status[f] = bad ? 1u : 0u;
+#endif
 }

@@ -29,7 +29,7 @@ extern "C" __global__ void vp8_interframe_kernel(const DevJob *jobs, int njobs, 
                                                unsigned int *sched, int nwaves);
 extern "C" __global__ void vp8_inter_pred_kernel(const DevJob *jobs, int njobs, DevGeom g, int upf);
 extern "C" __global__ void vp8_entropy_kernel(const vp8hip_entropy_frame *frames, int count, int lpw, const uint8_t *data, DevGeom g,
-                                              unsigned int limit, char *slot_base, size_t slot_bytes, size_t o_mbs, size_t o_coef,
+                                              size_t data_bytes, char *slot_base, size_t slot_bytes, size_t o_mbs, size_t o_coef,
                                               int first_slot, unsigned int *scratch, unsigned int *status);
 extern "C" __global__ void vp8_md5_kernel(const uint8_t *frames, size_t fstride, int count, DevGeom g, int w, int h, uint8_t *out);
 #ifdef VP8_STAMPS
@@ -1271,7 +1271,7 @@ extern "C" int vp8hip_mfqe(vp8hip_ctx *c, int show_fb, int prev_fb, int dst_fb, 
 extern "C" int vp8hip_entropy_decode(vp8hip_ctx *c, int first_slot, int count, const vp8hip_entropy_frame *frames, const uint8_t *data,
                                      size_t data_bytes)
 {
-    if (!c || !frames || !data || count < 1 || first_slot < 0 || first_slot + count > (int)c->slots.size() || data_bytes >= (1ull << 32) - 16)
+    if (!c || !frames || !data || count < 1 || first_slot < 0 || first_slot + count > (int)c->slots.size())
         return fail(c, -2, "vp8hip_entropy_decode: bad arguments");
     for (int i = 0; i < count; i++) {
         const vp8hip_entropy_frame &f = frames[i];
@@ -1281,7 +1281,7 @@ extern "C" int vp8hip_entropy_decode(vp8hip_ctx *c, int first_slot, int count, c
             return fail(c, -2, "vp8hip_entropy_decode: frame %d is %dx%d MBs, context configured for %dx%d", i, h.mb_cols, h.mb_rows,
                         c->dg.mb_cols, c->dg.mb_rows);
         bool ok = (f.num_tok == 1 || f.num_tok == 2 || f.num_tok == 4 || f.num_tok == 8) && f.data_off <= data_bytes &&
-                  f.first_pos <= f.first_end && f.first_end <= data_bytes - f.data_off && f.first_range >= 128 && f.first_range <= 255 &&
+                  f.first_pos <= f.first_end && f.first_end <= data_bytes - f.data_off && data_bytes - f.data_off >= f.first_end && f.first_range >= 128 && f.first_range <= 255 &&
                   f.first_bits >= -8 && f.first_bits <= 24;
         for (unsigned k = 0; ok && k < f.num_tok; k++) ok = f.tok_pos[k] <= f.tok_end[k] && f.tok_end[k] <= data_bytes - f.data_off;
         if (!ok) return fail(c, -2, "vp8hip_entropy_decode: frame %d: partitions outside the data, or no decoder state", i);
@@ -1330,7 +1330,7 @@ extern "C" int vp8hip_entropy_decode(vp8hip_ctx *c, int first_slot, int count, c
     // 1.28 s at 4 -- so waves are filled)
     const int lpw = c->ent_lpw ? c->ent_lpw : 64;
     hipLaunchKernelGGL(vp8_entropy_kernel, dim3((unsigned)((count + lpw - 1) / lpw)), dim3(64), 0, c->stream,
-                       (const vp8hip_entropy_frame *)c->d_ent_frames, count, lpw, (const uint8_t *)c->d_ent_data, c->dg, (unsigned int)data_bytes, c->slot_block_dev,
+                       (const vp8hip_entropy_frame *)c->d_ent_frames, count, lpw, (const uint8_t *)c->d_ent_data, c->dg, data_bytes, c->slot_block_dev,
                        c->slot_bytes, c->o_mbs, c->o_coef, first_slot, c->d_ent_scratch, c->d_ent_status);
     HIPCHK(c, hipGetLastError());
     return 0;

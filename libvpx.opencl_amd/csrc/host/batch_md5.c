@@ -99,6 +99,11 @@ static int g_dev_md5;                               /* hash on the device (vp8hi
                                                        the feeder keeps the host's cores */
 static volatile int g_failed;
 static int g_dev_entropy;                           /* --device-entropy */
+static long *g_order;                               /* --device-entropy: which frame of the run the k-th processed one is.  A lane of the
+                                                       entropy kernel is busy for as long as its frame is large and a launch lasts as long
+                                                       as its longest lane, so the frames of SORT_WINDOW batches at a time are taken
+                                                       largest first: the frames of a launch are of a size */
+#define SORT_WINDOW 16
 static vp8hip_entropy_frame *g_ent[2];              /* per set: the frames' descriptions for vp8hip_entropy_decode (pinned) */
 static uint8_t *g_ent_data[2];                      /* ... and their bytes, one after the other */
 static size_t g_ent_cap;
@@ -109,6 +114,14 @@ typedef struct batch_ref { int b, n; long first; } batch_ref;     /* batch numbe
  *   this thread      uploads batch b (one copy + one expansion launch per frame), launches its pixel path, then asks for the
  *                    frames back: ONE asynchronous device-to-host copy of the whole batch on a stream of its own
  *   hash threads     MD5 of batch b-1, which that copy delivered during the previous iteration */
+
+static inline long run_index(long k) { return g_order ? g_order[k] : k; }
+static int by_size_desc(const void *pa, const void *pb)
+{
+    const long a = *(const long *)pa, b = *(const long *)pb;
+    const size_t sa = g_frames[a % g_nframes].size, sb = g_frames[b % g_nframes].size;
+    return sa != sb ? (sa < sb ? 1 : -1) : (a < b ? -1 : a > b);
+}
 
 static void parse_one(void *arg, int i, int worker)
 {
@@ -128,9 +141,9 @@ static void parse_one(void *arg, int i, int worker)
 static void export_one(void *arg, int i, int worker)
 {
     const batch_ref *br = (const batch_ref *)arg;
-    const frame *f = &g_frames[(br->first + i) % g_nframes];
+    const frame *f = &g_frames[run_index(br->first + i) % g_nframes];
     vp8hip_entropy_frame *e = &g_ent[br->b & 1][i];
-    const uint32_t off = e->data_off;
+    const uint64_t off = e->data_off;
     vp8ir_frame_hdr hdr;
     int rc = vp8_parser_begin_frame(g_parsers[worker], f->data, f->size, &hdr);
     if (!rc && (hdr.frame_type != 0 || hdr.width != g_width || hdr.height != g_height)) rc = VP8P_UNSUP_BITSTREAM;
@@ -144,8 +157,8 @@ static size_t place_frames(const batch_ref *br)
 {
     size_t off = 0;
     for (int i = 0; i < br->n; i++) {
-        g_ent[br->b & 1][i].data_off = (uint32_t)off;
-        off += g_frames[(br->first + i) % g_nframes].size;
+        g_ent[br->b & 1][i].data_off = off;
+        off += g_frames[run_index(br->first + i) % g_nframes].size;
     }
     return off;
 }
@@ -163,9 +176,12 @@ static void hash_one(void *arg, int i, int worker)
         const uint8_t *p = fb + (plane == 0 ? g_geom.y_off : plane == 1 ? g_geom.u_off : g_geom.v_off);
         for (int y = 0; y < rows; y++, p += stride) md5_update(&md5, p, (size_t)w);
     }
-    md5_final(&md5, g_digest[br->first + i]);
+    md5_final(&md5, g_digest[run_index(br->first + i)]);
 }
-static void take_digests(const batch_ref *br) { memcpy(g_digest[br->first], g_dig[br->b & 1], 16 * (size_t)br->n); }
+static void take_digests(const batch_ref *br)
+{
+    for (int i = 0; i < br->n; i++) memcpy(g_digest[run_index(br->first + i)], g_dig[br->b & 1] + 16 * (size_t)i, 16);
+}
 
 static double now_s(void)
 {
@@ -230,16 +246,18 @@ int main(int argc, char **argv)
     HIP(vp8hip_configure(g_hip, g_width, g_height, fb_sets * g_batch, slot_sets * g_batch));
     HIP(vp8hip_geometry(g_hip, &g_geom));
     if (g_dev_entropy) {
-        {   /* the largest run of g_batch consecutive frames, the stream repeating */
-            size_t all = 0, best = 0;
-            const int rem = g_batch % g_nframes;
-            for (int i = 0; i < g_nframes; i++) all += g_frames[i].size;
-            for (int i = 0; i < g_nframes; i++) {
-                size_t run = 0;
-                for (int k = 0; k < rem; k++) run += g_frames[(i + k) % g_nframes].size;
-                if (run > best) best = run;
+        {   /* a batch's bytes at most: the frames are taken in order of size within windows of SORT_WINDOW batches */
+            g_order = (long *)malloc(sizeof(long) * (size_t)total);
+            for (long k = 0; k < total; k++) g_order[k] = k;
+            for (long w0 = 0; w0 < total; w0 += (long)SORT_WINDOW * g_batch) {
+                const long wn = total - w0 < (long)SORT_WINDOW * g_batch ? total - w0 : (long)SORT_WINDOW * g_batch;
+                qsort(g_order + w0, (size_t)wn, sizeof(long), by_size_desc);
             }
-            g_ent_cap = (size_t)(g_batch / g_nframes) * all + best;
+            for (long k0 = 0; k0 < total; k0 += g_batch) {
+                size_t run = 0;
+                for (long k = k0; k < k0 + g_batch && k < total; k++) run += g_frames[g_order[k] % g_nframes].size;
+                if (run > g_ent_cap) g_ent_cap = run;
+            }
         }
         for (int k = 0; k < 2; k++) {
             if (!(g_ent[k] = (vp8hip_entropy_frame *)vp8hip_host_alloc(g_hip, (size_t)g_batch * sizeof(vp8hip_entropy_frame))) ||
