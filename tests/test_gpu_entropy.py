@@ -84,3 +84,66 @@ def test_lanes_per_wave(lanes, monkeypatch):
     for i, (hdr, mbs, coef) in enumerate(host):
         _compare(ctx, i, mbs, coef, (lanes, i))
     ctx.close()
+
+
+def test_written_streams():
+    """Frames from the suite's own writer (tests/vp8_writer.py) turn on what the fixtures lack: a segment map, skipped macroblocks
+    between coded ones at several skip probabilities, 2 / 4 / 8 partitions at small sizes, coefficients up to DCT_VAL_CATEGORY6."""
+    from test_gpu_writer import CASES
+    from vp8_testlib import synth_ir
+    from vp8_writer import write_key_frame
+    P = load_package()
+    for case in CASES:
+        w, h, seed, lp, ftype, dense, big, seg = case
+        hdr, mbs, coef, mvs = synth_ir(w, h, seed, inter=False, filter_type=ftype, dense=dense, big=big, segmented=seg)
+        hdr.num_token_partitions = 1 << lp
+        frames = [write_key_frame(hdr, mbs, coef, log2_parts=lp, prob_skip_false=p) for p in (200, 1, 255, 128)]
+        host = _host_ir(P, frames)
+        efs = _export(P, frames)
+        ctx = P.Vp8Hip()
+        ctx.configure(w, h, 1, len(frames))
+        assert not ctx.entropy_decode(0, efs, frames).any()
+        for i, (_, hm, hc) in enumerate(host):
+            _compare(ctx, i, hm, hc, (case, i))
+        ctx.close()
+
+
+@pytest.mark.parametrize("name", ["kf_640x360", "kf_8part_1920x1080"])
+def test_frames_cut_short(name):
+    """A frame that ends early -- in the last token partition, in an earlier one, in the first partition -- gives the IR and the
+    corrupt flag the host feeder gives (zeros are read past the end, as the reference does: dboolhuff.c:44-60; no tokens once a
+    partition has run out: decodframe.c:119-130), next to whole frames in the same launch; a frame whose header does not fit is
+    refused by the host before anything is launched."""
+    P = load_package()
+    w, h, frames = P.read_ivf(ivf_path(name))
+    data = frames[1]
+    n = len(data)
+    cuts = [n - 1, n - 7, n - n // 50, n - n // 3, n // 2, n // 4, n // 10]
+    variants = [data] + [data[:c] for c in cuts] + [data]
+    host, efs, kept = [], [], []
+    for v in variants:
+        ph, pd = P.Parser(), P.Parser()
+        try:
+            hdr, _ = pd.begin(v)
+            ef = pd.export_entropy()
+        except ValueError:
+            continue                     # (the partition table itself is cut off: both refuse the frame)
+        finally:
+            pass
+        h0, _, _, _, _ = P.parse_to_numpy(ph, frames[0])       # (a decoder that has seen a complete key frame goes on after a damaged one)
+        ph.swap(h0)
+        hh, _ = ph.begin(v)
+        nmb = hh.mb_cols * hh.mb_rows
+        mbs, coef, mvs = np.zeros((nmb, 64), np.uint8), np.zeros((nmb, 400), np.int16), np.zeros((nmb, 16, 2), np.int16)
+        corrupt = ph.decode_mbs(mbs.ctypes.data, coef.ctypes.data, mvs.ctypes.data)
+        host.append((mbs, coef, corrupt)); efs.append(ef); kept.append(v)
+        ph.close(); pd.close()
+    assert len(kept) >= 4           # (with several partitions only cuts inside the last one pass the partition table)
+    ctx = P.Vp8Hip()
+    ctx.configure(w, h, 1, len(kept))
+    st = ctx.entropy_decode(0, efs, kept)
+    assert [int(s) & 1 for s in st] == [int(bool(c)) for _, _, c in host]
+    assert st[0] == 0 and st[-1] == 0 and st.any()
+    for i, (mbs, coef, _) in enumerate(host):
+        _compare(ctx, i, mbs, coef, (name, i))
+    ctx.close()

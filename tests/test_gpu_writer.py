@@ -82,8 +82,9 @@ def test_written_stream_through_the_tools(pkg, tmp_path):
         want.append(_oracle_md5(pkg, hdr, mbs, coef, mvs))
     ivf = tmp_path / "s.ivf"
     write_ivf(ivf, w, h, frames)
-    for tool, extra in (("decode_to_md5", []), ("batch_md5", ["--threads", "3", "--batch", "5"])):
-        out = tmp_path / (tool + ".md5")
+    for tool, extra in (("decode_to_md5", []), ("batch_md5", ["--threads", "3", "--batch", "5"]),
+                        ("batch_md5", ["--device-entropy", "--batch", "5"])):
+        out = tmp_path / (tool + "".join(extra) + ".md5")
         r = subprocess.run([os.path.join(BIN, tool)] + extra + [str(ivf), str(out)], capture_output=True, text=True)
         assert r.returncode == 0, r.stderr
         assert [l.split()[0] for l in open(out)] == want, tool
