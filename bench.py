@@ -195,7 +195,7 @@ def inter_frame_probe(P, device, n=4096, name="p_dense_1920x1080", k=2):
                          "note": "SURVEY 8(d) full inter path 2407 B/MB x macroblocks per launch / wall time per launch"}}
 
 
-def batch_md5_probe(fixture, device, loops=205):
+def batch_md5_probe(fixture, device, loops=205, extra=()):
     """The same end-to-end pipeline with the C host side (bin/batch_md5: feeder threads, batched launches, MD5 on the device where the
     frame size allows): the fixture looped, listing checked line by line against the reference decoder's digests."""
     import tempfile
@@ -205,17 +205,19 @@ def batch_md5_probe(fixture, device, loops=205):
     with tempfile.TemporaryDirectory() as d:
         out = os.path.join(d, "o.md5")
         env = dict(os.environ, VP8HIP_DEVICE=str(device))
-        r = subprocess.run([tool, "--loop", str(loops), ivf, out], capture_output=True, text=True, env=env, timeout=300)
+        r = subprocess.run([tool, *extra, "--loop", str(loops), ivf, out], capture_output=True, text=True, env=env, timeout=300)
         if r.returncode:
             return {"error": r.stderr[-300:]}
         got = [l.split()[0] for l in open(out).read().splitlines()]
     bad = sum(1 for i, g in enumerate(got) if g != gold[i % len(gold)]) + abs(len(got) - loops * len(gold))
     import re
-    m = re.search(r"(\d+) frames in ([0-9.]+) s: ([0-9.]+) frames/s, ([0-9.]+) Mpix/s \((\d+) feeder threads, (\d+) frames per launch, MD5 on the (\w+)\)", r.stderr)
+    m = re.search(r"(\d+) frames in ([0-9.]+) s: ([0-9.]+) frames/s, ([0-9.]+) Mpix/s \((\d+) feeder threads, (\d+) frames per launch, "
+                  r"entropy decode on the (\w+), MD5 on the (\w+)(, frames not downloaded)?\)", r.stderr)
     if not m:
         return {"error": "unparsed: " + r.stderr[-200:]}
-    return {"tool": "bin/batch_md5 --loop %d" % loops, "frames": int(m.group(1)), "frames_per_s": float(m.group(3)), "Mpix_s": float(m.group(4)),
-            "host_threads": int(m.group(5)), "frames_per_launch": int(m.group(6)), "md5_on": m.group(7), "md5_mismatches": bad}
+    return {"tool": " ".join(["bin/batch_md5", *extra, "--loop", str(loops)]), "frames": int(m.group(1)), "frames_per_s": float(m.group(3)),
+            "Mpix_s": float(m.group(4)), "host_threads": int(m.group(5)), "frames_per_launch": int(m.group(6)), "entropy_decode_on": m.group(7),
+            "md5_on": m.group(8), "frames_downloaded": m.group(9) is None, "md5_mismatches": bad}
 
 
 def load_stream(P, ctx, fixture, F, lo):
@@ -560,6 +562,12 @@ def main():
                 import e2e
                 out["config"]["end_to_end"] = e2e.run(P, local_rank, fixture=fixture, nframes=2048)
                 out["config"]["end_to_end"]["c_host"] = batch_md5_probe(fixture, local_rank)
+                # ... and with the macroblocks' modes and tokens decoded on the GPU, a frame per lane (vp8hip_entropy_decode): the host
+                # reads the frame headers only
+                out["config"]["end_to_end"]["device_entropy"] = batch_md5_probe(
+                    fixture, local_rank, 4096, ("--device-entropy", "--batch", "4096"))
+                out["config"]["end_to_end"]["device_entropy_frames_stay"] = batch_md5_probe(
+                    fixture, local_rank, 4096, ("--device-entropy", "--no-download", "--batch", "8192"))
             except Exception as ex:      # a probe, not the benchmark: report, do not fail the line
                 out["config"]["end_to_end"] = {"error": repr(ex)}
         if not args.no_cpu_baseline and world == 1:      # the contract: rank 0 at N = 1 only
