@@ -57,11 +57,9 @@ struct BD {
     u32 value;      // window: the active byte in bits 31..24
     int bits;       // valid bits below it; negative: refill before the next decision
     u32 range;      // 128..255
-    u32 pos, end;   // next byte to request / end of the partition (offsets into the launch's data)
-    u32 n01, n2;    // bytes pos-3, pos-2 (a little-endian pair) and pos-1 as requested at the refill before (not looked at until the next refill takes them:
-                    // the requests have the decisions in between to land) ...
-    u32 nmask;      // ... and which of them exist (zeros from the partition's end on)
-    u32 over;       // bytes taken from behind the end so far
+    u32 pos, end;   // next byte to request / end of the partition (offsets from the frame's first byte)
+    u32 n01, n2;    // bytes pos-3, pos-2 (a little-endian pair) and pos-1 as requested at the refill before (not looked at until
+                    // the next refill takes them: the requests have the decisions in between to land)
 #ifdef ENT_STATS
     u32 count;      // (diagnostic builds: decisions taken)
 #endif
@@ -71,11 +69,9 @@ struct BD {
 // padding, and `limit` keeps a decoder that runs on through a damaged partition inside it).
 __device__ __forceinline__ void request3(BD &b, const uint8_t *__restrict__ data, u32 pos, u32 limit)
 {
-    const uint8_t *p = data + (pos < limit ? pos : limit);
     typedef unsigned short __attribute__((aligned(1), may_alias)) u16u;
+    const uint8_t *p = data + (pos < limit ? pos : limit);
     b.n01 = *(const u16u *)p; b.n2 = p[2];
-    const u32 rem = b.end > pos ? b.end - pos : 0u;
-    b.nmask = rem >= 3u ? 0xffffffu : ~(0xffffffu >> (8 * rem)) & 0xffffffu;
 }
 
 // vp8dx_decode_bool (dboolhuff.h:76-120): split = 1 + (((range - 1) * probability) >> 8), the decision is whether the window is
@@ -87,10 +83,13 @@ __device__ __forceinline__ int bd_get(BD &b, const uint8_t *__restrict__ data, u
     b.count++;
 #endif
     if (b.bits < 0) {                                   // 1..8 bits of the top byte are spent: three more bytes under them
-        const u32 nxt = ((b.n01 & 255u) << 16 | (b.n01 & 0xff00u) | b.n2) & b.nmask;
+        u32 nxt = (b.n01 & 255u) << 16 | (b.n01 & 0xff00u) | b.n2;
+        if (b.pos > b.end) {                            // (the partition ends inside these three, or has ended: zeros from there on)
+            const u32 past = b.pos - b.end;
+            nxt = past >= 3u ? 0u : nxt & ~(0xffffffu >> (8 * (3u - past)));
+        }
         b.value |= nxt << (-b.bits);
         b.bits += 24;
-        b.over += b.pos > b.end ? (b.pos - b.end > 3u ? 3u : b.pos - b.end) : 0u;   // how many of those three were not there
         request3(b, data, b.pos, limit);
         b.pos += 3;
     }
@@ -98,7 +97,7 @@ __device__ __forceinline__ int bd_get(BD &b, const uint8_t *__restrict__ data, u
     const bool bit = b.value >= big;
     b.value -= bit ? big : 0u;
     b.range = bit ? b.range - split : split;
-    const int shift = __clz((int)b.range) - 24;
+    const int shift = __builtin_clz(b.range) - 24;      // (range is never 0)
     b.range <<= shift;
     b.value <<= shift;
     b.bits -= shift;
@@ -107,8 +106,13 @@ __device__ __forceinline__ int bd_get(BD &b, const uint8_t *__restrict__ data, u
 #define GET(b, prob) bd_get(b, data, limit, prob)
 
 // vp8dx_bool_error (dboolhuff.h:131-153) as csrc/host/vp8_boolreader.h states it: zeros from behind the end of the partition have
-// reached the top byte
-__device__ __forceinline__ bool bd_error(const BD &b) { return b.over > 0 && b.bits - 8 * (int)b.over < 0; }
+// reached the top byte.  Bytes are taken in order, so those taken from behind the end are what the position says (the three
+// before `pos` are requested, not taken).
+__device__ __forceinline__ bool bd_error(const BD &b)
+{
+    const int over = (int)(b.pos - 3u) - (int)b.end;
+    return over > 0 && b.bits - 8 * over < 0;
+}
 
 // intra sub-block mode tree (vp8_bmode_tree, vp8/common/entropymode.c)
 __device__ __forceinline__ int read_bmode(BD &b, const uint8_t *__restrict__ data, u32 limit, const Row pr)
@@ -225,7 +229,7 @@ vp8_entropy_kernel(const vp8hip_entropy_frame *__restrict__ frames, int count, i
         t[0] = 0; t[1] = (u32)-8; t[2] = 255; t[3] = base + F.tok_pos[k]; t[4] = base + F.tok_end[k]; t[5] = 0;
     }
     BD fb;                                                             // first partition: where the host's header parse stopped
-    fb.value = F.first_value; fb.bits = F.first_bits; fb.range = F.first_range; fb.end = base + F.first_end; fb.over = 0;
+    fb.value = F.first_value; fb.bits = F.first_bits; fb.range = F.first_range; fb.end = base + F.first_end;
 #ifdef ENT_STATS
     fb.count = 0; u32 tcount = 0;
 #endif
@@ -242,12 +246,12 @@ vp8_entropy_kernel(const vp8hip_entropy_frame *__restrict__ frames, int count, i
         BD tb;
         {
             const u32 *t = tst + 8 * (r & (ntok - 1));                 // round robin by row (decodframe.c:1116-1129)
-            tb.value = t[0]; tb.bits = (int)t[1]; tb.range = t[2]; tb.end = t[4]; tb.over = t[5];
+            tb.value = t[0]; tb.bits = (int)t[1]; tb.range = t[2]; tb.end = t[4];
 #ifdef ENT_STATS
             tb.count = 0;
 #endif
             if (r < ntok) { request3(tb, data, t[3], limit); tb.pos = t[3] + 3; }
-            else { tb.n01 = (t[6] >> 16) | (t[6] & 0xff00u); tb.n2 = t[6] & 255u; tb.nmask = 0xffffffu; tb.pos = t[3]; }
+            else { tb.n01 = t[6] >> 8; tb.n2 = t[6] & 255u; tb.pos = t[3]; }
         }
         u32 lbm = 0, lnz = 0;                                          // left of the row: B_DC_PRED, nothing coded
         for (int c = 0; c < cols; c++) {
@@ -336,7 +340,7 @@ vp8_entropy_kernel(const vp8hip_entropy_frame *__restrict__ frames, int count, i
 #endif
         {
             u32 *t = tst + 8 * (r & (ntok - 1));
-            t[0] = tb.value; t[1] = (u32)tb.bits; t[2] = tb.range; t[3] = tb.pos; t[5] = tb.over; t[6] = ((tb.n01 & 255u) << 16 | (tb.n01 & 0xff00u) | tb.n2) & tb.nmask;
+            t[0] = tb.value; t[1] = (u32)tb.bits; t[2] = tb.range; t[3] = tb.pos; t[6] = tb.n01 << 8 | tb.n2;
         }
     }
     bad |= bd_error(fb);
