@@ -180,7 +180,105 @@ __device__ __forceinline__ int read_block(BD &b, const uint8_t *__restrict__ dat
     }
 }
 
+// What the first partition says about one macroblock (vp8_kfread_modes, decodemv.c:50-173).  above / left: the sub-block modes
+// of the row above at this column and of the macroblock to the left (four nibbles each), updated for the neighbours to come.
+struct MbModes { int ymode, uvmode, seg, skip; u64 bm; };    // bm: B_PRED's sixteen modes, a nibble each
+struct ModeParams { bool seg_map, has_skip; u32 p_skip, tp0, tp1, tp2; };
+__device__ __forceinline__ MbModes read_mb_modes(BD &fb, const uint8_t *__restrict__ data, u32 limit, const ModeParams &P, const row_t *kfb,
+                                                 u32 &above, u32 &lbm)
+{
+    MbModes m;
+    m.seg = 0;
+    if (P.seg_map) m.seg = GET(fb, P.tp0) ? 2 + GET(fb, P.tp2) : GET(fb, P.tp1);
+    m.skip = P.has_skip ? GET(fb, P.p_skip) : 0;
+    if (!GET(fb, 145)) m.ymode = VP8IR_B_PRED;
+    else if (!GET(fb, 156)) m.ymode = GET(fb, 163) ? VP8IR_V_PRED : VP8IR_DC_PRED;
+    else m.ymode = GET(fb, 128) ? VP8IR_TM_PRED : VP8IR_H_PRED;
+    m.bm = 0;
+    if (m.ymode == VP8IR_B_PRED) {
+        u64 bm = 0;
+        for (int i = 0; i < 16; i++) {
+            const int A = i < 4 ? (int)((above >> (4 * i)) & 15) : (int)((bm >> (4 * (i - 4))) & 15);
+            const int L = (i & 3) == 0 ? (int)((lbm >> (i & 12)) & 15) : (int)((bm >> (4 * (i - 1))) & 15);
+            bm |= (u64)read_bmode(fb, data, limit, row_at(kfb + (A * 10 + L) * 3)) << (4 * i);
+        }
+        above = (u32)(bm >> 48);
+        lbm = (u32)((bm >> 12) & 15) | (u32)((bm >> 28) & 15) << 4 | (u32)((bm >> 44) & 15) << 8 | (u32)((bm >> 60) & 15) << 12;
+        m.bm = bm;
+    } else {
+        // the sub-block mode a whole-macroblock mode stands for in its neighbours' contexts (findnearmv.h:131-188)
+        const u32 im = m.ymode == VP8IR_V_PRED ? VP8IR_B_VE_PRED : m.ymode == VP8IR_H_PRED ? VP8IR_B_HE_PRED
+                     : m.ymode == VP8IR_TM_PRED ? VP8IR_B_TM_PRED : VP8IR_B_DC_PRED;
+        above = lbm = im * 0x1111u;
+    }
+    if (!GET(fb, 142)) m.uvmode = VP8IR_DC_PRED;
+    else if (!GET(fb, 114)) m.uvmode = VP8IR_V_PRED;
+    else m.uvmode = GET(fb, 183) ? VP8IR_TM_PRED : VP8IR_H_PRED;
+    return m;
+}
+
+// The macroblock's tokens (decode_macroblock, decodframe.c:100-130; vp8_decode_mb_tokens) and its place in the IR: coefficients
+// to out_coef (fifty 16-byte pieces), the descriptor to out_mb (four).  A / lnz: the non-zero flags of the row above at this
+// column and of the macroblock to the left (bits 0..3 Y, 4..5 U, 6..7 V, 8 Y2), updated.  desc / blk: the lane's staging in LDS.
+__device__ __forceinline__ void read_mb_tokens(BD &tb, const uint8_t *__restrict__ data, u32 limit, const MbModes &m, const row_t *probs,
+                                               const row_t *cat, u32 &A, u32 &lnz, u32 *desc, u32 *blk, u32x4 *out_coef, u32x4 *out_mb)
+{
+    const bool has_y2 = m.ymode != VP8IR_B_PRED;
+    int skip = m.skip;
+#pragma unroll
+    for (int i = 0; i < 16; i++) desc[i] = 0;
+    if (!has_y2) {
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            const u32 four = (u32)(m.bm >> (16 * w)) & 0xffffu;  // modes 4w .. 4w+3, a nibble each -> a byte each (descriptor bytes 40..55)
+            desc[10 + w] = (four & 15u) | (four >> 4 & 15u) << 8 | (four >> 8 & 15u) << 16 | (four >> 12 & 15u) << 24;
+        }
+    }
+    if (skip) {                                                // vp8_reset_mb_tokens_context (detokenize.c:70-85)
+        A = has_y2 ? 0u : A & 0x100u;
+        lnz = has_y2 ? 0u : lnz & 0x100u;
+    } else if (bd_error(tb)) {
+        // the partition has run out: no tokens, contexts and skip flag stay, no residual (decodframe.c:119-130)
+#pragma unroll
+        for (int i = 0; i < 50; i++) out_coef[i] = (u32x4){ 0, 0, 0, 0 };
+    } else {
+        int total = 0;
+        for (int i = has_y2 ? -1 : 0; i < 24; i++) {
+            // block order: Y2 (when there is one), 16 Y, 4 U, 4 V; its place among the 25 of the IR; its context bits
+            const int k = i < 0 ? 24 : i;
+            int abit, lbit, type, first = 0;
+            if (i < 0) { abit = lbit = 8; type = 1; }
+            else if (i < 16) { abit = i & 3; lbit = i >> 2; type = has_y2 ? 0 : 3; first = has_y2 ? 1 : 0; }
+            else { const int j = i - 16; abit = 4 + ((j >> 2) << 1) + (j & 1); lbit = 4 + ((j >> 2) << 1) + ((j >> 1) & 1); type = 2; }
+#pragma unroll
+            for (int w = 0; w < 8; w++) blk[w] = 0;
+            int nz;
+            const int ctx = (int)((A >> abit) & 1) + (int)((lnz >> lbit) & 1);
+            const int e = read_block(tb, data, limit, probs + type * 72, cat, ctx, first, (coef_t *)blk, nz);
+            A = (A & ~(1u << abit)) | (u32)nz << abit;
+            lnz = (lnz & ~(1u << lbit)) | (u32)nz << lbit;
+            ((uint8_t *)desc)[8 + k] = (uint8_t)e;
+            total += e;
+            out_coef[2 * k] = (u32x4){ blk[0], blk[1], blk[2], blk[3] };
+            out_coef[2 * k + 1] = (u32x4){ blk[4], blk[5], blk[6], blk[7] };
+        }
+        if (has_y2) total -= 16;                               // (the sixteen luma blocks started at position 1)
+        else { out_coef[48] = (u32x4){ 0, 0, 0, 0 }; out_coef[49] = (u32x4){ 0, 0, 0, 0 }; }
+        if (total == 0) {                                      // decodframe.c:129: nothing coded after all
+            skip = 1;
+#pragma unroll
+            for (int w = 2; w < 9; w++) desc[w] = 0;           // (eobs live in bytes 8..32; 33..35 are reserved zeros)
+        }
+    }
+    desc[0] = (u32)m.ymode | (u32)m.uvmode << 8 | (u32)(skip ? VP8IR_MB_SKIP : 0) << 24;
+    desc[1] = (u32)m.seg;
+#pragma unroll
+    for (int w = 0; w < 4; w++) out_mb[w] = (u32x4){ desc[4 * w], desc[4 * w + 1], desc[4 * w + 2], desc[4 * w + 3] };
+}
+
 }  // namespace
+
+extern "C" size_t vp8_entropy_lds_bytes(int lpw) { return (size_t)lpw * (ENT_PROB_WORDS + ENT_DESC_WORDS + ENT_BLK_WORDS) * 4; }
 
 // frames: `count` of them; frame f goes to the IR slot at slot_base + (first_slot + f) * slot_bytes (descriptors at o_mbs, dense
 // coefficients at o_coef).  lpw: lanes of each wave that carry a frame (1..64).  scratch: per frame (2 * mb_cols + 64) words
@@ -190,9 +288,11 @@ vp8_entropy_kernel(const vp8hip_entropy_frame *__restrict__ frames, int count, i
                    size_t data_bytes, char *slot_base, size_t slot_bytes, size_t o_mbs, size_t o_coef, int first_slot,
                    u32 *__restrict__ scratch, u32 *__restrict__ status)
 {
-    __shared__ row_t s_probs[64 * ENT_PROB_WORDS];
-    __shared__ u32 s_desc[64 * ENT_DESC_WORDS];
-    __shared__ u32 s_blk[64 * ENT_BLK_WORDS];
+    // LDS by lanes that carry a frame (the launch says how much: vp8_entropy_lds_bytes): probabilities, descriptor, block
+    extern __shared__ u32 s_dyn[];
+    row_t *s_probs = (row_t *)s_dyn;
+    u32 *s_desc = s_dyn + lpw * ENT_PROB_WORDS;
+    u32 *s_blk = s_desc + lpw * ENT_DESC_WORDS;
     __shared__ row_t s_kfb[100 * 3];                    // kf_bmode_probs, a row per (above, left)
     __shared__ row_t s_cat[6 * 3];
     const int lane = threadIdx.x;
@@ -235,8 +335,8 @@ vp8_entropy_kernel(const vp8hip_entropy_frame *__restrict__ frames, int count, i
 #endif
     request3(fb, data, base + F.first_pos, limit);
     fb.pos = base + F.first_pos + 3;
-    const bool seg_map = F.update_mb_segmentation_map != 0, has_skip = F.mb_no_coeff_skip != 0;
-    const u32 p_skip = F.prob_skip_false, tp0 = F.segment_tree_probs[0], tp1 = F.segment_tree_probs[1], tp2 = F.segment_tree_probs[2];
+    const ModeParams MP = { F.update_mb_segmentation_map != 0, F.mb_no_coeff_skip != 0, F.prob_skip_false, F.segment_tree_probs[0],
+                            F.segment_tree_probs[1], F.segment_tree_probs[2] };
     char *slot = slot_base + slot_bytes * (size_t)(first_slot + f);
     u32x4 *out_mbs = (u32x4 *)(slot + o_mbs);
     u32x4 *out_coef = (u32x4 *)(slot + o_coef);
@@ -256,83 +356,12 @@ vp8_entropy_kernel(const vp8hip_entropy_frame *__restrict__ frames, int count, i
         u32 lbm = 0, lnz = 0;                                          // left of the row: B_DC_PRED, nothing coded
         for (int c = 0; c < cols; c++) {
             const long n = (long)r * cols + c;
-            // ---- modes (vp8_kfread_modes, decodemv.c:50-173)
-            int seg = 0;
-            if (seg_map) seg = GET(fb, tp0) ? 2 + GET(fb, tp2) : GET(fb, tp1);
-            int skip = has_skip ? GET(fb, p_skip) : 0;
-            int ymode;
-            if (!GET(fb, 145)) ymode = VP8IR_B_PRED;
-            else if (!GET(fb, 156)) ymode = GET(fb, 163) ? VP8IR_V_PRED : VP8IR_DC_PRED;
-            else ymode = GET(fb, 128) ? VP8IR_TM_PRED : VP8IR_H_PRED;
-#pragma unroll
-            for (int i = 0; i < 16; i++) desc[i] = 0;
-            const u32 above = abm[c];
-            if (ymode == VP8IR_B_PRED) {
-                u64 bm = 0;                                            // the macroblock's sixteen modes, a nibble each
-                for (int i = 0; i < 16; i++) {
-                    const int A = i < 4 ? (int)((above >> (4 * i)) & 15) : (int)((bm >> (4 * (i - 4))) & 15);
-                    const int L = (i & 3) == 0 ? (int)((lbm >> (i & 12)) & 15) : (int)((bm >> (4 * (i - 1))) & 15);
-                    const int m = read_bmode(fb, data, limit, row_at(s_kfb + (A * 10 + L) * 3));
-                    bm |= (u64)m << (4 * i);
-                    ((uint8_t *)desc)[40 + i] = (uint8_t)m;
-                }
-                abm[c] = (u32)(bm >> 48);
-                lbm = (u32)((bm >> 12) & 15) | (u32)((bm >> 28) & 15) << 4 | (u32)((bm >> 44) & 15) << 8 | (u32)((bm >> 60) & 15) << 12;
-            } else {
-                // the sub-block mode a whole-macroblock mode stands for in its neighbours' contexts (findnearmv.h:131-188)
-                const u32 im = ymode == VP8IR_V_PRED ? VP8IR_B_VE_PRED : ymode == VP8IR_H_PRED ? VP8IR_B_HE_PRED
-                             : ymode == VP8IR_TM_PRED ? VP8IR_B_TM_PRED : VP8IR_B_DC_PRED;
-                abm[c] = lbm = im * 0x1111u;
-            }
-            int uvmode;
-            if (!GET(fb, 142)) uvmode = VP8IR_DC_PRED;
-            else if (!GET(fb, 114)) uvmode = VP8IR_V_PRED;
-            else uvmode = GET(fb, 183) ? VP8IR_TM_PRED : VP8IR_H_PRED;
-
-            // ---- tokens (decode_macroblock, decodframe.c:100-130; vp8_decode_mb_tokens)
-            const bool has_y2 = ymode != VP8IR_B_PRED;
+            u32 above = abm[c];
+            const MbModes m = read_mb_modes(fb, data, limit, MP, s_kfb, above, lbm);
+            abm[c] = above;
             u32 A = anz[c];
-            if (skip) {                                                // vp8_reset_mb_tokens_context (detokenize.c:70-85)
-                A = has_y2 ? 0u : A & 0x100u;
-                lnz = has_y2 ? 0u : lnz & 0x100u;
-            } else if (bd_error(tb)) {
-                // the partition has run out: no tokens, contexts and skip flag stay, no residual (decodframe.c:119-130)
-#pragma unroll
-                for (int i = 0; i < 50; i++) out_coef[n * 50 + i] = (u32x4){ 0, 0, 0, 0 };
-            } else {
-                int total = 0;
-                for (int i = has_y2 ? -1 : 0; i < 24; i++) {
-                    // block order: Y2 (when there is one), 16 Y, 4 U, 4 V; its place among the 25 of the IR; its context bits
-                    const int k = i < 0 ? 24 : i;
-                    int abit, lbit, type, first = 0;
-                    if (i < 0) { abit = lbit = 8; type = 1; }
-                    else if (i < 16) { abit = i & 3; lbit = i >> 2; type = has_y2 ? 0 : 3; first = has_y2 ? 1 : 0; }
-                    else { const int j = i - 16; abit = 4 + ((j >> 2) << 1) + (j & 1); lbit = 4 + ((j >> 2) << 1) + ((j >> 1) & 1); type = 2; }
-#pragma unroll
-                    for (int w = 0; w < 8; w++) blk[w] = 0;
-                    int nz;
-                    const int ctx = (int)((A >> abit) & 1) + (int)((lnz >> lbit) & 1);
-                    const int e = read_block(tb, data, limit, probs + type * 72, s_cat, ctx, first, (coef_t *)blk, nz);
-                    A = (A & ~(1u << abit)) | (u32)nz << abit;
-                    lnz = (lnz & ~(1u << lbit)) | (u32)nz << lbit;
-                    ((uint8_t *)desc)[8 + k] = (uint8_t)e;
-                    total += e;
-                    out_coef[n * 50 + 2 * k] = (u32x4){ blk[0], blk[1], blk[2], blk[3] };
-                    out_coef[n * 50 + 2 * k + 1] = (u32x4){ blk[4], blk[5], blk[6], blk[7] };
-                }
-                if (has_y2) total -= 16;                               // (the sixteen luma blocks started at position 1)
-                else { out_coef[n * 50 + 48] = (u32x4){ 0, 0, 0, 0 }; out_coef[n * 50 + 49] = (u32x4){ 0, 0, 0, 0 }; }
-                if (total == 0) {                                      // decodframe.c:129: nothing coded after all
-                    skip = 1;
-#pragma unroll
-                    for (int w = 2; w < 9; w++) desc[w] = 0;           // (eobs live in bytes 8..32; 33..35 are reserved zeros)
-                }
-            }
+            read_mb_tokens(tb, data, limit, m, probs, s_cat, A, lnz, desc, blk, out_coef + n * 50, out_mbs + n * 4);
             anz[c] = A;
-            desc[0] = (u32)ymode | (u32)uvmode << 8 | (u32)(skip ? VP8IR_MB_SKIP : 0) << 24;
-            desc[1] = (u32)seg;
-#pragma unroll
-            for (int w = 0; w < 4; w++) out_mbs[n * 4 + w] = (u32x4){ desc[4 * w], desc[4 * w + 1], desc[4 * w + 2], desc[4 * w + 3] };
         }
         bad |= bd_error(tb);
 #ifdef ENT_STATS
@@ -349,4 +378,123 @@ vp8_entropy_kernel(const vp8hip_entropy_frame *__restrict__ frames, int count, i
 #else
     if (status) status[f] = bad ? 1u : 0u;
 #endif
+}
+
+// Frames coded with several token partitions (2, 4 or 8: the encoder's --token-parts; macroblock row r is in partition r mod NP,
+// decodframe.c:1116-1129), a PARTITION per lane.  The partitions of a frame are separate bool-coded streams; what ties them is
+// the entropy context a macroblock takes from the one above it, which belongs to the partition before.  So the NP lanes of a
+// frame walk their rows one macroblock behind each other -- lane p decodes macroblock (row, c) in the step after lane p - 1
+// decoded (row - 1, c) -- like the lanes of the lane-per-row pixel kernels, the non-zero flags of the row above handed over
+// through LDS (a word per macroblock column and frame).  64 / NP frames per wave.  The first partition (the modes: one stream)
+// is decoded first, by each frame's lane 0, into a scratch array the token lanes read (12 bytes per macroblock).
+// scratch per frame: mb_cols words (the modes' row above) + 3 words per macroblock.  cols <= ENT_PARTS_MAX_COLS.
+#define ENT_PARTS_MAX_COLS 256
+extern "C" __global__ void __launch_bounds__(64)
+vp8_entropy_parts_kernel(const vp8hip_entropy_frame *__restrict__ frames, int count, int np, const uint8_t *__restrict__ all_data, DevGeom g,
+                         size_t data_bytes, char *slot_base, size_t slot_bytes, size_t o_mbs, size_t o_coef, int first_slot,
+                         u32 *__restrict__ scratch, u32 *__restrict__ status)
+{
+    __shared__ row_t s_probs[32 * ENT_PROB_WORDS];     // per frame (at most 32 frames of two partitions in a wave)
+    __shared__ u32 s_desc[64 * ENT_DESC_WORDS];
+    __shared__ u32 s_blk[64 * ENT_BLK_WORDS];
+    __shared__ row_t s_kfb[100 * 3];
+    __shared__ row_t s_cat[6 * 3];
+    __shared__ u32 s_anz[32 * ENT_PARTS_MAX_COLS / 2];  // per frame: cols words; frames * cols <= 32 * 128 = 8 * 512 words
+    __shared__ u32 s_bad[32];
+    const int lane = threadIdx.x;
+    const int fpw = 64 / np, fi = lane / np, part = lane - fi * np;
+    const int f = blockIdx.x * fpw + fi;
+    const bool live = f < count;
+    const int cols = g.mb_cols, rows = g.mb_rows, nmb = cols * rows;
+    for (int i = lane; i < 100 * ENT_ROW; i += 64) {
+        const int row = i / ENT_ROW, k = i - row * ENT_ROW;
+        ((uint8_t *)s_kfb)[i] = k < 9 ? k_kf_bmode_probs[row * 9 + k] : (uint8_t)0;
+    }
+    for (int i = lane; i < 6 * ENT_ROW; i += 64) ((uint8_t *)s_cat)[i] = k_cat_rows[i];
+    if (lane < 32) s_bad[lane] = 0;
+    const vp8hip_entropy_frame &F = frames[live ? f : 0];
+    row_t *probs = s_probs + fi * ENT_PROB_WORDS;
+    u32 *anz = s_anz + fi * cols;
+    for (int i = part; i < 96 * ENT_ROW; i += np) {     // the frame's lanes share the copying of its probabilities
+        const int row = i / ENT_ROW, k = i - row * ENT_ROW;
+        ((uint8_t *)probs)[i] = k < 11 ? F.coef_probs[row * 11 + k] : (uint8_t)0;
+    }
+    for (int c = part; c < cols; c += np) anz[c] = 0;
+    u32 *abm = scratch + (size_t)(live ? f : 0) * (cols + 3 * (size_t)nmb);
+    u32 *modes = abm + cols;
+    const uint8_t *__restrict__ data = all_data + F.data_off;
+    const u32 limit = data_bytes - F.data_off < 0xfffffff0ull ? (u32)(data_bytes - F.data_off) : 0xfffffff0u;
+    u32 *desc = s_desc + lane * ENT_DESC_WORDS;
+    u32 *blk = s_blk + lane * ENT_BLK_WORDS;
+    bool bad = false;
+    __syncthreads();
+
+    // ---- the modes of the whole frame: lane 0 of the frame
+    if (live && part == 0) {
+        BD fb;
+        fb.value = F.first_value; fb.bits = F.first_bits; fb.range = F.first_range; fb.end = F.first_end;
+#ifdef ENT_STATS
+        fb.count = 0;
+#endif
+        request3(fb, data, F.first_pos, limit);
+        fb.pos = F.first_pos + 3;
+        const ModeParams MP = { F.update_mb_segmentation_map != 0, F.mb_no_coeff_skip != 0, F.prob_skip_false, F.segment_tree_probs[0],
+                                F.segment_tree_probs[1], F.segment_tree_probs[2] };
+        for (int c = 0; c < cols; c++) abm[c] = 0;
+        for (int r = 0; r < rows; r++) {
+            u32 lbm = 0;
+            for (int c = 0; c < cols; c++) {
+                u32 above = abm[c];
+                const MbModes m = read_mb_modes(fb, data, limit, MP, s_kfb, above, lbm);
+                abm[c] = above;
+                u32 *o = modes + 3 * ((size_t)r * cols + c);
+                o[0] = (u32)m.ymode | (u32)m.uvmode << 8 | (u32)m.seg << 16 | (u32)m.skip << 24;
+                o[1] = (u32)m.bm; o[2] = (u32)(m.bm >> 32);
+            }
+        }
+        bad |= bd_error(fb);
+    }
+    // what lane 0 wrote to memory is read by the frame's other lanes from here on
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+
+    // ---- the tokens: lane `part` takes rows part, part + np, ..., a macroblock behind the lane before it
+    char *slot = slot_base + slot_bytes * (size_t)(first_slot + (live ? f : 0));
+    u32x4 *out_mbs = (u32x4 *)(slot + o_mbs);
+    u32x4 *out_coef = (u32x4 *)(slot + o_coef);
+    BD tb;
+    tb.value = 0; tb.bits = -8; tb.range = 255; tb.end = F.tok_end[part];
+#ifdef ENT_STATS
+    tb.count = 0;
+#endif
+    request3(tb, data, F.tok_pos[part], limit);
+    tb.pos = F.tok_pos[part] + 3;
+    const int rounds = (rows + np - 1) / np, steps = rounds * cols + np - 1;
+    int row = part, c = -part - 1;                      // (lane `part` starts `part` steps late)
+    u32 lnz = 0;
+    for (int t = 0; t < steps; t++) {
+        if (++c == cols) { c = 0; row += np; lnz = 0; }
+        const bool work = live && c >= 0 && row < rows;
+        u32 A = 0;
+        if (work) A = anz[c];                           // left there by the lane before, a step ago (or by nobody: row 0)
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (work) {
+            const long n = (long)row * cols + c;
+            const u32 *mo = modes + 3 * n;
+            const u32 m0 = mo[0];
+            MbModes m;
+            m.ymode = (int)(m0 & 255u); m.uvmode = (int)(m0 >> 8 & 255u); m.seg = (int)(m0 >> 16 & 255u); m.skip = (int)(m0 >> 24);
+            m.bm = (u64)mo[1] | (u64)mo[2] << 32;
+            read_mb_tokens(tb, data, limit, m, probs, s_cat, A, lnz, desc, blk, out_coef + n * 50, out_mbs + n * 4);
+            anz[c] = A;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    bad |= bd_error(tb);
+    if (live && bad) atomicOr(&s_bad[fi], 1u);
+    __syncthreads();
+    if (live && part == 0 && status) status[f] = s_bad[fi];
 }

@@ -31,6 +31,10 @@ extern "C" __global__ void vp8_inter_pred_kernel(const DevJob *jobs, int njobs, 
 extern "C" __global__ void vp8_entropy_kernel(const vp8hip_entropy_frame *frames, int count, int lpw, const uint8_t *data, DevGeom g,
                                               size_t data_bytes, char *slot_base, size_t slot_bytes, size_t o_mbs, size_t o_coef,
                                               int first_slot, unsigned int *scratch, unsigned int *status);
+extern "C" size_t vp8_entropy_lds_bytes(int lpw);
+extern "C" __global__ void vp8_entropy_parts_kernel(const vp8hip_entropy_frame *frames, int count, int np, const uint8_t *data, DevGeom g,
+                                                    size_t data_bytes, char *slot_base, size_t slot_bytes, size_t o_mbs, size_t o_coef,
+                                                    int first_slot, unsigned int *scratch, unsigned int *status);
 extern "C" __global__ void vp8_md5_kernel(const uint8_t *frames, size_t fstride, int count, DevGeom g, int w, int h, uint8_t *out);
 #ifdef VP8_STAMPS
 #define VP8HIP_SCHED_WORDS (16 + 16384 + 4 * 4096)     // + the diagnostic builds' log: four words per wave
@@ -274,7 +278,7 @@ struct vp8hip_ctx {
     uint8_t *d_mfqe, *h_mfqe; int mfqe_cap; hipEvent_t ev_mfqe;     // vp8hip_mfqe: the macroblock classes of the frame
     // vp8hip_entropy_decode: the frames' descriptions, their bytes, per-frame scratch and status on the device
     char *d_ent_frames, *d_ent_data; unsigned int *d_ent_scratch, *d_ent_status; size_t ent_frames_cap, ent_data_cap, ent_scratch_cap;
-    bool ent_tables_loaded; int ent_lpw;
+    bool ent_tables_loaded, ent_parts_off; int ent_lpw;
     unsigned int *d_sched;         // vp8_keyframe_kernel's role / work counters
     int *h_pack, *d_pack; int pack_cap;      // slots whose coefficients a launch has to pack / unpack first
 };
@@ -1288,7 +1292,13 @@ extern "C" int vp8hip_entropy_decode(vp8hip_ctx *c, int first_slot, int count, c
     }
     HIPCHK(c, hipSetDevice(c->device));
     const size_t fbytes = (size_t)count * sizeof(vp8hip_entropy_frame);
-    const size_t swords = (size_t)count * (2 * (size_t)c->dg.mb_cols + 64);
+    // frames coded with several token partitions, all with the same number: a partition per lane (vp8_entropy_parts_kernel)
+    int np = (int)frames[0].num_tok;
+    for (int i = 1; i < count && np > 1; i++) if ((int)frames[i].num_tok != np) np = 1;
+    // (the lanes of a frame follow each other a macroblock apart and lane 0 follows the last one into the next round of rows: rows
+    // at least as long as the partitions are many; the row above's flags of a wave's frames in 16 KB of LDS)
+    if (c->dg.mb_cols < np || c->dg.mb_cols > 256 || c->dg.mb_cols * (64 / np) > 4096 || c->ent_parts_off) np = 1;
+    const size_t swords = np > 1 ? (size_t)count * ((size_t)c->dg.mb_cols + 3 * (size_t)c->nmb) : (size_t)count * (2 * (size_t)c->dg.mb_cols + 64);
     if (fbytes > c->ent_frames_cap) {
         HIPCHK(c, hipStreamSynchronize(c->stream));
         if (c->d_ent_frames) (void)hipFree(c->d_ent_frames);
@@ -1315,8 +1325,11 @@ extern "C" int vp8hip_entropy_decode(vp8hip_ctx *c, int first_slot, int count, c
     }
     if (!c->ent_tables_loaded) {
         c->ent_tables_loaded = true;
+        HIPCHK(c, hipFuncSetAttribute((const void *)vp8_entropy_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)vp8_entropy_lds_bytes(64)));
         const char *e = getenv("VP8HIP_ENTROPY_LANES");     // lanes of a wave that carry a frame (a tuning knob: read once)
         c->ent_lpw = e ? atoi(e) : 0;
+        const char *e2 = getenv("VP8HIP_ENTROPY_PARTS");   // 0: a frame per lane whatever the number of token partitions
+        c->ent_parts_off = e2 && atoi(e2) == 0;
         if (c->ent_lpw < 1 || c->ent_lpw > 64) c->ent_lpw = 0;
     }
     HIPCHK(c, hipMemcpyAsync(c->d_ent_frames, frames, fbytes, hipMemcpyHostToDevice, c->stream));
@@ -1326,10 +1339,18 @@ extern "C" int vp8hip_entropy_decode(vp8hip_ctx *c, int first_slot, int count, c
         s.hdr_copy = frames[i].hdr;
         s.packed = false;
     }
-    // (lanes per wave: a frame's time hardly depends on how many other frames share its wave -- 2048 1080p frames: 1.36 s at 64,
-    // 1.28 s at 4 -- so waves are filled)
-    const int lpw = c->ent_lpw ? c->ent_lpw : 64;
-    hipLaunchKernelGGL(vp8_entropy_kernel, dim3((unsigned)((count + lpw - 1) / lpw)), dim3(64), 0, c->stream,
+    // Lanes per wave.  The lanes of a wave go through the macroblocks together, each macroblock taking as long as the slowest
+    // lane's, so fewer frames to a wave waste less -- while there are CUs without a wave; several waves to a CU slow each other
+    // down again (8192 1080p frames per launch, frames per second over a run: 64 lanes 15.4 k, 32: 16.9-17.9 k, 16: 16.1 k, 8: 12.7 k;
+    // 4096 per launch with every frame downloaded: the same 9 k at 16 and 64)
+    int lpw = c->ent_lpw;
+    if (!lpw) lpw = (count + 31) / 32 <= c->num_cu ? 32 : 64;
+    if (np > 1)
+        hipLaunchKernelGGL(vp8_entropy_parts_kernel, dim3((unsigned)((count + 64 / np - 1) / (64 / np))), dim3(64), 0, c->stream,
+                           (const vp8hip_entropy_frame *)c->d_ent_frames, count, np, (const uint8_t *)c->d_ent_data, c->dg, data_bytes,
+                           c->slot_block_dev, c->slot_bytes, c->o_mbs, c->o_coef, first_slot, c->d_ent_scratch, c->d_ent_status);
+    else
+    hipLaunchKernelGGL(vp8_entropy_kernel, dim3((unsigned)((count + lpw - 1) / lpw)), dim3(64), vp8_entropy_lds_bytes(lpw), c->stream,
                        (const vp8hip_entropy_frame *)c->d_ent_frames, count, lpw, (const uint8_t *)c->d_ent_data, c->dg, data_bytes, c->slot_block_dev,
                        c->slot_bytes, c->o_mbs, c->o_coef, first_slot, c->d_ent_scratch, c->d_ent_status);
     HIPCHK(c, hipGetLastError());

@@ -69,6 +69,26 @@ def test_device_ir_is_the_host_feeders_and_decodes_to_the_references_md5(name):
     ctx.close()
 
 
+@pytest.mark.parametrize("parts", ["0", "1"])
+def test_a_partition_per_lane_or_a_frame_per_lane(parts, monkeypatch):
+    """Frames coded with several token partitions, all with the same number, are decoded a PARTITION per lane, rows a macroblock
+    behind each other (vp8_entropy_parts_kernel); VP8HIP_ENTROPY_PARTS=0 keeps the frame-per-lane kernel.  Same IR either way;
+    a launch that mixes partition counts takes the frame-per-lane kernel by itself."""
+    monkeypatch.setenv("VP8HIP_ENTROPY_PARTS", parts)
+    P = load_package()
+    w, h, frames = P.read_ivf(ivf_path("kf_8part_1920x1080"))
+    frames = (frames * 4)[:11]                              # (11 frames of 8 partitions: a wave and a half)
+    host = _host_ir(P, frames)
+    efs = _export(P, frames)
+    assert all(e.num_tok == 8 for e in efs)
+    ctx = P.Vp8Hip()
+    ctx.configure(w, h, 1, len(frames))
+    assert not ctx.entropy_decode(0, efs, frames).any()
+    for i, (hdr, mbs, coef) in enumerate(host):
+        _compare(ctx, i, mbs, coef, (parts, i))
+    ctx.close()
+
+
 @pytest.mark.parametrize("lanes", [1, 5, 64])
 def test_lanes_per_wave(lanes, monkeypatch):
     """The launch shape is a tuning knob (VP8HIP_ENTROPY_LANES): any number of frames per wave gives the same IR."""
