@@ -174,8 +174,20 @@ typedef struct vp8hip_entropy_frame {
  * vp8hip_sync).  Asynchronous on the context's stream. */
 int  vp8hip_entropy_decode(vp8hip_ctx *ctx, int first_slot, int count, const vp8hip_entropy_frame *frames, const uint8_t *data,
                            size_t data_bytes);
-/* What became of the frames of the last vp8hip_entropy_decode, a word each: bit 0 = a partition of the frame ended early, the
- * frame is corrupt (what vp8_parser_decode_mbs reports through *corrupt).  Synchronous. */
+/* The same, the IR in its SPARSE form (include/vp8_ir.h) in arenas of the context instead of IR slots: a third of the dense form's
+ * bytes on the benchmark stream, so that more frames can be in flight than there are slots -- a lane is busy for as long as its
+ * frame is large whatever the launch's size, and the rate of the decoder is frames in flight / that time.  vp8hip_ir_expand then
+ * turns frames first_frame .. first_frame + n - 1 of that launch into the dense IR of slots first_slot .. (one kernel; same
+ * stream) for vp8hip_decode, a part of the launch at a time.  blocks_cap / dcs_cap: entries of the two arenas (0: an estimate
+ * from the compressed size, generous for key frames; a lane takes 256 blocks / 1024 DCs at a time).  When an arena runs out the
+ * whole launch is void: vp8hip_entropy_status says so (bit 1 in every word) and the caller repeats it with larger arenas or in
+ * the dense form.  One sparse launch at a time: the next one overwrites the arenas. */
+int  vp8hip_entropy_decode_sparse(vp8hip_ctx *ctx, int count, const vp8hip_entropy_frame *frames, const uint8_t *data, size_t data_bytes,
+                                  size_t blocks_cap, size_t dcs_cap);
+int  vp8hip_ir_expand(vp8hip_ctx *ctx, int first_frame, int first_slot, int n);
+/* What became of the frames of the last vp8hip_entropy_decode[_sparse], a word each: bit 0 = a partition of the frame ended early,
+ * the frame is corrupt (what vp8_parser_decode_mbs reports through *corrupt); bit 1 = a sparse launch ran out of arena.
+ * Synchronous. */
 int  vp8hip_entropy_status(vp8hip_ctx *ctx, int count, uint32_t *status);
 /* The IR of a slot as it stands on the device, dense form (tests, debugging): mbs[nmb], coef[nmb * 400].  Synchronous. */
 int  vp8hip_ir_fetch(vp8hip_ctx *ctx, int slot, vp8ir_mb *mbs, int16_t *coef);

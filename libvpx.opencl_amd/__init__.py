@@ -314,6 +314,8 @@ def load_hip():
         L.vp8hip_mfqe.argtypes = [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int]
         L.vp8hip_entropy_decode.argtypes = [c_void_p, c_int, c_int, c_void_p, c_void_p, c_size_t]
         L.vp8hip_entropy_status.argtypes = [c_void_p, c_int, c_void_p]
+        L.vp8hip_entropy_decode_sparse.argtypes = [c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_size_t, c_size_t]
+        L.vp8hip_ir_expand.argtypes = [c_void_p, c_int, c_int, c_int]
         L.vp8hip_ir_fetch.argtypes = [c_void_p, c_int, c_void_p, c_void_p]
         _hip = L
     return _hip
@@ -457,9 +459,10 @@ class Vp8Hip:
                             noise_rows.ctypes.data if noise_rows is not None else None)
         self._chk(self.L.vp8hip_postproc(self.h, src_fb, dst_fb, tmp_fb, ctypes.byref(pp)), "postproc")
 
-    def entropy_decode(self, first_slot, frames, datas):
+    def entropy_decode(self, first_slot, frames, datas, sparse_caps=None):
         """vp8hip_entropy_decode: frames = EntropyFrame list (from Parser.export_entropy), datas = the frames' bytes; slot
-        first_slot + i receives frame i's IR.  Returns the per-frame status words (synchronises)."""
+        first_slot + i receives frame i's IR.  Returns the per-frame status words (synchronises).  sparse_caps = (blocks, dcs):
+        vp8hip_entropy_decode_sparse instead (first_slot ignored; vp8hip_ir_expand via ir_expand)."""
         n = len(frames)
         arr = (EntropyFrame * n)()
         off = 0
@@ -468,10 +471,16 @@ class Vp8Hip:
             arr[i].data_off = off
             off += len(d)
         blob = b"".join(datas)
-        self._chk(self.L.vp8hip_entropy_decode(self.h, first_slot, n, ctypes.byref(arr), blob, len(blob)), "entropy_decode")
+        if sparse_caps is not None:
+            self._chk(self.L.vp8hip_entropy_decode_sparse(self.h, n, ctypes.byref(arr), blob, len(blob), sparse_caps[0], sparse_caps[1]), "entropy_decode_sparse")
+        else:
+            self._chk(self.L.vp8hip_entropy_decode(self.h, first_slot, n, ctypes.byref(arr), blob, len(blob)), "entropy_decode")
         st = np.zeros(n, np.uint32)
         self._chk(self.L.vp8hip_entropy_status(self.h, n, st.ctypes.data), "entropy_status")
         return st
+
+    def ir_expand(self, first_frame, first_slot, n):
+        self._chk(self.L.vp8hip_ir_expand(self.h, first_frame, first_slot, n), "ir_expand")
 
     def ir_fetch(self, slot):
         """The slot's IR as it stands on the device: (mbs uint8[n,64], coef int16[n,400])."""

@@ -217,11 +217,53 @@ __device__ __forceinline__ MbModes read_mb_modes(BD &fb, const uint8_t *__restri
     return m;
 }
 
+// Where a lane's coefficients go.  Dense: the macroblock's 800 bytes in its frame's slot.  Sparse (include/vp8_ir.h: blocks with
+// more than one coded position, 32 bytes each; lone DCs, 2 bytes each; found through vp8ir_mb::sparse_first / dc_first): two
+// arenas shared by the launch, from which a lane takes a chunk at a time (an atomic add per 256 blocks / 1024 DCs; a macroblock's
+// entries stay together, so a chunk with fewer than 25 left is given up) -- a third of the dense form's bytes on the benchmark
+// stream, which is what lets more frames be in flight (vp8hip_entropy_decode_sparse).
+#define ENT_BLOCK_CHUNK 256u
+#define ENT_DC_CHUNK    1024u
+struct SparseOut {
+    u32x4 *blocks; short *dcs;              // the arenas
+    u32 *cursors;                           // [0] blocks handed out, [1] DCs handed out, [2] set when an arena ran out
+    u32 cap_blocks, cap_dcs;
+    u32 b_next, b_left, d_next, d_left;     // the lane's chunks
+};
+__device__ __forceinline__ void sparse_reserve(SparseOut &o)
+{
+    if (o.b_left < 25u) {
+        u32 at = atomicAdd(&o.cursors[0], ENT_BLOCK_CHUNK);
+        if (at + ENT_BLOCK_CHUNK > o.cap_blocks) { o.cursors[2] = 1u; at = 0; }      // (out of arena: the launch is void; stay inside)
+        o.b_next = at; o.b_left = ENT_BLOCK_CHUNK;
+    }
+    if (o.d_left < 25u) {
+        u32 at = atomicAdd(&o.cursors[1], ENT_DC_CHUNK);
+        if (at + ENT_DC_CHUNK > o.cap_dcs) { o.cursors[2] = 1u; at = 0; }
+        o.d_next = at; o.d_left = ENT_DC_CHUNK;
+    }
+}
+// one decoded block (eight words) into the streams: more than one coded position -> a block; a lone first coefficient -> a DC
+// (luma blocks of a macroblock with Y2 start at position 1: theirs is eob 2 and up)
+__device__ __forceinline__ void sparse_emit(SparseOut &o, int e, bool y_after_y2, const u32 (&w)[8])
+{
+    if (e > 1) {
+        o.blocks[2 * (size_t)o.b_next] = (u32x4){ w[0], w[1], w[2], w[3] };
+        o.blocks[2 * (size_t)o.b_next + 1] = (u32x4){ w[4], w[5], w[6], w[7] };
+        o.b_next++; o.b_left--;
+    } else if (e == 1 && !y_after_y2) {
+        o.dcs[o.d_next] = (short)(w[0] & 0xffffu);
+        o.d_next++; o.d_left--;
+    }
+}
+
 // The macroblock's tokens (decode_macroblock, decodframe.c:100-130; vp8_decode_mb_tokens) and its place in the IR: coefficients
 // to out_coef (fifty 16-byte pieces), the descriptor to out_mb (four).  A / lnz: the non-zero flags of the row above at this
 // column and of the macroblock to the left (bits 0..3 Y, 4..5 U, 6..7 V, 8 Y2), updated.  desc / blk: the lane's staging in LDS.
+template <bool SPARSE>
 __device__ __forceinline__ void read_mb_tokens(BD &tb, const uint8_t *__restrict__ data, u32 limit, const MbModes &m, const row_t *probs,
-                                               const row_t *cat, u32 &A, u32 &lnz, u32 *desc, u32 *blk, u32x4 *out_coef, u32x4 *out_mb)
+                                               const row_t *cat, u32 &A, u32 &lnz, u32 *desc, u32 *blk, u32x4 *out_coef, u32x4 *out_mb,
+                                               SparseOut &sp)
 {
     const bool has_y2 = m.ymode != VP8IR_B_PRED;
     int skip = m.skip;
@@ -234,15 +276,19 @@ __device__ __forceinline__ void read_mb_tokens(BD &tb, const uint8_t *__restrict
             desc[10 + w] = (four & 15u) | (four >> 4 & 15u) << 8 | (four >> 8 & 15u) << 16 | (four >> 12 & 15u) << 24;
         }
     }
+    if (SPARSE) { sparse_reserve(sp); desc[14] = sp.b_next; desc[15] = sp.d_next; }
     if (skip) {                                                // vp8_reset_mb_tokens_context (detokenize.c:70-85)
         A = has_y2 ? 0u : A & 0x100u;
         lnz = has_y2 ? 0u : lnz & 0x100u;
     } else if (bd_error(tb)) {
         // the partition has run out: no tokens, contexts and skip flag stay, no residual (decodframe.c:119-130)
+        if (!SPARSE) {
 #pragma unroll
-        for (int i = 0; i < 50; i++) out_coef[i] = (u32x4){ 0, 0, 0, 0 };
+            for (int i = 0; i < 50; i++) out_coef[i] = (u32x4){ 0, 0, 0, 0 };
+        }
     } else {
-        int total = 0;
+        int total = 0, e_y2 = 0;
+        u32 y2w[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };              // (sparse: the Y2 block is decoded first and listed last)
         for (int i = has_y2 ? -1 : 0; i < 24; i++) {
             // block order: Y2 (when there is one), 16 Y, 4 U, 4 V; its place among the 25 of the IR; its context bits
             const int k = i < 0 ? 24 : i;
@@ -259,11 +305,24 @@ __device__ __forceinline__ void read_mb_tokens(BD &tb, const uint8_t *__restrict
             lnz = (lnz & ~(1u << lbit)) | (u32)nz << lbit;
             ((uint8_t *)desc)[8 + k] = (uint8_t)e;
             total += e;
-            out_coef[2 * k] = (u32x4){ blk[0], blk[1], blk[2], blk[3] };
-            out_coef[2 * k + 1] = (u32x4){ blk[4], blk[5], blk[6], blk[7] };
+            if (SPARSE) {
+                u32 w[8];
+#pragma unroll
+                for (int q = 0; q < 8; q++) w[q] = blk[q];
+                if (i < 0) {
+                    e_y2 = e;
+#pragma unroll
+                    for (int q = 0; q < 8; q++) y2w[q] = w[q];
+                } else
+                    sparse_emit(sp, e, has_y2 && i < 16, w);
+            } else {
+                out_coef[2 * k] = (u32x4){ blk[0], blk[1], blk[2], blk[3] };
+                out_coef[2 * k + 1] = (u32x4){ blk[4], blk[5], blk[6], blk[7] };
+            }
         }
+        if (SPARSE && has_y2) sparse_emit(sp, e_y2, false, y2w);
         if (has_y2) total -= 16;                               // (the sixteen luma blocks started at position 1)
-        else { out_coef[48] = (u32x4){ 0, 0, 0, 0 }; out_coef[49] = (u32x4){ 0, 0, 0, 0 }; }
+        else if (!SPARSE) { out_coef[48] = (u32x4){ 0, 0, 0, 0 }; out_coef[49] = (u32x4){ 0, 0, 0, 0 }; }
         if (total == 0) {                                      // decodframe.c:129: nothing coded after all
             skip = 1;
 #pragma unroll
@@ -283,10 +342,12 @@ extern "C" size_t vp8_entropy_lds_bytes(int lpw) { return (size_t)lpw * (ENT_PRO
 // frames: `count` of them; frame f goes to the IR slot at slot_base + (first_slot + f) * slot_bytes (descriptors at o_mbs, dense
 // coefficients at o_coef).  lpw: lanes of each wave that carry a frame (1..64).  scratch: per frame (2 * mb_cols + 64) words
 // (the row above's sub-block modes and non-zero flags per macroblock column, the token partitions' decoder states).
-extern "C" __global__ void __launch_bounds__(64)
-vp8_entropy_kernel(const vp8hip_entropy_frame *__restrict__ frames, int count, int lpw, const uint8_t *__restrict__ all_data, DevGeom g,
-                   size_t data_bytes, char *slot_base, size_t slot_bytes, size_t o_mbs, size_t o_coef, int first_slot,
-                   u32 *__restrict__ scratch, u32 *__restrict__ status)
+// (sparse: the descriptors go to arena.mbs, a frame after the other, the coefficients to the arenas of SparseArena; slot_* unused)
+struct SparseArena { u32x4 *mbs; u32x4 *blocks; short *dcs; u32 *cursors; u32 cap_blocks, cap_dcs; };
+template <bool SPARSE>
+__device__ __forceinline__ void entropy_body(const vp8hip_entropy_frame *__restrict__ frames, int count, int lpw, const uint8_t *__restrict__ all_data,
+                                             DevGeom g, size_t data_bytes, char *slot_base, size_t slot_bytes, size_t o_mbs, size_t o_coef,
+                                             int first_slot, u32 *__restrict__ scratch, u32 *__restrict__ status, const SparseArena &arena)
 {
     // LDS by lanes that carry a frame (the launch says how much: vp8_entropy_lds_bytes): probabilities, descriptor, block
     extern __shared__ u32 s_dyn[];
@@ -338,8 +399,9 @@ vp8_entropy_kernel(const vp8hip_entropy_frame *__restrict__ frames, int count, i
     const ModeParams MP = { F.update_mb_segmentation_map != 0, F.mb_no_coeff_skip != 0, F.prob_skip_false, F.segment_tree_probs[0],
                             F.segment_tree_probs[1], F.segment_tree_probs[2] };
     char *slot = slot_base + slot_bytes * (size_t)(first_slot + f);
-    u32x4 *out_mbs = (u32x4 *)(slot + o_mbs);
+    u32x4 *out_mbs = SPARSE ? arena.mbs + (size_t)f * cols * rows * 4 : (u32x4 *)(slot + o_mbs);
     u32x4 *out_coef = (u32x4 *)(slot + o_coef);
+    SparseOut sp = { arena.blocks, arena.dcs, arena.cursors, arena.cap_blocks, arena.cap_dcs, 0, 0, 0, 0 };
     bool bad = false;
 
     for (int r = 0; r < rows; r++) {
@@ -360,7 +422,7 @@ vp8_entropy_kernel(const vp8hip_entropy_frame *__restrict__ frames, int count, i
             const MbModes m = read_mb_modes(fb, data, limit, MP, s_kfb, above, lbm);
             abm[c] = above;
             u32 A = anz[c];
-            read_mb_tokens(tb, data, limit, m, probs, s_cat, A, lnz, desc, blk, out_coef + n * 50, out_mbs + n * 4);
+            read_mb_tokens<SPARSE>(tb, data, limit, m, probs, s_cat, A, lnz, desc, blk, out_coef + n * 50, out_mbs + n * 4, sp);
             anz[c] = A;
         }
         bad |= bd_error(tb);
@@ -378,6 +440,26 @@ vp8_entropy_kernel(const vp8hip_entropy_frame *__restrict__ frames, int count, i
 #else
     if (status) status[f] = bad ? 1u : 0u;
 #endif
+}
+
+extern "C" __global__ void __launch_bounds__(64)
+vp8_entropy_kernel(const vp8hip_entropy_frame *__restrict__ frames, int count, int lpw, const uint8_t *__restrict__ all_data, DevGeom g,
+                   size_t data_bytes, char *slot_base, size_t slot_bytes, size_t o_mbs, size_t o_coef, int first_slot,
+                   u32 *__restrict__ scratch, u32 *__restrict__ status)
+{
+    const SparseArena none = { nullptr, nullptr, nullptr, nullptr, 0, 0 };
+    entropy_body<false>(frames, count, lpw, all_data, g, data_bytes, slot_base, slot_bytes, o_mbs, o_coef, first_slot, scratch, status, none);
+}
+
+// The same into the sparse streams (descriptors: mbs, frame after frame; blocks / dcs: the launch's arenas; cursors: three words,
+// zeroed by the caller, the third set when an arena ran out -- the launch's output is void then).
+extern "C" __global__ void __launch_bounds__(64)
+vp8_entropy_sparse_kernel(const vp8hip_entropy_frame *__restrict__ frames, int count, int lpw, const uint8_t *__restrict__ all_data, DevGeom g,
+                          size_t data_bytes, u32 *__restrict__ scratch, u32 *__restrict__ status, u32x4 *mbs, u32x4 *blocks, short *dcs,
+                          u32 *cursors, u32 cap_blocks, u32 cap_dcs)
+{
+    const SparseArena arena = { mbs, blocks, dcs, cursors, cap_blocks, cap_dcs };
+    entropy_body<true>(frames, count, lpw, all_data, g, data_bytes, nullptr, 0, 0, 0, 0, scratch, status, arena);
 }
 
 // Frames coded with several token partitions (2, 4 or 8: the encoder's --token-parts; macroblock row r is in partition r mod NP,
@@ -487,7 +569,8 @@ vp8_entropy_parts_kernel(const vp8hip_entropy_frame *__restrict__ frames, int co
             MbModes m;
             m.ymode = (int)(m0 & 255u); m.uvmode = (int)(m0 >> 8 & 255u); m.seg = (int)(m0 >> 16 & 255u); m.skip = (int)(m0 >> 24);
             m.bm = (u64)mo[1] | (u64)mo[2] << 32;
-            read_mb_tokens(tb, data, limit, m, probs, s_cat, A, lnz, desc, blk, out_coef + n * 50, out_mbs + n * 4);
+            SparseOut none = { nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, 0 };
+            read_mb_tokens<false>(tb, data, limit, m, probs, s_cat, A, lnz, desc, blk, out_coef + n * 50, out_mbs + n * 4, none);
             anz[c] = A;
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");

@@ -32,6 +32,11 @@ extern "C" __global__ void vp8_entropy_kernel(const vp8hip_entropy_frame *frames
                                               size_t data_bytes, char *slot_base, size_t slot_bytes, size_t o_mbs, size_t o_coef,
                                               int first_slot, unsigned int *scratch, unsigned int *status);
 extern "C" size_t vp8_entropy_lds_bytes(int lpw);
+typedef unsigned int ent_u32x4 __attribute__((ext_vector_type(4)));
+extern "C" __global__ void vp8_entropy_sparse_kernel(const vp8hip_entropy_frame *frames, int count, int lpw, const uint8_t *data, DevGeom g,
+                                                     size_t data_bytes, unsigned int *scratch, unsigned int *status, ent_u32x4 *mbs,
+                                                     ent_u32x4 *blocks, short *dcs, unsigned int *cursors, unsigned int cap_blocks,
+                                                     unsigned int cap_dcs);
 extern "C" __global__ void vp8_entropy_parts_kernel(const vp8hip_entropy_frame *frames, int count, int np, const uint8_t *data, DevGeom g,
                                                     size_t data_bytes, char *slot_base, size_t slot_bytes, size_t o_mbs, size_t o_coef,
                                                     int first_slot, unsigned int *scratch, unsigned int *status);
@@ -79,6 +84,30 @@ vp8_ir_expand_kernel(const vp8ir_mb *__restrict__ mbs, const int16_t *__restrict
         else if (!(ch & 1)) v.x = (unsigned short)dcs[(size_t)m.dc_first + rank];      // IR order: the DC is the block's first entry
     }
     *(u32x4 *)(coef + (size_t)mb * VP8IR_COEF_PER_MB + k * 16 + (ch & 1) * 8) = v;
+}
+
+// The same for `gridDim.y` frames whose sparse form was written on the device (vp8_entropy_sparse_kernel): descriptors frame after
+// frame in sp_mbs, the streams in arenas shared by all of them (sparse_first / dc_first index the arenas); frame y -> slot first_slot + y.
+__global__ void __launch_bounds__(256)
+vp8_ir_expand_batch_kernel(const vp8ir_mb *__restrict__ sp_mbs, const int16_t *__restrict__ blocks, const int16_t *__restrict__ dcs,
+                           char *slot_base, size_t slot_bytes, size_t o_mbs, size_t o_coef, int first_slot, int nmb)
+{
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+    const int mb = (int)(gid / 50), ch = (int)(gid % 50), k = ch >> 1;
+    if (mb >= nmb) return;
+    const vp8ir_mb &m = sp_mbs[(size_t)blockIdx.y * nmb + mb];
+    char *slot = slot_base + slot_bytes * (size_t)(first_slot + (int)blockIdx.y);
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    if (ch < 4) ((u32x4 *)((vp8ir_mb *)(slot + o_mbs) + mb))[ch] = ((const u32x4 *)&m)[ch];
+    u32x4 v = { 0, 0, 0, 0 };
+    const int kind = vp8ir_block_kind(&m, k);
+    if (kind) {
+        int rank = 0;
+        for (int j = 0; j < k; j++) rank += vp8ir_block_kind(&m, j) == kind;
+        if (kind == 2) v = *(const u32x4 *)(blocks + ((size_t)m.sparse_first + rank) * 16 + (ch & 1) * 8);
+        else if (!(ch & 1)) v.x = (unsigned short)dcs[(size_t)m.dc_first + rank];
+    }
+    *(u32x4 *)((int16_t *)(slot + o_coef) + (size_t)mb * VP8IR_COEF_PER_MB + k * 16 + (ch & 1) * 8) = v;
 }
 
 // Packed coefficients: the form vp8_keyframe_kernel / vp8_interframe_kernel read a slot in.  Of a macroblock's blocks 0..23 those a
@@ -278,7 +307,10 @@ struct vp8hip_ctx {
     uint8_t *d_mfqe, *h_mfqe; int mfqe_cap; hipEvent_t ev_mfqe;     // vp8hip_mfqe: the macroblock classes of the frame
     // vp8hip_entropy_decode: the frames' descriptions, their bytes, per-frame scratch and status on the device
     char *d_ent_frames, *d_ent_data; unsigned int *d_ent_scratch, *d_ent_status; size_t ent_frames_cap, ent_data_cap, ent_scratch_cap;
-    bool ent_tables_loaded, ent_parts_off; int ent_lpw;
+    bool ent_tables_loaded, ent_parts_off, ent_last_sparse; int ent_lpw;
+    // vp8hip_entropy_decode_sparse: descriptors of the launch's frames, the two arenas, cursors; the frames' headers for vp8hip_ir_expand
+    char *d_sp_mbs, *d_sp_blocks, *d_sp_dcs; unsigned int *d_sp_cursors; size_t sp_mbs_cap, sp_blocks_cap, sp_dcs_cap, sp_blocks_use, sp_dcs_use; int sp_count;
+    std::vector<vp8ir_frame_hdr> sp_hdrs;
     unsigned int *d_sched;         // vp8_keyframe_kernel's role / work counters
     int *h_pack, *d_pack; int pack_cap;      // slots whose coefficients a launch has to pack / unpack first
 };
@@ -423,6 +455,10 @@ extern "C" void vp8hip_destroy(vp8hip_ctx *c)
     if (c->d_md5) (void)hipFree(c->d_md5);
     if (c->h_pp) (void)hipHostFree(c->h_pp);
     if (c->ev_pp) (void)hipEventDestroy(c->ev_pp);
+    if (c->d_sp_mbs) (void)hipFree(c->d_sp_mbs);
+    if (c->d_sp_blocks) (void)hipFree(c->d_sp_blocks);
+    if (c->d_sp_dcs) (void)hipFree(c->d_sp_dcs);
+    if (c->d_sp_cursors) (void)hipFree(c->d_sp_cursors);
     if (c->d_ent_frames) (void)hipFree(c->d_ent_frames);
     if (c->d_ent_data) (void)hipFree(c->d_ent_data);
     if (c->d_ent_scratch) (void)hipFree(c->d_ent_scratch);
@@ -1272,10 +1308,12 @@ extern "C" int vp8hip_mfqe(vp8hip_ctx *c, int show_fb, int prev_fb, int dst_fb, 
     return 0;
 }
 
-extern "C" int vp8hip_entropy_decode(vp8hip_ctx *c, int first_slot, int count, const vp8hip_entropy_frame *frames, const uint8_t *data,
-                                     size_t data_bytes)
+// first_slot >= 0: into the IR slots (dense); first_slot < 0: into the context's sparse arenas (vp8hip_entropy_decode_sparse)
+static int entropy_launch(vp8hip_ctx *c, int first_slot, int count, const vp8hip_entropy_frame *frames, const uint8_t *data, size_t data_bytes,
+                          size_t blocks_cap, size_t dcs_cap)
 {
-    if (!c || !frames || !data || count < 1 || first_slot < 0 || first_slot + count > (int)c->slots.size())
+    const bool sparse = first_slot < 0;
+    if (!c || !frames || !data || count < 1 || (!sparse && first_slot + count > (int)c->slots.size()))
         return fail(c, -2, "vp8hip_entropy_decode: bad arguments");
     for (int i = 0; i < count; i++) {
         const vp8hip_entropy_frame &f = frames[i];
@@ -1297,7 +1335,7 @@ extern "C" int vp8hip_entropy_decode(vp8hip_ctx *c, int first_slot, int count, c
     for (int i = 1; i < count && np > 1; i++) if ((int)frames[i].num_tok != np) np = 1;
     // (the lanes of a frame follow each other a macroblock apart and lane 0 follows the last one into the next round of rows: rows
     // at least as long as the partitions are many; the row above's flags of a wave's frames in 16 KB of LDS)
-    if (c->dg.mb_cols < np || c->dg.mb_cols > 256 || c->dg.mb_cols * (64 / np) > 4096 || c->ent_parts_off) np = 1;
+    if (c->dg.mb_cols < np || c->dg.mb_cols > 256 || c->dg.mb_cols * (64 / np) > 4096 || c->ent_parts_off || sparse) np = 1;
     const size_t swords = np > 1 ? (size_t)count * ((size_t)c->dg.mb_cols + 3 * (size_t)c->nmb) : (size_t)count * (2 * (size_t)c->dg.mb_cols + 64);
     if (fbytes > c->ent_frames_cap) {
         HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1326,6 +1364,7 @@ extern "C" int vp8hip_entropy_decode(vp8hip_ctx *c, int first_slot, int count, c
     if (!c->ent_tables_loaded) {
         c->ent_tables_loaded = true;
         HIPCHK(c, hipFuncSetAttribute((const void *)vp8_entropy_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)vp8_entropy_lds_bytes(64)));
+        HIPCHK(c, hipFuncSetAttribute((const void *)vp8_entropy_sparse_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)vp8_entropy_lds_bytes(64)));
         const char *e = getenv("VP8HIP_ENTROPY_LANES");     // lanes of a wave that carry a frame (a tuning knob: read once)
         c->ent_lpw = e ? atoi(e) : 0;
         const char *e2 = getenv("VP8HIP_ENTROPY_PARTS");   // 0: a frame per lane whatever the number of token partitions
@@ -1334,18 +1373,60 @@ extern "C" int vp8hip_entropy_decode(vp8hip_ctx *c, int first_slot, int count, c
     }
     HIPCHK(c, hipMemcpyAsync(c->d_ent_frames, frames, fbytes, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->d_ent_data, data, data_bytes, hipMemcpyHostToDevice, c->stream));
-    for (int i = 0; i < count; i++) {
-        Slot &s = c->slots[first_slot + i];
-        s.hdr_copy = frames[i].hdr;
-        s.packed = false;
-    }
+    if (sparse) {
+        // arenas: descriptors for every frame; blocks and DCs by the caller's estimate, or by what key frames have been seen to need
+        // (blocks: up to 0.41 per compressed byte, DCs up to 0.54), with room to spare and a chunk per lane on top
+        // (never more than every block of every macroblock, plus the chunk a lane may leave unfinished)
+        const size_t worst_b = (size_t)count * ((size_t)c->nmb * 25 + 2 * 256), worst_d = (size_t)count * ((size_t)c->nmb * 25 + 2 * 1024);
+        size_t nb = blocks_cap ? blocks_cap : (size_t)(data_bytes * 0.6) + (size_t)count * 512, nd = dcs_cap ? dcs_cap : (size_t)(data_bytes * 1.2) + (size_t)count * 2048;
+        if (nb > worst_b) nb = worst_b;
+        if (nd > worst_d) nd = worst_d;
+        if (nb + 1024 >= (1ull << 32) || nd + 4096 >= (1ull << 32)) return fail(c, -2, "vp8hip_entropy_decode_sparse: more than 2^32 blocks: fewer frames per call");
+        const size_t mbytes = (size_t)count * c->nmb * sizeof(vp8ir_mb);
+        if (mbytes > c->sp_mbs_cap || nb > c->sp_blocks_cap || nd > c->sp_dcs_cap) HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (mbytes > c->sp_mbs_cap) {
+            if (c->d_sp_mbs) (void)hipFree(c->d_sp_mbs);
+            c->d_sp_mbs = nullptr; c->sp_mbs_cap = 0;
+            HIPCHK(c, hipMalloc((void **)&c->d_sp_mbs, mbytes));
+            c->sp_mbs_cap = mbytes;
+        }
+        if (nb > c->sp_blocks_cap) {
+            if (c->d_sp_blocks) (void)hipFree(c->d_sp_blocks);
+            c->d_sp_blocks = nullptr; c->sp_blocks_cap = 0;
+            HIPCHK(c, hipMalloc((void **)&c->d_sp_blocks, nb * 32 + 64));
+            c->sp_blocks_cap = nb;
+        }
+        if (nd > c->sp_dcs_cap) {
+            if (c->d_sp_dcs) (void)hipFree(c->d_sp_dcs);
+            c->d_sp_dcs = nullptr; c->sp_dcs_cap = 0;
+            HIPCHK(c, hipMalloc((void **)&c->d_sp_dcs, nd * 2 + 64));
+            c->sp_dcs_cap = nd;
+        }
+        if (!c->d_sp_cursors) HIPCHK(c, hipMalloc((void **)&c->d_sp_cursors, 16));
+        HIPCHK(c, hipMemsetAsync(c->d_sp_cursors, 0, 16, c->stream));
+        c->sp_hdrs.resize((size_t)count);
+        for (int i = 0; i < count; i++) c->sp_hdrs[(size_t)i] = frames[i].hdr;
+        c->sp_count = count;
+        c->sp_blocks_use = nb; c->sp_dcs_use = nd;
+    } else
+        for (int i = 0; i < count; i++) {
+            Slot &s = c->slots[first_slot + i];
+            s.hdr_copy = frames[i].hdr;
+            s.packed = false;
+        }
     // Lanes per wave.  The lanes of a wave go through the macroblocks together, each macroblock taking as long as the slowest
     // lane's, so fewer frames to a wave waste less -- while there are CUs without a wave; several waves to a CU slow each other
     // down again (8192 1080p frames per launch, frames per second over a run: 64 lanes 15.4 k, 32: 16.9-17.9 k, 16: 16.1 k, 8: 12.7 k;
     // 4096 per launch with every frame downloaded: the same 9 k at 16 and 64)
+    c->ent_last_sparse = sparse;
     int lpw = c->ent_lpw;
     if (!lpw) lpw = (count + 31) / 32 <= c->num_cu ? 32 : 64;
-    if (np > 1)
+    if (sparse)
+        hipLaunchKernelGGL(vp8_entropy_sparse_kernel, dim3((unsigned)((count + lpw - 1) / lpw)), dim3(64), vp8_entropy_lds_bytes(lpw), c->stream,
+                           (const vp8hip_entropy_frame *)c->d_ent_frames, count, lpw, (const uint8_t *)c->d_ent_data, c->dg, data_bytes,
+                           c->d_ent_scratch, c->d_ent_status, (ent_u32x4 *)c->d_sp_mbs, (ent_u32x4 *)c->d_sp_blocks, (short *)c->d_sp_dcs,
+                           c->d_sp_cursors, (unsigned int)c->sp_blocks_use, (unsigned int)c->sp_dcs_use);
+    else if (np > 1)
         hipLaunchKernelGGL(vp8_entropy_parts_kernel, dim3((unsigned)((count + 64 / np - 1) / (64 / np))), dim3(64), 0, c->stream,
                            (const vp8hip_entropy_frame *)c->d_ent_frames, count, np, (const uint8_t *)c->d_ent_data, c->dg, data_bytes,
                            c->slot_block_dev, c->slot_bytes, c->o_mbs, c->o_coef, first_slot, c->d_ent_scratch, c->d_ent_status);
@@ -1357,6 +1438,37 @@ extern "C" int vp8hip_entropy_decode(vp8hip_ctx *c, int first_slot, int count, c
     return 0;
 }
 
+extern "C" int vp8hip_entropy_decode(vp8hip_ctx *c, int first_slot, int count, const vp8hip_entropy_frame *frames, const uint8_t *data,
+                                     size_t data_bytes)
+{
+    if (first_slot < 0) return fail(c, -2, "vp8hip_entropy_decode: bad arguments");
+    return entropy_launch(c, first_slot, count, frames, data, data_bytes, 0, 0);
+}
+
+extern "C" int vp8hip_entropy_decode_sparse(vp8hip_ctx *c, int count, const vp8hip_entropy_frame *frames, const uint8_t *data, size_t data_bytes,
+                                            size_t blocks_cap, size_t dcs_cap)
+{
+    return entropy_launch(c, -1, count, frames, data, data_bytes, blocks_cap, dcs_cap);
+}
+
+extern "C" int vp8hip_ir_expand(vp8hip_ctx *c, int first_frame, int first_slot, int n)
+{
+    if (!c || n < 1 || first_frame < 0 || first_frame + n > c->sp_count || first_slot < 0 || first_slot + n > (int)c->slots.size() || n > 65535)
+        return fail(c, -2, "vp8hip_ir_expand: bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    for (int i = 0; i < n; i++) {
+        Slot &s = c->slots[first_slot + i];
+        s.hdr_copy = c->sp_hdrs[(size_t)(first_frame + i)];
+        s.packed = false;
+    }
+    const long chunks = (long)c->nmb * 50;
+    hipLaunchKernelGGL(vp8_ir_expand_batch_kernel, dim3((unsigned)((chunks + 255) / 256), (unsigned)n), dim3(256), 0, c->stream,
+                       (const vp8ir_mb *)c->d_sp_mbs + (size_t)first_frame * c->nmb, (const int16_t *)c->d_sp_blocks, (const int16_t *)c->d_sp_dcs,
+                       c->slot_block_dev, c->slot_bytes, c->o_mbs, c->o_coef, first_slot, c->nmb);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
 extern "C" int vp8hip_entropy_status(vp8hip_ctx *c, int count, uint32_t *status)
 {
     if (!c || !status || count < 1 || (size_t)count * sizeof(vp8hip_entropy_frame) > c->ent_frames_cap)
@@ -1364,6 +1476,11 @@ extern "C" int vp8hip_entropy_status(vp8hip_ctx *c, int count, uint32_t *status)
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipMemcpy(status, c->d_ent_status, (size_t)count * 4, hipMemcpyDeviceToHost));
+    if (c->ent_last_sparse) {                               // did the arenas hold?
+        unsigned int cur[4] = { 0, 0, 0, 0 };
+        HIPCHK(c, hipMemcpy(cur, c->d_sp_cursors, 16, hipMemcpyDeviceToHost));
+        if (cur[2]) for (int i = 0; i < count; i++) status[i] |= 2u;
+    }
     return 0;
 }
 

@@ -167,3 +167,38 @@ def test_frames_cut_short(name):
     for i, (mbs, coef, _) in enumerate(host):
         _compare(ctx, i, mbs, coef, (name, i))
     ctx.close()
+
+
+@pytest.mark.parametrize("name", ["kf_odd_67x45", "kf_640x360", "kf_1920x1080", "kf_8part_1920x1080"])
+def test_sparse_form_through_the_arenas(name):
+    """vp8hip_entropy_decode_sparse + vp8hip_ir_expand: more frames in one launch than the context has slots, expanded into the
+    slots a part at a time -- the same dense IR (sparse_first / dc_first aside: arena indices), the reference's MD5s; arenas too
+    small for the launch are reported, not overrun."""
+    P = load_package()
+    w, h, frames = P.read_ivf(ivf_path(name))
+    frames = (frames * 3)[:max(7, len(frames))]
+    host = _host_ir(P, frames)
+    efs = _export(P, frames)
+    n, nslots = len(frames), 3
+    ctx = P.Vp8Hip()
+    ctx.configure(w, h, nslots, nslots)
+    st = ctx.entropy_decode(0, efs, frames, sparse_caps=(0, 0))
+    assert not st.any()
+    gold = golden_md5(name)
+    for lo in range(0, n, nslots):
+        m = min(nslots, n - lo)
+        ctx.ir_expand(lo, 0, m)
+        for i in range(m):
+            dm, dc = ctx.ir_fetch(i)
+            hm, hc = host[lo + i][1].copy(), host[lo + i][2]
+            dm[:, 56:64] = 0; hm[:, 56:64] = 0
+            assert (dm == hm).all(), (name, lo + i)
+            coded = (hm[:, 3] & 1) == 0
+            assert (dc[coded] == hc[coded]).all(), (name, lo + i)
+            assert not dc[~coded].any()
+        ctx.decode([(i, i, (-1, -1, -1)) for i in range(m)], P.STAGE_ALL)
+        assert [P.planes_md5(*ctx.download_planes(i)) for i in range(m)] == [gold[(lo + i) % len(gold)] for i in range(m)]
+    st = ctx.entropy_decode(0, efs, frames, sparse_caps=(256, 1024))         # a chunk each: not enough for anything but tiny frames
+    assert all(int(x) & 2 for x in st) or name == "kf_odd_67x45"
+    assert not ctx.entropy_decode(0, efs, frames, sparse_caps=(0, 0)).any()  # ... and the next launch is fine again
+    ctx.close()
