@@ -212,12 +212,13 @@ def batch_md5_probe(fixture, device, loops=205, extra=()):
     bad = sum(1 for i, g in enumerate(got) if g != gold[i % len(gold)]) + abs(len(got) - loops * len(gold))
     import re
     m = re.search(r"(\d+) frames in ([0-9.]+) s: ([0-9.]+) frames/s, ([0-9.]+) Mpix/s \((\d+) feeder threads, (\d+) frames per launch, "
-                  r"entropy decode on the (\w+), MD5 on the (\w+)(, frames not downloaded)?\)", r.stderr)
+                  r"entropy decode on the (\w+), MD5 on the (\w+)(, frames not downloaded)?(?:; (\d+) frames per entropy launch)?\)", r.stderr)
     if not m:
         return {"error": "unparsed: " + r.stderr[-200:]}
     return {"tool": " ".join(["bin/batch_md5", *extra, "--loop", str(loops)]), "frames": int(m.group(1)), "frames_per_s": float(m.group(3)),
             "Mpix_s": float(m.group(4)), "host_threads": int(m.group(5)), "frames_per_launch": int(m.group(6)), "entropy_decode_on": m.group(7),
-            "md5_on": m.group(8), "frames_downloaded": m.group(9) is None, "md5_mismatches": bad}
+            "md5_on": m.group(8), "frames_downloaded": m.group(9) is None, "frames_per_entropy_launch": int(m.group(10) or m.group(6)),
+            "md5_mismatches": bad}
 
 
 def load_stream(P, ctx, fixture, F, lo):

@@ -185,6 +185,9 @@ int  vp8hip_entropy_decode(vp8hip_ctx *ctx, int first_slot, int count, const vp8
 int  vp8hip_entropy_decode_sparse(vp8hip_ctx *ctx, int count, const vp8hip_entropy_frame *frames, const uint8_t *data, size_t data_bytes,
                                   size_t blocks_cap, size_t dcs_cap);
 int  vp8hip_ir_expand(vp8hip_ctx *ctx, int first_frame, int first_slot, int n);
+/* Memory for sparse launches of up to max_count frames up front (a launch larger than anything before it otherwise stops to
+ * allocate): descriptors for max_count frames, arenas of blocks_cap blocks and dcs_cap DCs. */
+int  vp8hip_entropy_reserve_sparse(vp8hip_ctx *ctx, int max_count, size_t blocks_cap, size_t dcs_cap);
 /* What became of the frames of the last vp8hip_entropy_decode[_sparse], a word each: bit 0 = a partition of the frame ended early,
  * the frame is corrupt (what vp8_parser_decode_mbs reports through *corrupt); bit 1 = a sparse launch ran out of arena.
  * Synchronous. */

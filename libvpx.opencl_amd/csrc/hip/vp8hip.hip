@@ -88,26 +88,49 @@ vp8_ir_expand_kernel(const vp8ir_mb *__restrict__ mbs, const int16_t *__restrict
 
 // The same for `gridDim.y` frames whose sparse form was written on the device (vp8_entropy_sparse_kernel): descriptors frame after
 // frame in sp_mbs, the streams in arenas shared by all of them (sparse_first / dc_first index the arenas); frame y -> slot first_slot + y.
+// Two kernels: the slots' coefficient arrays are cleared (most of the dense form is zeros: plain 16-byte stores, a row of the grid
+// per frame), then a thread per macroblock walks its 25 eobs and puts the coded entries in place.
+__global__ void __launch_bounds__(256)
+vp8_ir_clear_kernel(char *slot_base, size_t slot_bytes, size_t o_coef, int first_slot, size_t coef_bytes)
+{
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 *p = (u32x4 *)(slot_base + slot_bytes * (size_t)(first_slot + (int)blockIdx.y) + o_coef);
+    const size_t n = coef_bytes / 16;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i] = (u32x4){ 0, 0, 0, 0 };
+}
 __global__ void __launch_bounds__(256)
 vp8_ir_expand_batch_kernel(const vp8ir_mb *__restrict__ sp_mbs, const int16_t *__restrict__ blocks, const int16_t *__restrict__ dcs,
                            char *slot_base, size_t slot_bytes, size_t o_mbs, size_t o_coef, int first_slot, int nmb)
 {
-    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
-    const int mb = (int)(gid / 50), ch = (int)(gid % 50), k = ch >> 1;
-    if (mb >= nmb) return;
-    const vp8ir_mb &m = sp_mbs[(size_t)blockIdx.y * nmb + mb];
-    char *slot = slot_base + slot_bytes * (size_t)(first_slot + (int)blockIdx.y);
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-    if (ch < 4) ((u32x4 *)((vp8ir_mb *)(slot + o_mbs) + mb))[ch] = ((const u32x4 *)&m)[ch];
-    u32x4 v = { 0, 0, 0, 0 };
-    const int kind = vp8ir_block_kind(&m, k);
-    if (kind) {
-        int rank = 0;
-        for (int j = 0; j < k; j++) rank += vp8ir_block_kind(&m, j) == kind;
-        if (kind == 2) v = *(const u32x4 *)(blocks + ((size_t)m.sparse_first + rank) * 16 + (ch & 1) * 8);
-        else if (!(ch & 1)) v.x = (unsigned short)dcs[(size_t)m.dc_first + rank];
+    const int mb = (int)(blockIdx.x * 256 + threadIdx.x);
+    if (mb >= nmb) return;
+    const vp8ir_mb *m = sp_mbs + (size_t)blockIdx.y * nmb + mb;
+    char *slot = slot_base + slot_bytes * (size_t)(first_slot + (int)blockIdx.y);
+    const u32x4 d0 = ((const u32x4 *)m)[0], d1 = ((const u32x4 *)m)[1], d2 = ((const u32x4 *)m)[2], d3 = ((const u32x4 *)m)[3];
+    u32x4 *md = (u32x4 *)((vp8ir_mb *)(slot + o_mbs) + mb);
+    md[0] = d0; md[1] = d1; md[2] = d2; md[3] = d3;
+    const unsigned int ymode = d0.x & 255u, flags = d0.x >> 24;
+    if (flags & VP8IR_MB_SKIP) return;
+    const bool has_y2 = ymode != VP8IR_B_PRED && ymode != VP8IR_SPLITMV;
+    // eobs: descriptor bytes 8..32
+    const unsigned int ew[7] = { d0.z, d0.w, d1.x, d1.y, d1.z, d1.w, d2.x };
+    size_t b = d3.z, d = d3.w;                                            // sparse_first, dc_first
+    int16_t *coef = (int16_t *)(slot + o_coef) + (size_t)mb * VP8IR_COEF_PER_MB;
+#pragma unroll
+    for (int k = 0; k < 25; k++) {
+        if (k == 24 && !has_y2) break;
+        const unsigned int e = (ew[k >> 2] >> (8 * (k & 3))) & 255u;
+        if (e > 1) {
+            const u32x4 *src = (const u32x4 *)(blocks + b * 16);
+            ((u32x4 *)(coef + k * 16))[0] = src[0];
+            ((u32x4 *)(coef + k * 16))[1] = src[1];
+            b++;
+        } else if (e == 1 && !(has_y2 && k < 16)) {
+            coef[k * 16] = dcs[d];
+            d++;
+        }
     }
-    *(u32x4 *)((int16_t *)(slot + o_coef) + (size_t)mb * VP8IR_COEF_PER_MB + k * 16 + (ch & 1) * 8) = v;
 }
 
 // Packed coefficients: the form vp8_keyframe_kernel / vp8_interframe_kernel read a slot in.  Of a macroblock's blocks 0..23 those a
@@ -1375,39 +1398,22 @@ static int entropy_launch(vp8hip_ctx *c, int first_slot, int count, const vp8hip
     HIPCHK(c, hipMemcpyAsync(c->d_ent_data, data, data_bytes, hipMemcpyHostToDevice, c->stream));
     if (sparse) {
         // arenas: descriptors for every frame; blocks and DCs by the caller's estimate, or by what key frames have been seen to need
-        // (blocks: up to 0.41 per compressed byte, DCs up to 0.54), with room to spare and a chunk per lane on top
+        // (blocks: up to 0.41 per compressed byte, DCs up to 0.54), with room to spare (0.6, 0.8) and a chunk per lane on top
         // (never more than every block of every macroblock, plus the chunk a lane may leave unfinished)
         const size_t worst_b = (size_t)count * ((size_t)c->nmb * 25 + 2 * 256), worst_d = (size_t)count * ((size_t)c->nmb * 25 + 2 * 1024);
-        size_t nb = blocks_cap ? blocks_cap : (size_t)(data_bytes * 0.6) + (size_t)count * 512, nd = dcs_cap ? dcs_cap : (size_t)(data_bytes * 1.2) + (size_t)count * 2048;
+        size_t nb = blocks_cap ? blocks_cap : (size_t)(data_bytes * 0.6) + (size_t)count * 512, nd = dcs_cap ? dcs_cap : (size_t)(data_bytes * 0.8) + (size_t)count * 2048;
         if (nb > worst_b) nb = worst_b;
         if (nd > worst_d) nd = worst_d;
-        if (nb + 1024 >= (1ull << 32) || nd + 4096 >= (1ull << 32)) return fail(c, -2, "vp8hip_entropy_decode_sparse: more than 2^32 blocks: fewer frames per call");
-        const size_t mbytes = (size_t)count * c->nmb * sizeof(vp8ir_mb);
-        if (mbytes > c->sp_mbs_cap || nb > c->sp_blocks_cap || nd > c->sp_dcs_cap) HIPCHK(c, hipStreamSynchronize(c->stream));
-        if (mbytes > c->sp_mbs_cap) {
-            if (c->d_sp_mbs) (void)hipFree(c->d_sp_mbs);
-            c->d_sp_mbs = nullptr; c->sp_mbs_cap = 0;
-            HIPCHK(c, hipMalloc((void **)&c->d_sp_mbs, mbytes));
-            c->sp_mbs_cap = mbytes;
-        }
-        if (nb > c->sp_blocks_cap) {
-            if (c->d_sp_blocks) (void)hipFree(c->d_sp_blocks);
-            c->d_sp_blocks = nullptr; c->sp_blocks_cap = 0;
-            HIPCHK(c, hipMalloc((void **)&c->d_sp_blocks, nb * 32 + 64));
-            c->sp_blocks_cap = nb;
-        }
-        if (nd > c->sp_dcs_cap) {
-            if (c->d_sp_dcs) (void)hipFree(c->d_sp_dcs);
-            c->d_sp_dcs = nullptr; c->sp_dcs_cap = 0;
-            HIPCHK(c, hipMalloc((void **)&c->d_sp_dcs, nd * 2 + 64));
-            c->sp_dcs_cap = nd;
-        }
+        if (nb > 0xffff0000ull) nb = 0xffff0000ull;          // (sparse_first / dc_first are 32-bit indices)
+        if (nd > 0xffff0000ull) nd = 0xffff0000ull;
+        if (vp8hip_entropy_reserve_sparse(c, count, nb, nd)) return -1;
         if (!c->d_sp_cursors) HIPCHK(c, hipMalloc((void **)&c->d_sp_cursors, 16));
         HIPCHK(c, hipMemsetAsync(c->d_sp_cursors, 0, 16, c->stream));
         c->sp_hdrs.resize((size_t)count);
         for (int i = 0; i < count; i++) c->sp_hdrs[(size_t)i] = frames[i].hdr;
         c->sp_count = count;
-        c->sp_blocks_use = nb; c->sp_dcs_use = nd;
+        // (the caller's caps are honoured as they are; without any, what has been reserved is there to be used)
+        c->sp_blocks_use = blocks_cap ? nb : c->sp_blocks_cap; c->sp_dcs_use = dcs_cap ? nd : c->sp_dcs_cap;
     } else
         for (int i = 0; i < count; i++) {
             Slot &s = c->slots[first_slot + i];
@@ -1451,6 +1457,35 @@ extern "C" int vp8hip_entropy_decode_sparse(vp8hip_ctx *c, int count, const vp8h
     return entropy_launch(c, -1, count, frames, data, data_bytes, blocks_cap, dcs_cap);
 }
 
+extern "C" int vp8hip_entropy_reserve_sparse(vp8hip_ctx *c, int max_count, size_t blocks_cap, size_t dcs_cap)
+{
+    if (!c || max_count < 1 || !c->nmb) return fail(c, -2, "vp8hip_entropy_reserve_sparse: bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t mbytes = (size_t)max_count * c->nmb * sizeof(vp8ir_mb);
+    if (blocks_cap > 0xffff0000ull) blocks_cap = 0xffff0000ull;
+    if (dcs_cap > 0xffff0000ull) dcs_cap = 0xffff0000ull;
+    if (mbytes > c->sp_mbs_cap || blocks_cap > c->sp_blocks_cap || dcs_cap > c->sp_dcs_cap) HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (mbytes > c->sp_mbs_cap) {
+        if (c->d_sp_mbs) (void)hipFree(c->d_sp_mbs);
+        c->d_sp_mbs = nullptr; c->sp_mbs_cap = 0;
+        HIPCHK(c, hipMalloc((void **)&c->d_sp_mbs, mbytes));
+        c->sp_mbs_cap = mbytes;
+    }
+    if (blocks_cap > c->sp_blocks_cap) {
+        if (c->d_sp_blocks) (void)hipFree(c->d_sp_blocks);
+        c->d_sp_blocks = nullptr; c->sp_blocks_cap = 0;
+        HIPCHK(c, hipMalloc((void **)&c->d_sp_blocks, blocks_cap * 32 + 64));
+        c->sp_blocks_cap = blocks_cap;
+    }
+    if (dcs_cap > c->sp_dcs_cap) {
+        if (c->d_sp_dcs) (void)hipFree(c->d_sp_dcs);
+        c->d_sp_dcs = nullptr; c->sp_dcs_cap = 0;
+        HIPCHK(c, hipMalloc((void **)&c->d_sp_dcs, dcs_cap * 2 + 64));
+        c->sp_dcs_cap = dcs_cap;
+    }
+    return 0;
+}
+
 extern "C" int vp8hip_ir_expand(vp8hip_ctx *c, int first_frame, int first_slot, int n)
 {
     if (!c || n < 1 || first_frame < 0 || first_frame + n > c->sp_count || first_slot < 0 || first_slot + n > (int)c->slots.size() || n > 65535)
@@ -1461,8 +1496,9 @@ extern "C" int vp8hip_ir_expand(vp8hip_ctx *c, int first_frame, int first_slot, 
         s.hdr_copy = c->sp_hdrs[(size_t)(first_frame + i)];
         s.packed = false;
     }
-    const long chunks = (long)c->nmb * 50;
-    hipLaunchKernelGGL(vp8_ir_expand_batch_kernel, dim3((unsigned)((chunks + 255) / 256), (unsigned)n), dim3(256), 0, c->stream,
+    hipLaunchKernelGGL(vp8_ir_clear_kernel, dim3(64, (unsigned)n), dim3(256), 0, c->stream, c->slot_block_dev, c->slot_bytes, c->o_coef, first_slot,
+                       (size_t)c->nmb * VP8IR_COEF_PER_MB * sizeof(int16_t));
+    hipLaunchKernelGGL(vp8_ir_expand_batch_kernel, dim3((unsigned)((c->nmb + 255) / 256), (unsigned)n), dim3(256), 0, c->stream,
                        (const vp8ir_mb *)c->d_sp_mbs + (size_t)first_frame * c->nmb, (const int16_t *)c->d_sp_blocks, (const int16_t *)c->d_sp_dcs,
                        c->slot_block_dev, c->slot_bytes, c->o_mbs, c->o_coef, first_slot, c->nmb);
     HIPCHK(c, hipGetLastError());

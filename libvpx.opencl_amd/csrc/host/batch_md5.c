@@ -1,4 +1,4 @@
-/* batch_md5 [--threads T] [--batch B] [--loop N] [--host-md5] [--device-entropy [--no-download]] <in.ivf> <out.md5>
+/* batch_md5 [--threads T] [--batch B] [--loop N] [--host-md5] [--device-entropy [--entropy-batch E] [--no-download]] <in.ivf> <out.md5>
  *
  * decode_to_md5 for streams of independently decodable frames (all key frames), at the rate the host can feed the
  * GPU: SURVEY.md 8(f)1.  The output file has decode_to_md5's lines ("<md5>  img-<w>x<h>-<%04d>.i420", one per frame,
@@ -16,7 +16,10 @@
  * copy the compressed frames into page-locked memory; the macroblocks' modes and coefficient tokens are decoded on the GPU, a
  * frame per lane (vp8hip_entropy_decode), straight into the IR slots the pixel path reads.  A lane takes about a second for a
  * large 1080p key frame whatever the batch, so this mode wants batches of thousands (one set of IR slots, two sets of frame
- * buffers).  --no-download: with the MD5s computed on the device the frames themselves stay there.
+ * buffers).  --no-download: with the MD5s computed on the device the frames themselves stay there.  --entropy-batch E (a
+ * multiple of B): the entropy decoder takes E frames per launch and leaves their IR in its sparse form (a third of the bytes:
+ * vp8hip_entropy_decode_sparse), the pixel path expands and decodes them B at a time -- more frames in flight for the same memory,
+ * and frames in flight over the time of the largest is what the entropy decoder's rate is.
  *
  * Prints frames, seconds and frames/s for the region "first byte parsed .. last digest done" on stderr. */
 #include <pthread.h>
@@ -99,6 +102,7 @@ static int g_dev_md5;                               /* hash on the device (vp8hi
                                                        the feeder keeps the host's cores */
 static volatile int g_failed;
 static int g_dev_entropy;                           /* --device-entropy */
+static int g_ebatch;                                /* --entropy-batch: frames per entropy launch (0: = g_batch, dense) */
 static long *g_order;                               /* --device-entropy: which frame of the run the k-th processed one is.  A lane of the
                                                        entropy kernel is busy for as long as its frame is large and a launch lasts as long
                                                        as its longest lane, so the frames of SORT_WINDOW batches at a time are taken
@@ -202,12 +206,13 @@ int main(int argc, char **argv)
         else if (!strcmp(argv[a], "--host-md5")) host_md5 = 1;          /* hash on the host whatever the frame size */
         else if (!strcmp(argv[a], "--device-entropy")) g_dev_entropy = 1;
         else if (!strcmp(argv[a], "--no-download")) no_download = 1;
+        else if (!strcmp(argv[a], "--entropy-batch") && a + 1 < argc) g_ebatch = atoi(argv[++a]);
         else if (!strcmp(argv[a], "--batch") && a + 1 < argc) g_batch = atoi(argv[++a]);
         else if (!strcmp(argv[a], "--loop") && a + 1 < argc) loop = atoi(argv[++a]);
-        else DIE("Usage: %s [--threads T] [--batch B] [--loop N] [--host-md5] [--device-entropy [--no-download]] <in.ivf> <out.md5>", argv[0]);
+        else DIE("Usage: %s [--threads T] [--batch B] [--loop N] [--host-md5] [--device-entropy [--entropy-batch E] [--no-download]] <in.ivf> <out.md5>", argv[0]);
     }
     if (argc - a != 2 || g_batch < 1 || loop < 1)
-        DIE("Usage: %s [--threads T] [--batch B] [--loop N] [--host-md5] [--device-entropy [--no-download]] <in.ivf> <out.md5>", argv[0]);
+        DIE("Usage: %s [--threads T] [--batch B] [--loop N] [--host-md5] [--device-entropy [--entropy-batch E] [--no-download]] <in.ivf> <out.md5>", argv[0]);
     if (threads < 1) {
         long n = sysconf(_SC_NPROCESSORS_ONLN);
         threads = n > 33 ? 32 : (n > 2 ? (int)n - 1 : 1);      /* more than ~32 feeders gain nothing: the host memory system is the limit */
@@ -233,12 +238,16 @@ int main(int argc, char **argv)
     if (rc < 0 || !g_nframes) DIE("failed to read %s", argv[a]);
     const long total = (long)g_nframes * loop;
     if (g_batch > total) g_batch = (int)total;
+    if (g_ebatch && (!g_dev_entropy || g_ebatch < g_batch || g_ebatch % g_batch)) DIE("--entropy-batch goes with --device-entropy and is a multiple of --batch");
+    if (g_ebatch == g_batch) g_ebatch = 0;
+    const int unit = g_ebatch ? g_ebatch : g_batch;            /* frames per entropy launch */
 
     /* ---- device and host state */
     int device = -1;
     if (getenv("VP8HIP_DEVICE")) device = atoi(getenv("VP8HIP_DEVICE"));
     if (vp8hip_create(device, &g_hip)) DIE("vp8hip_create: %s (no CPU fallback)", vp8hip_last_error(NULL));
     g_dev_md5 = !host_md5 && g_width % 128 == 0;
+    if (g_ebatch && !g_dev_md5) DIE("--entropy-batch needs the MD5s computed on the device (a width that is a multiple of 128, no --host-md5)");
     if (no_download && !g_dev_md5) DIE("--no-download needs the MD5s computed on the device (a width that is a multiple of 128, no --host-md5)");
     /* slots and frame buffers: three sets for the host feeder (parsed / on the GPU / coming back); with the entropy decoder on
        the device the IR is written and read on one stream, one set does, and the frame buffers alternate between two */
@@ -249,18 +258,19 @@ int main(int argc, char **argv)
         {   /* a batch's bytes at most: the frames are taken in order of size within windows of SORT_WINDOW batches */
             g_order = (long *)malloc(sizeof(long) * (size_t)total);
             for (long k = 0; k < total; k++) g_order[k] = k;
-            for (long w0 = 0; w0 < total; w0 += (long)SORT_WINDOW * g_batch) {
-                const long wn = total - w0 < (long)SORT_WINDOW * g_batch ? total - w0 : (long)SORT_WINDOW * g_batch;
+            const long window = (long)SORT_WINDOW * g_batch > 4L * unit ? (long)SORT_WINDOW * g_batch : 4L * unit;
+            for (long w0 = 0; w0 < total; w0 += window) {
+                const long wn = total - w0 < window ? total - w0 : window;
                 qsort(g_order + w0, (size_t)wn, sizeof(long), by_size_desc);
             }
-            for (long k0 = 0; k0 < total; k0 += g_batch) {
+            for (long k0 = 0; k0 < total; k0 += unit) {
                 size_t run = 0;
-                for (long k = k0; k < k0 + g_batch && k < total; k++) run += g_frames[g_order[k] % g_nframes].size;
+                for (long k = k0; k < k0 + unit && k < total; k++) run += g_frames[g_order[k] % g_nframes].size;
                 if (run > g_ent_cap) g_ent_cap = run;
             }
         }
         for (int k = 0; k < 2; k++) {
-            if (!(g_ent[k] = (vp8hip_entropy_frame *)vp8hip_host_alloc(g_hip, (size_t)g_batch * sizeof(vp8hip_entropy_frame))) ||
+            if (!(g_ent[k] = (vp8hip_entropy_frame *)vp8hip_host_alloc(g_hip, (size_t)unit * sizeof(vp8hip_entropy_frame))) ||
                 !(g_ent_data[k] = (uint8_t *)vp8hip_host_alloc(g_hip, g_ent_cap + 16))) DIE("vp8hip_host_alloc: %s", vp8hip_last_error(g_hip));
         }
     } else {
@@ -281,6 +291,97 @@ int main(int argc, char **argv)
         pthread_create(&tid[t], NULL, worker_main, (void *)(size_t)t);
     }
     vp8hip_job *jobs = calloc((size_t)g_batch, sizeof *jobs);
+
+    if (g_ebatch) {
+        /* ---- the pipeline with the entropy decoder on the device in launches of up to E frames (sparse IR), the pixel path B at a
+           time: headers of launch L+1 on the host while launch L is on the GPU; per part of a launch: expand, decode, digests back.
+           A launch takes as many frames (a multiple of B) as stay under LAUNCH_BYTES compressed -- the arenas are sized by the
+           compressed bytes -- and one that comes down to B frames (large frames: the sparse form saves little there) goes straight
+           into the slots in the dense form. */
+#define LAUNCH_BYTES ((size_t)3200 << 20)
+#define LAUNCH_FRAMES(first, n_out) do {                                                                                      \
+            long n_ = total - (first) < g_ebatch ? total - (first) : g_ebatch;                                               \
+            for (;;) {                                                                                                        \
+                size_t by_ = 0;                                                                                               \
+                for (long k_ = 0; k_ < n_; k_++) by_ += g_frames[run_index((first) + k_) % g_nframes].size;                  \
+                if (by_ <= LAUNCH_BYTES || n_ <= g_batch) break;                                                              \
+                n_ -= g_batch;                                                                                                \
+            }                                                                                                                 \
+            (n_out) = (int)n_;                                                                                                \
+        } while (0)
+        task parse_t;
+        batch_ref cur = { 0, 0, 0 }, prev = { -1, 0, 0 };
+        long part_no = 0, L = 0;
+        /* the arenas once, for the largest launch: by what key frames have been seen to need per compressed byte, with room to spare */
+        const size_t most = g_ent_cap < LAUNCH_BYTES + ((size_t)256 << 20) ? g_ent_cap : LAUNCH_BYTES + ((size_t)256 << 20);
+        HIP(vp8hip_entropy_reserve_sparse(g_hip, g_ebatch, (size_t)(most * 0.6) + (size_t)g_ebatch * 512, (size_t)(most * 0.8) + (size_t)g_ebatch * 2048));
+        const double t0 = now_s();
+        LAUNCH_FRAMES(0, cur.n);
+        size_t bytes = place_frames(&cur);
+        task_start(&parse_t, 0, export_one, &cur, cur.n);
+        for (long done = 0; done < total; L++) {
+            task_wait(&parse_t, 0);
+            if (g_failed) DIE("a frame of launch %ld failed to parse", L);
+            const batch_ref now = cur;
+            const int sparse = now.n > g_batch;
+            done += now.n;
+            if (sparse) HIP(vp8hip_entropy_decode_sparse(g_hip, now.n, g_ent[now.b & 1], g_ent_data[now.b & 1], bytes, 0, 0));
+            else HIP(vp8hip_entropy_decode(g_hip, 0, now.n, g_ent[now.b & 1], g_ent_data[now.b & 1], bytes));
+            for (int at = 0; at < now.n; at += g_batch, part_no++) {
+                const batch_ref part = { (int)(part_no & 0x3fffffff), now.n - at < g_batch ? now.n - at : g_batch, now.first + at };
+                const int fb0 = (part.b & 1) * g_batch;
+                if (sparse) HIP(vp8hip_ir_expand(g_hip, at, 0, part.n));
+                for (int i = 0; i < part.n; i++) {
+                    jobs[i].ir_slot = i; jobs[i].dst_fb = fb0 + i;
+                    jobs[i].ref_fb[0] = jobs[i].ref_fb[1] = jobs[i].ref_fb[2] = jobs[i].ref_fb[3] = -1;
+                }
+                HIP(vp8hip_decode(g_hip, jobs, part.n, VP8HIP_STAGE_ALL));
+                if (prev.b >= 0) {
+                    HIP(vp8hip_download_wait(g_hip));
+                    take_digests(&prev);
+                }
+                if (at == 0 && done < total) {
+                    /* (the page-locked set the next launch's frames are written to belonged to launch L - 1, whose last digests have
+                       just come back: its copies are done) */
+                    const long first = cur.first + cur.n;
+                    cur.b = cur.b + 1; cur.first = first;
+                    LAUNCH_FRAMES(first, cur.n);
+                    bytes = place_frames(&cur);
+                    task_start(&parse_t, 0, export_one, &cur, cur.n);
+                }
+                HIP(vp8hip_frames_fetch_async(g_hip, fb0, part.n, no_download ? NULL : g_host[part.b & 1], g_dig[part.b & 1]));
+                prev = part;
+            }
+            {   /* did the arenas hold? (before the next launch resets them) */
+                static uint32_t *st;
+                if (!st) st = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)g_ebatch);
+                if (sparse) {
+                    HIP(vp8hip_entropy_status(g_hip, now.n, st));
+                    if (st[0] & 2u) DIE("the sparse arenas of launch %ld ran out: use a smaller --entropy-batch, or none", L);
+                }
+            }
+        }
+        HIP(vp8hip_download_wait(g_hip));
+        take_digests(&prev);
+        const double dt = now_s() - t0;
+        FILE *out = fopen(argv[a + 1], "wb");
+        if (!out) DIE("Failed to open %s for writing", argv[a + 1]);
+        for (long f = 0; f < total; f++) {
+            for (int i = 0; i < 16; i++) fprintf(out, "%02x", g_digest[f][i]);
+            fprintf(out, "  img-%dx%d-%04ld.i420\n", g_width, g_height, f + 1);
+        }
+        fclose(out);
+        fprintf(stderr, "%ld frames in %.3f s: %.1f frames/s, %.1f Mpix/s (%d feeder threads, %d frames per launch, entropy decode on the %s, MD5 on the %s%s; %d frames per entropy launch)\n",
+                total, dt, total / dt, total / dt * g_width * g_height / 1e6, threads, g_batch, "device", "device",
+                no_download ? ", frames not downloaded" : "", g_ebatch);
+        pthread_mutex_lock(&pool.mu);
+        pool.stop = 1;
+        pthread_cond_broadcast(&pool.work);
+        pthread_mutex_unlock(&pool.mu);
+        for (int t = 0; t < threads; t++) { pthread_join(tid[t], NULL); vp8_parser_destroy(g_parsers[t]); }
+        vp8hip_destroy(g_hip);
+        return EXIT_SUCCESS;
+    }
 
     /* ---- the pipeline */
     const long nbatch = (total + g_batch - 1) / g_batch;
