@@ -82,7 +82,7 @@ __device__ __forceinline__ int bd_get(BD &b, const uint8_t *__restrict__ data, u
 #ifdef ENT_STATS
     b.count++;
 #endif
-    if (b.bits < 0) {                                   // 1..8 bits of the top byte are spent: three more bytes under them
+    if (__builtin_expect(b.bits < 0, 0)) {              // 1..8 bits of the top byte are spent: three more bytes under them
         u32 nxt = (b.n01 & 255u) << 16 | (b.n01 & 0xff00u) | b.n2;
         if (b.pos > b.end) {                            // (the partition ends inside these three, or has ended: zeros from there on)
             const u32 past = b.pos - b.end;

@@ -117,7 +117,6 @@ vp8_ir_expand_batch_kernel(const vp8ir_mb *__restrict__ sp_mbs, const int16_t *_
     const unsigned int ew[7] = { d0.z, d0.w, d1.x, d1.y, d1.z, d1.w, d2.x };
     size_t b = d3.z, d = d3.w;                                            // sparse_first, dc_first
     int16_t *coef = (int16_t *)(slot + o_coef) + (size_t)mb * VP8IR_COEF_PER_MB;
-#pragma unroll
     for (int k = 0; k < 25; k++) {
         if (k == 24 && !has_y2) break;
         const unsigned int e = (ew[k >> 2] >> (8 * (k & 3))) & 255u;
@@ -1524,8 +1523,17 @@ extern "C" int vp8hip_ir_fetch(vp8hip_ctx *c, int slot, vp8ir_mb *mbs, int16_t *
 {
     if (!c || slot < 0 || slot >= (int)c->slots.size()) return fail(c, -2, "vp8hip_ir_fetch: bad slot %d", slot);
     Slot &s = c->slots[slot];
-    if (s.packed) return fail(c, -2, "vp8hip_ir_fetch: slot %d holds the packed form (a launch has consumed it)", slot);
     HIPCHK(c, hipSetDevice(c->device));
+    if (s.packed) {                 // (a large launch has consumed the slot: the dense form, which is what callers see, back in place)
+        int *d_one = nullptr;
+        HIPCHK(c, hipMalloc((void **)&d_one, sizeof(int)));
+        HIPCHK(c, hipMemcpyAsync(d_one, &slot, sizeof(int), hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(vp8_ir_pack_kernel, dim3((unsigned)((c->nmb + 255) / 256)), dim3(256), 0, c->stream, c->slot_block_dev, c->slot_bytes,
+                           c->o_mbs, c->o_coef, (const int *)d_one, 1, c->nmb, 1);
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        (void)hipFree(d_one);
+        s.packed = false;
+    }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (mbs) HIPCHK(c, hipMemcpy(mbs, s.d_mbs, (size_t)c->nmb * sizeof(vp8ir_mb), hipMemcpyDeviceToHost));
     if (coef) HIPCHK(c, hipMemcpy(coef, s.d_coef, (size_t)c->nmb * VP8IR_COEF_PER_MB * sizeof(int16_t), hipMemcpyDeviceToHost));
