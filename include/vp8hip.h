@@ -155,9 +155,11 @@ int  vp8hip_mfqe(vp8hip_ctx *ctx, int show_fb, int prev_fb, int dst_fb, const ui
  * behind (vp8_parser_export_entropy, csrc/host/vp8_parser.h): the decoder state of the first partition where the per-macroblock
  * data start, the token partitions' extents, the probabilities.  The kernel writes the dense IR of include/vp8_ir.h into the
  * frames' slots -- descriptors and coefficients byte for byte what vp8_parser_decode_mbs writes -- and vp8hip_decode takes it
- * from there.  Integer only. */
+ * from there.  Inter frames too (vp8_decode_mode_mvs' per-macroblock half: reference frame, the near / nearest candidates from the
+ * macroblocks above, left and above-left, NEWMV / SPLITMV vectors: decodemv.c:323-569) -- which only pays where many frames are
+ * independent of each other, as the same position of many streams is.  Integer only. */
 typedef struct vp8hip_entropy_frame {
-    vp8ir_frame_hdr hdr;                /* as vp8_parser_begin_frame returned it; a key frame of the context's size */
+    vp8ir_frame_hdr hdr;                /* as vp8_parser_begin_frame returned it; a frame of the context's size */
     uint64_t data_off;                  /* the frame's first byte in the buffer handed to vp8hip_entropy_decode */
     uint32_t first_pos, first_end;      /* first partition, relative to data_off: the next byte the decoder takes, and its end */
     uint32_t first_value;               /* ... its window (32 bits, the active byte on top), */
@@ -168,6 +170,12 @@ typedef struct vp8hip_entropy_frame {
     uint8_t  update_mb_segmentation_map, mb_no_coeff_skip, prob_skip_false, rsv0;
     uint8_t  segment_tree_probs[3], rsv1;
     uint8_t  coef_probs[1056];          /* [block type 4][band 8][context 3][node 11] */
+    /* inter frames (hdr.frame_type 1; mb_mode_mv_init, decodemv.c:178-224): */
+    uint8_t  prob_intra, prob_last, prob_gf, rsv2;
+    uint8_t  ymode_prob[4];
+    uint8_t  uvmode_prob[3], rsv3;
+    uint8_t  mvc[2][19], rsv4[2];       /* motion-vector probabilities, row then column */
+    uint8_t  rsv5[4];
 } vp8hip_entropy_frame;
 /* frames[i] -> IR slot first_slot + i.  `data`: the compressed frames (data_bytes in all; any host memory -- page-locked memory
  * from vp8hip_host_alloc makes the copy asynchronous, and then `frames` and `data` have to stay untouched until the next
@@ -194,6 +202,7 @@ int  vp8hip_entropy_reserve_sparse(vp8hip_ctx *ctx, int max_count, size_t blocks
 int  vp8hip_entropy_status(vp8hip_ctx *ctx, int count, uint32_t *status);
 /* The IR of a slot as it stands on the device, dense form (tests, debugging): mbs[nmb], coef[nmb * 400].  Synchronous. */
 int  vp8hip_ir_fetch(vp8hip_ctx *ctx, int slot, vp8ir_mb *mbs, int16_t *coef);
+int  vp8hip_ir_fetch_mvs(vp8hip_ctx *ctx, int slot, vp8ir_mv *mvs);      /* ... and its vectors: mvs[nmb * 16] */
 
 /* Batch form for pipelines (tools/e2e.py, bin/batch_md5): `count` consecutive frame buffers, whole, as ONE asynchronous copy on
  * a stream of its own -- it starts when everything queued on the context's stream so far has finished and runs beside later

@@ -69,7 +69,10 @@ class EntropyFrame(ctypes.Structure):
                 ("num_tok", ctypes.c_uint32), ("tok_pos", ctypes.c_uint32 * 8), ("tok_end", ctypes.c_uint32 * 8),
                 ("update_mb_segmentation_map", ctypes.c_uint8), ("mb_no_coeff_skip", ctypes.c_uint8),
                 ("prob_skip_false", ctypes.c_uint8), ("rsv0", ctypes.c_uint8), ("segment_tree_probs", ctypes.c_uint8 * 3),
-                ("rsv1", ctypes.c_uint8), ("coef_probs", ctypes.c_uint8 * 1056)]
+                ("rsv1", ctypes.c_uint8), ("coef_probs", ctypes.c_uint8 * 1056),
+                ("prob_intra", ctypes.c_uint8), ("prob_last", ctypes.c_uint8), ("prob_gf", ctypes.c_uint8), ("rsv2", ctypes.c_uint8),
+                ("ymode_prob", ctypes.c_uint8 * 4), ("uvmode_prob", ctypes.c_uint8 * 3), ("rsv3", ctypes.c_uint8),
+                ("mvc", ctypes.c_uint8 * 38), ("rsv4", ctypes.c_uint8 * 2), ("rsv5", ctypes.c_uint8 * 4)]
 
 
 class Geom(ctypes.Structure):
@@ -317,6 +320,7 @@ def load_hip():
         L.vp8hip_entropy_decode_sparse.argtypes = [c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_size_t, c_size_t]
         L.vp8hip_ir_expand.argtypes = [c_void_p, c_int, c_int, c_int]
         L.vp8hip_ir_fetch.argtypes = [c_void_p, c_int, c_void_p, c_void_p]
+        L.vp8hip_ir_fetch_mvs.argtypes = [c_void_p, c_int, c_void_p]
         _hip = L
     return _hip
 
@@ -478,6 +482,12 @@ class Vp8Hip:
         st = np.zeros(n, np.uint32)
         self._chk(self.L.vp8hip_entropy_status(self.h, n, st.ctypes.data), "entropy_status")
         return st
+
+    def mvs_fetch(self, slot):
+        """The slot's motion vectors as they stand on the device: int16[n * 16, 2] (row, col)."""
+        mv = np.zeros((self.g_mbs() * 16, 2), np.int16)
+        self._chk(self.L.vp8hip_ir_fetch_mvs(self.h, slot, mv.ctypes.data), "ir_fetch_mvs")
+        return mv
 
     def ir_expand(self, first_frame, first_slot, n):
         self._chk(self.L.vp8hip_ir_expand(self.h, first_frame, first_slot, n), "ir_expand")

@@ -182,12 +182,13 @@ __device__ __forceinline__ int read_block(BD &b, const uint8_t *__restrict__ dat
 
 // What the first partition says about one macroblock (vp8_kfread_modes, decodemv.c:50-173).  above / left: the sub-block modes
 // of the row above at this column and of the macroblock to the left (four nibbles each), updated for the neighbours to come.
-struct MbModes { int ymode, uvmode, seg, skip; u64 bm; };    // bm: B_PRED's sixteen modes, a nibble each
+struct MbModes { int ymode, uvmode, seg, skip; u64 bm; int ref, clamp, part; };    // bm: B_PRED's sixteen modes, a nibble each
 struct ModeParams { bool seg_map, has_skip; u32 p_skip, tp0, tp1, tp2; };
 __device__ __forceinline__ MbModes read_mb_modes(BD &fb, const uint8_t *__restrict__ data, u32 limit, const ModeParams &P, const row_t *kfb,
                                                  u32 &above, u32 &lbm)
 {
     MbModes m;
+    m.ref = VP8IR_INTRA_FRAME; m.clamp = 0; m.part = 0;
     m.seg = 0;
     if (P.seg_map) m.seg = GET(fb, P.tp0) ? 2 + GET(fb, P.tp2) : GET(fb, P.tp1);
     m.skip = P.has_skip ? GET(fb, P.p_skip) : 0;
@@ -214,6 +215,197 @@ __device__ __forceinline__ MbModes read_mb_modes(BD &fb, const uint8_t *__restri
     if (!GET(fb, 142)) m.uvmode = VP8IR_DC_PRED;
     else if (!GET(fb, 114)) m.uvmode = VP8IR_V_PRED;
     else m.uvmode = GET(fb, 183) ? VP8IR_TM_PRED : VP8IR_H_PRED;
+    return m;
+}
+
+// ---- inter frames (read_mb_modes / read_mbinfo, decodemv.c:323-569; vp8_find_near_mvs, findnearmv.c:25-140, as decodemv.c inlines it)
+// A motion vector is a word: row in the low half, column in the high half (vp8ir_mv).  What a macroblock leaves for its
+// neighbours: its vector (SPLITMV: the last block's; intra: 0), reference frame and mode, and the four sub-block vectors on the
+// side the neighbour touches (a macroblock that is not split: its vector four times).
+struct Nb { u32 mv, bmv[4], ref, ymode; };
+struct InterParams { u32 p_intra, p_last, p_gf; u32 ymode[4]; u32 uvmode[3]; u32 sign_bias; const uint8_t *mvc; };   // sign_bias: bit per reference frame
+
+__device__ __forceinline__ u32 mv_neg(u32 mv) { return ((0u - (mv & 0xffffu)) & 0xffffu) | ((0u - (mv >> 16)) << 16); }
+__device__ __forceinline__ u32 mv_add(u32 a, u32 b) { return ((a + b) & 0xffffu) | ((a >> 16) + (b >> 16)) << 16; }
+__device__ __forceinline__ int mv_row(u32 mv) { return (int)(short)(mv & 0xffffu); }
+__device__ __forceinline__ int mv_col(u32 mv) { return (int)(short)(mv >> 16); }
+__device__ __forceinline__ u32 mv_make(int row, int col) { return ((u32)row & 0xffffu) | (u32)col << 16; }
+struct Edges { int left, right, top, bottom; };
+__device__ __forceinline__ u32 mv_clamp(u32 mv, const Edges &e)            // vp8_clamp_mv2, findnearmv.h:32-44
+{
+    int r = mv_row(mv), c = mv_col(mv);
+    c = c < e.left ? e.left : c > e.right ? e.right : c;
+    r = r < e.top ? e.top : r > e.bottom ? e.bottom : r;
+    return mv_make(r, c);
+}
+__device__ __forceinline__ int mv_outside(u32 mv, const Edges &e)         // vp8_check_mv_bounds
+{
+    const int r = mv_row(mv), c = mv_col(mv);
+    return (c < e.left) | (c > e.right) | (r < e.top) | (r > e.bottom);
+}
+// read_mvcomponent (decodemv.c:75-110): the long form's bits 0, 1, 2, then 9 .. 4, bit 3 last (and only if it can be zero)
+__device__ __forceinline__ int read_mv_component(BD &fb, const uint8_t *__restrict__ data, u32 limit, const uint8_t *pr)
+{
+    int x = 0;
+    if (GET(fb, pr[0])) {
+        for (int i = 0; i < 3; i++) x += GET(fb, pr[9 + i]) << i;
+        for (int i = 9; i > 3; i--) x += GET(fb, pr[9 + i]) << i;
+        if (!(x & 0xfff0) || GET(fb, pr[9 + 3])) x += 8;
+    } else {
+        if (!GET(fb, pr[2])) {
+            if (!GET(fb, pr[3])) x = GET(fb, pr[4]);
+            else x = 2 + GET(fb, pr[5]);
+        } else {
+            if (!GET(fb, pr[6])) x = 4 + GET(fb, pr[7]);
+            else x = 6 + GET(fb, pr[8]);
+        }
+    }
+    if (x && GET(fb, pr[1])) x = -x;
+    return x;
+}
+__device__ __forceinline__ u32 read_mv(BD &fb, const uint8_t *__restrict__ data, u32 limit, const uint8_t *mvc)
+{
+    const int r = read_mv_component(fb, data, limit, mvc) * 2;
+    const int c = read_mv_component(fb, data, limit, mvc + 19) * 2;
+    return mv_make(r, c);
+}
+
+__constant__ uint8_t k_mode_contexts[24] = { 7, 1, 1, 143, 14, 18, 14, 107, 135, 64, 57, 68, 60, 56, 128, 65, 159, 134, 128, 34, 234, 188, 128, 28 };
+__constant__ uint8_t k_submv_prob[8][3] = { { 147, 136, 18 }, { 223, 1, 34 }, { 106, 145, 1 }, { 208, 1, 1 },
+                                            { 179, 121, 1 }, { 223, 1, 34 }, { 179, 121, 1 }, { 208, 1, 1 } };       // vp8_sub_mv_ref_prob3
+
+// One macroblock of an inter frame.  above / left / aboveleft: the neighbours' records; mvs: the lane's sixteen block vectors in
+// LDS (out: what the macroblock's blocks use, vp8ir_mv order).  Returns the modes; `self` = the record for the neighbours to come
+// (bmv as the macroblock's own sixteen say: the caller picks the side).
+__device__ __forceinline__ MbModes read_mb_modes_inter(BD &fb, const uint8_t *__restrict__ data, u32 limit, const ModeParams &P,
+                                                       const InterParams &I, const Nb &above, const Nb &left, const Nb &aboveleft,
+                                                       int mb_row, int mb_col, int rows, int cols, u32 *mvs, Nb &self)
+{
+    MbModes m;
+    m.bm = 0; m.clamp = 0; m.part = 0; m.uvmode = VP8IR_DC_PRED;
+    m.seg = 0;
+    if (P.seg_map) m.seg = GET(fb, P.tp0) ? 2 + GET(fb, P.tp2) : GET(fb, P.tp1);
+    m.skip = P.has_skip ? GET(fb, P.p_skip) : 0;
+    u32 mv = 0;
+    m.ref = GET(fb, I.p_intra);
+    if (m.ref) {
+        if (GET(fb, I.p_last)) m.ref = 2 + GET(fb, I.p_gf);
+        const u32 my_bias = (I.sign_bias >> m.ref) & 1u;
+        u32 near[4] = { 0, 0, 0, 0 };
+        int cnt[4] = { 0, 0, 0, 0 };
+        int n = 0;                                  // the most recently added candidate: near[n], cnt[n]
+        // (near / cnt indexed by n: four entries, selects)
+#define NEAR_SET(i, v) do { near[0] = (i) == 0 ? (v) : near[0]; near[1] = (i) == 1 ? (v) : near[1]; near[2] = (i) == 2 ? (v) : near[2]; near[3] = (i) == 3 ? (v) : near[3]; } while (0)
+#define NEAR_GET(i) ((i) == 0 ? near[0] : (i) == 1 ? near[1] : (i) == 2 ? near[2] : near[3])
+#define CNT_ADD(i, v) do { cnt[0] += (i) == 0 ? (v) : 0; cnt[1] += (i) == 1 ? (v) : 0; cnt[2] += (i) == 2 ? (v) : 0; cnt[3] += (i) == 3 ? (v) : 0; } while (0)
+        if (above.ref != VP8IR_INTRA_FRAME) {
+            if (above.mv) {
+                const u32 t = ((I.sign_bias >> above.ref) & 1u) != my_bias ? mv_neg(above.mv) : above.mv;
+                n++; NEAR_SET(n, t);
+            }
+            CNT_ADD(n, 2);
+        }
+        if (left.ref != VP8IR_INTRA_FRAME) {
+            if (left.mv) {
+                const u32 t = ((I.sign_bias >> left.ref) & 1u) != my_bias ? mv_neg(left.mv) : left.mv;
+                if (t != NEAR_GET(n)) { n++; NEAR_SET(n, t); }
+                CNT_ADD(n, 2);
+            } else
+                cnt[0] += 2;
+        }
+        if (aboveleft.ref != VP8IR_INTRA_FRAME) {
+            if (aboveleft.mv) {
+                const u32 t = ((I.sign_bias >> aboveleft.ref) & 1u) != my_bias ? mv_neg(aboveleft.mv) : aboveleft.mv;
+                if (t != NEAR_GET(n)) { n++; NEAR_SET(n, t); }
+                CNT_ADD(n, 1);
+            } else
+                cnt[0] += 1;
+        }
+        if (GET(fb, k_mode_contexts[cnt[0] * 4 + 0])) {
+            Edges e;
+            e.left = -((mb_col * 16) << 3) - (16 << 3);
+            e.right = (((cols - 1 - mb_col) * 16) << 3) + (16 << 3);
+            e.top = -((mb_row * 16) << 3) - (16 << 3);
+            e.bottom = (((rows - 1 - mb_row) * 16) << 3) + (16 << 3);
+            // three distinct candidates: the above-left one counts for NEAREST when they are equal
+            if (cnt[3] && NEAR_GET(n) == near[1]) cnt[1] += 1;
+            cnt[3] = ((above.ymode == VP8IR_SPLITMV) + (left.ymode == VP8IR_SPLITMV)) * 2 + (aboveleft.ymode == VP8IR_SPLITMV);
+            if (cnt[2] > cnt[1]) {
+                const int t = cnt[1]; const u32 tm = near[1];
+                cnt[1] = cnt[2]; cnt[2] = t;
+                near[1] = near[2]; near[2] = tm;
+            }
+            if (GET(fb, k_mode_contexts[cnt[1] * 4 + 1])) {
+                if (GET(fb, k_mode_contexts[cnt[2] * 4 + 2])) {
+                    if (cnt[1] >= cnt[0]) near[0] = near[1];
+                    const u32 best = mv_clamp(near[0], e);
+                    if (GET(fb, k_mode_contexts[cnt[3] * 4 + 3])) {
+                        // decode_split_mv (decodemv.c:252-321): 16x8, 8x16, 8x8 or 4x4; a part's vector from its left / above
+                        // neighbours' or new
+                        int sp = 3, nparts = 16;
+                        if (GET(fb, 110)) {
+                            sp = 2; nparts = 4;
+                            if (GET(fb, 111)) { sp = GET(fb, 150); nparts = 2; }
+                        }
+                        for (int j = 0; j < nparts; j++) {
+                            // the part's first block: 16x8 {0, 8}, 8x16 {0, 2}, 8x8 {0, 2, 8, 10}, 4x4 j
+                            const int k = sp == 0 ? 8 * j : sp == 1 ? 2 * j : sp == 2 ? (j & 1) * 2 + (j >> 1) * 8 : j;
+                            const u32 leftmv = (k & 3) ? mvs[k - 1] : left.bmv[k >> 2];
+                            const u32 abovemv = k >= 4 ? mvs[k - 4] : above.bmv[k];
+                            const uint8_t *pr = k_submv_prob[((abovemv == 0) << 2) | ((leftmv == 0) << 1) | (leftmv == abovemv)];
+                            u32 v;
+                            if (!GET(fb, pr[0])) v = leftmv;
+                            else if (!GET(fb, pr[1])) v = abovemv;
+                            else if (!GET(fb, pr[2])) v = 0;
+                            else v = mv_add(read_mv(fb, data, limit, I.mvc), best);
+                            m.clamp |= mv_outside(v, e);
+                            for (int bb = 0; bb < 16; bb++) {
+                                const int part = sp == 0 ? bb >> 3 : sp == 1 ? (bb >> 1) & 1 : sp == 2 ? ((bb >> 3) << 1) | ((bb >> 1) & 1) : bb;
+                                if (part == j) mvs[bb] = v;
+                            }
+                        }
+                        m.part = sp;
+                        mv = mvs[15];
+                        m.ymode = VP8IR_SPLITMV;
+                    } else {
+                        mv = mv_add(read_mv(fb, data, limit, I.mvc), best);
+                        m.clamp = mv_outside(mv, e);
+                        m.ymode = VP8IR_NEWMV;
+                    }
+                } else {
+                    m.ymode = VP8IR_NEARMV;
+                    mv = mv_clamp(near[2], e);
+                }
+            } else {
+                m.ymode = VP8IR_NEARESTMV;
+                mv = mv_clamp(near[1], e);
+            }
+        } else {
+            m.ymode = VP8IR_ZEROMV;
+            mv = 0;
+        }
+#undef NEAR_SET
+#undef NEAR_GET
+#undef CNT_ADD
+        if (m.ymode != VP8IR_SPLITMV)
+            for (int bb = 0; bb < 16; bb++) mvs[bb] = mv;
+    } else {
+        if (!GET(fb, I.ymode[0])) m.ymode = VP8IR_DC_PRED;
+        else if (!GET(fb, I.ymode[1])) m.ymode = GET(fb, I.ymode[2]) ? VP8IR_H_PRED : VP8IR_V_PRED;
+        else m.ymode = GET(fb, I.ymode[3]) ? VP8IR_B_PRED : VP8IR_TM_PRED;
+        if (m.ymode == VP8IR_B_PRED) {
+            Row pr;                                            // the nine fixed probabilities as a row (vp8_bmode_prob defaults)
+            pr.w0 = 120u | 90u << 8 | 79u << 16 | 133u << 24; pr.w1 = 87u | 85u << 8 | 80u << 16 | 111u << 24; pr.w2 = 151u;
+            u64 bm = 0;
+            for (int i = 0; i < 16; i++) bm |= (u64)read_bmode(fb, data, limit, pr) << (4 * i);
+            m.bm = bm;
+        }
+        if (!GET(fb, I.uvmode[0])) m.uvmode = VP8IR_DC_PRED;
+        else if (!GET(fb, I.uvmode[1])) m.uvmode = VP8IR_V_PRED;
+        else m.uvmode = GET(fb, I.uvmode[2]) ? VP8IR_TM_PRED : VP8IR_H_PRED;
+        for (int bb = 0; bb < 16; bb++) mvs[bb] = 0;
+    }
+    self.mv = mv; self.ref = (u32)m.ref; self.ymode = (u32)m.ymode;
     return m;
 }
 
@@ -265,11 +457,11 @@ __device__ __forceinline__ void read_mb_tokens(BD &tb, const uint8_t *__restrict
                                                const row_t *cat, u32 &A, u32 &lnz, u32 *desc, u32 *blk, u32x4 *out_coef, u32x4 *out_mb,
                                                SparseOut &sp)
 {
-    const bool has_y2 = m.ymode != VP8IR_B_PRED;
+    const bool has_y2 = m.ymode != VP8IR_B_PRED && m.ymode != VP8IR_SPLITMV;
     int skip = m.skip;
 #pragma unroll
     for (int i = 0; i < 16; i++) desc[i] = 0;
-    if (!has_y2) {
+    if (m.ymode == VP8IR_B_PRED) {
 #pragma unroll
         for (int w = 0; w < 4; w++) {
             const u32 four = (u32)(m.bm >> (16 * w)) & 0xffffu;  // modes 4w .. 4w+3, a nibble each -> a byte each (descriptor bytes 40..55)
@@ -329,15 +521,15 @@ __device__ __forceinline__ void read_mb_tokens(BD &tb, const uint8_t *__restrict
             for (int w = 2; w < 9; w++) desc[w] = 0;           // (eobs live in bytes 8..32; 33..35 are reserved zeros)
         }
     }
-    desc[0] = (u32)m.ymode | (u32)m.uvmode << 8 | (u32)(skip ? VP8IR_MB_SKIP : 0) << 24;
-    desc[1] = (u32)m.seg;
+    desc[0] = (u32)m.ymode | (u32)m.uvmode << 8 | (u32)m.ref << 16 | (u32)((skip ? VP8IR_MB_SKIP : 0) | (m.clamp ? VP8IR_MB_CLAMP : 0)) << 24;
+    desc[1] = (u32)m.seg | (u32)m.part << 8;
 #pragma unroll
     for (int w = 0; w < 4; w++) out_mb[w] = (u32x4){ desc[4 * w], desc[4 * w + 1], desc[4 * w + 2], desc[4 * w + 3] };
 }
 
 }  // namespace
 
-extern "C" size_t vp8_entropy_lds_bytes(int lpw) { return (size_t)lpw * (ENT_PROB_WORDS + ENT_DESC_WORDS + ENT_BLK_WORDS) * 4; }
+extern "C" size_t vp8_entropy_lds_bytes(int lpw) { return (size_t)lpw * (ENT_PROB_WORDS + ENT_DESC_WORDS + ENT_BLK_WORDS + 17) * 4; }
 
 // frames: `count` of them; frame f goes to the IR slot at slot_base + (first_slot + f) * slot_bytes (descriptors at o_mbs, dense
 // coefficients at o_coef).  lpw: lanes of each wave that carry a frame (1..64).  scratch: per frame (2 * mb_cols + 64) words
@@ -346,7 +538,7 @@ extern "C" size_t vp8_entropy_lds_bytes(int lpw) { return (size_t)lpw * (ENT_PRO
 struct SparseArena { u32x4 *mbs; u32x4 *blocks; short *dcs; u32 *cursors; u32 cap_blocks, cap_dcs; };
 template <bool SPARSE>
 __device__ __forceinline__ void entropy_body(const vp8hip_entropy_frame *__restrict__ frames, int count, int lpw, const uint8_t *__restrict__ all_data,
-                                             DevGeom g, size_t data_bytes, char *slot_base, size_t slot_bytes, size_t o_mbs, size_t o_coef,
+                                             DevGeom g, size_t data_bytes, char *slot_base, size_t slot_bytes, size_t o_mbs, size_t o_coef, size_t o_mvs,
                                              int first_slot, u32 *__restrict__ scratch, u32 *__restrict__ status, const SparseArena &arena)
 {
     // LDS by lanes that carry a frame (the launch says how much: vp8_entropy_lds_bytes): probabilities, descriptor, block
@@ -354,6 +546,7 @@ __device__ __forceinline__ void entropy_body(const vp8hip_entropy_frame *__restr
     row_t *s_probs = (row_t *)s_dyn;
     u32 *s_desc = s_dyn + lpw * ENT_PROB_WORDS;
     u32 *s_blk = s_desc + lpw * ENT_DESC_WORDS;
+    u32 *s_mvs = s_blk + lpw * ENT_BLK_WORDS;           // inter frames: the macroblock's sixteen block vectors (17 words a lane)
     __shared__ row_t s_kfb[100 * 3];                    // kf_bmode_probs, a row per (above, left)
     __shared__ row_t s_cat[6 * 3];
     const int lane = threadIdx.x;
@@ -367,9 +560,11 @@ __device__ __forceinline__ void entropy_body(const vp8hip_entropy_frame *__restr
     if (lane >= lpw || f >= count) return;
     const vp8hip_entropy_frame &F = frames[f];
     const int cols = g.mb_cols, rows = g.mb_rows;
-    u32 *abm = scratch + (size_t)f * (2 * cols + 64);   // the row above: four sub-block modes per macroblock column, a nibble each
+    u32 *abm = scratch + (size_t)f * (8 * cols + 64);   // the row above: four sub-block modes per macroblock column, a nibble each
     u32 *anz = abm + cols;                              // ... and its non-zero flags: bits 0..3 Y, 4..5 U, 6..7 V, 8 Y2
     u32 *tst = anz + cols;                              // token partitions' states: 8 words each
+    u32 *anb = tst + 64;                                // inter frames: the row above's records (Nb), six words a column
+    u32 *mvs = s_mvs + lane * 17;
     row_t *probs = s_probs + lane * ENT_PROB_WORDS;
     u32 *desc = s_desc + lane * ENT_DESC_WORDS;
     u32 *blk = s_blk + lane * ENT_BLK_WORDS;
@@ -380,6 +575,8 @@ __device__ __forceinline__ void entropy_body(const vp8hip_entropy_frame *__restr
         dst[11] = 0;
     }
     for (int c = 0; c < cols; c++) { abm[c] = 0; anz[c] = 0; }         // outside the frame: B_DC_PRED, nothing coded
+    const bool inter = F.hdr.frame_type != 0;
+    if (inter) for (int i = 0; i < 6 * cols; i++) anb[i] = 0;          // ... intra, no vector
     // positions are relative to the frame's first byte; what may be read: to the end of the launch's data (followed by padding)
     const uint8_t *__restrict__ data = all_data + F.data_off;
     const u32 limit = data_bytes - F.data_off < 0xfffffff0ull ? (u32)(data_bytes - F.data_off) : 0xfffffff0u;
@@ -401,6 +598,10 @@ __device__ __forceinline__ void entropy_body(const vp8hip_entropy_frame *__restr
     char *slot = slot_base + slot_bytes * (size_t)(first_slot + f);
     u32x4 *out_mbs = SPARSE ? arena.mbs + (size_t)f * cols * rows * 4 : (u32x4 *)(slot + o_mbs);
     u32x4 *out_coef = (u32x4 *)(slot + o_coef);
+    u32x4 *out_mvs = (u32x4 *)(slot + o_mvs);
+    const InterParams IP = { F.prob_intra, F.prob_last, F.prob_gf, { F.ymode_prob[0], F.ymode_prob[1], F.ymode_prob[2], F.ymode_prob[3] },
+                             { F.uvmode_prob[0], F.uvmode_prob[1], F.uvmode_prob[2] },
+                             (u32)F.hdr.sign_bias_golden << VP8IR_GOLDEN_FRAME | (u32)F.hdr.sign_bias_alt << VP8IR_ALTREF_FRAME, &F.mvc[0][0] };
     SparseOut sp = { arena.blocks, arena.dcs, arena.cursors, arena.cap_blocks, arena.cap_dcs, 0, 0, 0, 0 };
     bool bad = false;
 
@@ -416,11 +617,26 @@ __device__ __forceinline__ void entropy_body(const vp8hip_entropy_frame *__restr
             else { tb.n01 = t[6] >> 8; tb.n2 = t[6] & 255u; tb.pos = t[3]; }
         }
         u32 lbm = 0, lnz = 0;                                          // left of the row: B_DC_PRED, nothing coded
+        Nb left = { 0, { 0, 0, 0, 0 }, 0, 0 }, aboveleft = { 0, { 0, 0, 0, 0 }, 0, 0 };
         for (int c = 0; c < cols; c++) {
             const long n = (long)r * cols + c;
-            u32 above = abm[c];
-            const MbModes m = read_mb_modes(fb, data, limit, MP, s_kfb, above, lbm);
-            abm[c] = above;
+            MbModes m;
+            if (inter) {
+                Nb above, self;
+                u32 *a6 = anb + 6 * c;
+                above.mv = a6[0]; above.bmv[0] = a6[1]; above.bmv[1] = a6[2]; above.bmv[2] = a6[3]; above.bmv[3] = a6[4];
+                above.ref = a6[5] & 255u; above.ymode = a6[5] >> 8;
+                m = read_mb_modes_inter(fb, data, limit, MP, IP, above, left, aboveleft, r, c, rows, cols, mvs, self);
+                a6[0] = self.mv; a6[1] = mvs[12]; a6[2] = mvs[13]; a6[3] = mvs[14]; a6[4] = mvs[15]; a6[5] = self.ref | self.ymode << 8;
+                aboveleft = above;
+                left = self; left.bmv[0] = mvs[3]; left.bmv[1] = mvs[7]; left.bmv[2] = mvs[11]; left.bmv[3] = mvs[15];
+#pragma unroll
+                for (int w = 0; w < 4; w++) out_mvs[n * 4 + w] = (u32x4){ mvs[4 * w], mvs[4 * w + 1], mvs[4 * w + 2], mvs[4 * w + 3] };
+            } else {
+                u32 above = abm[c];
+                m = read_mb_modes(fb, data, limit, MP, s_kfb, above, lbm);
+                abm[c] = above;
+            }
             u32 A = anz[c];
             read_mb_tokens<SPARSE>(tb, data, limit, m, probs, s_cat, A, lnz, desc, blk, out_coef + n * 50, out_mbs + n * 4, sp);
             anz[c] = A;
@@ -444,11 +660,11 @@ __device__ __forceinline__ void entropy_body(const vp8hip_entropy_frame *__restr
 
 extern "C" __global__ void __launch_bounds__(64)
 vp8_entropy_kernel(const vp8hip_entropy_frame *__restrict__ frames, int count, int lpw, const uint8_t *__restrict__ all_data, DevGeom g,
-                   size_t data_bytes, char *slot_base, size_t slot_bytes, size_t o_mbs, size_t o_coef, int first_slot,
+                   size_t data_bytes, char *slot_base, size_t slot_bytes, size_t o_mbs, size_t o_coef, size_t o_mvs, int first_slot,
                    u32 *__restrict__ scratch, u32 *__restrict__ status)
 {
     const SparseArena none = { nullptr, nullptr, nullptr, nullptr, 0, 0 };
-    entropy_body<false>(frames, count, lpw, all_data, g, data_bytes, slot_base, slot_bytes, o_mbs, o_coef, first_slot, scratch, status, none);
+    entropy_body<false>(frames, count, lpw, all_data, g, data_bytes, slot_base, slot_bytes, o_mbs, o_coef, o_mvs, first_slot, scratch, status, none);
 }
 
 // The same into the sparse streams (descriptors: mbs, frame after frame; blocks / dcs: the launch's arenas; cursors: three words,
@@ -459,7 +675,7 @@ vp8_entropy_sparse_kernel(const vp8hip_entropy_frame *__restrict__ frames, int c
                           u32 *cursors, u32 cap_blocks, u32 cap_dcs)
 {
     const SparseArena arena = { mbs, blocks, dcs, cursors, cap_blocks, cap_dcs };
-    entropy_body<true>(frames, count, lpw, all_data, g, data_bytes, nullptr, 0, 0, 0, 0, scratch, status, arena);
+    entropy_body<true>(frames, count, lpw, all_data, g, data_bytes, nullptr, 0, 0, 0, 0, 0, scratch, status, arena);
 }
 
 // Frames coded with several token partitions (2, 4 or 8: the encoder's --token-parts; macroblock row r is in partition r mod NP,
@@ -568,6 +784,7 @@ vp8_entropy_parts_kernel(const vp8hip_entropy_frame *__restrict__ frames, int co
             const u32 m0 = mo[0];
             MbModes m;
             m.ymode = (int)(m0 & 255u); m.uvmode = (int)(m0 >> 8 & 255u); m.seg = (int)(m0 >> 16 & 255u); m.skip = (int)(m0 >> 24);
+            m.ref = VP8IR_INTRA_FRAME; m.clamp = 0; m.part = 0;
             m.bm = (u64)mo[1] | (u64)mo[2] << 32;
             SparseOut none = { nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, 0 };
             read_mb_tokens<false>(tb, data, limit, m, probs, s_cat, A, lnz, desc, blk, out_coef + n * 50, out_mbs + n * 4, none);

@@ -29,7 +29,7 @@ extern "C" __global__ void vp8_interframe_kernel(const DevJob *jobs, int njobs, 
                                                unsigned int *sched, int nwaves);
 extern "C" __global__ void vp8_inter_pred_kernel(const DevJob *jobs, int njobs, DevGeom g, int upf);
 extern "C" __global__ void vp8_entropy_kernel(const vp8hip_entropy_frame *frames, int count, int lpw, const uint8_t *data, DevGeom g,
-                                              size_t data_bytes, char *slot_base, size_t slot_bytes, size_t o_mbs, size_t o_coef,
+                                              size_t data_bytes, char *slot_base, size_t slot_bytes, size_t o_mbs, size_t o_coef, size_t o_mvs,
                                               int first_slot, unsigned int *scratch, unsigned int *status);
 extern "C" size_t vp8_entropy_lds_bytes(int lpw);
 typedef unsigned int ent_u32x4 __attribute__((ext_vector_type(4)));
@@ -1335,12 +1335,16 @@ static int entropy_launch(vp8hip_ctx *c, int first_slot, int count, const vp8hip
                           size_t blocks_cap, size_t dcs_cap)
 {
     const bool sparse = first_slot < 0;
+    bool any_inter = false;
     if (!c || !frames || !data || count < 1 || (!sparse && first_slot + count > (int)c->slots.size()))
         return fail(c, -2, "vp8hip_entropy_decode: bad arguments");
     for (int i = 0; i < count; i++) {
         const vp8hip_entropy_frame &f = frames[i];
         const vp8ir_frame_hdr &h = f.hdr;
-        if (h.frame_type != 0) return fail(c, -2, "vp8hip_entropy_decode: frame %d is not a key frame", i);
+        if (h.frame_type != 0) {
+            any_inter = true;
+            if (sparse) return fail(c, -2, "vp8hip_entropy_decode_sparse: frame %d is not a key frame", i);
+        }
         if (h.mb_cols != c->dg.mb_cols || h.mb_rows != c->dg.mb_rows)
             return fail(c, -2, "vp8hip_entropy_decode: frame %d is %dx%d MBs, context configured for %dx%d", i, h.mb_cols, h.mb_rows,
                         c->dg.mb_cols, c->dg.mb_rows);
@@ -1357,8 +1361,8 @@ static int entropy_launch(vp8hip_ctx *c, int first_slot, int count, const vp8hip
     for (int i = 1; i < count && np > 1; i++) if ((int)frames[i].num_tok != np) np = 1;
     // (the lanes of a frame follow each other a macroblock apart and lane 0 follows the last one into the next round of rows: rows
     // at least as long as the partitions are many; the row above's flags of a wave's frames in 16 KB of LDS)
-    if (c->dg.mb_cols < np || c->dg.mb_cols > 256 || c->dg.mb_cols * (64 / np) > 4096 || c->ent_parts_off || sparse) np = 1;
-    const size_t swords = np > 1 ? (size_t)count * ((size_t)c->dg.mb_cols + 3 * (size_t)c->nmb) : (size_t)count * (2 * (size_t)c->dg.mb_cols + 64);
+    if (c->dg.mb_cols < np || c->dg.mb_cols > 256 || c->dg.mb_cols * (64 / np) > 4096 || c->ent_parts_off || sparse || any_inter) np = 1;
+    const size_t swords = np > 1 ? (size_t)count * ((size_t)c->dg.mb_cols + 3 * (size_t)c->nmb) : (size_t)count * (8 * (size_t)c->dg.mb_cols + 64);
     if (fbytes > c->ent_frames_cap) {
         HIPCHK(c, hipStreamSynchronize(c->stream));
         if (c->d_ent_frames) (void)hipFree(c->d_ent_frames);
@@ -1438,7 +1442,7 @@ static int entropy_launch(vp8hip_ctx *c, int first_slot, int count, const vp8hip
     else
     hipLaunchKernelGGL(vp8_entropy_kernel, dim3((unsigned)((count + lpw - 1) / lpw)), dim3(64), vp8_entropy_lds_bytes(lpw), c->stream,
                        (const vp8hip_entropy_frame *)c->d_ent_frames, count, lpw, (const uint8_t *)c->d_ent_data, c->dg, data_bytes, c->slot_block_dev,
-                       c->slot_bytes, c->o_mbs, c->o_coef, first_slot, c->d_ent_scratch, c->d_ent_status);
+                       c->slot_bytes, c->o_mbs, c->o_coef, c->o_mvs, first_slot, c->d_ent_scratch, c->d_ent_status);
     HIPCHK(c, hipGetLastError());
     return 0;
 }
@@ -1516,6 +1520,15 @@ extern "C" int vp8hip_entropy_status(vp8hip_ctx *c, int count, uint32_t *status)
         HIPCHK(c, hipMemcpy(cur, c->d_sp_cursors, 16, hipMemcpyDeviceToHost));
         if (cur[2]) for (int i = 0; i < count; i++) status[i] |= 2u;
     }
+    return 0;
+}
+
+extern "C" int vp8hip_ir_fetch_mvs(vp8hip_ctx *c, int slot, vp8ir_mv *mvs)
+{
+    if (!c || !mvs || slot < 0 || slot >= (int)c->slots.size()) return fail(c, -2, "vp8hip_ir_fetch_mvs: bad slot %d", slot);
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(mvs, c->slots[slot].d_mvs, (size_t)c->nmb * 16 * sizeof(vp8ir_mv), hipMemcpyDeviceToHost));
     return 0;
 }
 

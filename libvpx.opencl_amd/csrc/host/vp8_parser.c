@@ -79,6 +79,7 @@ struct vp8_parser {
     vp8_boolreader tok[8];       /* token partitions */
     const uint8_t *tok_start[8]; /* ... where each begins (vp8_parser_export_entropy) */
     const uint8_t *frame_data;   /* the frame, when it came as one buffer */
+    int segmap_stale;            /* the last frame's macroblocks were decoded elsewhere (vp8_parser_export_entropy) */
     int num_tok;
     int frame_open;
 
@@ -526,8 +527,9 @@ int vp8_parser_export_entropy(vp8_parser *p, vp8hip_entropy_frame *out)
     const vp8_boolreader *br = &p->first;
     int i, bits, back;
     if (!p->frame_open) return fail(p, VP8P_ERROR, "export_entropy without begin_frame");
-    if (p->hdr.frame_type != 0 || !p->frame_data || p->ec_enabled) {      /* (the frame stays open) */
-        snprintf(p->err, sizeof p->err, "%s", "the device decodes key frames given as one buffer, without concealment");
+    if (!p->frame_data || p->ec_enabled ||
+        (p->hdr.frame_type != 0 && p->segmentation_enabled && !p->update_mb_segmentation_map)) {      /* (the frame stays open) */
+        snprintf(p->err, sizeof p->err, "%s", "one buffer, no concealment, a segment map of its own: or the device cannot decode it");
         return VP8P_UNSUP_BITSTREAM;
     }
     if (br->zero_fill || p->corrupted) return fail(p, VP8P_CORRUPT_FRAME, "the frame header ran past the end of the data");
@@ -553,13 +555,19 @@ int vp8_parser_export_entropy(vp8_parser *p, vp8hip_entropy_frame *out)
     out->prob_skip_false = p->prob_skip_false;
     memcpy(out->segment_tree_probs, p->segment_tree_probs, 3);
     memcpy(out->coef_probs, p->fc.coef, 1056);
-    /* the frame is over for the parser (what vp8_parser_decode_mbs does at its end); the macroblocks' modes never came by here,
-       so nothing that leans on them -- an inter frame -- may follow before the next key frame decoded on the host */
+    out->prob_intra = p->prob_intra; out->prob_last = p->prob_last; out->prob_gf = p->prob_gf;
+    memcpy(out->ymode_prob, p->fc.ymode, 4);
+    memcpy(out->uvmode_prob, p->fc.uvmode, 3);
+    memcpy(out->mvc, p->fc.mvc, 38);
+    /* the frame is over for the parser (what vp8_parser_decode_mbs does at its end).  The macroblocks' modes never came by here;
+       the one thing a later frame takes from them is the segment map when it does not bring its own: such a frame is refused
+       until a frame decoded on the host has brought one (segmap_stale) */
     if (p->restore_probs) {
         p->fc = p->saved_fc;
         p->independent_partitions = p->prev_independent;
     }
-    p->have_key_frame = 0;
+    if (p->hdr.frame_type == 0) p->have_key_frame = 1;
+    p->segmap_stale = 1;
     p->frame_open = 0;
     return VP8P_OK;
 }
@@ -1181,6 +1189,9 @@ static int decode_mbs(vp8_parser *p, vp8ir_mb *mbs, int16_t *coef, int16_t *bloc
     is_key = p->hdr.frame_type == 0;
     if (!is_key && !mvs)
         return fail(p, VP8P_INVALID_PARAM, "inter frame needs an mv array");
+    if (p->segmap_stale && !is_key && p->segmentation_enabled && !p->update_mb_segmentation_map)
+        return fail(p, VP8P_UNSUP_BITSTREAM, "the segment map this frame keeps belongs to a frame that was decoded on the device");
+    if (is_key || !p->segmentation_enabled || p->update_mb_segmentation_map) p->segmap_stale = 0;
 
     read_modes(p);
     bad |= vp8br_error(&p->first) | p->corrupted;

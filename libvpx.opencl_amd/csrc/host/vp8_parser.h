@@ -83,9 +83,11 @@ int vp8_parser_decode_mbs_sparse(vp8_parser *p, vp8ir_mb *mbs, int16_t *blocks, 
 
 /* Step 2 on the device (include/vp8hip.h: vp8hip_entropy_decode): instead of decoding the macroblocks, hand over what the
  * frame header left behind -- the first partition's decoder state at the first macroblock, the token partitions' extents (all
- * relative to the start of the buffer begin_frame was given), the probabilities.  Key frames given as one buffer, without
- * concealment (VP8P_UNSUP_BITSTREAM otherwise, and the frame stays open for vp8_parser_decode_mbs); a frame whose header ran
- * past its data is VP8P_CORRUPT_FRAME.  Closes the frame; the next frame has to be a key frame. */
+ * relative to the start of the buffer begin_frame was given), the probabilities.  Frames given as one buffer, without
+ * concealment, and -- inter frames -- bringing their segment map if segmentation is on (VP8P_UNSUP_BITSTREAM otherwise, and the
+ * frame stays open for vp8_parser_decode_mbs); a frame whose header ran past its data is VP8P_CORRUPT_FRAME.  Closes the frame.
+ * The frame header is all the parser needs of a frame to go on to the next, with one exception: an inter frame that keeps the
+ * segment map of a frame decoded this way is refused, by this call and by vp8_parser_decode_mbs. */
 int vp8_parser_export_entropy(vp8_parser *p, vp8hip_entropy_frame *out);
 
 const char *vp8_parser_error(const vp8_parser *p);

@@ -102,24 +102,22 @@ def test_exported_state_continues_into_the_modes(name):
     ph.close(); pd.close()
 
 
-def test_export_refuses_what_the_device_does_not_decode():
+def test_export_goes_through_a_stream_and_refuses_what_the_device_does_not_decode():
     P = load_package()
     _, _, frames = P.read_ivf(ivf_path("p_lowrate_640x360"))
     p = P.Parser()
-    hdr, _ = p.begin(frames[0])
-    ef = p.export_entropy()
-    assert ef is not None                     # the key frame
-    p.swap(hdr)
-    with pytest.raises(ValueError):           # ... after which the parser has no modes to predict an inter frame's from
-        p.begin(frames[1])
+    for i, data in enumerate(frames[:4]):        # key frame, then inter frames: only the headers are read here
+        hdr, _ = p.begin(data)
+        ef = p.export_entropy()
+        assert ef is not None and ef.hdr.frame_type == (0 if i == 0 else 1)
+        if i:
+            assert ef.prob_intra and bytes(ef.mvc) != bytes(38) and bytes(ef.ymode_prob) != bytes(4)
+        p.swap(hdr)
     p.close()
-    p = P.Parser()
-    for data in frames[:2]:
-        hdr, _, _, _, _ = P.parse_to_numpy(p, data) if data is frames[0] else (None,) * 5
-        if hdr is not None:
-            p.swap(hdr)
-    hdr, _ = p.begin(frames[1])
-    assert p.export_entropy() is None         # an inter frame: stays open for the host feeder
+    p = P.Parser()                               # with concealment the frames stay with the host feeder
+    p.set_error_concealment(True)
+    hdr, _ = p.begin(frames[0])
+    assert p.export_entropy() is None
     n = hdr.mb_cols * hdr.mb_rows
     mbs, coef, mvs = np.zeros((n, 64), np.uint8), np.zeros((n, 400), np.int16), np.zeros((n, 16, 2), np.int16)
     p.decode_mbs(mbs.ctypes.data, coef.ctypes.data, mvs.ctypes.data)

@@ -202,3 +202,50 @@ def test_sparse_form_through_the_arenas(name):
     assert all(int(x) & 2 for x in st) or name == "kf_odd_67x45"
     assert not ctx.entropy_decode(0, efs, frames, sparse_caps=(0, 0)).any()  # ... and the next launch is fine again
     ctx.close()
+
+
+INTER_STREAMS = ["p_lowrate_640x360", "p_odd_130x98", "p_sharp_320x240", "p_split_352x288", "p_arf_176x144", "p_prof1_640x360", "p_prof3_640x360",
+                 "p_1920x1080", "p_dense_1920x1080"]
+
+
+@pytest.mark.parametrize("name", INTER_STREAMS)
+def test_inter_frames(name):
+    """Inter frames: reference frame, near / nearest / new / split vectors with their above, left and above-left candidates
+    (decodemv.c:323-569), intra macroblocks among them, golden / alt-ref with sign bias, bilinear and full-pixel versions -- a
+    whole stream with only the frame headers read on the host: every frame's IR (descriptors, coefficients, sixteen vectors per
+    macroblock) is the host feeder's, and the frames decode to the reference's MD5s."""
+    P = load_package()
+    w, h, frames = P.read_ivf(ivf_path(name))
+    frames = frames[:24]
+    ph, pd = P.Parser(), P.Parser()
+    ctx = P.Vp8Hip()
+    ctx.configure(w, h, 4, 1)
+    gold = golden_md5(name)
+    shown = 0
+    n_inter = 0
+    for i, data in enumerate(frames):
+        hdr, _, mbs, coef, mvs = P.parse_to_numpy(ph, data)
+        ph.swap(hdr)
+        h2, _ = pd.begin(data)
+        ef = pd.export_entropy()
+        if ef is None:                       # (an inter frame that keeps a segment map: the host feeder's)
+            pytest.skip("stream keeps segment maps across frames")
+        assert not ctx.entropy_decode(0, [ef], [data]).any()
+        dm, dc = ctx.ir_fetch(0)
+        bad = np.nonzero((dm != mbs).any(axis=1))[0]
+        assert bad.size == 0, (name, i, "descriptor", int(bad[0]), dm[bad[0]].tolist(), mbs[bad[0]].tolist())
+        coded = (mbs[:, 3] & 1) == 0
+        assert (dc[coded] == coef[coded]).all(), (name, i, "coefficients")
+        r = pd.refs
+        if hdr.frame_type:
+            n_inter += 1
+            dv = ctx.mvs_fetch(0)
+            badv = np.nonzero((dv != mvs.reshape(dv.shape)).any(axis=1))[0]
+            assert badv.size == 0, (name, i, "vectors", int(badv[0]), dv[badv[0]].tolist(), mvs.reshape(dv.shape)[badv[0]].tolist())
+        ctx.decode([(0, r.new_idx, (r.lst_idx, r.gld_idx, r.alt_idx))], P.STAGE_ALL)
+        pd.swap(h2)
+        if hdr.show_frame:
+            assert P.planes_md5(*ctx.download_planes(pd.refs.show_idx)) == gold[shown], (name, i)
+            shown += 1
+    assert n_inter > 0
+    ph.close(); pd.close(); ctx.close()
