@@ -249,3 +249,14 @@ def test_inter_frames(name):
             shown += 1
     assert n_inter > 0
     ph.close(); pd.close(); ctx.close()
+
+
+@pytest.mark.parametrize("name,mode", [("p_lowrate_640x360", "device"), ("p_arf_176x144", "device"), ("p_lowrate_640x360", "host")])
+def test_streams_side_by_side(name, mode):
+    """tools/streams_probe.py: several copies of an inter-frame stream, a launch per position (golden / alt-ref bookkeeping shared,
+    four frame buffers per stream), every shown frame of every stream against the reference's listing."""
+    import os, subprocess, sys
+    from vp8_testlib import ROOT
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "streams_probe.py"), "5", name, mode], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "digests differing from the reference's: 0" in r.stdout, r.stdout
