@@ -221,6 +221,21 @@ def batch_md5_probe(fixture, device, loops=205, extra=()):
             "md5_mismatches": bad}
 
 
+def streams_probe(device, streams=1024, fixture="p_1920x1080"):
+    """Inter-frame streams side by side with the entropy decoder on the device (tools/streams_probe.py): `streams` copies of the
+    fixture (a key frame and nine P frames), a launch per position, only the frame headers read on the host; every shown frame of
+    every stream hashed on the device and compared with the reference decoder's listing."""
+    import re
+    env = dict(os.environ, VP8HIP_DEVICE=str(device))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "streams_probe.py"), str(streams), fixture, "device"], capture_output=True,
+                       text=True, env=env, timeout=300)
+    m = re.search(r"(\d+) frames each, entropy decode on the device: ([0-9.]+) s = (\d+) frames/s = ([0-9.]+) Gpix/s.*differing from the reference's: (\d+)", r.stdout)
+    if r.returncode or not m:
+        return {"error": (r.stderr or r.stdout)[-300:]}
+    return {"tool": "tools/streams_probe.py %d %s device" % (streams, fixture), "streams": streams, "frames_per_stream": int(m.group(1)),
+            "seconds": float(m.group(2)), "frames_per_s": int(m.group(3)), "Mpix_s": round(float(m.group(4)) * 1e3, 1), "md5_mismatches": int(m.group(5))}
+
+
 def load_stream(P, ctx, fixture, F, lo):
     """Slots 0 .. F-1 of `ctx` <- frames lo .. lo+F-1 of the looped stream (frame i of the stream is source frame i mod nsrc;
     every key frame is independently decodable).  Host feeder once per source frame, device-to-device copies for the rest."""
@@ -569,6 +584,7 @@ def main():
                     fixture, local_rank, 4096, ("--device-entropy", "--batch", "4096"))
                 out["config"]["end_to_end"]["device_entropy_frames_stay"] = batch_md5_probe(
                     fixture, local_rank, 4096, ("--device-entropy", "--no-download", "--batch", "8192"))
+                out["config"]["end_to_end"]["inter_streams_device_entropy"] = streams_probe(local_rank)
             except Exception as ex:      # a probe, not the benchmark: report, do not fail the line
                 out["config"]["end_to_end"] = {"error": repr(ex)}
         if not args.no_cpu_baseline and world == 1:      # the contract: rank 0 at N = 1 only
