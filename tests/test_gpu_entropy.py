@@ -260,3 +260,63 @@ def test_streams_side_by_side(name, mode):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "streams_probe.py"), "5", name, mode], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "digests differing from the reference's: 0" in r.stdout, r.stdout
+
+
+@pytest.mark.parametrize("name,index", [("kf_640x360", 1), ("p_lowrate_640x360", 3), ("p_split_352x288", 5)])
+def test_damaged_payloads(name, index):
+    """Random damage behind the frame header (bytes overwritten, bytes flipped, the tail cut): whatever the bits then say -- modes,
+    vectors, runs of large coefficients, partitions that end early -- the device reads what the host feeder reads: same IR, same
+    vectors, same corrupt flag, all frames of the launch side by side."""
+    P = load_package()
+    w, h, frames = P.read_ivf(ivf_path(name))
+    rng = np.random.default_rng(index * 17 + len(name))
+    good = frames[index]
+    variants = []
+    for v in range(24):
+        d = bytearray(good)
+        lo = 64 + int(rng.integers(0, 64))                      # (past the frame header and the start of the first partition)
+        kind = v % 3
+        if kind == 0:
+            for _ in range(1 + v // 3):
+                at = int(rng.integers(lo, len(d)))
+                d[at] ^= 1 << int(rng.integers(0, 8))
+        elif kind == 1:
+            at = int(rng.integers(lo, len(d) - 16))
+            d[at:at + 16] = bytes(rng.integers(0, 256, size=16).astype(np.uint8))
+        else:
+            d = d[:int(rng.integers(len(d) // 2, len(d)))]
+        variants.append(bytes(d))
+    host, efs, kept = [], [], []
+    for v in variants:
+        ph, pd = P.Parser(), P.Parser()
+        try:
+            for data in frames[:index]:                         # the frames before, as they are (state of the header parse)
+                hh, _, _, _, _ = P.parse_to_numpy(ph, data); ph.swap(hh)
+                hd, _ = pd.begin(data); assert pd.export_entropy() is not None; pd.swap(hd)
+            try:
+                hd, _ = pd.begin(v)
+                ef = pd.export_entropy()
+            except ValueError:
+                continue                                        # the header itself refuses the frame: nothing to compare
+            if ef is None:
+                continue
+            hh, _ = ph.begin(v)
+            n = hh.mb_cols * hh.mb_rows
+            mbs, coef, mvs = np.zeros((n, 64), np.uint8), np.zeros((n, 400), np.int16), np.zeros((n, 16, 2), np.int16)
+            try:
+                corrupt = ph.decode_mbs(mbs.ctypes.data, coef.ctypes.data, mvs.ctypes.data)
+            except ValueError:
+                continue
+            host.append((hh, mbs, coef, mvs, corrupt)); efs.append(ef); kept.append(v)
+        finally:
+            ph.close(); pd.close()
+    assert len(kept) >= 12
+    ctx = P.Vp8Hip()
+    ctx.configure(w, h, 1, len(kept))
+    st = ctx.entropy_decode(0, efs, kept)
+    assert [int(s) & 1 for s in st] == [int(bool(c)) for *_, c in host]
+    for i, (hh, mbs, coef, mvs, _) in enumerate(host):
+        _compare(ctx, i, mbs, coef, (name, i))
+        if hh.frame_type:
+            assert (ctx.mvs_fetch(i) == mvs.reshape(-1, 2)).all(), (name, i)
+    ctx.close()
