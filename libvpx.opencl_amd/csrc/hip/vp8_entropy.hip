@@ -1,24 +1,29 @@
-// Entropy decoding of key frames on the device, one frame per LANE (gfx950).
+// Entropy decoding on the device, one frame per LANE (gfx950): the macroblocks' modes, motion vectors and coefficient tokens of
+// key and inter frames.
 //
 // What it replaces: the per-macroblock half of the reference's CPU front end -- vp8_kfread_modes (vp8/decoder/decodemv.c:50-173:
-// segment id, skip flag, intra modes with the sub-block modes' above / left contexts) and vp8_decode_mb_tokens
-// (vp8/decoder/detokenize.c:183-405: the coefficient token tree over the bool decoder of vp8/decoder/dboolhuff.h:76-120) as
-// decode_mb_row drives them (vp8/decoder/decodframe.c:293-470: left / above entropy contexts, vp8_reset_mb_tokens_context for
-// skipped macroblocks, eobtotal == 0 turning a macroblock into a skipped one, token partitions taken round robin by macroblock
-// row).  In this repository the same work is csrc/host/vp8_parser.c's read_modes / decode_row, at ~10 ms per 1080p frame and
-// host core; what the kernel writes into a frame's IR slot -- descriptors and dense coefficients, include/vp8_ir.h -- is byte
-// for byte what vp8_parser_decode_mbs writes (tests/test_gpu_entropy.py).
+// segment id, skip flag, intra modes with the sub-block modes' above / left contexts), read_mb_modes for inter frames
+// (decodemv.c:323-569: reference frame, the near / nearest candidates of vp8_find_near_mvs, NEWMV and SPLITMV vectors) and
+// vp8_decode_mb_tokens (vp8/decoder/detokenize.c:183-405: the coefficient token tree over the bool decoder of
+// vp8/decoder/dboolhuff.h:76-120) as decode_mb_row drives them (vp8/decoder/decodframe.c:293-470: left / above entropy contexts,
+// vp8_reset_mb_tokens_context for skipped macroblocks, eobtotal == 0 turning a macroblock into a skipped one, token partitions
+// taken round robin by macroblock row).  In this repository the same work is csrc/host/vp8_parser.c's read_modes / decode_row,
+// at ~10 ms per 1080p key frame and host core; what the kernels write into a frame's IR slot -- descriptors, coefficients,
+// vectors: include/vp8_ir.h -- is byte for byte what vp8_parser_decode_mbs writes (tests/test_gpu_entropy.py).  The frame header
+// stays on the host (csrc/host/vp8_parser.h: vp8_parser_export_entropy).
 //
 // A bool decoder is a serial machine: every decision needs range and window as the decision before left them.  So there is
 // nothing to spread over lanes inside a partition, and a frame is one lane's work from its first macroblock to its last (the
 // partitions of a frame with several are taken in macroblock-row order, as the reference's single thread takes them: the
-// contexts of a row come from the row above, which belongs to another partition).  The frames of a batch run side by side.
-// What decides the rate is the length of the dependent instruction chain per decision and how many different paths through
-// the token tree the lanes of a wave are on at once, so: 32-bit window (a 64-bit one is two instructions per shift), the next
-// three bytes of the partition requested when the three before are taken (the request has ~25 decisions to land), the frame's
-// 1056 coefficient probabilities in LDS (a row of 1060 bytes per lane: consecutive lanes on different banks), the macroblock
-// descriptor and the block being decoded assembled in LDS and written out whole (16-byte stores), and a launch parameter for
-// how many lanes of a wave carry frames (fewer lanes: fewer paths per wave, more waves).  Integer only; no MFMA.
+// contexts of a row come from the row above, which belongs to another partition; vp8_entropy_parts_kernel gives each partition
+// a lane instead, the lanes a macroblock behind each other).  The frames of a batch run side by side.  A lone wave issues a
+// dependent instruction every ~7 cycles, so a lane's speed is its instruction count per decision:
+// 32-bit window (a 64-bit one is two instructions per shift), the next three bytes of the partition requested when the three
+// before are taken (the request has ~25 decisions to land), probabilities in LDS in rows of 12 bytes read as three words when a
+// row is entered (per-lane tables 289 words apart: consecutive lanes on different banks), the macroblock descriptor and the
+// block being decoded assembled in LDS and written out whole (16-byte stores), and a launch parameter for how many lanes of a
+// wave carry frames.  Two forms of output: the dense IR in the frame's slot, the sparse streams in arenas shared by the launch
+// (vp8_entropy_sparse_kernel: more frames in flight for the same memory).  Integer only; no MFMA.
 #include "vp8_common.hip.h"
 #include "vp8hip.h"
 
