@@ -129,6 +129,9 @@ FIXTURES = {
     # decode of the feeder is for
     "kf_8part_1920x1080": (1920, 1080, 3, 81, 6, ALLKEY + ["--good", "--cpu-used=5", "--end-usage=cq", "--cq-level=20",
                                                              "--target-bitrate=20000", "--token-parts=3"]),
+    # segmentation in inter frames: the real-time encoder's cyclic refresh (error-resilient mode) codes a segment map with every
+    # frame -- per-segment quantisers and loop-filter levels, the map's tree in the first partition of inter frames
+    "p_seg_176x144": (176, 144, 30, 77, 4, INTER + ["--rt", "--error-resilient=1", "--cpu-used=-6", "--target-bitrate=150"]),
     # low bitrate: high filter levels, many skipped MBs (mb_skip_coeff / skip_lf paths)
     "p_lowrate_640x360": (640, 360, 10, 71, 4, INTER + ["--good", "--cpu-used=3", "--target-bitrate=150"]),
 }

@@ -204,7 +204,7 @@ def test_sparse_form_through_the_arenas(name):
     ctx.close()
 
 
-INTER_STREAMS = ["p_lowrate_640x360", "p_odd_130x98", "p_sharp_320x240", "p_split_352x288", "p_arf_176x144", "p_prof1_640x360", "p_prof3_640x360",
+INTER_STREAMS = ["p_seg_176x144", "p_lowrate_640x360", "p_odd_130x98", "p_sharp_320x240", "p_split_352x288", "p_arf_176x144", "p_prof1_640x360", "p_prof3_640x360",
                  "p_1920x1080", "p_dense_1920x1080"]
 
 
