@@ -583,7 +583,7 @@ def main():
                 out["config"]["end_to_end"]["device_entropy"] = batch_md5_probe(
                     fixture, local_rank, 4096, ("--device-entropy", "--batch", "4096"))
                 out["config"]["end_to_end"]["device_entropy_frames_stay"] = batch_md5_probe(
-                    fixture, local_rank, 4096, ("--device-entropy", "--no-download", "--batch", "8192"))
+                    fixture, local_rank, 8192, ("--device-entropy", "--no-download", "--batch", "8192", "--entropy-batch", "16384", "--entropy-dense"))
                 out["config"]["end_to_end"]["inter_streams_device_entropy"] = streams_probe(local_rank)
             except Exception as ex:      # a probe, not the benchmark: report, do not fail the line
                 out["config"]["end_to_end"] = {"error": repr(ex)}

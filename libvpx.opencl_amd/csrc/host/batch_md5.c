@@ -1,4 +1,4 @@
-/* batch_md5 [--threads T] [--batch B] [--loop N] [--host-md5] [--device-entropy [--entropy-batch E] [--no-download]] <in.ivf> <out.md5>
+/* batch_md5 [--threads T] [--batch B] [--loop N] [--host-md5] [--device-entropy [--entropy-batch E [--entropy-dense]] [--no-download]] <in.ivf> <out.md5>
  *
  * decode_to_md5 for streams of independently decodable frames (all key frames), at the rate the host can feed the
  * GPU: SURVEY.md 8(f)1.  The output file has decode_to_md5's lines ("<md5>  img-<w>x<h>-<%04d>.i420", one per frame,
@@ -19,7 +19,9 @@
  * buffers).  --no-download: with the MD5s computed on the device the frames themselves stay there.  --entropy-batch E (a
  * multiple of B): the entropy decoder takes E frames per launch and leaves their IR in its sparse form (a third of the bytes:
  * vp8hip_entropy_decode_sparse), the pixel path expands and decodes them B at a time -- more frames in flight for the same memory,
- * and frames in flight over the time of the largest is what the entropy decoder's rate is.
+ * and frames in flight over the time of the largest is what the entropy decoder's rate is.  --entropy-dense: IR slots for all E
+ * frames instead (no sparse form in between): the memory that buys frames in flight is then the pixel path's, whose tile scratch
+ * and frame buffers are only needed for B frames at a time.
  *
  * Prints frames, seconds and frames/s for the region "first byte parsed .. last digest done" on stderr. */
 #include <pthread.h>
@@ -103,6 +105,7 @@ static int g_dev_md5;                               /* hash on the device (vp8hi
 static volatile int g_failed;
 static int g_dev_entropy;                           /* --device-entropy */
 static int g_ebatch;                                /* --entropy-batch: frames per entropy launch (0: = g_batch, dense) */
+static int g_edense;                                /* --entropy-dense: with --entropy-batch E, IR slots for all E frames (no sparse detour) */
 static long *g_order;                               /* --device-entropy: which frame of the run the k-th processed one is.  A lane of the
                                                        entropy kernel is busy for as long as its frame is large and a launch lasts as long
                                                        as its longest lane, so the frames of SORT_WINDOW batches at a time are taken
@@ -207,12 +210,13 @@ int main(int argc, char **argv)
         else if (!strcmp(argv[a], "--device-entropy")) g_dev_entropy = 1;
         else if (!strcmp(argv[a], "--no-download")) no_download = 1;
         else if (!strcmp(argv[a], "--entropy-batch") && a + 1 < argc) g_ebatch = atoi(argv[++a]);
+        else if (!strcmp(argv[a], "--entropy-dense")) g_edense = 1;
         else if (!strcmp(argv[a], "--batch") && a + 1 < argc) g_batch = atoi(argv[++a]);
         else if (!strcmp(argv[a], "--loop") && a + 1 < argc) loop = atoi(argv[++a]);
-        else DIE("Usage: %s [--threads T] [--batch B] [--loop N] [--host-md5] [--device-entropy [--entropy-batch E] [--no-download]] <in.ivf> <out.md5>", argv[0]);
+        else DIE("Usage: %s [--threads T] [--batch B] [--loop N] [--host-md5] [--device-entropy [--entropy-batch E [--entropy-dense]] [--no-download]] <in.ivf> <out.md5>", argv[0]);
     }
     if (argc - a != 2 || g_batch < 1 || loop < 1)
-        DIE("Usage: %s [--threads T] [--batch B] [--loop N] [--host-md5] [--device-entropy [--entropy-batch E] [--no-download]] <in.ivf> <out.md5>", argv[0]);
+        DIE("Usage: %s [--threads T] [--batch B] [--loop N] [--host-md5] [--device-entropy [--entropy-batch E [--entropy-dense]] [--no-download]] <in.ivf> <out.md5>", argv[0]);
     if (threads < 1) {
         long n = sysconf(_SC_NPROCESSORS_ONLN);
         threads = n > 33 ? 32 : (n > 2 ? (int)n - 1 : 1);      /* more than ~32 feeders gain nothing: the host memory system is the limit */
@@ -252,7 +256,7 @@ int main(int argc, char **argv)
     /* slots and frame buffers: three sets for the host feeder (parsed / on the GPU / coming back); with the entropy decoder on
        the device the IR is written and read on one stream, one set does, and the frame buffers alternate between two */
     const int slot_sets = g_dev_entropy ? 1 : 3, fb_sets = g_dev_entropy ? 2 : 3;
-    HIP(vp8hip_configure(g_hip, g_width, g_height, fb_sets * g_batch, slot_sets * g_batch));
+    HIP(vp8hip_configure(g_hip, g_width, g_height, fb_sets * g_batch, g_edense && g_ebatch ? g_ebatch : slot_sets * g_batch));
     HIP(vp8hip_geometry(g_hip, &g_geom));
     if (g_dev_entropy) {
         {   /* a batch's bytes at most: the frames are taken in order of size within windows of SORT_WINDOW batches */
@@ -304,7 +308,7 @@ int main(int argc, char **argv)
             for (;;) {                                                                                                        \
                 size_t by_ = 0;                                                                                               \
                 for (long k_ = 0; k_ < n_; k_++) by_ += g_frames[run_index((first) + k_) % g_nframes].size;                  \
-                if (by_ <= LAUNCH_BYTES || n_ <= g_batch) break;                                                              \
+                if (g_edense || by_ <= LAUNCH_BYTES || n_ <= g_batch) break;                                                            \
                 n_ -= g_batch;                                                                                                \
             }                                                                                                                 \
             (n_out) = (int)n_;                                                                                                \
@@ -314,7 +318,7 @@ int main(int argc, char **argv)
         long part_no = 0, L = 0;
         /* the arenas once, for the largest launch: by what key frames have been seen to need per compressed byte, with room to spare */
         const size_t most = g_ent_cap < LAUNCH_BYTES + ((size_t)256 << 20) ? g_ent_cap : LAUNCH_BYTES + ((size_t)256 << 20);
-        HIP(vp8hip_entropy_reserve_sparse(g_hip, g_ebatch, (size_t)(most * 0.6) + (size_t)g_ebatch * 512, (size_t)(most * 0.8) + (size_t)g_ebatch * 2048));
+        if (!g_edense) HIP(vp8hip_entropy_reserve_sparse(g_hip, g_ebatch, (size_t)(most * 0.6) + (size_t)g_ebatch * 512, (size_t)(most * 0.8) + (size_t)g_ebatch * 2048));
         const double t0 = now_s();
         LAUNCH_FRAMES(0, cur.n);
         size_t bytes = place_frames(&cur);
@@ -323,7 +327,7 @@ int main(int argc, char **argv)
             task_wait(&parse_t, 0);
             if (g_failed) DIE("a frame of launch %ld failed to parse", L);
             const batch_ref now = cur;
-            const int sparse = now.n > g_batch;
+            const int sparse = now.n > g_batch && !g_edense;
             done += now.n;
             if (sparse) HIP(vp8hip_entropy_decode_sparse(g_hip, now.n, g_ent[now.b & 1], g_ent_data[now.b & 1], bytes, 0, 0));
             else HIP(vp8hip_entropy_decode(g_hip, 0, now.n, g_ent[now.b & 1], g_ent_data[now.b & 1], bytes));
@@ -332,7 +336,7 @@ int main(int argc, char **argv)
                 const int fb0 = (part.b & 1) * g_batch;
                 if (sparse) HIP(vp8hip_ir_expand(g_hip, at, 0, part.n));
                 for (int i = 0; i < part.n; i++) {
-                    jobs[i].ir_slot = i; jobs[i].dst_fb = fb0 + i;
+                    jobs[i].ir_slot = g_edense ? at + i : i; jobs[i].dst_fb = fb0 + i;
                     jobs[i].ref_fb[0] = jobs[i].ref_fb[1] = jobs[i].ref_fb[2] = jobs[i].ref_fb[3] = -1;
                 }
                 HIP(vp8hip_decode(g_hip, jobs, part.n, VP8HIP_STAGE_ALL));

@@ -57,7 +57,10 @@ def test_api_rejects_bad_streams():
                                        # ... in launches of more frames than the pixel path takes at a time (the IR in its sparse form in between)
                                        ("kf_640x360", ["--device-entropy", "--batch", "4", "--entropy-batch", "12", "--loop", "5"]),
                                        ("kf_8part_1920x1080", ["--device-entropy", "--batch", "3", "--entropy-batch", "6", "--loop", "5", "--no-download"]),
-                                       ("kf_1920x1080", ["--device-entropy", "--batch", "16", "--entropy-batch", "64", "--loop", "13"])])
+                                       ("kf_1920x1080", ["--device-entropy", "--batch", "16", "--entropy-batch", "64", "--loop", "13"]),
+                                       # ... with IR slots for the whole entropy launch (no sparse form in between)
+                                       ("kf_640x360", ["--device-entropy", "--batch", "4", "--entropy-batch", "12", "--entropy-dense", "--loop", "5"]),
+                                       ("kf_1920x1080", ["--device-entropy", "--batch", "16", "--entropy-batch", "48", "--entropy-dense", "--loop", "11", "--no-download"])])
 def test_batch_md5_listing_equals_decode_to_md5(name, args, tmp_path):
     """The threaded feeder + batched launches (batch_md5) write decode_to_md5's listing, line for line; looped, the
     digests repeat with continuing frame numbers."""
