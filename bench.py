@@ -221,7 +221,7 @@ def batch_md5_probe(fixture, device, loops=205, extra=()):
             "md5_mismatches": bad}
 
 
-def streams_probe(device, streams=1024, fixture="p_1920x1080"):
+def streams_probe(device, streams=4096, fixture="p_1920x1080"):
     """Inter-frame streams side by side with the entropy decoder on the device (tools/streams_probe.py): `streams` copies of the
     fixture (a key frame and nine P frames), a launch per position, only the frame headers read on the host; every shown frame of
     every stream hashed on the device and compared with the reference decoder's listing."""
