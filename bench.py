@@ -247,10 +247,10 @@ def load_stream(P, ctx, fixture, F, lo):
     t0 = time.time()
     for j in range(min(F, nsrc)):
         k = (lo + j) % nsrc
-        hdr = ctx.parse_into_slot(parser, frames[k], j)
+        # the feeder writes the device form of include/vp8_ir.h into the slot's pinned staging; one copy takes it to the slot
+        hdr, _ = ctx.parse_into_slot_compact(parser, frames[k], j)
         assert hdr.frame_type == 0, "bench stream must be all key frames"
         parser.swap(hdr)
-        ctx.upload(j)
         first[k] = j
     feed_s = time.time() - t0
     for j in range(nsrc, F):

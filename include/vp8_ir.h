@@ -24,10 +24,12 @@
  *     load and run the (vertical-first) IDCT pass of vp8_short_idct4x4llm_c
  *     (vp8/common/idctllm.c:28-60) without a transpose.
  *   - MBs with VP8IR_MB_SKIP set have UNDEFINED coefficient contents (never read).
+ *   - the arrays above are the DENSE form: the host-side view.  What lies in HBM is the device form (vp8ir_mbx, below).
  */
 #ifndef VP8_IR_H
 #define VP8_IR_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -52,15 +54,9 @@ enum { VP8IR_INTRA_FRAME = 0, VP8IR_LAST_FRAME, VP8IR_GOLDEN_FRAME, VP8IR_ALTREF
 
 #define VP8IR_COEF_PER_MB 400
 
-/* Sparse coefficient streams (the host -> device form of `coef`; the kernels always read the dense array).  Two of them, in
- * macroblock order and block order 0..24 inside a macroblock:
- *   blocks: the 16-coefficient blocks with more than one coded position, 32 bytes each;
- *   dcs:    one int16 for every block whose only coded coefficient is its first (eob == 1, token decode started at 0).
- * Which kind a block is follows from the descriptor alone (vp8ir_block_kind): a luma block of a macroblock with Y2 starts its
- * token decode at position 1 (detokenize.c:361), so it has coefficients only if eob > 1; any other block is a DC with eob == 1
- * and a full block with eob > 1; nothing in a skipped macroblock.  vp8ir_mb::sparse_first / dc_first locate a macroblock's
- * first entry in either stream.  On the 1080p benchmark stream, descriptors included: 0.37 of the dense form's bytes (3.4 B per pixel dense), which
- * is what PCIe and the host memory system -- not the GPU -- limit an all-key-frame pipeline by. */
+/* The DEVICE FORM of the coefficients -- what an IR slot holds in HBM -- is not the dense array but the compact form described
+ * at vp8ir_mbx below: every producer writes it, every pixel kernel reads it, nothing converts it in between.  The dense array is
+ * the host-side view (oracle, tests, vp8hip_ir_map / vp8hip_ir_fetch). */
 #define VP8IR_BORDER 32         /* VP8BORDERINPIXELS (vpx_scale/yv12config.h:20) */
 
 typedef struct vp8ir_mb {       /* 64 bytes */
@@ -75,8 +71,8 @@ typedef struct vp8ir_mb {       /* 64 bytes */
                                    Y blocks of an MB that has a Y2 block start at 1 */
     uint8_t rsv1[7];
     uint8_t b_modes[16];        /* B_PRED only */
-    uint32_t sparse_first;      /* sparse coefficient streams only: index of this MB's first entry in `blocks` ... */
-    uint32_t dc_first;          /* ... and in `dcs` */
+    uint32_t sparse_first;      /* device form only (vp8ir_mbx): index of this MB's first block in the slot's block stream */
+    uint32_t dc_first;          /* reserved (0) */
 } vp8ir_mb;
 
 typedef struct vp8ir_mv {       /* MV (vp8/common/mv.h:16-26): 1/8-pel units as stored by decodemv.c:112 */
@@ -124,7 +120,9 @@ typedef struct vp8ir_frame_hdr { /* 64 bytes */
 /* the frame type the loop filter's hev threshold goes by */
 VP8IR_INLINE int vp8ir_lf_frame_type(const vp8ir_frame_hdr *h) { return h->frame_type && !h->lf_key_frame; }
 
-/* 0: block k of the macroblock has no coefficients, 1: only its first (in `dcs`), 2: a full block (in `blocks`) */
+/* 0: block k of the macroblock has no coefficients, 1: only its first (a lone DC), 2: more than that.
+ * A luma block of a macroblock with Y2 starts its token decode at position 1 (detokenize.c:361): it has coefficients only if eob > 1;
+ * any other block is a lone DC with eob == 1 and a full block with eob > 1; nothing in a skipped macroblock. */
 VP8IR_INLINE int vp8ir_block_kind(const vp8ir_mb *m, int k)
 {
     const int has_y2 = m->y_mode != VP8IR_B_PRED && m->y_mode != VP8IR_SPLITMV;
@@ -136,6 +134,85 @@ VP8IR_INLINE int vp8ir_block_kind(const vp8ir_mb *m, int k)
 
 typedef char vp8ir_static_assert_mb[(sizeof(vp8ir_mb) == 64) ? 1 : -1];
 typedef char vp8ir_static_assert_hdr[(sizeof(vp8ir_frame_hdr) == 64) ? 1 : -1];
+
+/* ---------------------------------------------------------------------------------------------------------------------
+ * The DEVICE FORM of a frame's macroblock data (an IR slot in HBM; the pinned staging a feeder fills for it has the same layout
+ * and is copied as it is):
+ *
+ *   mbx[nmb]   one vp8ir_mbx per macroblock, raster order: 128 bytes = one cache line -- the descriptor and the coefficients
+ *              a kernel needs with it whatever the blocks hold (the Y2 block; the blocks' lone first coefficients)
+ *   blocks[]   32 bytes (16 int16, column-major as in the dense form) for every block k in 0..23 with eobs[k] > 1, and for no
+ *              other: in block order inside a macroblock, the macroblocks of a MACROBLOCK ROW one after the other from
+ *              mbx[row start].d.sparse_first on.  (Rows may stand in any order and with gaps between them: a feeder that decodes
+ *              token partitions on several threads, or lanes, gives each a region of its own.  d.sparse_first is valid for every
+ *              macroblock; a consumer may follow it per macroblock or count blocks along a row.)
+ *   mvs[nmb*16] as in the dense form (inter frames only)
+ *
+ * This is what the reference's decode_macroblock consumes as vp8_decode_mb_tokens left it (vp8/decoder/decodframe.c:126 ->
+ * :224-296, vp8/common/idct_blk.c:20-86: qcoeff + eobs), minus the zeros: a block with eob <= 1 is either nothing or a single
+ * first coefficient, and only blocks with more are worth 32 bytes and a memory request.  On the 1080p benchmark stream the
+ * form is 0.4 of the dense form's bytes; it is what crosses PCIe, what lies in HBM and what the kernels fetch.
+ * A skipped macroblock (VP8IR_MB_SKIP) has no blocks; its y2 / cdc are zero.
+ */
+typedef struct vp8ir_mbx {      /* 128 bytes */
+    vp8ir_mb d;
+    int16_t y2[16];             /* macroblock with a Y2 block (y_mode neither B_PRED nor SPLITMV): that block's coefficients, zeros
+                                   past its eob.  Without: y2[k] = the first coefficient of luma block k where eobs[k] == 1, else 0 */
+    int16_t cdc[8];             /* cdc[k] = the first coefficient of chroma block 16 + k where eobs[16 + k] == 1, else 0 */
+    int16_t rsv[8];             /* zero */
+} vp8ir_mbx;
+typedef char vp8ir_static_assert_mbx[(sizeof(vp8ir_mbx) == 128) ? 1 : -1];
+#define VP8IR_MBX_WORDS 32      /* dwords per vp8ir_mbx */
+#define VP8IR_MAX_BLOCKS_PER_MB 24
+
+/* dense -> device form of one macroblock: *x and up to 24 blocks at blocks + 16 * first; returns the number of blocks written */
+static inline unsigned vp8ir_compact_mb(const vp8ir_mb *m, const int16_t *coef /* 400, dense */, uint32_t first, vp8ir_mbx *x,
+                                        int16_t *blocks)
+{
+    const int has_y2 = m->y_mode != VP8IR_B_PRED && m->y_mode != VP8IR_SPLITMV;
+    unsigned n = 0;
+    int k, i;
+    x->d = *m;
+    x->d.sparse_first = first;
+    x->d.dc_first = 0;
+    for (i = 0; i < 16; i++) x->y2[i] = 0;
+    for (i = 0; i < 8; i++) x->cdc[i] = x->rsv[i] = 0;
+    if (m->flags & VP8IR_MB_SKIP) return 0;
+    if (has_y2)
+        for (i = 0; i < 16; i++) x->y2[i] = m->eobs[24] ? coef[384 + i] : (int16_t)0;
+    for (k = 0; k < 24; k++) {
+        const int kind = vp8ir_block_kind(m, k);
+        if (kind == 2) {
+            for (i = 0; i < 16; i++) blocks[((size_t)first + n) * 16 + i] = coef[k * 16 + i];
+            n++;
+        } else if (kind == 1) {
+            if (k < 16) x->y2[k] = coef[k * 16];
+            else x->cdc[k - 16] = coef[k * 16];
+        }
+    }
+    return n;
+}
+
+/* device form -> dense form of one macroblock (zeros where a block has no coefficients; a skipped macroblock: all zeros) */
+static inline void vp8ir_expand_mb(const vp8ir_mbx *x, const int16_t *blocks /* the slot's stream */, vp8ir_mb *m, int16_t *coef /* 400 */)
+{
+    const int has_y2 = x->d.y_mode != VP8IR_B_PRED && x->d.y_mode != VP8IR_SPLITMV;
+    size_t at = x->d.sparse_first;
+    int k, i;
+    if (m) { *m = x->d; m->sparse_first = 0; m->dc_first = 0; }
+    for (i = 0; i < VP8IR_COEF_PER_MB; i++) coef[i] = 0;
+    if (x->d.flags & VP8IR_MB_SKIP) return;
+    if (has_y2 && x->d.eobs[24])
+        for (i = 0; i < 16; i++) coef[384 + i] = x->y2[i];
+    for (k = 0; k < 24; k++) {
+        const int kind = vp8ir_block_kind(&x->d, k);
+        if (kind == 2) {
+            for (i = 0; i < 16; i++) coef[k * 16 + i] = blocks[at * 16 + i];
+            at++;
+        } else if (kind == 1)
+            coef[k * 16] = k < 16 ? x->y2[k] : x->cdc[k - 16];
+    }
+}
 
 /* Frame-buffer geometry shared by every implementation (vp8_yv12_alloc_frame_buffer,
  * vpx_scale/generic/yv12config.c:55-112): 32-pixel luma border, 16-pixel chroma border,

@@ -11,9 +11,10 @@
  *                                          incl. the per-frame-buffer device memory the reference
  *                                          attaches as YV12_BUFFER_CONFIG.buffer_mem
  *                                          (vpx_scale/yv12config.h:63-65, yv12config.c:97-105)
- *   vp8hip_ir_map / vp8hip_ir_upload    <- the per-MB submit points of the reference's CL path
- *                                          (vp8/decoder/decodframe.c:149-156: qcoeff/eobs/MODE_INFO
- *                                          handed to vp8_decode_macroblock_cl)
+ *   vp8hip_ir_map_compact /             <- the per-MB submit points of the reference's CL path
+ *   vp8hip_ir_upload_compact               (vp8/decoder/decodframe.c:149-156: qcoeff/eobs/MODE_INFO
+ *   (vp8hip_ir_map / vp8hip_ir_upload:     handed to vp8_decode_macroblock_cl)
+ *    the same from dense arrays)
  *   vp8hip_decode                       <- decode_mb_row x mb_rows (decodframe.c:1116-1129),
  *                                          vp8_loop_filter_frame (vp8/common/loopfilter.c:203; its
  *                                          CL diversion at :225-230) and
@@ -60,12 +61,12 @@ typedef struct vp8hip_stats {      /* filled by vp8hip_get_stats; times from HIP
     int   recon_waves, lf_waves;        /* waves per workgroup (1 = the lane-per-row kernels ran, 4 = the cross-CU
                                            variant of the wave-per-row kernels: small launches) */
     int   workgroups;
-    int   detile_pass;                  /* 1: a tiled -> raster pass finished the launch (lane-per-row kernels with no
-                                           filtered frame in the launch, or VP8HIP_LF_RASTER=0); extend_ms covers it */
-    int   lf_kernels;                   /* lane-per-row loop filter: 2 = luma and chroma kernels side by side, 1 = one kernel,
-                                           0 = none (fused) */
-    int   fused;                        /* 1: vp8_keyframe_simt_kernel reconstructed AND filtered the launch (all key frames, both
-                                           stages); recon_ms covers it, lf_ms is 0 */
+    int   detile_pass;                  /* 1: a tiled -> raster pass finished the launch (the lane-per-row kernels ran); extend_ms
+                                           covers it */
+    int   lf_kernels;                   /* loop-filter kernels launched: 1 (wave-per-row family, some frame filtered) or 0 */
+    int   fused;                        /* 1: the lane-per-row kernels -- vp8_keyframe_kernel, or vp8_inter_pred_kernel +
+                                           vp8_interframe_kernel -- reconstructed AND filtered the launch; recon_ms covers it,
+                                           lf_ms is 0 */
 } vp8hip_stats;
 
 /* device < 0: use the current HIP device.  Returns 0 or a negative error. */
@@ -73,27 +74,28 @@ int  vp8hip_create(int device, vp8hip_ctx **out);
 void vp8hip_destroy(vp8hip_ctx *ctx);
 const char *vp8hip_last_error(const vp8hip_ctx *ctx);   /* ctx may be NULL: creation error */
 
-/* (Re)allocate device state for frames of width x height: num_fb frame buffers
- * (vp8ir_geom layout, borders included) and num_slots IR slots (hdr + mbs + coef + mvs, each
- * with a pinned host staging mirror).  Existing contents are discarded. */
+/* (Re)allocate device state for frames of width x height: num_fb frame buffers (vp8ir_geom layout, borders included) and
+ * num_slots IR slots.  A slot holds one frame's macroblock data in the DEVICE FORM of include/vp8_ir.h (records, block stream
+ * sized for the worst case, vectors: 960 bytes per macroblock) and gets pinned host staging of the same layout when it is first
+ * mapped.  Existing contents are discarded. */
 int  vp8hip_configure(vp8hip_ctx *ctx, int width, int height, int num_fb, int num_slots);
 int  vp8hip_geometry(const vp8hip_ctx *ctx, vp8ir_geom *g);
 
-/* Pinned host staging of a slot, for the feeder to write the IR into directly. */
+/* Pinned host staging of a slot in the device form, for a feeder to write into directly (vp8_parser_decode_mbs_compact): mbx[nmb],
+ * blocks[*cap_blocks * 16] right behind them, mvs[nmb * 16].  vp8hip_ir_upload_compact sends header, records and the first
+ * nblocks blocks with ONE asynchronous copy on the context's stream (+ one for the vectors of an inter frame); the pixel
+ * kernels read what arrives, nothing on the device touches it in between.  The staging may be rewritten once that copy has run
+ * (vp8hip_sync, or any later synchronisation of the stream). */
+int  vp8hip_ir_map_compact(vp8hip_ctx *ctx, int slot, vp8ir_frame_hdr **hdr, vp8ir_mbx **mbx, int16_t **blocks, size_t *cap_blocks,
+                           vp8ir_mv **mvs);
+int  vp8hip_ir_upload_compact(vp8hip_ctx *ctx, int slot, size_t nblocks);
+/* The same from the DENSE view (mbs[nmb], coef[nmb * 400]: what the oracle and the tests speak): host memory the caller fills;
+ * vp8hip_ir_upload turns it into the device form on the host (vp8ir_compact_mb), in the slot's staging, and uploads that.  It
+ * waits for the context's stream first (the staging may still be on its way from the upload before). */
 int  vp8hip_ir_map(vp8hip_ctx *ctx, int slot, vp8ir_frame_hdr **hdr, vp8ir_mb **mbs,
                    int16_t **coef, vp8ir_mv **mvs);
-/* Asynchronous H2D copy of one slot on the context's stream (mvs only for inter frames). */
 int  vp8hip_ir_upload(vp8hip_ctx *ctx, int slot);
-/* The same two steps with the coefficients as the SPARSE streams of include/vp8_ir.h (full blocks and lone DCs of the blocks
- * that have coefficients at all: about a third of the dense form's bytes over PCIe on real streams): `blocks` is pinned
- * staging for up to *cap_blocks blocks of 16 int16 (it shares its memory with the dense `coef` staging of vp8hip_ir_map: a slot
- * is filled one way or the other), `dcs` for 25 int16 per macroblock; vp8hip_ir_upload_sparse copies header, descriptors (whose
- * sparse_first / dc_first fields locate each macroblock's entries), nblocks blocks, ndcs DCs and, for inter frames, the MVs,
- * and expands the streams into the slot's dense coefficient array on the device.  Asynchronous, on the context's stream. */
-int  vp8hip_ir_map_sparse(vp8hip_ctx *ctx, int slot, vp8ir_frame_hdr **hdr, vp8ir_mb **mbs, int16_t **blocks,
-                          size_t *cap_blocks, int16_t **dcs, vp8ir_mv **mvs);
-int  vp8hip_ir_upload_sparse(vp8hip_ctx *ctx, int slot, size_t nblocks, size_t ndcs);
-/* Device-to-device replication of an uploaded slot (synthetic looped streams: every key frame
+/* Device-to-device replication of a slot (synthetic looped streams: every key frame
  * is independently decodable, decodframe.c:610-639). */
 int  vp8hip_ir_copy(vp8hip_ctx *ctx, int dst_slot, int src_slot);
 
@@ -153,9 +155,9 @@ int  vp8hip_mfqe(vp8hip_ctx *ctx, int show_fb, int prev_fb, int dst_fb, const ui
  * decoded in macroblock-row order like the reference's single thread does); the frames of a batch run side by side, 64 to a
  * wave.  The frame header stays with the host (a few thousand bools: vp8_parser_begin_frame), which hands over what it leaves
  * behind (vp8_parser_export_entropy, csrc/host/vp8_parser.h): the decoder state of the first partition where the per-macroblock
- * data start, the token partitions' extents, the probabilities.  The kernel writes the dense IR of include/vp8_ir.h into the
- * frames' slots -- descriptors and coefficients byte for byte what vp8_parser_decode_mbs writes -- and vp8hip_decode takes it
- * from there.  Inter frames too (vp8_decode_mode_mvs' per-macroblock half: reference frame, the near / nearest candidates from the
+ * data start, the token partitions' extents, the probabilities.  The kernel writes the frames' slots in the device form of
+ * include/vp8_ir.h -- what vp8_parser_decode_mbs_compact writes on the host -- and vp8hip_decode reads it as it stands.  Inter
+ * frames too (vp8_decode_mode_mvs' per-macroblock half: reference frame, the near / nearest candidates from the
  * macroblocks above, left and above-left, NEWMV / SPLITMV vectors: decodemv.c:323-569) -- which only pays where many frames are
  * independent of each other, as the same position of many streams is.  Integer only. */
 typedef struct vp8hip_entropy_frame {
@@ -182,25 +184,14 @@ typedef struct vp8hip_entropy_frame {
  * vp8hip_sync).  Asynchronous on the context's stream. */
 int  vp8hip_entropy_decode(vp8hip_ctx *ctx, int first_slot, int count, const vp8hip_entropy_frame *frames, const uint8_t *data,
                            size_t data_bytes);
-/* The same, the IR in its SPARSE form (include/vp8_ir.h) in arenas of the context instead of IR slots: a third of the dense form's
- * bytes on the benchmark stream, so that more frames can be in flight than there are slots -- a lane is busy for as long as its
- * frame is large whatever the launch's size, and the rate of the decoder is frames in flight / that time.  vp8hip_ir_expand then
- * turns frames first_frame .. first_frame + n - 1 of that launch into the dense IR of slots first_slot .. (one kernel; same
- * stream) for vp8hip_decode, a part of the launch at a time.  blocks_cap / dcs_cap: entries of the two arenas (0: an estimate
- * from the compressed size, generous for key frames; a lane takes 256 blocks / 1024 DCs at a time).  When an arena runs out the
- * whole launch is void: vp8hip_entropy_status says so (bit 1 in every word) and the caller repeats it with larger arenas or in
- * the dense form.  One sparse launch at a time: the next one overwrites the arenas. */
-int  vp8hip_entropy_decode_sparse(vp8hip_ctx *ctx, int count, const vp8hip_entropy_frame *frames, const uint8_t *data, size_t data_bytes,
-                                  size_t blocks_cap, size_t dcs_cap);
-int  vp8hip_ir_expand(vp8hip_ctx *ctx, int first_frame, int first_slot, int n);
-/* Memory for sparse launches of up to max_count frames up front (a launch larger than anything before it otherwise stops to
- * allocate): descriptors for max_count frames, arenas of blocks_cap blocks and dcs_cap DCs. */
-int  vp8hip_entropy_reserve_sparse(vp8hip_ctx *ctx, int max_count, size_t blocks_cap, size_t dcs_cap);
-/* What became of the frames of the last vp8hip_entropy_decode[_sparse], a word each: bit 0 = a partition of the frame ended early,
- * the frame is corrupt (what vp8_parser_decode_mbs reports through *corrupt); bit 1 = a sparse launch ran out of arena.
- * Synchronous. */
+/* What became of the frames of the last vp8hip_entropy_decode, a word each: bit 0 = a partition of the frame ended early, the
+ * frame is corrupt (what vp8_parser_decode_mbs reports through *corrupt).  Synchronous.  _async: the copy is queued on the
+ * context's stream into page-locked memory of the caller's (vp8hip_host_alloc) and has landed after the next synchronisation
+ * (vp8hip_sync, or vp8hip_download_wait for a fetch queued behind it). */
 int  vp8hip_entropy_status(vp8hip_ctx *ctx, int count, uint32_t *status);
-/* The IR of a slot as it stands on the device, dense form (tests, debugging): mbs[nmb], coef[nmb * 400].  Synchronous. */
+int  vp8hip_entropy_status_async(vp8hip_ctx *ctx, int count, uint32_t *status);
+/* The IR of a slot as it stands on the device, expanded to the dense view on the host (tests, debugging): mbs[nmb],
+ * coef[nmb * 400], zeros where a block has no coefficients.  Synchronous. */
 int  vp8hip_ir_fetch(vp8hip_ctx *ctx, int slot, vp8ir_mb *mbs, int16_t *coef);
 int  vp8hip_ir_fetch_mvs(vp8hip_ctx *ctx, int slot, vp8ir_mv *mvs);      /* ... and its vectors: mvs[nmb * 16] */
 

@@ -169,8 +169,7 @@ def load_host():
         L.vp8_parser_frame_hdr.argtypes = [c_void_p, c_void_p]
         L.vp8_parser_begin_frame.argtypes = [c_void_p, ctypes.c_char_p, c_size_t, c_void_p]
         L.vp8_parser_decode_mbs.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
-        L.vp8_parser_decode_mbs_sparse.argtypes = [c_void_p, c_void_p, c_void_p, c_size_t, ctypes.POINTER(c_size_t), c_void_p,
-                                                   ctypes.POINTER(c_size_t), c_void_p, c_void_p]
+        L.vp8_parser_decode_mbs_compact.argtypes = [c_void_p, c_void_p, c_void_p, c_size_t, ctypes.POINTER(c_size_t), c_void_p, c_void_p]
         L.vp8_parser_export_entropy.argtypes = [c_void_p, c_void_p]
         L.vp8_parser_error.argtypes = [c_void_p]
         L.vp8_parser_error.restype = ctypes.c_char_p
@@ -246,18 +245,89 @@ class Parser:
             raise ValueError(f"vp8 macroblock data error {rc}: {self.L.vp8_parser_error(self.p).decode()}")
         return corrupt.value
 
-    def decode_mbs_sparse(self, mbs_ptr, blocks_ptr, cap_blocks, dcs_ptr, mvs_ptr):
-        """-> (full blocks, lone DCs written to the sparse coefficient streams, corrupt flag)"""
-        corrupt, nb, nd = c_int(0), c_size_t(0), c_size_t(0)
-        rc = self.L.vp8_parser_decode_mbs_sparse(self.p, mbs_ptr, blocks_ptr, cap_blocks, ctypes.byref(nb), dcs_ptr, ctypes.byref(nd),
-                                                 mvs_ptr, ctypes.byref(corrupt))
+    def decode_mbs_compact(self, mbx_ptr, blocks_ptr, cap_blocks, mvs_ptr):
+        """The macroblocks in the DEVICE FORM of include/vp8_ir.h (records + block stream) -> (blocks written, corrupt flag)"""
+        corrupt, nb = c_int(0), c_size_t(0)
+        rc = self.L.vp8_parser_decode_mbs_compact(self.p, mbx_ptr, blocks_ptr, cap_blocks, ctypes.byref(nb), mvs_ptr, ctypes.byref(corrupt))
         if rc:
             self.L.vp8_refs_release_new(ctypes.byref(self.refs))
             raise ValueError(f"vp8 macroblock data error {rc}: {self.L.vp8_parser_error(self.p).decode()}")
-        return nb.value, nd.value, corrupt.value
+        return nb.value, corrupt.value
 
     def swap(self, hdr):
         self.L.vp8_refs_swap(ctypes.byref(self.refs), ctypes.byref(hdr))
+
+
+def parse_to_numpy_compact(parser, data):
+    """One frame in the device form -> (hdr, mbx uint8[n,128], blocks int16[nb,16], mvs int16[n,16,2], corrupt)."""
+    hdr, changed = parser.begin(data)
+    n = hdr.mb_cols * hdr.mb_rows
+    mbx = np.zeros((n, 128), np.uint8)
+    blocks = np.zeros((n * 24, 16), np.int16)
+    mvs = np.zeros((n, 16, 2), np.int16)
+    nb, corrupt = parser.decode_mbs_compact(mbx.ctypes.data, blocks.ctypes.data, n * 24, mvs.ctypes.data)
+    return hdr, mbx, blocks[:nb].copy(), mvs, corrupt
+
+
+def block_kinds(mbs):
+    """vp8ir_block_kind for every block of every macroblock: uint8[n, 25] of 0 (nothing), 1 (a lone first coefficient), 2 (more).
+    mbs: uint8[n, >=64] descriptors."""
+    ymode, flags, eobs = mbs[:, 0], mbs[:, 3], mbs[:, 8:33]
+    has_y2 = (ymode != 4) & (ymode != 9)
+    kind = np.zeros(eobs.shape, np.uint8)
+    kind[eobs == 1] = 1
+    kind[eobs > 1] = 2
+    kind[:, :16][(eobs[:, :16] == 1) & has_y2[:, None]] = 0
+    kind[~has_y2, 24] = 0
+    kind[(flags & 1) != 0] = 0
+    return kind
+
+
+def compact_from_dense(mbs, coef):
+    """The device form of include/vp8_ir.h (vp8ir_compact_mb restated with numpy): (mbx uint8[n,128], blocks int16[nb,16])."""
+    n = mbs.shape[0]
+    kind = block_kinds(mbs)
+    c = coef.reshape(n, 25, 16)
+    mbx = np.zeros((n, 128), np.uint8)
+    mbx[:, :64] = mbs[:, :64]
+    full = kind[:, :24] == 2
+    first = np.concatenate(([0], np.cumsum(full.sum(1))[:-1])).astype(np.uint32)
+    mbx[:, 56:60] = first.view(np.uint8).reshape(n, 4)
+    mbx[:, 60:64] = 0
+    aux = np.zeros((n, 32), np.int16)
+    has_y2 = (mbs[:, 0] != 4) & (mbs[:, 0] != 9)
+    skip = (mbs[:, 3] & 1) != 0
+    y2rows = has_y2 & ~skip & (mbs[:, 8 + 24] != 0)
+    aux[y2rows, :16] = c[y2rows, 24, :]
+    lone = kind[:, :24] == 1
+    dc = c[:, :24, 0]
+    aux[:, :16] = np.where(lone[:, :16], dc[:, :16], aux[:, :16])
+    aux[:, 16:24] = np.where(lone[:, 16:24], dc[:, 16:24], 0)
+    mbx[:, 64:128] = aux.view(np.uint8).reshape(n, 64)
+    return mbx, np.ascontiguousarray(c[:, :24][full])
+
+
+def dense_from_compact(mbx, blocks):
+    """vp8ir_expand_mb restated with numpy: (mbs uint8[n,64] with sparse_first cleared, coef int16[n,400])."""
+    n = mbx.shape[0]
+    mbs = mbx[:, :64].copy()
+    first = mbs[:, 56:60].copy().view(np.uint32).reshape(n)
+    mbs[:, 56:64] = 0
+    kind = block_kinds(mbs)
+    aux = mbx[:, 64:128].copy().view(np.int16).reshape(n, 32)
+    c = np.zeros((n, 25, 16), np.int16)
+    has_y2 = (mbs[:, 0] != 4) & (mbs[:, 0] != 9)
+    skip = (mbs[:, 3] & 1) != 0
+    y2rows = has_y2 & ~skip & (mbs[:, 8 + 24] != 0)
+    c[y2rows, 24, :] = aux[y2rows, :16]
+    lone = kind[:, :24] == 1
+    c[:, :16, 0] = np.where(lone[:, :16], aux[:, :16], 0)
+    c[:, 16:24, 0] = np.where(lone[:, 16:24], aux[:, 16:24], 0)
+    full = kind[:, :24] == 2
+    rank = np.cumsum(full, 1) - full
+    idx = first[:, None] + rank
+    c[:, :24][full] = blocks[idx[full]]
+    return mbs, c.reshape(n, 400)
 
 
 def parse_to_numpy(parser, data):
@@ -299,9 +369,9 @@ def load_hip():
         L.vp8hip_geometry.argtypes = [c_void_p, c_void_p]
         L.vp8hip_ir_map.argtypes = [c_void_p, c_int] + [ctypes.POINTER(c_void_p)] * 4
         L.vp8hip_ir_upload.argtypes = [c_void_p, c_int]
-        L.vp8hip_ir_map_sparse.argtypes = [c_void_p, c_int, ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p),
-                                           ctypes.POINTER(c_size_t), ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p)]
-        L.vp8hip_ir_upload_sparse.argtypes = [c_void_p, c_int, c_size_t, c_size_t]
+        L.vp8hip_ir_map_compact.argtypes = [c_void_p, c_int, ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p),
+                                            ctypes.POINTER(c_size_t), ctypes.POINTER(c_void_p)]
+        L.vp8hip_ir_upload_compact.argtypes = [c_void_p, c_int, c_size_t]
         L.vp8hip_ir_copy.argtypes = [c_void_p, c_int, c_int]
         L.vp8hip_decode.argtypes = [c_void_p, c_void_p, c_int, c_int]
         L.vp8hip_frame_download.argtypes = [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int]
@@ -317,8 +387,6 @@ def load_hip():
         L.vp8hip_mfqe.argtypes = [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int]
         L.vp8hip_entropy_decode.argtypes = [c_void_p, c_int, c_int, c_void_p, c_void_p, c_size_t]
         L.vp8hip_entropy_status.argtypes = [c_void_p, c_int, c_void_p]
-        L.vp8hip_entropy_decode_sparse.argtypes = [c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_size_t, c_size_t]
-        L.vp8hip_ir_expand.argtypes = [c_void_p, c_int, c_int, c_int]
         L.vp8hip_ir_fetch.argtypes = [c_void_p, c_int, c_void_p, c_void_p]
         L.vp8hip_ir_fetch_mvs.argtypes = [c_void_p, c_int, c_void_p]
         _hip = L
@@ -378,19 +446,37 @@ class Vp8Hip:
         ctypes.memmove(ph, ctypes.byref(hdr), 64)
         return hdr
 
-    def parse_into_slot_sparse(self, parser, data, slot):
-        """Feeder writes descriptors and the SPARSE coefficient stream into the pinned staging of `slot` and queues the upload
-        (+ expansion on the device); returns (hdr, blocks in the stream)."""
+    def ir_map_compact(self, slot):
+        """Pinned staging of `slot` in the device form: (hdr, mbx, blocks, mvs addresses, blocks the stream may take)."""
+        ph, pm, pb, pv, cap = c_void_p(), c_void_p(), c_void_p(), c_void_p(), c_size_t()
+        self._chk(self.L.vp8hip_ir_map_compact(self.h, slot, ctypes.byref(ph), ctypes.byref(pm), ctypes.byref(pb), ctypes.byref(cap),
+                                               ctypes.byref(pv)), "vp8hip_ir_map_compact")
+        return ph.value, pm.value, pb.value, pv.value, cap.value
+
+    def parse_into_slot_compact(self, parser, data, slot):
+        """Feeder writes the frame in the DEVICE FORM (include/vp8_ir.h) into the pinned staging of `slot` and queues the upload
+        (one copy; nothing on the device touches the slot before the pixel kernels read it); returns (hdr, bytes uploaded)."""
         hdr, changed = parser.begin(data)
         if (hdr.width, hdr.height) != (self.width, self.height):
             raise RuntimeError("dimension change: reconfigure the context first")
-        ph, pm, pb, pd, pv, cap = c_void_p(), c_void_p(), c_void_p(), c_void_p(), c_void_p(), c_size_t()
-        self._chk(self.L.vp8hip_ir_map_sparse(self.h, slot, ctypes.byref(ph), ctypes.byref(pm), ctypes.byref(pb), ctypes.byref(cap),
-                                              ctypes.byref(pd), ctypes.byref(pv)), "vp8hip_ir_map_sparse")
-        nb, nd, _ = parser.decode_mbs_sparse(pm.value, pb.value, cap.value, pd.value, pv.value)
-        ctypes.memmove(ph.value, ctypes.byref(hdr), 64)
-        self._chk(self.L.vp8hip_ir_upload_sparse(self.h, slot, nb, nd), "vp8hip_ir_upload_sparse")
-        return hdr, nb * 32 + nd * 2
+        ph, pm, pb, pv, cap = self.ir_map_compact(slot)
+        nb, _ = parser.decode_mbs_compact(pm, pb, cap, pv)
+        parser.final_hdr(hdr)
+        ctypes.memmove(ph, ctypes.byref(hdr), 64)
+        self._chk(self.L.vp8hip_ir_upload_compact(self.h, slot, nb), "vp8hip_ir_upload_compact")
+        return hdr, self.nmb * 128 + nb * 32
+
+    def fill_slot_compact(self, slot, hdr, mbx, blocks, mvs):
+        """numpy arrays in the device form (compact_from_dense) into a slot's pinned staging, and up."""
+        ph, pm, pb, pv, cap = self.ir_map_compact(slot)
+        assert blocks.shape[0] <= cap
+        ctypes.memmove(ph, ctypes.byref(hdr), 64)
+        ctypes.memmove(pm, mbx.ctypes.data, mbx.nbytes)
+        if blocks.nbytes:
+            ctypes.memmove(pb, blocks.ctypes.data, blocks.nbytes)
+        if hdr.frame_type != 0:
+            ctypes.memmove(pv, mvs.ctypes.data, mvs.nbytes)
+        self._chk(self.L.vp8hip_ir_upload_compact(self.h, slot, blocks.shape[0]), "vp8hip_ir_upload_compact")
 
     def upload(self, slot):
         self._chk(self.L.vp8hip_ir_upload(self.h, slot), "vp8hip_ir_upload")
@@ -463,10 +549,9 @@ class Vp8Hip:
                             noise_rows.ctypes.data if noise_rows is not None else None)
         self._chk(self.L.vp8hip_postproc(self.h, src_fb, dst_fb, tmp_fb, ctypes.byref(pp)), "postproc")
 
-    def entropy_decode(self, first_slot, frames, datas, sparse_caps=None):
+    def entropy_decode(self, first_slot, frames, datas):
         """vp8hip_entropy_decode: frames = EntropyFrame list (from Parser.export_entropy), datas = the frames' bytes; slot
-        first_slot + i receives frame i's IR.  Returns the per-frame status words (synchronises).  sparse_caps = (blocks, dcs):
-        vp8hip_entropy_decode_sparse instead (first_slot ignored; vp8hip_ir_expand via ir_expand)."""
+        first_slot + i receives frame i's IR.  Returns the per-frame status words (synchronises)."""
         n = len(frames)
         arr = (EntropyFrame * n)()
         off = 0
@@ -475,10 +560,7 @@ class Vp8Hip:
             arr[i].data_off = off
             off += len(d)
         blob = b"".join(datas)
-        if sparse_caps is not None:
-            self._chk(self.L.vp8hip_entropy_decode_sparse(self.h, n, ctypes.byref(arr), blob, len(blob), sparse_caps[0], sparse_caps[1]), "entropy_decode_sparse")
-        else:
-            self._chk(self.L.vp8hip_entropy_decode(self.h, first_slot, n, ctypes.byref(arr), blob, len(blob)), "entropy_decode")
+        self._chk(self.L.vp8hip_entropy_decode(self.h, first_slot, n, ctypes.byref(arr), blob, len(blob)), "entropy_decode")
         st = np.zeros(n, np.uint32)
         self._chk(self.L.vp8hip_entropy_status(self.h, n, st.ctypes.data), "entropy_status")
         return st
@@ -488,9 +570,6 @@ class Vp8Hip:
         mv = np.zeros((self.g_mbs() * 16, 2), np.int16)
         self._chk(self.L.vp8hip_ir_fetch_mvs(self.h, slot, mv.ctypes.data), "ir_fetch_mvs")
         return mv
-
-    def ir_expand(self, first_frame, first_slot, n):
-        self._chk(self.L.vp8hip_ir_expand(self.h, first_frame, first_slot, n), "ir_expand")
 
     def ir_fetch(self, slot):
         """The slot's IR as it stands on the device: (mbs uint8[n,64], coef int16[n,400])."""

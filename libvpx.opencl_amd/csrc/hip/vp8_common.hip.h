@@ -7,8 +7,8 @@
 // One frame of work as the kernels see it (device memory, one entry per job of a launch).
 struct DevJob {
     vp8ir_frame_hdr hdr;          // 64 B
-    const vp8ir_mb *mbs;
-    const int16_t  *coef;
+    const vp8ir_mbx *mbx;         // the slot's macroblock records (include/vp8_ir.h, the device form): 128 B each
+    const int16_t  *blocks;       // ... and its block stream: 32 B per block with eob > 1
     const vp8ir_mv *mvs;
     uint8_t        *dst;
     const uint8_t  *ref[4];       // [1..3] = last / golden / alt-ref frame buffers (inter frames); [0] unused
@@ -28,8 +28,7 @@ struct DevGeom {
 
 #define WAVE 64
 
-// Macroblock-tiled scratch frame of the one-MB-row-per-lane pipeline: tile (r, c) at (r * mb_cols + c) *
-// VP8_TILE_BYTES = 16 luma rows x 16 B | 8 U rows x 8 B | 8 V rows x 8 B = three 128-byte lines.
+// Macroblock tiles of the one-MB-row-per-lane pipeline (vp8_keyframe_simt.hip has the layout): three 128-byte lines per macroblock.
 #define VP8_TILE_BYTES 384
 
 // Pointers that come out of a DevJob (i.e. out of memory) are generic to the compiler, which then

@@ -1,16 +1,10 @@
-// Macroblock-tiled scratch frame -> raster frame buffer, optionally with the reference's border extension.
+// Macroblock-window tiles -> raster frame buffer.
 //
-// The one-MB-row-per-lane kernels keep a frame as one 384-byte tile per macroblock (VP8_TILE_BYTES: 16 luma
-// rows of 16 B, 8 U rows of 8 B, 8 V rows of 8 B) so that every lane reads and writes whole 128-byte lines.
-// The frame buffer the rest of the world sees -- reference frames for motion compensation, the frames handed
-// back through vp8hip_frame_download -- is the reference decoder's raster YV12 layout with its 32-pixel
-// borders (vpx_scale/generic/yv12config.c:55-112).  This pass is pure data movement: each workgroup takes one
-// macroblock row of one frame, eight macroblocks per iteration; eight neighbouring threads read the same
-// pixel row of eight tiles and write 128 (luma) / 64 (chroma) contiguous bytes.  With `extend` set it also
-// does vp8_yv12_extend_frame_borders (vpx_scale/generic/yv12extend.c:24-145) on the fly -- the thread that
-// holds the first / last pixels of a row replicates them into the left / right border, the first / last
-// macroblock row replicates its outer pixel row (borders included) 32 (chroma: 16) times -- so a macroblock
-// row leaves the workgroup as one contiguous run of 16 full frame-buffer rows.
+// The one-MB-row-per-lane kernels (vp8_keyframe_simt.hip) leave a frame as 384-byte tiles, one per macroblock and one more per
+// macroblock row, so that every lane writes whole 64-byte half lines.  The frame buffer the rest of the world sees -- reference
+// frames for motion compensation, the frames handed back through vp8hip_frame_download -- is the reference decoder's raster
+// YV12 layout with its 32-pixel borders (vpx_scale/generic/yv12config.c:55-112).  This pass is pure data movement;
+// vp8_extend_kernel (vp8_loopfilter.hip) adds the borders behind it.
 #include "vp8_common.hip.h"
 
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
@@ -18,77 +12,7 @@ typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
 typedef GLOBAL_AS u32x4_t *g_x4p;
 typedef GLOBAL_AS u32x2_t *g_x2p;
 
-extern "C" __global__ void __launch_bounds__(256)
-vp8_detile_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g, int extend)
-{
-    const DevJob &job = jobs[blockIdx.y];
-    const int r = blockIdx.x, cols = g.mb_cols, rows = g.mb_rows;
-    const int t = threadIdx.x;
-    const unsigned char *trow = job.tile + (long)r * cols * VP8_TILE_BYTES;
-    unsigned char *dst = job.dst;
-    const int tile = t & 7;
-    const bool luma = t < 128;
-    const int pl = (t - 128) >> 6;                                  // chroma threads: 0 = U, 1 = V
-    const int row = luma ? t >> 3 : ((t - 128) >> 3) & 7;           // pixel row inside the macroblock
-    const int nrow = luma ? 16 : 8, border = luma ? 32 : 16;
-    const long stride = luma ? g.y_stride : g.uv_stride;
-    unsigned char *prow = dst + (luma ? g.y_off : (pl ? g.v_off : g.u_off)) + (long)(r * nrow + row) * stride;
-    // rows of the top / bottom border this thread's row is copied to (vertical extension)
-    const int vcopies = !extend ? 0 : ((r == 0 && row == 0) || (r == rows - 1 && row == nrow - 1)) ? border : 0;
-    const long vstep = (r == 0 && row == 0) ? -stride : stride;
-    // four iterations' worth of loads are issued before the first store: the pass is latency-bound otherwise
-    for (int cb = 0; cb < cols; cb += 32) {
-        u32x4_t vy[4];
-        u32x2_t vc[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int c = cb + 8 * k + tile;
-            if (c < cols) {
-                const unsigned char *tp = trow + (long)c * VP8_TILE_BYTES;
-                if (luma) vy[k] = *(const GLOBAL_AS u32x4_t *)(tp + 16 * row);
-                else vc[k] = *(const GLOBAL_AS u32x2_t *)(tp + 256 + 64 * pl + 8 * row);
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int c = cb + 8 * k + tile;
-            if (c >= cols) continue;
-            if (luma) {
-                const u32x4_t v = vy[k];
-                unsigned char *p = prow + c * 16;
-                *(g_x4p)p = v;
-                const bool lb = extend && c == 0, rb = extend && c == cols - 1;
-                const unsigned int l = (v.x & 0xff) * 0x01010101u, rr = (v.w >> 24) * 0x01010101u;
-                const u32x4_t lv = { l, l, l, l }, rv = { rr, rr, rr, rr };
-                if (lb) { *(g_x4p)(p - 32) = lv; *(g_x4p)(p - 16) = lv; }
-                if (rb) { *(g_x4p)(p + 16) = rv; *(g_x4p)(p + 32) = rv; }
-                for (int b = 1; b <= vcopies; b++) {
-                    unsigned char *q = p + b * vstep;
-                    *(g_x4p)q = v;
-                    if (lb) { *(g_x4p)(q - 32) = lv; *(g_x4p)(q - 16) = lv; }
-                    if (rb) { *(g_x4p)(q + 16) = rv; *(g_x4p)(q + 32) = rv; }
-                }
-            } else {
-                const u32x2_t v = vc[k];
-                unsigned char *p = prow + c * 8;
-                *(g_x2p)p = v;
-                const bool lb = extend && c == 0, rb = extend && c == cols - 1;
-                const unsigned int l = (v.x & 0xff) * 0x01010101u, rr = (v.y >> 24) * 0x01010101u;
-                const u32x2_t lv = { l, l }, rv = { rr, rr };
-                if (lb) { *(g_x2p)(p - 16) = lv; *(g_x2p)(p - 8) = lv; }
-                if (rb) { *(g_x2p)(p + 8) = rv; *(g_x2p)(p + 16) = rv; }
-                for (int b = 1; b <= vcopies; b++) {
-                    unsigned char *q = p + b * vstep;
-                    *(g_x2p)q = v;
-                    if (lb) { *(g_x2p)(q - 16) = lv; *(g_x2p)(q - 8) = lv; }
-                    if (rb) { *(g_x2p)(q + 8) = rv; *(g_x2p)(q + 16) = rv; }
-                }
-            }
-        }
-    }
-}
-
-// The same pass for the tiles vp8_keyframe_kernel leaves (vp8_keyframe_simt.hip): rows x (cols + 1) tiles per frame; luma rows
+// The tiles vp8_keyframe_kernel / vp8_interframe_kernel leave (vp8_keyframe_simt.hip): rows x (cols + 1) tiles per frame; luma rows
 // 0..11 (chroma rows 0..3) of tile c hold the pixel columns 16c-4 .. 16c+11 (8c-4 .. 8c+3) -- the macroblock's WINDOW, shifted
 // left by the four pixels its left-edge filter still changes --, luma rows 12..15 (chroma 4..7) the macroblock's own columns.
 // Eight neighbouring threads copy the same pixel row of eight tiles: 128 (64) contiguous bytes of a frame row, for the

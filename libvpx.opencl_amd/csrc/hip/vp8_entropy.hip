@@ -8,9 +8,10 @@
 // vp8/decoder/dboolhuff.h:76-120) as decode_mb_row drives them (vp8/decoder/decodframe.c:293-470: left / above entropy contexts,
 // vp8_reset_mb_tokens_context for skipped macroblocks, eobtotal == 0 turning a macroblock into a skipped one, token partitions
 // taken round robin by macroblock row).  In this repository the same work is csrc/host/vp8_parser.c's read_modes / decode_row,
-// at ~10 ms per 1080p key frame and host core; what the kernels write into a frame's IR slot -- descriptors, coefficients,
-// vectors: include/vp8_ir.h -- is byte for byte what vp8_parser_decode_mbs writes (tests/test_gpu_entropy.py).  The frame header
-// stays on the host (csrc/host/vp8_parser.h: vp8_parser_export_entropy).
+// at ~10 ms per 1080p key frame and host core; what the kernels write into a frame's IR slot is the DEVICE FORM of
+// include/vp8_ir.h -- records, block stream, vectors: what vp8_parser_decode_mbs_compact writes on the host and what the pixel
+// kernels read as it stands (tests/test_gpu_entropy.py).  The frame header stays on the host (csrc/host/vp8_parser.h:
+// vp8_parser_export_entropy).
 //
 // A bool decoder is a serial machine: every decision needs range and window as the decision before left them.  So there is
 // nothing to spread over lanes inside a partition, and a frame is one lane's work from its first macroblock to its last (the
@@ -21,9 +22,9 @@
 // 32-bit window (a 64-bit one is two instructions per shift), the next three bytes of the partition requested when the three
 // before are taken (the request has ~25 decisions to land), probabilities in LDS in rows of 12 bytes read as three words when a
 // row is entered (per-lane tables 289 words apart: consecutive lanes on different banks), the macroblock descriptor and the
-// block being decoded assembled in LDS and written out whole (16-byte stores), and a launch parameter for how many lanes of a
-// wave carry frames.  Two forms of output: the dense IR in the frame's slot, the sparse streams in arenas shared by the launch
-// (vp8_entropy_sparse_kernel: more frames in flight for the same memory).  Integer only; no MFMA.
+// record and the block being decoded assembled in LDS and written out whole (16-byte stores; a block only if it has more than
+// a first coefficient: nothing is written for the zeros of the dense form), and a launch parameter for how many lanes of a
+// wave carry frames.  Integer only; no MFMA.
 #include "vp8_common.hip.h"
 #include "vp8hip.h"
 
@@ -40,7 +41,7 @@ typedef u32 __attribute__((may_alias)) row_t;        // probability rows are wri
 // with one three-word read when the row is entered, not with a byte read in front of every decision.
 #define ENT_ROW 12
 #define ENT_PROB_WORDS 289         // per lane: 96 rows = 288 words, + 1 so that consecutive lanes start on different banks
-#define ENT_DESC_WORDS 17          // 64-byte descriptor + a word of padding
+#define ENT_DESC_WORDS 33          // the macroblock's 128-byte record (vp8ir_mbx) + a word of padding
 #define ENT_BLK_WORDS  8           // the block being decoded
 
 __constant__ uint8_t k_kf_bmode_probs[900] = {
@@ -414,58 +415,18 @@ __device__ __forceinline__ MbModes read_mb_modes_inter(BD &fb, const uint8_t *__
     return m;
 }
 
-// Where a lane's coefficients go.  Dense: the macroblock's 800 bytes in its frame's slot.  Sparse (include/vp8_ir.h: blocks with
-// more than one coded position, 32 bytes each; lone DCs, 2 bytes each; found through vp8ir_mb::sparse_first / dc_first): two
-// arenas shared by the launch, from which a lane takes a chunk at a time (an atomic add per 256 blocks / 1024 DCs; a macroblock's
-// entries stay together, so a chunk with fewer than 25 left is given up) -- a third of the dense form's bytes on the benchmark
-// stream, which is what lets more frames be in flight (vp8hip_entropy_decode_sparse).
-#define ENT_BLOCK_CHUNK 256u
-#define ENT_DC_CHUNK    1024u
-struct SparseOut {
-    u32x4 *blocks; short *dcs;              // the arenas
-    u32 *cursors;                           // [0] blocks handed out, [1] DCs handed out, [2] set when an arena ran out
-    u32 cap_blocks, cap_dcs;
-    u32 b_next, b_left, d_next, d_left;     // the lane's chunks
-};
-__device__ __forceinline__ void sparse_reserve(SparseOut &o)
-{
-    if (o.b_left < 25u) {
-        u32 at = atomicAdd(&o.cursors[0], ENT_BLOCK_CHUNK);
-        if (at + ENT_BLOCK_CHUNK > o.cap_blocks) { o.cursors[2] = 1u; at = 0; }      // (out of arena: the launch is void; stay inside)
-        o.b_next = at; o.b_left = ENT_BLOCK_CHUNK;
-    }
-    if (o.d_left < 25u) {
-        u32 at = atomicAdd(&o.cursors[1], ENT_DC_CHUNK);
-        if (at + ENT_DC_CHUNK > o.cap_dcs) { o.cursors[2] = 1u; at = 0; }
-        o.d_next = at; o.d_left = ENT_DC_CHUNK;
-    }
-}
-// one decoded block (eight words) into the streams: more than one coded position -> a block; a lone first coefficient -> a DC
-// (luma blocks of a macroblock with Y2 start at position 1: theirs is eob 2 and up)
-__device__ __forceinline__ void sparse_emit(SparseOut &o, int e, bool y_after_y2, const u32 (&w)[8])
-{
-    if (e > 1) {
-        o.blocks[2 * (size_t)o.b_next] = (u32x4){ w[0], w[1], w[2], w[3] };
-        o.blocks[2 * (size_t)o.b_next + 1] = (u32x4){ w[4], w[5], w[6], w[7] };
-        o.b_next++; o.b_left--;
-    } else if (e == 1 && !y_after_y2) {
-        o.dcs[o.d_next] = (short)(w[0] & 0xffffu);
-        o.d_next++; o.d_left--;
-    }
-}
-
-// The macroblock's tokens (decode_macroblock, decodframe.c:100-130; vp8_decode_mb_tokens) and its place in the IR: coefficients
-// to out_coef (fifty 16-byte pieces), the descriptor to out_mb (four).  A / lnz: the non-zero flags of the row above at this
-// column and of the macroblock to the left (bits 0..3 Y, 4..5 U, 6..7 V, 8 Y2), updated.  desc / blk: the lane's staging in LDS.
-template <bool SPARSE>
+// The macroblock's tokens (decode_macroblock, decodframe.c:100-130; vp8_decode_mb_tokens) and its place in the IR (the device
+// form, include/vp8_ir.h): the record to out_mb (eight 16-byte pieces); a block with more than a first coefficient to the
+// slot's block stream at index bw, which moves on; the Y2 block and lone first coefficients into the record.  A / lnz: the
+// non-zero flags of the row above at this column and of the macroblock to the left (bits 0..3 Y, 4..5 U, 6..7 V, 8 Y2),
+// updated.  desc / blk: the lane's staging in LDS.
 __device__ __forceinline__ void read_mb_tokens(BD &tb, const uint8_t *__restrict__ data, u32 limit, const MbModes &m, const row_t *probs,
-                                               const row_t *cat, u32 &A, u32 &lnz, u32 *desc, u32 *blk, u32x4 *out_coef, u32x4 *out_mb,
-                                               SparseOut &sp)
+                                               const row_t *cat, u32 &A, u32 &lnz, u32 *desc, u32 *blk, u32x4 *out_blocks, u32 &bw, u32x4 *out_mb)
 {
     const bool has_y2 = m.ymode != VP8IR_B_PRED && m.ymode != VP8IR_SPLITMV;
     int skip = m.skip;
 #pragma unroll
-    for (int i = 0; i < 16; i++) desc[i] = 0;
+    for (int i = 0; i < 32; i++) desc[i] = 0;
     if (m.ymode == VP8IR_B_PRED) {
 #pragma unroll
         for (int w = 0; w < 4; w++) {
@@ -473,19 +434,14 @@ __device__ __forceinline__ void read_mb_tokens(BD &tb, const uint8_t *__restrict
             desc[10 + w] = (four & 15u) | (four >> 4 & 15u) << 8 | (four >> 8 & 15u) << 16 | (four >> 12 & 15u) << 24;
         }
     }
-    if (SPARSE) { sparse_reserve(sp); desc[14] = sp.b_next; desc[15] = sp.d_next; }
+    desc[14] = bw;                                             // vp8ir_mb::sparse_first
     if (skip) {                                                // vp8_reset_mb_tokens_context (detokenize.c:70-85)
         A = has_y2 ? 0u : A & 0x100u;
         lnz = has_y2 ? 0u : lnz & 0x100u;
     } else if (bd_error(tb)) {
         // the partition has run out: no tokens, contexts and skip flag stay, no residual (decodframe.c:119-130)
-        if (!SPARSE) {
-#pragma unroll
-            for (int i = 0; i < 50; i++) out_coef[i] = (u32x4){ 0, 0, 0, 0 };
-        }
     } else {
-        int total = 0, e_y2 = 0;
-        u32 y2w[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };              // (sparse: the Y2 block is decoded first and listed last)
+        int total = 0;
         for (int i = has_y2 ? -1 : 0; i < 24; i++) {
             // block order: Y2 (when there is one), 16 Y, 4 U, 4 V; its place among the 25 of the IR; its context bits
             const int k = i < 0 ? 24 : i;
@@ -502,25 +458,19 @@ __device__ __forceinline__ void read_mb_tokens(BD &tb, const uint8_t *__restrict
             lnz = (lnz & ~(1u << lbit)) | (u32)nz << lbit;
             ((uint8_t *)desc)[8 + k] = (uint8_t)e;
             total += e;
-            if (SPARSE) {
-                u32 w[8];
+            if (i < 0) {                                       // the Y2 block: with the record, whatever it holds (vp8ir_mbx::y2)
 #pragma unroll
-                for (int q = 0; q < 8; q++) w[q] = blk[q];
-                if (i < 0) {
-                    e_y2 = e;
-#pragma unroll
-                    for (int q = 0; q < 8; q++) y2w[q] = w[q];
-                } else
-                    sparse_emit(sp, e, has_y2 && i < 16, w);
-            } else {
-                out_coef[2 * k] = (u32x4){ blk[0], blk[1], blk[2], blk[3] };
-                out_coef[2 * k + 1] = (u32x4){ blk[4], blk[5], blk[6], blk[7] };
+                for (int w = 0; w < 8; w++) desc[16 + w] = blk[w];
+            } else if (e > 1) {
+                out_blocks[2 * (size_t)bw] = (u32x4){ blk[0], blk[1], blk[2], blk[3] };
+                out_blocks[2 * (size_t)bw + 1] = (u32x4){ blk[4], blk[5], blk[6], blk[7] };
+                bw++;
+            } else if (e == 1 && !(has_y2 && i < 16)) {        // a lone first coefficient: y2[k] (no Y2 block), cdc[k - 16]
+                ((unsigned short *)desc)[i < 16 ? 32 + i : 48 + (i - 16)] = (unsigned short)(blk[0] & 0xffffu);
             }
         }
-        if (SPARSE && has_y2) sparse_emit(sp, e_y2, false, y2w);
         if (has_y2) total -= 16;                               // (the sixteen luma blocks started at position 1)
-        else if (!SPARSE) { out_coef[48] = (u32x4){ 0, 0, 0, 0 }; out_coef[49] = (u32x4){ 0, 0, 0, 0 }; }
-        if (total == 0) {                                      // decodframe.c:129: nothing coded after all
+        if (total == 0) {                                      // decodframe.c:129: nothing coded after all (no block, no lone coefficient: the record's are zeros)
             skip = 1;
 #pragma unroll
             for (int w = 2; w < 9; w++) desc[w] = 0;           // (eobs live in bytes 8..32; 33..35 are reserved zeros)
@@ -529,22 +479,21 @@ __device__ __forceinline__ void read_mb_tokens(BD &tb, const uint8_t *__restrict
     desc[0] = (u32)m.ymode | (u32)m.uvmode << 8 | (u32)m.ref << 16 | (u32)((skip ? VP8IR_MB_SKIP : 0) | (m.clamp ? VP8IR_MB_CLAMP : 0)) << 24;
     desc[1] = (u32)m.seg | (u32)m.part << 8;
 #pragma unroll
-    for (int w = 0; w < 4; w++) out_mb[w] = (u32x4){ desc[4 * w], desc[4 * w + 1], desc[4 * w + 2], desc[4 * w + 3] };
+    for (int w = 0; w < 8; w++) out_mb[w] = (u32x4){ desc[4 * w], desc[4 * w + 1], desc[4 * w + 2], desc[4 * w + 3] };
 }
 
 }  // namespace
 
 extern "C" size_t vp8_entropy_lds_bytes(int lpw) { return (size_t)lpw * (ENT_PROB_WORDS + ENT_DESC_WORDS + ENT_BLK_WORDS + 17) * 4; }
 
-// frames: `count` of them; frame f goes to the IR slot at slot_base + (first_slot + f) * slot_bytes (descriptors at o_mbs, dense
-// coefficients at o_coef).  lpw: lanes of each wave that carry a frame (1..64).  scratch: per frame (2 * mb_cols + 64) words
-// (the row above's sub-block modes and non-zero flags per macroblock column, the token partitions' decoder states).
-// (sparse: the descriptors go to arena.mbs, a frame after the other, the coefficients to the arenas of SparseArena; slot_* unused)
-struct SparseArena { u32x4 *mbs; u32x4 *blocks; short *dcs; u32 *cursors; u32 cap_blocks, cap_dcs; };
-template <bool SPARSE>
-__device__ __forceinline__ void entropy_body(const vp8hip_entropy_frame *__restrict__ frames, int count, int lpw, const uint8_t *__restrict__ all_data,
-                                             DevGeom g, size_t data_bytes, char *slot_base, size_t slot_bytes, size_t o_mbs, size_t o_coef, size_t o_mvs,
-                                             int first_slot, u32 *__restrict__ scratch, u32 *__restrict__ status, const SparseArena &arena)
+// frames: `count` of them; frame f goes to the IR slot at slot_base + (first_slot + f) * slot_bytes (records at o_mbx, block
+// stream at o_blocks, vectors at o_mvs).  lpw: lanes of each wave that carry a frame (1..64).  scratch: per frame (8 * mb_cols +
+// 64) words (the row above's sub-block modes and non-zero flags per macroblock column, the token partitions' decoder states,
+// inter frames: the row above's records).
+extern "C" __global__ void __launch_bounds__(64)
+vp8_entropy_kernel(const vp8hip_entropy_frame *__restrict__ frames, int count, int lpw, const uint8_t *__restrict__ all_data, DevGeom g,
+                   size_t data_bytes, char *slot_base, size_t slot_bytes, size_t o_mbx, size_t o_blocks, size_t o_mvs, int first_slot,
+                   u32 *__restrict__ scratch, u32 *__restrict__ status)
 {
     // LDS by lanes that carry a frame (the launch says how much: vp8_entropy_lds_bytes): probabilities, descriptor, block
     extern __shared__ u32 s_dyn[];
@@ -601,13 +550,13 @@ __device__ __forceinline__ void entropy_body(const vp8hip_entropy_frame *__restr
     const ModeParams MP = { F.update_mb_segmentation_map != 0, F.mb_no_coeff_skip != 0, F.prob_skip_false, F.segment_tree_probs[0],
                             F.segment_tree_probs[1], F.segment_tree_probs[2] };
     char *slot = slot_base + slot_bytes * (size_t)(first_slot + f);
-    u32x4 *out_mbs = SPARSE ? arena.mbs + (size_t)f * cols * rows * 4 : (u32x4 *)(slot + o_mbs);
-    u32x4 *out_coef = (u32x4 *)(slot + o_coef);
+    u32x4 *out_mbs = (u32x4 *)(slot + o_mbx);
+    u32x4 *out_blocks = (u32x4 *)(slot + o_blocks);
     u32x4 *out_mvs = (u32x4 *)(slot + o_mvs);
+    u32 bw = 0;                                                        // blocks written to the slot's stream so far
     const InterParams IP = { F.prob_intra, F.prob_last, F.prob_gf, { F.ymode_prob[0], F.ymode_prob[1], F.ymode_prob[2], F.ymode_prob[3] },
                              { F.uvmode_prob[0], F.uvmode_prob[1], F.uvmode_prob[2] },
                              (u32)F.hdr.sign_bias_golden << VP8IR_GOLDEN_FRAME | (u32)F.hdr.sign_bias_alt << VP8IR_ALTREF_FRAME, &F.mvc[0][0] };
-    SparseOut sp = { arena.blocks, arena.dcs, arena.cursors, arena.cap_blocks, arena.cap_dcs, 0, 0, 0, 0 };
     bool bad = false;
 
     for (int r = 0; r < rows; r++) {
@@ -643,7 +592,7 @@ __device__ __forceinline__ void entropy_body(const vp8hip_entropy_frame *__restr
                 abm[c] = above;
             }
             u32 A = anz[c];
-            read_mb_tokens<SPARSE>(tb, data, limit, m, probs, s_cat, A, lnz, desc, blk, out_coef + n * 50, out_mbs + n * 4, sp);
+            read_mb_tokens(tb, data, limit, m, probs, s_cat, A, lnz, desc, blk, out_blocks, bw, out_mbs + n * 8);
             anz[c] = A;
         }
         bad |= bd_error(tb);
@@ -663,26 +612,6 @@ __device__ __forceinline__ void entropy_body(const vp8hip_entropy_frame *__restr
 #endif
 }
 
-extern "C" __global__ void __launch_bounds__(64)
-vp8_entropy_kernel(const vp8hip_entropy_frame *__restrict__ frames, int count, int lpw, const uint8_t *__restrict__ all_data, DevGeom g,
-                   size_t data_bytes, char *slot_base, size_t slot_bytes, size_t o_mbs, size_t o_coef, size_t o_mvs, int first_slot,
-                   u32 *__restrict__ scratch, u32 *__restrict__ status)
-{
-    const SparseArena none = { nullptr, nullptr, nullptr, nullptr, 0, 0 };
-    entropy_body<false>(frames, count, lpw, all_data, g, data_bytes, slot_base, slot_bytes, o_mbs, o_coef, o_mvs, first_slot, scratch, status, none);
-}
-
-// The same into the sparse streams (descriptors: mbs, frame after frame; blocks / dcs: the launch's arenas; cursors: three words,
-// zeroed by the caller, the third set when an arena ran out -- the launch's output is void then).
-extern "C" __global__ void __launch_bounds__(64)
-vp8_entropy_sparse_kernel(const vp8hip_entropy_frame *__restrict__ frames, int count, int lpw, const uint8_t *__restrict__ all_data, DevGeom g,
-                          size_t data_bytes, u32 *__restrict__ scratch, u32 *__restrict__ status, u32x4 *mbs, u32x4 *blocks, short *dcs,
-                          u32 *cursors, u32 cap_blocks, u32 cap_dcs)
-{
-    const SparseArena arena = { mbs, blocks, dcs, cursors, cap_blocks, cap_dcs };
-    entropy_body<true>(frames, count, lpw, all_data, g, data_bytes, nullptr, 0, 0, 0, 0, 0, scratch, status, arena);
-}
-
 // Frames coded with several token partitions (2, 4 or 8: the encoder's --token-parts; macroblock row r is in partition r mod NP,
 // decodframe.c:1116-1129), a PARTITION per lane.  The partitions of a frame are separate bool-coded streams; what ties them is
 // the entropy context a macroblock takes from the one above it, which belongs to the partition before.  So the NP lanes of a
@@ -690,11 +619,13 @@ vp8_entropy_sparse_kernel(const vp8hip_entropy_frame *__restrict__ frames, int c
 // decoded (row - 1, c) -- like the lanes of the lane-per-row pixel kernels, the non-zero flags of the row above handed over
 // through LDS (a word per macroblock column and frame).  64 / NP frames per wave.  The first partition (the modes: one stream)
 // is decoded first, by each frame's lane 0, into a scratch array the token lanes read (12 bytes per macroblock).
+// Every partition's blocks go to a region of the slot's block stream of its own (the worst case of its rows: the rows' blocks
+// stay together, which is what the device form asks, include/vp8_ir.h).
 // scratch per frame: mb_cols words (the modes' row above) + 3 words per macroblock.  cols <= ENT_PARTS_MAX_COLS.
 #define ENT_PARTS_MAX_COLS 256
 extern "C" __global__ void __launch_bounds__(64)
 vp8_entropy_parts_kernel(const vp8hip_entropy_frame *__restrict__ frames, int count, int np, const uint8_t *__restrict__ all_data, DevGeom g,
-                         size_t data_bytes, char *slot_base, size_t slot_bytes, size_t o_mbs, size_t o_coef, int first_slot,
+                         size_t data_bytes, char *slot_base, size_t slot_bytes, size_t o_mbx, size_t o_blocks, int first_slot,
                          u32 *__restrict__ scratch, u32 *__restrict__ status)
 {
     __shared__ row_t s_probs[32 * ENT_PROB_WORDS];     // per frame (at most 32 frames of two partitions in a wave)
@@ -764,8 +695,11 @@ vp8_entropy_parts_kernel(const vp8hip_entropy_frame *__restrict__ frames, int co
 
     // ---- the tokens: lane `part` takes rows part, part + np, ..., a macroblock behind the lane before it
     char *slot = slot_base + slot_bytes * (size_t)(first_slot + (live ? f : 0));
-    u32x4 *out_mbs = (u32x4 *)(slot + o_mbs);
-    u32x4 *out_coef = (u32x4 *)(slot + o_coef);
+    u32x4 *out_mbs = (u32x4 *)(slot + o_mbx);
+    u32x4 *out_blocks = (u32x4 *)(slot + o_blocks);
+    // rows part, part + np, ...: the partitions before this one own ceil((rows - q) / np) rows each, q < part
+    u32 bw = 0;
+    for (int q = 0; q < part; q++) bw += (u32)((rows - q + np - 1) / np) * (u32)cols * VP8IR_MAX_BLOCKS_PER_MB;
     BD tb;
     tb.value = 0; tb.bits = -8; tb.range = 255; tb.end = F.tok_end[part];
 #ifdef ENT_STATS
@@ -791,8 +725,7 @@ vp8_entropy_parts_kernel(const vp8hip_entropy_frame *__restrict__ frames, int co
             m.ymode = (int)(m0 & 255u); m.uvmode = (int)(m0 >> 8 & 255u); m.seg = (int)(m0 >> 16 & 255u); m.skip = (int)(m0 >> 24);
             m.ref = VP8IR_INTRA_FRAME; m.clamp = 0; m.part = 0;
             m.bm = (u64)mo[1] | (u64)mo[2] << 32;
-            SparseOut none = { nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, 0 };
-            read_mb_tokens<false>(tb, data, limit, m, probs, s_cat, A, lnz, desc, blk, out_coef + n * 50, out_mbs + n * 4, none);
+            read_mb_tokens(tb, data, limit, m, probs, s_cat, A, lnz, desc, blk, out_blocks, bw, out_mbs + n * 8);
             anz[c] = A;
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");

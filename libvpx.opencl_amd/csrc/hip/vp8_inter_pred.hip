@@ -225,11 +225,11 @@ vp8_inter_pred_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g, int
         const DevJob &job = jobs[j];
         if (job.hdr.frame_type == 0) continue;
         const bool bil = job.hdr.version != 0, fullpix = job.hdr.version == 3;
-        g_cu32p mbs = (g_cu32p)job.mbs;
+        g_cu32p mbs = (g_cu32p)job.mbx;
         g_cmvp mvs = (g_cmvp)job.mvs;
         const g_u8p tiles = (g_u8p)job.tile;
         const int mb_l = u * 64 + lane;
-        const u32 w0_l = mb_l < nmb ? mbs[(long)mb_l * 16] : 0u;
+        const u32 w0_l = mb_l < nmb ? mbs[(long)mb_l * VP8IR_MBX_WORDS] : 0u;
         const bool inter_l = ((w0_l >> 16) & 0xff) != VP8IR_INTRA_FRAME;
         const bool split_l = inter_l && (w0_l & 0xff) == VP8IR_SPLITMV;
         const unsigned long long balP = __builtin_amdgcn_ballot_w64(inter_l && !split_l), balS = __builtin_amdgcn_ballot_w64(split_l);

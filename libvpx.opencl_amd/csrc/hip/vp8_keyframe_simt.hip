@@ -133,8 +133,9 @@ __device__ __forceinline__ void frame_levels_inter(const vp8ir_frame_hdr &h, u32
 //   s_stage  [block of the phase][half][lane] 16 B: the owner's coefficients in, residuals out     8192 B
 //   s_queue  owner lane | block in phase << 6 | DC given << 8                 512 B
 //   s_tab    per owner: quantiser (dc | ac << 16)                             256 B
-//   s_y2dc   per owner: the sixteen luma DCs out of the Y2 block, or -- no Y2 block -- the luma blocks' first coefficients (luma)   2048 B
-//   s_desc   [piece][lane] 16 B: the next macroblock's descriptor (luma 5 pieces, chroma 2)   5120 B
+//   s_y2dc   per owner: the sixteen luma DCs out of the Y2 block, or -- no Y2 block -- the luma blocks' lone first coefficients
+//            (vp8ir_mbx::y2); chroma: the eight chroma blocks' lone first coefficients (vp8ir_mbx::cdc)                  2048 B
+//   s_desc   [piece][lane] 16 B: the next macroblock's record (vp8ir_mbx: luma 5 pieces, chroma 3)   5120 B
 //   s_sf     [row][lane]: the last four pixels (filtered, biased) of pixel rows of the macroblock to the left -- luma rows 0..11,
 //            chroma U rows 0..3, V rows 0..3 (the bottom four rows' are in registers: they double as the lane below's context).
 //            Per-lane state read and written once per step and indexed by the block row: in LDS it costs no registers    3072 B
@@ -161,8 +162,8 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
     asm volatile("" : "+v"(one));            // see nz_clear
 
     // ---- per-lane row state; the pointers are valid addresses at all times
-    g_cu32p mbp = (g_cu32p)jobs[0].mbs;         // descriptor of the current macroblock
-    g_cs16p cfp = (g_cs16p)jobs[0].coef;        // its coefficients
+    g_cu32p mbp = (g_cu32p)jobs[0].mbx;         // record of the current macroblock (vp8ir_mbx: VP8IR_MBX_WORDS dwords)
+    g_cs16p bp = (g_cs16p)jobs[0].blocks;       // its first block in the slot's block stream (the blocks of a row follow each other)
     g_u8p tp = (g_u8p)dummy, hp = (g_u8p)dummy; // first tile / first unfiltered line of its macroblock row
     int r = 0;
     u32 dqs[4][2];                              // luma: y1, y2 quantisers per segment (dc | ac << 16); chroma: uv in [s][0]
@@ -203,21 +204,16 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
     // The owner requests the coefficients of the blocks cfb[0..3] of its macroblock that have any (`m4`) into ITS OWN four staging
     // slots (s_stage[block][half][lane]: no look-up stands between knowing the macroblock and the request), and the lanes
     // queue these blocks, behind the n0 already queued, for the transform.
-    // (The slots this kernel decodes hold their coefficients PACKED: the blocks 0..23 of a macroblock that have any stand at the
-    // start of its 800 bytes, in block order -- vp8_ir_pack_kernel --, so that what is fetched is what is used: with a third of
-    // the blocks coded, the dense form touches four of every five 128-byte lines.  rank0: coded blocks of the macroblock in
-    // front of this phase's.)
-    // m4: the phase's coded blocks; f4: those of them with more than a DC (only these are queued for the transform: the owner adds
-    // a lone DC itself -- vp8_dc_only_idct_add_c, idctllm.c:112-137 -- from the block's first coefficient in its slot, or, with a
-    // Y2 block, from the Walsh transform's output, for which nothing is fetched at all)
-    auto queue = [&](g_cs16p cf_mb, const int rank0, const u32 m4, const u32 f4, const u32 dcg, const int n0) {
-        // what is fetched, and where it stands (vp8_ir_pack_kernel): luma -- the blocks with more than a DC (a lone DC comes out of the Y2
-        // block or came with the descriptor); chroma -- the blocks with any coefficient
-        const u32 get4 = LUMA ? f4 : m4, s4 = get4;
+    // (The slot's block stream -- include/vp8_ir.h, the device form -- holds the blocks with eob > 1 and no others, a macroblock's
+    // in block order at cf_mb: what is fetched is what is used.  rank0: such blocks of the macroblock in front of this phase's.)
+    // f4: the phase's blocks with more than a DC: fetched, and queued for the transform.  The owner adds a lone DC itself
+    // (vp8_dc_only_idct_add_c, idctllm.c:112-137) from the first coefficient that came with the macroblock's record, or, with a
+    // Y2 block, from the Walsh transform's output.
+    auto queue = [&](g_cs16p cf_mb, const int rank0, const u32 f4, const u32 dcg, const int n0) {
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            if ((get4 >> i) & 1) {
-                g_cs16p cfb = cf_mb + (rank0 + __builtin_popcount(s4 & ((1u << i) - 1))) * 16;
+            if ((f4 >> i) & 1) {
+                g_cs16p cfb = cf_mb + (rank0 + __builtin_popcount(f4 & ((1u << i) - 1))) * 16;
                 __builtin_amdgcn_global_load_lds((g_cvp)cfb, (lds_vp)(s_stage + i * 512), 16, 0, 0);
                 __builtin_amdgcn_global_load_lds((g_cvp)(cfb + 8), (lds_vp)(s_stage + i * 512 + 256), 16, 0, 0);
             }
@@ -229,7 +225,7 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
             const bool b = (f4 >> i) & 1;
             const unsigned long long bal = __builtin_amdgcn_ballot_w64(b);
             const u32 at = __builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, (u32)n));
-            if (b) s_queue[at] = (unsigned short)((u32)lane | ((u32)i << 6) | (dcg << 8));
+            if (b) s_queue[at] = (unsigned short)((u32)lane | ((u32)i << 6) | ((dcg & 1u) << 8));
             n += __builtin_popcountll(bal);
         }
         q_n = n;
@@ -283,10 +279,12 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rr[0]), "+v"(rr[1]), "+v"(rr[2]), "+v"(rr[3]), "+v"(rr[4]), "+v"(rr[5]), "+v"(rr[6]), "+v"(rr[7]) :: "memory");
     };
 
-    // ---- what the transform needs to know about a macroblock, from its descriptor words (m0: words 0-3, m1: words 4-7) and, luma,
-    // its Y2 block: which of its blocks (luma: 16 bits, chroma: 8) have a residual (`jm`), whether the luma DCs come out of the Y2
-    // block (`dcg`); the lane's entry of s_tab (coefficient pointer, quantiser) and, with a Y2 block, of s_y2dc
-    auto prepare_mb = [&](const u32x4 m0, const u32x4 m1, const u32x4 y2a, const u32x4 y2b, g_cs16p cf, u32 &jm, u32 &dcg, u32 &dq_out) {
+    // ---- what the transform needs to know about a macroblock, from its record (m0: words 0-3, m1: words 4-7; luma: y2a, y2b =
+    // vp8ir_mbx::y2; chroma: y2a = vp8ir_mbx::cdc): which of its blocks (luma: 16 bits, chroma: 8) have a residual (`jm`), whether
+    // the luma DCs come out of the Y2 block (bit 0 of `dcg`); how many blocks it has in the stream (luma: its own are jm's bits
+    // 16..31, the chroma ones' number in dcg's bits 8..12; chroma: the luma ones' number in jm's bits 8..12, its own are bits
+    // 16..23); the lane's entry of s_tab (quantiser) and of s_y2dc
+    auto prepare_mb = [&](const u32x4 m0, const u32x4 m1, const u32x4 y2a, const u32x4 y2b, u32 &jm, u32 &dcg, u32 &dq_out) {
         const u32 w0 = m0.x, w1 = m0.y;
         const int y_mode = w0 & 0xff;
         const bool skip = (w0 >> 24) & VP8IR_MB_SKIP;
@@ -300,7 +298,7 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
         // eobs (detokenize.c:363), a byte per block, 0..16: which blocks have a token at all.  A luma block of a macroblock with
         // Y2 always has its DC (idct_blk.c:20-44, decodframe.c:262-296).
         // Bits 16.. of the result: the blocks with more than a DC (eob >= 2), which alone go through the transform.
-        u32 m = 0;
+        u32 m = 0, nchroma = 0;
         if constexpr (LUMA) {
             const u32 e[4] = { m0.z, m0.w, m1.x, m1.y };
 #pragma unroll
@@ -311,6 +309,8 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
                 m |= (((ge2 * 0x00204081u) >> 21) & 0xfu) << (16 + 4 * q);
             }
             if (has_y2) m |= 0xffffu;
+            // the chroma blocks behind this macroblock's luma blocks in the stream
+            nchroma = __builtin_popcount((m1.z + 0x7e7e7e7eu) & 0x80808080u) + __builtin_popcount((m1.w + 0x7e7e7e7eu) & 0x80808080u);
         } else {
             const u32 e[2] = { m1.z, m1.w };
 #pragma unroll
@@ -324,19 +324,19 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
             const u32 el[4] = { m0.z, m0.w, m1.x, m1.y };
             u32 nl = 0;
 #pragma unroll
-            for (int q = 0; q < 4; q++) nl += __builtin_popcount((el[q] + 0x7e7e7e7eu) & 0x80808080u);       // (eob >= 2: see vp8_ir_pack_kernel)
+            for (int q = 0; q < 4; q++) nl += __builtin_popcount((el[q] + 0x7e7e7e7eu) & 0x80808080u);       // (eob >= 2: the blocks in the stream)
             m |= nl << 8;
         }
         if (skip) m = 0;
         jm = m;
-        dcg = LUMA && has_y2 && !skip;
+        dcg = (LUMA && has_y2 && !skip ? 1u : 0u) | (skip ? 0u : nchroma << 8);
         s_tab[lane] = dq0;
         dq_out = dq0;
         if constexpr (LUMA) {
             // Y2: vp8_dequantize_b + vp8_short_inv_walsh4x4_c (idctllm.c:140-192) -> the 16 luma DCs.  With nothing but a DC
             // coefficient the full transform gives what vp8_short_inv_walsh4x4_1_c gives (decodframe.c:282-285).
-            if (__builtin_amdgcn_ballot_w64(dcg != 0) != 0) {
-                if (dcg) {
+            if (__builtin_amdgcn_ballot_w64((dcg & 1) != 0) != 0) {
+                if (dcg & 1) {
                     const u32 q[8] = { y2a.x, y2a.y, y2a.z, y2a.w, y2b.x, y2b.y, y2b.z, y2b.w };
                     const int fdc = dq1 & 0xffff, fac = dq1 >> 16;
                     int tt[16], dc[16];
@@ -365,23 +365,28 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
                     dst[1] = (u32x4){ o[4], o[5], o[6], o[7] };
                 }
             }
-            // without a Y2 block: block 24's place holds the sixteen luma blocks' first coefficients (vp8_ir_pack_kernel) -- the lone DCs
+            // without a Y2 block: vp8ir_mbx::y2 holds the sixteen luma blocks' lone first coefficients
             if (!has_y2 && !skip) {
                 u32x4 *dst = (u32x4 *)(s_y2dc + lane * 8);
                 dst[0] = y2a;
                 dst[1] = y2b;
             }
+        } else {
+            // the eight chroma blocks' lone first coefficients (vp8ir_mbx::cdc)
+            if (!skip) *(u32x4 *)(s_y2dc + lane * 8) = y2a;
         }
     };
-    // the next macroblock's descriptor pieces, requested into the lane's slots of s_desc (mb: its descriptor, cf: its coefficients)
-    auto request_desc = [&](g_cu32p mb, g_cs16p cf) {
+    // the next macroblock's record (vp8ir_mbx), the pieces this role reads, requested into the lane's slots of s_desc: descriptor
+    // words 0-3, 4-7; luma: the sub-block modes (words 10-13) and y2 (16-23); chroma: cdc (24-27)
+    auto request_desc = [&](g_cu32p mb) {
         __builtin_amdgcn_global_load_lds((g_cvp)mb, (lds_vp)(s_desc), 16, 0, 0);
         __builtin_amdgcn_global_load_lds((g_cvp)(mb + 4), (lds_vp)(s_desc + 256), 16, 0, 0);
         if constexpr (LUMA) {
             __builtin_amdgcn_global_load_lds((g_cvp)(mb + 10), (lds_vp)(s_desc + 512), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((g_cvp)(cf + 384), (lds_vp)(s_desc + 768), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((g_cvp)(cf + 392), (lds_vp)(s_desc + 1024), 16, 0, 0);
-        }
+            __builtin_amdgcn_global_load_lds((g_cvp)(mb + 16), (lds_vp)(s_desc + 768), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((g_cvp)(mb + 20), (lds_vp)(s_desc + 1024), 16, 0, 0);
+        } else
+            __builtin_amdgcn_global_load_lds((g_cvp)(mb + 24), (lds_vp)(s_desc + 512), 16, 0, 0);
     };
 
     int c = -2 * pos - 1, V = pos;
@@ -427,28 +432,30 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
             } else
                 frame_levels(h, lv_plain, lv_bpred);
             sharp = h.sharpness_level; simple = h.filter_type == 1;
-            mbp = (g_cu32p)(job->mbs + (long)r * cols);
-            cfp = (g_cs16p)(job->coef + (long)r * cols * VP8IR_COEF_PER_MB);
+            mbp = (g_cu32p)(job->mbx + (long)r * cols);
             tp = (g_u8p)(job->tile + (long)r * rowbytes);
             hp = (g_u8p)(job->tile + (long)rows * rowbytes + (long)r * hrow);
             l0[0] = l0[1] = l0[2] = l0[3] = 0x81818181u;    // left border 129 (setupintrarecon.c:15-32)
             u32x4 m0 = *(g_cu32x4p)mbp, m1 = *(g_cu32x4p)(mbp + 4), b0 = { 0, 0, 0, 0 }, y2a = { 0, 0, 0, 0 }, y2b = { 0, 0, 0, 0 };
-            if constexpr (LUMA) { b0 = *(g_cu32x4p)(mbp + 10); y2a = *(g_cu32x4p)(cfp + 384); y2b = *(g_cu32x4p)(cfp + 392); }
+            u32 first = mbp[14];                // vp8ir_mb::sparse_first: where the row's blocks begin
+            if constexpr (LUMA) { b0 = *(g_cu32x4p)(mbp + 10); y2a = *(g_cu32x4p)(mbp + 16); y2b = *(g_cu32x4p)(mbp + 20); }
+            else y2a = *(g_cu32x4p)(mbp + 24);
             // consumed here, so that no pending load leaves the branch
-            asm volatile("" : "+v"(m0), "+v"(m1), "+v"(b0), "+v"(y2a), "+v"(y2b));
+            asm volatile("" : "+v"(m0), "+v"(m1), "+v"(b0), "+v"(y2a), "+v"(y2b), "+v"(first));
+            bp = (g_cs16p)(job->blocks + (long)first * 16);
             cur_w0 = m0.x; cur_w1 = m0.y; bm = b0;
-            prepare_mb(m0, m1, y2a, y2b, cfp, jm, dc_given, cur_dq);
+            prepare_mb(m0, m1, y2a, y2b, jm, dc_given, cur_dq);
         }
         if (!act) { jm = 0; dc_given = 0; }
         // the row starters' first phase joins the queue behind the blocks the others had transformed at the end of the last step
         if (__builtin_amdgcn_ballot_w64(late) != 0) {
             const int n0 = q_n;
-            queue(cfp, LUMA ? 0 : (int)((jm >> 8) & 0x1f), late ? jm & 0xf : 0, late ? (jm >> 16) & 0xf : 0, dc_given, n0);
+            queue(bp, LUMA ? 0 : (int)((jm >> 8) & 0x1f), late ? (jm >> 16) & 0xf : 0, dc_given, n0);
             drain(LUMA ? 0 : 16, n0, 0);
         }
         // the descriptor of the macroblock after this one: on its way from here (a lane at the end of its row, or idle, fetches
         // whatever follows: never used)
-        request_desc(mbp + 16, cfp + VP8IR_COEF_PER_MB);
+        request_desc(mbp + VP8IR_MBX_WORDS);
         STAMP(1)
         const bool top = r == 0;
         const bool more = act && c + 1 < cols;
@@ -583,8 +590,7 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
                 if (by < 3) {
                     fetch(rr);
                     STAMP(8)
-                    queue(cfp, __builtin_popcount((jm >> 16) & 0xffffu & ((16u << (4 * by)) - 1)), (jm >> (4 * by + 4)) & 0xf,
-                          (jm >> (4 * by + 20)) & 0xf, dc_given, 0);
+                    queue(bp, __builtin_popcount((jm >> 16) & 0xffffu & ((16u << (4 * by)) - 1)), (jm >> (4 * by + 20)) & 0xf, dc_given, 0);
                 } else {
                     // (all of this macroblock's phases have been transformed: its entries of s_tab / s_y2dc are free)
                     u32 n_jm = 0, n_dcg = 0;
@@ -595,14 +601,16 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
                                      "ds_read_b128 %2, %4 offset:3072\n\tds_read_b128 %3, %4 offset:4096\n\ts_waitcnt lgkmcnt(0)"
                                      : "=&v"(m0), "=&v"(m1), "=&v"(y2a), "=&v"(y2b) : "v"(desc_lane) : "memory");
                         u32 n_dq = 0;
-                        if (more) prepare_mb(m0, m1, y2a, y2b, cfp + VP8IR_COEF_PER_MB, n_jm, n_dcg, n_dq);
+                        if (more) prepare_mb(m0, m1, y2a, y2b, n_jm, n_dcg, n_dq);
                         nx_w0 = m0.x; nx_w1 = m0.y; nx_jm = n_jm; nx_dcg = n_dcg; nx_dq = n_dq;
                     }
                     asm volatile("ds_read_b128 %0, %1 offset:2048\n\ts_waitcnt lgkmcnt(0)" : "=&v"(nx_bm) : "v"(desc_lane) : "memory");
                     STAMP(9)
                     fetch(rr);
                     STAMP(8)
-                    queue(cfp + VP8IR_COEF_PER_MB, 0, n_jm & 0xf, (n_jm >> 16) & 0xf, n_dcg, 0);
+                    // (this macroblock's blocks in the stream are behind us: the next one's follow them)
+                    bp += (__builtin_popcount(jm >> 16) + (int)((dc_given >> 8) & 0x1f)) * 16;
+                    queue(bp, 0, (n_jm >> 16) & 0xf, n_dcg, 0);
                 }
                 STAMP(3)
                 const u32 lcur = l0[0];
@@ -632,7 +640,7 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
                                 // a lone DC: (short)(q[0] * dq[0]) (idct_blk.c:34), or the Y2 block's; a1 = (dc + 4) >> 3 on every pixel
                                 const u32 y2w = k < 2 ? y2w0 : y2w1;
                                 const int raw = (short)(y2w >> (16 * (k & 1)));
-                                const int dc = dc_given ? raw : (short)(raw * (short)(cur_dq & 0xffff));
+                                const int dc = (dc_given & 1) ? raw : (short)(raw * (short)(cur_dq & 0xffff));
                                 const u32 a1 = (u32)((dc + 4) >> 3) & 0xffffu, a2 = a1 | (a1 << 16);
                                 ra = rb = (u32x4){ a2, a2, a2, a2 };
                             }
@@ -728,18 +736,22 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
                 u32x4 rr[8];
                 fetch(rr);
                 const u32 rmg = jm >> (4 * pl), rmf = jm >> (16 + 4 * pl);
-                if (pl == 0) queue(cfp, (int)((jm >> 8) & 0x1f) + __builtin_popcount(jm & 0xf), (jm >> 4) & 0xf, (jm >> 20) & 0xf, 0, 0);
+                // the plane's four lone first coefficients (read before the next macroblock's take their place)
+                const u32 cdc0 = s_y2dc[lane * 8 + 2 * pl], cdc1 = s_y2dc[lane * 8 + 2 * pl + 1];
+                if (pl == 0) queue(bp, (int)((jm >> 8) & 0x1f) + __builtin_popcount((jm >> 16) & 0xf), (jm >> 20) & 0xf, 0, 0);
                 else {
                     u32 n_jm = 0, n_dcg = 0;
                     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");          // (the descriptor: U's four row stores are younger)
                     u32x4 m0, m1;
-                    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024\n\ts_waitcnt lgkmcnt(0)"
-                                 : "=&v"(m0), "=&v"(m1) : "v"(desc_lane) : "memory");
+                    u32x4 cd;
+                    asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:1024\n\tds_read_b128 %2, %3 offset:2048\n\ts_waitcnt lgkmcnt(0)"
+                                 : "=&v"(m0), "=&v"(m1), "=&v"(cd) : "v"(desc_lane) : "memory");
                     const u32x4 z = { 0, 0, 0, 0 };
                     u32 n_dq = 0;
-                    if (more) prepare_mb(m0, m1, z, z, cfp + VP8IR_COEF_PER_MB, n_jm, n_dcg, n_dq);
+                    if (more) prepare_mb(m0, m1, cd, z, n_jm, n_dcg, n_dq);
                     nx_w0 = m0.x; nx_w1 = m0.y; nx_jm = n_jm; nx_dcg = 0; nx_dq = n_dq;
-                    queue(cfp + VP8IR_COEF_PER_MB, (int)((n_jm >> 8) & 0x1f), n_jm & 0xf, (n_jm >> 16) & 0xf, 0, 0);
+                    bp += ((int)((jm >> 8) & 0x1f) + __builtin_popcount((jm >> 16) & 0xff)) * 16;
+                    queue(bp, (int)((n_jm >> 8) & 0x1f), (n_jm >> 16) & 0xf, 0, 0);
                 }
                 STAMP(3)
                 const u32 aC0 = aA[0], aC1 = aA[1], lC0 = l0[0], lC1 = l0[1];
@@ -766,7 +778,8 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
                         if (hasr) {
                             u32x4 ra = rr[2 * k], rb = rr[2 * k + 1];
                             if (!((rmf >> k) & 1)) {          // a lone DC
-                                const int dc = (short)((short)ra.x * (short)(cur_dq & 0xffff));
+                                const u32 cw = k < 2 ? cdc0 : cdc1;
+                                const int dc = (short)((short)(cw >> (16 * (k & 1))) * (short)(cur_dq & 0xffff));
                                 const u32 a1 = (u32)((dc + 4) >> 3) & 0xffffu, a2 = a1 | (a1 << 16);
                                 ra = rb = (u32x4){ a2, a2, a2, a2 };
                             }
@@ -856,7 +869,7 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
             h1[0] = act ? bA[0] : h1[0]; h1[1] = act ? bA[1] : h1[1]; h1[2] = act ? bB[0] : h1[2]; h1[3] = act ? bB[1] : h1[3];
             prevLast = lastU; prevLast2 = lastV;
         }
-        if (act) { mbp += 16; cfp += VP8IR_COEF_PER_MB; }
+        if (act) mbp += VP8IR_MBX_WORDS;
         p_more = more;
         STAMP(7)
     }

@@ -183,9 +183,9 @@ __device__ __forceinline__ void lf_body(const DevJob *__restrict__ jobs, int njo
         const bool simple = (half ? hB.filter_type : hA.filter_type) != 0;
         const int sharp = half ? hB.sharpness_level : hA.sharpness_level;
         const int ftype = half ? vp8ir_lf_frame_type(&hB) : vp8ir_lf_frame_type(&hA);
-        const vp8ir_mb *mbs = half ? jobB.mbs : jobA.mbs;
+        const vp8ir_mbx *mbs = half ? jobB.mbx : jobA.mbx;
         uint8_t *dst = half ? jobB.dst : jobA.dst;
-        g_cu32p mbrow = (g_cu32p)(mbs + (long)r * cols);              // 16 dwords per MB
+        g_cu32p mbrow = (g_cu32p)(mbs + (long)r * cols);              // VP8IR_MBX_WORDS dwords per MB
         g_u8p fY = (g_u8p)(dst + g.y_off + (long)r * 16 * g.y_stride);
         g_u8p fU = (g_u8p)(dst + g.u_off + (long)r * 8 * g.uv_stride);
         g_u8p fV = (g_u8p)(dst + g.v_off + (long)r * 8 * g.uv_stride);
@@ -290,7 +290,7 @@ __device__ __forceinline__ void lf_body(const DevJob *__restrict__ jobs, int njo
             else { const u32x2 t = *(g_cu32x2p)(frow + c * 8); v.x = t.x; v.y = t.y; }
             return v;
         };
-        auto load_desc = [&](int c) -> u32 { return hl < 2 ? mbrow[c * 16 + hl] : 0u; };
+        auto load_desc = [&](int c) -> u32 { return hl < 2 ? mbrow[c * VP8IR_MBX_WORDS + hl] : 0u; };
         // descriptor fields and filter level of this half's MB (lanes 0,1 / 32,33 hold the dwords)
         auto mb_fields = [&](const u32 d, u32 &w0, u32 &w1, int &level) {
             const u32 a0 = (u32)__builtin_amdgcn_readlane((int)d, 0), a1 = (u32)__builtin_amdgcn_readlane((int)d, 1);

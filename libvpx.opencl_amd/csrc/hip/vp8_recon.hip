@@ -193,6 +193,37 @@ __device__ __forceinline__ MbLanes mb_lanes(int hl)
     return m;
 }
 struct Coefs { coef4 y0, y1, c, y2; };     // luma blocks 0..7, 8..15, chroma, Y2 (hl < 4)
+
+// A lane's coefficients out of the DEVICE FORM of the IR (include/vp8_ir.h: vp8ir_mbx + the slot's block stream): block column
+// hl & 3 of the luma blocks hl >> 2 and 8 + (hl >> 2), of chroma block 16 + (hl >> 2), and (hl < 4) of the Y2 block.  A block with
+// eob > 1 stands in the stream, behind the macroblock's such blocks before it; one with a lone first coefficient has it in the
+// record (y2[k] in a macroblock without a Y2 block, cdc[k]); any other is zeros.  w: the descriptor's eob words (dwords 2..7)
+// and sparse_first (dword 14); rec: the record; blocks: the slot's stream.
+struct MbWords { u32 e[6]; u32 first; };
+__device__ __forceinline__ Coefs load_coefs_dev(g_cu32p rec, g_cs16p blocks, const MbWords &w, bool has_y2, int hl)
+{
+    u32 ge2 = 0;
+#pragma unroll
+    for (int q = 0; q < 6; q++) ge2 |= ((((((w.e[q] + 0x7e7e7e7eu) & 0x80808080u) >> 7) * 0x00204081u) >> 21) & 0xfu) << (4 * q);
+    const int b = hl >> 2, col = hl & 3;
+    const GLOBAL_AS unsigned short *rec16 = (const GLOBAL_AS unsigned short *)rec;
+    g_cs16p base = blocks + (long)w.first * 16 + col * 4;
+    u32 l0 = 0, l1 = 0, lc = 0;
+    if (col == 0) {
+        if (!has_y2) { l0 = rec16[32 + b]; l1 = rec16[40 + b]; }
+        lc = rec16[48 + b];
+    }
+    auto blk = [&](int k, u32 lone) -> coef4 {
+        coef4 r = { lone, 0 };
+        if ((ge2 >> k) & 1) r = *(g_cs4p)(base + __builtin_popcount(ge2 & ((1u << k) - 1)) * 16);
+        return r;
+    };
+    Coefs v;
+    v.y0 = blk(b, l0); v.y1 = blk(b + 8, l1); v.c = blk(16 + b, lc);
+    v.y2 = (coef4){ 0, 0 };
+    if (hl < 4) v.y2 = *(g_cs4p)((g_cs16p)rec + 32 + hl * 4);
+    return v;
+}
 struct Mv2 { u32 a, b; };                  // the MVs of a lane's two luma segments
 
 // The residual of a macroblock (dequantisation, Y2 WHT, inverse DCT: decodframe.c:239-296, idctllm.c), by the 32 lanes
@@ -496,30 +527,17 @@ __device__ __forceinline__ void recon_body(const DevJob *__restrict__ jobs, int 
         // XCU: granule rows of this frame: mine (row r) and the one above
         g_u64p gran_mine = (g_u64p)(gran_base + ((long)(pair * 2 + half) * rows + r) * GS);
         g_u64p gran_above = gran_mine - GS;
-        const vp8ir_mb *mbs = half ? jobB.mbs : jobA.mbs;
-        const int16_t *coefs = half ? jobB.coef : jobA.coef;
+        const vp8ir_mbx *mbs = half ? jobB.mbx : jobA.mbx;
+        g_cs16p blocks = (g_cs16p)(half ? jobB.blocks : jobA.blocks);
         const vp8ir_mv *mvs = half ? jobB.mvs : jobA.mvs;
         uint8_t *dst = half ? jobB.dst : jobA.dst;
         g_u8p tile_out = (g_u8p)(half ? jobB.tile : jobA.tile);
-        g_cu32p mbrow = (g_cu32p)(mbs + (long)r * cols);          // 16 dwords per MB
-        g_cs16p coefrow = (g_cs16p)(coefs + (long)r * cols * VP8IR_COEF_PER_MB);
+        g_cu32p mbrow = (g_cu32p)(mbs + (long)r * cols);          // VP8IR_MBX_WORDS dwords per MB, the descriptor in the first 16
         g_u8p dY = (g_u8p)(dst + g.y_off + (long)r * 16 * g.y_stride);
         g_u8p dU = (g_u8p)(dst + g.u_off + (long)r * 8 * g.uv_stride);
         g_u8p dV = (g_u8p)(dst + g.v_off + (long)r * 8 * g.uv_stride);
 
-        auto load_coefs = [&](int c, bool skipped) __attribute__((always_inline)) -> Coefs {
-            g_cs16p q = coefrow + (long)c * VP8IR_COEF_PER_MB;
-            Coefs v;
-            v.y0 = v.y1 = v.c = v.y2 = (coef4){ 0, 0 };
-            if (!skipped) {                       // a skipped MB's coefficients are undefined and never read
-                v.y0 = *(g_cs4p)(q + hl * 4);
-                v.y1 = *(g_cs4p)(q + 128 + hl * 4);
-                v.c = *(g_cs4p)(q + 256 + hl * 4);
-                if (hl < 4) v.y2 = *(g_cs4p)(q + 384 + hl * 4);
-            }
-            return v;
-        };
-        auto load_desc = [&](int c) -> u32 { return hl < 16 ? mbrow[c * 16 + hl] : 0u; };
+        auto load_desc = [&](int c) -> u32 { return hl < 16 ? mbrow[c * VP8IR_MBX_WORDS + hl] : 0u; };
         // the two luma MVs of this lane's segments (blocks hl>>2 and 8 + hl>>2), fetched one macroblock ahead so that
         // the reference fetch does not wait for them (inter frames only; a non-split MB has its MV in all 16 entries)
         g_cu32p mvrow = (g_cu32p)(mvs + (long)r * cols * 16);
@@ -532,6 +550,18 @@ __device__ __forceinline__ void recon_body(const DevJob *__restrict__ jobs, int 
         auto half_sel = [&](u32 d, int idx) -> u32 {     // dword `idx` of this half's MB descriptor
             const u32 a = (u32)__builtin_amdgcn_readlane((int)d, idx), b = (u32)__builtin_amdgcn_readlane((int)d, 32 + idx);
             return half ? b : a;
+        };
+        // the coefficients of macroblock c, whose descriptor is d (a skipped macroblock has none)
+        auto load_coefs = [&](int c, u32 d, bool skipped) __attribute__((always_inline)) -> Coefs {
+            Coefs v;
+            v.y0 = v.y1 = v.c = v.y2 = (coef4){ 0, 0 };
+            MbWords w;
+#pragma unroll
+            for (int q = 0; q < 6; q++) w.e[q] = half_sel(d, 2 + q);
+            w.first = half_sel(d, 14);
+            const int ym = half_sel(d, 0) & 0xff;
+            if (!skipped) v = load_coefs_dev(mbrow + (long)c * VP8IR_MBX_WORDS, blocks, w, ym != VP8IR_B_PRED && ym != VP8IR_SPLITMV, hl);
+            return v;
         };
 
         // ------------------------------------------------------------------------------------------
@@ -748,7 +778,7 @@ __device__ __forceinline__ void recon_body(const DevJob *__restrict__ jobs, int 
             return ((w0 >> 24) & VP8IR_MB_SKIP) || (INTER_DONE && ((w0 >> 16) & 0xff) != VP8IR_INTRA_FRAME);
         };
         u32 dA = load_desc(0), dB = cols > 1 ? load_desc(1) : 0u;
-        Coefs qA = load_coefs(0, skipped(dA)), qB = qA;
+        Coefs qA = load_coefs(0, dA, skipped(dA)), qB = qA;
         Mv2 mA = load_mv(0), mB = mA;
         for (int c0 = 0; c0 < cols; c0 += 2) {
 #pragma unroll
@@ -760,7 +790,7 @@ __device__ __forceinline__ void recon_body(const DevJob *__restrict__ jobs, int 
                     if (c + 2 < cols) { if (u) dB = load_desc(c + 2); else dA = load_desc(c + 2); }
                     if (c + 1 < cols) {
                         const bool sk = skipped(dn);
-                        if (u) { qA = load_coefs(c + 1, sk); mA = load_mv(c + 1); } else { qB = load_coefs(c + 1, sk); mB = load_mv(c + 1); }
+                        if (u) { qA = load_coefs(c + 1, dn, sk); mA = load_mv(c + 1); } else { qB = load_coefs(c + 1, dn, sk); mB = load_mv(c + 1); }
                     }
                     process(c, d, u ? qB : qA, u ? mB : mA);
                 }
@@ -831,7 +861,7 @@ vp8_inter_mb_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g, unsig
         const bool valid = n < nmb;
         const int nn = valid ? n : nmb - 1;
         const int r = nn / cols, c = nn - r * cols;
-        const u32 d = hl < 16 ? ((g_cu32p)(job.mbs + nn))[hl] : 0u;
+        const u32 d = hl < 16 ? ((g_cu32p)(job.mbx + nn))[hl] : 0u;
         auto half_sel = [&](int idx) -> u32 {
             const u32 a = (u32)__builtin_amdgcn_readlane((int)d, idx), b = (u32)__builtin_amdgcn_readlane((int)d, 32 + idx);
             return half ? b : a;
@@ -850,11 +880,11 @@ vp8_inter_mb_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g, unsig
         if (inter) {
             mv2.a = mv[hl >> 2]; mv2.b = mv[8 + (hl >> 2)];
             if (!skip) {
-                g_cs16p cq = (g_cs16p)(job.coef + (long)nn * VP8IR_COEF_PER_MB);
-                q.y0 = *(g_cs4p)(cq + hl * 4);
-                q.y1 = *(g_cs4p)(cq + 128 + hl * 4);
-                q.c = *(g_cs4p)(cq + 256 + hl * 4);
-                if (hl < 4) q.y2 = *(g_cs4p)(cq + 384 + hl * 4);
+                MbWords w;
+#pragma unroll
+                for (int qq = 0; qq < 6; qq++) w.e[qq] = half_sel(2 + qq);
+                w.first = half_sel(14);
+                q = load_coefs_dev((g_cu32p)(job.mbx + nn), (g_cs16p)job.blocks, w, has_y2, hl);
             }
         }
         int rY0[4], rY1[4], rC[4];

@@ -1,0 +1,116 @@
+// vp8hip_entropy_decode (include/vp8hip.h): the launch of the device's entropy decoder (vp8_entropy.hip), which writes the
+// frames' IR slots in the device form of include/vp8_ir.h -- the form the pixel kernels read, nothing in between.
+#include "vp8hip_ctx.hip.h"
+
+extern "C" __global__ void vp8_entropy_kernel(const vp8hip_entropy_frame *frames, int count, int lpw, const uint8_t *data, DevGeom g,
+                                              size_t data_bytes, char *slot_base, size_t slot_bytes, size_t o_mbx, size_t o_blocks, size_t o_mvs,
+                                              int first_slot, unsigned int *scratch, unsigned int *status);
+extern "C" size_t vp8_entropy_lds_bytes(int lpw);
+extern "C" __global__ void vp8_entropy_parts_kernel(const vp8hip_entropy_frame *frames, int count, int np, const uint8_t *data, DevGeom g,
+                                                    size_t data_bytes, char *slot_base, size_t slot_bytes, size_t o_mbx, size_t o_blocks,
+                                                    int first_slot, unsigned int *scratch, unsigned int *status);
+
+extern "C" int vp8hip_entropy_decode(vp8hip_ctx *c, int first_slot, int count, const vp8hip_entropy_frame *frames, const uint8_t *data,
+                                     size_t data_bytes)
+{
+    bool any_inter = false;
+    if (!c || !frames || !data || count < 1 || first_slot < 0 || first_slot + count > (int)c->slots.size())
+        return fail(c, -2, "vp8hip_entropy_decode: bad arguments");
+    for (int i = 0; i < count; i++) {
+        const vp8hip_entropy_frame &f = frames[i];
+        const vp8ir_frame_hdr &h = f.hdr;
+        if (h.frame_type != 0) any_inter = true;
+        if (h.mb_cols != c->dg.mb_cols || h.mb_rows != c->dg.mb_rows)
+            return fail(c, -2, "vp8hip_entropy_decode: frame %d is %dx%d MBs, context configured for %dx%d", i, h.mb_cols, h.mb_rows,
+                        c->dg.mb_cols, c->dg.mb_rows);
+        bool ok = (f.num_tok == 1 || f.num_tok == 2 || f.num_tok == 4 || f.num_tok == 8) && f.data_off <= data_bytes &&
+                  f.first_pos <= f.first_end && f.first_end <= data_bytes - f.data_off && data_bytes - f.data_off >= f.first_end && f.first_range >= 128 && f.first_range <= 255 &&
+                  f.first_bits >= -8 && f.first_bits <= 24;
+        for (unsigned k = 0; ok && k < f.num_tok; k++) ok = f.tok_pos[k] <= f.tok_end[k] && f.tok_end[k] <= data_bytes - f.data_off;
+        if (!ok) return fail(c, -2, "vp8hip_entropy_decode: frame %d: partitions outside the data, or no decoder state", i);
+    }
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t fbytes = (size_t)count * sizeof(vp8hip_entropy_frame);
+    // frames coded with several token partitions, all with the same number: a partition per lane (vp8_entropy_parts_kernel)
+    int np = (int)frames[0].num_tok;
+    for (int i = 1; i < count && np > 1; i++) if ((int)frames[i].num_tok != np) np = 1;
+    // (the lanes of a frame follow each other a macroblock apart and lane 0 follows the last one into the next round of rows: rows
+    // at least as long as the partitions are many; the row above's flags of a wave's frames in 16 KB of LDS)
+    if (!c->ent_tables_loaded) {
+        c->ent_tables_loaded = true;
+        HIPCHK(c, hipFuncSetAttribute((const void *)vp8_entropy_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)vp8_entropy_lds_bytes(64)));
+        const char *e = getenv("VP8HIP_ENTROPY_LANES");     // lanes of a wave that carry a frame (a tuning knob: read once)
+        c->ent_lpw = e ? atoi(e) : 0;
+        const char *e2 = getenv("VP8HIP_ENTROPY_PARTS");   // 0: a frame per lane whatever the number of token partitions
+        c->ent_parts_off = e2 && atoi(e2) == 0;
+        if (c->ent_lpw < 1 || c->ent_lpw > 64) c->ent_lpw = 0;
+    }
+    if (c->dg.mb_cols < np || c->dg.mb_cols > 256 || c->dg.mb_cols * (64 / np) > 4096 || c->ent_parts_off || any_inter) np = 1;
+    const size_t swords = np > 1 ? (size_t)count * ((size_t)c->dg.mb_cols + 3 * (size_t)c->nmb) : (size_t)count * (8 * (size_t)c->dg.mb_cols + 64);
+    if (fbytes > c->ent_frames_cap) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (c->d_ent_frames) (void)hipFree(c->d_ent_frames);
+        if (c->d_ent_status) (void)hipFree(c->d_ent_status);
+        c->d_ent_frames = nullptr; c->d_ent_status = nullptr; c->ent_frames_cap = 0;
+        HIPCHK(c, hipMalloc((void **)&c->d_ent_frames, fbytes));
+        HIPCHK(c, hipMalloc((void **)&c->d_ent_status, (size_t)count * 4));
+        c->ent_frames_cap = fbytes;
+    }
+    if (data_bytes + 16 > c->ent_data_cap) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (c->d_ent_data) (void)hipFree(c->d_ent_data);
+        c->d_ent_data = nullptr; c->ent_data_cap = 0;
+        const size_t cap = data_bytes + data_bytes / 4 + 4096;
+        HIPCHK(c, hipMalloc((void **)&c->d_ent_data, cap));
+        c->ent_data_cap = cap;
+    }
+    if (swords > c->ent_scratch_cap) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (c->d_ent_scratch) (void)hipFree(c->d_ent_scratch);
+        c->d_ent_scratch = nullptr; c->ent_scratch_cap = 0;
+        HIPCHK(c, hipMalloc((void **)&c->d_ent_scratch, swords * 4));
+        c->ent_scratch_cap = swords;
+    }
+    HIPCHK(c, hipMemcpyAsync(c->d_ent_frames, frames, fbytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_ent_data, data, data_bytes, hipMemcpyHostToDevice, c->stream));
+    for (int i = 0; i < count; i++) {
+        Slot &s = c->slots[first_slot + i];
+        s.hdr_copy = frames[i].hdr;
+        s.nblocks = NBLOCKS_UNKNOWN;           // (the host never sees how many blocks the device wrote)
+    }
+    // Lanes per wave.  The lanes of a wave go through the macroblocks together, each macroblock taking as long as the slowest
+    // lane's, so fewer frames to a wave waste less -- while there are CUs without a wave; several waves to a CU slow each other
+    // down again (8192 1080p frames per launch, frames per second over a run: 64 lanes 15.4 k, 32: 16.9-17.9 k, 16: 16.1 k, 8: 12.7 k;
+    // 4096 per launch with every frame downloaded: the same 9 k at 16 and 64)
+    int lpw = c->ent_lpw;
+    if (!lpw) lpw = (count + 31) / 32 <= c->num_cu ? 32 : 64;
+    if (np > 1)
+        hipLaunchKernelGGL(vp8_entropy_parts_kernel, dim3((unsigned)((count + 64 / np - 1) / (64 / np))), dim3(64), 0, c->stream,
+                           (const vp8hip_entropy_frame *)c->d_ent_frames, count, np, (const uint8_t *)c->d_ent_data, c->dg, data_bytes,
+                           c->slot_block_dev, c->slot_bytes, c->o_mbx, c->o_blocks, first_slot, c->d_ent_scratch, c->d_ent_status);
+    else
+        hipLaunchKernelGGL(vp8_entropy_kernel, dim3((unsigned)((count + lpw - 1) / lpw)), dim3(64), vp8_entropy_lds_bytes(lpw), c->stream,
+                           (const vp8hip_entropy_frame *)c->d_ent_frames, count, lpw, (const uint8_t *)c->d_ent_data, c->dg, data_bytes,
+                           c->slot_block_dev, c->slot_bytes, c->o_mbx, c->o_blocks, c->o_mvs, first_slot, c->d_ent_scratch, c->d_ent_status);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
+extern "C" int vp8hip_entropy_status(vp8hip_ctx *c, int count, uint32_t *status)
+{
+    if (!c || !status || count < 1 || (size_t)count * sizeof(vp8hip_entropy_frame) > c->ent_frames_cap)
+        return fail(c, -2, "vp8hip_entropy_status: bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(status, c->d_ent_status, (size_t)count * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int vp8hip_entropy_status_async(vp8hip_ctx *c, int count, uint32_t *status)
+{
+    if (!c || !status || count < 1 || (size_t)count * sizeof(vp8hip_entropy_frame) > c->ent_frames_cap)
+        return fail(c, -2, "vp8hip_entropy_status_async: bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(status, c->d_ent_status, (size_t)count * 4, hipMemcpyDeviceToHost, c->stream));
+    return 0;
+}

@@ -1,0 +1,417 @@
+// vp8hip_decode (include/vp8hip.h): which kernels a launch of independent frames runs, and the tiled -> raster pass behind the
+// large ones.  What it stands for in the reference: decode_mb_row x mb_rows (vp8/decoder/decodframe.c:1116-1129),
+// vp8_loop_filter_frame (vp8/common/loopfilter.c:203) and vp8_yv12_extend_frame_borders_ptr (vp8/decoder/onyxd_if.c:607) for
+// every frame of the launch.
+//
+// TWO kernel families, one choice (launch_regime below):
+//   * large launches -- more than two frames per CU, reconstruction and loop filter both wanted -- run the LANE-PER-ROW kernels:
+//     vp8_keyframe_kernel (key frames only), or vp8_inter_pred_kernel + vp8_interframe_kernel (inter frames among them), into
+//     macroblock-window tiles; vp8_detile_kf_kernel + vp8_extend_kernel turn the tiles into the raster frame buffers on a second
+//     stream, beside the next launch;
+//   * everything else -- few frames, one frame (a single stream through vpx_codec_decode), single stages -- runs the WAVE-PER-ROW
+//     kernels (vp8_recon.hip, vp8_loopfilter.hip), which write the raster frame buffers themselves: up to 128 frame pairs spread
+//     over several CUs each (the _xcu variants), more than that one pair per workgroup; launches with inter frames of up to
+//     VP8HIP_INTER_SPLIT frames reconstruct their inter macroblocks first, every one on its own (vp8_inter_mb_kernel).
+// Every kernel reads the IR slots in the device form of include/vp8_ir.h, as the producers wrote them: nothing is converted here.
+#include "vp8hip_ctx.hip.h"
+
+extern "C" __global__ void vp8_recon_kernel(const DevJob *jobs, int njobs, DevGeom g);
+extern "C" __global__ void vp8_recon_xcu_kernel(const DevJob *jobs, int njobs, DevGeom g, unsigned long long *gran, unsigned int epoch,
+                                                int S, int *err);
+extern "C" __global__ void vp8_loopfilter_xcu_kernel(const DevJob *jobs, int njobs, DevGeom g, unsigned long long *gran,
+                                                     unsigned int epoch, int S, int *err);
+extern "C" __global__ void vp8_recon_intra_kernel(const DevJob *jobs, int njobs, DevGeom g, const unsigned int *intra_flags);
+extern "C" __global__ void vp8_recon_intra_xcu_kernel(const DevJob *jobs, int njobs, DevGeom g, unsigned long long *gran, unsigned int epoch,
+                                                      int S, int *err, const unsigned int *intra_flags);
+extern "C" __global__ void vp8_inter_mb_kernel(const DevJob *jobs, int njobs, DevGeom g, unsigned int *intra_flags);
+extern "C" __global__ void vp8_keyframe_kernel(const DevJob *jobs, int njobs, DevGeom g, int lgG, int P, int nstrands, uint8_t *dummy,
+                                               unsigned int *sched, int nwaves);
+extern "C" __global__ void vp8_interframe_kernel(const DevJob *jobs, int njobs, DevGeom g, int lgG, int P, int nstrands, uint8_t *dummy,
+                                               unsigned int *sched, int nwaves);
+extern "C" __global__ void vp8_inter_pred_kernel(const DevJob *jobs, int njobs, DevGeom g, int upf);
+extern "C" __global__ void vp8_loopfilter_kernel(const DevJob *jobs, int njobs, DevGeom g);
+extern "C" __global__ void vp8_extend_kernel(const DevJob *jobs, int njobs, DevGeom g);
+extern "C" __global__ void vp8_detile_kf_kernel(const DevJob *jobs, int njobs, DevGeom g);
+
+// the tiled -> raster pass (+ border extension) of a lane-per-row launch
+static int launch_detile(vp8hip_ctx *c, hipStream_t st, DevJob *jobs, int njobs, int extend)
+{
+    // Two workgroups per CU, each looping over macroblock rows: the pass runs beside the next launch's vp8_keyframe_kernel
+    // (its waves need 16 registers: they fit in the gap two of that kernel's waves leave on a SIMD) and is to trickle -- the
+    // pair is bound by HBM bandwidth when the pass goes at full speed, and the key-frame kernel then loses more than the pass
+    // gains.  8192 1080p frames per launch, ms per step: 2 per CU 45.7-47.1, 4 per CU 49.2-51.5, all at once 49.9-50.2, 1 per
+    // CU 65 (the pass becomes the longer one)
+    long units = (long)c->dg.mb_rows * njobs;
+    const int cap = c->knobs.detile_blocks > 0 ? c->knobs.detile_blocks : 2 * c->num_cu;
+    if (units > cap) units = cap;
+    hipLaunchKernelGGL(vp8_detile_kf_kernel, dim3((unsigned)units), dim3(256), 0, st, (const DevJob *)jobs, njobs, c->dg);
+    if (extend) {
+        int bx = (c->geom.aligned_h + 64) / 4;
+        if (bx < 1) bx = 1;
+        if (bx > 64) bx = 64;
+        hipLaunchKernelGGL(vp8_extend_kernel, dim3(bx, njobs), dim3(256), 0, st, (const DevJob *)jobs, njobs, c->dg);
+    }
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+// Launch the deferred tiled -> raster pass on the second stream, behind `after` (an event on the main stream).
+static int launch_deferred(vp8hip_ctx *c, hipEvent_t after)
+{
+    if (!c->deferred.valid) return 0;
+    HIPCHK(c, hipStreamWaitEvent(c->stream2, after, 0));
+    HIPCHK(c, hipEventRecord(c->deferred.ev[4], c->stream2));
+    if (launch_detile(c, c->stream2, c->deferred.jobs, c->deferred.njobs, c->deferred.extend)) return -1;
+    HIPCHK(c, hipEventRecord(c->deferred.ev[5], c->stream2));
+    HIPCHK(c, hipEventRecord(c->ev_detile_done[c->deferred.par], c->stream2));
+    c->deferred.valid = false;
+    return 0;
+}
+// Make the main stream wait for a tiled -> raster pass still running on the second stream (launching it first if it was held
+// back).  Every entry point that reads or writes frame buffers, other than another lane-per-row launch, calls this first.
+int vp8hip_join_detile(vp8hip_ctx *c)
+{
+    if (c->deferred.valid) {
+        HIPCHK(c, hipEventRecord(c->ev_lf_done, c->stream));
+        if (launch_deferred(c, c->ev_lf_done)) return -1;
+    }
+    if (c->detile_pending) {
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_detile_done[c->last_par], 0));
+        c->detile_pending = false;
+    }
+    c->detile_joined = c->detile_gen;
+    return 0;
+}
+#define join_detile vp8hip_join_detile
+extern "C" int vp8hip_join(vp8hip_ctx *c)
+{
+    if (!c) return -2;
+    HIPCHK(c, hipSetDevice(c->device));
+    return join_detile(c);
+}
+
+// The ONE place that decides which kernels a launch runs (header of this file).  The threshold is where the families cross on an
+// MI355X: the wave-per-row kernels are the faster ones up to one frame pair per CU (512 frames: 126 vs 85 Gpix/s at 1080p); beyond
+// that they need a second round of workgroups and the lane-per-row kernels win (640 frames: 108 vs 85).
+enum Regime { WAVE_PER_ROW = 0, LANE_KEY, LANE_INTER };
+static Regime launch_regime(const vp8hip_ctx *c, int njobs, int stages, bool all_key)
+{
+    const bool both = (stages & VP8HIP_STAGE_RECON) && (stages & VP8HIP_STAGE_LF);
+    bool lane = both && njobs > 2 * c->num_cu;
+    if (c->knobs.recon_force) lane = both && c->knobs.recon_force == 1;       // tuning / test knob: VP8HIP_RECON
+    return !lane ? WAVE_PER_ROW : all_key ? LANE_KEY : LANE_INTER;
+}
+
+extern "C" int vp8hip_decode(vp8hip_ctx *c, const vp8hip_job *jobs, int njobs, int stages)
+{
+    if (!c || !jobs || njobs <= 0) return fail(c, -2, "vp8hip_decode: bad arguments");
+    if (!c->width) return fail(c, -2, "vp8hip_decode: context not configured");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (njobs > c->jobs_cap) {
+        // the staging arrays are reused by in-flight launches: drain before growing
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (c->stream2) HIPCHK(c, hipStreamSynchronize(c->stream2));
+        for (int k = 0; k < VP8HIP_NBUF; k++) if (c->d_jobs2[k]) (void)hipFree(c->d_jobs2[k]);
+        if (c->h_jobs) (void)hipHostFree(c->h_jobs);
+        c->jobs_cap = njobs < 64 ? 64 : njobs;
+        for (int k = 0; k < VP8HIP_NBUF; k++) HIPCHK(c, hipMalloc((void **)&c->d_jobs2[k], sizeof(DevJob) * c->jobs_cap));
+        HIPCHK(c, hipHostMalloc((void **)&c->h_jobs, sizeof(DevJob) * c->jobs_cap, hipHostMallocDefault));
+    } else {
+        // h_jobs is read by an async copy of the previous call; wait for that copy only
+        HIPCHK(c, hipEventSynchronize(c->ev_jobs));
+    }
+    const int nfb = (int)c->fb.size(), nsl = (int)c->slots.size();
+    bool any_lf = false;
+    bool all_key = true;
+    for (int i = 0; i < njobs && all_key; i++)
+        if (jobs[i].ir_slot >= 0 && jobs[i].ir_slot < nsl) all_key = c->slots[jobs[i].ir_slot].hdr_copy.frame_type == 0;
+    const Knobs &K = c->knobs;
+    const Regime regime = launch_regime(c, njobs, stages, all_key);
+    const bool tiled = regime != WAVE_PER_ROW, inter_fused = regime == LANE_INTER;
+    // tiles of a frame: one per macroblock and one more per macroblock row, 32 bytes of unfiltered line per tile behind them
+    // (vp8_keyframe_simt.hip)
+    const size_t tile_frame = align_up((size_t)c->dg.mb_rows * (c->dg.mb_cols + 1) * (VP8_TILE_BYTES + 32), 256);
+    const int par = c->parity;
+    bool reads_pending = false;
+    if (!all_key)
+        for (int i = 0; i < njobs && !reads_pending; i++) {
+            if (jobs[i].ir_slot < 0 || jobs[i].ir_slot >= nsl || c->slots[jobs[i].ir_slot].hdr_copy.frame_type == 0) continue;
+            for (int k = 1; k < 4; k++) {
+                const int f = jobs[i].ref_fb[k];
+                if (f >= 0 && f < nfb && c->fb_detile_gen[f] > c->detile_joined) reads_pending = true;
+            }
+        }
+    if (!tiled || reads_pending) {
+        // this launch touches the raster frame buffers directly: it writes them, or (inter frames) reads reference frames a
+        // tiled -> raster pass of an earlier launch is still to produce
+        if (join_detile(c)) return -1;
+    }
+    if (tiled) {
+        // tile set and job table `par` were last read by the tiled -> raster pass VP8HIP_NBUF launches ago (three
+        // sets: that pass, launched beside the previous launch, may still be finishing)
+        if (c->detile_used[par]) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_detile_done[par], 0));
+        if (c->tile_cap[par] < tile_frame * njobs) {
+            // (re)allocate the set in use (the other sets only exist once the tiled -> raster pass has rotated to them)
+            if (join_detile(c)) return -1;          // a pass not launched yet still reads the old sets
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            if (c->stream2) HIPCHK(c, hipStreamSynchronize(c->stream2));
+            if (c->tile_cap[par] < tile_frame * njobs) {
+                if (c->tile_block[par]) (void)hipFree(c->tile_block[par]);
+                c->tile_block[par] = nullptr; c->tile_cap[par] = 0;
+                // + 8 KB: the dummy tile idle lanes write, and room for the kernels' prefetches past the last tile
+                HIPCHK(c, hipMalloc((void **)&c->tile_block[par], tile_frame * njobs + 8192));
+                c->tile_cap[par] = tile_frame * njobs;
+            }
+        }
+    }
+    c->d_jobs = c->d_jobs2[par];
+    for (int i = 0; i < njobs; i++) {
+        const vp8hip_job &j = jobs[i];
+        if (j.ir_slot < 0 || j.ir_slot >= nsl || j.dst_fb < 0 || j.dst_fb >= nfb)
+            return fail(c, -2, "vp8hip_decode: job %d has slot %d / fb %d out of range", i, j.ir_slot, j.dst_fb);
+        const Slot &s = c->slots[j.ir_slot];
+        DevJob &d = c->h_jobs[i];
+        d.hdr = s.hdr_copy;
+        d.mbx = s.d_mbx; d.blocks = s.d_blocks; d.mvs = s.d_mvs;
+        d.dst = c->fb[j.dst_fb];
+        d.ref[0] = nullptr;
+        d.tile = tiled ? c->tile_block[par] + tile_frame * i : nullptr;
+        for (int k = 1; k < 4; k++) {
+            d.ref[k] = nullptr;
+            if (s.hdr_copy.frame_type == 0) continue;          // key frames read no reference
+            int f = j.ref_fb[k];
+            if (f >= nfb) return fail(c, -2, "vp8hip_decode: job %d ref %d out of range", i, f);
+            if (f < 0) return fail(c, -2, "vp8hip_decode: inter frame job %d lacks reference %d", i, k);
+            if (f == j.dst_fb) return fail(c, -2, "vp8hip_decode: job %d decodes into its own reference", i);
+            d.ref[k] = c->fb[f];
+        }
+        any_lf |= s.hdr_copy.filter_level != 0;
+    }
+    if (c->d2h_count) {      // a batch download still in flight: a launch that writes one of its frame buffers waits for it
+        bool hit = false;
+        for (int i = 0; i < njobs && !hit; i++) hit = jobs[i].dst_fb >= c->d2h_first && jobs[i].dst_fb < c->d2h_first + c->d2h_count;
+        if (hit) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_d2h_done, 0));
+    }
+    HIPCHK(c, hipMemcpyAsync(c->d_jobs, c->h_jobs, sizeof(DevJob) * njobs, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipEventRecord(c->ev_jobs, c->stream));
+
+    const int wg_per_cu = K.wg_per_cu >= 1 && K.wg_per_cu <= 8 ? K.wg_per_cu : 1;
+    const int grid = njobs < c->num_cu * wg_per_cu ? njobs : c->num_cu * wg_per_cu;
+    c->stats.workgroups = grid;
+    c->stats.recon_waves = c->recon_nw;
+    c->stats.lf_waves = c->lf_nw;
+    // ---- small launches of the wave-per-row family: a frame pair is spread over S workgroups of XCU_NW waves on S CUs
+    // of one XCD (round-robin placement: workgroups b, b+8, b+16, ... share an XCD) instead of living on one CU, so
+    // that one 1080p frame keeps 68 SIMDs busy, not 4.  At most 32 CUs' worth of workgroups per XCD, one pair per group.
+    int XCU_NW = 4;
+    int xcu_S = 1, xcu_grid = 0;
+    if (!tiled) {
+        const int npairs = (njobs + 1) / 2, rows = c->dg.mb_rows, cols = c->dg.mb_cols;
+        const int per_xcd = (npairs + 7) / 8;
+        int S = (rows + XCU_NW - 1) / XCU_NW;                // a wave per row ...
+        if (per_xcd > 32) S = 1;
+        else if (S > 32 / per_xcd) S = 32 / per_xcd;         // ... or one workgroup on every CU of the XCD
+        // fewer waves than rows: two waves per SIMD.  Worth it as long as a pair gets more waves than the twelve it
+        // has on a single CU (a wave's macroblock step is a latency chain; throughput goes with the number of waves)
+        if (S * XCU_NW < rows) XCU_NW = 8;
+        if (S * XCU_NW <= c->recon_nw) S = 1;
+        if (!K.xcu) S = 1;
+        if (K.xcu_S >= 1 && K.xcu_S <= 64) S = K.xcu_S;
+        if (K.xcu_NW == 4 || K.xcu_NW == 8) XCU_NW = K.xcu_NW;
+        if (S > 1) {
+            // the workgroups of a group wait for each other: all of them have to be resident at once, on this device as it
+            // is (fewer CUs when partitioned), or the launch stays with one workgroup per pair
+            int per_cu_r = 0, per_cu_l = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_r, vp8_recon_xcu_kernel, 64 * XCU_NW, 1024 + XCU_NW * 2 * 2080) != hipSuccess
+                || hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_l, vp8_loopfilter_xcu_kernel, 64 * XCU_NW, 256 + XCU_NW * 2 * 4096) != hipSuccess
+                || 8 * S * per_xcd > c->num_cu * (per_cu_r < per_cu_l ? per_cu_r : per_cu_l))
+                S = 1;
+        }
+        if (S > 1) {
+            xcu_S = S; xcu_grid = 8 * S * per_xcd;
+            if (!c->h_status) {
+                HIPCHK(c, hipHostMalloc((void **)&c->h_status, sizeof(int), hipHostMallocMapped));
+                *c->h_status = 0;
+                HIPCHK(c, hipHostGetDevicePointer((void **)&c->d_status, c->h_status, 0));
+            }
+            // granule buffers: recon one unfiltered pixel line per MB row (cols*8+2 granules), loop filter four
+            // context rows per MB row (cols*32), per frame; zeroed once -- the tags of later launches never repeat
+            const size_t need_r = (size_t)npairs * 2 * rows * (cols * 8 + 2) * 8, need_l = (size_t)npairs * 2 * rows * cols * 32 * 8;
+            if (c->gran_recon_cap < need_r || c->gran_lf_cap < need_l) {
+                HIPCHK(c, hipStreamSynchronize(c->stream));
+                if (c->gran_recon) (void)hipFree(c->gran_recon);
+                if (c->gran_lf) (void)hipFree(c->gran_lf);
+                c->gran_recon = c->gran_lf = nullptr; c->gran_recon_cap = c->gran_lf_cap = 0;
+                HIPCHK(c, hipMalloc((void **)&c->gran_recon, need_r));
+                HIPCHK(c, hipMalloc((void **)&c->gran_lf, need_l));
+                HIPCHK(c, hipMemsetAsync(c->gran_recon, 0, need_r, c->stream));
+                HIPCHK(c, hipMemsetAsync(c->gran_lf, 0, need_l, c->stream));
+                c->gran_recon_cap = need_r; c->gran_lf_cap = need_l;
+                c->epoch = 0;
+            }
+            if (++c->epoch == 0) {          // 2^32 launches later: start over with clean buffers
+                HIPCHK(c, hipMemsetAsync(c->gran_recon, 0, c->gran_recon_cap, c->stream));
+                HIPCHK(c, hipMemsetAsync(c->gran_lf, 0, c->gran_lf_cap, c->stream));
+                c->epoch = 1;
+            }
+            c->stats.workgroups = xcu_grid; c->stats.recon_waves = XCU_NW; c->stats.lf_waves = XCU_NW;
+        }
+    }
+    hipEvent_t *ev = c->evr[c->ncalls % VP8HIP_STATS_RING];
+    HIPCHK(c, hipEventRecord(ev[0], c->stream));
+    // "one MB row per lane" kernels: G lanes per strand of frames, row period P >= max(cols, 2G+2).  G is at most
+    // the largest value that costs no idle steps (cols >= 2G+2), and otherwise as small as it can be while every
+    // strand of a full launch (4 waves per CU) still gets a frame: a small G means few pipeline-fill steps and a
+    // better fit of the frame's rows into whole row periods.
+    int lgG = 1;
+    {
+        const int cols = c->dg.mb_cols;
+        int lgmax = 1;
+        while (lgmax < 6 && 2 * (2 << lgmax) + 2 <= cols) lgmax++;
+        const long lanes = (long)c->num_cu * 4 * 64;                      // one wave per SIMD
+        while (lgG < 6 && (lanes >> lgG) > njobs) lgG++;                  // strands of a full launch <= frames
+        if (lgG > lgmax && ((long)njobs << lgmax) >= lanes) lgG = lgmax;   // no idle steps, if that still fills every SIMD
+        if (K.lgG >= 1 && K.lgG <= 6) lgG = K.lgG;
+    }
+    const int simtG = 1 << lgG, spw = 64 >> lgG;
+    const int simtP = c->dg.mb_cols > 2 * simtG + 2 ? c->dg.mb_cols : 2 * simtG + 2;
+    int simt_waves = (njobs + spw - 1) / spw;
+    {
+        int maxw = c->num_cu * 4;
+        if (K.simt_waves >= 1) maxw = K.simt_waves;
+        if (simt_waves > maxw) simt_waves = maxw;
+    }
+    if (tiled) { c->stats.workgroups = simt_waves; c->stats.recon_waves = 1; c->stats.lf_waves = 1; }
+    c->stats.detile_pass = tiled;
+
+    if (stages & VP8HIP_STAGE_RECON) {
+        if (tiled) {
+            // one kernel, two waves per SIMD: the first to arrive on a SIMD reconstructs luma, the second chroma (see the kernel)
+            if (!c->d_sched) {
+                HIPCHK(c, hipMalloc((void **)&c->d_sched, sizeof(unsigned int) * VP8HIP_SCHED_WORDS));
+                HIPCHK(c, hipMemsetAsync(c->d_sched, 0, sizeof(unsigned int) * VP8HIP_SCHED_WORDS, c->stream));
+            }
+            HIPCHK(c, hipMemsetAsync(c->d_sched, 0, 2 * sizeof(unsigned int), c->stream));
+            if (inter_fused) {
+                // the inter macroblocks' predictions into their tiles: a wave per 64 macroblocks, at most 8 waves per SIMD's worth
+                const int upf = (c->nmb + 63) / 64;
+                long pgrid = ((long)njobs * upf + 3) / 4;
+                if (pgrid > (long)c->num_cu * 8) pgrid = (long)c->num_cu * 8;
+                hipLaunchKernelGGL(vp8_inter_pred_kernel, dim3((unsigned)pgrid), dim3(256), 0, c->stream, (const DevJob *)c->d_jobs, njobs,
+                                   c->dg, upf);
+                // the previous launch's tiled -> raster pass, if it was held back: beside vp8_interframe_kernel, which is bound by
+                // arithmetic, not beside the prediction kernel, which is bound by memory bandwidth as the pass is
+                if (c->deferred.valid) {
+                    HIPCHK(c, hipEventRecord(c->ev_recon_done, c->stream));
+                    if (launch_deferred(c, c->ev_recon_done)) return -1;
+                }
+                hipLaunchKernelGGL(vp8_interframe_kernel, dim3(2 * simt_waves), dim3(64), 0, c->stream, (const DevJob *)c->d_jobs, njobs,
+                                   c->dg, lgG, simtP, simt_waves * spw, c->tile_block[par] + tile_frame * njobs + 4096,
+                                   c->d_sched, simt_waves);
+            } else
+                hipLaunchKernelGGL(vp8_keyframe_kernel, dim3(2 * simt_waves), dim3(64), 0, c->stream, (const DevJob *)c->d_jobs, njobs,
+                                   c->dg, lgG, simtP, simt_waves * spw, c->tile_block[par] + tile_frame * njobs + 4096,
+                                   c->d_sched, simt_waves);
+        } else {
+
+            const int npairs = (njobs + 1) / 2;          // two frames per wave
+            // launches with inter frames: their inter macroblocks first, every one on its own (vp8_inter_mb_kernel), then the
+            // row-ordered kernel for the intra macroblocks only
+            const bool inter_first = !all_key && njobs <= K.inter_split;
+            if (inter_first) {
+                if (c->intra_flags_cap < njobs) {
+                    if (c->d_intra_flags) (void)hipFree(c->d_intra_flags);
+                    c->d_intra_flags = nullptr; c->intra_flags_cap = 0;
+                    HIPCHK(c, hipMalloc((void **)&c->d_intra_flags, sizeof(unsigned int) * (size_t)njobs));
+                    c->intra_flags_cap = njobs;
+                }
+                HIPCHK(c, hipMemsetAsync(c->d_intra_flags, 0, sizeof(unsigned int) * (size_t)njobs, c->stream));
+                const long units = (long)njobs * ((c->nmb + 1) / 2);
+                long igrid = (units + 3) / 4;
+                if (igrid > (long)c->num_cu * 16) igrid = (long)c->num_cu * 16;
+                hipLaunchKernelGGL(vp8_inter_mb_kernel, dim3((unsigned)igrid), dim3(256), 0, c->stream, (const DevJob *)c->d_jobs, njobs,
+                                   c->dg, c->d_intra_flags);
+            }
+            if (xcu_S > 1) {
+                if (inter_first)
+                    hipLaunchKernelGGL(vp8_recon_intra_xcu_kernel, dim3(xcu_grid), dim3(64 * XCU_NW), 1024 + XCU_NW * 2 * 2080, c->stream,
+                                       (const DevJob *)c->d_jobs, njobs, c->dg, c->gran_recon, c->epoch, xcu_S, c->d_status,
+                                       (const unsigned int *)c->d_intra_flags);
+                else
+                hipLaunchKernelGGL(vp8_recon_xcu_kernel, dim3(xcu_grid), dim3(64 * XCU_NW), 1024 + XCU_NW * 2 * 2080, c->stream,
+                                   (const DevJob *)c->d_jobs, njobs, c->dg, c->gran_recon, c->epoch, xcu_S, c->d_status);
+            } else {
+            const int rgrid = npairs < c->num_cu * wg_per_cu ? npairs : c->num_cu * wg_per_cu;
+            if (inter_first)
+                hipLaunchKernelGGL(vp8_recon_intra_kernel, dim3(rgrid), dim3(64 * c->recon_nw), c->recon_lds, c->stream,
+                                   (const DevJob *)c->d_jobs, njobs, c->dg, (const unsigned int *)c->d_intra_flags);
+            else
+            hipLaunchKernelGGL(vp8_recon_kernel, dim3(rgrid), dim3(64 * c->recon_nw), c->recon_lds, c->stream,
+                               (const DevJob *)c->d_jobs, njobs, c->dg);
+            }
+        }
+
+        HIPCHK(c, hipGetLastError());
+    }
+    HIPCHK(c, hipEventRecord(ev[1], c->stream));
+    if (tiled && c->deferred.valid) {          // a pass still held back (the launch before had inter frames, this one has none)
+        HIPCHK(c, hipEventRecord(c->ev_recon_done, c->stream));
+        if (launch_deferred(c, c->ev_recon_done)) return -1;
+    }
+    c->stats.fused = tiled;
+    c->stats.lf_kernels = 0;
+    if ((stages & VP8HIP_STAGE_LF) && any_lf && !tiled) {
+        c->stats.lf_kernels = 1;
+        const int npairs = (njobs + 1) / 2;          // the loop filter works on two frames per wave
+        if (xcu_S > 1) {
+            hipLaunchKernelGGL(vp8_loopfilter_xcu_kernel, dim3(xcu_grid), dim3(64 * XCU_NW), 256 + XCU_NW * 2 * 4096, c->stream,
+                               (const DevJob *)c->d_jobs, njobs, c->dg, c->gran_lf, c->epoch, xcu_S, c->d_status);
+        } else {
+            const int lfgrid = npairs < c->num_cu * wg_per_cu ? npairs : c->num_cu * wg_per_cu;
+            hipLaunchKernelGGL(vp8_loopfilter_kernel, dim3(lfgrid), dim3(64 * c->lf_nw), c->lf_lds, c->stream,
+                               (const DevJob *)c->d_jobs, njobs, c->dg);
+        }
+        HIPCHK(c, hipGetLastError());
+    }
+    HIPCHK(c, hipEventRecord(ev[2], c->stream));
+    if (tiled) {      // the frame buffers get the result from the tiles; borders are extended on the way
+        const bool own_stream = K.detile_stream;
+        if (own_stream && !c->stream2) {
+            int prio_least = 0, prio_greatest = 0;
+            HIPCHK(c, hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+            HIPCHK(c, hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio_least));
+        }
+        // The key-frame kernel's pass goes out at once: its waves are small enough -- 16 registers -- to run in the gaps the next
+        // launch's kernel leaves on every SIMD.  After a launch with inter frames it waits for the next launch's prediction
+        // kernel (or the next join).
+        const bool defer = own_stream && inter_fused;
+        hipStream_t ds = own_stream ? c->stream2 : c->stream;
+        if (defer) {
+            c->deferred.valid = true; c->deferred.jobs = c->d_jobs; c->deferred.njobs = njobs;
+            c->deferred.extend = (stages & VP8HIP_STAGE_EXTEND) ? 1 : 0; c->deferred.par = par; c->deferred.ev = ev;
+        } else {
+            if (own_stream) {
+                HIPCHK(c, hipEventRecord(c->ev_lf_done, c->stream));
+                HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_lf_done, 0));
+            }
+            HIPCHK(c, hipEventRecord(ev[4], ds));
+            if (launch_detile(c, ds, c->d_jobs, njobs, (stages & VP8HIP_STAGE_EXTEND) ? 1 : 0)) return -1;
+            HIPCHK(c, hipEventRecord(ev[5], ds));
+            HIPCHK(c, hipEventRecord(c->ev_detile_done[par], ds));
+        }
+        c->detile_used[par] = true; c->detile_pending = true; c->last_par = par; c->parity = (par + 1) % VP8HIP_NBUF;
+        ++c->detile_gen;
+        for (int i = 0; i < njobs; i++) c->fb_detile_gen[jobs[i].dst_fb] = c->detile_gen;
+    } else if (stages & VP8HIP_STAGE_EXTEND) {
+        int bx = (c->geom.aligned_h + 64) / 4;
+        if (bx < 1) bx = 1;
+        if (bx > 64) bx = 64;
+        hipLaunchKernelGGL(vp8_extend_kernel, dim3(bx, njobs), dim3(256), 0, c->stream, (const DevJob *)c->d_jobs,
+                           njobs, c->dg);
+        HIPCHK(c, hipGetLastError());
+    }
+    HIPCHK(c, hipEventRecord(ev[3], c->stream));
+    c->evr_tiled[c->ncalls % VP8HIP_STATS_RING] = tiled;
+    c->evr_stats[c->ncalls % VP8HIP_STATS_RING] = c->stats;
+    c->ncalls++;
+    return 0;
+}

@@ -1,4 +1,4 @@
-/* batch_md5 [--threads T] [--batch B] [--loop N] [--host-md5] [--device-entropy [--entropy-batch E [--entropy-dense]] [--no-download]] <in.ivf> <out.md5>
+/* batch_md5 [--threads T] [--batch B] [--loop N] [--host-md5] [--device-entropy [--entropy-batch E] [--no-download]] <in.ivf> <out.md5>
  *
  * decode_to_md5 for streams of independently decodable frames (all key frames), at the rate the host can feed the
  * GPU: SURVEY.md 8(f)1.  The output file has decode_to_md5's lines ("<md5>  img-<w>x<h>-<%04d>.i420", one per frame,
@@ -6,8 +6,8 @@
  *
  * The reference decodes one frame at a time on one thread (decoder_tmpl.c:47-103).  Key frames reset every piece of
  * decoder state (decodframe.c:610-639), so here T feeder threads run the entropy decoder (vp8_parser.h) on different
- * frames at once, each writing the IR straight into the pinned staging of an IR slot (vp8hip_ir_map); the main thread
- * uploads a batch of B slots, launches the pixel path for the whole batch (vp8hip_decode), downloads the previous
+ * frames at once, each writing the IR -- in the device form of include/vp8_ir.h, the form the kernels read -- straight into the
+ * pinned staging of an IR slot (vp8hip_ir_map_compact); the main thread uploads a batch of B slots (a copy each), launches the pixel path for the whole batch (vp8hip_decode), downloads the previous
  * batch into pinned host memory, and the same pool hashes it.  Three slot / frame-buffer sets rotate: batch k+1 is
  * parsed while batch k is on the GPU and batch k-1 is downloaded and hashed.  --loop repeats the stream N times
  * (benchmarking; the listing then has N * frames lines).
@@ -17,11 +17,10 @@
  * frame per lane (vp8hip_entropy_decode), straight into the IR slots the pixel path reads.  A lane takes about a second for a
  * large 1080p key frame whatever the batch, so this mode wants batches of thousands (one set of IR slots, two sets of frame
  * buffers).  --no-download: with the MD5s computed on the device the frames themselves stay there.  --entropy-batch E (a
- * multiple of B): the entropy decoder takes E frames per launch and leaves their IR in its sparse form (a third of the bytes:
- * vp8hip_entropy_decode_sparse), the pixel path expands and decodes them B at a time -- more frames in flight for the same memory,
- * and frames in flight over the time of the largest is what the entropy decoder's rate is.  --entropy-dense: IR slots for all E
- * frames instead (no sparse form in between): the memory that buys frames in flight is then the pixel path's, whose tile scratch
- * and frame buffers are only needed for B frames at a time.
+ * multiple of B): the entropy decoder takes E frames per launch, into E IR slots, and the pixel path decodes them B at a time --
+ * more frames in flight (frames in flight over the time of the largest is what the entropy decoder's rate is) for the memory of
+ * the slots alone: tiles and frame buffers are only needed for B frames at a time.  Frames the device reports as cut short
+ * (vp8hip_entropy_status) are counted and named on stderr, as the host feeder's *corrupt would.
  *
  * Prints frames, seconds and frames/s for the region "first byte parsed .. last digest done" on stderr. */
 #include <pthread.h>
@@ -94,8 +93,8 @@ static vp8hip_ctx *g_hip;
 static vp8_parser **g_parsers;                      /* one per worker */
 static int g_batch, g_width, g_height;
 static vp8ir_geom g_geom;
-/* 3 * batch slots; the coefficients go up as the sparse streams of include/vp8_ir.h (a third of the dense bytes) */
-static struct { vp8ir_frame_hdr *hdr; vp8ir_mb *mbs; int16_t *blocks, *dcs; size_t cap, nblocks, ndcs; vp8ir_mv *mvs; } *g_maps;
+/* 3 * batch slots: their pinned staging, in the device form of include/vp8_ir.h (0.4 of the dense bytes) */
+static struct { vp8ir_frame_hdr *hdr; vp8ir_mbx *mbx; int16_t *blocks; size_t cap, nblocks; vp8ir_mv *mvs; } *g_maps;
 static uint8_t *g_host[2];                          /* 2 x batch pinned frame buffers: one being filled by the GPU, one being hashed */
 static size_t g_stride;                             /* bytes from one frame buffer to the next */
 static unsigned char (*g_digest)[16];               /* one per frame of the whole run */
@@ -105,7 +104,8 @@ static int g_dev_md5;                               /* hash on the device (vp8hi
 static volatile int g_failed;
 static int g_dev_entropy;                           /* --device-entropy */
 static int g_ebatch;                                /* --entropy-batch: frames per entropy launch (0: = g_batch, dense) */
-static int g_edense;                                /* --entropy-dense: with --entropy-batch E, IR slots for all E frames (no sparse detour) */
+static uint32_t *g_ent_status[2];                   /* per set: the device's status words of the launch (pinned) */
+static long g_corrupt;                              /* frames whose partitions ended early */
 static long *g_order;                               /* --device-entropy: which frame of the run the k-th processed one is.  A lane of the
                                                        entropy kernel is busy for as long as its frame is large and a launch lasts as long
                                                        as its longest lane, so the frames of SORT_WINDOW batches at a time are taken
@@ -117,8 +117,8 @@ static size_t g_ent_cap;
 
 typedef struct batch_ref { int b, n; long first; } batch_ref;     /* batch number, frames in it, index of its first frame */
 /* The pipeline, batch by batch (three slot / frame-buffer sets, two pinned host sets):
- *   feeder threads   parse batch b+1 into slot set (b+1)%3            (sparse coefficient streams, include/vp8_ir.h)
- *   this thread      uploads batch b (one copy + one expansion launch per frame), launches its pixel path, then asks for the
+ *   feeder threads   parse batch b+1 into slot set (b+1)%3            (the device form, include/vp8_ir.h)
+ *   this thread      uploads batch b (one copy per frame), launches its pixel path, then asks for the
  *                    frames back: ONE asynchronous device-to-host copy of the whole batch on a stream of its own
  *   hash threads     MD5 of batch b-1, which that copy delivered during the previous iteration */
 
@@ -138,8 +138,8 @@ static void parse_one(void *arg, int i, int worker)
     vp8ir_frame_hdr hdr;
     int rc = vp8_parser_begin_frame(g_parsers[worker], f->data, f->size, &hdr);
     if (!rc && (hdr.frame_type != 0 || hdr.width != g_width || hdr.height != g_height)) rc = VP8P_UNSUP_BITSTREAM;
-    if (!rc) rc = vp8_parser_decode_mbs_sparse(g_parsers[worker], g_maps[slot].mbs, g_maps[slot].blocks, g_maps[slot].cap,
-                                               &g_maps[slot].nblocks, g_maps[slot].dcs, &g_maps[slot].ndcs, g_maps[slot].mvs, NULL);
+    if (!rc) rc = vp8_parser_decode_mbs_compact(g_parsers[worker], g_maps[slot].mbx, g_maps[slot].blocks, g_maps[slot].cap,
+                                                &g_maps[slot].nblocks, g_maps[slot].mvs, NULL);
     if (rc) { g_failed = 1; return; }
     *g_maps[slot].hdr = hdr;
 }
@@ -189,6 +189,14 @@ static void take_digests(const batch_ref *br)
 {
     for (int i = 0; i < br->n; i++) memcpy(g_digest[run_index(br->first + i)], g_dig[br->b & 1] + 16 * (size_t)i, 16);
 }
+/* the status words of an entropy launch (set `set`, n frames from run position `first` on), once its copy has landed */
+static void take_status(int set, long first, int n)
+{
+    for (int i = 0; i < n; i++)
+        if (g_ent_status[set][i] & 1u) {
+            if (g_corrupt++ < 8) fprintf(stderr, "frame %ld: a partition ended early (corrupt)\n", run_index(first + i) + 1);
+        }
+}
 
 static double now_s(void)
 {
@@ -210,13 +218,13 @@ int main(int argc, char **argv)
         else if (!strcmp(argv[a], "--device-entropy")) g_dev_entropy = 1;
         else if (!strcmp(argv[a], "--no-download")) no_download = 1;
         else if (!strcmp(argv[a], "--entropy-batch") && a + 1 < argc) g_ebatch = atoi(argv[++a]);
-        else if (!strcmp(argv[a], "--entropy-dense")) g_edense = 1;
+        else if (!strcmp(argv[a], "--entropy-dense")) ;                 /* (what --entropy-batch does anyway since the slots hold the compact form) */
         else if (!strcmp(argv[a], "--batch") && a + 1 < argc) g_batch = atoi(argv[++a]);
         else if (!strcmp(argv[a], "--loop") && a + 1 < argc) loop = atoi(argv[++a]);
-        else DIE("Usage: %s [--threads T] [--batch B] [--loop N] [--host-md5] [--device-entropy [--entropy-batch E [--entropy-dense]] [--no-download]] <in.ivf> <out.md5>", argv[0]);
+        else DIE("Usage: %s [--threads T] [--batch B] [--loop N] [--host-md5] [--device-entropy [--entropy-batch E] [--no-download]] <in.ivf> <out.md5>", argv[0]);
     }
     if (argc - a != 2 || g_batch < 1 || loop < 1)
-        DIE("Usage: %s [--threads T] [--batch B] [--loop N] [--host-md5] [--device-entropy [--entropy-batch E [--entropy-dense]] [--no-download]] <in.ivf> <out.md5>", argv[0]);
+        DIE("Usage: %s [--threads T] [--batch B] [--loop N] [--host-md5] [--device-entropy [--entropy-batch E] [--no-download]] <in.ivf> <out.md5>", argv[0]);
     if (threads < 1) {
         long n = sysconf(_SC_NPROCESSORS_ONLN);
         threads = n > 33 ? 32 : (n > 2 ? (int)n - 1 : 1);      /* more than ~32 feeders gain nothing: the host memory system is the limit */
@@ -256,7 +264,7 @@ int main(int argc, char **argv)
     /* slots and frame buffers: three sets for the host feeder (parsed / on the GPU / coming back); with the entropy decoder on
        the device the IR is written and read on one stream, one set does, and the frame buffers alternate between two */
     const int slot_sets = g_dev_entropy ? 1 : 3, fb_sets = g_dev_entropy ? 2 : 3;
-    HIP(vp8hip_configure(g_hip, g_width, g_height, fb_sets * g_batch, g_edense && g_ebatch ? g_ebatch : slot_sets * g_batch));
+    HIP(vp8hip_configure(g_hip, g_width, g_height, fb_sets * g_batch, g_ebatch ? g_ebatch : slot_sets * g_batch));
     HIP(vp8hip_geometry(g_hip, &g_geom));
     if (g_dev_entropy) {
         {   /* a batch's bytes at most: the frames are taken in order of size within windows of SORT_WINDOW batches */
@@ -275,12 +283,13 @@ int main(int argc, char **argv)
         }
         for (int k = 0; k < 2; k++) {
             if (!(g_ent[k] = (vp8hip_entropy_frame *)vp8hip_host_alloc(g_hip, (size_t)unit * sizeof(vp8hip_entropy_frame))) ||
-                !(g_ent_data[k] = (uint8_t *)vp8hip_host_alloc(g_hip, g_ent_cap + 16))) DIE("vp8hip_host_alloc: %s", vp8hip_last_error(g_hip));
+                !(g_ent_data[k] = (uint8_t *)vp8hip_host_alloc(g_hip, g_ent_cap + 16)) ||
+                !(g_ent_status[k] = (uint32_t *)vp8hip_host_alloc(g_hip, (size_t)unit * sizeof(uint32_t)))) DIE("vp8hip_host_alloc: %s", vp8hip_last_error(g_hip));
         }
     } else {
         g_maps = calloc((size_t)3 * g_batch, sizeof *g_maps);
         for (int s = 0; s < 3 * g_batch; s++)
-            HIP(vp8hip_ir_map_sparse(g_hip, s, &g_maps[s].hdr, &g_maps[s].mbs, &g_maps[s].blocks, &g_maps[s].cap, &g_maps[s].dcs, &g_maps[s].mvs));
+            HIP(vp8hip_ir_map_compact(g_hip, s, &g_maps[s].hdr, &g_maps[s].mbx, &g_maps[s].blocks, &g_maps[s].cap, &g_maps[s].mvs));
     }
     g_stride = vp8hip_frame_stride(g_hip);
     for (int k = 0; k < 2; k++) {
@@ -297,28 +306,16 @@ int main(int argc, char **argv)
     vp8hip_job *jobs = calloc((size_t)g_batch, sizeof *jobs);
 
     if (g_ebatch) {
-        /* ---- the pipeline with the entropy decoder on the device in launches of up to E frames (sparse IR), the pixel path B at a
-           time: headers of launch L+1 on the host while launch L is on the GPU; per part of a launch: expand, decode, digests back.
-           A launch takes as many frames (a multiple of B) as stay under LAUNCH_BYTES compressed -- the arenas are sized by the
-           compressed bytes -- and one that comes down to B frames (large frames: the sparse form saves little there) goes straight
-           into the slots in the dense form. */
-#define LAUNCH_BYTES ((size_t)3200 << 20)
-#define LAUNCH_FRAMES(first, n_out) do {                                                                                      \
-            long n_ = total - (first) < g_ebatch ? total - (first) : g_ebatch;                                               \
-            for (;;) {                                                                                                        \
-                size_t by_ = 0;                                                                                               \
-                for (long k_ = 0; k_ < n_; k_++) by_ += g_frames[run_index((first) + k_) % g_nframes].size;                  \
-                if (g_edense || by_ <= LAUNCH_BYTES || n_ <= g_batch) break;                                                            \
-                n_ -= g_batch;                                                                                                \
-            }                                                                                                                 \
-            (n_out) = (int)n_;                                                                                                \
-        } while (0)
+        /* ---- the pipeline with the entropy decoder on the device in launches of up to E frames, the pixel path B at a time:
+           headers of launch L+1 on the host while launch L is on the GPU; per part of a launch: decode, digests back. */
+#define LAUNCH_FRAMES(first, n_out) do { (n_out) = (int)(total - (first) < g_ebatch ? total - (first) : g_ebatch); } while (0)
         task parse_t;
         batch_ref cur = { 0, 0, 0 }, prev = { -1, 0, 0 };
-        long part_no = 0, L = 0;
-        /* the arenas once, for the largest launch: by what key frames have been seen to need per compressed byte, with room to spare */
-        const size_t most = g_ent_cap < LAUNCH_BYTES + ((size_t)256 << 20) ? g_ent_cap : LAUNCH_BYTES + ((size_t)256 << 20);
-        if (!g_edense) HIP(vp8hip_entropy_reserve_sparse(g_hip, g_ebatch, (size_t)(most * 0.6) + (size_t)g_ebatch * 512, (size_t)(most * 0.8) + (size_t)g_ebatch * 2048));
+        long part_no = 0, L = 0, prev_launch = -1;
+        /* the status words of a launch are good once a fetch queued behind their copy has come back: any part of that launch */
+        struct { int valid, n; long first, launch; } pend[2] = { { 0, 0, 0, 0 }, { 0, 0, 0, 0 } };
+#define TAKE_PENDING() do { for (int k_ = 0; k_ < 2; k_++) if (pend[k_].valid && pend[k_].launch <= prev_launch) {          \
+                                take_status(k_, pend[k_].first, pend[k_].n); pend[k_].valid = 0; } } while (0)
         const double t0 = now_s();
         LAUNCH_FRAMES(0, cur.n);
         size_t bytes = place_frames(&cur);
@@ -327,22 +324,22 @@ int main(int argc, char **argv)
             task_wait(&parse_t, 0);
             if (g_failed) DIE("a frame of launch %ld failed to parse", L);
             const batch_ref now = cur;
-            const int sparse = now.n > g_batch && !g_edense;
             done += now.n;
-            if (sparse) HIP(vp8hip_entropy_decode_sparse(g_hip, now.n, g_ent[now.b & 1], g_ent_data[now.b & 1], bytes, 0, 0));
-            else HIP(vp8hip_entropy_decode(g_hip, 0, now.n, g_ent[now.b & 1], g_ent_data[now.b & 1], bytes));
+            HIP(vp8hip_entropy_decode(g_hip, 0, now.n, g_ent[now.b & 1], g_ent_data[now.b & 1], bytes));
+            HIP(vp8hip_entropy_status_async(g_hip, now.n, g_ent_status[now.b & 1]));
+            pend[now.b & 1].valid = 1; pend[now.b & 1].n = now.n; pend[now.b & 1].first = now.first; pend[now.b & 1].launch = L;
             for (int at = 0; at < now.n; at += g_batch, part_no++) {
                 const batch_ref part = { (int)(part_no & 0x3fffffff), now.n - at < g_batch ? now.n - at : g_batch, now.first + at };
                 const int fb0 = (part.b & 1) * g_batch;
-                if (sparse) HIP(vp8hip_ir_expand(g_hip, at, 0, part.n));
                 for (int i = 0; i < part.n; i++) {
-                    jobs[i].ir_slot = g_edense ? at + i : i; jobs[i].dst_fb = fb0 + i;
+                    jobs[i].ir_slot = at + i; jobs[i].dst_fb = fb0 + i;
                     jobs[i].ref_fb[0] = jobs[i].ref_fb[1] = jobs[i].ref_fb[2] = jobs[i].ref_fb[3] = -1;
                 }
                 HIP(vp8hip_decode(g_hip, jobs, part.n, VP8HIP_STAGE_ALL));
                 if (prev.b >= 0) {
                     HIP(vp8hip_download_wait(g_hip));
                     take_digests(&prev);
+                    TAKE_PENDING();
                 }
                 if (at == 0 && done < total) {
                     /* (the page-locked set the next launch's frames are written to belonged to launch L - 1, whose last digests have
@@ -354,19 +351,12 @@ int main(int argc, char **argv)
                     task_start(&parse_t, 0, export_one, &cur, cur.n);
                 }
                 HIP(vp8hip_frames_fetch_async(g_hip, fb0, part.n, no_download ? NULL : g_host[part.b & 1], g_dig[part.b & 1]));
-                prev = part;
-            }
-            {   /* did the arenas hold? (before the next launch resets them) */
-                static uint32_t *st;
-                if (!st) st = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)g_ebatch);
-                if (sparse) {
-                    HIP(vp8hip_entropy_status(g_hip, now.n, st));
-                    if (st[0] & 2u) DIE("the sparse arenas of launch %ld ran out: use a smaller --entropy-batch, or none", L);
-                }
+                prev = part; prev_launch = L;
             }
         }
         HIP(vp8hip_download_wait(g_hip));
         take_digests(&prev);
+        TAKE_PENDING();
         const double dt = now_s() - t0;
         FILE *out = fopen(argv[a + 1], "wb");
         if (!out) DIE("Failed to open %s for writing", argv[a + 1]);
@@ -375,9 +365,9 @@ int main(int argc, char **argv)
             fprintf(out, "  img-%dx%d-%04ld.i420\n", g_width, g_height, f + 1);
         }
         fclose(out);
-        fprintf(stderr, "%ld frames in %.3f s: %.1f frames/s, %.1f Mpix/s (%d feeder threads, %d frames per launch, entropy decode on the %s, MD5 on the %s%s; %d frames per entropy launch)\n",
+        fprintf(stderr, "%ld frames in %.3f s: %.1f frames/s, %.1f Mpix/s (%d feeder threads, %d frames per launch, entropy decode on the %s, MD5 on the %s%s; %d frames per entropy launch; %ld corrupt)\n",
                 total, dt, total / dt, total / dt * g_width * g_height / 1e6, threads, g_batch, "device", "device",
-                no_download ? ", frames not downloaded" : "", g_ebatch);
+                no_download ? ", frames not downloaded" : "", g_ebatch, g_corrupt);
         pthread_mutex_lock(&pool.mu);
         pool.stop = 1;
         pthread_cond_broadcast(&pool.work);
@@ -409,16 +399,20 @@ int main(int argc, char **argv)
             task_start(&parse_t, 0, feed, &cur, cur.n);
         }
         const int fb0 = g_dev_entropy ? (now.b & 1) * g_batch : (now.b % 3) * g_batch;
-        if (g_dev_entropy) HIP(vp8hip_entropy_decode(g_hip, 0, now.n, g_ent[now.b & 1], g_ent_data[now.b & 1], ent_bytes));
+        if (g_dev_entropy) {
+            HIP(vp8hip_entropy_decode(g_hip, 0, now.n, g_ent[now.b & 1], g_ent_data[now.b & 1], ent_bytes));
+            HIP(vp8hip_entropy_status_async(g_hip, now.n, g_ent_status[now.b & 1]));
+        }
         for (int i = 0; i < now.n; i++) {
             const int s = g_dev_entropy ? i : (now.b % 3) * g_batch + i;
-            if (!g_dev_entropy) HIP(vp8hip_ir_upload_sparse(g_hip, s, g_maps[s].nblocks, g_maps[s].ndcs));
+            if (!g_dev_entropy) HIP(vp8hip_ir_upload_compact(g_hip, s, g_maps[s].nblocks));
             jobs[i].ir_slot = s; jobs[i].dst_fb = fb0 + i;
             jobs[i].ref_fb[0] = jobs[i].ref_fb[1] = jobs[i].ref_fb[2] = jobs[i].ref_fb[3] = -1;
         }
         HIP(vp8hip_decode(g_hip, jobs, now.n, VP8HIP_STAGE_ALL));
         if (prev.b >= 0) {
             HIP(vp8hip_download_wait(g_hip));                               /* batch b-1 is in host set (b-1)&1 */
+            if (g_dev_entropy) take_status(prev.b & 1, prev.first, prev.n); /* (its status copy was queued in front of its fetch) */
             if (g_dev_md5) take_digests(&prev);
             else {
                 if (hashing.b >= 0) task_wait(&hash_t, 1);                  /* batch b-2 hashed: host set b&1 is free again */
@@ -439,6 +433,7 @@ int main(int argc, char **argv)
         prev = now;
     }
     HIP(vp8hip_download_wait(g_hip));
+    if (g_dev_entropy) take_status(prev.b & 1, prev.first, prev.n);
     if (g_dev_md5) take_digests(&prev);
     else {
         if (hashing.b >= 0) task_wait(&hash_t, 1);
@@ -456,9 +451,9 @@ int main(int argc, char **argv)
         fprintf(out, "  img-%dx%d-%04ld.i420\n", g_width, g_height, f + 1);
     }
     fclose(out);
-    fprintf(stderr, "%ld frames in %.3f s: %.1f frames/s, %.1f Mpix/s (%d feeder threads, %d frames per launch, entropy decode on the %s, MD5 on the %s%s)\n",
+    fprintf(stderr, "%ld frames in %.3f s: %.1f frames/s, %.1f Mpix/s (%d feeder threads, %d frames per launch, entropy decode on the %s, MD5 on the %s%s%s)\n",
             total, dt, total / dt, total / dt * g_width * g_height / 1e6, threads, g_batch, g_dev_entropy ? "device" : "host",
-            g_dev_md5 ? "device" : "host", no_download ? ", frames not downloaded" : "");
+            g_dev_md5 ? "device" : "host", no_download ? ", frames not downloaded" : "", g_corrupt ? "; CORRUPT FRAMES, see above" : "");
 
     pthread_mutex_lock(&pool.mu);
     pool.stop = 1;

@@ -161,9 +161,9 @@ static vpx_codec_err_t vp8_decode(vpx_codec_alg_priv_t *p, const uint8_t *data, 
                                   long deadline)
 {
     vp8ir_frame_hdr hdr, *h_hdr;
-    vp8ir_mb *h_mbs;
-    int16_t *h_blocks, *h_dcs;
-    size_t cap_blocks, nblocks = 0, ndcs = 0;
+    vp8ir_mbx *h_mbx;
+    int16_t *h_blocks;
+    size_t cap_blocks, nblocks = 0;
     vp8ir_mv *h_mvs;
     vp8hip_job job;
     int rc, corrupt = 0, i, nmb, nfrags;
@@ -256,12 +256,13 @@ static vpx_codec_err_t vp8_decode(vpx_codec_alg_priv_t *p, const uint8_t *data, 
         vp8_refs_on_alloc(&p->refs);
         memset(p->fb_corrupted, 0, sizeof p->fb_corrupted);
     }
-    /* the coefficients go up as the sparse streams of include/vp8_ir.h: a third of the bytes the dense array would cost PCIe */
-    if (vp8hip_ir_map_sparse(p->hip, 0, &h_hdr, &h_mbs, &h_blocks, &cap_blocks, &h_dcs, &h_mvs)) {
+    /* the feeder writes the device form of include/vp8_ir.h straight into the slot's pinned staging: what goes up is what the
+       kernels read (0.4 of the bytes the dense arrays would cost PCIe), with one copy and nothing in between */
+    if (vp8hip_ir_map_compact(p->hip, 0, &h_hdr, &h_mbx, &h_blocks, &cap_blocks, &h_mvs)) {
         vp8_refs_release_new(&p->refs);
         return gpu_error(p, "vp8hip_ir_map");
     }
-    rc = vp8_parser_decode_mbs_sparse(p->parser, h_mbs, h_blocks, cap_blocks, &nblocks, h_dcs, &ndcs, h_mvs, &corrupt);
+    rc = vp8_parser_decode_mbs_compact(p->parser, h_mbx, h_blocks, cap_blocks, &nblocks, h_mvs, &corrupt);
     if (rc) {
         vp8_refs_release_new(&p->refs);
         return set_detail(p, (vpx_codec_err_t)rc, vp8_parser_error(p->parser));
@@ -274,7 +275,7 @@ static vpx_codec_err_t vp8_decode(vpx_codec_alg_priv_t *p, const uint8_t *data, 
     p->ref_used = 0;
     if (hdr.frame_type != 0)
         for (i = 0; i < nmb; i++) {
-            int rf = h_mbs[i].ref_frame;
+            int rf = h_mbx[i].d.ref_frame;
             if (rf == VP8IR_LAST_FRAME) p->ref_used |= VP8_LAST_FRAME;
             else if (rf == VP8IR_GOLDEN_FRAME) p->ref_used |= VP8_GOLD_FRAME;
             else if (rf == VP8IR_ALTREF_FRAME) p->ref_used |= VP8_ALTR_FRAME;
@@ -299,7 +300,7 @@ static vpx_codec_err_t vp8_decode(vpx_codec_alg_priv_t *p, const uint8_t *data, 
         p->mb_class_cap = n;
     }
     t1 = now_s();
-    if (vp8hip_ir_upload_sparse(p->hip, 0, nblocks, ndcs)) { vp8_refs_release_new(&p->refs); return gpu_error(p, "vp8hip_ir_upload_sparse"); }
+    if (vp8hip_ir_upload_compact(p->hip, 0, nblocks)) { vp8_refs_release_new(&p->refs); return gpu_error(p, "vp8hip_ir_upload_compact"); }
     job.ir_slot = 0;
     job.dst_fb = p->refs.new_idx;
     job.ref_fb[0] = -1;
@@ -336,7 +337,7 @@ static vpx_codec_err_t vp8_decode(vpx_codec_alg_priv_t *p, const uint8_t *data, 
                        are asked for -- its intermediate buffer is never allocated, :929-941 -- so that combination is the one
                        piece here no listing pins.) */
                     const int deblocking = filters & (VP8HIP_PP_DEBLOCK | VP8HIP_PP_DEMACROBLOCK);
-                    vp8_pp_mfqe_classes(&hdr, h_mbs, h_mvs, p->mb_class);
+                    vp8_pp_mfqe_classes(&hdr, h_mbx, sizeof *h_mbx, h_mvs, p->mb_class);
                     if (vp8hip_mfqe(p->hip, show_fb, FB_POST, deblocking ? FB_PPINT : FB_POST, p->mb_class, hdr.base_qindex, qprev))
                         return gpu_error(p, "vp8hip_mfqe");
                     if (deblocking) {

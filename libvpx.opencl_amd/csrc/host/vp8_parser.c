@@ -1001,19 +1001,19 @@ static int read_mb_tokens(vp8_parser *p, vp8_boolreader *brp, const mbinfo *m, e
     return total;
 }
 
-static int decode_mbs(vp8_parser *p, vp8ir_mb *mbs, int16_t *coef, int16_t *blocks, size_t cap_blocks, size_t *nblocks,
-                      int16_t *dcs, size_t *ndcs, vp8ir_mv *mvs, int *corrupt);
+static int decode_mbs(vp8_parser *p, vp8ir_mb *mbs, int16_t *coef, vp8ir_mbx *mbx, int16_t *blocks, size_t cap_blocks, size_t *nblocks,
+                      vp8ir_mv *mvs, int *corrupt);
 
 int vp8_parser_decode_mbs(vp8_parser *p, vp8ir_mb *mbs, int16_t *coef, vp8ir_mv *mvs, int *corrupt)
 {
-    return decode_mbs(p, mbs, coef, NULL, 0, NULL, NULL, NULL, mvs, corrupt);
+    return decode_mbs(p, mbs, coef, NULL, NULL, 0, NULL, mvs, corrupt);
 }
 
-int vp8_parser_decode_mbs_sparse(vp8_parser *p, vp8ir_mb *mbs, int16_t *blocks, size_t cap_blocks, size_t *nblocks,
-                                 int16_t *dcs, size_t *ndcs, vp8ir_mv *mvs, int *corrupt)
+int vp8_parser_decode_mbs_compact(vp8_parser *p, vp8ir_mbx *mbx, int16_t *blocks, size_t cap_blocks, size_t *nblocks, vp8ir_mv *mvs,
+                                  int *corrupt)
 {
-    if (!blocks || !nblocks || !dcs || !ndcs) return fail(p, VP8P_INVALID_PARAM, "decode_mbs_sparse: no output streams");
-    return decode_mbs(p, mbs, NULL, blocks, cap_blocks, nblocks, dcs, ndcs, mvs, corrupt);
+    if (!mbx || !blocks || !nblocks) return fail(p, VP8P_INVALID_PARAM, "decode_mbs_compact: no output streams");
+    return decode_mbs(p, NULL, NULL, mbx, blocks, cap_blocks, nblocks, mvs, corrupt);
 }
 
 /* ---- token partitions -----------------------------------------------------------------------
@@ -1023,29 +1023,30 @@ int vp8_parser_decode_mbs_sparse(vp8_parser *p, vp8ir_mb *mbs, int16_t *blocks, 
  * several partitions are decoded by up to min(T, N) threads, each owning the partitions t, t+T, ..., rows in order;
  * a row runs at most as far as the row above has got (per-row progress counters, release / acquire), which is how the
  * reference's own multi-threaded decoder synchronises (vp8/decoder/threading.c, sync_range).  The output is the serial
- * decoder's byte for byte: sparse streams are written per thread into disjoint regions of the caller's arrays and
- * closed up afterwards. */
+ * decoder's in the dense form; in the device form every thread writes its rows' blocks into a region of the block stream of
+ * its own, closed up afterwards (a row's blocks stay together, which is all the form asks: include/vp8_ir.h). */
 #define PROGRESS_STRIDE 16       /* ints: a cache line per row counter */
-typedef struct tok_stream {      /* where a thread's sparse output goes */
-    int16_t *blocks, *dcs;
-    size_t first_block, first_dc;    /* region start inside the caller's arrays (entries) */
-    size_t cap_blocks;               /* entries this region may take */
-    size_t nb, nd;
+typedef struct tok_stream {      /* where a thread's blocks go (device form) */
+    int16_t *blocks;
+    size_t first_block;              /* region start inside the caller's array (blocks) */
+    size_t cap_blocks;               /* blocks this region may take */
+    size_t nb;
 } tok_stream;
 
 typedef struct tok_job {
     vp8_parser *p;
-    vp8ir_mb *mbs;
+    vp8ir_mb *mbs;                   /* dense form: descriptors, coefficients ... */
     int16_t *coef;
+    vp8ir_mbx *mbx;                  /* ... or the device form: records (+ the threads' block streams) */
     vp8ir_mv *mvs;
     int nthreads;
     volatile int *progress;          /* per row: macroblocks finished */
-    int overflow;                 /* set by any thread (atomically): a sparse stream ran out of room */
+    int overflow;                 /* set by any thread (atomically): a block stream ran out of room */
 } tok_job;
 
 typedef struct tok_worker { tok_job *job; int id; tok_stream out; int bad; pthread_t thread; } tok_worker;
 
-/* one macroblock row; returns nonzero when the thread's sparse region is full */
+/* one macroblock row; returns nonzero when the thread's region of the block stream is full */
 static int decode_row(tok_job *j, tok_stream *out, int r, vp8_boolreader *br)
 {
     vp8_parser *p = j->p;
@@ -1057,7 +1058,8 @@ static int decode_row(tok_job *j, tok_stream *out, int r, vp8_boolreader *br)
     memset(&left, 0, sizeof left);
     for (c = 0; c < p->mb_cols; c++, m++) {
         size_t n = (size_t)r * p->mb_cols + c;
-        vp8ir_mb *o = &j->mbs[n];
+        vp8ir_mbx *x = j->mbx ? &j->mbx[n] : NULL;
+        vp8ir_mb *o = x ? &x->d : &j->mbs[n];
         entropy_ctx *A = &p->above[c];
         const unsigned mb_idx = (unsigned)n;
         int has_y2;
@@ -1079,7 +1081,8 @@ static int decode_row(tok_job *j, tok_stream *out, int r, vp8_boolreader *br)
                 if (++spins < 2000) cpu_relax(); else sched_yield();
             }
         }
-        memset(o, 0, sizeof *o);
+        if (x) { memset(x, 0, sizeof *x); o->sparse_first = (uint32_t)(out->first_block + out->nb); }
+        else memset(o, 0, sizeof *o);
         if (m->skip) {                       /* vp8_reset_mb_tokens_context, detokenize.c:70-85 */
             uint8_t ay2 = A->y2, ly2 = left.y2;
             memset(A, 0, sizeof *A);
@@ -1090,7 +1093,6 @@ static int decode_row(tok_job *j, tok_stream *out, int r, vp8_boolreader *br)
                neither reset nor marked skipped (its inner edges are loop-filtered), it gets no residual: the reference adds
                the all-zero qcoeff through whatever eobs the macroblock before left behind, which is the prediction unchanged */
             if (coef) memset(coef + n * VP8IR_COEF_PER_MB, 0, VP8IR_COEF_PER_MB * sizeof(int16_t));
-            else { o->sparse_first = (uint32_t)(out->first_block + out->nb); o->dc_first = (uint32_t)(out->first_dc + out->nd); }
         } else {
             int16_t local[VP8IR_COEF_PER_MB];
             int16_t *q = coef ? coef + n * VP8IR_COEF_PER_MB : local;
@@ -1105,19 +1107,19 @@ static int decode_row(tok_job *j, tok_stream *out, int r, vp8_boolreader *br)
                    residual keeps the prediction alone; its skip flag stays what the tokens said */
                 memset(o->eobs, 0, 25);
                 if (coef) memset(q, 0, VP8IR_COEF_PER_MB * sizeof(int16_t));
-                else { o->sparse_first = (uint32_t)(out->first_block + out->nb); o->dc_first = (uint32_t)(out->first_dc + out->nd); }
-            } else if (!coef) {              /* sparse streams: full blocks and lone DCs, in block order (vp8_ir.h) */
+            } else if (x) {
+                /* the device form (vp8_ir.h): the Y2 block and the lone first coefficients with the record, the blocks with more
+                   than that into the stream, in block order */
                 int k;
-                o->sparse_first = (uint32_t)(out->first_block + out->nb);
-                o->dc_first = (uint32_t)(out->first_dc + out->nd);
-                for (k = 0; k < 25; k++) {
-                    if (k == 24 && !has_y2) break;
+                if (has_y2) memcpy(x->y2, q + 24 * 16, 32);
+                for (k = 0; k < 24; k++) {
                     if (o->eobs[k] > 1) {
                         if (out->nb >= out->cap_blocks) { __atomic_store_n(&j->overflow, 1, __ATOMIC_RELEASE); return 1; }
                         memcpy(out->blocks + (out->first_block + out->nb) * 16, q + k * 16, 32);
                         out->nb++;
-                    } else if (o->eobs[k] == 1 && !(has_y2 && k < 16))
-                        out->dcs[out->first_dc + out->nd++] = q[k * 16];   /* (at most 25 per macroblock: the caller's array is that large) */
+                    } else if (o->eobs[k] == 1 && !(has_y2 && k < 16)) {
+                        if (k < 16) x->y2[k] = q[k * 16]; else x->cdc[k - 16] = q[k * 16];
+                    }
                 }
             }
         }
@@ -1128,7 +1130,6 @@ static int decode_row(tok_job *j, tok_stream *out, int r, vp8_boolreader *br)
         o->uv_mode = m->uv_mode;
         o->ref_frame = m->ref_frame;
         o->flags = (uint8_t)((m->skip ? VP8IR_MB_SKIP : 0) | (m->need_clamp ? VP8IR_MB_CLAMP : 0));
-        if (!coef && m->skip) { o->sparse_first = (uint32_t)(out->first_block + out->nb); o->dc_first = (uint32_t)(out->first_dc + out->nd); }
         o->segment_id = m->segment_id;
         o->partitioning = m->y_mode == VP8IR_SPLITMV ? m->partitioning : 0;
         if (m->y_mode == VP8IR_B_PRED)
@@ -1175,13 +1176,13 @@ void vp8_parser_set_threads(vp8_parser *p, int threads)
     if (p) p->threads = threads < 1 ? 1 : (threads > 8 ? 8 : threads);
 }
 
-/* coef != NULL: dense output; else the sparse stream (vp8_ir.h) */
-static int decode_mbs(vp8_parser *p, vp8ir_mb *mbs, int16_t *coef, int16_t *blocks, size_t cap_blocks, size_t *nblocks,
-                      int16_t *dcs, size_t *ndcs, vp8ir_mv *mvs, int *corrupt)
+/* mbx == NULL: the dense form (mbs, coef); else the device form (mbx, blocks) of vp8_ir.h */
+static int decode_mbs(vp8_parser *p, vp8ir_mb *mbs, int16_t *coef, vp8ir_mbx *mbx, int16_t *blocks, size_t cap_blocks, size_t *nblocks,
+                      vp8ir_mv *mvs, int *corrupt)
 {
     int r, t, bad = 0, nthreads;
     int is_key;
-    size_t nb = 0, nd = 0;
+    size_t nb = 0;
     tok_job job;
     tok_worker w[8];
     if (!p->frame_open)
@@ -1191,7 +1192,8 @@ static int decode_mbs(vp8_parser *p, vp8ir_mb *mbs, int16_t *coef, int16_t *bloc
         return fail(p, VP8P_INVALID_PARAM, "inter frame needs an mv array");
     if (p->segmap_stale && !is_key && p->segmentation_enabled && !p->update_mb_segmentation_map)
         return fail(p, VP8P_UNSUP_BITSTREAM, "the segment map this frame keeps belongs to a frame that was decoded on the device");
-    if (is_key || !p->segmentation_enabled || p->update_mb_segmentation_map) p->segmap_stale = 0;
+    /* (only a frame that writes every segment id makes the host's map current again: a frame with segmentation off leaves it alone) */
+    if (is_key || (p->segmentation_enabled && p->update_mb_segmentation_map)) p->segmap_stale = 0;
 
     read_modes(p);
     bad |= vp8br_error(&p->first) | p->corrupted;
@@ -1204,24 +1206,24 @@ static int decode_mbs(vp8_parser *p, vp8ir_mb *mbs, int16_t *coef, int16_t *bloc
     memset(p->above, 0, (size_t)p->mb_cols * sizeof(entropy_ctx));
     memset(&job, 0, sizeof job);
     memset(w, 0, sizeof w);
-    job.p = p; job.mbs = mbs; job.coef = coef; job.mvs = mvs;
+    job.p = p; job.mbs = mbs; job.coef = coef; job.mbx = mbx; job.mvs = mvs;
     nthreads = p->threads < p->num_tok ? p->threads : p->num_tok;
     if (nthreads > p->mb_rows) nthreads = p->mb_rows;
     if (p->ec_active) nthreads = 1;              /* what a lost residual does to the macroblocks after it is decided in frame order */
-    /* a thread's sparse region has to hold the worst case of its rows; with a smaller array the frame is decoded serially */
-    if (nthreads > 1 && !coef && cap_blocks < (size_t)p->mb_rows * p->mb_cols * 25) nthreads = 1;
+    /* a thread's region of the block stream has to hold the worst case of its rows; with a smaller array the frame is decoded serially */
+    if (nthreads > 1 && mbx && cap_blocks < (size_t)p->mb_rows * p->mb_cols * VP8IR_MAX_BLOCKS_PER_MB) nthreads = 1;
     if (nthreads > 1) {
         int *pr = (int *)realloc(p->progress, (size_t)p->mb_rows * PROGRESS_STRIDE * sizeof(int));
         if (pr) p->progress = pr; else nthreads = 1;
     }
     if (nthreads <= 1) {
-        w[0].out.blocks = blocks; w[0].out.dcs = dcs; w[0].out.cap_blocks = cap_blocks;
+        w[0].out.blocks = blocks; w[0].out.cap_blocks = cap_blocks;
         for (r = 0; r < p->mb_rows; r++) {
             vp8_boolreader *br = &p->tok[r & (p->num_tok - 1)];   /* round-robin, decodframe.c:1116-1129 */
-            if (decode_row(&job, &w[0].out, r, br)) return fail(p, VP8P_MEM_ERROR, "sparse coefficient stream overflow");
+            if (decode_row(&job, &w[0].out, r, br)) return fail(p, VP8P_MEM_ERROR, "block stream overflow");
             bad |= vp8br_error(br);
         }
-        nb = w[0].out.nb; nd = w[0].out.nd;
+        nb = w[0].out.nb;
     } else {
         size_t at = 0;
         int started = 0;
@@ -1232,9 +1234,9 @@ static int decode_mbs(vp8_parser *p, vp8ir_mb *mbs, int16_t *coef, int16_t *bloc
             size_t rows_t = 0;
             for (r = 0; r < p->mb_rows; r++) rows_t += row_owner(p, r, nthreads) == t;
             w[t].job = &job; w[t].id = t;
-            w[t].out.blocks = blocks; w[t].out.dcs = dcs;
-            w[t].out.first_block = w[t].out.first_dc = at;         /* the same offsets serve both arrays: 25 entries per macroblock */
-            w[t].out.cap_blocks = rows_t * p->mb_cols * 25;
+            w[t].out.blocks = blocks;
+            w[t].out.first_block = at;
+            w[t].out.cap_blocks = rows_t * p->mb_cols * VP8IR_MAX_BLOCKS_PER_MB;
             at += w[t].out.cap_blocks;
         }
         for (t = 1; t < nthreads; t++) {
@@ -1248,24 +1250,23 @@ static int decode_mbs(vp8_parser *p, vp8ir_mb *mbs, int16_t *coef, int16_t *bloc
         }
         tok_worker_main(&w[0]);
         for (t = 1; t < nthreads; t++) pthread_join(w[t].thread, NULL);
-        if (__atomic_load_n(&job.overflow, __ATOMIC_ACQUIRE)) return fail(p, VP8P_MEM_ERROR, "sparse coefficient stream overflow");
+        if (__atomic_load_n(&job.overflow, __ATOMIC_ACQUIRE)) return fail(p, VP8P_MEM_ERROR, "block stream overflow");
         for (t = 0; t < nthreads; t++) bad |= w[t].bad;
-        if (!coef) {
-            /* close the gaps: thread t's entries follow thread t-1's, and its macroblocks' indices move with them.
-               (Macroblock order inside the streams is by thread, then by row: the streams are addressed through
-               sparse_first / dc_first only.) */
+        if (mbx) {
+            /* close the gaps: thread t's blocks follow thread t-1's, and its macroblocks' indices move with them.
+               (Row order inside the stream is by thread: the stream is addressed through sparse_first, row by row.) */
             for (t = 0; t < nthreads; t++) {
-                const size_t db = w[t].out.first_block - nb, dd = w[t].out.first_dc - nd;
-                if (db) memmove(blocks + nb * 16, blocks + w[t].out.first_block * 16, w[t].out.nb * 32);
-                if (dd) memmove(dcs + nd, dcs + w[t].out.first_dc, w[t].out.nd * sizeof(int16_t));
-                if (db || dd)
+                const size_t db = w[t].out.first_block - nb;
+                if (db) {
+                    memmove(blocks + nb * 16, blocks + w[t].out.first_block * 16, w[t].out.nb * 32);
                     for (r = 0; r < p->mb_rows; r++)
                         if (row_owner(p, r, nthreads) == t) {
-                            vp8ir_mb *o = mbs + (size_t)r * p->mb_cols;
+                            vp8ir_mbx *o = mbx + (size_t)r * p->mb_cols;
                             int c;
-                            for (c = 0; c < p->mb_cols; c++) { o[c].sparse_first -= (uint32_t)db; o[c].dc_first -= (uint32_t)dd; }
+                            for (c = 0; c < p->mb_cols; c++) o[c].d.sparse_first -= (uint32_t)db;
                         }
-                nb += w[t].out.nb; nd += w[t].out.nd;
+                }
+                nb += w[t].out.nb;
             }
         }
     }
@@ -1290,7 +1291,6 @@ static int decode_mbs(vp8_parser *p, vp8ir_mb *mbs, int16_t *coef, int16_t *bloc
     }
     if (corrupt) *corrupt = bad;
     if (nblocks) *nblocks = nb;
-    if (ndcs) *ndcs = nd;
     p->frame_open = 0;
     return VP8P_OK;
 }

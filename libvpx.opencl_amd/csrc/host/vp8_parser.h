@@ -47,7 +47,7 @@ void vp8_parser_destroy(vp8_parser *p);
  * their harmless values.  A short FIRST partition stays an error (the reference reads behind the buffer there). */
 void vp8_parser_set_error_concealment(vp8_parser *p, int on);
 int  vp8_parser_conceals(const vp8_parser *p);
-/* The header of the frame vp8_parser_decode_mbs[_sparse] has just decoded, as the pixel path is to see it: what begin_frame
+/* The header of the frame vp8_parser_decode_mbs[_compact] has just decoded, as the pixel path is to see it: what begin_frame
  * returned, except for a key frame in which concealment replaced intra macroblocks by inter ones (frame_type 1, lf_key_frame 1:
  * vp8_ir.h).  Callers that enable concealment pass THIS header on; key frames then need the mv array too. */
 void vp8_parser_frame_hdr(const vp8_parser *p, vp8ir_frame_hdr *out);
@@ -74,12 +74,13 @@ int vp8_parser_begin_frame_fragments(vp8_parser *p, const uint8_t *const *frags,
  * Returns VP8P_OK, or an error; *corrupt (optional) reports a truncated partition. */
 int vp8_parser_decode_mbs(vp8_parser *p, vp8ir_mb *mbs, int16_t *coef, vp8ir_mv *mvs, int *corrupt);
 
-/* The same with the coefficients as the sparse streams of include/vp8_ir.h: `blocks` receives 16 int16 per block with more
- * than one coded position (at most cap_blocks of them; 25 per macroblock is the worst case), `dcs` (room for 25 per macroblock)
- * one int16 per block with a lone DC; *nblocks / *ndcs how many; mbs[].sparse_first / dc_first say where each macroblock's
- * entries start. */
-int vp8_parser_decode_mbs_sparse(vp8_parser *p, vp8ir_mb *mbs, int16_t *blocks, size_t cap_blocks, size_t *nblocks,
-                                 int16_t *dcs, size_t *ndcs, vp8ir_mv *mvs, int *corrupt);
+/* The same straight into the DEVICE FORM of include/vp8_ir.h -- what an IR slot holds in HBM and the pixel kernels read: a
+ * feeder gives the pinned staging of a slot (vp8hip_ir_map_compact) and the upload is one copy.  mbx[n]: the records; `blocks`:
+ * 16 int16 per block with more than one coded position (at most cap_blocks of them; 24 per macroblock is the worst case);
+ * *nblocks how many.  With vp8_parser_set_threads the rows of different token partitions stand in the stream thread by thread
+ * (every row's blocks together, found through mbx[row start].d.sparse_first, as the form allows). */
+int vp8_parser_decode_mbs_compact(vp8_parser *p, vp8ir_mbx *mbx, int16_t *blocks, size_t cap_blocks, size_t *nblocks, vp8ir_mv *mvs,
+                                  int *corrupt);
 
 /* Step 2 on the device (include/vp8hip.h: vp8hip_entropy_decode): instead of decoding the macroblocks, hand over what the
  * frame header left behind -- the first partition's decoder state at the first macroblock, the token partitions' extents (all

@@ -112,11 +112,12 @@ int vp8_pp_mfqe_step(vp8_pp_state *st, const vp8_postproc_cfg_t *cfg, int base_q
     return 0;
 }
 
-void vp8_pp_mfqe_classes(const vp8ir_frame_hdr *hdr, const vp8ir_mb *mbs, const vp8ir_mv *mvs, uint8_t *cls)
+void vp8_pp_mfqe_classes(const vp8ir_frame_hdr *hdr, const void *mb_array, size_t mb_stride, const vp8ir_mv *mvs, uint8_t *cls)
 {
     const int n = hdr->mb_cols * hdr->mb_rows;
     int i;
     for (i = 0; i < n; i++) {
+        const vp8ir_mb *mbs = (const vp8ir_mb *)((const char *)mb_array + (size_t)i * mb_stride) - i;   /* mbs[i] = descriptor i */
         int still = hdr->frame_type == 0;
         if (!still) {
             const int intra = mbs[i].ref_frame == VP8IR_INTRA_FRAME || !mvs;

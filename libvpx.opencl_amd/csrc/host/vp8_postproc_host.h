@@ -34,7 +34,8 @@ int vp8_pp_prepare(vp8_pp_state *st, const vp8_postproc_cfg_t *cfg, int filter_l
  * index -- with *qprev = that index; the running index then moves a quarter of the way (:969), otherwise it becomes the frame's. */
 int vp8_pp_mfqe_step(vp8_pp_state *st, const vp8_postproc_cfg_t *cfg, int base_qindex, int *qprev);
 /* ... and the class of every macroblock for vp8hip_mfqe (postproc.c:834-843): cls[mb_rows * mb_cols]; mvs may be NULL on key
- * frames.  A macroblock's vector is its last block's (decodemv.c:490), zero for intra macroblocks (:563). */
-void vp8_pp_mfqe_classes(const vp8ir_frame_hdr *hdr, const vp8ir_mb *mbs, const vp8ir_mv *mvs, uint8_t *cls);
+ * frames.  A macroblock's vector is its last block's (decodemv.c:490), zero for intra macroblocks (:563).  mb_array: the
+ * macroblocks' descriptors (vp8ir_mb), mb_stride bytes apart (64: a dense array; 128: the records of the device form). */
+void vp8_pp_mfqe_classes(const vp8ir_frame_hdr *hdr, const void *mb_array, size_t mb_stride, const vp8ir_mv *mvs, uint8_t *cls);
 
 #endif

@@ -129,7 +129,7 @@ def test_mfqe_policy(pkg):
         hdr = pkg.FrameHdr()
         hdr.mb_cols, hdr.mb_rows, hdr.frame_type = 25, 20, frame_type
         cls = np.zeros(n, np.uint8)
-        H.vp8_pp_mfqe_classes(ctypes.byref(hdr), ctypes.c_void_p(mbs.ctypes.data), ctypes.c_void_p(mvs.ctypes.data), ctypes.c_void_p(cls.ctypes.data))
+        H.vp8_pp_mfqe_classes(ctypes.byref(hdr), ctypes.c_void_p(mbs.ctypes.data), ctypes.c_size_t(64), ctypes.c_void_p(mvs.ctypes.data), ctypes.c_void_p(cls.ctypes.data))
         for i in range(n):
             mv = (0, 0) if mbs[i, 2] == 0 else tuple(int(v) for v in mvs[i, 15])
             still = frame_type == 0 or (abs(mv[0]) <= 10 and abs(mv[1]) <= 10)

@@ -48,14 +48,14 @@ def _launch(P, ctx, refs, n):
 
 def test_every_launch_size_regime_gives_the_reference_frame(decoded, monkeypatch):
     P, ctx, refs, gold = decoded
-    for v in ("VP8HIP_INTER_SPLIT", "VP8HIP_INTER_TILED", "VP8HIP_RECON", "VP8HIP_XCU", "VP8HIP_LF_RASTER"):
+    for v in ("VP8HIP_INTER_SPLIT", "VP8HIP_RECON", "VP8HIP_XCU"):
         monkeypatch.delenv(v, raising=False)
     whole = None
-    for n, lane_lf in ((1, False), (3, False), (384, False), (500, False), (640, True), (700, True)):
+    for n, lane_lf in ((1, False), (3, False), (384, False), (500, False), (513, True), (700, True)):
         for i in range(n):                                   # nothing left over from the previous launch
             ctx.upload_frame(4 + i, np.zeros(ctx.g.frame_size, np.uint8)) if i in (0, n // 2, n - 1) else None
         st = _launch(P, ctx, refs, n)
-        assert (st.lf_waves == 1) == lane_lf, (n, st.lf_waves)       # 640 and more: one macroblock row per lane ...
+        assert (st.lf_waves == 1) == lane_lf, (n, st.lf_waves)       # more than two frames per CU: one macroblock row per lane ...
         assert st.fused == int(lane_lf), (n, st.fused)               # ... prediction kernel + vp8_interframe_kernel
         for i in sorted({0, n // 2, n - 1}):
             assert P.planes_md5(*ctx.download_planes(4 + i)) == gold, (n, i)
@@ -65,15 +65,13 @@ def test_every_launch_size_regime_gives_the_reference_frame(decoded, monkeypatch
         assert np.array_equal(full, whole), n                # borders included, bit for bit the same on every path
 
 
-@pytest.mark.parametrize("knobs", [{"VP8HIP_RECON": "simt"},                                    # key frames: the fused kernel, its pass on stream 2
-                                   {"VP8HIP_RECON": "simt", "VP8HIP_FUSED": "0", "VP8HIP_LF_RASTER": "0"},   # ... the deferred pass
-                                   {"VP8HIP_RECON": "simt", "VP8HIP_INTER_TILED": "1", "VP8HIP_LF_RASTER": "0"}])
+@pytest.mark.parametrize("knobs", [{"VP8HIP_RECON": "simt"}])                                   # the lane-per-row kernels, their pass on stream 2
 def test_launches_chained_without_sync_wait_for_the_raster_pass(pkg, monkeypatch, knobs):
     """A launch whose tiled -> raster pass still runs (or has not even been launched) on the second stream, followed at once --
     no sync, no download -- by launches of inter frames that read those frame buffers as references: the library has to join
-    the pass first (vp8hip.hip: `!all_key` in the join condition).  Eight streams side by side, three frames each."""
+    the pass first (vp8hip_launch.hip: `reads_pending`).  Eight streams side by side, three frames each."""
     P = pkg
-    for k in ("VP8HIP_RECON", "VP8HIP_FUSED", "VP8HIP_LF_RASTER", "VP8HIP_INTER_TILED", "VP8HIP_INTER_SPLIT"):
+    for k in ("VP8HIP_RECON", "VP8HIP_INTER_SPLIT"):
         monkeypatch.delenv(k, raising=False)
     for k, v in knobs.items():
         monkeypatch.setenv(k, v)
@@ -113,7 +111,7 @@ def test_independent_launches_run_past_the_raster_pass_dependent_ones_wait(pkg, 
     long ago: the library lets it start while the first launch's tiled -> raster pass still runs --, then frame 3, which
     predicts from what the first launch wrote and has to wait for that pass.  Everything equals the reference decoder's frames."""
     P = pkg
-    for k in ("VP8HIP_FUSED", "VP8HIP_LF_RASTER", "VP8HIP_INTER_TILED", "VP8HIP_INTER_SPLIT", "VP8HIP_INTER_FUSED"):
+    for k in ("VP8HIP_INTER_SPLIT",):
         monkeypatch.delenv(k, raising=False)
     monkeypatch.setenv("VP8HIP_RECON", "simt")
     name, n = "p_dense_1920x1080", 8
@@ -164,7 +162,7 @@ def test_mixed_launch_sizes_chained_without_sync(pkg, monkeypatch, sizes):
     some launch before it wrote.  A stream's frame f is only launched where its frame f - 1 was; all of them must be the
     reference decoder's."""
     P = pkg
-    for k in ("VP8HIP_RECON", "VP8HIP_FUSED", "VP8HIP_LF_RASTER", "VP8HIP_INTER_TILED", "VP8HIP_INTER_SPLIT", "VP8HIP_INTER_FUSED"):
+    for k in ("VP8HIP_RECON", "VP8HIP_INTER_SPLIT"):
         monkeypatch.delenv(k, raising=False)
     name = "p_dense_1920x1080"
     w, h, frames = P.read_ivf(ivf_path(name))
@@ -208,7 +206,7 @@ def test_key_and_inter_frames_in_one_launch(pkg, monkeypatch):
     different points: some start over with their key frame while the others decode a P frame): the key frames go the key-frame way
     inside the inter-frame kernel, nobody's tiles or references get mixed up."""
     P = pkg
-    for k in ("VP8HIP_FUSED", "VP8HIP_LF_RASTER", "VP8HIP_INTER_TILED", "VP8HIP_INTER_SPLIT", "VP8HIP_INTER_FUSED"):
+    for k in ("VP8HIP_INTER_SPLIT",):
         monkeypatch.delenv(k, raising=False)
     monkeypatch.setenv("VP8HIP_RECON", "simt")
     name, n = "p_dense_1920x1080", 12

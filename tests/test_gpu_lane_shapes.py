@@ -1,11 +1,11 @@
 """GPU (-m gpu): every launch shape of the lane-per-row kernel family, through the C ABI.
 
-The host picks the lanes per strand G = 2 .. 64 from the launch size (libvpx.opencl_amd/csrc/hip/vp8hip.hip), so
+The host picks the lanes per strand G = 2 .. 64 from the launch size (libvpx.opencl_amd/csrc/hip/vp8hip_launch.hip), so
 small test launches always ran G = 64 (one strand per wave) while the benchmark's 8192-frame launch runs G = 8:
 eight strands per wave, where the DPP `wave_shr:1` hand-over crosses strand boundaries and is gated off for the
-first lane of every strand, strands take jobs q, q + nstrands, ..., and the three scratch sets rotate.  These tests
-force every G (VP8HIP_SIMT_LGG) with both output paths (loop filter writing raster / tiled -> raster pass) and
-few waves (VP8HIP_SIMT_WAVES) so that strands carry several jobs, on content that differs per strand:
+first lane of every strand, strands take jobs q, q + nstrands, ..., and the three tile sets rotate.  These tests
+force every G (VP8HIP_SIMT_LGG) and few waves (VP8HIP_SIMT_WAVES) so that strands carry several jobs, on content that
+differs per strand:
 
  * seeded random IR against the oracle, whole buffer incl. borders (decode_mb_row order, vp8/decoder/decodframe.c:334-436;
    loop filter order, vp8/common/loopfilter.c:265-299), sizes on both sides of cols = 2G+2, filtered and unfiltered
@@ -34,19 +34,12 @@ def lgG(request):
     return request.param
 
 
-@pytest.fixture(params=["fused", "raster", "detile"])
-def lane_shape(request, lgG, monkeypatch):
-    """fused: reconstruction and loop filter in one kernel (vp8_keyframe_simt_kernel), what all-key-frame launches run by default.
-    The others are the two-kernel pipeline (VP8HIP_FUSED=0).  raster / detile: the loop filter writes the frame buffers itself / a tiled -> raster pass does; the loop filter runs as
-    luma + chroma kernels side by side."""
+@pytest.fixture
+def lane_shape(lgG, monkeypatch):
+    """Reconstruction and loop filter in one kernel (vp8_keyframe_kernel), what large all-key-frame launches run, at every G."""
     monkeypatch.setenv("VP8HIP_RECON", "simt")
     monkeypatch.setenv("VP8HIP_SIMT_LGG", str(lgG))
-    monkeypatch.setenv("VP8HIP_FUSED", "1" if request.param == "fused" else "0")
-    if request.param == "detile":
-        monkeypatch.setenv("VP8HIP_LF_RASTER", "0")
-    else:
-        monkeypatch.delenv("VP8HIP_LF_RASTER", raising=False)
-    return lgG, request.param
+    return lgG, "fused"
 
 
 def _waves_for(n, lgG, jobs_per_strand):
@@ -105,7 +98,7 @@ def test_benchmark_shape_full_size(pkg, monkeypatch):
     kernel and shape choice.  Frames i and i + 10k decode copies of the same IR on different strands, waves and scratch
     sets: >= 64 of them, spread over the launch, must equal the reference MD5 and each other byte for byte (borders
     included); three launches back to back rotate the scratch sets and job tables."""
-    for k in ("VP8HIP_RECON", "VP8HIP_SIMT_LGG", "VP8HIP_SIMT_WAVES", "VP8HIP_LF_RASTER", "VP8HIP_FUSED"):
+    for k in ("VP8HIP_RECON", "VP8HIP_SIMT_LGG", "VP8HIP_SIMT_WAVES"):
         monkeypatch.delenv(k, raising=False)
     import torch
     free, _total = torch.cuda.mem_get_info(0)

@@ -20,38 +20,22 @@ def ctx(pkg):
     c.close()
 
 
-@pytest.fixture(params=["wave", "wave1cu", "wave_split", "wave1cu_split", "wave_tiled", "lane", "lane_2k", "lane_detile"], autouse=True)
+@pytest.fixture(params=["wave", "wave1cu", "wave_split", "wave1cu_split", "lane"], autouse=True)
 def kernel_family(request, monkeypatch):
     """Every test runs with all kernel variants: "wave" = one wave per MB row with a frame pair spread over several
     CUs where the launch is small enough (granule hand-over through global memory), "wave1cu" = the same kernels with
-    a frame pair on one CU (hand-over through LDS; what larger launches use), "lane" = one MB row per lane (large launches):
-    launches of key frames with both stages run the fused kernel (vp8_keyframe_simt_kernel: reconstruction + loop filter in one
-    pass, raster output), "lane_2k" = the two-kernel pipeline on macroblock-tiled scratch frames instead (VP8HIP_FUSED=0; the loop
-    filter writes the raster frame buffers when some frame of the launch is filtered, else a detile pass does), "lane_detile" =
-    the same with the detile pass always.  "..._split":
-    launches with inter frames always run vp8_inter_mb_kernel (every inter macroblock on its own) before the row-ordered kernel
-    does the intra macroblocks -- by default only launches of up to 384 frames do; "wave1cu" never does.  "wave_tiled": every
-    launch with inter frames hands over from the wave-per-row recon to the lane-per-row loop filter through the tiled scratch
-    frames (by default launches of 640 frames and more).  VP8HIP_RECON /
-    VP8HIP_XCU / VP8HIP_INTER_SPLIT are the library's tuning knobs that override the automatic choice
-    (libvpx.opencl_amd/csrc/hip/vp8hip.hip)."""
+    a frame pair on one CU (hand-over through LDS; what larger launches use), "lane" = one MB row per lane (what large launches
+    run): launches with both stages run vp8_keyframe_kernel, or vp8_inter_pred_kernel + vp8_interframe_kernel when inter frames
+    are among them (reconstruction + loop filter in one pass into macroblock-window tiles, then the tiled -> raster pass);
+    single-stage launches run the wave-per-row kernels whatever the knob says.  "..._split": launches with inter frames
+    always run vp8_inter_mb_kernel (every inter macroblock on its own) before the row-ordered kernel does the intra macroblocks
+    -- by default only launches of up to 384 frames do; "wave1cu" never does.  VP8HIP_RECON / VP8HIP_XCU / VP8HIP_INTER_SPLIT are
+    the library's tuning knobs that override the automatic choice (libvpx.opencl_amd/csrc/hip/vp8hip_launch.hip: launch_regime)."""
     monkeypatch.setenv("VP8HIP_RECON", "simt" if request.param.startswith("lane") else "wave")
-    if request.param == "lane_detile":      # the tiled -> raster pass also for launches whose loop filter could write raster
-        monkeypatch.setenv("VP8HIP_LF_RASTER", "0")
-    else:
-        monkeypatch.delenv("VP8HIP_LF_RASTER", raising=False)
-    if request.param in ("lane_2k", "lane_detile"):
-        monkeypatch.setenv("VP8HIP_FUSED", "0")
-    else:
-        monkeypatch.delenv("VP8HIP_FUSED", raising=False)
     if request.param.startswith("wave1cu"):
         monkeypatch.setenv("VP8HIP_XCU", "0")
     else:
         monkeypatch.delenv("VP8HIP_XCU", raising=False)
-    if request.param == "wave_tiled":
-        monkeypatch.setenv("VP8HIP_INTER_TILED", "1")
-    else:
-        monkeypatch.delenv("VP8HIP_INTER_TILED", raising=False)
     if request.param.endswith("_split"):
         monkeypatch.setenv("VP8HIP_INTER_SPLIT", "100000")
     elif request.param == "wave1cu":

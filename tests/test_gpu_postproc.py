@@ -130,7 +130,7 @@ def test_mfqe_against_the_oracle(w, h):
                     ctypes.c_void_p(show.ctypes.data), ctypes.c_void_p(expect.ctypes.data), ctypes.c_int(qcurr), ctypes.c_int(qprev))
         H = P.load_host()
         cls = np.zeros(n, np.uint8)
-        H.vp8_pp_mfqe_classes(ctypes.byref(hdr), ctypes.c_void_p(mbs.ctypes.data), ctypes.c_void_p(mvs.ctypes.data),
+        H.vp8_pp_mfqe_classes(ctypes.byref(hdr), ctypes.c_void_p(mbs.ctypes.data), ctypes.c_size_t(64), ctypes.c_void_p(mvs.ctypes.data),
                               ctypes.c_void_p(cls.ctypes.data))
         seen |= set(cls.tolist())
         ctx.upload_frame(0, show)

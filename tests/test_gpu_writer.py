@@ -21,19 +21,17 @@ CASES = [  # width, height, seed, log2 partitions, filter_type, dense, big, segm
 ]
 
 
-@pytest.fixture(params=["auto", "wave1cu", "lane", "lane_detile"], autouse=True)
+@pytest.fixture(params=["auto", "wave1cu", "lane"], autouse=True)
 def kernel_family(request, monkeypatch):
     """The library's own choice for the launch size (small launches: cross-CU wave-per-row kernels), and the other
     kernel variants forced through the tuning knobs (see tests/test_gpu_parity.py)."""
-    for k in ("VP8HIP_RECON", "VP8HIP_XCU", "VP8HIP_LF_RASTER"):
+    for k in ("VP8HIP_RECON", "VP8HIP_XCU"):
         monkeypatch.delenv(k, raising=False)
     if request.param == "wave1cu":
         monkeypatch.setenv("VP8HIP_RECON", "wave")
         monkeypatch.setenv("VP8HIP_XCU", "0")
     elif request.param.startswith("lane"):
         monkeypatch.setenv("VP8HIP_RECON", "simt")
-        if request.param == "lane_detile":
-            monkeypatch.setenv("VP8HIP_LF_RASTER", "0")
     return request.param
 
 

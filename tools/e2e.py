@@ -33,13 +33,9 @@ def run(P, device=0, fixture="kf_1920x1080", nframes=1024, batch=128, threads=No
     import ctypes
     c_void_p, c_size_t = ctypes.c_void_p, ctypes.c_size_t
 
-    def map_sparse(slot):            # pinned staging of a slot: header, descriptors, the two sparse coefficient streams, MVs
-        ph, pm, pb, pd, pv, cap = c_void_p(), c_void_p(), c_void_p(), c_void_p(), c_void_p(), c_size_t()
-        ctx._chk(ctx.L.vp8hip_ir_map_sparse(ctx.h, slot, ctypes.byref(ph), ctypes.byref(pm), ctypes.byref(pb), ctypes.byref(cap),
-                                            ctypes.byref(pd), ctypes.byref(pv)), "vp8hip_ir_map_sparse")
-        return ph.value, pm.value, pb.value, cap.value, pd.value, pv.value
-    maps = [map_sparse(s) for s in range(3 * batch)]   # created by the main thread
-    counts = [(0, 0)] * (3 * batch)                     # (full blocks, lone DCs) the feeder wrote per slot
+    # pinned staging of the slots in the device form of include/vp8_ir.h: header, records, block stream, MVs
+    maps = [ctx.ir_map_compact(s) for s in range(3 * batch)]   # created by the main thread
+    counts = [0] * (3 * batch)                          # blocks the feeder wrote per slot
     h2d_bytes = [0]
     parsers = [P.Parser() for _ in range(threads)]
     free = list(range(threads))
@@ -48,9 +44,9 @@ def run(P, device=0, fixture="kf_1920x1080", nframes=1024, batch=128, threads=No
         k = free.pop()                                 # list.pop / append are atomic under the GIL
         ps = parsers[k]
         hdr, _ = ps.begin(data)
-        ph, pm, pb, cap, pd, pv = maps[slot]
-        nb, nd, _ = ps.decode_mbs_sparse(pm, pb, cap, pd, pv)
-        counts[slot] = (nb, nd)
+        ph, pm, pb, pv, cap = maps[slot]
+        nb, _ = ps.decode_mbs_compact(pm, pb, cap, pv)
+        counts[slot] = nb
         ctypes.memmove(ph, ctypes.byref(hdr), 64)
         ps.swap(hdr)
         free.append(k)
@@ -91,9 +87,9 @@ def run(P, device=0, fixture="kf_1920x1080", nframes=1024, batch=128, threads=No
     def launch(b, n):
         base = (b % 3) * batch
         for i in range(n):
-            nb, nd = counts[base + i]
-            ctx._chk(L.vp8hip_ir_upload_sparse(ctx.h, base + i, nb, nd), "vp8hip_ir_upload_sparse")
-            h2d_bytes[0] += nb * 32 + nd * 2 + ctx.nmb * 64
+            nb = counts[base + i]
+            ctx._chk(L.vp8hip_ir_upload_compact(ctx.h, base + i, nb), "vp8hip_ir_upload_compact")
+            h2d_bytes[0] += nb * 32 + ctx.nmb * 128
         ctx.decode([(base + i, base + i, None) for i in range(n)], P.STAGE_ALL)
 
     hashing = None                                     # (batch, futures) whose digests are still being computed
