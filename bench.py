@@ -3,14 +3,19 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--frames F] [--workload 1080p|4k]
 
-One "step" = one pass of the whole pixel path (dequant+IDCT/WHT + intra reconstruction, in-loop
-deblocking filter, border extension: the three kernels behind include/vp8hip.h) over a batch of F
-independent key frames whose IR (modes, eobs, dense coefficients) is ALREADY RESIDENT IN HBM.  The
-batch is the committed fixture tests/golden/kf_1920x1080.ivf (10 key frames, entropy-decoded once
-on the host, outside the timed region) looped F/10 times -- legal because every key frame is
-independently decodable (reference: vp8/decoder/decodframe.c:610-639).  Before timing, decoded
-frames are checked bit-exactly against the reference decoder's per-frame MD5s
-(tests/golden/*.md5).
+One "step" = one pass of the whole pixel path (dequant + IDCT / WHT, intra reconstruction, in-loop deblocking filter: the
+kernels behind include/vp8hip.h) over a batch of F independent key frames.  What is resident in HBM when the timed region starts
+is the frames' IR AS A PRODUCER LEFT IT: every slot holds the device form of include/vp8_ir.h -- the form the host feeder
+(vp8_parser_decode_mbs_compact) writes into a slot's pinned staging and one copy uploads, and the form the device's entropy
+decoder writes; no kernel conditions it before the pixel kernels read it (rounds 1-3 ran a packing pass over fresh slots
+outside the timed region).  The batch is the committed fixture tests/golden/kf_1920x1080.ivf (10 key frames, entropy-decoded
+once on the host, outside the timed region) looped F/10 times -- legal because every key frame is independently decodable
+(reference: vp8/decoder/decodframe.c:610-639).  What a step leaves: the decoded frames in the TILED form of a large launch
+(macroblock-window tiles, include/vp8hip.h "two forms"), which the consumers of such a pipeline read without a further pass --
+the device's MD5 kernel (vpxdec --md5 / decode_to_md5), a batch download into page-locked memory (the tiled -> raster pass IS
+the download), the border-extended raster form for inter prediction on demand.  `config.consumers` times the step with each of
+them behind it; `config.with_raster_form` is round 3's step (decode, then the raster form of every frame in HBM).  Before
+timing, decoded frames are checked bit-exactly against the reference decoder's per-frame MD5s (tests/golden/*.md5).
 
 N > 1: one rank per GPU -- under torch.distributed.run, or spawned by bench.py itself when no launcher set
 WORLD_SIZE -- decoding ONE looped stream of N * F frames in contiguous blocks of F (rank r: frames [r*F, (r+1)*F),
@@ -21,7 +26,8 @@ which must equal the 1-GPU listing.
 Prints ONE JSON line on rank 0 (see README / DESIGN.md for the field definitions):
   value      whole-job Mpix/s (display pixels) = N * F * K * w * h / seconds
   roofline   dominant kernel: algorithmic bytes per launch (SURVEY.md 8d byte model) / mean launch
-             time measured with HIP events on the launch stream, vs 8 TB/s HBM peak
+             time measured with HIP events on the launch stream, vs 8 TB/s HBM peak; `traffic` from the counter passes
+             recorded in profiles/traffic_per_mb.json (tools/profile_round.sh writes it)
   cpu_baseline  the REAL reference decoder (oracle/_ref, generic-C build of /root/reference) timed on
              this host on the same stream, 1 core; falls back to the repo's C restatement ("port")
 """
@@ -40,26 +46,21 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 B_RECON = 833 + 384      # coefficients+eobs+params read, pixels written (key frames)
 B_LF = 770               # pixels read + written, params
 B_EXTEND = 36
-B_DETILE = 384 + 384 + 36  # lane-per-row pipeline only: tiled scratch read, raster frame + borders written
+B_DETILE = 384 + 384 + 36  # the tiled -> raster pass: tiles read, raster frame + borders written
 B_INTER_FULL = 833 + 768 + 770 + 36   # full path on P frames
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-# HBM traffic per macroblock of the lane-per-row kernels (1080p key frames, G = 8 as at the default launch size), from
-# `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, KiB; FETCH_SIZE doubled: the gfx950 correction
-# for 16-byte-per-lane loads, which the detile pass confirms -- it reads exactly 384 B/MB) over tools/pmc_one.py 7 1024
-# with VP8HIP_SIMT_LGG=3: profiles/r01_*_pmc_*_1024frames_G8*.csv.  The counter passes crash or hang at 8192 frames per
-# launch and under torch, so bench.py scales these per-macroblock figures instead of counting live.
-PMC_TRAFFIC_B_PER_MB = {        # the loop filter (luma + chroma kernels) writes the raster frame buffers, then vp8_extend_kernel (default);
-    # profiles/r02_a_pmc_{FETCH,WRITE}_SIZE_1024frames_G8.csv.  The loop filter's 1014 B/MB of writes against 384 B/MB of pixels are
-    # the 32-byte (luma) and 16-byte (chroma) pieces of frame rows a lane has to give at a time
-    "recon": 2 * 529.5 + 385.7, "loopfilter": 2 * (168.1 + 104.1) + 535.6 + 478.8, "extend": 2 * 27.5 + 40.4}
-# vp8_keyframe_kernel (reconstruction + loop filter in one pass, packed coefficients in, macroblock-window tiles out) and its tiled ->
-# raster pass + border extension: profiles/r03_b_pmc_{fetch,write}_1024_G8.csv (1024 frames per launch, 8 lanes per strand as at the
-# default launch size; FETCH_SIZE doubled as above).  At 64 lanes per strand -- every SIMD busy, most lanes idle -- the kernel fetches
-# 1270 B/MB (r03_b_pmc_fetch_1024_G64.csv); its writes at 8192 frames per launch: 495 B/MB (r03_b_pmc_write_8192_sharedIR.csv).
-# End of round 3 (lone luma DCs with the descriptor, 16-byte chroma stores): profiles/r03_g_pmc_{fetch,write}_1024_G8.*
-PMC_TRAFFIC_B_PER_MB_FUSED = {"recon": 2 * 369.5 + 462.3, "loopfilter": 0.0, "extend": 2 * 193.8 + 396.5 + 2 * 27.5 + 40.4}
-PMC_TRAFFIC_B_PER_MB_DETILE = { # tiled -> raster pass (vp8_detile_kernel) after the loop filter
-    "recon": 2 * 448.68 + 385.22, "loopfilter": 2 * 239.63 + 414.12, "extend": 2 * 192.08 + 466.87}
+
+
+def load_traffic():
+    """HBM traffic per macroblock of the kernels of a step, from `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes (separate
+    passes; FETCH_SIZE doubled: the gfx950 correction for 16-byte-per-lane loads): profiles/traffic_per_mb.json, written by
+    tools/profile_round.sh from the passes whose CSVs lie beside it.  The counter passes do not survive under torch, so bench.py
+    scales these per-macroblock figures by the macroblocks of a launch instead of counting live; None if the file is missing."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "traffic_per_mb.json")))
+    except Exception:  # noqa: BLE001
+        return None
+
 
 WORKLOADS = {
     "1080p": ("kf_1920x1080", 1920, 1080),
@@ -149,7 +150,7 @@ def inter_frame_probe(P, device, n=4096, name="p_dense_1920x1080", k=2):
         ctx.L.vp8hip_frame_copy(ctx.h, 4 + 2 * i, r.lst_idx)
         jobs[i].ir_slot, jobs[i].dst_fb = 2 + i, 5 + 2 * i
         jobs[i].ref_fb[1], jobs[i].ref_fb[2], jobs[i].ref_fb[3] = 4 + 2 * i, r.gld_idx, r.alt_idx
-    for _ in range(3):              # (the library's three scratch sets are allocated by the first three launches that rotate them)
+    for _ in range(2):              # (the first launch allocates the tiled forms)
         ctx.decode_array(jobs, n, P.STAGE_ALL)
     ctx.sync()
     ok = P.planes_md5(*ctx.download_planes(5 + 2 * (n // 2))) == gold[k]
@@ -161,7 +162,7 @@ def inter_frame_probe(P, device, n=4096, name="p_dense_1920x1080", k=2):
     dt = (time.perf_counter() - t0) / reps
     st = ctx.stats()
     # the same launches CHAINED: every launch predicts from the frames the launch before it wrote (n streams in lock step, as a
-    # decoder runs them), so nothing of a launch -- its tiled -> raster pass neither -- can run beside the next one
+    # decoder runs them): the reference frames' raster form is produced at the start of every launch
     back = (P.Job * n)()
     for i in range(n):
         back[i].ir_slot, back[i].dst_fb = 2 + i, 4 + 2 * i
@@ -186,10 +187,10 @@ def inter_frame_probe(P, device, n=4096, name="p_dense_1920x1080", k=2):
             "kernel_ms": {"recon": round(st.recon_ms, 3), "loopfilter": round(st.lf_ms, 3), "extend": round(st.extend_ms, 3)},
             "kernel_family": ("vp8_inter_pred_kernel (every inter macroblock's six-tap prediction, order-free, into the macroblock's tile) + "
                               "vp8_interframe_kernel (residual + loop filter, one macroblock row per lane, luma and chroma waves paired "
-                              "on every SIMD: kernel_ms.recon is both) + vp8_detile_kf_kernel / vp8_extend_kernel beside the next launch"
-                              if st.fused else
-                              "wave-per-row recon into the tiled scratch frames, lane-per-row loop filter (luma + chroma kernels)"
-                              if st.lf_waves == 1 else "one wave per macroblock row"),
+                              "on every SIMD: kernel_ms.recon is both); the frames are left as tiles, and a launch that predicts from "
+                              "frames the launch before left that way (chained) first gets their border-extended raster form "
+                              "(vp8_detile_kf_kernel + vp8_extend_kernel, on the same stream)"
+                              if st.fused else "one wave per macroblock row"),
             "roofline": {"bound": "hbm", "achieved": round(gbps, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(gbps / HBM_PEAK_GBPS, 5),
                          "note": "SURVEY 8(d) full inter path 2407 B/MB x macroblocks per launch / wall time per launch"}}
@@ -212,13 +213,14 @@ def batch_md5_probe(fixture, device, loops=205, extra=()):
     bad = sum(1 for i, g in enumerate(got) if g != gold[i % len(gold)]) + abs(len(got) - loops * len(gold))
     import re
     m = re.search(r"(\d+) frames in ([0-9.]+) s: ([0-9.]+) frames/s, ([0-9.]+) Mpix/s \((\d+) feeder threads, (\d+) frames per launch, "
-                  r"entropy decode on the (\w+), MD5 on the (\w+)(, frames not downloaded)?(?:; (\d+) frames per entropy launch)?\)", r.stderr)
+                  r"entropy decode on the (\w+), MD5 on the (\w+)(, frames not downloaded)?(?:; (\d+) frames per entropy launch)?(?:; (\d+) corrupt)?"
+                  r"(; CORRUPT FRAMES, see above)?\)", r.stderr)
     if not m:
         return {"error": "unparsed: " + r.stderr[-200:]}
     return {"tool": " ".join(["bin/batch_md5", *extra, "--loop", str(loops)]), "frames": int(m.group(1)), "frames_per_s": float(m.group(3)),
             "Mpix_s": float(m.group(4)), "host_threads": int(m.group(5)), "frames_per_launch": int(m.group(6)), "entropy_decode_on": m.group(7),
             "md5_on": m.group(8), "frames_downloaded": m.group(9) is None, "frames_per_entropy_launch": int(m.group(10) or m.group(6)),
-            "md5_mismatches": bad}
+            "md5_mismatches": bad, "corrupt_frames": int(m.group(11)) if m.group(11) else (1 if m.group(12) else 0)}
 
 
 def streams_probe(device, streams=4096, fixture="p_1920x1080"):
@@ -423,6 +425,75 @@ def main():
         dist.all_gather(allt, t)
         per_rank = [float(x.item()) for x in allt]
         elapsed = max(per_rank)
+    # ---- the step with a consumer behind it (rank 0, N = 1; never `value`): what reads the frames a step leaves
+    consumers = with_raster = None
+    if rank == 0 and world == 1:
+        def timed(fn, reps=3):
+            fn(); ctx.sync()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            ctx.sync()
+            return (time.perf_counter() - t0) / reps * 1e3
+
+        L = ctx.L
+        L.vp8hip_frames_fetch_async.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+        L.vp8hip_download_wait.argtypes = [ctypes.c_void_p]
+        L.vp8hip_host_alloc.restype = ctypes.c_void_p
+        L.vp8hip_host_alloc.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+        L.vp8hip_host_free.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        L.vp8hip_frame_stride.restype = ctypes.c_size_t
+        L.vp8hip_frame_stride.argtypes = [ctypes.c_void_p]
+        dig = L.vp8hip_host_alloc(ctx.h, 16 * F)
+
+        def step_md5():
+            ctx.decode_array(jobs, F, P.STAGE_ALL)
+            ctx._chk(L.vp8hip_frames_fetch_async(ctx.h, 0, F, None, dig), "fetch")
+            ctx._chk(L.vp8hip_download_wait(ctx.h), "wait")
+
+        def step_raster():
+            ctx.decode_array(jobs, F, P.STAGE_ALL)
+            ctx.frames_to_raster(0, F)
+
+        consumers = {}
+        try:
+            t_md5 = timed(step_md5)
+            import numpy as np
+            got = np.ctypeslib.as_array(ctypes.cast(dig, ctypes.POINTER(ctypes.c_uint8)), shape=(F, 16))
+            bad = sum(1 for i in range(F) if got[i].tobytes().hex() != gold[(lo + i) % nsrc])
+            consumers["device_md5"] = {"ms_per_step": round(t_md5, 3), "Mpix_s": round(F * W * H / t_md5 / 1e3, 1), "md5_mismatches": bad,
+                                       "what": f"decode {F} frames, then vp8_md5_tiles_kernel hashes every one of them from the tiles (a frame per "
+                                               f"lane) and the {F} digests come back: decode_to_md5's output for the step"}
+        except Exception as ex:      # noqa: BLE001 - a probe, not the benchmark
+            consumers["device_md5"] = {"error": repr(ex)}
+        try:
+            nd = min(F, 512)
+            stride = L.vp8hip_frame_stride(ctx.h)
+            host = L.vp8hip_host_alloc(ctx.h, stride * nd)
+
+            def dl():
+                ctx._chk(L.vp8hip_frames_fetch_async(ctx.h, 0, nd, host, None), "fetch")
+                ctx._chk(L.vp8hip_download_wait(ctx.h), "wait")
+            ctx.decode_array(jobs, F, P.STAGE_ALL); ctx.sync()
+            t_dl = timed(dl)
+            import numpy as np
+            hv = np.ctypeslib.as_array(ctypes.cast(host, ctypes.POINTER(ctypes.c_uint8)), shape=(nd, stride))
+            okd = all(P.frame_md5(hv[i], ctx.g, W, H) == gold[(lo + i) % nsrc] for i in (0, nd // 2, nd - 1))
+            consumers["download"] = {"frames": nd, "ms": round(t_dl, 3), "GB_s_over_pcie": round(nd * W * H * 1.5 / t_dl / 1e6, 2), "md5_ok": bool(okd),
+                                     "what": "vp8_detile_run_kernel writes the raster rows of the frames straight into page-locked host memory "
+                                             "(the tiled -> raster pass is the download; no raster form in HBM)"}
+            L.vp8hip_host_free(ctx.h, host)
+        except Exception as ex:      # noqa: BLE001
+            consumers["download"] = {"error": repr(ex)}
+        try:
+            t_r = timed(step_raster)
+            with_raster = {"ms_per_step": round(t_r, 3), "Mpix_s": round(F * W * H / t_r / 1e3, 1),
+                           "roofline_pipeline_frac": round((B_RECON + B_LF + B_EXTEND) * nmb * F / (t_r * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5),
+                           "what": "round 3's step: decode, then the border-extended raster form of every frame in HBM (vp8_detile_kf_kernel + "
+                                   "vp8_extend_kernel behind the launch on the same stream); 2023 B/MB"}
+        except Exception as ex:      # noqa: BLE001
+            with_raster = {"error": repr(ex)}
+        L.vp8hip_host_free(ctx.h, dig)
     # single-frame latency: one frame per launch (what a single-stream decoder sees), kernels only
     latency_ms = None
     copy_gbps = None
@@ -454,33 +525,21 @@ def main():
     if rank == 0:
         K = args.steps
         total_pix = world * F * K * W * H
-        lane = st.recon_waves == 1            # the lane-per-row kernels ran (see vp8hip_stats)
-        detile = bool(st.detile_pass)         # ... finished by the tiled -> raster pass instead of the loop filter's own raster output
-        bytes_per_launch = {"recon": B_RECON * nmb * F, "loopfilter": B_LF * nmb * F,
-                            "extend": (B_DETILE if detile else B_EXTEND) * nmb * F}
-        # (the lane-per-row loop filter is two kernels side by side on two streams, luma and chroma; "loopfilter" is the interval
-        #  both take together, which is the duration of the luma kernel -- the chroma kernel ends inside it)
-        split = st.lf_kernels == 2      # (VP8HIP_FUSED=0 only: the two-kernel pipeline's loop filter as luma + chroma kernels)
-        fused = bool(getattr(st, "fused", 0))   # reconstruction + loop filter in ONE kernel (vp8_keyframe_kernel): ms["recon"] is its time
-        if fused:
-            # SURVEY.md 8(d)'s byte model for the stages the kernel covers: residual + intra recon (1217) + loop filter (770)
-            bytes_per_launch["recon"] = (B_RECON + B_LF) * nmb * F
-            bytes_per_launch["loopfilter"] = 0
-        names = ({"recon": "vp8_recon_simt_kernel",
-                  "loopfilter": "vp8_loopfilter_simt_luma_kernel (with vp8_loopfilter_simt_chroma_kernel beside it)",
-                  "extend": "vp8_detile_kernel (tiled -> raster + border extension)" if detile else "vp8_extend_kernel"} if lane else
+        lane = bool(st.fused)                 # the lane-per-row kernels ran (see vp8hip_stats): reconstruction + loop filter in ONE kernel
+        bytes_per_launch = {"recon": B_RECON * nmb * F, "loopfilter": B_LF * nmb * F, "extend": B_EXTEND * nmb * F}
+        if lane:
+            # SURVEY.md 8(d)'s byte model for the stages the kernel covers: residual + intra recon (1217) + loop filter (770); the
+            # borders are produced with the raster form, when something asks for it (config.with_raster_form)
+            bytes_per_launch = {"recon": (B_RECON + B_LF) * nmb * F, "loopfilter": 0, "extend": 0}
+        names = ({"recon": "vp8_keyframe_kernel", "loopfilter": None, "extend": None} if lane else
                  {"recon": "vp8_recon_kernel", "loopfilter": "vp8_loopfilter_kernel", "extend": "vp8_extend_kernel"})
-        if fused:
-            names["recon"] = "vp8_keyframe_kernel"
-            names["loopfilter"] = None
-            names["extend"] = ("vp8_detile_kf_kernel + vp8_extend_kernel (tiled -> raster, then borders; on a second stream BESIDE the next "
-                               "launch's vp8_keyframe_kernel, so its time overlaps that kernel's)")
         dom = max(ms, key=lambda k: ms[k])
         achieved = bytes_per_launch[dom] / (ms[dom] * 1e-3) / 1e9
-        # SURVEY.md 8(d)'s own figure for the full key-frame path: 1217 + 770 + 36 = 2023 B/MB
-        survey_gbps = (B_RECON + B_LF + B_EXTEND) * nmb * F / (elapsed_local / K) / 1e9
-        pmc = PMC_TRAFFIC_B_PER_MB_FUSED if fused else PMC_TRAFFIC_B_PER_MB_DETILE if detile else PMC_TRAFFIC_B_PER_MB
-        counted = lane and args.workload == "1080p"
+        # the whole step by SURVEY.md 8(d): 1217 + 770 B/MB (+ 36 when the step extends borders: the wave-per-row kernels)
+        step_bytes = (B_RECON + B_LF + (0 if lane else B_EXTEND)) * nmb * F
+        survey_gbps = step_bytes / (elapsed_local / K) / 1e9
+        traffic = load_traffic()
+        tk = (traffic or {}).get("kernels", {}).get(names[dom] or "", None) if args.workload == "1080p" else None
         out = {
             "metric": "vp8_decode_pixel_path_mpix_per_s",
             "value": round(total_pix / elapsed / 1e6, 1),
@@ -496,8 +555,11 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"{W}x{H} all-key-frame VP8 stream (tests/golden/{fixture}.ivf looped to {world * F} frames), full "
-                            f"pixel path: dequant+IDCT/WHT + intra recon + loop filter + border extend "
-                            f"(BASELINE configs[1]+[3]{'+[4]' if args.workload == '4k' else ''}); IR resident in HBM, MD5-checked vs the reference",
+                            f"pixel path: dequant+IDCT/WHT + intra recon + loop filter "
+                            f"(BASELINE configs[1]+[3]{'+[4]' if args.workload == '4k' else ''}); IR resident in HBM in the device form of "
+                            f"include/vp8_ir.h exactly as the host feeder uploaded it (no conditioning pass); frames left in the "
+                            f"tiled form a large launch writes, read as such by the MD5 kernel and the batch download "
+                            f"(config.consumers); MD5-checked vs the reference",
                 "frames_per_gpu_per_step": F,
                 "macroblocks_per_frame": nmb,
                 "parallelism": f"one stream of {world * F} frames sharded in contiguous blocks over {world} GPU(s) (rank r: frames "
@@ -507,13 +569,14 @@ def main():
                 "md5_checked_frames_per_rank": len(sample),
                 "kernel_ms": {k: round(v, 4) for k, v in ms.items()},
                 "kernel_family": ("one macroblock row per lane; reconstruction + loop filter fused, luma and chroma waves paired on every SIMD"
-                                  if fused else "one macroblock row per lane, macroblock-tiled scratch frames") if lane
-                                 else "one wave per macroblock row",
+                                  if lane else "one wave per macroblock row"),
                 "kernels": names,
                 "waves_per_workgroup": {"recon": st.recon_waves, "loopfilter": st.lf_waves},
                 "workgroups": st.workgroups,
                 "host_feeder_s_for_source_frames": round(feed_s, 4),
                 "single_frame_launch_ms": round(latency_ms, 3),
+                "consumers": consumers,
+                "with_raster_form": with_raster,
             },
             "roofline": {
                 "bound": "hbm",
@@ -522,17 +585,19 @@ def main():
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 5),
-                "traffic": round(pmc[dom] * nmb * F) if counted and pmc[dom] is not None else None,
-                "traffic_source": ("scaled: per-macroblock FETCH_SIZE x2 + WRITE_SIZE of this kernel from rocprofv3 --pmc passes at "
-                                   "1024 frames per launch (profiles/), times the macroblocks of this launch") if counted else None,
-                "traffic_bytes_per_macroblock": ({k: (round(v, 1) if v is not None else None) for k, v in pmc.items()} if counted else None),
+                "traffic": round((2 * tk["fetch_KiB_per_mb"] + tk["write_KiB_per_mb"]) * 1024 * nmb * F) if tk else None,
+                "traffic_source": (f"scaled: per-macroblock FETCH_SIZE x2 + WRITE_SIZE of this kernel from the rocprofv3 --pmc passes of "
+                                   f"{traffic.get('source')} ({traffic.get('frames_per_launch')} frames per launch, {traffic.get('lanes_per_strand')} lanes "
+                                   f"per strand), times the macroblocks of this launch") if tk else None,
+                "traffic_bytes_per_macroblock": ({k: round((2 * v["fetch_KiB_per_mb"] + v["write_KiB_per_mb"]) * 1024, 1)
+                                                  for k, v in traffic["kernels"].items()} if tk else None),
                 "algorithmic_bytes_per_launch": bytes_per_launch[dom],
                 "mean_launch_ms": round(ms[dom], 4),
-                "all_kernels_GBps": {k: round(bytes_per_launch[k] / (ms[k] * 1e-3) / 1e9, 2) if ms[k] > 0 else None
+                "all_kernels_GBps": {k: round(bytes_per_launch[k] / (ms[k] * 1e-3) / 1e9, 2) if ms[k] > 1e-2 else None
                                      for k in ms},
                 "pipeline": {"achieved": round(survey_gbps, 2), "frac": round(survey_gbps / HBM_PEAK_GBPS, 5),
-                             "note": "SURVEY 8(d) bytes of the whole path (recon + loop filter + border extend = 2023 B/MB) / "
-                                     "whole step time, one GPU"},
+                             "note": "SURVEY 8(d) bytes of the stages the step runs (recon 1217 + loop filter 770 B/MB" +
+                                     ("" if lane else " + border extend 36") + ") / whole step time, one GPU"},
                 "device_copy_probe_GBps": round(copy_gbps, 1) if copy_gbps else None,
             },
         }
@@ -557,7 +622,7 @@ def main():
                     torch.cuda.synchronize()
                     c4.sync()
                 e4, ms4, _ = timed_steps(P, c4, j4, F4, 3, 1, b4)
-                gb4 = (B_RECON + B_LF + B_EXTEND) * c4.nmb * F4 / (e4 / 3) / 1e9
+                gb4 = (B_RECON + B_LF) * c4.nmb * F4 / (e4 / 3) / 1e9
                 out["config"]["workload_4k"] = {
                     "workload": f"{W4}x{H4} all-key-frame stream ({fx4}.ivf looped), {F4} frames per step, 3 steps",
                     "md5_ok": bool(ok4), "Mpix_s": round(F4 * 3 * W4 * H4 / e4 / 1e6, 1), "ms_per_step": round(e4 / 3 * 1e3, 3),
@@ -572,21 +637,28 @@ def main():
             except Exception as ex:      # a probe, not the benchmark: report, do not fail the line
                 out["config"]["inter_frames"] = {"error": repr(ex)}
         if world == 1 and args.workload == "1080p" and not args.no_end_to_end:
-            # host-inclusive rate (never `value`): compressed frames in host memory -> per-frame MD5, tools/e2e.py
-            try:
-                sys.path.insert(0, os.path.join(ROOT, "tools"))
+            # host-inclusive rates (never `value`): compressed frames in host memory -> per-frame MD5.  Every probe on its own: one
+            # that fails reports its error and leaves the others' results alone
+            e2 = out["config"]["end_to_end"] = {}
+
+            def probe(key, fn):
+                try:
+                    e2[key] = fn()
+                except Exception as ex:      # noqa: BLE001 - a probe, not the benchmark
+                    e2[key] = {"error": repr(ex)}
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+            def py_pipeline():
                 import e2e
-                out["config"]["end_to_end"] = e2e.run(P, local_rank, fixture=fixture, nframes=2048)
-                out["config"]["end_to_end"]["c_host"] = batch_md5_probe(fixture, local_rank)
-                # ... and with the macroblocks' modes and tokens decoded on the GPU, a frame per lane (vp8hip_entropy_decode): the host
-                # reads the frame headers only
-                out["config"]["end_to_end"]["device_entropy"] = batch_md5_probe(
-                    fixture, local_rank, 4096, ("--device-entropy", "--batch", "4096"))
-                out["config"]["end_to_end"]["device_entropy_frames_stay"] = batch_md5_probe(
-                    fixture, local_rank, 8192, ("--device-entropy", "--no-download", "--batch", "8192", "--entropy-batch", "16384", "--entropy-dense"))
-                out["config"]["end_to_end"]["inter_streams_device_entropy"] = streams_probe(local_rank)
-            except Exception as ex:      # a probe, not the benchmark: report, do not fail the line
-                out["config"]["end_to_end"] = {"error": repr(ex)}
+                return e2e.run(P, local_rank, fixture=fixture, nframes=2048)
+            probe("python_host_feeder", py_pipeline)
+            probe("c_host", lambda: batch_md5_probe(fixture, local_rank))
+            # ... and with the macroblocks' modes and tokens decoded on the GPU, a frame per lane (vp8hip_entropy_decode): the host
+            # reads the frame headers only
+            probe("device_entropy", lambda: batch_md5_probe(fixture, local_rank, 4096, ("--device-entropy", "--batch", "4096")))
+            probe("device_entropy_frames_stay", lambda: batch_md5_probe(
+                fixture, local_rank, 8192, ("--device-entropy", "--no-download", "--batch", "8192", "--entropy-batch", "16384")))
+            probe("inter_streams_device_entropy", lambda: streams_probe(local_rank))
         if not args.no_cpu_baseline and world == 1:      # the contract: rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(fixture)
         print(json.dumps(out))

@@ -56,13 +56,13 @@ typedef struct vp8hip_job {
 } vp8hip_job;
 
 typedef struct vp8hip_stats {      /* filled by vp8hip_get_stats; times from HIP events, ms */
-    float recon_ms, lf_ms, extend_ms;   /* last vp8hip_decode call; extend_ms = border extension, plus the
-                                           tiled-to-raster pass when the lane-per-row kernels ran */
+    float recon_ms, lf_ms, extend_ms;   /* last vp8hip_decode call; extend_ms = border extension (wave-per-row kernels), or the
+                                           tiled -> raster pass + borders if the launch ran it at once (detile_pass) */
     int   recon_waves, lf_waves;        /* waves per workgroup (1 = the lane-per-row kernels ran, 4 = the cross-CU
                                            variant of the wave-per-row kernels: small launches) */
     int   workgroups;
-    int   detile_pass;                  /* 1: a tiled -> raster pass finished the launch (the lane-per-row kernels ran); extend_ms
-                                           covers it */
+    int   detile_pass;                  /* 1: the launch produced the raster form of its frames at once (VP8HIP_EAGER_RASTER); by
+                                           default a large launch leaves tiles and the pass runs when the raster form is asked for */
     int   lf_kernels;                   /* loop-filter kernels launched: 1 (wave-per-row family, some frame filtered) or 0 */
     int   fused;                        /* 1: the lane-per-row kernels -- vp8_keyframe_kernel, or vp8_inter_pred_kernel +
                                            vp8_interframe_kernel -- reconstructed AND filtered the launch; recon_ms covers it,
@@ -209,6 +209,16 @@ int  vp8hip_download_wait(vp8hip_ctx *ctx);
  * have landed when vp8hip_download_wait returns.  Display widths that are not a multiple of 128 are refused with -3 (rows have
  * to be whole MD5 blocks): the caller hashes those frames on the host. */
 int  vp8hip_frames_fetch_async(vp8hip_ctx *ctx, int first_fb, int count, uint8_t *dst, uint8_t *digests);
+/* A frame buffer has two forms on the device: the RASTER form (vp8ir_geom: the reference's YV12 layout, borders included), which
+ * the small-launch kernels write and everything that reads pixels by coordinate reads (inter prediction, vp8hip_frame_download,
+ * the post-processing filters), and the TILED form a large launch leaves (macroblock-window tiles: the form in which a lane of
+ * vp8_keyframe_kernel can write whole 64-byte sectors).  The library converts a frame when something needs the form it is not in
+ * -- never behind the caller's back after a launch -- and reads tiles where it can: the MD5 kernel of vp8hip_frames_fetch_async
+ * walks them, and a batch download into page-locked memory is the tiled -> raster pass itself, writing host memory (the frame's
+ * raster form never exists in HBM; what lands in the destination's border bytes is then undefined).  vp8hip_frames_to_raster asks
+ * for the raster form of `count` consecutive frame buffers explicitly (asynchronous, on the context's stream; a no-op for frames
+ * that have it). */
+int  vp8hip_frames_to_raster(vp8hip_ctx *ctx, int first_fb, int count);
 /* Upload a whole frame buffer (frame_size bytes) -- tests and VP8_SET_REFERENCE. */
 int  vp8hip_frame_upload(vp8hip_ctx *ctx, int fb, const uint8_t *buf);
 int  vp8hip_frame_copy(vp8hip_ctx *ctx, int dst_fb, int src_fb);
@@ -227,14 +237,10 @@ int  vp8hip_get_stats(vp8hip_ctx *ctx, vp8hip_stats *st);
 /* Stats of an earlier launch: back = 0 the last vp8hip_decode call, 1 the one before, ... (up to 31).  Waits
  * for that launch only, so a caller can time a pipelined sequence and read the kernel times afterwards. */
 int  vp8hip_get_stats_at(vp8hip_ctx *ctx, int back, vp8hip_stats *st);
-/* The HIP stream (hipStream_t, as void*) the work of this context is enqueued on, so callers can
- * bracket it with their own events.  One exception: after a large all-key-frame launch the last pass
- * (tiled scratch -> raster frame buffer + borders) runs on a second, internal stream, and is only launched
- * together with the next such launch (it then runs beside that launch's loop filter) or by the next call that
- * needs it.  Every vp8hip_* call that touches frame buffers (download, upload, copy, sync, a launch of the other
- * kernel family, get_stats) takes care of that; a caller that enqueues its OWN work on vp8hip_stream() to read
- * frame buffers calls vp8hip_join() first, which launches the pass if need be and makes the stream wait (on the
- * device, not the host) for it. */
+/* The HIP stream (hipStream_t, as void*) the work of this context is enqueued on, so callers can bracket it with their own
+ * events.  (vp8hip_join: rounds 1-3 ran a pass on a second stream that callers with work of their own had to join; there is
+ * no such stream any more and the call does nothing.  A caller that reads frame buffers with kernels of its own asks for
+ * their raster form first: vp8hip_frames_to_raster.) */
 void *vp8hip_stream(vp8hip_ctx *ctx);
 int  vp8hip_join(vp8hip_ctx *ctx);
 

@@ -377,6 +377,7 @@ def load_hip():
         L.vp8hip_frame_download.argtypes = [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int]
         L.vp8hip_frame_upload.argtypes = [c_void_p, c_int, c_void_p]
         L.vp8hip_frame_copy.argtypes = [c_void_p, c_int, c_int]
+        L.vp8hip_frames_to_raster.argtypes = [c_void_p, c_int, c_int]
         L.vp8hip_sync.argtypes = [c_void_p]
         L.vp8hip_join.argtypes = [c_void_p]
         L.vp8hip_get_stats_at.argtypes = [c_void_p, c_int, ctypes.POINTER(Stats)]
@@ -535,6 +536,10 @@ class Vp8Hip:
         self._chk(self.L.vp8hip_frames_fetch_async(self.h, first_fb, count, None, out.ctypes.data), "vp8hip_frames_fetch_async")
         self._chk(self.L.vp8hip_download_wait(self.h), "vp8hip_download_wait")
         return [out[16 * i: 16 * i + 16].tobytes().hex() for i in range(count)]
+
+    def frames_to_raster(self, first_fb, count):
+        """Ask for the raster form of frame buffers a large launch left as tiles (vp8hip_frames_to_raster; asynchronous)."""
+        self._chk(self.L.vp8hip_frames_to_raster(self.h, first_fb, count), "vp8hip_frames_to_raster")
 
     def upload_frame(self, fb, buf):
         assert buf.nbytes == self.g.frame_size

@@ -19,16 +19,17 @@ typedef GLOBAL_AS u32x2_t *g_x2p;
 // window rows at an offset of -4 (the pieces of neighbouring groups complete the lines).  The first window's four pixels left of
 // the frame and the last window's pixels right of it land in the border, which vp8_extend_kernel writes afterwards.
 //
-// This pass is meant to run BESIDE the next launch's vp8_keyframe_kernel, whose two waves per SIMD leave 16 of the SIMD's 512
-// registers free: it keeps to 16 (two pointers, one piece of data, a counter; one load in flight per thread -- memory-level
-// parallelism comes from the six free wave slots of every SIMD, not from unrolling), so its waves fit in that gap and the
-// pass is hidden behind a kernel that is bound by the vector ALU.
+// The pass keeps to 16 registers (two pointers, one piece of data, a counter; one load in flight per thread -- memory-level
+// parallelism comes from the waves, not from unrolling): through round 3 it ran after every large launch, beside the next
+// launch's vp8_keyframe_kernel, in the 16 registers that kernel's two waves leave free on a SIMD; now it runs when a frame is
+// asked for in raster form (vp8hip_launch.hip).
 typedef u32x4_t u32x4_u4 __attribute__((aligned(4)));
 typedef u32x2_t u32x2_u4 __attribute__((aligned(4)));
-extern "C" __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(16)))
-vp8_detile_kf_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g)
+// `unit_of(unit, sbase, dbase)`: where macroblock row r of frame j (unit = j * rows + r) has its tiles and where the frame's raster form is
+template <class F>
+__device__ __forceinline__ void detile_body(int nunits, DevGeom g, F unit_of)
 {
-    const int cols = g.mb_cols, rows = g.mb_rows;
+    const int cols = g.mb_cols;
     const int t = threadIdx.x;
     const int tile = t & 7;
     const int wv = __builtin_amdgcn_readfirstlane(t >> 6);          // waves 0, 1: luma; 2: U; 3: V
@@ -42,12 +43,15 @@ vp8_detile_kf_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g)
     const unsigned doff = (unsigned)((luma ? g.y_off : (pl ? g.v_off : g.u_off)) + row * stride - (window ? 4 : 0) + tile * (luma ? 16 : 8));
     const unsigned soff = (unsigned)(tile * VP8_TILE_BYTES + src);
     const int ntiles = (window ? cols + 1 : cols) - tile;           // tiles tile, tile + 8, ... of a macroblock row
-    // a workgroup takes macroblock rows blockIdx.x, blockIdx.x + gridDim.x, ... of the launch (row r of job j: unit j * rows + r)
+    // a workgroup takes macroblock rows blockIdx.x, blockIdx.x + gridDim.x, ... of the launch
 #pragma unroll 1
-    for (int unit = blockIdx.x; unit < njobs * rows; unit += gridDim.x) {
-        const int j = unit / rows, r = unit - j * rows;
-        const GLOBAL_AS unsigned char *sbase = (const GLOBAL_AS unsigned char *)jobs[j].tile + (long)r * (cols + 1) * VP8_TILE_BYTES;
-        GLOBAL_AS unsigned char *dbase = (GLOBAL_AS unsigned char *)jobs[j].dst + (long)(r * (luma ? 16 : 8)) * stride;
+    for (int unit = blockIdx.x; unit < nunits; unit += gridDim.x) {
+        const GLOBAL_AS unsigned char *sbase;
+        GLOBAL_AS unsigned char *dbase;
+        int r;
+        unit_of(unit, sbase, dbase, r);
+        sbase += (long)r * (cols + 1) * VP8_TILE_BYTES;
+        dbase += (long)(r * (luma ? 16 : 8)) * stride;
         unsigned so = soff, dO = doff;
         if (luma) {
 #pragma unroll 1
@@ -59,4 +63,33 @@ vp8_detile_kf_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g)
                 *(GLOBAL_AS u32x2_u4 *)(dbase + dO) = *(const GLOBAL_AS u32x2_t *)(sbase + so);
         }
     }
+}
+
+extern "C" __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(16)))
+vp8_detile_kf_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g)
+{
+    const int rows = g.mb_rows;
+    detile_body(njobs * rows, g, [&](int unit, const GLOBAL_AS unsigned char *&sbase, GLOBAL_AS unsigned char *&dbase, int &r) {
+        const int j = unit / rows;
+        r = unit - j * rows;
+        sbase = (const GLOBAL_AS unsigned char *)jobs[j].tile;
+        dbase = (GLOBAL_AS unsigned char *)jobs[j].dst;
+    });
+}
+
+// The same for `count` frames whose tiled forms stand tstride bytes apart, into raster forms dstride bytes apart -- page-locked
+// HOST memory (vp8hip_frames_fetch_async): the frames leave the device through this pass, over PCIe, and their raster form never
+// exists in HBM.  (The left / right border columns next to the picture receive the first window's four pixels left of the frame and
+// the last window's pixels right of it: the destination is a whole frame buffer with its borders, whose contents outside the
+// picture are not defined by this path.)
+extern "C" __global__ void __launch_bounds__(256)
+vp8_detile_run_kernel(const uint8_t *__restrict__ tiles, size_t tstride, uint8_t *__restrict__ dst, size_t dstride, int count, DevGeom g)
+{
+    const int rows = g.mb_rows;
+    detile_body(count * rows, g, [&](int unit, const GLOBAL_AS unsigned char *&sbase, GLOBAL_AS unsigned char *&dbase, int &r) {
+        const int j = unit / rows;
+        r = unit - j * rows;
+        sbase = (const GLOBAL_AS unsigned char *)(tiles + tstride * (size_t)j);
+        dbase = (GLOBAL_AS unsigned char *)(dst + dstride * (size_t)j);
+    });
 }

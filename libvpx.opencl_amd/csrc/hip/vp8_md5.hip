@@ -11,7 +11,9 @@
 // walk over planes, rows and blocks is wave-uniform (scalar); only the frame's base address is per lane.  The blocks are
 // requested AHEAD blocks before they are hashed (each lane reads its own 64 bytes: nothing coalesces, only latency matters).
 // Rows must be whole blocks: display width a multiple of 128 (vp8hip_frames_fetch_async refuses other sizes; the caller hashes
-// those on the host).  Integer only.
+// those on the host).  Two readers: the raster form of a frame buffer (vp8_md5_kernel), and the TILED form a large launch leaves
+// (vp8_md5_tiles_kernel: macroblock-window tiles, vp8_keyframe_simt.hip) -- the hash is the consumer that proves a frame, and it
+// takes the frame as the decoder left it, without a tiled -> raster pass in between.  Integer only.
 #include "vp8_common.hip.h"
 
 namespace {
@@ -19,6 +21,7 @@ namespace {
 typedef unsigned int u32;
 typedef u32 u32x4 __attribute__((ext_vector_type(4)));
 typedef GLOBAL_AS const u32x4 *g_cu32x4p;
+typedef GLOBAL_AS const u32 *g_cu32p_;
 
 __device__ __forceinline__ u32 rol(u32 x, int s) { return __builtin_rotateleft32(x, (u32)s); }
 
@@ -50,12 +53,57 @@ __device__ __forceinline__ void md5_block(u32 &A, u32 &B, u32 &C, u32 &D, const 
     A += a; B += b; C += c; D += d;
 }
 
-} // namespace
+// The 64 bytes of block bx of pixel row `row` of plane pl, out of the frame's TILES (layout: vp8_keyframe_simt.hip, KT_*): rows
+// 0..11 of a macroblock row (chroma: 0..3) stand in the macroblocks' WINDOWS, shifted four pixels = one dword to the left -- a
+// block's sixteen dwords are dwords 1.. of five (chroma: nine) neighbouring tiles' row pieces --, rows 12..15 (4..7)
+// macroblock-aligned.  All offsets are wave-uniform; only `base` is the lane's.
+__device__ __forceinline__ void tile_block(g_cu8p base, int cols, int pl, int row, int bx, u32x4 (&q)[4])
+{
+    typedef u32 u32x2 __attribute__((ext_vector_type(2)));
+    typedef GLOBAL_AS const u32x2 *g_cu32x2p;
+    u32 m[16];
+    if (pl == 0) {
+        const int yy = row & 15;
+        g_cu8p t = base + ((long)(row >> 4) * (cols + 1) + 4 * bx) * VP8_TILE_BYTES;
+        if (yy >= 12) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) q[k] = *(g_cu32x4p)(t + k * VP8_TILE_BYTES + 192 + 16 * (yy - 12));
+            return;
+        }
+        t += 16 * yy;
+        const u32x4 a = *(g_cu32x4p)t, b = *(g_cu32x4p)(t + VP8_TILE_BYTES), c = *(g_cu32x4p)(t + 2 * VP8_TILE_BYTES),
+                    d = *(g_cu32x4p)(t + 3 * VP8_TILE_BYTES);
+        const u32 e = *(g_cu32p_)(t + 4 * VP8_TILE_BYTES);
+        q[0] = (u32x4){ a.y, a.z, a.w, b.x }; q[1] = (u32x4){ b.y, b.z, b.w, c.x };
+        q[2] = (u32x4){ c.y, c.z, c.w, d.x }; q[3] = (u32x4){ d.y, d.z, d.w, e };
+        return;
+    }
+    const int yy = row & 7;
+    g_cu8p t = base + ((long)(row >> 3) * (cols + 1) + 8 * bx) * VP8_TILE_BYTES + 32 * (pl - 1);
+    if (yy >= 4) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const u32x2 v = *(g_cu32x2p)(t + k * VP8_TILE_BYTES + 320 + 8 * (yy - 4));
+            m[2 * k] = v.x; m[2 * k + 1] = v.y;
+        }
+    } else {
+        t += 256 + 8 * yy;
+        u32 prev = *(g_cu32p_)(t + 4);                 // the second dword of the first window's row piece
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const u32x2 v = *(g_cu32x2p)(t + (k + 1) * VP8_TILE_BYTES);
+            m[2 * k] = prev; m[2 * k + 1] = v.x;
+            prev = v.y;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) q[k] = (u32x4){ m[4 * k], m[4 * k + 1], m[4 * k + 2], m[4 * k + 3] };
+}
 
-// frames: the first frame buffer; fstride: bytes from one to the next; w, h: display size (w a multiple of 128); out: 16 bytes per
-// frame.  One lane per frame, 64-thread blocks.
-extern "C" __global__ void __launch_bounds__(64)
-vp8_md5_kernel(const uint8_t *__restrict__ frames, size_t fstride, int count, DevGeom g, int w, int h, uint8_t *__restrict__ out)
+// frames: the first frame buffer (TILED: its tiles); fstride: bytes from one to the next; w, h: display size (w a multiple of 128);
+// out: 16 bytes per frame.  One lane per frame, 64-thread blocks.
+template <bool TILED>
+__device__ __forceinline__ void md5_frames(const uint8_t *__restrict__ frames, size_t fstride, int count, DevGeom g, int w, int h, uint8_t *__restrict__ out)
 {
     const int f = blockIdx.x * 64 + threadIdx.x;
     const bool live = f < count;
@@ -67,21 +115,22 @@ vp8_md5_kernel(const uint8_t *__restrict__ frames, size_t fstride, int count, De
     const long nblk = (long)h * (w >> 6) + 2L * ch * (cw >> 6);
     // fetch cursor (AHEAD blocks in front of the hash cursor); wave-uniform
     int pl = 0, row = 0, bx = 0;
-    auto next_addr = [&]() -> long {
-        const long off = pl == 0 ? g.y_off + (long)row * g.y_stride : (pl == 1 ? g.u_off : g.v_off) + (long)row * g.uv_stride;
-        const long a = off + 64L * bx;
+    auto fetch = [&](u32x4 (&q)[4]) {
+        if constexpr (TILED) tile_block(base, g.mb_cols, pl, row, bx, q);
+        else {
+            const long off = pl == 0 ? g.y_off + (long)row * g.y_stride : (pl == 1 ? g.u_off : g.v_off) + (long)row * g.uv_stride;
+            g_cu32x4p p = (g_cu32x4p)(base + off + 64L * bx);
+#pragma unroll
+            for (int k = 0; k < 4; k++) q[k] = p[k];
+        }
         const int per_row = (pl == 0 ? w : cw) >> 6, rows = pl == 0 ? h : ch;
         if (++bx == per_row) { bx = 0; if (++row == rows) { row = 0; pl++; } }
-        return a;
     };
     u32x4 q[AHEAD][4];
 #pragma unroll
     for (int i = 0; i < AHEAD; i++) {
-        if (i < nblk) {
-            g_cu32x4p p = (g_cu32x4p)(base + next_addr());
-#pragma unroll
-            for (int k = 0; k < 4; k++) q[i][k] = p[k];
-        } else {
+        if (i < nblk) fetch(q[i]);
+        else {
 #pragma unroll
             for (int k = 0; k < 4; k++) q[i][k] = (u32x4){ 0, 0, 0, 0 };
         }
@@ -92,11 +141,7 @@ vp8_md5_kernel(const uint8_t *__restrict__ frames, size_t fstride, int count, De
             if (blk + i < nblk) {
                 const u32 m[16] = { q[i][0].x, q[i][0].y, q[i][0].z, q[i][0].w, q[i][1].x, q[i][1].y, q[i][1].z, q[i][1].w,
                                     q[i][2].x, q[i][2].y, q[i][2].z, q[i][2].w, q[i][3].x, q[i][3].y, q[i][3].z, q[i][3].w };
-                if (blk + i + AHEAD < nblk) {
-                    g_cu32x4p p = (g_cu32x4p)(base + next_addr());
-#pragma unroll
-                    for (int k = 0; k < 4; k++) q[i][k] = p[k];
-                }
+                if (blk + i + AHEAD < nblk) fetch(q[i]);
                 md5_block(A, B, C, D, m);
             }
         }
@@ -108,4 +153,17 @@ vp8_md5_kernel(const uint8_t *__restrict__ frames, size_t fstride, int count, De
         md5_block(A, B, C, D, m);
     }
     if (live) *(GLOBAL_AS u32x4 *)(out + 16 * (size_t)f) = (u32x4){ A, B, C, D };
+}
+
+} // namespace
+
+extern "C" __global__ void __launch_bounds__(64)
+vp8_md5_kernel(const uint8_t *__restrict__ frames, size_t fstride, int count, DevGeom g, int w, int h, uint8_t *__restrict__ out)
+{
+    md5_frames<false>(frames, fstride, count, g, w, h, out);
+}
+extern "C" __global__ void __launch_bounds__(64)
+vp8_md5_tiles_kernel(const uint8_t *__restrict__ tiles, size_t tstride, int count, DevGeom g, int w, int h, uint8_t *__restrict__ out)
+{
+    md5_frames<true>(tiles, tstride, count, g, w, h, out);
 }

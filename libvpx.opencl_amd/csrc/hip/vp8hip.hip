@@ -14,6 +14,8 @@ extern "C" __global__ void vp8_recon_intra_xcu_kernel(const DevJob *jobs, int nj
                                                       int S, int *err, const unsigned int *intra_flags);
 extern "C" __global__ void vp8_loopfilter_kernel(const DevJob *jobs, int njobs, DevGeom g);
 extern "C" __global__ void vp8_md5_kernel(const uint8_t *frames, size_t fstride, int count, DevGeom g, int w, int h, uint8_t *out);
+extern "C" __global__ void vp8_md5_tiles_kernel(const uint8_t *tiles, size_t tstride, int count, DevGeom g, int w, int h, uint8_t *out);
+extern "C" __global__ void vp8_detile_run_kernel(const uint8_t *tiles, size_t tstride, uint8_t *dst, size_t dstride, int count, DevGeom g);
 
 static char g_create_error[256] = "";
 
@@ -27,12 +29,11 @@ static void read_knobs(Knobs &k)
     k.wg_per_cu = env_int("VP8HIP_WG_PER_CU", 1);
     k.xcu = env_int("VP8HIP_XCU", 1) != 0;
     k.xcu_S = env_int("VP8HIP_XCU_S", 0);
-    k.detile_blocks = env_int("VP8HIP_DETILE_BLOCKS", 0);
+    k.eager_raster = env_int("VP8HIP_EAGER_RASTER", 0) != 0;
     k.inter_split = env_int("VP8HIP_INTER_SPLIT", 384);
     k.xcu_NW = env_int("VP8HIP_XCU_NW", 0);
     k.recon_nw = env_int("VP8HIP_RECON_NW", 0);
     k.lf_nw = env_int("VP8HIP_LF_NW", 0);
-    k.detile_stream = env_int("VP8HIP_DETILE_STREAM", 1) != 0;
 }
 
 __device__ unsigned int vp8_gran_broken;      // see gran_wait (vp8_common.hip.h)
@@ -51,7 +52,8 @@ extern "C" const char *vp8hip_last_error(const vp8hip_ctx *ctx) { return ctx ? c
 static void free_pools(vp8hip_ctx *c)
 {
     if (c->fb_block) (void)hipFree(c->fb_block);
-    for (int k = 0; k < VP8HIP_NBUF; k++) { if (c->tile_block[k]) (void)hipFree(c->tile_block[k]); c->tile_block[k] = nullptr; c->tile_cap[k] = 0; }
+    if (c->tile_block) (void)hipFree(c->tile_block);
+    c->tile_block = nullptr;
     if (c->slot_block_dev) (void)hipFree(c->slot_block_dev);
     if (c->gran_recon) (void)hipFree(c->gran_recon);
     if (c->gran_lf) (void)hipFree(c->gran_lf);
@@ -63,16 +65,14 @@ static void free_pools(vp8hip_ctx *c)
         free(s.h_dense);
     }
     c->fb_block = nullptr; c->slot_block_dev = nullptr;
-    c->fb.clear(); c->slots.clear();
+    c->fb.clear(); c->fb_tiles.clear(); c->fb_state.clear(); c->slots.clear();
 }
 
 static void destroy_events(vp8hip_ctx *c)
 {
     for (int r = 0; r < VP8HIP_STATS_RING; r++) for (int i = 0; i < 6; i++) if (c->evr[r][i]) (void)hipEventDestroy(c->evr[r][i]);
     if (c->ev_jobs) (void)hipEventDestroy(c->ev_jobs);
-    if (c->ev_lf_done) (void)hipEventDestroy(c->ev_lf_done);
-    if (c->ev_recon_done) (void)hipEventDestroy(c->ev_recon_done);
-    for (int k = 0; k < VP8HIP_NBUF; k++) if (c->ev_detile_done[k]) (void)hipEventDestroy(c->ev_detile_done[k]);
+    if (c->ev_conv) (void)hipEventDestroy(c->ev_conv);
 }
 
 
@@ -102,14 +102,11 @@ extern "C" int vp8hip_create(int device, vp8hip_ctx **out)
     c->max_lds = 160 * 1024;
     c->fb_block = nullptr; c->slot_block_dev = nullptr;
     read_knobs(c->knobs);
-    for (int k = 0; k < VP8HIP_NBUF; k++) { c->tile_block[k] = nullptr; c->tile_cap[k] = 0; }
+    c->tile_block = nullptr; c->tile_frame = 0;
     c->d_jobs = nullptr; c->h_jobs = nullptr; c->jobs_cap = 0;
     for (int k = 0; k < VP8HIP_NBUF; k++) c->d_jobs2[k] = nullptr;
-    for (int k = 0; k < VP8HIP_NBUF; k++) c->detile_used[k] = false;
-    c->detile_pending = false; c->parity = 0; c->last_par = 0;
-    c->detile_gen = c->detile_joined = 0;
+    c->parity = 0;
     c->d_md5 = nullptr; c->md5_cap = 0;
-    c->deferred.valid = false;
     c->width = c->height = 0;
     c->ncalls = 0;
     c->gran_recon = c->gran_lf = nullptr; c->gran_recon_cap = c->gran_lf_cap = 0; c->epoch = 0;
@@ -120,19 +117,15 @@ extern "C" int vp8hip_create(int device, vp8hip_ctx **out)
         delete c;
         return -1;
     }
-    c->stream2 = nullptr;      // created by the first launch that wants it
     c->stream_d2h = nullptr; c->ev_d2h_from = c->ev_d2h_done = nullptr; c->d2h_first = c->d2h_count = 0; c->fb_stride = 0;
     // events: every creation is checked; on failure whatever exists is destroyed again (null handles are skipped)
     for (int r = 0; r < VP8HIP_STATS_RING; r++) for (int i = 0; i < 6; i++) c->evr[r][i] = nullptr;
-    c->ev_jobs = c->ev_lf_done = c->ev_recon_done = nullptr;
-    for (int k = 0; k < VP8HIP_NBUF; k++) c->ev_detile_done[k] = nullptr;
+    c->ev_jobs = c->ev_conv = nullptr;
     e = hipSuccess;
     for (int r = 0; r < VP8HIP_STATS_RING && e == hipSuccess; r++)
         for (int i = 0; i < 6 && e == hipSuccess; i++) e = hipEventCreate(&c->evr[r][i]);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_jobs, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_lf_done, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_recon_done, hipEventDisableTiming);
-    for (int k = 0; k < VP8HIP_NBUF && e == hipSuccess; k++) e = hipEventCreateWithFlags(&c->ev_detile_done[k], hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_conv, hipEventDisableTiming);
     const char *what = "hipEventCreate";
     const void *big_lds[6] = { (const void *)vp8_recon_kernel, (const void *)vp8_recon_xcu_kernel,
                                (const void *)vp8_loopfilter_xcu_kernel, (const void *)vp8_loopfilter_kernel,
@@ -157,10 +150,10 @@ extern "C" void vp8hip_destroy(vp8hip_ctx *c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    (void)vp8hip_join_detile(c);
     (void)hipStreamSynchronize(c->stream);
-    if (c->stream2) (void)hipStreamSynchronize(c->stream2);
     free_pools(c);
+    if (c->d_conv_jobs) (void)hipFree(c->d_conv_jobs);
+    if (c->h_conv_jobs) (void)hipHostFree(c->h_conv_jobs);
     for (int k = 0; k < VP8HIP_NBUF; k++) if (c->d_jobs2[k]) (void)hipFree(c->d_jobs2[k]);
     if (c->h_jobs) (void)hipHostFree(c->h_jobs);
     if (c->h_status) (void)hipHostFree(c->h_status);
@@ -183,7 +176,6 @@ extern "C" void vp8hip_destroy(vp8hip_ctx *c)
     if (c->ev_d2h_from) (void)hipEventDestroy(c->ev_d2h_from);
     if (c->ev_d2h_done) (void)hipEventDestroy(c->ev_d2h_done);
     (void)hipStreamDestroy(c->stream);
-    if (c->stream2) (void)hipStreamDestroy(c->stream2);
     delete c;
 }
 
@@ -209,11 +201,7 @@ static int configure_pools(vp8hip_ctx *c, int width, int height, int num_fb, int
     if (width <= 0 || height <= 0 || width > 16383 || height > 16383 || num_fb < 1 || num_slots < 1)
         return fail(c, -2, "vp8hip_configure: bad arguments %dx%d fb=%d slots=%d", width, height, num_fb, num_slots);
     HIPCHK(c, hipSetDevice(c->device));
-    if (c->width && vp8hip_join_detile(c)) return -1;
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (c->stream2) HIPCHK(c, hipStreamSynchronize(c->stream2));
-    c->detile_pending = false;
-    for (int k = 0; k < VP8HIP_NBUF; k++) c->detile_used[k] = false;
     free_pools(c);
     read_knobs(c->knobs);
     c->width = width; c->height = height;
@@ -245,7 +233,9 @@ static int configure_pools(vp8hip_ctx *c, int width, int height, int num_fb, int
     HIPCHK(c, hipMalloc((void **)&c->fb_block, fbsz * num_fb));
     HIPCHK(c, hipMemsetAsync(c->fb_block, 0, fbsz * num_fb, c->stream));
     for (int i = 0; i < num_fb; i++) c->fb.push_back(c->fb_block + fbsz * i);
-    c->fb_detile_gen.assign((size_t)num_fb, 0u); c->detile_gen = c->detile_joined = 0;
+    // (the tiled forms come with the first large launch: vp8hip_launch.hip)
+    c->fb_state.assign((size_t)num_fb, (uint8_t)FB_RASTER);
+    c->tile_frame = align_up((size_t)c->dg.mb_rows * (c->dg.mb_cols + 1) * (VP8_TILE_BYTES + 32), 256);
     c->fb_stride = fbsz;
     if (c->stream_d2h) HIPCHK(c, hipStreamSynchronize(c->stream_d2h));
     c->d2h_count = 0;
@@ -388,13 +378,11 @@ int vp8hip_check_status(vp8hip_ctx *c)
     return 0;
 }
 #define check_status vp8hip_check_status
-#define join_detile vp8hip_join_detile
 
 extern "C" int vp8hip_sync(vp8hip_ctx *c)
 {
     if (!c) return -2;
     HIPCHK(c, hipSetDevice(c->device));
-    if (join_detile(c)) return -1;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return check_status(c);
 }
@@ -404,7 +392,6 @@ extern "C" int vp8hip_get_stats_at(vp8hip_ctx *c, int back, vp8hip_stats *st)
     if (!c || !st || back < 0 || back >= VP8HIP_STATS_RING) return -2;
     if (back >= c->ncalls) { memset(st, 0, sizeof *st); return c->ncalls ? fail(c, -2, "vp8hip_get_stats_at: only %ld launches so far", c->ncalls) : 0; }
     const int r = (int)((c->ncalls - 1 - back) % VP8HIP_STATS_RING);
-    if (c->deferred.valid && join_detile(c)) return -1;      // its events are read below: it has to be launched
     hipEvent_t *ev = c->evr[r];
     vp8hip_stats out = c->evr_stats[r];
     HIPCHK(c, hipEventSynchronize(ev[3]));
@@ -427,7 +414,7 @@ extern "C" int vp8hip_frame_download(vp8hip_ctx *c, int fb, int full, uint8_t *y
 {
     if (!c || fb < 0 || fb >= (int)c->fb.size() || !y) return fail(c, -2, "vp8hip_frame_download: bad arguments");
     HIPCHK(c, hipSetDevice(c->device));
-    if (join_detile(c)) return -1;
+    if (vp8hip_need_raster(c, fb, 1)) return -1;
     const vp8ir_geom &g = c->geom;
     if (full) {
         HIPCHK(c, hipMemcpyAsync(y, c->fb[fb], (size_t)g.frame_size, hipMemcpyDeviceToHost, c->stream));
@@ -493,7 +480,19 @@ extern "C" int vp8hip_frames_fetch_async(vp8hip_ctx *c, int first_fb, int count,
     if (digests && (c->width & 127))
         return fail(c, -3, "vp8hip_frames_fetch_async: digests on the device need a display width that is a multiple of 128 (%d)", c->width);
     HIPCHK(c, hipSetDevice(c->device));
-    if (join_detile(c)) return -1;
+    // Frames that only exist as tiles (a large launch wrote them, nothing has asked for their raster form) are read as tiles: the
+    // MD5 kernel walks the tiles, and the frames leave through a kernel that writes raster rows straight into the caller's
+    // page-locked memory -- the tiled -> raster pass happens where the frame leaves the device, on the way out, and costs the HBM
+    // one read.  Anything else -- a frame already in raster form among them, a destination the device cannot write -- goes the
+    // plain way: raster form first (vp8hip_need_raster), then copies.
+    bool tiled = c->tile_block != nullptr;
+    for (int i = 0; i < count && tiled; i++) tiled = c->fb_state[(size_t)(first_fb + i)] == FB_TILES;
+    if (tiled && dst) {
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, dst) != hipSuccess) { (void)hipGetLastError(); tiled = false; }
+        else tiled = at.type == hipMemoryTypeHost;
+    }
+    if (!tiled && vp8hip_need_raster(c, first_fb, count)) return -1;
     if (!c->stream_d2h) {
         HIPCHK(c, hipStreamCreateWithFlags(&c->stream_d2h, hipStreamNonBlocking));
         HIPCHK(c, hipEventCreateWithFlags(&c->ev_d2h_from, hipEventDisableTiming));
@@ -502,7 +501,16 @@ extern "C" int vp8hip_frames_fetch_async(vp8hip_ctx *c, int first_fb, int count,
     if (c->d2h_count) HIPCHK(c, hipEventSynchronize(c->ev_d2h_done));  // one copy in flight at a time
     HIPCHK(c, hipEventRecord(c->ev_d2h_from, c->stream));             // everything queued so far: the frames' kernels
     HIPCHK(c, hipStreamWaitEvent(c->stream_d2h, c->ev_d2h_from, 0));
-    if (dst) HIPCHK(c, hipMemcpyAsync(dst, c->fb[first_fb], c->fb_stride * (size_t)count, hipMemcpyDeviceToHost, c->stream_d2h));
+    if (dst) {
+        if (tiled) {
+            long units = (long)c->dg.mb_rows * count;
+            if (units > 8L * c->num_cu) units = 8L * c->num_cu;
+            hipLaunchKernelGGL(vp8_detile_run_kernel, dim3((unsigned)units), dim3(256), 0, c->stream_d2h, (const uint8_t *)c->fb_tiles[(size_t)first_fb],
+                               c->tile_frame, dst, c->fb_stride, count, c->dg);
+            HIPCHK(c, hipGetLastError());
+        } else
+            HIPCHK(c, hipMemcpyAsync(dst, c->fb[first_fb], c->fb_stride * (size_t)count, hipMemcpyDeviceToHost, c->stream_d2h));
+    }
     if (digests) {
         if (c->md5_cap < count) {
             HIPCHK(c, hipStreamSynchronize(c->stream_d2h));
@@ -512,14 +520,25 @@ extern "C" int vp8hip_frames_fetch_async(vp8hip_ctx *c, int first_fb, int count,
             c->md5_cap = count < 64 ? 64 : count;
         }
         // a frame per lane: the frames' hashes run side by side, behind the copy of the frames themselves (if asked for)
-        hipLaunchKernelGGL(vp8_md5_kernel, dim3((unsigned)((count + 63) / 64)), dim3(64), 0, c->stream_d2h, (const uint8_t *)c->fb[first_fb],
-                           c->fb_stride, count, c->dg, c->width, c->height, c->d_md5);
+        if (tiled)
+            hipLaunchKernelGGL(vp8_md5_tiles_kernel, dim3((unsigned)((count + 63) / 64)), dim3(64), 0, c->stream_d2h,
+                               (const uint8_t *)c->fb_tiles[(size_t)first_fb], c->tile_frame, count, c->dg, c->width, c->height, c->d_md5);
+        else
+            hipLaunchKernelGGL(vp8_md5_kernel, dim3((unsigned)((count + 63) / 64)), dim3(64), 0, c->stream_d2h, (const uint8_t *)c->fb[first_fb],
+                               c->fb_stride, count, c->dg, c->width, c->height, c->d_md5);
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipMemcpyAsync(digests, c->d_md5, 16 * (size_t)count, hipMemcpyDeviceToHost, c->stream_d2h));
     }
     HIPCHK(c, hipEventRecord(c->ev_d2h_done, c->stream_d2h));
     c->d2h_first = first_fb; c->d2h_count = count;
     return 0;
+}
+
+extern "C" int vp8hip_frames_to_raster(vp8hip_ctx *c, int first_fb, int count)
+{
+    if (!c || first_fb < 0 || count < 1 || first_fb + count > (int)c->fb.size()) return fail(c, -2, "vp8hip_frames_to_raster: bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    return vp8hip_need_raster(c, first_fb, count);
 }
 
 extern "C" int vp8hip_frames_download_async(vp8hip_ctx *c, int first_fb, int count, uint8_t *dst)
@@ -557,9 +576,9 @@ extern "C" int vp8hip_frame_upload(vp8hip_ctx *c, int fb, const uint8_t *buf)
 {
     if (!c || fb < 0 || fb >= (int)c->fb.size() || !buf) return fail(c, -2, "vp8hip_frame_upload: bad arguments");
     HIPCHK(c, hipSetDevice(c->device));
-    if (join_detile(c)) return -1;
     HIPCHK(c, hipMemcpyAsync(c->fb[fb], buf, (size_t)c->geom.frame_size, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->fb_state[(size_t)fb] = FB_RASTER;
     return 0;
 }
 
@@ -568,8 +587,12 @@ extern "C" int vp8hip_frame_copy(vp8hip_ctx *c, int dst, int src)
     if (!c || dst < 0 || src < 0 || dst >= (int)c->fb.size() || src >= (int)c->fb.size())
         return fail(c, -2, "vp8hip_frame_copy: bad arguments");
     HIPCHK(c, hipSetDevice(c->device));
-    if (join_detile(c)) return -1;
-    HIPCHK(c, hipMemcpyAsync(c->fb[dst], c->fb[src], (size_t)c->geom.frame_size, hipMemcpyDeviceToDevice, c->stream));
+    if (dst == src) return 0;
+    // in whatever form(s) the source holds the frame
+    const uint8_t st = c->fb_state[(size_t)src];
+    if (st & FB_RASTER) HIPCHK(c, hipMemcpyAsync(c->fb[dst], c->fb[src], (size_t)c->geom.frame_size, hipMemcpyDeviceToDevice, c->stream));
+    if (st & FB_TILES) HIPCHK(c, hipMemcpyAsync(c->fb_tiles[(size_t)dst], c->fb_tiles[(size_t)src], c->tile_frame, hipMemcpyDeviceToDevice, c->stream));
+    c->fb_state[(size_t)dst] = st;
     return 0;
 }
 

@@ -1,6 +1,6 @@
 // Internal to libvp8hip.so: the context behind include/vp8hip.h's opaque handle, shared by the shim's translation units --
 //   vp8hip.hip          context, pools, IR slots (upload / copy / fetch), frame buffers, statistics
-//   vp8hip_launch.hip   vp8hip_decode: which kernels a launch runs, and the tiled -> raster pass behind the large ones
+//   vp8hip_launch.hip   vp8hip_decode: which kernels a launch runs; the two forms a frame buffer has on the device
 //   vp8hip_entropy.hip  vp8hip_entropy_decode
 //   vp8hip_postproc.hip vp8hip_postproc, vp8hip_mfqe
 #pragma once
@@ -15,7 +15,7 @@
 #include "vp8_common.hip.h"
 
 #define VP8HIP_STATS_RING 32
-#define VP8HIP_NBUF 3          // tile sets / job tables in rotation (the tiled -> raster pass of a launch runs beside the next one)
+#define VP8HIP_NBUF 3          // device job tables in rotation (a launch's table may still be read while the next one is staged)
 #ifdef VP8_STAMPS
 #define VP8HIP_SCHED_WORDS (16 + 16384 + 4 * 4096)     // + the diagnostic builds' log: four words per wave
 #else
@@ -40,15 +40,14 @@ struct Slot {
 //   VP8HIP_RECON=simt|wave     force one of the two kernel families whatever the launch's size
 //   VP8HIP_SIMT_LGG=1..6       lane-per-row kernels: lanes per strand (log2); VP8HIP_SIMT_WAVES=n  at most n waves per launch
 //   VP8HIP_WG_PER_CU, VP8HIP_XCU, VP8HIP_XCU_S, VP8HIP_XCU_NW, VP8HIP_RECON_NW, VP8HIP_LF_NW   wave-per-row family shapes
-//   VP8HIP_DETILE_STREAM=0     run the tiled -> raster pass on the main stream
-//   VP8HIP_DETILE_BLOCKS=n     workgroups of that pass (default: two per CU)
+//   VP8HIP_EAGER_RASTER=1      large launches produce the raster form of their frames at once (default: when something asks for it)
 //   VP8HIP_INTER_SPLIT=N       launches of up to N frames with inter frames among them run vp8_inter_mb_kernel first (default 384; 0:
 //                              never).  It shortens a frame's critical path (1080p P frames, 1..16 per launch: recon 0.91 -> 0.46-0.56
 //                              ms; 128: 1.56 -> 1.45) and costs throughput in launches that fill the chip anyway (512: 3.82 -> 4.03)
 struct Knobs {
     int recon_force;       // 0 automatic, 1 lane-per-row, 2 wave-per-row
-    int inter_split, detile_blocks;
-    int lgG, simt_waves, wg_per_cu, xcu, xcu_S, xcu_NW, recon_nw, lf_nw, detile_stream;
+    int inter_split, eager_raster;
+    int lgG, simt_waves, wg_per_cu, xcu, xcu_S, xcu_NW, recon_nw, lf_nw;
 };
 
 struct vp8hip_ctx {
@@ -61,33 +60,23 @@ struct vp8hip_ctx {
     bool evr_tiled[VP8HIP_STATS_RING]; vp8hip_stats evr_stats[VP8HIP_STATS_RING];
     long ncalls;
     hipEvent_t ev_jobs;            // job table of the previous call has been copied
-    // The tiled -> raster pass of a large launch is memory-bound while the kernel in front of it is bound by arithmetic, so it
-    // runs on a second stream beside the NEXT launch.  VP8HIP_NBUF tile sets and device job tables rotate; any other use of the
-    // frame buffers first joins the second stream.
-    hipStream_t stream2;
-    hipEvent_t ev_lf_done, ev_detile_done[VP8HIP_NBUF];
-    bool detile_used[VP8HIP_NBUF], detile_pending;
-    // a tiled -> raster pass not launched yet (launches with inter frames: it goes out beside the NEXT launch's
-    // vp8_interframe_kernel, behind its prediction kernel, or at the next join)
-    struct { bool valid; DevJob *jobs; int njobs, extend, par; hipEvent_t *ev; } deferred;
-    hipEvent_t ev_recon_done;
-    int parity, last_par;        // set used by the next lane-per-row launch / by the last one
+    int parity;                    // job table used by the next launch
     char err[256];
     // geometry
     int width, height;
     vp8ir_geom geom;
     DevGeom dg;
     int nmb;
-    // pools
-    std::vector<uint8_t *> fb;
-    // which tiled -> raster pass writes a frame buffer's raster: passes are numbered as they are issued (detile_gen); passes up to
-    // detile_joined have been waited for by the main stream.  A launch that reads reference frames only has to join if one of
-    // them is still to be written by a pass it has not waited for
-    std::vector<unsigned> fb_detile_gen;
-    unsigned detile_gen, detile_joined;
+    // pools.  A frame buffer has TWO forms on the device (vp8hip_launch.hip): the raster form -- the reference's YV12 layout with
+    // its borders, fb[i] -- and the tiled form the lane-per-row kernels write -- macroblock-window tiles, fb_tiles[i], allocated
+    // with the first large launch --, and fb_state[i] says which of them hold the frame.  Whoever needs a form the frame is not
+    // in asks for it (vp8hip_need_raster): the conversion runs when something reads the frame as raster, not after every launch.
+    std::vector<uint8_t *> fb, fb_tiles;
+    std::vector<uint8_t> fb_state;
     std::vector<Slot> slots;
     uint8_t *fb_block; char *slot_block_dev;
-    uint8_t *tile_block[VP8HIP_NBUF]; size_t tile_cap[VP8HIP_NBUF];   // macroblock-window tiles of the lane-per-row kernels
+    uint8_t *tile_block; size_t tile_frame;          // the tiled forms of all frame buffers (tile_frame bytes each) + the dummy tile
+    DevJob *d_conv_jobs, *h_conv_jobs; int conv_cap; hipEvent_t ev_conv;    // job table of a tiled -> raster pass
     size_t slot_bytes, o_mbx, o_blocks, o_mvs, cap_blocks;            // slot layout; cap_blocks = nmb * 24
     // job staging
     DevJob *d_jobs2[VP8HIP_NBUF]; DevJob *d_jobs; DevJob *h_jobs; int jobs_cap;   // d_jobs = d_jobs2[parity of the call]
@@ -130,7 +119,11 @@ int vp8hip_fail(vp8hip_ctx *c, int code, const char *fmt, ...);
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-// vp8hip_launch.hip
-int vp8hip_join_detile(vp8hip_ctx *c);        // the main stream waits for a tiled -> raster pass still running (or not launched yet)
+#define FB_RASTER 1u            // fb_state bits: the raster form holds the frame (borders included) ...
+#define FB_TILES  2u            // ... the tiled form does
+// vp8hip_launch.hip: make sure the raster form of frame buffers first .. first + count - 1 holds their frames (a tiled -> raster
+// pass + border extension on the context's stream for those that are only there as tiles)
+int vp8hip_need_raster(vp8hip_ctx *c, int first, int count);
+int vp8hip_need_raster_list(vp8hip_ctx *c, const int *fbs, int n);
 // vp8hip.hip
 int vp8hip_check_status(vp8hip_ctx *c);       // after a stream synchronisation: did a kernel of the cross-CU family give up on a hand-over?

@@ -1,18 +1,25 @@
-// vp8hip_decode (include/vp8hip.h): which kernels a launch of independent frames runs, and the tiled -> raster pass behind the
-// large ones.  What it stands for in the reference: decode_mb_row x mb_rows (vp8/decoder/decodframe.c:1116-1129),
+// vp8hip_decode (include/vp8hip.h): which kernels a launch of independent frames runs, and the two forms a frame buffer has on
+// the device.  What it stands for in the reference: decode_mb_row x mb_rows (vp8/decoder/decodframe.c:1116-1129),
 // vp8_loop_filter_frame (vp8/common/loopfilter.c:203) and vp8_yv12_extend_frame_borders_ptr (vp8/decoder/onyxd_if.c:607) for
 // every frame of the launch.
 //
 // TWO kernel families, one choice (launch_regime below):
 //   * large launches -- more than two frames per CU, reconstruction and loop filter both wanted -- run the LANE-PER-ROW kernels:
-//     vp8_keyframe_kernel (key frames only), or vp8_inter_pred_kernel + vp8_interframe_kernel (inter frames among them), into
-//     macroblock-window tiles; vp8_detile_kf_kernel + vp8_extend_kernel turn the tiles into the raster frame buffers on a second
-//     stream, beside the next launch;
+//     vp8_keyframe_kernel (key frames only), or vp8_inter_pred_kernel + vp8_interframe_kernel (inter frames among them), which
+//     leave a frame as macroblock-window tiles (vp8_keyframe_simt.hip: the form in which a lane can write whole 64-byte sectors);
 //   * everything else -- few frames, one frame (a single stream through vpx_codec_decode), single stages -- runs the WAVE-PER-ROW
-//     kernels (vp8_recon.hip, vp8_loopfilter.hip), which write the raster frame buffers themselves: up to 128 frame pairs spread
+//     kernels (vp8_recon.hip, vp8_loopfilter.hip), which write the raster frame buffers: up to 128 frame pairs spread
 //     over several CUs each (the _xcu variants), more than that one pair per workgroup; launches with inter frames of up to
 //     VP8HIP_INTER_SPLIT frames reconstruct their inter macroblocks first, every one on its own (vp8_inter_mb_kernel).
 // Every kernel reads the IR slots in the device form of include/vp8_ir.h, as the producers wrote them: nothing is converted here.
+//
+// TWO forms of a frame buffer (vp8hip_ctx::fb_state): the RASTER form is the reference's YV12 layout with its borders
+// (vpx_scale/generic/yv12config.c:55-112) -- what the wave-per-row kernels read and write, what inter prediction reads, what
+// vp8hip_frame_download and the post-processing filters see --, the TILED form is what a large launch leaves.  A frame is
+// converted (vp8_detile_kf_kernel + vp8_extend_kernel, one pass over the frame) when something asks for the form it is not in
+// (vp8hip_need_raster), not after every launch: the MD5 kernel reads tiles, a batch download writes raster rows straight into
+// the caller's page-locked memory (vp8hip_frames_fetch_async), so a pipeline of large launches never pays the pass in HBM.
+// Through round 3 the pass ran after every large launch, beside the next one: 38 % of a step's HBM traffic.
 #include "vp8hip_ctx.hip.h"
 
 extern "C" __global__ void vp8_recon_kernel(const DevJob *jobs, int njobs, DevGeom g);
@@ -33,61 +40,56 @@ extern "C" __global__ void vp8_loopfilter_kernel(const DevJob *jobs, int njobs, 
 extern "C" __global__ void vp8_extend_kernel(const DevJob *jobs, int njobs, DevGeom g);
 extern "C" __global__ void vp8_detile_kf_kernel(const DevJob *jobs, int njobs, DevGeom g);
 
-// the tiled -> raster pass (+ border extension) of a lane-per-row launch
-static int launch_detile(vp8hip_ctx *c, hipStream_t st, DevJob *jobs, int njobs, int extend)
+// The raster form of the frame buffers fbs[0..n-1], for those that only exist as tiles: the tiled -> raster pass and the borders
+// (vp8_yv12_extend_frame_borders, onyxd_if.c:607), on the context's stream.
+int vp8hip_need_raster_list(vp8hip_ctx *c, const int *fbs, int n)
 {
-    // Two workgroups per CU, each looping over macroblock rows: the pass runs beside the next launch's vp8_keyframe_kernel
-    // (its waves need 16 registers: they fit in the gap two of that kernel's waves leave on a SIMD) and is to trickle -- the
-    // pair is bound by HBM bandwidth when the pass goes at full speed, and the key-frame kernel then loses more than the pass
-    // gains.  8192 1080p frames per launch, ms per step: 2 per CU 45.7-47.1, 4 per CU 49.2-51.5, all at once 49.9-50.2, 1 per
-    // CU 65 (the pass becomes the longer one)
-    long units = (long)c->dg.mb_rows * njobs;
-    const int cap = c->knobs.detile_blocks > 0 ? c->knobs.detile_blocks : 2 * c->num_cu;
-    if (units > cap) units = cap;
-    hipLaunchKernelGGL(vp8_detile_kf_kernel, dim3((unsigned)units), dim3(256), 0, st, (const DevJob *)jobs, njobs, c->dg);
-    if (extend) {
-        int bx = (c->geom.aligned_h + 64) / 4;
-        if (bx < 1) bx = 1;
-        if (bx > 64) bx = 64;
-        hipLaunchKernelGGL(vp8_extend_kernel, dim3(bx, njobs), dim3(256), 0, st, (const DevJob *)jobs, njobs, c->dg);
+    int m = 0;
+    for (int i = 0; i < n; i++) m += c->fb_state[(size_t)fbs[i]] == FB_TILES;
+    if (!m) return 0;
+    if (m > c->conv_cap) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (c->d_conv_jobs) (void)hipFree(c->d_conv_jobs);
+        if (c->h_conv_jobs) (void)hipHostFree(c->h_conv_jobs);
+        c->d_conv_jobs = c->h_conv_jobs = nullptr; c->conv_cap = 0;
+        const int cap = m < 64 ? 64 : m;
+        HIPCHK(c, hipMalloc((void **)&c->d_conv_jobs, sizeof(DevJob) * (size_t)cap));
+        HIPCHK(c, hipHostMalloc((void **)&c->h_conv_jobs, sizeof(DevJob) * (size_t)cap, hipHostMallocDefault));
+        c->conv_cap = cap;
+    } else
+        HIPCHK(c, hipEventSynchronize(c->ev_conv));           // the table of the pass before has been copied
+    m = 0;
+    for (int i = 0; i < n; i++) {
+        const int f = fbs[i];
+        if (c->fb_state[(size_t)f] != FB_TILES) continue;
+        DevJob &d = c->h_conv_jobs[m++];
+        memset(&d, 0, sizeof d);
+        d.dst = c->fb[(size_t)f]; d.tile = c->fb_tiles[(size_t)f];
+        c->fb_state[(size_t)f] = FB_TILES | FB_RASTER;          // (a frame buffer named twice converts once)
     }
+    HIPCHK(c, hipMemcpyAsync(c->d_conv_jobs, c->h_conv_jobs, sizeof(DevJob) * (size_t)m, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipEventRecord(c->ev_conv, c->stream));
+    long units = (long)c->dg.mb_rows * m;
+    if (units > 8L * c->num_cu) units = 8L * c->num_cu;
+    hipLaunchKernelGGL(vp8_detile_kf_kernel, dim3((unsigned)units), dim3(256), 0, c->stream, (const DevJob *)c->d_conv_jobs, m, c->dg);
+    int bx = (c->geom.aligned_h + 64) / 4;
+    if (bx < 1) bx = 1;
+    if (bx > 64) bx = 64;
+    hipLaunchKernelGGL(vp8_extend_kernel, dim3(bx, m), dim3(256), 0, c->stream, (const DevJob *)c->d_conv_jobs, m, c->dg);
     HIPCHK(c, hipGetLastError());
     return 0;
 }
-// Launch the deferred tiled -> raster pass on the second stream, behind `after` (an event on the main stream).
-static int launch_deferred(vp8hip_ctx *c, hipEvent_t after)
+int vp8hip_need_raster(vp8hip_ctx *c, int first, int count)
 {
-    if (!c->deferred.valid) return 0;
-    HIPCHK(c, hipStreamWaitEvent(c->stream2, after, 0));
-    HIPCHK(c, hipEventRecord(c->deferred.ev[4], c->stream2));
-    if (launch_detile(c, c->stream2, c->deferred.jobs, c->deferred.njobs, c->deferred.extend)) return -1;
-    HIPCHK(c, hipEventRecord(c->deferred.ev[5], c->stream2));
-    HIPCHK(c, hipEventRecord(c->ev_detile_done[c->deferred.par], c->stream2));
-    c->deferred.valid = false;
-    return 0;
+    bool any = false;
+    for (int i = 0; i < count && !any; i++) any = c->fb_state[(size_t)(first + i)] == FB_TILES;
+    if (!any) return 0;
+    std::vector<int> v((size_t)count);
+    for (int i = 0; i < count; i++) v[(size_t)i] = first + i;
+    return vp8hip_need_raster_list(c, v.data(), count);
 }
-// Make the main stream wait for a tiled -> raster pass still running on the second stream (launching it first if it was held
-// back).  Every entry point that reads or writes frame buffers, other than another lane-per-row launch, calls this first.
-int vp8hip_join_detile(vp8hip_ctx *c)
-{
-    if (c->deferred.valid) {
-        HIPCHK(c, hipEventRecord(c->ev_lf_done, c->stream));
-        if (launch_deferred(c, c->ev_lf_done)) return -1;
-    }
-    if (c->detile_pending) {
-        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_detile_done[c->last_par], 0));
-        c->detile_pending = false;
-    }
-    c->detile_joined = c->detile_gen;
-    return 0;
-}
-#define join_detile vp8hip_join_detile
-extern "C" int vp8hip_join(vp8hip_ctx *c)
-{
-    if (!c) return -2;
-    HIPCHK(c, hipSetDevice(c->device));
-    return join_detile(c);
-}
+// (kept for callers of round 3's interface: there is no second stream to join any more -- conversions run on the context's stream)
+extern "C" int vp8hip_join(vp8hip_ctx *c) { return c ? 0 : -2; }
 
 // The ONE place that decides which kernels a launch runs (header of this file).  The threshold is where the families cross on an
 // MI355X: the wave-per-row kernels are the faster ones up to one frame pair per CU (512 frames: 126 vs 85 Gpix/s at 1080p); beyond
@@ -109,7 +111,6 @@ extern "C" int vp8hip_decode(vp8hip_ctx *c, const vp8hip_job *jobs, int njobs, i
     if (njobs > c->jobs_cap) {
         // the staging arrays are reused by in-flight launches: drain before growing
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        if (c->stream2) HIPCHK(c, hipStreamSynchronize(c->stream2));
         for (int k = 0; k < VP8HIP_NBUF; k++) if (c->d_jobs2[k]) (void)hipFree(c->d_jobs2[k]);
         if (c->h_jobs) (void)hipHostFree(c->h_jobs);
         c->jobs_cap = njobs < 64 ? 64 : njobs;
@@ -127,54 +128,43 @@ extern "C" int vp8hip_decode(vp8hip_ctx *c, const vp8hip_job *jobs, int njobs, i
     const Knobs &K = c->knobs;
     const Regime regime = launch_regime(c, njobs, stages, all_key);
     const bool tiled = regime != WAVE_PER_ROW, inter_fused = regime == LANE_INTER;
-    // tiles of a frame: one per macroblock and one more per macroblock row, 32 bytes of unfiltered line per tile behind them
-    // (vp8_keyframe_simt.hip)
-    const size_t tile_frame = align_up((size_t)c->dg.mb_rows * (c->dg.mb_cols + 1) * (VP8_TILE_BYTES + 32), 256);
     const int par = c->parity;
-    bool reads_pending = false;
-    if (!all_key)
-        for (int i = 0; i < njobs && !reads_pending; i++) {
-            if (jobs[i].ir_slot < 0 || jobs[i].ir_slot >= nsl || c->slots[jobs[i].ir_slot].hdr_copy.frame_type == 0) continue;
-            for (int k = 1; k < 4; k++) {
-                const int f = jobs[i].ref_fb[k];
-                if (f >= 0 && f < nfb && c->fb_detile_gen[f] > c->detile_joined) reads_pending = true;
-            }
-        }
-    if (!tiled || reads_pending) {
-        // this launch touches the raster frame buffers directly: it writes them, or (inter frames) reads reference frames a
-        // tiled -> raster pass of an earlier launch is still to produce
-        if (join_detile(c)) return -1;
+    c->parity = (par + 1) % VP8HIP_NBUF;
+    for (int i = 0; i < njobs; i++)
+        if (jobs[i].ir_slot < 0 || jobs[i].ir_slot >= nsl || jobs[i].dst_fb < 0 || jobs[i].dst_fb >= nfb)
+            return fail(c, -2, "vp8hip_decode: job %d has slot %d / fb %d out of range", i, jobs[i].ir_slot, jobs[i].dst_fb);
+    if (tiled && !c->tile_block) {
+        // the tiled forms of all frame buffers, with the first large launch: tile_frame bytes each (one tile per macroblock and
+        // one more per macroblock row, 32 bytes of unfiltered line per tile behind them: vp8_keyframe_simt.hip), + 8 KB: the dummy
+        // tile idle lanes write, and room for the kernels' prefetches past the last tile
+        HIPCHK(c, hipMalloc((void **)&c->tile_block, c->tile_frame * (size_t)nfb + 8192));
+        c->fb_tiles.resize((size_t)nfb);
+        for (int i = 0; i < nfb; i++) c->fb_tiles[(size_t)i] = c->tile_block + c->tile_frame * (size_t)i;
     }
-    if (tiled) {
-        // tile set and job table `par` were last read by the tiled -> raster pass VP8HIP_NBUF launches ago (three
-        // sets: that pass, launched beside the previous launch, may still be finishing)
-        if (c->detile_used[par]) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_detile_done[par], 0));
-        if (c->tile_cap[par] < tile_frame * njobs) {
-            // (re)allocate the set in use (the other sets only exist once the tiled -> raster pass has rotated to them)
-            if (join_detile(c)) return -1;          // a pass not launched yet still reads the old sets
-            HIPCHK(c, hipStreamSynchronize(c->stream));
-            if (c->stream2) HIPCHK(c, hipStreamSynchronize(c->stream2));
-            if (c->tile_cap[par] < tile_frame * njobs) {
-                if (c->tile_block[par]) (void)hipFree(c->tile_block[par]);
-                c->tile_block[par] = nullptr; c->tile_cap[par] = 0;
-                // + 8 KB: the dummy tile idle lanes write, and room for the kernels' prefetches past the last tile
-                HIPCHK(c, hipMalloc((void **)&c->tile_block[par], tile_frame * njobs + 8192));
-                c->tile_cap[par] = tile_frame * njobs;
-            }
+    {
+        // what this launch reads as raster: its reference frames (inter prediction reads the raster form, borders included), and
+        // -- a wave-per-row launch of the loop filter alone -- the frames it filters in place
+        std::vector<int> need;
+        for (int i = 0; i < njobs; i++) {
+            if (c->slots[jobs[i].ir_slot].hdr_copy.frame_type != 0)
+                for (int k = 1; k < 4; k++) {
+                    const int f = jobs[i].ref_fb[k];
+                    if (f >= 0 && f < nfb && c->fb_state[(size_t)f] == FB_TILES) need.push_back(f);
+                }
+            if (!tiled && !(stages & VP8HIP_STAGE_RECON) && c->fb_state[(size_t)jobs[i].dst_fb] == FB_TILES) need.push_back(jobs[i].dst_fb);
         }
+        if (!need.empty() && vp8hip_need_raster_list(c, need.data(), (int)need.size())) return -1;
     }
     c->d_jobs = c->d_jobs2[par];
     for (int i = 0; i < njobs; i++) {
         const vp8hip_job &j = jobs[i];
-        if (j.ir_slot < 0 || j.ir_slot >= nsl || j.dst_fb < 0 || j.dst_fb >= nfb)
-            return fail(c, -2, "vp8hip_decode: job %d has slot %d / fb %d out of range", i, j.ir_slot, j.dst_fb);
         const Slot &s = c->slots[j.ir_slot];
         DevJob &d = c->h_jobs[i];
         d.hdr = s.hdr_copy;
         d.mbx = s.d_mbx; d.blocks = s.d_blocks; d.mvs = s.d_mvs;
         d.dst = c->fb[j.dst_fb];
         d.ref[0] = nullptr;
-        d.tile = tiled ? c->tile_block[par] + tile_frame * i : nullptr;
+        d.tile = tiled ? c->fb_tiles[(size_t)j.dst_fb] : nullptr;
         for (int k = 1; k < 4; k++) {
             d.ref[k] = nullptr;
             if (s.hdr_copy.frame_type == 0) continue;          // key frames read no reference
@@ -281,7 +271,7 @@ extern "C" int vp8hip_decode(vp8hip_ctx *c, const vp8hip_job *jobs, int njobs, i
         if (simt_waves > maxw) simt_waves = maxw;
     }
     if (tiled) { c->stats.workgroups = simt_waves; c->stats.recon_waves = 1; c->stats.lf_waves = 1; }
-    c->stats.detile_pass = tiled;
+    c->stats.detile_pass = tiled && K.eager_raster;
 
     if (stages & VP8HIP_STAGE_RECON) {
         if (tiled) {
@@ -298,18 +288,12 @@ extern "C" int vp8hip_decode(vp8hip_ctx *c, const vp8hip_job *jobs, int njobs, i
                 if (pgrid > (long)c->num_cu * 8) pgrid = (long)c->num_cu * 8;
                 hipLaunchKernelGGL(vp8_inter_pred_kernel, dim3((unsigned)pgrid), dim3(256), 0, c->stream, (const DevJob *)c->d_jobs, njobs,
                                    c->dg, upf);
-                // the previous launch's tiled -> raster pass, if it was held back: beside vp8_interframe_kernel, which is bound by
-                // arithmetic, not beside the prediction kernel, which is bound by memory bandwidth as the pass is
-                if (c->deferred.valid) {
-                    HIPCHK(c, hipEventRecord(c->ev_recon_done, c->stream));
-                    if (launch_deferred(c, c->ev_recon_done)) return -1;
-                }
                 hipLaunchKernelGGL(vp8_interframe_kernel, dim3(2 * simt_waves), dim3(64), 0, c->stream, (const DevJob *)c->d_jobs, njobs,
-                                   c->dg, lgG, simtP, simt_waves * spw, c->tile_block[par] + tile_frame * njobs + 4096,
+                                   c->dg, lgG, simtP, simt_waves * spw, c->tile_block + c->tile_frame * (size_t)nfb + 4096,
                                    c->d_sched, simt_waves);
             } else
                 hipLaunchKernelGGL(vp8_keyframe_kernel, dim3(2 * simt_waves), dim3(64), 0, c->stream, (const DevJob *)c->d_jobs, njobs,
-                                   c->dg, lgG, simtP, simt_waves * spw, c->tile_block[par] + tile_frame * njobs + 4096,
+                                   c->dg, lgG, simtP, simt_waves * spw, c->tile_block + c->tile_frame * (size_t)nfb + 4096,
                                    c->d_sched, simt_waves);
         } else {
 
@@ -353,10 +337,6 @@ extern "C" int vp8hip_decode(vp8hip_ctx *c, const vp8hip_job *jobs, int njobs, i
         HIPCHK(c, hipGetLastError());
     }
     HIPCHK(c, hipEventRecord(ev[1], c->stream));
-    if (tiled && c->deferred.valid) {          // a pass still held back (the launch before had inter frames, this one has none)
-        HIPCHK(c, hipEventRecord(c->ev_recon_done, c->stream));
-        if (launch_deferred(c, c->ev_recon_done)) return -1;
-    }
     c->stats.fused = tiled;
     c->stats.lf_kernels = 0;
     if ((stages & VP8HIP_STAGE_LF) && any_lf && !tiled) {
@@ -373,34 +353,13 @@ extern "C" int vp8hip_decode(vp8hip_ctx *c, const vp8hip_job *jobs, int njobs, i
         HIPCHK(c, hipGetLastError());
     }
     HIPCHK(c, hipEventRecord(ev[2], c->stream));
-    if (tiled) {      // the frame buffers get the result from the tiles; borders are extended on the way
-        const bool own_stream = K.detile_stream;
-        if (own_stream && !c->stream2) {
-            int prio_least = 0, prio_greatest = 0;
-            HIPCHK(c, hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
-            HIPCHK(c, hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio_least));
-        }
-        // The key-frame kernel's pass goes out at once: its waves are small enough -- 16 registers -- to run in the gaps the next
-        // launch's kernel leaves on every SIMD.  After a launch with inter frames it waits for the next launch's prediction
-        // kernel (or the next join).
-        const bool defer = own_stream && inter_fused;
-        hipStream_t ds = own_stream ? c->stream2 : c->stream;
-        if (defer) {
-            c->deferred.valid = true; c->deferred.jobs = c->d_jobs; c->deferred.njobs = njobs;
-            c->deferred.extend = (stages & VP8HIP_STAGE_EXTEND) ? 1 : 0; c->deferred.par = par; c->deferred.ev = ev;
-        } else {
-            if (own_stream) {
-                HIPCHK(c, hipEventRecord(c->ev_lf_done, c->stream));
-                HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_lf_done, 0));
-            }
-            HIPCHK(c, hipEventRecord(ev[4], ds));
-            if (launch_detile(c, ds, c->d_jobs, njobs, (stages & VP8HIP_STAGE_EXTEND) ? 1 : 0)) return -1;
-            HIPCHK(c, hipEventRecord(ev[5], ds));
-            HIPCHK(c, hipEventRecord(c->ev_detile_done[par], ds));
-        }
-        c->detile_used[par] = true; c->detile_pending = true; c->last_par = par; c->parity = (par + 1) % VP8HIP_NBUF;
-        ++c->detile_gen;
-        for (int i = 0; i < njobs; i++) c->fb_detile_gen[jobs[i].dst_fb] = c->detile_gen;
+    if (tiled) {
+        // the frames are there as tiles; their raster form when somebody asks (or at once: VP8HIP_EAGER_RASTER)
+        std::vector<int> dsts((size_t)njobs);
+        for (int i = 0; i < njobs; i++) { c->fb_state[(size_t)jobs[i].dst_fb] = FB_TILES; dsts[(size_t)i] = jobs[i].dst_fb; }
+        HIPCHK(c, hipEventRecord(ev[4], c->stream));
+        if (K.eager_raster && vp8hip_need_raster_list(c, dsts.data(), njobs)) return -1;
+        HIPCHK(c, hipEventRecord(ev[5], c->stream));
     } else if (stages & VP8HIP_STAGE_EXTEND) {
         int bx = (c->geom.aligned_h + 64) / 4;
         if (bx < 1) bx = 1;
@@ -409,6 +368,8 @@ extern "C" int vp8hip_decode(vp8hip_ctx *c, const vp8hip_job *jobs, int njobs, i
                            njobs, c->dg);
         HIPCHK(c, hipGetLastError());
     }
+    if (!tiled && (stages & (VP8HIP_STAGE_RECON | VP8HIP_STAGE_LF | VP8HIP_STAGE_EXTEND)))
+        for (int i = 0; i < njobs; i++) c->fb_state[(size_t)jobs[i].dst_fb] = FB_RASTER;
     HIPCHK(c, hipEventRecord(ev[3], c->stream));
     c->evr_tiled[c->ncalls % VP8HIP_STATS_RING] = tiled;
     c->evr_stats[c->ncalls % VP8HIP_STATS_RING] = c->stats;

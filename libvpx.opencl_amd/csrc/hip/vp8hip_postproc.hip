@@ -1,7 +1,6 @@
 // vp8hip_postproc, vp8hip_mfqe (include/vp8hip.h): the host entry points of the output-side filters; the kernels are in
 // vp8_postproc.hip.
 #include "vp8hip_ctx.hip.h"
-#define join_detile vp8hip_join_detile
 
 // vp8_postproc.hip
 void vp8pp_down_and_across(hipStream_t st, const uint8_t *src, uint8_t *dst, int stride, int rows, int cols, int flimit);
@@ -31,7 +30,11 @@ extern "C" int vp8hip_postproc(vp8hip_ctx *c, int src_fb, int dst_fb, int tmp_fb
     if (noise && (!pp->noise_rows || g.aligned_w + 255 > 3072 || g.aligned_h > 16384))
         return fail(c, -2, "vp8hip_postproc: noise needs the row phases and a frame at most 2816 wide");
     HIPCHK(c, hipSetDevice(c->device));
-    if (join_detile(c)) return -1;
+    {   // the filters read and write the raster form
+        if (vp8hip_need_raster(c, src_fb, 1)) return -1;
+        c->fb_state[(size_t)dst_fb] = FB_RASTER;
+        if (demacro) c->fb_state[(size_t)tmp_fb] = FB_RASTER;
+    }
     if (c->d2h_count) { HIPCHK(c, hipEventSynchronize(c->ev_d2h_done)); c->d2h_count = 0; }   // a batch download may be reading dst
     if (!c->d_pp || !c->h_pp || !c->ev_pp) {
         // (each piece on its own: a failure half way leaves what exists for the next call, never a null event to wait on)
@@ -88,7 +91,11 @@ extern "C" int vp8hip_mfqe(vp8hip_ctx *c, int show_fb, int prev_fb, int dst_fb, 
         show_fb == prev_fb || show_fb == dst_fb || qcurr < 0 || qcurr > 127 || qprev < 0 || qprev > qcurr)
         return fail(c, -2, "vp8hip_mfqe: bad arguments");
     HIPCHK(c, hipSetDevice(c->device));
-    if (join_detile(c)) return -1;
+    {
+        const int need[2] = { show_fb, prev_fb };
+        if (vp8hip_need_raster_list(c, need, 2)) return -1;
+        c->fb_state[(size_t)dst_fb] = FB_RASTER;
+    }
     if (c->d2h_count) { HIPCHK(c, hipEventSynchronize(c->ev_d2h_done)); c->d2h_count = 0; }   // a batch download may be reading dst
     const int nmb = c->dg.mb_cols * c->dg.mb_rows;
     if (nmb > c->mfqe_cap) {

@@ -207,10 +207,9 @@ def test_cross_cu_small_launches(pkg, ctx, kernel_family):
 
 
 def test_back_to_back_launches_and_stats_ring(pkg, ctx, kernel_family):
-    """Launches are asynchronous and pipeline on the device (the lane family finishes on a second stream with
-    double-buffered scratch): three launches without a host sync in between, then downloads -- which order
-    themselves behind the last pass -- must see the reference's frames; the per-launch kernel times of all three
-    are still readable afterwards (vp8hip_get_stats_at)."""
+    """Launches are asynchronous and pipeline on the device: three launches without a host sync in between, then downloads
+    -- which ask for the raster form of frames the lane family left as tiles -- must see the reference's frames; the per-launch
+    kernel times of all three are still readable afterwards (vp8hip_get_stats_at)."""
     n = 64
     w, h, frames = pkg.read_ivf(ivf_path("kf_q0_176x144"))
     gold = golden_md5("kf_q0_176x144")
@@ -229,7 +228,7 @@ def test_back_to_back_launches_and_stats_ring(pkg, ctx, kernel_family):
         assert pkg.planes_md5(*ctx.download_planes(i)) == gold[((i + 2) % n) % len(frames)], i
     for back in range(3):
         st = ctx.stats(back)
-        assert st.recon_ms > 0 and st.extend_ms > 0
+        assert st.recon_ms > 0 and st.extend_ms >= 0
         assert st.recon_waves == (1 if kernel_family.startswith("lane") else st.recon_waves)
     ctx.join()
     ctx.sync()

@@ -1,4 +1,4 @@
-"""Dev aid (GPU): one launch of n frames for a profiler pass.  python3 tools/pmc_one.py <stages> <frames> [fixture] [shared]
+"""Dev aid (GPU): one launch of n frames for a profiler pass.  python3 tools/pmc_one.py <stages> <frames> [fixture] [shared|""] [raster]
    shared: all frames decode the fixture's few IR slots (no per-frame copy of the IR: far fewer API calls, which rocprofv3
    survives at 8192 frames; the coefficient reads then hit the caches -- SQ counters only)."""
 import os, sys
@@ -13,10 +13,12 @@ ns = len(frames)
 ctx = P.Vp8Hip(0); ctx.configure(w, h, n, ns if shared else n)
 parser = P.Parser()
 for i, data in enumerate(frames):
-    hdr = ctx.parse_into_slot(parser, data, i); parser.swap(hdr); ctx.upload(i)
+    hdr, _ = ctx.parse_into_slot_compact(parser, data, i); parser.swap(hdr)
 if not shared:
     for i in range(ns, n): ctx.ir_copy(i, i % ns)
 jobs = (P.Job * n)()
 for i in range(n): jobs[i].ir_slot, jobs[i].dst_fb = (i % ns if shared else i), i
 ctx.decode_array(jobs, n, stage); ctx.sync()
+if len(sys.argv) > 5 and sys.argv[5] == "raster":      # ... and the raster form of every frame (vp8_detile_kf_kernel + vp8_extend_kernel)
+    ctx.frames_to_raster(0, n); ctx.sync()
 print("done", stage, n)
