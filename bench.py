@@ -474,14 +474,17 @@ def main():
             def dl():
                 ctx._chk(L.vp8hip_frames_fetch_async(ctx.h, 0, nd, host, None), "fetch")
                 ctx._chk(L.vp8hip_download_wait(ctx.h), "wait")
+            ctx.L.vp8hip_set_direct_download(ctx.h, 1)
             ctx.decode_array(jobs, F, P.STAGE_ALL); ctx.sync()
             t_dl = timed(dl)
+            ctx.L.vp8hip_set_direct_download(ctx.h, 0)
             import numpy as np
             hv = np.ctypeslib.as_array(ctypes.cast(host, ctypes.POINTER(ctypes.c_uint8)), shape=(nd, stride))
             okd = all(P.frame_md5(hv[i], ctx.g, W, H) == gold[(lo + i) % nsrc] for i in (0, nd // 2, nd - 1))
             consumers["download"] = {"frames": nd, "ms": round(t_dl, 3), "GB_s_over_pcie": round(nd * W * H * 1.5 / t_dl / 1e6, 2), "md5_ok": bool(okd),
-                                     "what": "vp8_detile_run_kernel writes the raster rows of the frames straight into page-locked host memory "
-                                             "(the tiled -> raster pass is the download; no raster form in HBM)"}
+                                     "what": "vp8hip_set_direct_download: vp8_detile_run_kernel writes the raster rows of the frames straight into "
+                                             "page-locked host memory (the tiled -> raster pass is the download; no raster form in HBM); the "
+                                             "default download goes through the raster form and the copy engines"}
             L.vp8hip_host_free(ctx.h, host)
         except Exception as ex:      # noqa: BLE001
             consumers["download"] = {"error": repr(ex)}

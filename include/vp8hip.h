@@ -214,11 +214,13 @@ int  vp8hip_frames_fetch_async(vp8hip_ctx *ctx, int first_fb, int count, uint8_t
  * the post-processing filters), and the TILED form a large launch leaves (macroblock-window tiles: the form in which a lane of
  * vp8_keyframe_kernel can write whole 64-byte sectors).  The library converts a frame when something needs the form it is not in
  * -- never behind the caller's back after a launch -- and reads tiles where it can: the MD5 kernel of vp8hip_frames_fetch_async
- * walks them, and a batch download into page-locked memory is the tiled -> raster pass itself, writing host memory (the frame's
- * raster form never exists in HBM; what lands in the destination's border bytes is then undefined).  vp8hip_frames_to_raster asks
- * for the raster form of `count` consecutive frame buffers explicitly (asynchronous, on the context's stream; a no-op for frames
- * that have it). */
+ * walks them.  vp8hip_frames_to_raster asks for the raster form of `count` consecutive frame buffers explicitly (asynchronous, on
+ * the context's stream; a no-op for frames that have it).  vp8hip_set_direct_download(ctx, 1): a batch download of tiled frames
+ * into page-locked memory IS the tiled -> raster pass, a kernel writing the host buffer (the frames' raster form never exists in
+ * HBM; what lands in the destination's border bytes is then undefined) -- faster than the copy engines on an otherwise idle
+ * device, slower beside other kernels, hence off by default (VP8HIP_DIRECT_DOWNLOAD=1 sets the default). */
 int  vp8hip_frames_to_raster(vp8hip_ctx *ctx, int first_fb, int count);
+int  vp8hip_set_direct_download(vp8hip_ctx *ctx, int on);
 /* Upload a whole frame buffer (frame_size bytes) -- tests and VP8_SET_REFERENCE. */
 int  vp8hip_frame_upload(vp8hip_ctx *ctx, int fb, const uint8_t *buf);
 int  vp8hip_frame_copy(vp8hip_ctx *ctx, int dst_fb, int src_fb);

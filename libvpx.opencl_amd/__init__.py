@@ -22,7 +22,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 LIBDIR = os.path.join(HERE, "lib")
-HIP_LIB = os.path.join(LIBDIR, "libvp8hip.so")
+HIP_LIB = os.environ.get("VP8HIP_LIB") or os.path.join(LIBDIR, "libvp8hip.so")      # (VP8HIP_LIB: a diagnostic variant, tools/variant.sh)
 HOST_LIB = os.path.join(LIBDIR, "libvpx_hip.so")
 
 c_void_p, c_int, c_size_t = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
@@ -378,6 +378,7 @@ def load_hip():
         L.vp8hip_frame_upload.argtypes = [c_void_p, c_int, c_void_p]
         L.vp8hip_frame_copy.argtypes = [c_void_p, c_int, c_int]
         L.vp8hip_frames_to_raster.argtypes = [c_void_p, c_int, c_int]
+        L.vp8hip_set_direct_download.argtypes = [c_void_p, c_int]
         L.vp8hip_sync.argtypes = [c_void_p]
         L.vp8hip_join.argtypes = [c_void_p]
         L.vp8hip_get_stats_at.argtypes = [c_void_p, c_int, ctypes.POINTER(Stats)]

@@ -30,6 +30,9 @@ static void read_knobs(Knobs &k)
     k.xcu = env_int("VP8HIP_XCU", 1) != 0;
     k.xcu_S = env_int("VP8HIP_XCU_S", 0);
     k.eager_raster = env_int("VP8HIP_EAGER_RASTER", 0) != 0;
+    k.direct_download = env_int("VP8HIP_DIRECT_DOWNLOAD", 0) != 0;
+    k.download_blocks = env_int("VP8HIP_DOWNLOAD_BLOCKS", 0);
+    k.d2h_prio = env_int("VP8HIP_D2H_PRIO", 1);
     k.inter_split = env_int("VP8HIP_INTER_SPLIT", 384);
     k.xcu_NW = env_int("VP8HIP_XCU_NW", 0);
     k.recon_nw = env_int("VP8HIP_RECON_NW", 0);
@@ -481,12 +484,15 @@ extern "C" int vp8hip_frames_fetch_async(vp8hip_ctx *c, int first_fb, int count,
         return fail(c, -3, "vp8hip_frames_fetch_async: digests on the device need a display width that is a multiple of 128 (%d)", c->width);
     HIPCHK(c, hipSetDevice(c->device));
     // Frames that only exist as tiles (a large launch wrote them, nothing has asked for their raster form) are read as tiles: the
-    // MD5 kernel walks the tiles, and the frames leave through a kernel that writes raster rows straight into the caller's
-    // page-locked memory -- the tiled -> raster pass happens where the frame leaves the device, on the way out, and costs the HBM
-    // one read.  Anything else -- a frame already in raster form among them, a destination the device cannot write -- goes the
-    // plain way: raster form first (vp8hip_need_raster), then copies.
+    // MD5 kernel walks the tiles, and -- direct downloads switched on (vp8hip_set_direct_download) -- the frames leave through a
+    // kernel that writes raster rows straight into the caller's page-locked memory: the tiled -> raster pass happens where the
+    // frame leaves the device and costs the HBM one read (44 GB/s over PCIe on an otherwise idle device, against the copy engines'
+    // 25-33).  The default is the plain way -- raster form in HBM first (vp8hip_need_raster), then the copy engines -- because a
+    // pass that waits on PCIe occupies wave slots beside whatever else runs: with the entropy decoder on the device the pipeline
+    // of bin/batch_md5 does 9.6 k 1080p frames/s the plain way and 6.5-8.5 k with direct downloads (gpurun_out/r4e).
     bool tiled = c->tile_block != nullptr;
     for (int i = 0; i < count && tiled; i++) tiled = c->fb_state[(size_t)(first_fb + i)] == FB_TILES;
+    if (tiled && dst && !c->knobs.direct_download) tiled = false;
     if (tiled && dst) {
         hipPointerAttribute_t at;
         if (hipPointerGetAttributes(&at, dst) != hipSuccess) { (void)hipGetLastError(); tiled = false; }
@@ -494,7 +500,11 @@ extern "C" int vp8hip_frames_fetch_async(vp8hip_ctx *c, int first_fb, int count,
     }
     if (!tiled && vp8hip_need_raster(c, first_fb, count)) return -1;
     if (!c->stream_d2h) {
-        HIPCHK(c, hipStreamCreateWithFlags(&c->stream_d2h, hipStreamNonBlocking));
+        // (a stream of another priority class than the context's: the runtime then gives it a hardware queue of its own, and what
+        // it carries -- a pass that waits on PCIe for a third of a second per 4096 frames -- runs BESIDE the main stream's kernels)
+        int prio_least = 0, prio_greatest = 0;
+        HIPCHK(c, hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+        HIPCHK(c, hipStreamCreateWithPriority(&c->stream_d2h, hipStreamNonBlocking, c->knobs.d2h_prio ? prio_least : 0));
         HIPCHK(c, hipEventCreateWithFlags(&c->ev_d2h_from, hipEventDisableTiming));
         HIPCHK(c, hipEventCreateWithFlags(&c->ev_d2h_done, hipEventDisableTiming));
     }
@@ -503,8 +513,11 @@ extern "C" int vp8hip_frames_fetch_async(vp8hip_ctx *c, int first_fb, int count,
     HIPCHK(c, hipStreamWaitEvent(c->stream_d2h, c->ev_d2h_from, 0));
     if (dst) {
         if (tiled) {
+            // (the pass is bound by PCIe, not by the device: a workgroup per CU keeps the link full and leaves the SIMDs to the
+            // launches that run beside it)
             long units = (long)c->dg.mb_rows * count;
-            if (units > 8L * c->num_cu) units = 8L * c->num_cu;
+            const long cap = c->knobs.download_blocks > 0 ? c->knobs.download_blocks : c->num_cu;
+            if (units > cap) units = cap;
             hipLaunchKernelGGL(vp8_detile_run_kernel, dim3((unsigned)units), dim3(256), 0, c->stream_d2h, (const uint8_t *)c->fb_tiles[(size_t)first_fb],
                                c->tile_frame, dst, c->fb_stride, count, c->dg);
             HIPCHK(c, hipGetLastError());
@@ -531,6 +544,13 @@ extern "C" int vp8hip_frames_fetch_async(vp8hip_ctx *c, int first_fb, int count,
     }
     HIPCHK(c, hipEventRecord(c->ev_d2h_done, c->stream_d2h));
     c->d2h_first = first_fb; c->d2h_count = count;
+    return 0;
+}
+
+extern "C" int vp8hip_set_direct_download(vp8hip_ctx *c, int on)
+{
+    if (!c) return -2;
+    c->knobs.direct_download = on != 0;
     return 0;
 }
 

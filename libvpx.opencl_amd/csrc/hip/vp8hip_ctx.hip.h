@@ -41,12 +41,14 @@ struct Slot {
 //   VP8HIP_SIMT_LGG=1..6       lane-per-row kernels: lanes per strand (log2); VP8HIP_SIMT_WAVES=n  at most n waves per launch
 //   VP8HIP_WG_PER_CU, VP8HIP_XCU, VP8HIP_XCU_S, VP8HIP_XCU_NW, VP8HIP_RECON_NW, VP8HIP_LF_NW   wave-per-row family shapes
 //   VP8HIP_EAGER_RASTER=1      large launches produce the raster form of their frames at once (default: when something asks for it)
+//   VP8HIP_DIRECT_DOWNLOAD=0   batch downloads of tiled frames go through the raster form in HBM and a copy (default: the tiled ->
+//                              raster pass writes the page-locked destination itself); VP8HIP_DOWNLOAD_BLOCKS=n  its workgroups
 //   VP8HIP_INTER_SPLIT=N       launches of up to N frames with inter frames among them run vp8_inter_mb_kernel first (default 384; 0:
 //                              never).  It shortens a frame's critical path (1080p P frames, 1..16 per launch: recon 0.91 -> 0.46-0.56
 //                              ms; 128: 1.56 -> 1.45) and costs throughput in launches that fill the chip anyway (512: 3.82 -> 4.03)
 struct Knobs {
     int recon_force;       // 0 automatic, 1 lane-per-row, 2 wave-per-row
-    int inter_split, eager_raster;
+    int inter_split, eager_raster, direct_download, download_blocks, d2h_prio;
     int lgG, simt_waves, wg_per_cu, xcu, xcu_S, xcu_NW, recon_nw, lf_nw;
 };
 

@@ -53,7 +53,8 @@ def test_tiles_are_read_where_they_lie(pkg, monkeypatch, name, n):
         # digests from the tiles
         assert ctx.frames_md5(0, n) == want
         assert ctx.frames_md5(3, 2) == want[3:5]
-        # frames + digests in one call, the frames into page-locked memory: the pass writes host memory
+        # frames + digests in one call, the frames into page-locked memory, direct downloads on: the pass writes host memory
+        L.vp8hip_set_direct_download(ctx.h, 1)
         stride = L.vp8hip_frame_stride(ctx.h)
         pinned = L.vp8hip_host_alloc(ctx.h, stride * n)
         assert pinned
@@ -66,8 +67,10 @@ def test_tiles_are_read_where_they_lie(pkg, monkeypatch, name, n):
             for i in range(n):
                 assert dig[16 * i: 16 * i + 16].tobytes().hex() == want[i]
                 assert P.frame_md5(host[i], ctx.g, ctx.width, ctx.height) == want[i], i
+            assert ctx.stats().detile_pass == 0 and not any(host[0, :ctx.g.y_off - 8] != 0x5a)      # (no raster form, no borders)
         finally:
             L.vp8hip_host_free(ctx.h, pinned)
+            L.vp8hip_set_direct_download(ctx.h, 0)
         # ... into ordinary memory: raster form on the device first, then a copy (and now both forms hold the frames)
         frames = np.zeros((n, stride), np.uint8)
         ctx._chk(L.vp8hip_frames_fetch_async(ctx.h, 0, n, frames.ctypes.data, None), "fetch")

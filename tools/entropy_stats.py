@@ -1,4 +1,4 @@
-"""Dev aid: decisions per frame of the device entropy decoder (a library built with -DENT_STATS: tools/build_var.sh entstats
+"""Dev aid: decisions per frame of the device entropy decoder (a library built with -DENT_STATS: tools/variant.sh entstats
 -DENT_STATS; VP8HIP_LIB=...) and the time of a launch: cycles per decision of the slowest lane."""
 import os, sys, time, ctypes
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
