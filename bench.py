@@ -283,6 +283,42 @@ def timed_steps(P, ctx, jobs, F, steps, warmup, barrier):
     return elapsed, ms, st
 
 
+def pin_rank(local_rank, world):
+    """CPU affinity of a rank: the CPUs of the NUMA node its GPU hangs on (sysfs), cut into as many slices as ranks share the
+    node; without that information a contiguous slice of the CPUs this process may use.  The timed region is device work, so this
+    matters for what feeds it -- the host feeder threads of the end-to-end pipelines, the IR uploads -- and keeps N ranks from
+    migrating over each other.  VP8BENCH_NO_AFFINITY=1 leaves the affinity alone.  Returns the CPU list (or None)."""
+    if os.environ.get("VP8BENCH_NO_AFFINITY") == "1" or not hasattr(os, "sched_setaffinity"):
+        return None
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+        cpus = None
+        try:
+            import torch
+            pr = torch.cuda.get_device_properties(local_rank)
+            bdf = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+        except Exception:  # noqa: BLE001 - (older torch: no PCI ids in the properties)
+            bdf = None
+        if bdf:
+            path = f"/sys/bus/pci/devices/{str(bdf).lower()}/local_cpulist"
+            if os.path.exists(path):
+                node = []
+                for part in open(path).read().strip().split(","):
+                    if part:
+                        a, _, b = part.partition("-")
+                        node += list(range(int(a), int(b or a) + 1))
+                node = [c for c in node if c in allowed]
+                if node:
+                    cpus = node
+        if cpus is None:
+            per = max(1, len(allowed) // max(1, world))
+            cpus = allowed[local_rank * per:(local_rank + 1) * per] or allowed
+        os.sched_setaffinity(0, cpus)
+        return cpus
+    except Exception:  # noqa: BLE001 - affinity is an optimisation
+        return None
+
+
 def spawn_ranks(args):
     """--gpus N without a launcher: start N fresh child processes, one rank per GPU, from a parent that never touches a GPU
     (rank 0's stdout is passed through; the exit code is the worst child's)."""
@@ -335,6 +371,7 @@ def main():
     if one_dev:
         local_rank = 0
     torch.cuda.set_device(local_rank)
+    my_cpus = pin_rank(local_rank, world) if world > 1 else None
     coll_dev = torch.device("cpu") if one_dev else torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
@@ -419,7 +456,11 @@ def main():
     elapsed_local, ms, st = timed_steps(P, ctx, jobs, F, args.steps, args.warmup, barrier)
     elapsed = elapsed_local
     per_rank = [elapsed_local]
+    rank_cpus = [f"{len(my_cpus)} CPUs from {my_cpus[0]}" if my_cpus else None]
     if dist is not None:
+        obj = [None] * world
+        dist.all_gather_object(obj, rank_cpus[0])
+        rank_cpus = obj
         t = torch.tensor([elapsed_local], device=coll_dev, dtype=torch.float64)
         allt = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(allt, t)
@@ -568,6 +609,7 @@ def main():
                 "parallelism": f"one stream of {world * F} frames sharded in contiguous blocks over {world} GPU(s) (rank r: frames "
                                f"[r*{F}, (r+1)*{F})), no pixel exchange; RCCL carries barriers, times and the MD5 listing",
                 "per_rank_Mpix_s": [round(F * K * W * H / t / 1e6, 1) for t in per_rank],
+                "rank_cpu_affinity": rank_cpus,
                 "sharded_md5_listing_equals_1gpu_listing": listing_ok,
                 "md5_checked_frames_per_rank": len(sample),
                 "kernel_ms": {k: round(v, 4) for k, v in ms.items()},
