@@ -169,7 +169,9 @@ typedef struct vp8hip_entropy_frame {
     uint32_t first_range;               /*     and its range, 128..255 */
     uint32_t num_tok;                   /* 1, 2, 4 or 8 token partitions */
     uint32_t tok_pos[8], tok_end[8];    /* their extents, relative to data_off */
-    uint8_t  update_mb_segmentation_map, mb_no_coeff_skip, prob_skip_false, rsv0;
+    uint8_t  update_mb_segmentation_map, mb_no_coeff_skip, prob_skip_false;
+    uint8_t  segmap_keep;               /* 1: a macroblock's segment id is the one the slot's record holds from the frame before
+                                           (a stream decoded frame after frame into this slot: vp8_parser_set_device_segmap) */
     uint8_t  segment_tree_probs[3], rsv1;
     uint8_t  coef_probs[1056];          /* [block type 4][band 8][context 3][node 11] */
     /* inter frames (hdr.frame_type 1; mb_mode_mv_init, decodemv.c:178-224): */
@@ -209,6 +211,9 @@ int  vp8hip_download_wait(vp8hip_ctx *ctx);
  * have landed when vp8hip_download_wait returns.  Display widths that are not a multiple of 128 are refused with -3 (rows have
  * to be whole MD5 blocks): the caller hashes those frames on the host. */
 int  vp8hip_frames_fetch_async(vp8hip_ctx *ctx, int first_fb, int count, uint8_t *dst, uint8_t *digests);
+/* The digests alone, of ANY n frame buffers (fbs[i]; not necessarily neighbours: the shown frames of many streams decoded side by
+ * side, bin/batch_md5 --streams): digests[16 * i].  Same stream, same wait and same width rule as vp8hip_frames_fetch_async. */
+int  vp8hip_frames_md5_list_async(vp8hip_ctx *ctx, const int *fbs, int n, uint8_t *digests);
 /* A frame buffer has two forms on the device: the RASTER form (vp8ir_geom: the reference's YV12 layout, borders included), which
  * the small-launch kernels write and everything that reads pixels by coordinate reads (inter prediction, vp8hip_frame_download,
  * the post-processing filters), and the TILED form a large launch leaves (macroblock-window tiles: the form in which a lane of

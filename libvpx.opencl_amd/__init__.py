@@ -68,7 +68,7 @@ class EntropyFrame(ctypes.Structure):
                 ("first_value", ctypes.c_uint32), ("first_bits", ctypes.c_int32), ("first_range", ctypes.c_uint32),
                 ("num_tok", ctypes.c_uint32), ("tok_pos", ctypes.c_uint32 * 8), ("tok_end", ctypes.c_uint32 * 8),
                 ("update_mb_segmentation_map", ctypes.c_uint8), ("mb_no_coeff_skip", ctypes.c_uint8),
-                ("prob_skip_false", ctypes.c_uint8), ("rsv0", ctypes.c_uint8), ("segment_tree_probs", ctypes.c_uint8 * 3),
+                ("prob_skip_false", ctypes.c_uint8), ("segmap_keep", ctypes.c_uint8), ("segment_tree_probs", ctypes.c_uint8 * 3),
                 ("rsv1", ctypes.c_uint8), ("coef_probs", ctypes.c_uint8 * 1056),
                 ("prob_intra", ctypes.c_uint8), ("prob_last", ctypes.c_uint8), ("prob_gf", ctypes.c_uint8), ("rsv2", ctypes.c_uint8),
                 ("ymode_prob", ctypes.c_uint8 * 4), ("uvmode_prob", ctypes.c_uint8 * 3), ("rsv3", ctypes.c_uint8),
@@ -164,6 +164,7 @@ def load_host():
         L.vp8_parser_create.restype = c_void_p
         L.vp8_parser_destroy.argtypes = [c_void_p]
         L.vp8_parser_set_threads.argtypes = [c_void_p, c_int]
+        L.vp8_parser_set_device_segmap.argtypes = [c_void_p, c_int]
         L.vp8_parser_set_error_concealment.argtypes = [c_void_p, c_int]
         L.vp8_parser_conceals.argtypes = [c_void_p]
         L.vp8_parser_frame_hdr.argtypes = [c_void_p, c_void_p]
@@ -199,6 +200,10 @@ class Parser:
     def set_threads(self, n):
         """token partitions of a frame on up to n threads (vp8_parser_set_threads)"""
         self.L.vp8_parser_set_threads(self.p, n)
+
+    def set_device_segmap(self, on=True):
+        """the device keeps this stream's segment map, in the IR slot its frames are decoded into (vp8_parser_set_device_segmap)"""
+        self.L.vp8_parser_set_device_segmap(self.p, int(on))
 
     def final_hdr(self, hdr):
         """after decode_mbs: the header as the pixel path is to see it (vp8_parser_frame_hdr)"""

@@ -189,13 +189,14 @@ __device__ __forceinline__ int read_block(BD &b, const uint8_t *__restrict__ dat
 // What the first partition says about one macroblock (vp8_kfread_modes, decodemv.c:50-173).  above / left: the sub-block modes
 // of the row above at this column and of the macroblock to the left (four nibbles each), updated for the neighbours to come.
 struct MbModes { int ymode, uvmode, seg, skip; u64 bm; int ref, clamp, part; };    // bm: B_PRED's sixteen modes, a nibble each
+// (kept_seg: the segment id of a macroblock whose frame does not code one -- 0, or what the slot's record held: segmap_keep)
 struct ModeParams { bool seg_map, has_skip; u32 p_skip, tp0, tp1, tp2; };
 __device__ __forceinline__ MbModes read_mb_modes(BD &fb, const uint8_t *__restrict__ data, u32 limit, const ModeParams &P, const row_t *kfb,
-                                                 u32 &above, u32 &lbm)
+                                                 u32 &above, u32 &lbm, int kept_seg)
 {
     MbModes m;
     m.ref = VP8IR_INTRA_FRAME; m.clamp = 0; m.part = 0;
-    m.seg = 0;
+    m.seg = kept_seg;
     if (P.seg_map) m.seg = GET(fb, P.tp0) ? 2 + GET(fb, P.tp2) : GET(fb, P.tp1);
     m.skip = P.has_skip ? GET(fb, P.p_skip) : 0;
     if (!GET(fb, 145)) m.ymode = VP8IR_B_PRED;
@@ -285,11 +286,11 @@ __constant__ uint8_t k_submv_prob[8][3] = { { 147, 136, 18 }, { 223, 1, 34 }, { 
 // (bmv as the macroblock's own sixteen say: the caller picks the side).
 __device__ __forceinline__ MbModes read_mb_modes_inter(BD &fb, const uint8_t *__restrict__ data, u32 limit, const ModeParams &P,
                                                        const InterParams &I, const Nb &above, const Nb &left, const Nb &aboveleft,
-                                                       int mb_row, int mb_col, int rows, int cols, u32 *mvs, Nb &self)
+                                                       int mb_row, int mb_col, int rows, int cols, u32 *mvs, Nb &self, int kept_seg)
 {
     MbModes m;
     m.bm = 0; m.clamp = 0; m.part = 0; m.uvmode = VP8IR_DC_PRED;
-    m.seg = 0;
+    m.seg = kept_seg;
     if (P.seg_map) m.seg = GET(fb, P.tp0) ? 2 + GET(fb, P.tp2) : GET(fb, P.tp1);
     m.skip = P.has_skip ? GET(fb, P.p_skip) : 0;
     u32 mv = 0;
@@ -575,12 +576,14 @@ vp8_entropy_kernel(const vp8hip_entropy_frame *__restrict__ frames, int count, i
         for (int c = 0; c < cols; c++) {
             const long n = (long)r * cols + c;
             MbModes m;
+            // a kept segment map: the id the frame before left in this slot's record (descriptor byte 4), before it is overwritten
+            const int kept_seg = F.segmap_keep ? (int)(((const u32 *)(out_mbs + n * 8))[1] & 3u) : 0;
             if (inter) {
                 Nb above, self;
                 u32 *a6 = anb + 6 * c;
                 above.mv = a6[0]; above.bmv[0] = a6[1]; above.bmv[1] = a6[2]; above.bmv[2] = a6[3]; above.bmv[3] = a6[4];
                 above.ref = a6[5] & 255u; above.ymode = a6[5] >> 8;
-                m = read_mb_modes_inter(fb, data, limit, MP, IP, above, left, aboveleft, r, c, rows, cols, mvs, self);
+                m = read_mb_modes_inter(fb, data, limit, MP, IP, above, left, aboveleft, r, c, rows, cols, mvs, self, kept_seg);
                 a6[0] = self.mv; a6[1] = mvs[12]; a6[2] = mvs[13]; a6[3] = mvs[14]; a6[4] = mvs[15]; a6[5] = self.ref | self.ymode << 8;
                 aboveleft = above;
                 left = self; left.bmv[0] = mvs[3]; left.bmv[1] = mvs[7]; left.bmv[2] = mvs[11]; left.bmv[3] = mvs[15];
@@ -588,7 +591,7 @@ vp8_entropy_kernel(const vp8hip_entropy_frame *__restrict__ frames, int count, i
                 for (int w = 0; w < 4; w++) out_mvs[n * 4 + w] = (u32x4){ mvs[4 * w], mvs[4 * w + 1], mvs[4 * w + 2], mvs[4 * w + 3] };
             } else {
                 u32 above = abm[c];
-                m = read_mb_modes(fb, data, limit, MP, s_kfb, above, lbm);
+                m = read_mb_modes(fb, data, limit, MP, s_kfb, above, lbm, kept_seg);
                 abm[c] = above;
             }
             u32 A = anz[c];
@@ -679,7 +682,8 @@ vp8_entropy_parts_kernel(const vp8hip_entropy_frame *__restrict__ frames, int co
             u32 lbm = 0;
             for (int c = 0; c < cols; c++) {
                 u32 above = abm[c];
-                const MbModes m = read_mb_modes(fb, data, limit, MP, s_kfb, above, lbm);
+                const int kept_seg = F.segmap_keep ? (int)(((const u32 *)((u32x4 *)(slot_base + slot_bytes * (size_t)(first_slot + f) + o_mbx) + ((size_t)r * cols + c) * 8))[1] & 3u) : 0;
+                const MbModes m = read_mb_modes(fb, data, limit, MP, s_kfb, above, lbm, kept_seg);
                 abm[c] = above;
                 u32 *o = modes + 3 * ((size_t)r * cols + c);
                 o[0] = (u32)m.ymode | (u32)m.uvmode << 8 | (u32)m.seg << 16 | (u32)m.skip << 24;

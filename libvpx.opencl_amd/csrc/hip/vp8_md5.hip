@@ -100,14 +100,16 @@ __device__ __forceinline__ void tile_block(g_cu8p base, int cols, int pl, int ro
     for (int k = 0; k < 4; k++) q[k] = (u32x4){ m[4 * k], m[4 * k + 1], m[4 * k + 2], m[4 * k + 3] };
 }
 
-// frames: the first frame buffer (TILED: its tiles); fstride: bytes from one to the next; w, h: display size (w a multiple of 128);
-// out: 16 bytes per frame.  One lane per frame, 64-thread blocks.
+// frames: frame buffer 0 of the pool (TILED: its tiles); fstride: bytes from one to the next; index: which frame buffer lane f
+// hashes (null: first + f); w, h: display size (w a multiple of 128); out: 16 bytes per frame.  One lane per frame, 64-thread blocks.
 template <bool TILED>
-__device__ __forceinline__ void md5_frames(const uint8_t *__restrict__ frames, size_t fstride, int count, DevGeom g, int w, int h, uint8_t *__restrict__ out)
+__device__ __forceinline__ void md5_frames(const uint8_t *__restrict__ frames, size_t fstride, const int *__restrict__ index, int first, int count,
+                                           DevGeom g, int w, int h, uint8_t *__restrict__ out)
 {
     const int f = blockIdx.x * 64 + threadIdx.x;
     const bool live = f < count;
-    g_cu8p base = (g_cu8p)(frames + fstride * (size_t)(live ? f : 0));
+    const int fbi = index ? index[live ? f : 0] : first + (live ? f : 0);
+    g_cu8p base = (g_cu8p)(frames + fstride * (size_t)fbi);
     u32 A = 0x67452301u, B = 0xefcdab89u, C = 0x98badcfeu, D = 0x10325476u;
     constexpr int AHEAD = 4;
     // the walk: plane 0 = Y (h rows of w / 64 blocks), 1 = U, 2 = V ((h + 1) / 2 rows of w / 128 blocks)
@@ -158,12 +160,14 @@ __device__ __forceinline__ void md5_frames(const uint8_t *__restrict__ frames, s
 } // namespace
 
 extern "C" __global__ void __launch_bounds__(64)
-vp8_md5_kernel(const uint8_t *__restrict__ frames, size_t fstride, int count, DevGeom g, int w, int h, uint8_t *__restrict__ out)
+vp8_md5_kernel(const uint8_t *__restrict__ frames, size_t fstride, const int *__restrict__ index, int first, int count, DevGeom g, int w, int h,
+               uint8_t *__restrict__ out)
 {
-    md5_frames<false>(frames, fstride, count, g, w, h, out);
+    md5_frames<false>(frames, fstride, index, first, count, g, w, h, out);
 }
 extern "C" __global__ void __launch_bounds__(64)
-vp8_md5_tiles_kernel(const uint8_t *__restrict__ tiles, size_t tstride, int count, DevGeom g, int w, int h, uint8_t *__restrict__ out)
+vp8_md5_tiles_kernel(const uint8_t *__restrict__ tiles, size_t tstride, const int *__restrict__ index, int first, int count, DevGeom g, int w, int h,
+                     uint8_t *__restrict__ out)
 {
-    md5_frames<true>(tiles, tstride, count, g, w, h, out);
+    md5_frames<true>(tiles, tstride, index, first, count, g, w, h, out);
 }

@@ -13,8 +13,10 @@ extern "C" __global__ void vp8_recon_intra_kernel(const DevJob *jobs, int njobs,
 extern "C" __global__ void vp8_recon_intra_xcu_kernel(const DevJob *jobs, int njobs, DevGeom g, unsigned long long *gran, unsigned int epoch,
                                                       int S, int *err, const unsigned int *intra_flags);
 extern "C" __global__ void vp8_loopfilter_kernel(const DevJob *jobs, int njobs, DevGeom g);
-extern "C" __global__ void vp8_md5_kernel(const uint8_t *frames, size_t fstride, int count, DevGeom g, int w, int h, uint8_t *out);
-extern "C" __global__ void vp8_md5_tiles_kernel(const uint8_t *tiles, size_t tstride, int count, DevGeom g, int w, int h, uint8_t *out);
+extern "C" __global__ void vp8_md5_kernel(const uint8_t *frames, size_t fstride, const int *index, int first, int count, DevGeom g, int w, int h,
+                                          uint8_t *out);
+extern "C" __global__ void vp8_md5_tiles_kernel(const uint8_t *tiles, size_t tstride, const int *index, int first, int count, DevGeom g, int w,
+                                                int h, uint8_t *out);
 extern "C" __global__ void vp8_detile_run_kernel(const uint8_t *tiles, size_t tstride, uint8_t *dst, size_t dstride, int count, DevGeom g);
 
 static char g_create_error[256] = "";
@@ -165,6 +167,8 @@ extern "C" void vp8hip_destroy(vp8hip_ctx *c)
     // postproc_state.noise across vp8_alloc_frame_buffers) and only sends the noise table again when q changes
     if (c->d_pp) (void)hipFree(c->d_pp);
     if (c->d_md5) (void)hipFree(c->d_md5);
+    if (c->d_md5_idx) (void)hipFree(c->d_md5_idx);
+    if (c->h_md5_idx) (void)hipHostFree(c->h_md5_idx);
     if (c->h_pp) (void)hipHostFree(c->h_pp);
     if (c->ev_pp) (void)hipEventDestroy(c->ev_pp);
     if (c->d_ent_frames) (void)hipFree(c->d_ent_frames);
@@ -535,10 +539,10 @@ extern "C" int vp8hip_frames_fetch_async(vp8hip_ctx *c, int first_fb, int count,
         // a frame per lane: the frames' hashes run side by side, behind the copy of the frames themselves (if asked for)
         if (tiled)
             hipLaunchKernelGGL(vp8_md5_tiles_kernel, dim3((unsigned)((count + 63) / 64)), dim3(64), 0, c->stream_d2h,
-                               (const uint8_t *)c->fb_tiles[(size_t)first_fb], c->tile_frame, count, c->dg, c->width, c->height, c->d_md5);
+                               (const uint8_t *)c->tile_block, c->tile_frame, (const int *)nullptr, first_fb, count, c->dg, c->width, c->height, c->d_md5);
         else
-            hipLaunchKernelGGL(vp8_md5_kernel, dim3((unsigned)((count + 63) / 64)), dim3(64), 0, c->stream_d2h, (const uint8_t *)c->fb[first_fb],
-                               c->fb_stride, count, c->dg, c->width, c->height, c->d_md5);
+            hipLaunchKernelGGL(vp8_md5_kernel, dim3((unsigned)((count + 63) / 64)), dim3(64), 0, c->stream_d2h, (const uint8_t *)c->fb_block,
+                               c->fb_stride, (const int *)nullptr, first_fb, count, c->dg, c->width, c->height, c->d_md5);
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipMemcpyAsync(digests, c->d_md5, 16 * (size_t)count, hipMemcpyDeviceToHost, c->stream_d2h));
     }
@@ -559,6 +563,63 @@ extern "C" int vp8hip_frames_to_raster(vp8hip_ctx *c, int first_fb, int count)
     if (!c || first_fb < 0 || count < 1 || first_fb + count > (int)c->fb.size()) return fail(c, -2, "vp8hip_frames_to_raster: bad arguments");
     HIPCHK(c, hipSetDevice(c->device));
     return vp8hip_need_raster(c, first_fb, count);
+}
+
+// The digests of any n frame buffers (fbs[i]: not necessarily neighbours -- the shown frames of many streams decoded side by
+// side).  Same stream, same wait (vp8hip_download_wait) as vp8hip_frames_fetch_async; `fbs` may be reused when the call returns.
+extern "C" int vp8hip_frames_md5_list_async(vp8hip_ctx *c, const int *fbs, int n, uint8_t *digests)
+{
+    if (!c || !fbs || n < 1 || !digests) return fail(c, -2, "vp8hip_frames_md5_list_async: bad arguments");
+    if (c->width & 127)
+        return fail(c, -3, "vp8hip_frames_md5_list_async: digests on the device need a display width that is a multiple of 128 (%d)", c->width);
+    for (int i = 0; i < n; i++)
+        if (fbs[i] < 0 || fbs[i] >= (int)c->fb.size()) return fail(c, -2, "vp8hip_frames_md5_list_async: frame buffer %d out of range", fbs[i]);
+    HIPCHK(c, hipSetDevice(c->device));
+    bool tiled = c->tile_block != nullptr;
+    for (int i = 0; i < n && tiled; i++) tiled = (c->fb_state[(size_t)fbs[i]] & FB_TILES) != 0;
+    if (!tiled && vp8hip_need_raster_list(c, fbs, n)) return -1;
+    if (!c->stream_d2h) {
+        int prio_least = 0, prio_greatest = 0;
+        HIPCHK(c, hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+        HIPCHK(c, hipStreamCreateWithPriority(&c->stream_d2h, hipStreamNonBlocking, c->knobs.d2h_prio ? prio_least : 0));
+        HIPCHK(c, hipEventCreateWithFlags(&c->ev_d2h_from, hipEventDisableTiming));
+        HIPCHK(c, hipEventCreateWithFlags(&c->ev_d2h_done, hipEventDisableTiming));
+    }
+    if (c->d2h_count) HIPCHK(c, hipEventSynchronize(c->ev_d2h_done));  // one fetch in flight at a time
+    if (c->md5_cap < n || c->md5_idx_cap < n) {
+        HIPCHK(c, hipStreamSynchronize(c->stream_d2h));
+        const int cap = n < 64 ? 64 : n;
+        if (c->md5_cap < n) {
+            if (c->d_md5) (void)hipFree(c->d_md5);
+            c->d_md5 = nullptr; c->md5_cap = 0;
+            HIPCHK(c, hipMalloc((void **)&c->d_md5, 16 * (size_t)cap));
+            c->md5_cap = cap;
+        }
+        if (c->md5_idx_cap < n) {
+            if (c->d_md5_idx) (void)hipFree(c->d_md5_idx);
+            if (c->h_md5_idx) (void)hipHostFree(c->h_md5_idx);
+            c->d_md5_idx = nullptr; c->h_md5_idx = nullptr; c->md5_idx_cap = 0;
+            HIPCHK(c, hipMalloc((void **)&c->d_md5_idx, sizeof(int) * (size_t)cap));
+            HIPCHK(c, hipHostMalloc((void **)&c->h_md5_idx, sizeof(int) * (size_t)cap, hipHostMallocDefault));
+            c->md5_idx_cap = cap;
+        }
+    }
+    memcpy(c->h_md5_idx, fbs, sizeof(int) * (size_t)n);      // (the previous fetch, which read this staging, has been waited for)
+    HIPCHK(c, hipEventRecord(c->ev_d2h_from, c->stream));
+    HIPCHK(c, hipStreamWaitEvent(c->stream_d2h, c->ev_d2h_from, 0));
+    HIPCHK(c, hipMemcpyAsync(c->d_md5_idx, c->h_md5_idx, sizeof(int) * (size_t)n, hipMemcpyHostToDevice, c->stream_d2h));
+    if (tiled)
+        hipLaunchKernelGGL(vp8_md5_tiles_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, c->stream_d2h, (const uint8_t *)c->tile_block,
+                           c->tile_frame, (const int *)c->d_md5_idx, 0, n, c->dg, c->width, c->height, c->d_md5);
+    else
+        hipLaunchKernelGGL(vp8_md5_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, c->stream_d2h, (const uint8_t *)c->fb_block,
+                           c->fb_stride, (const int *)c->d_md5_idx, 0, n, c->dg, c->width, c->height, c->d_md5);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(digests, c->d_md5, 16 * (size_t)n, hipMemcpyDeviceToHost, c->stream_d2h));
+    HIPCHK(c, hipEventRecord(c->ev_d2h_done, c->stream_d2h));
+    // (a launch that writes ANY frame buffer waits for this fetch: the list may name any of them)
+    c->d2h_first = 0; c->d2h_count = (int)c->fb.size();
+    return 0;
 }
 
 extern "C" int vp8hip_frames_download_async(vp8hip_ctx *c, int first_fb, int count, uint8_t *dst)

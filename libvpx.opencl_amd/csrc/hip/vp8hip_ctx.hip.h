@@ -99,6 +99,7 @@ struct vp8hip_ctx {
     hipEvent_t ev_d2h_from, ev_d2h_done;
     int d2h_first, d2h_count;      // frame buffers of the copy in flight (count 0: none)
     uint8_t *d_md5; int md5_cap;   // vp8hip_frames_fetch_async: the batch's digests on the device
+    int *d_md5_idx, *h_md5_idx; int md5_idx_cap;    // vp8hip_frames_md5_list_async: which frame buffers
     size_t fb_stride;
     unsigned int *d_intra_flags; int intra_flags_cap;       // per job of a launch: the frame has intra macroblocks (vp8_inter_mb_kernel)
     // vp8hip_postproc: dither table (440 shorts), noise table (3072) and per-row noise phases (16384) on the device

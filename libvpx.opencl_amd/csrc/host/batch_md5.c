@@ -1,4 +1,5 @@
-/* batch_md5 [--threads T] [--batch B] [--loop N] [--host-md5] [--device-entropy [--entropy-batch E] [--no-download]] <in.ivf> <out.md5>
+/* batch_md5 [--threads T] [--batch B] [--loop N] [--host-md5] [--device-entropy [--entropy-batch E] [--no-download]] [--gpus G] <in.ivf> <out.md5>
+ * batch_md5 --streams S [--threads T] [--gpus G] <in.ivf> [<in2.ivf> ...] <out.md5>
  *
  * decode_to_md5 for streams of independently decodable frames (all key frames), at the rate the host can feed the
  * GPU: SURVEY.md 8(f)1.  The output file has decode_to_md5's lines ("<md5>  img-<w>x<h>-<%04d>.i420", one per frame,
@@ -22,7 +23,21 @@
  * the slots alone: tiles and frame buffers are only needed for B frames at a time.  Frames the device reports as cut short
  * (vp8hip_entropy_status) are counted and named on stderr, as the host feeder's *corrupt would.
  *
+ * --streams S: S streams of ANY frame types decoded side by side, position t of all of them in one launch (stream s plays input
+ * s mod inputs; all inputs of one frame size; the shortest sets the length): only the frame headers are read on the host, a
+ * stream's frames go through ONE IR slot and four frame buffers of its own, the segment map a stream keeps from frame to frame
+ * stays on the device with them (vp8_parser_set_device_segmap), every shown frame is hashed on the device
+ * (vp8hip_frames_md5_list_async).  The listing has decode_to_md5's lines stream after stream ("stream<s>/img-..." labels when
+ * S > 1).  This is how inter-frame streams use the device's entropy decoder: a stream's frames depend on each other, streams do not.
+ *
+ * --gpus G: G worker processes, one per device (one feeder pool and one context each), over contiguous shares of the work --
+ * frames of the looped stream, or streams --; the listings are merged in order.  VP8BATCH_SINGLE_DEVICE=1 (test boxes with one
+ * GPU) puts every worker on device 0.
+ *
  * Prints frames, seconds and frames/s for the region "first byte parsed .. last digest done" on stderr. */
+#define _GNU_SOURCE
+#include <sched.h>
+#include <sys/wait.h>
 #include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -87,6 +102,8 @@ static void task_wait(task *t, int slot)
 /* ---- the stream in memory -------------------------------------------------------------------------------------------- */
 typedef struct frame { uint8_t *data; size_t size; } frame;
 static frame *g_frames; static int g_nframes;
+static long g_first;                                /* --gpus: this worker's share starts at frame g_first of the looped stream */
+#define FRAME_AT(k) (&g_frames[(g_first + (k)) % g_nframes])
 
 /* ---- per-run state shared with the workers ------------------------------------------------------------------------ */
 static vp8hip_ctx *g_hip;
@@ -126,14 +143,14 @@ static inline long run_index(long k) { return g_order ? g_order[k] : k; }
 static int by_size_desc(const void *pa, const void *pb)
 {
     const long a = *(const long *)pa, b = *(const long *)pb;
-    const size_t sa = g_frames[a % g_nframes].size, sb = g_frames[b % g_nframes].size;
+    const size_t sa = FRAME_AT(a)->size, sb = FRAME_AT(b)->size;
     return sa != sb ? (sa < sb ? 1 : -1) : (a < b ? -1 : a > b);
 }
 
 static void parse_one(void *arg, int i, int worker)
 {
     const batch_ref *br = (const batch_ref *)arg;
-    const frame *f = &g_frames[(br->first + i) % g_nframes];
+    const frame *f = FRAME_AT(br->first + i);
     const int slot = (br->b % 3) * g_batch + i;
     vp8ir_frame_hdr hdr;
     int rc = vp8_parser_begin_frame(g_parsers[worker], f->data, f->size, &hdr);
@@ -148,7 +165,7 @@ static void parse_one(void *arg, int i, int worker)
 static void export_one(void *arg, int i, int worker)
 {
     const batch_ref *br = (const batch_ref *)arg;
-    const frame *f = &g_frames[run_index(br->first + i) % g_nframes];
+    const frame *f = FRAME_AT(run_index(br->first + i));
     vp8hip_entropy_frame *e = &g_ent[br->b & 1][i];
     const uint64_t off = e->data_off;
     vp8ir_frame_hdr hdr;
@@ -165,7 +182,7 @@ static size_t place_frames(const batch_ref *br)
     size_t off = 0;
     for (int i = 0; i < br->n; i++) {
         g_ent[br->b & 1][i].data_off = off;
-        off += g_frames[run_index(br->first + i) % g_nframes].size;
+        off += FRAME_AT(run_index(br->first + i))->size;
     }
     return off;
 }
@@ -208,9 +225,244 @@ static double now_s(void)
 #define DIE(...) do { fprintf(stderr, __VA_ARGS__); fprintf(stderr, "\n"); exit(EXIT_FAILURE); } while (0)
 #define HIP(call) do { if (call) DIE("%s: %s", #call, vp8hip_last_error(g_hip)); } while (0)
 
+
+/* ---- --gpus: workers ------------------------------------------------------------------------------------------------------- */
+static const char *g_stat_path;                     /* a worker leaves "frames seconds" here for the parent */
+static void leave_stats(long frames, double seconds)
+{
+    if (!g_stat_path) return;
+    FILE *f = fopen(g_stat_path, "w");
+    if (f) { fprintf(f, "%ld %.6f\n", frames, seconds); fclose(f); }
+}
+/* this process's CPUs: share `g` of `G` of what it may run on (contiguous slices: the feeder threads of a device's worker stay
+   together and off the other workers' cores) */
+static void pin_share(int g, int G)
+{
+    cpu_set_t all, mine;
+    if (getenv("VP8BATCH_NO_AFFINITY") || sched_getaffinity(0, sizeof all, &all)) return;
+    const int n = CPU_COUNT(&all), per = n / G;
+    if (per < 1) return;
+    CPU_ZERO(&mine);
+    int seen = 0;
+    for (int c = 0; c < CPU_SETSIZE; c++)
+        if (CPU_ISSET(c, &all)) { if (seen >= g * per && seen < (g + 1) * per) CPU_SET(c, &mine); seen++; }
+    (void)sched_setaffinity(0, sizeof mine, &mine);
+}
+/* Fork G workers over [0, total) (frames or streams).  In a worker: returns its index and sets *lo / *hi and VP8HIP_DEVICE; in the
+   parent: waits, merges the workers' listings into `out_path`, prints the aggregate, and exits. */
+static int fork_workers(int G, long total, long *lo, long *hi, const char *out_path, char *part_path, size_t part_len, const char *unit,
+                        long pixels_per_unit_frame)
+{
+    pid_t pid[64];
+    if (G > 64) G = 64;
+    if (G > total) G = (int)total;
+    const double t0 = now_s();
+    for (int g = 0; g < G; g++) {
+        fflush(NULL);
+        pid[g] = fork();
+        if (pid[g] < 0) DIE("fork failed");
+        if (pid[g] == 0) {
+            char dev[16];
+            snprintf(dev, sizeof dev, "%d", getenv("VP8BATCH_SINGLE_DEVICE") ? 0 : g);
+            setenv("VP8HIP_DEVICE", dev, 1);
+            pin_share(g, G);
+            const long base = total / G, extra = total % G;
+            *lo = g * base + (g < extra ? g : extra);
+            *hi = *lo + base + (g < extra ? 1 : 0);
+            snprintf(part_path, part_len, "%s.part%d", out_path, g);
+            static char stat[4096];
+            snprintf(stat, sizeof stat, "%s.stat%d", out_path, g);
+            g_stat_path = stat;
+            return g;
+        }
+    }
+    int bad = 0;
+    for (int g = 0; g < G; g++) {
+        int st = 0;
+        if (waitpid(pid[g], &st, 0) < 0 || !WIFEXITED(st) || WEXITSTATUS(st)) bad = 1;
+    }
+    const double wall = now_s() - t0;
+    if (bad) DIE("a worker failed");
+    FILE *out = fopen(out_path, "wb");
+    if (!out) DIE("Failed to open %s for writing", out_path);
+    long frames = 0; double slowest = 0;
+    for (int g = 0; g < G; g++) {
+        char path[4096], buf[65536];
+        snprintf(path, sizeof path, "%s.part%d", out_path, g);
+        FILE *in = fopen(path, "rb");
+        if (!in) DIE("worker %d left no listing", g);
+        size_t n;
+        while ((n = fread(buf, 1, sizeof buf, in)) > 0) fwrite(buf, 1, n, out);
+        fclose(in); remove(path);
+        snprintf(path, sizeof path, "%s.stat%d", out_path, g);
+        in = fopen(path, "r");
+        long f = 0; double sec = 0;
+        if (in) { if (fscanf(in, "%ld %lf", &f, &sec) != 2) f = 0; fclose(in); remove(path); }
+        fprintf(stderr, "  device %d: %ld frames in %.3f s: %.1f frames/s\n", getenv("VP8BATCH_SINGLE_DEVICE") ? 0 : g, f, sec, sec > 0 ? f / sec : 0.0);
+        frames += f; if (sec > slowest) slowest = sec;
+    }
+    fclose(out);
+    fprintf(stderr, "%ld frames on %d GPUs (%s sharded in contiguous blocks): %.1f frames/s, %.1f Mpix/s over the slowest worker's %.3f s (%.3f s wall with start-up)\n",
+            frames, G, unit, slowest > 0 ? frames / slowest : 0.0, slowest > 0 ? frames / slowest * pixels_per_unit_frame / 1e6 : 0.0, slowest, wall);
+    exit(EXIT_SUCCESS);
+}
+
+/* ---- --streams: S streams side by side, entropy decode on the device -------------------------------------------------------- */
+typedef struct input { frame *frames; int nframes; } input;
+static struct {
+    input *in; int nin; int S; long s0;               /* inputs; streams of this worker: global streams s0 .. s0 + S - 1 */
+    int t;                                              /* position being parsed */
+    vp8_parser **parser; vp8_refs *refs; vp8ir_frame_hdr *hdr; int *have_dims;
+    vp8hip_entropy_frame *ent[2]; uint8_t *arena[2]; size_t *off;
+} st;
+static void stream_header_one(void *arg, int s, int worker)
+{
+    (void)arg; (void)worker;
+    const input *in = &st.in[(st.s0 + s) % st.nin];
+    const frame *f = &in->frames[st.t];
+    vp8hip_entropy_frame *e = &st.ent[st.t & 1][s];
+    if (vp8_refs_get_free(&st.refs[s]) < 0) { g_failed = 1; return; }
+    int rc = vp8_parser_begin_frame(st.parser[s], f->data, f->size, &st.hdr[s]);
+    if (!rc && (st.hdr[s].width != g_width || st.hdr[s].height != g_height)) rc = VP8P_UNSUP_BITSTREAM;
+    if (!rc && !st.have_dims[s]) { st.have_dims[s] = 1; vp8_refs_on_alloc(&st.refs[s]); }
+    if (!rc) rc = vp8_parser_export_entropy(st.parser[s], e);
+    if (rc) { fprintf(stderr, "stream %ld frame %d: %s\n", st.s0 + s, st.t + 1, vp8_parser_error(st.parser[s])); g_failed = 1; return; }
+    e->data_off = st.off[s];
+    memcpy(st.arena[st.t & 1] + st.off[s], f->data, f->size);
+}
+static int run_streams(int S_total, int threads, int gpus, int argc, char **argv, int a)
+{
+    const int nin = argc - a - 1;
+    const char *out_path = argv[argc - 1];
+    if (nin < 1 || S_total < 1) DIE("--streams S <in.ivf> [<in2.ivf> ...] <out.md5>");
+    input *in = calloc((size_t)nin, sizeof *in);
+    int T = -1;
+    for (int k = 0; k < nin; k++) {
+        ivf_reader rd; const uint8_t *data; size_t size; int rc, cap = 0;
+        if (ivf_open(&rd, argv[a + k])) DIE("%s is not an IVF file.", argv[a + k]);
+        while ((rc = ivf_next(&rd, &data, &size)) == 1) {
+            if (in[k].nframes == cap) { cap = cap ? 2 * cap : 64; in[k].frames = realloc(in[k].frames, sizeof(frame) * (size_t)cap); }
+            if (in[k].nframes == 0) {
+                int key, w, h;
+                if (vp8_parser_peek(data, size, &key, &w, &h) || !key) DIE("%s does not start with a key frame", argv[a + k]);
+                if (k == 0) { g_width = w; g_height = h; }
+                else if (w != g_width || h != g_height) DIE("%s: all streams must have one frame size", argv[a + k]);
+            }
+            in[k].frames[in[k].nframes].data = malloc(size + 16);
+            memcpy(in[k].frames[in[k].nframes].data, data, size);
+            in[k].frames[in[k].nframes].size = size;
+            in[k].nframes++;
+        }
+        ivf_close(&rd);
+        if (rc < 0 || !in[k].nframes) DIE("failed to read %s", argv[a + k]);
+        if (T < 0 || in[k].nframes < T) T = in[k].nframes;
+    }
+    long lo = 0, hi = S_total;
+    char part[4096] = "";
+    if (gpus > 1) { fork_workers(gpus, S_total, &lo, &hi, out_path, part, sizeof part, "streams", (long)g_width * g_height); out_path = part; }
+    const int S = (int)(hi - lo);
+    if (g_width % 128) DIE("--streams needs the MD5s computed on the device: a width that is a multiple of 128");
+    int device = -1;
+    if (getenv("VP8HIP_DEVICE")) device = atoi(getenv("VP8HIP_DEVICE"));
+    if (vp8hip_create(device, &g_hip)) DIE("vp8hip_create: %s (no CPU fallback)", vp8hip_last_error(NULL));
+    HIP(vp8hip_configure(g_hip, g_width, g_height, 4 * S, S));
+    st.in = in; st.nin = nin; st.S = S; st.s0 = lo;
+    st.parser = calloc((size_t)S, sizeof *st.parser); st.refs = calloc((size_t)S, sizeof *st.refs);
+    st.hdr = calloc((size_t)S, sizeof *st.hdr); st.have_dims = calloc((size_t)S, sizeof(int)); st.off = calloc((size_t)S + 1, sizeof(size_t));
+    size_t arena_cap = 0;
+    for (int t = 0; t < T; t++) {
+        size_t sum = 0;
+        for (int s = 0; s < S; s++) sum += in[(lo + s) % nin].frames[t].size;
+        if (sum > arena_cap) arena_cap = sum;
+    }
+    uint32_t *status[2]; uint8_t *dig[2]; int *list[2];
+    for (int k = 0; k < 2; k++) {
+        st.ent[k] = vp8hip_host_alloc(g_hip, (size_t)S * sizeof(vp8hip_entropy_frame));
+        st.arena[k] = vp8hip_host_alloc(g_hip, arena_cap + 16);
+        status[k] = vp8hip_host_alloc(g_hip, (size_t)S * sizeof(uint32_t));
+        dig[k] = vp8hip_host_alloc(g_hip, (size_t)S * 16);
+        list[k] = malloc(sizeof(int) * (size_t)S);
+        if (!st.ent[k] || !st.arena[k] || !status[k] || !dig[k]) DIE("vp8hip_host_alloc: %s", vp8hip_last_error(g_hip));
+    }
+    for (int s = 0; s < S; s++) {
+        if (!(st.parser[s] = vp8_parser_create())) DIE("out of memory");
+        vp8_parser_set_device_segmap(st.parser[s], 1);
+        vp8_refs_init(&st.refs[s]);
+    }
+    pthread_t *tid = calloc((size_t)threads, sizeof *tid);
+    for (int t = 0; t < threads; t++) pthread_create(&tid[t], NULL, worker_main, (void *)(size_t)t);
+    unsigned char (*digest)[16] = calloc((size_t)S * (size_t)T, 16);     /* [stream][shown frame] */
+    int *nshown = calloc((size_t)S, sizeof(int));
+    vp8hip_job *jobs = calloc((size_t)S, sizeof *jobs);
+    long frames = 0, corrupt = 0;
+    task parse_t;
+    int prev_n = -1, prev_t = -1;                       /* the fetch in flight: shown frames, its position */
+    int *prev_list = NULL;
+#define PLACE(t_) do { size_t o_ = 0; for (int s_ = 0; s_ < S; s_++) { st.off[s_] = o_; o_ += in[(lo + s_) % nin].frames[t_].size; } st.off[S] = o_; } while (0)
+#define TAKE_PREV() do { if (prev_n >= 0) { HIP(vp8hip_download_wait(g_hip));                                             \
+        for (int i_ = 0; i_ < prev_n; i_++) { const int s_ = prev_list[i_] / 4; memcpy(digest[(size_t)s_ * T + nshown[s_]++], dig[prev_t & 1] + 16 * (size_t)i_, 16); } \
+        for (int s_ = 0; s_ < S; s_++) if (status[prev_t & 1][s_] & 1u) { if (corrupt++ < 8) fprintf(stderr, "stream %ld frame %d: a partition ended early (corrupt)\n", lo + s_, prev_t + 1); } \
+        prev_n = -1; } } while (0)
+    const double t0 = now_s();
+    st.t = 0; PLACE(0);
+    size_t bytes = st.off[S];
+    task_start(&parse_t, 0, stream_header_one, NULL, S);
+    for (int t = 0; t < T; t++) {
+        task_wait(&parse_t, 0);
+        if (g_failed) DIE("a frame header of position %d failed to parse", t + 1);
+        HIP(vp8hip_entropy_decode(g_hip, 0, S, st.ent[t & 1], st.arena[t & 1], bytes));
+        /* (status and digests of position t - 1 are taken below, before their page-locked sets come round again at t + 1) */
+        for (int s = 0; s < S; s++) {
+            const vp8_refs *r = &st.refs[s];
+            jobs[s].ir_slot = s; jobs[s].dst_fb = 4 * s + r->new_idx;
+            jobs[s].ref_fb[0] = -1; jobs[s].ref_fb[1] = 4 * s + r->lst_idx; jobs[s].ref_fb[2] = 4 * s + r->gld_idx; jobs[s].ref_fb[3] = 4 * s + r->alt_idx;
+        }
+        HIP(vp8hip_decode(g_hip, jobs, S, VP8HIP_STAGE_ALL));
+        TAKE_PREV();
+        HIP(vp8hip_entropy_status_async(g_hip, S, status[t & 1]));
+        int n = 0;
+        for (int s = 0; s < S; s++) {
+            vp8_refs_swap(&st.refs[s], &st.hdr[s]);
+            if (st.hdr[s].show_frame) list[t & 1][n++] = 4 * s + st.refs[s].show_idx;
+        }
+        frames += S;
+        if (n) HIP(vp8hip_frames_md5_list_async(g_hip, list[t & 1], n, dig[t & 1]));
+        else HIP(vp8hip_sync(g_hip));
+        prev_n = n; prev_t = t; prev_list = list[t & 1];
+        if (t + 1 < T) {                                 /* the next position's headers while the device works on this one */
+            st.t = t + 1; PLACE(t + 1); bytes = st.off[S];
+            task_start(&parse_t, 0, stream_header_one, NULL, S);
+        }
+    }
+    if (prev_n == 0) { prev_n = -1; for (int s_ = 0; s_ < S; s_++) if (status[prev_t & 1][s_] & 1u) corrupt++; }
+    TAKE_PREV();
+    HIP(vp8hip_sync(g_hip));
+    const double dt = now_s() - t0;
+    FILE *out = fopen(out_path, "wb");
+    if (!out) DIE("Failed to open %s for writing", out_path);
+    for (int s = 0; s < S; s++)
+        for (int k = 0; k < nshown[s]; k++) {
+            for (int i = 0; i < 16; i++) fprintf(out, "%02x", digest[(size_t)s * T + k][i]);
+            if (S_total > 1) fprintf(out, "  stream%ld/img-%dx%d-%04d.i420\n", lo + s, g_width, g_height, k + 1);
+            else fprintf(out, "  img-%dx%d-%04d.i420\n", g_width, g_height, k + 1);
+        }
+    fclose(out);
+    fprintf(stderr, "%ld frames in %.3f s: %.1f frames/s, %.1f Mpix/s (%d streams of %d frames side by side, %d feeder threads, entropy decode on the device, MD5 on the device; %ld corrupt)\n",
+            frames, dt, frames / dt, frames / dt * g_width * g_height / 1e6, S, T, threads, corrupt);
+    leave_stats(frames, dt);
+    pthread_mutex_lock(&pool.mu);
+    pool.stop = 1;
+    pthread_cond_broadcast(&pool.work);
+    pthread_mutex_unlock(&pool.mu);
+    for (int t = 0; t < threads; t++) pthread_join(tid[t], NULL);
+    for (int s = 0; s < S; s++) vp8_parser_destroy(st.parser[s]);
+    vp8hip_destroy(g_hip);
+    return EXIT_SUCCESS;
+}
+
 int main(int argc, char **argv)
 {
-    int threads = 0, loop = 1, a = 1, host_md5 = 0, no_download = 0;
+    int threads = 0, loop = 1, a = 1, host_md5 = 0, no_download = 0, streams = 0, gpus = 1;
     g_batch = 128;
     for (; a < argc && argv[a][0] == '-' && argv[a][1] == '-'; a++) {
         if (!strcmp(argv[a], "--threads") && a + 1 < argc) threads = atoi(argv[++a]);
@@ -219,16 +471,22 @@ int main(int argc, char **argv)
         else if (!strcmp(argv[a], "--no-download")) no_download = 1;
         else if (!strcmp(argv[a], "--entropy-batch") && a + 1 < argc) g_ebatch = atoi(argv[++a]);
         else if (!strcmp(argv[a], "--entropy-dense")) ;                 /* (what --entropy-batch does anyway since the slots hold the compact form) */
+        else if (!strcmp(argv[a], "--streams") && a + 1 < argc) streams = atoi(argv[++a]);
+        else if (!strcmp(argv[a], "--gpus") && a + 1 < argc) gpus = atoi(argv[++a]);
         else if (!strcmp(argv[a], "--batch") && a + 1 < argc) g_batch = atoi(argv[++a]);
         else if (!strcmp(argv[a], "--loop") && a + 1 < argc) loop = atoi(argv[++a]);
         else DIE("Usage: %s [--threads T] [--batch B] [--loop N] [--host-md5] [--device-entropy [--entropy-batch E] [--no-download]] <in.ivf> <out.md5>", argv[0]);
     }
-    if (argc - a != 2 || g_batch < 1 || loop < 1)
-        DIE("Usage: %s [--threads T] [--batch B] [--loop N] [--host-md5] [--device-entropy [--entropy-batch E] [--no-download]] <in.ivf> <out.md5>", argv[0]);
     if (threads < 1) {
         long n = sysconf(_SC_NPROCESSORS_ONLN);
         threads = n > 33 ? 32 : (n > 2 ? (int)n - 1 : 1);      /* more than ~32 feeders gain nothing: the host memory system is the limit */
+        if (gpus > 1 && threads > 2 * gpus) threads = threads / gpus > 2 ? threads / gpus : 2;      /* a pool per device */
     }
+    if (gpus < 1) gpus = 1;
+    if (streams > 0) return run_streams(streams, threads, gpus, argc, argv, a);
+    if (argc - a != 2 || g_batch < 1 || loop < 1)
+        DIE("Usage: %s [--threads T] [--batch B] [--loop N] [--host-md5] [--device-entropy [--entropy-batch E] [--no-download]] [--gpus G] <in.ivf> <out.md5>\n"
+            "       %s --streams S [--threads T] [--gpus G] <in.ivf> [<in2.ivf> ...] <out.md5>", argv[0], argv[0]);
 
     /* ---- read the whole stream; every frame must be a key frame of one size */
     ivf_reader in;
@@ -248,7 +506,14 @@ int main(int argc, char **argv)
     }
     ivf_close(&in);
     if (rc < 0 || !g_nframes) DIE("failed to read %s", argv[a]);
-    const long total = (long)g_nframes * loop;
+    long total = (long)g_nframes * loop;
+    const char *out_path = argv[a + 1];
+    char part[4096] = "";
+    if (gpus > 1) {
+        long lo = 0, hi = total;
+        fork_workers(gpus, total, &lo, &hi, out_path, part, sizeof part, "frames", (long)g_width * g_height);
+        g_first = lo; total = hi - lo; out_path = part;
+    }
     if (g_batch > total) g_batch = (int)total;
     if (g_ebatch && (!g_dev_entropy || g_ebatch < g_batch || g_ebatch % g_batch)) DIE("--entropy-batch goes with --device-entropy and is a multiple of --batch");
     if (g_ebatch == g_batch) g_ebatch = 0;
@@ -277,7 +542,7 @@ int main(int argc, char **argv)
             }
             for (long k0 = 0; k0 < total; k0 += unit) {
                 size_t run = 0;
-                for (long k = k0; k < k0 + unit && k < total; k++) run += g_frames[g_order[k] % g_nframes].size;
+                for (long k = k0; k < k0 + unit && k < total; k++) run += FRAME_AT(g_order[k])->size;
                 if (run > g_ent_cap) g_ent_cap = run;
             }
         }
@@ -358,16 +623,17 @@ int main(int argc, char **argv)
         take_digests(&prev);
         TAKE_PENDING();
         const double dt = now_s() - t0;
-        FILE *out = fopen(argv[a + 1], "wb");
-        if (!out) DIE("Failed to open %s for writing", argv[a + 1]);
+        FILE *out = fopen(out_path, "wb");
+        if (!out) DIE("Failed to open %s for writing", out_path);
         for (long f = 0; f < total; f++) {
             for (int i = 0; i < 16; i++) fprintf(out, "%02x", g_digest[f][i]);
-            fprintf(out, "  img-%dx%d-%04ld.i420\n", g_width, g_height, f + 1);
+            fprintf(out, "  img-%dx%d-%04ld.i420\n", g_width, g_height, g_first + f + 1);
         }
         fclose(out);
         fprintf(stderr, "%ld frames in %.3f s: %.1f frames/s, %.1f Mpix/s (%d feeder threads, %d frames per launch, entropy decode on the %s, MD5 on the %s%s; %d frames per entropy launch; %ld corrupt)\n",
                 total, dt, total / dt, total / dt * g_width * g_height / 1e6, threads, g_batch, "device", "device",
                 no_download ? ", frames not downloaded" : "", g_ebatch, g_corrupt);
+        leave_stats(total, dt);
         pthread_mutex_lock(&pool.mu);
         pool.stop = 1;
         pthread_cond_broadcast(&pool.work);
@@ -444,16 +710,17 @@ int main(int argc, char **argv)
     const double dt = now_s() - t0;
 
     /* ---- the listing */
-    FILE *out = fopen(argv[a + 1], "wb");
-    if (!out) DIE("Failed to open %s for writing", argv[a + 1]);
+    FILE *out = fopen(out_path, "wb");
+    if (!out) DIE("Failed to open %s for writing", out_path);
     for (long f = 0; f < total; f++) {
         for (int i = 0; i < 16; i++) fprintf(out, "%02x", g_digest[f][i]);
-        fprintf(out, "  img-%dx%d-%04ld.i420\n", g_width, g_height, f + 1);
+        fprintf(out, "  img-%dx%d-%04ld.i420\n", g_width, g_height, g_first + f + 1);
     }
     fclose(out);
     fprintf(stderr, "%ld frames in %.3f s: %.1f frames/s, %.1f Mpix/s (%d feeder threads, %d frames per launch, entropy decode on the %s, MD5 on the %s%s%s)\n",
             total, dt, total / dt, total / dt * g_width * g_height / 1e6, threads, g_batch, g_dev_entropy ? "device" : "host",
             g_dev_md5 ? "device" : "host", no_download ? ", frames not downloaded" : "", g_corrupt ? "; CORRUPT FRAMES, see above" : "");
+    leave_stats(total, dt);
 
     pthread_mutex_lock(&pool.mu);
     pool.stop = 1;

@@ -80,6 +80,7 @@ struct vp8_parser {
     const uint8_t *tok_start[8]; /* ... where each begins (vp8_parser_export_entropy) */
     const uint8_t *frame_data;   /* the frame, when it came as one buffer */
     int segmap_stale;            /* the last frame's macroblocks were decoded elsewhere (vp8_parser_export_entropy) */
+    int device_segmap;           /* vp8_parser_set_device_segmap: the device keeps this stream's segment map (in the stream's IR slot) */
     int num_tok;
     int frame_open;
 
@@ -528,7 +529,7 @@ int vp8_parser_export_entropy(vp8_parser *p, vp8hip_entropy_frame *out)
     int i, bits, back;
     if (!p->frame_open) return fail(p, VP8P_ERROR, "export_entropy without begin_frame");
     if (!p->frame_data || p->ec_enabled ||
-        (p->hdr.frame_type != 0 && p->segmentation_enabled && !p->update_mb_segmentation_map)) {      /* (the frame stays open) */
+        (!p->device_segmap && p->hdr.frame_type != 0 && p->segmentation_enabled && !p->update_mb_segmentation_map)) {      /* (the frame stays open) */
         snprintf(p->err, sizeof p->err, "%s", "one buffer, no concealment, a segment map of its own: or the device cannot decode it");
         return VP8P_UNSUP_BITSTREAM;
     }
@@ -551,6 +552,11 @@ int vp8_parser_export_entropy(vp8_parser *p, vp8hip_entropy_frame *out)
         out->tok_end[i] = (uint32_t)(p->tok[i].end - p->frame_data);
     }
     out->update_mb_segmentation_map = (uint8_t)(p->update_mb_segmentation_map && p->segmentation_enabled);
+    /* a macroblock's segment id when the frame does not code it, as read_modes has it (decodemv.c:594-606): the id the frame
+       before left -- with the update flag set and segmentation off, and in inter frames --, or 0 (key frames).  Kept ids live in
+       the stream's IR slot, which only a caller that decodes every frame of the stream there may rely on */
+    out->segmap_keep = (uint8_t)(p->device_segmap && !out->update_mb_segmentation_map &&
+                                 (p->update_mb_segmentation_map || p->hdr.frame_type != 0));
     out->mb_no_coeff_skip = (uint8_t)p->mb_no_coeff_skip;
     out->prob_skip_false = p->prob_skip_false;
     memcpy(out->segment_tree_probs, p->segment_tree_probs, 3);
@@ -1169,6 +1175,11 @@ static void *tok_worker_main(void *arg)
 void vp8_parser_set_error_concealment(vp8_parser *p, int on)
 {
     if (p && !p->width) p->ec_enabled = on != 0;      /* before the first frame only: the mode-info arrays are allocated with it */
+}
+
+void vp8_parser_set_device_segmap(vp8_parser *p, int on)
+{
+    if (p) p->device_segmap = on != 0;
 }
 
 void vp8_parser_set_threads(vp8_parser *p, int threads)

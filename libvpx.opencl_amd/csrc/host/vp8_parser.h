@@ -91,6 +91,14 @@ int vp8_parser_decode_mbs_compact(vp8_parser *p, vp8ir_mbx *mbx, int16_t *blocks
  * segment map of a frame decoded this way is refused, by this call and by vp8_parser_decode_mbs. */
 int vp8_parser_export_entropy(vp8_parser *p, vp8hip_entropy_frame *out);
 
+/* The segment map on the device.  A macroblock's segment id persists from frame to frame until a frame codes it anew
+ * (decodemv.c:594-606).  With the entropy decoder on the device the ids of the frame before are where that decoder left them: in
+ * the records of the IR slot the frame was decoded into.  A caller that decodes EVERY frame of a stream on the device, into ONE
+ * slot (many streams side by side: a slot each), says so here; vp8_parser_export_entropy then hands over the frames that keep their
+ * map as well (vp8hip_entropy_frame::segmap_keep: the kernel takes the ids out of the slot before it overwrites them) instead of
+ * refusing them. */
+void vp8_parser_set_device_segmap(vp8_parser *p, int on);
+
 const char *vp8_parser_error(const vp8_parser *p);
 
 /* Reference-buffer index bookkeeping shared by every decoder built on the parser:

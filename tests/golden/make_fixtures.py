@@ -27,6 +27,7 @@ REFDIR = os.path.join(ROOT, "oracle", "_ref")
 VPXENC = os.path.join(REFDIR, "vpxenc_ref")
 REFMD5 = os.path.join(REFDIR, "ref_md5")
 VPXDEC = os.path.join(REFDIR, "vpxdec_ref")
+ROIENC = os.path.join(REFDIR, "roi_enc")        # oracle/roi_enc.c: the reference ENCODER with a region-of-interest map installed
 
 
 def synth_i420(w, h, frames, seed, noise=6, speed=(1.375, 0.625)):
@@ -134,6 +135,10 @@ FIXTURES = {
     "p_seg_176x144": (176, 144, 30, 77, 4, INTER + ["--rt", "--error-resilient=1", "--cpu-used=-6", "--target-bitrate=150"]),
     # low bitrate: high filter levels, many skipped MBs (mb_skip_coeff / skip_lf paths)
     "p_lowrate_640x360": (640, 360, 10, 71, 4, INTER + ["--good", "--cpu-used=3", "--target-bitrate=150"]),
+    # inter frames with segmentation ON that code no map (they keep the one they have: decodemv.c:594-606): the reference
+    # encoder with a region-of-interest map installed before frames 3 and 8 (oracle/roi_enc.c: VP8E_SET_ROI_MAP; this encoder
+    # never gets to code the map or its data with an inter frame, see there).  ("roi": arguments of roi_enc, not vpxenc's)
+    "p_roi_640x360": (640, 360, 12, 91, 5, ["roi", "3", "8"]),
 }
 
 
@@ -272,8 +277,11 @@ def main():
             yuv = os.path.join(td, "in.yuv")
             with open(yuv, "wb") as f:
                 f.write(synth_i420(w, h, frames, seed, noise, speed))
-            base = args if "-p" in args else COMMON + args
-            run([VPXENC, *base, "-w", str(w), "-h", str(h), "-o", ivf, yuv])
+            if args and args[0] == "roi":
+                run([ROIENC, str(w), str(h), yuv, ivf, *args[1:]])
+            else:
+                base = args if "-p" in args else COMMON + args
+                run([VPXENC, *base, "-w", str(w), "-h", str(h), "-o", ivf, yuv])
         run([REFMD5, ivf, md5])
         stream_md5(name)
         nshown = sum(1 for _ in open(md5))

@@ -83,6 +83,58 @@ def test_batch_md5_listing_equals_decode_to_md5(name, args, tmp_path):
         assert label.endswith("-%04d.i420" % (i + 1))
 
 
+@pytest.mark.parametrize("inputs,streams", [(["p_lowrate_640x360"], 3), (["p_prof1_640x360", "p_lowrate_640x360", "kf_640x360"], 7),
+                                            (["p_roi_640x360"], 5), (["p_1920x1080"], 2)])
+def test_batch_md5_streams_side_by_side(inputs, streams, tmp_path):
+    """--streams S: S streams of any frame types decoded side by side -- position t of all of them in one launch, only the frame
+    headers read on the host, the macroblocks' modes, vectors and tokens on the device (inter frames too), a stream's frames through
+    one IR slot (p_roi_640x360: inter frames with segmentation on that keep their segment map, which therefore lives on the
+    device), every shown frame hashed on the device: stream s's listing is the reference decoder's for input s mod inputs."""
+    out = tmp_path / "out.md5"
+    r = subprocess.run([os.path.join(BIN, "batch_md5"), "--streams", str(streams)] + [ivf_path(n) for n in inputs] + [str(out)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "streams of" in r.stderr and "0 corrupt" in r.stderr
+    golds = [[ln.split()[0] for ln in open(os.path.join(GOLDEN, n + ".md5")).read().splitlines()] for n in inputs]
+    T = min(len(g) for g in golds)                # (every frame of these fixtures is shown)
+    got = open(out).read().splitlines()
+    assert len(got) == streams * T
+    for s in range(streams):
+        for k in range(T):
+            digest, label = got[s * T + k].split()
+            assert digest == golds[s % len(inputs)][k], (s, k)
+            assert label.startswith("stream%d/" % s) and label.endswith("-%04d.i420" % (k + 1))
+
+
+@pytest.mark.parametrize("args,name", [(["--loop", "13"], "kf_640x360"),
+                                       (["--device-entropy", "--batch", "16", "--loop", "9"], "kf_1920x1080")])
+def test_batch_md5_workers_per_device(args, name, tmp_path, monkeypatch):
+    """--gpus G: G worker processes over contiguous shares of the looped stream, one device each (here: both on the box's one
+    GPU, VP8BATCH_SINGLE_DEVICE=1), listings merged in frame order: byte for byte the single-process listing."""
+    monkeypatch.setenv("VP8BATCH_SINGLE_DEVICE", "1")
+    one, two = tmp_path / "one.md5", tmp_path / "two.md5"
+    for out, extra in ((one, []), (two, ["--gpus", "2"])):
+        r = subprocess.run([os.path.join(BIN, "batch_md5")] + args + extra + [ivf_path(name), str(out)], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+    assert "on 2 GPUs" in r.stderr
+    assert open(one).read() == open(two).read()
+    gold = open(os.path.join(GOLDEN, name + ".md5")).read().splitlines()
+    got = open(two).read().splitlines()
+    assert [g.split()[0] for g in got] == [gold[i % len(gold)].split()[0] for i in range(len(got))]
+
+
+def test_batch_md5_streams_over_two_workers(tmp_path, monkeypatch):
+    monkeypatch.setenv("VP8BATCH_SINGLE_DEVICE", "1")
+    out = tmp_path / "out.md5"
+    r = subprocess.run([os.path.join(BIN, "batch_md5"), "--streams", "5", "--gpus", "2", ivf_path("p_lowrate_640x360"), str(out)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    gold = [ln.split()[0] for ln in open(os.path.join(GOLDEN, "p_lowrate_640x360.md5")).read().splitlines()]
+    got = open(out).read().splitlines()
+    assert [g.split()[0] for g in got] == gold * 5
+    assert [g.split()[1].split("/")[0] for g in got] == ["stream%d" % (i // len(gold)) for i in range(len(got))]
+
+
 def test_batch_md5_refuses_inter_frames(tmp_path):
     r = subprocess.run([os.path.join(BIN, "batch_md5"), ivf_path("p_lowrate_640x360"), str(tmp_path / "o")],
                        capture_output=True, text=True)

@@ -170,7 +170,7 @@ def test_frames_cut_short(name):
     ctx.close()
 
 
-INTER_STREAMS = ["p_seg_176x144", "p_lowrate_640x360", "p_odd_130x98", "p_sharp_320x240", "p_split_352x288", "p_arf_176x144", "p_prof1_640x360", "p_prof3_640x360",
+INTER_STREAMS = ["p_seg_176x144", "p_roi_640x360", "p_lowrate_640x360", "p_odd_130x98", "p_sharp_320x240", "p_split_352x288", "p_arf_176x144", "p_prof1_640x360", "p_prof3_640x360",
                  "p_1920x1080", "p_dense_1920x1080"]
 
 
@@ -179,11 +179,13 @@ def test_inter_frames(name):
     """Inter frames: reference frame, near / nearest / new / split vectors with their above, left and above-left candidates
     (decodemv.c:323-569), intra macroblocks among them, golden / alt-ref with sign bias, bilinear and full-pixel versions -- a
     whole stream with only the frame headers read on the host: every frame's IR (descriptors, coefficients, sixteen vectors per
-    macroblock) is the host feeder's, and the frames decode to the reference's MD5s."""
+    macroblock) is the host feeder's, and the frames decode to the reference's MD5s.  The stream's frames go through ONE slot, so
+    the segment map a frame keeps is the one the frame before left there (vp8_parser_set_device_segmap; p_roi_640x360)."""
     P = load_package()
     w, h, frames = P.read_ivf(ivf_path(name))
     frames = frames[:24]
     ph, pd = P.Parser(), P.Parser()
+    pd.set_device_segmap(True)
     ctx = P.Vp8Hip()
     ctx.configure(w, h, 4, 1)
     gold = golden_md5(name)
@@ -194,8 +196,7 @@ def test_inter_frames(name):
         ph.swap(hdr)
         h2, _ = pd.begin(data)
         ef = pd.export_entropy()
-        if ef is None:                       # (an inter frame that keeps a segment map: the host feeder's)
-            pytest.skip("stream keeps segment maps across frames")
+        assert ef is not None
         assert not ctx.entropy_decode(0, [ef], [data]).any()
         dm, dc = ctx.ir_fetch(0)
         bad = np.nonzero((dm != mbs).any(axis=1))[0]
