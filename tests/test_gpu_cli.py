@@ -175,3 +175,26 @@ def test_vpxdec_threads_option():
         r = subprocess.run([os.path.join(BIN, "vpxdec"), "-t", t, "--md5", "--i420", ivf_path(name)], capture_output=True, text=True)
         assert r.returncode == 0, r.stderr
         assert r.stdout.split()[0] == open(os.path.join(GOLDEN, name + ".vpxdec_md5")).read().strip(), t
+
+
+def test_written_inter_streams_through_the_tools(tmp_path):
+    """Streams from the suite's own writer (inter frames that code, keep or re-data their segment map; every mode, reference and
+    split shape): decode_to_md5 -- the host decoder behind the vpx codec API -- and batch_md5 --streams -- modes and tokens read
+    on the device, the kept map in the stream's IR slot -- both list the MD5s feeder + oracle give (which tests/test_writer_cpu.py
+    pins to the reference decoder where /root/reference is).  Hidden frames are in there too (show_frame = 0)."""
+    from test_gpu_entropy import oracle_listing
+    from test_writer_cpu import INTER_CASES, inter_sequence
+    from vp8_testlib import load_package
+    from vp8_writer import write_ivf
+    P = load_package()
+    for n, (w, h, seed, plan, lp, big) in enumerate(INTER_CASES):
+        frames, _ = inter_sequence(w, h, seed, plan, lp, big=big)
+        gold = oracle_listing(P, w, h, frames)
+        ivf, out = tmp_path / ("w%d.ivf" % n), tmp_path / ("w%d.md5" % n)
+        write_ivf(ivf, w, h, frames)
+        r = subprocess.run([os.path.join(BIN, "decode_to_md5"), str(ivf), str(out)], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        assert [ln.split()[0] for ln in open(out)] == gold, (n, "decode_to_md5")
+        r = subprocess.run([os.path.join(BIN, "batch_md5"), "--streams", "3", str(ivf), str(out)], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        assert [ln.split()[0] for ln in open(out)] == gold * 3, (n, "batch_md5 --streams")

@@ -183,12 +183,15 @@ def test_inter_frames(name):
     the segment map a frame keeps is the one the frame before left there (vp8_parser_set_device_segmap; p_roi_640x360)."""
     P = load_package()
     w, h, frames = P.read_ivf(ivf_path(name))
-    frames = frames[:24]
+    assert _one_slot_stream(P, w, h, frames[:24], golden_md5(name), name) > 0
+
+
+def _one_slot_stream(P, w, h, frames, gold, name):
+    """-> inter frames seen"""
     ph, pd = P.Parser(), P.Parser()
     pd.set_device_segmap(True)
     ctx = P.Vp8Hip()
     ctx.configure(w, h, 4, 1)
-    gold = golden_md5(name)
     shown = 0
     n_inter = 0
     for i, data in enumerate(frames):
@@ -214,8 +217,39 @@ def test_inter_frames(name):
         if hdr.show_frame:
             assert P.planes_md5(*ctx.download_planes(pd.refs.show_idx)) == gold[shown], (name, i)
             shown += 1
-    assert n_inter > 0
     ph.close(); pd.close(); ctx.close()
+    return n_inter
+
+
+def oracle_listing(P, w, h, frames):
+    """feeder + oracle over a written stream: the MD5 of every shown frame (pinned to the reference decoder by
+    tests/test_writer_cpu.py, where /root/reference is)"""
+    from vp8_testlib import oracle_decode
+    parser = P.Parser()
+    g = P.geom(w, h)
+    bufs = [np.zeros(g.frame_size, np.uint8) for _ in range(4)]
+    out = []
+    for data in frames:
+        hdr, _, mbs, coef, mvs = P.parse_to_numpy(parser, data)
+        r = parser.refs
+        oracle_decode(hdr, mbs, coef, mvs, bufs[r.new_idx], (bufs[r.lst_idx], bufs[r.gld_idx], bufs[r.alt_idx]))
+        parser.swap(hdr)
+        if hdr.show_frame:
+            out.append(P.frame_md5(bufs[parser.refs.show_idx], g, w, h))
+    parser.close()
+    return out
+
+
+def test_written_inter_streams():
+    """Inter frames from the suite's own writer: every mode on every macroblock, three references with either sign bias, split
+    vectors of all four shapes, 1..8 partitions -- and what no encoder here produces: inter frames that code a new segment map,
+    that keep the map under new segment data, that keep both (the map then lives in the stream's IR slot on the device), frames
+    with segmentation off in between."""
+    from test_writer_cpu import INTER_CASES, inter_sequence
+    P = load_package()
+    for w, h, seed, plan, lp, big in INTER_CASES:
+        frames, _ = inter_sequence(w, h, seed, plan, lp, big=big)
+        assert _one_slot_stream(P, w, h, frames, oracle_listing(P, w, h, frames), (w, h, seed)) == len(plan)
 
 
 @pytest.mark.parametrize("name,mode", [("p_lowrate_640x360", "device"), ("p_arf_176x144", "device"), ("p_lowrate_640x360", "host")])

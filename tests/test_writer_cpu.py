@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 
 from vp8_testlib import ROOT, load_package, oracle_decode, synth_ir
-from vp8_writer import write_ivf, write_key_frame
+from vp8_writer import write_inter_frame, write_ivf, write_key_frame
 
 REF_MD5 = os.path.join(ROOT, "oracle", "_ref", "ref_md5")
 
@@ -68,3 +68,117 @@ def test_reference_decodes_written_streams_like_the_oracle(pkg, case, tmp_path):
     oracle_decode(hdr, mbs, coef, mvs, buf, (None, None, None))
     mine = pkg.frame_md5(buf, g, hdr.width, hdr.height)
     assert ref == [mine, mine]
+
+
+# ---- inter frames: every inter mode, all three references with sign biases, split vectors, and the segment map's three lives
+# (coded, kept with new data, kept untouched) -- content the reference ENCODER never produces (it codes no map on inter frames)
+def inter_sequence(w, h, seed, plan, lp=0, dense=0.25, big=False):
+    """A key frame and one inter frame per entry of plan ("keep": segmentation on, nothing coded; "data": new segment data, map
+    kept; "map": new map, data kept; "both"; "off": segmentation off).  Returns the frames and, per frame, the IR the stream was
+    written from as a decoder is to read it back: (hdr, mbs, coef, mvs, segment map known)."""
+    rng = np.random.default_rng(seed)
+    hdr, mbs, coef, mvs = synth_ir(w, h, seed, inter=False, dense=dense, big=big, segmented=True)
+    hdr.num_token_partitions = 1 << lp
+    frames, expect = [write_key_frame(hdr, mbs, coef, log2_parts=lp)], [(hdr, mbs, coef, mvs, True)]
+    segmap, absd = mbs[:, 4].copy(), hdr.mb_segment_abs_delta
+    segq, seglf = list(hdr.segment_quant), list(hdr.segment_lf)
+    known = True
+    for i, step in enumerate(plan):
+        hdr, mbs, coef, mvs = synth_ir(w, h, seed * 100 + i + 1, inter=True, dense=dense, big=big, segmented=step != "off")
+        hdr.num_token_partitions = 1 << lp
+        hdr.refresh_last = int(rng.integers(0, 4) > 0)
+        hdr.refresh_golden, hdr.refresh_alt = int(rng.integers(0, 3) == 0), int(rng.integers(0, 3) == 0)
+        hdr.copy_buffer_to_gf = 0 if hdr.refresh_golden else int(rng.integers(0, 3))
+        hdr.copy_buffer_to_arf = 0 if hdr.refresh_alt else int(rng.integers(0, 3))
+        hdr.sign_bias_golden, hdr.sign_bias_alt = int(rng.integers(0, 2)), int(rng.integers(0, 2))
+        hdr.show_frame = int(rng.integers(0, 5) > 0)
+        um = step in ("map", "both")
+        ud = step in ("data", "both")
+        if step != "off":
+            if not um:
+                mbs[:, 4] = segmap
+            if not ud:
+                hdr.mb_segment_abs_delta = absd
+                for k in range(4):
+                    hdr.segment_quant[k], hdr.segment_lf[k] = segq[k], seglf[k]
+        data, mbs2, mvs2 = write_inter_frame(hdr, mbs, coef, mvs, log2_parts=lp, update_map=um, update_data=ud)
+        if um:
+            segmap, known = mbs[:, 4].copy(), True
+        if ud:
+            absd, segq, seglf = hdr.mb_segment_abs_delta, list(hdr.segment_quant), list(hdr.segment_lf)
+        if step == "off":
+            known = False                               # (what a later frame that keeps "the" map sees is the decoder's business)
+        frames.append(data)
+        expect.append((hdr, mbs2, coef, mvs2, known))
+    return frames, expect
+
+
+INTER_CASES = [  # width, height, seed, plan, log2 partitions, big coefficients
+    (64, 48, 11, ("keep", "data", "keep", "map", "keep", "both", "keep"), 0, False),
+    (176, 144, 12, ("keep", "keep", "data", "off", "both", "keep"), 1, False),
+    (130, 98, 13, ("both", "keep", "map", "data"), 2, True),
+    (33, 200, 14, ("off", "off", "both", "keep"), 0, False),
+    (320, 192, 15, ("keep", "data", "map"), 3, False),
+]
+
+
+def _feed(pkg, frames):
+    """feeder over the frames -> per frame (hdr, mbs, coef, mvs) and the frame-buffer indices before / after"""
+    parser = pkg.Parser()
+    out = []
+    for data in frames:
+        hdr, changed, mbs, coef, mvs = pkg.parse_to_numpy(parser, data)
+        r = parser.refs
+        idx = (r.new_idx, r.lst_idx, r.gld_idx, r.alt_idx)
+        parser.swap(hdr)
+        out.append((hdr, mbs, coef, mvs, idx, parser.refs.show_idx))
+    parser.close()
+    return out
+
+
+@pytest.mark.parametrize("case", INTER_CASES)
+def test_feeder_reads_back_inter_frames(pkg, case):
+    w, h, seed, plan, lp, big = case
+    frames, expect = inter_sequence(w, h, seed, plan, lp, big=big)
+    got = _feed(pkg, frames)
+    for k, ((hdr, mbs, coef, mvs, known), (h2, m2, c2, v2, _, _)) in enumerate(zip(expect, got)):
+        for f in ("frame_type", "show_frame", "filter_type", "filter_level", "sharpness_level", "segmentation_enabled", "base_qindex",
+                  "refresh_last", "refresh_golden", "refresh_alt", "copy_buffer_to_gf", "copy_buffer_to_arf", "sign_bias_golden",
+                  "sign_bias_alt", "num_token_partitions"):
+            if k == 0 and f.startswith(("refresh", "copy", "sign")):
+                continue
+            assert getattr(h2, f) == getattr(hdr, f), (k, f)
+        if hdr.segmentation_enabled:
+            assert h2.mb_segment_abs_delta == hdr.mb_segment_abs_delta, k
+            assert list(h2.segment_quant) == list(hdr.segment_quant) and list(h2.segment_lf) == list(hdr.segment_lf), k
+            if known:
+                assert np.array_equal(m2[:, 4], mbs[:, 4]), k
+        assert np.array_equal(m2[:, 0], mbs[:, 0]) and np.array_equal(m2[:, 2], mbs[:, 2]), k
+        intra = mbs[:, 2] == 0
+        assert np.array_equal(m2[intra, 1], mbs[intra, 1]), k
+        assert np.array_equal(m2[:, 3] & 3, mbs[:, 3] & 3), k
+        split = mbs[:, 0] == 9
+        assert np.array_equal(m2[split, 5], mbs[split, 5]), k
+        assert np.array_equal(v2, mvs), k
+        live = (mbs[:, 3] & 1) == 0
+        assert np.array_equal(m2[live, 8:33], mbs[live, 8:33]) and np.array_equal(c2[live], coef[live]), k
+
+
+@pytest.mark.skipif(not os.path.exists(REF_MD5), reason="oracle/_ref not built (needs /root/reference)")
+@pytest.mark.parametrize("case", INTER_CASES)
+def test_reference_decodes_written_inter_streams_like_the_oracle(pkg, case, tmp_path):
+    w, h, seed, plan, lp, big = case
+    frames, _ = inter_sequence(w, h, seed, plan, lp, big=big)
+    ivf, out = tmp_path / "s.ivf", tmp_path / "s.md5"
+    write_ivf(ivf, w, h, frames)
+    r = subprocess.run([REF_MD5, str(ivf), str(out)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    ref = [l.split()[0] for l in open(out)]
+    g = pkg.geom(w, h)
+    bufs = [np.zeros(g.frame_size, np.uint8) for _ in range(4)]
+    mine = []
+    for hdr, mbs, coef, mvs, (new, lst, gld, alt), show in _feed(pkg, frames):
+        oracle_decode(hdr, mbs, coef, mvs, bufs[new], (bufs[lst], bufs[gld], bufs[alt]))
+        if hdr.show_frame:
+            mine.append(pkg.frame_md5(bufs[show], g, w, h))
+    assert mine == ref
