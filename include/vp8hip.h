@@ -208,11 +208,12 @@ int  vp8hip_download_wait(vp8hip_ctx *ctx);
 /* The same with the frames' MD5s computed on the device: what `vpxdec --md5` (vpxdec.c:1080-1101) and examples/decode_to_md5
  * (decode_to_md5.txt) hash on the host -- the visible rows of the Y, U and V planes, vpx_image_t d_w x d_h -- one 16-byte digest
  * per frame into digests[16 * i], a frame per lane (csrc/hip/vp8_md5.hip).  dst and digests may each be NULL (not both); both
- * have landed when vp8hip_download_wait returns.  Display widths that are not a multiple of 128 are refused with -3 (rows have
- * to be whole MD5 blocks): the caller hashes those frames on the host. */
+ * have landed when vp8hip_download_wait returns.  Any display size: where a row is whole MD5 blocks (width a multiple of 128) the
+ * kernel reads block by block, from whichever form the frames are in; other widths are hashed from the raster form by a kernel
+ * whose blocks straddle rows (correct, slower: the conformance streams' odd sizes, not the throughput path). */
 int  vp8hip_frames_fetch_async(vp8hip_ctx *ctx, int first_fb, int count, uint8_t *dst, uint8_t *digests);
 /* The digests alone, of ANY n frame buffers (fbs[i]; not necessarily neighbours: the shown frames of many streams decoded side by
- * side, bin/batch_md5 --streams): digests[16 * i].  Same stream, same wait and same width rule as vp8hip_frames_fetch_async. */
+ * side, bin/batch_md5 --streams): digests[16 * i].  Same stream and same wait as vp8hip_frames_fetch_async. */
 int  vp8hip_frames_md5_list_async(vp8hip_ctx *ctx, const int *fbs, int n, uint8_t *digests);
 /* A frame buffer has two forms on the device: the RASTER form (vp8ir_geom: the reference's YV12 layout, borders included), which
  * the small-launch kernels write and everything that reads pixels by coordinate reads (inter prediction, vp8hip_frame_download,

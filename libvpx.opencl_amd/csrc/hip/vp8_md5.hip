@@ -10,10 +10,12 @@
 // block); the frames of a batch run side by side in the lanes of a few waves.  All frames of a context have one geometry, so the
 // walk over planes, rows and blocks is wave-uniform (scalar); only the frame's base address is per lane.  The blocks are
 // requested AHEAD blocks before they are hashed (each lane reads its own 64 bytes: nothing coalesces, only latency matters).
-// Rows must be whole blocks: display width a multiple of 128 (vp8hip_frames_fetch_async refuses other sizes; the caller hashes
-// those on the host).  Two readers: the raster form of a frame buffer (vp8_md5_kernel), and the TILED form a large launch leaves
-// (vp8_md5_tiles_kernel: macroblock-window tiles, vp8_keyframe_simt.hip) -- the hash is the consumer that proves a frame, and it
-// takes the frame as the decoder left it, without a tiled -> raster pass in between.  Integer only.
+// Where rows are whole blocks -- display width a multiple of 128 -- there are two readers: the raster form of a frame buffer
+// (vp8_md5_kernel), and the TILED form a large launch leaves (vp8_md5_tiles_kernel: macroblock-window tiles,
+// vp8_keyframe_simt.hip) -- the hash is the consumer that proves a frame, and it takes the frame as the decoder left it, without
+// a tiled -> raster pass in between.  Any other width: vp8_md5_any_kernel, the same chain over a message whose blocks straddle
+// rows (raster form; word by word, byte by byte across a row's end) -- the odd sizes of the conformance streams, not the
+// throughput path.  Integer only.
 #include "vp8_common.hip.h"
 
 namespace {
@@ -157,6 +159,64 @@ __device__ __forceinline__ void md5_frames(const uint8_t *__restrict__ frames, s
     if (live) *(GLOBAL_AS u32x4 *)(out + 16 * (size_t)f) = (u32x4){ A, B, C, D };
 }
 
+// Any display size, raster form: the message is the visible rows of Y, U ((w + 1) / 2 x (h + 1) / 2), V back to back, so a
+// 64-byte block starts anywhere in a row and may run over its end.  The walk stays wave-uniform (one geometry): a word that lies
+// within a row is one load at whatever alignment, the others are put together from bytes; behind the last byte come 0x80, zeros
+// and, in the last block, the length (RFC 1321 3.1-3.2).
+__device__ __forceinline__ void md5_frames_any(const uint8_t *__restrict__ frames, size_t fstride, const int *__restrict__ index, int first,
+                                               int count, DevGeom g, int w, int h, uint8_t *__restrict__ out)
+{
+    const int f = blockIdx.x * 64 + threadIdx.x;
+    const bool live = f < count;
+    const int fbi = index ? index[live ? f : 0] : first + (live ? f : 0);
+    g_cu8p base = (g_cu8p)(frames + fstride * (size_t)fbi);
+    u32 A = 0x67452301u, B = 0xefcdab89u, C = 0x98badcfeu, D = 0x10325476u;
+    const int cw = (w + 1) >> 1, ch = (h + 1) >> 1;
+    const long nbytes = (long)w * h + 2L * cw * ch;
+    const long nblk = (nbytes + 9 + 63) >> 6;
+    long left = nbytes;                                   // bytes of the message still to come; -1 once the 0x80 is out
+    int pl = 0, row = 0, col = 0, roww = w;
+    g_cu8p rp = base + g.y_off;
+    auto next_row = [&]() {
+        col = 0;
+        if (++row == (pl == 0 ? h : ch)) { row = 0; pl++; roww = cw; }
+        rp = base + (pl == 0 ? g.y_off + (long)row * g.y_stride : (pl == 1 ? g.u_off : g.v_off) + (long)row * g.uv_stride);
+    };
+    auto word = [&]() -> u32 {
+        u32 v = 0;
+        if (left >= 4 && col + 4 <= roww) {
+            __builtin_memcpy(&v, (const void *)(rp + col), 4);
+            col += 4; left -= 4;
+            if (col == roww && left > 0) next_row();
+            return v;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            u32 b = 0;
+            if (left > 0) {
+                b = rp[col];
+                left--;
+                if (++col == roww && left > 0) next_row();
+            } else if (left == 0) {
+                b = 0x80u; left = -1;
+            }
+            v |= b << (8 * k);
+        }
+        return v;
+    };
+    for (long blk = 0; blk < nblk; blk++) {
+        u32 m[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) m[j] = word();
+        if (blk == nblk - 1) {
+            const unsigned long long bits = (unsigned long long)nbytes * 8ull;
+            m[14] = (u32)bits; m[15] = (u32)(bits >> 32);
+        }
+        md5_block(A, B, C, D, m);
+    }
+    if (live) *(GLOBAL_AS u32x4 *)(out + 16 * (size_t)f) = (u32x4){ A, B, C, D };
+}
+
 } // namespace
 
 extern "C" __global__ void __launch_bounds__(64)
@@ -170,4 +230,10 @@ vp8_md5_tiles_kernel(const uint8_t *__restrict__ tiles, size_t tstride, const in
                      uint8_t *__restrict__ out)
 {
     md5_frames<true>(tiles, tstride, index, first, count, g, w, h, out);
+}
+extern "C" __global__ void __launch_bounds__(64)
+vp8_md5_any_kernel(const uint8_t *__restrict__ frames, size_t fstride, const int *__restrict__ index, int first, int count, DevGeom g, int w, int h,
+                   uint8_t *__restrict__ out)
+{
+    md5_frames_any(frames, fstride, index, first, count, g, w, h, out);
 }

@@ -15,6 +15,8 @@ extern "C" __global__ void vp8_recon_intra_xcu_kernel(const DevJob *jobs, int nj
 extern "C" __global__ void vp8_loopfilter_kernel(const DevJob *jobs, int njobs, DevGeom g);
 extern "C" __global__ void vp8_md5_kernel(const uint8_t *frames, size_t fstride, const int *index, int first, int count, DevGeom g, int w, int h,
                                           uint8_t *out);
+extern "C" __global__ void vp8_md5_any_kernel(const uint8_t *frames, size_t fstride, const int *index, int first, int count, DevGeom g, int w, int h,
+                                              uint8_t *out);
 extern "C" __global__ void vp8_md5_tiles_kernel(const uint8_t *tiles, size_t tstride, const int *index, int first, int count, DevGeom g, int w,
                                                 int h, uint8_t *out);
 extern "C" __global__ void vp8_detile_run_kernel(const uint8_t *tiles, size_t tstride, uint8_t *dst, size_t dstride, int count, DevGeom g);
@@ -484,8 +486,6 @@ extern "C" int vp8hip_frames_fetch_async(vp8hip_ctx *c, int first_fb, int count,
 {
     if (!c || first_fb < 0 || count < 1 || first_fb + count > (int)c->fb.size() || (!dst && !digests))
         return fail(c, -2, "vp8hip_frames_fetch_async: bad arguments");
-    if (digests && (c->width & 127))
-        return fail(c, -3, "vp8hip_frames_fetch_async: digests on the device need a display width that is a multiple of 128 (%d)", c->width);
     HIPCHK(c, hipSetDevice(c->device));
     // Frames that only exist as tiles (a large launch wrote them, nothing has asked for their raster form) are read as tiles: the
     // MD5 kernel walks the tiles, and -- direct downloads switched on (vp8hip_set_direct_download) -- the frames leave through a
@@ -494,7 +494,8 @@ extern "C" int vp8hip_frames_fetch_async(vp8hip_ctx *c, int first_fb, int count,
     // 25-33).  The default is the plain way -- raster form in HBM first (vp8hip_need_raster), then the copy engines -- because a
     // pass that waits on PCIe occupies wave slots beside whatever else runs: with the entropy decoder on the device the pipeline
     // of bin/batch_md5 does 9.6 k 1080p frames/s the plain way and 6.5-8.5 k with direct downloads (gpurun_out/r4e).
-    bool tiled = c->tile_block != nullptr;
+    const bool whole_blocks = (c->width & 127) == 0;        // a row is whole MD5 blocks (vp8_md5.hip); other widths: raster form, vp8_md5_any_kernel
+    bool tiled = c->tile_block != nullptr && (whole_blocks || !digests);
     for (int i = 0; i < count && tiled; i++) tiled = c->fb_state[(size_t)(first_fb + i)] == FB_TILES;
     if (tiled && dst && !c->knobs.direct_download) tiled = false;
     if (tiled && dst) {
@@ -541,8 +542,8 @@ extern "C" int vp8hip_frames_fetch_async(vp8hip_ctx *c, int first_fb, int count,
             hipLaunchKernelGGL(vp8_md5_tiles_kernel, dim3((unsigned)((count + 63) / 64)), dim3(64), 0, c->stream_d2h,
                                (const uint8_t *)c->tile_block, c->tile_frame, (const int *)nullptr, first_fb, count, c->dg, c->width, c->height, c->d_md5);
         else
-            hipLaunchKernelGGL(vp8_md5_kernel, dim3((unsigned)((count + 63) / 64)), dim3(64), 0, c->stream_d2h, (const uint8_t *)c->fb_block,
-                               c->fb_stride, (const int *)nullptr, first_fb, count, c->dg, c->width, c->height, c->d_md5);
+            hipLaunchKernelGGL(whole_blocks ? vp8_md5_kernel : vp8_md5_any_kernel, dim3((unsigned)((count + 63) / 64)), dim3(64), 0, c->stream_d2h,
+                               (const uint8_t *)c->fb_block, c->fb_stride, (const int *)nullptr, first_fb, count, c->dg, c->width, c->height, c->d_md5);
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipMemcpyAsync(digests, c->d_md5, 16 * (size_t)count, hipMemcpyDeviceToHost, c->stream_d2h));
     }
@@ -570,12 +571,11 @@ extern "C" int vp8hip_frames_to_raster(vp8hip_ctx *c, int first_fb, int count)
 extern "C" int vp8hip_frames_md5_list_async(vp8hip_ctx *c, const int *fbs, int n, uint8_t *digests)
 {
     if (!c || !fbs || n < 1 || !digests) return fail(c, -2, "vp8hip_frames_md5_list_async: bad arguments");
-    if (c->width & 127)
-        return fail(c, -3, "vp8hip_frames_md5_list_async: digests on the device need a display width that is a multiple of 128 (%d)", c->width);
     for (int i = 0; i < n; i++)
         if (fbs[i] < 0 || fbs[i] >= (int)c->fb.size()) return fail(c, -2, "vp8hip_frames_md5_list_async: frame buffer %d out of range", fbs[i]);
     HIPCHK(c, hipSetDevice(c->device));
-    bool tiled = c->tile_block != nullptr;
+    const bool whole_blocks = (c->width & 127) == 0;
+    bool tiled = c->tile_block != nullptr && whole_blocks;
     for (int i = 0; i < n && tiled; i++) tiled = (c->fb_state[(size_t)fbs[i]] & FB_TILES) != 0;
     if (!tiled && vp8hip_need_raster_list(c, fbs, n)) return -1;
     if (!c->stream_d2h) {
@@ -612,8 +612,8 @@ extern "C" int vp8hip_frames_md5_list_async(vp8hip_ctx *c, const int *fbs, int n
         hipLaunchKernelGGL(vp8_md5_tiles_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, c->stream_d2h, (const uint8_t *)c->tile_block,
                            c->tile_frame, (const int *)c->d_md5_idx, 0, n, c->dg, c->width, c->height, c->d_md5);
     else
-        hipLaunchKernelGGL(vp8_md5_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, c->stream_d2h, (const uint8_t *)c->fb_block,
-                           c->fb_stride, (const int *)c->d_md5_idx, 0, n, c->dg, c->width, c->height, c->d_md5);
+        hipLaunchKernelGGL(whole_blocks ? vp8_md5_kernel : vp8_md5_any_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, c->stream_d2h,
+                           (const uint8_t *)c->fb_block, c->fb_stride, (const int *)c->d_md5_idx, 0, n, c->dg, c->width, c->height, c->d_md5);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(digests, c->d_md5, 16 * (size_t)n, hipMemcpyDeviceToHost, c->stream_d2h));
     HIPCHK(c, hipEventRecord(c->ev_d2h_done, c->stream_d2h));

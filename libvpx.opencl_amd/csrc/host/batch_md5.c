@@ -361,7 +361,6 @@ static int run_streams(int S_total, int threads, int gpus, int argc, char **argv
     char part[4096] = "";
     if (gpus > 1) { fork_workers(gpus, S_total, &lo, &hi, out_path, part, sizeof part, "streams", (long)g_width * g_height); out_path = part; }
     const int S = (int)(hi - lo);
-    if (g_width % 128) DIE("--streams needs the MD5s computed on the device: a width that is a multiple of 128");
     int device = -1;
     if (getenv("VP8HIP_DEVICE")) device = atoi(getenv("VP8HIP_DEVICE"));
     if (vp8hip_create(device, &g_hip)) DIE("vp8hip_create: %s (no CPU fallback)", vp8hip_last_error(NULL));
@@ -523,9 +522,9 @@ int main(int argc, char **argv)
     int device = -1;
     if (getenv("VP8HIP_DEVICE")) device = atoi(getenv("VP8HIP_DEVICE"));
     if (vp8hip_create(device, &g_hip)) DIE("vp8hip_create: %s (no CPU fallback)", vp8hip_last_error(NULL));
-    g_dev_md5 = !host_md5 && g_width % 128 == 0;
-    if (g_ebatch && !g_dev_md5) DIE("--entropy-batch needs the MD5s computed on the device (a width that is a multiple of 128, no --host-md5)");
-    if (no_download && !g_dev_md5) DIE("--no-download needs the MD5s computed on the device (a width that is a multiple of 128, no --host-md5)");
+    g_dev_md5 = !host_md5;
+    if (g_ebatch && !g_dev_md5) DIE("--entropy-batch needs the MD5s computed on the device (no --host-md5)");
+    if (no_download && !g_dev_md5) DIE("--no-download needs the MD5s computed on the device (no --host-md5)");
     /* slots and frame buffers: three sets for the host feeder (parsed / on the GPU / coming back); with the entropy decoder on
        the device the IR is written and read on one stream, one set does, and the frame buffers alternate between two */
     const int slot_sets = g_dev_entropy ? 1 : 3, fb_sets = g_dev_entropy ? 2 : 3;

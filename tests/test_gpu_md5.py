@@ -64,12 +64,35 @@ def test_frames_and_digests_in_one_call(pkg):
         ctx.close()
 
 
-def test_widths_that_are_not_whole_md5_blocks_are_refused(pkg):
+@pytest.mark.parametrize("name", ["kf_odd_67x45", "kf_q0_176x144"])
+def test_widths_that_are_not_whole_md5_blocks(pkg, name):
+    """Any display size: rows that are not whole MD5 blocks (odd widths, odd heights -- chroma planes of (w + 1) / 2 x (h + 1) / 2 --,
+    messages that end anywhere in a block, 56..63 bytes into it included) are hashed by vp8_md5_any_kernel."""
     P = pkg
     ctx = P.Vp8Hip(0)
     try:
-        _decode_all(P, ctx, "kf_odd_67x45")
-        with pytest.raises(RuntimeError, match="multiple of 128"):
-            ctx.frames_md5(0, 1)
+        n = _decode_all(P, ctx, name)
+        assert ctx.frames_md5(0, n) == golden_md5(name)[:n]
+    finally:
+        ctx.close()
+
+
+@pytest.mark.parametrize("w,h", [(1, 1), (2, 2), (7, 9), (10, 5), (11, 5), (16, 16), (55, 1), (56, 1), (63, 3), (64, 2), (66, 2), (120, 3), (129, 2)])
+def test_message_tails(pkg, w, h):
+    """The padding cases of RFC 1321 3.1 by size: w * h + 2 * ((w + 1) / 2) * ((h + 1) / 2) bytes leave 0..63 in the last block --
+    55 (the 0x80 and the length just fit), 56 (they do not: one more block), 0 (a block of padding alone)."""
+    import hashlib
+    P = pkg
+    ctx = P.Vp8Hip(0)
+    try:
+        ctx.configure(w, h, 2, 1)
+        g = ctx.g
+        rng = np.random.default_rng(w * 1000 + h)
+        want = []
+        for fb in range(2):
+            buf = rng.integers(0, 256, size=g.frame_size).astype(np.uint8)
+            ctx.upload_frame(fb, buf)
+            want.append(P.frame_md5(buf, g, w, h))
+        assert ctx.frames_md5(0, 2) == want
     finally:
         ctx.close()
