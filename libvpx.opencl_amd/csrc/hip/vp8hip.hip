@@ -237,12 +237,10 @@ static int configure_pools(vp8hip_ctx *c, int width, int height, int num_fb, int
     if (c->knobs.lf_nw >= 2 && c->knobs.lf_nw <= 16) lnw = c->knobs.lf_nw;
     c->lf_nw = lnw; c->lf_lds = lf_lds_bytes(lnw);
 
-    // frame buffers: one block, each buffer 256-B aligned
+    // frame buffers: one block, each buffer 256-B aligned -- allocated with the first use of a raster form (vp8hip_raster_pool);
+    // the tiled forms come with the first large launch (vp8hip_launch.hip)
     const size_t fbsz = align_up((size_t)g.frame_size, 256);
-    HIPCHK(c, hipMalloc((void **)&c->fb_block, fbsz * num_fb));
-    HIPCHK(c, hipMemsetAsync(c->fb_block, 0, fbsz * num_fb, c->stream));
-    for (int i = 0; i < num_fb; i++) c->fb.push_back(c->fb_block + fbsz * i);
-    // (the tiled forms come with the first large launch: vp8hip_launch.hip)
+    c->fb.assign((size_t)num_fb, (uint8_t *)nullptr);
     c->fb_state.assign((size_t)num_fb, (uint8_t)FB_RASTER);
     c->tile_frame = align_up((size_t)c->dg.mb_rows * (c->dg.mb_cols + 1) * (VP8_TILE_BYTES + 32), 256);
     c->fb_stride = fbsz;
@@ -268,6 +266,21 @@ static int configure_pools(vp8hip_ctx *c, int width, int height, int num_fb, int
         memset(&s.hdr_copy, 0, sizeof s.hdr_copy);
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int vp8hip_raster_pool(vp8hip_ctx *c)
+{
+    if (c->fb_block || c->fb.empty()) return 0;
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t n = c->fb.size();
+    if (hipMalloc((void **)&c->fb_block, c->fb_stride * n) != hipSuccess) {
+        (void)hipGetLastError();
+        c->fb_block = nullptr;
+        return fail(c, -1, "no device memory for the raster form of %zu frame buffers (%zu MB)", n, c->fb_stride * n >> 20);
+    }
+    HIPCHK(c, hipMemsetAsync(c->fb_block, 0, c->fb_stride * n, c->stream));
+    for (size_t i = 0; i < n; i++) c->fb[i] = c->fb_block + c->fb_stride * i;
     return 0;
 }
 
@@ -423,7 +436,7 @@ extern "C" int vp8hip_frame_download(vp8hip_ctx *c, int fb, int full, uint8_t *y
 {
     if (!c || fb < 0 || fb >= (int)c->fb.size() || !y) return fail(c, -2, "vp8hip_frame_download: bad arguments");
     HIPCHK(c, hipSetDevice(c->device));
-    if (vp8hip_need_raster(c, fb, 1)) return -1;
+    if (vp8hip_raster_pool(c) || vp8hip_need_raster(c, fb, 1)) return -1;
     const vp8ir_geom &g = c->geom;
     if (full) {
         HIPCHK(c, hipMemcpyAsync(y, c->fb[fb], (size_t)g.frame_size, hipMemcpyDeviceToHost, c->stream));
@@ -503,7 +516,7 @@ extern "C" int vp8hip_frames_fetch_async(vp8hip_ctx *c, int first_fb, int count,
         if (hipPointerGetAttributes(&at, dst) != hipSuccess) { (void)hipGetLastError(); tiled = false; }
         else tiled = at.type == hipMemoryTypeHost;
     }
-    if (!tiled && vp8hip_need_raster(c, first_fb, count)) return -1;
+    if (!tiled && (vp8hip_raster_pool(c) || vp8hip_need_raster(c, first_fb, count))) return -1;
     if (!c->stream_d2h) {
         // (a stream of another priority class than the context's: the runtime then gives it a hardware queue of its own, and what
         // it carries -- a pass that waits on PCIe for a third of a second per 4096 frames -- runs BESIDE the main stream's kernels)
@@ -577,7 +590,7 @@ extern "C" int vp8hip_frames_md5_list_async(vp8hip_ctx *c, const int *fbs, int n
     const bool whole_blocks = (c->width & 127) == 0;
     bool tiled = c->tile_block != nullptr && whole_blocks;
     for (int i = 0; i < n && tiled; i++) tiled = (c->fb_state[(size_t)fbs[i]] & FB_TILES) != 0;
-    if (!tiled && vp8hip_need_raster_list(c, fbs, n)) return -1;
+    if (!tiled && (vp8hip_raster_pool(c) || vp8hip_need_raster_list(c, fbs, n))) return -1;
     if (!c->stream_d2h) {
         int prio_least = 0, prio_greatest = 0;
         HIPCHK(c, hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
@@ -657,6 +670,7 @@ extern "C" int vp8hip_frame_upload(vp8hip_ctx *c, int fb, const uint8_t *buf)
 {
     if (!c || fb < 0 || fb >= (int)c->fb.size() || !buf) return fail(c, -2, "vp8hip_frame_upload: bad arguments");
     HIPCHK(c, hipSetDevice(c->device));
+    if (vp8hip_raster_pool(c)) return -1;
     HIPCHK(c, hipMemcpyAsync(c->fb[fb], buf, (size_t)c->geom.frame_size, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->fb_state[(size_t)fb] = FB_RASTER;
@@ -671,7 +685,10 @@ extern "C" int vp8hip_frame_copy(vp8hip_ctx *c, int dst, int src)
     if (dst == src) return 0;
     // in whatever form(s) the source holds the frame
     const uint8_t st = c->fb_state[(size_t)src];
-    if (st & FB_RASTER) HIPCHK(c, hipMemcpyAsync(c->fb[dst], c->fb[src], (size_t)c->geom.frame_size, hipMemcpyDeviceToDevice, c->stream));
+    if ((st & FB_RASTER) && !c->fb_block) {                 // (never written: the raster form is zeros, and so will the copy's be)
+        if (!(st & FB_TILES) && vp8hip_raster_pool(c)) return -1;
+    }
+    if ((st & FB_RASTER) && c->fb_block) HIPCHK(c, hipMemcpyAsync(c->fb[dst], c->fb[src], (size_t)c->geom.frame_size, hipMemcpyDeviceToDevice, c->stream));
     if (st & FB_TILES) HIPCHK(c, hipMemcpyAsync(c->fb_tiles[(size_t)dst], c->fb_tiles[(size_t)src], c->tile_frame, hipMemcpyDeviceToDevice, c->stream));
     c->fb_state[(size_t)dst] = st;
     return 0;

@@ -109,6 +109,7 @@ struct vp8hip_ctx {
     // launch runs on (its own: beside the pixel path of other slots) and the events that order it against the main stream
     char *d_ent_frames, *d_ent_data; unsigned int *d_ent_scratch, *d_ent_status; size_t ent_frames_cap, ent_data_cap, ent_scratch_cap;
     bool ent_tables_loaded, ent_parts_off; int ent_lpw;
+    int ent_resident[3];           // waves of vp8_entropy_kernel the device holds at once with 64 / 32 / 16 lanes carrying a frame (LDS)
     unsigned int *d_sched;         // vp8_keyframe_kernel's role / work counters
 };
 
@@ -126,6 +127,10 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 #define FB_TILES  2u            // ... the tiled form does
 // vp8hip_launch.hip: make sure the raster form of frame buffers first .. first + count - 1 holds their frames (a tiled -> raster
 // pass + border extension on the context's stream for those that are only there as tiles)
+// The raster pool itself is allocated when something first needs it (vp8hip_raster_pool; c->fb[i] are null until then): a
+// pipeline whose frames are written as tiles, hashed as tiles and never read by coordinate never pays for it -- at 1080p 3.2 MB
+// per frame buffer, a quarter of what a frame in flight costs.
+int vp8hip_raster_pool(vp8hip_ctx *c);
 int vp8hip_need_raster(vp8hip_ctx *c, int first, int count);
 int vp8hip_need_raster_list(vp8hip_ctx *c, const int *fbs, int n);
 // vp8hip.hip

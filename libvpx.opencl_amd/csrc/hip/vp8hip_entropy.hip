@@ -78,12 +78,27 @@ extern "C" int vp8hip_entropy_decode(vp8hip_ctx *c, int first_slot, int count, c
         s.hdr_copy = frames[i].hdr;
         s.nblocks = NBLOCKS_UNKNOWN;           // (the host never sees how many blocks the device wrote)
     }
-    // Lanes per wave.  The lanes of a wave go through the macroblocks together, each macroblock taking as long as the slowest
-    // lane's, so fewer frames to a wave waste less -- while there are CUs without a wave; several waves to a CU slow each other
-    // down again (8192 1080p frames per launch, frames per second over a run: 64 lanes 15.4 k, 32: 16.9-17.9 k, 16: 16.1 k, 8: 12.7 k;
-    // 4096 per launch with every frame downloaded: the same 9 k at 16 and 64)
+    // Lanes per wave.  A launch lasts as long as its largest frame IF all its waves are on the device at once, and what bounds
+    // that is LDS -- 1.4 KB a lane (the frame's coefficient probabilities: 1152 bytes), so a CU holds one wave of 64 lanes, three
+    // of 32, seven of 16: 16,384 / 24,576 / 28,672 frames on the 256 CUs; a launch with more waves than fit runs in rounds, each
+    // as long as ITS largest frame (24,576 1080p frames: 1.14 s with 32 lanes a wave, 1.97 s with 64; 640x360: the same steps,
+    // tools/entropy_scale.sh).  Where they fit, more lanes to a wave are a little faster (8192 frames: 1.05 s at 64, 1.13 at 32,
+    // 1.45 at 16).  So: the most lanes per wave with which the launch is one round.
     int lpw = c->ent_lpw;
-    if (!lpw) lpw = (count + 31) / 32 <= c->num_cu ? 32 : 64;
+    if (!lpw) {
+        if (!c->ent_resident[0])
+            for (int k = 0; k < 3; k++) {
+                int nb = 0;
+                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, vp8_entropy_kernel, 64, vp8_entropy_lds_bytes(64 >> k)) != hipSuccess || nb < 1) {
+                    (void)hipGetLastError();
+                    nb = 1;
+                }
+                c->ent_resident[k] = nb * c->num_cu;
+            }
+        lpw = 64;
+        for (int k = 0; k < 3; k++)
+            if ((count + (64 >> k) - 1) / (64 >> k) <= c->ent_resident[k]) { lpw = 64 >> k; break; }
+    }
     if (np > 1)
         hipLaunchKernelGGL(vp8_entropy_parts_kernel, dim3((unsigned)((count + 64 / np - 1) / (64 / np))), dim3(64), 0, c->stream,
                            (const vp8hip_entropy_frame *)c->d_ent_frames, count, np, (const uint8_t *)c->d_ent_data, c->dg, data_bytes,

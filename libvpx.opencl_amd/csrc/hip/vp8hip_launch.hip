@@ -47,6 +47,7 @@ int vp8hip_need_raster_list(vp8hip_ctx *c, const int *fbs, int n)
     int m = 0;
     for (int i = 0; i < n; i++) m += c->fb_state[(size_t)fbs[i]] == FB_TILES;
     if (!m) return 0;
+    if (vp8hip_raster_pool(c)) return -1;
     if (m > c->conv_cap) {
         HIPCHK(c, hipStreamSynchronize(c->stream));
         if (c->d_conv_jobs) (void)hipFree(c->d_conv_jobs);
@@ -99,6 +100,9 @@ static Regime launch_regime(const vp8hip_ctx *c, int njobs, int stages, bool all
 {
     const bool both = (stages & VP8HIP_STAGE_RECON) && (stages & VP8HIP_STAGE_LF);
     bool lane = both && njobs > 2 * c->num_cu;
+    // a context whose frames have only ever been tiles (the raster pool was never needed: vp8hip_raster_pool) stays with the
+    // kernels that write tiles for the odd small launch of key frames -- the tail of a run -- rather than allocate the pool for it
+    if (both && all_key && c->tile_block && !c->fb_block) lane = true;
     if (c->knobs.recon_force) lane = both && c->knobs.recon_force == 1;       // tuning / test knob: VP8HIP_RECON
     return !lane ? WAVE_PER_ROW : all_key ? LANE_KEY : LANE_INTER;
 }
@@ -145,14 +149,18 @@ extern "C" int vp8hip_decode(vp8hip_ctx *c, const vp8hip_job *jobs, int njobs, i
         // what this launch reads as raster: its reference frames (inter prediction reads the raster form, borders included), and
         // -- a wave-per-row launch of the loop filter alone -- the frames it filters in place
         std::vector<int> need;
+        bool pool = !tiled || K.eager_raster;               // (a large launch of key frames writes tiles only)
         for (int i = 0; i < njobs; i++) {
-            if (c->slots[jobs[i].ir_slot].hdr_copy.frame_type != 0)
+            if (c->slots[jobs[i].ir_slot].hdr_copy.frame_type != 0) {
+                pool = true;
                 for (int k = 1; k < 4; k++) {
                     const int f = jobs[i].ref_fb[k];
                     if (f >= 0 && f < nfb && c->fb_state[(size_t)f] == FB_TILES) need.push_back(f);
                 }
+            }
             if (!tiled && !(stages & VP8HIP_STAGE_RECON) && c->fb_state[(size_t)jobs[i].dst_fb] == FB_TILES) need.push_back(jobs[i].dst_fb);
         }
+        if (pool && vp8hip_raster_pool(c)) return -1;
         if (!need.empty() && vp8hip_need_raster_list(c, need.data(), (int)need.size())) return -1;
     }
     c->d_jobs = c->d_jobs2[par];

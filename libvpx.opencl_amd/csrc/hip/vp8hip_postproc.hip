@@ -50,6 +50,7 @@ extern "C" int vp8hip_postproc(vp8hip_ctx *c, int src_fb, int dst_fb, int tmp_fb
     const short *d_rv = (const short *)c->d_pp;
     signed char *d_noise = (signed char *)c->d_pp + 1024;
     uint8_t *d_rows = (uint8_t *)c->d_pp + 1024 + 3072;
+    if (vp8hip_raster_pool(c)) return -1;
     uint8_t *src = c->fb[src_fb], *dst = c->fb[dst_fb];
     const struct { int off, stride, rows, cols; } pl[3] = { { g.y_off, g.y_stride, g.aligned_h, g.aligned_w },
                                                             { g.u_off, g.uv_stride, g.aligned_h / 2, g.aligned_w / 2 },
@@ -93,7 +94,7 @@ extern "C" int vp8hip_mfqe(vp8hip_ctx *c, int show_fb, int prev_fb, int dst_fb, 
     HIPCHK(c, hipSetDevice(c->device));
     {
         const int need[2] = { show_fb, prev_fb };
-        if (vp8hip_need_raster_list(c, need, 2)) return -1;
+        if (vp8hip_raster_pool(c) || vp8hip_need_raster_list(c, need, 2)) return -1;
         c->fb_state[(size_t)dst_fb] = FB_RASTER;
     }
     if (c->d2h_count) { HIPCHK(c, hipEventSynchronize(c->ev_d2h_done)); c->d2h_count = 0; }   // a batch download may be reading dst
