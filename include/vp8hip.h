@@ -79,6 +79,20 @@ const char *vp8hip_last_error(const vp8hip_ctx *ctx);   /* ctx may be NULL: crea
  * sized for the worst case, vectors: 960 bytes per macroblock) and gets pinned host staging of the same layout when it is first
  * mapped.  Existing contents are discarded. */
 int  vp8hip_configure(vp8hip_ctx *ctx, int width, int height, int num_fb, int num_slots);
+/* The same with the slots' block streams out of ONE pool.  The worst case a slot of vp8hip_configure is sized for -- 24 blocks a
+ * macroblock, 768 of its 960 bytes per macroblock -- is rarely what a frame needs (a 1080p key frame of 200 KB: 62 k blocks = 2.0 of
+ * 6.3 MB), and frames in flight are what the device's entropy decoder lives on (vp8hip_entropy_decode: a frame per lane).  Here a
+ * slot holds records and vectors only (192 bytes per macroblock) and the entropy decoder takes the blocks' room out of the pool as
+ * it goes, a chunk (four macroblock rows' worst case) at a time: a row's blocks stay together, the records' sparse_first count
+ * from the pool's start, and vp8hip_decode reads the slots as ever.  vp8hip_pool_reset (on the context's stream: after the launches
+ * queued so far) empties the pool -- when the frames decoded out of it have been through vp8hip_decode; the caller says when.  A
+ * frame that finds the pool empty gets bit 1 of its status word (vp8hip_entropy_status) and is not to be decoded.  The host-side
+ * producers (vp8hip_ir_map*, vp8hip_ir_upload*) are refused on such a context; vp8hip_ir_copy copies the records, which then share
+ * the blocks; frames with several token partitions are decoded a frame per lane.  vp8hip_pool_usage (synchronises): bytes taken
+ * since the last reset (more than *pool_bytes: that much was asked for) and the pool's size. */
+int  vp8hip_configure_pooled(vp8hip_ctx *ctx, int width, int height, int num_fb, int num_slots, size_t pool_bytes);
+int  vp8hip_pool_reset(vp8hip_ctx *ctx);
+int  vp8hip_pool_usage(vp8hip_ctx *ctx, size_t *used_bytes, size_t *pool_bytes);
 int  vp8hip_geometry(const vp8hip_ctx *ctx, vp8ir_geom *g);
 
 /* Pinned host staging of a slot in the device form, for a feeder to write into directly (vp8_parser_decode_mbs_compact): mbx[nmb],
@@ -186,7 +200,8 @@ typedef struct vp8hip_entropy_frame {
  * vp8hip_sync).  Asynchronous on the context's stream. */
 int  vp8hip_entropy_decode(vp8hip_ctx *ctx, int first_slot, int count, const vp8hip_entropy_frame *frames, const uint8_t *data,
                            size_t data_bytes);
-/* What became of the frames of the last vp8hip_entropy_decode, a word each: bit 0 = a partition of the frame ended early, the
+/* What became of the frames of the last vp8hip_entropy_decode, a word each: bit 1 = the block pool was empty (vp8hip_configure_pooled:
+ * the frame's slot is not to be decoded); bit 0 = a partition of the frame ended early, the
  * frame is corrupt (what vp8_parser_decode_mbs reports through *corrupt).  Synchronous.  _async: the copy is queued on the
  * context's stream into page-locked memory of the caller's (vp8hip_host_alloc) and has landed after the next synchronisation
  * (vp8hip_sync, or vp8hip_download_wait for a fetch queued behind it). */

@@ -428,6 +428,26 @@ class Vp8Hip:
         self.nmb = (self.g.aligned_w // 16) * (self.g.aligned_h // 16)
         self.num_fb, self.num_slots = num_fb, num_slots
 
+    def configure_pooled(self, width, height, num_fb, num_slots, pool_bytes):
+        """vp8hip_configure_pooled: slots without block streams of their own + one pool the device's entropy decoder fills"""
+        self.L.vp8hip_configure_pooled.argtypes = [c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_size_t]
+        self._chk(self.L.vp8hip_configure_pooled(self.h, width, height, num_fb, num_slots, pool_bytes), "vp8hip_configure_pooled")
+        self.width, self.height = width, height
+        self.g = geom(width, height)
+        self.nmb = (self.g.aligned_w // 16) * (self.g.aligned_h // 16)
+        self.num_fb, self.num_slots = num_fb, num_slots
+
+    def pool_reset(self):
+        self.L.vp8hip_pool_reset.argtypes = [c_void_p]
+        self._chk(self.L.vp8hip_pool_reset(self.h), "vp8hip_pool_reset")
+
+    def pool_usage(self):
+        """-> (bytes taken since the last reset, bytes the pool holds)"""
+        used, size = ctypes.c_size_t(), ctypes.c_size_t()
+        self.L.vp8hip_pool_usage.argtypes = [c_void_p, c_void_p, c_void_p]
+        self._chk(self.L.vp8hip_pool_usage(self.h, ctypes.byref(used), ctypes.byref(size)), "vp8hip_pool_usage")
+        return used.value, size.value
+
     def ir_map(self, slot):
         ptrs = [c_void_p() for _ in range(4)]
         self._chk(self.L.vp8hip_ir_map(self.h, slot, *[ctypes.byref(p) for p in ptrs]), "vp8hip_ir_map")

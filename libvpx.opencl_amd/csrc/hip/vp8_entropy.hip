@@ -488,13 +488,16 @@ __device__ __forceinline__ void read_mb_tokens(BD &tb, const uint8_t *__restrict
 extern "C" size_t vp8_entropy_lds_bytes(int lpw) { return (size_t)lpw * (ENT_PROB_WORDS + ENT_DESC_WORDS + ENT_BLK_WORDS + 17) * 4; }
 
 // frames: `count` of them; frame f goes to the IR slot at slot_base + (first_slot + f) * slot_bytes (records at o_mbx, block
-// stream at o_blocks, vectors at o_mvs).  lpw: lanes of each wave that carry a frame (1..64).  scratch: per frame (8 * mb_cols +
+// stream at o_blocks, vectors at o_mvs).  pool (or null): the context's block pool (vp8hip_configure_pooled) -- the slots then
+// have no block streams of their own; a lane takes a chunk of chunk_blocks blocks out of the pool (*pool_ctr: the next free
+// chunk; pool_chunks of them, and one more behind them that takes what no longer fits) whenever what is left of its chunk
+// would not hold a macroblock row's worst case, so a row's blocks stay together and sparse_first counts from the pool's start.  lpw: lanes of each wave that carry a frame (1..64).  scratch: per frame (8 * mb_cols +
 // 64) words (the row above's sub-block modes and non-zero flags per macroblock column, the token partitions' decoder states,
 // inter frames: the row above's records).
 extern "C" __global__ void __launch_bounds__(64)
 vp8_entropy_kernel(const vp8hip_entropy_frame *__restrict__ frames, int count, int lpw, const uint8_t *__restrict__ all_data, DevGeom g,
                    size_t data_bytes, char *slot_base, size_t slot_bytes, size_t o_mbx, size_t o_blocks, size_t o_mvs, int first_slot,
-                   u32 *__restrict__ scratch, u32 *__restrict__ status)
+                   u32 *__restrict__ scratch, u32 *__restrict__ status, char *pool, u32 *pool_ctr, u32 pool_chunks, u32 chunk_blocks)
 {
     // LDS by lanes that carry a frame (the launch says how much: vp8_entropy_lds_bytes): probabilities, descriptor, block
     extern __shared__ u32 s_dyn[];
@@ -552,9 +555,11 @@ vp8_entropy_kernel(const vp8hip_entropy_frame *__restrict__ frames, int count, i
                             F.segment_tree_probs[1], F.segment_tree_probs[2] };
     char *slot = slot_base + slot_bytes * (size_t)(first_slot + f);
     u32x4 *out_mbs = (u32x4 *)(slot + o_mbx);
-    u32x4 *out_blocks = (u32x4 *)(slot + o_blocks);
+    u32x4 *out_blocks = pool ? (u32x4 *)pool : (u32x4 *)(slot + o_blocks);
     u32x4 *out_mvs = (u32x4 *)(slot + o_mvs);
-    u32 bw = 0;                                                        // blocks written to the slot's stream so far
+    u32 bw = 0;                                                        // blocks written to the slot's stream so far (pool: where the next one goes)
+    u32 bw_end = pool ? 0u : 0xffffffffu;                              // pool: the end of the lane's chunk
+    bool pool_full = false;
     const InterParams IP = { F.prob_intra, F.prob_last, F.prob_gf, { F.ymode_prob[0], F.ymode_prob[1], F.ymode_prob[2], F.ymode_prob[3] },
                              { F.uvmode_prob[0], F.uvmode_prob[1], F.uvmode_prob[2] },
                              (u32)F.hdr.sign_bias_golden << VP8IR_GOLDEN_FRAME | (u32)F.hdr.sign_bias_alt << VP8IR_ALTREF_FRAME, &F.mvc[0][0] };
@@ -562,6 +567,11 @@ vp8_entropy_kernel(const vp8hip_entropy_frame *__restrict__ frames, int count, i
 
     for (int r = 0; r < rows; r++) {
         BD tb;
+        if (bw_end - bw < (u32)cols * VP8IR_MAX_BLOCKS_PER_MB) {      // (pool only) the next chunk
+            u32 ch = atomicAdd(pool_ctr, 1u);
+            if (ch >= pool_chunks) { ch = pool_chunks; pool_full = true; }
+            bw = ch * chunk_blocks; bw_end = bw + chunk_blocks;
+        }
         {
             const u32 *t = tst + 8 * (r & (ntok - 1));                 // round robin by row (decodframe.c:1116-1129)
             tb.value = t[0]; tb.bits = (int)t[1]; tb.range = t[2]; tb.end = t[4];
@@ -611,7 +621,7 @@ vp8_entropy_kernel(const vp8hip_entropy_frame *__restrict__ frames, int count, i
 #ifdef ENT_STATS      // decisions of the first partition in the low half, of the token partitions (the last row's) in the high half
     if (status) status[f] = (fb.count >> 4 & 0xffffu) | tcount >> 8 << 16;
 #else
-    if (status) status[f] = bad ? 1u : 0u;
+    if (status) status[f] = (bad ? 1u : 0u) | (pool_full ? 2u : 0u);
 #endif
 }
 

@@ -62,6 +62,9 @@ static void free_pools(vp8hip_ctx *c)
     if (c->tile_block) (void)hipFree(c->tile_block);
     c->tile_block = nullptr;
     if (c->slot_block_dev) (void)hipFree(c->slot_block_dev);
+    if (c->pool) (void)hipFree(c->pool);
+    if (c->d_pool_ctr) (void)hipFree(c->d_pool_ctr);
+    c->pool = nullptr; c->d_pool_ctr = nullptr; c->pool_chunks = c->chunk_blocks = 0;
     if (c->gran_recon) (void)hipFree(c->gran_recon);
     if (c->gran_lf) (void)hipFree(c->gran_lf);
     if (c->d_intra_flags) (void)hipFree(c->d_intra_flags);
@@ -173,8 +176,13 @@ extern "C" void vp8hip_destroy(vp8hip_ctx *c)
     if (c->h_md5_idx) (void)hipHostFree(c->h_md5_idx);
     if (c->h_pp) (void)hipHostFree(c->h_pp);
     if (c->ev_pp) (void)hipEventDestroy(c->ev_pp);
-    if (c->d_ent_frames) (void)hipFree(c->d_ent_frames);
-    if (c->d_ent_data) (void)hipFree(c->d_ent_data);
+    for (int k = 0; k < 2; k++) {
+        if (c->d_ent_frames2[k]) (void)hipFree(c->d_ent_frames2[k]);
+        if (c->d_ent_data2[k]) (void)hipFree(c->d_ent_data2[k]);
+        if (c->ev_ent_in[k]) (void)hipEventDestroy(c->ev_ent_in[k]);
+        if (c->ev_ent_out[k]) (void)hipEventDestroy(c->ev_ent_out[k]);
+    }
+    if (c->stream_h2d) (void)hipStreamDestroy(c->stream_h2d);
     if (c->d_ent_scratch) (void)hipFree(c->d_ent_scratch);
     if (c->d_ent_status) (void)hipFree(c->d_ent_status);
     if (c->d_mfqe) (void)hipFree(c->d_mfqe);
@@ -192,11 +200,11 @@ extern "C" void vp8hip_destroy(vp8hip_ctx *c)
 static size_t recon_lds_bytes(int nw, int aligned_w) { return 1024 + (size_t)nw * 2 * (2080 + 2 * aligned_w + 96); }   // two frames per wave
 static size_t lf_lds_bytes(int nw) { return 256 + (size_t)nw * 2 * 4096; }   // two frames per wave
 
-static int configure_pools(vp8hip_ctx *c, int width, int height, int num_fb, int num_slots);
+static int configure_pools(vp8hip_ctx *c, int width, int height, int num_fb, int num_slots, size_t pool_bytes);
 
 extern "C" int vp8hip_configure(vp8hip_ctx *c, int width, int height, int num_fb, int num_slots)
 {
-    const int rc = configure_pools(c, width, height, num_fb, num_slots);
+    const int rc = configure_pools(c, width, height, num_fb, num_slots, 0);
     if (rc && c) {               // a failed (re)configuration leaves an UNconfigured context, not a half-allocated one
         free_pools(c);
         c->width = c->height = 0;
@@ -204,7 +212,38 @@ extern "C" int vp8hip_configure(vp8hip_ctx *c, int width, int height, int num_fb
     return rc;
 }
 
-static int configure_pools(vp8hip_ctx *c, int width, int height, int num_fb, int num_slots)
+extern "C" int vp8hip_configure_pooled(vp8hip_ctx *c, int width, int height, int num_fb, int num_slots, size_t pool_bytes)
+{
+    if (!c || !pool_bytes) return fail(c, -2, "vp8hip_configure_pooled: bad arguments");
+    const int rc = configure_pools(c, width, height, num_fb, num_slots, pool_bytes);
+    if (rc) {
+        free_pools(c);
+        c->width = c->height = 0;
+    }
+    return rc;
+}
+
+extern "C" int vp8hip_pool_reset(vp8hip_ctx *c)
+{
+    if (!c || !c->pool) return fail(c, -2, "vp8hip_pool_reset: the context has no block pool (vp8hip_configure_pooled)");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemsetAsync(c->d_pool_ctr, 0, sizeof(unsigned int), c->stream));
+    return 0;
+}
+
+extern "C" int vp8hip_pool_usage(vp8hip_ctx *c, size_t *used_bytes, size_t *pool_bytes)
+{
+    if (!c || !c->pool) return fail(c, -2, "vp8hip_pool_usage: the context has no block pool (vp8hip_configure_pooled)");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    unsigned int n = 0;
+    HIPCHK(c, hipMemcpy(&n, c->d_pool_ctr, sizeof n, hipMemcpyDeviceToHost));
+    if (used_bytes) *used_bytes = (size_t)n * c->chunk_blocks * 32;          // (more than the pool holds: that much was asked for)
+    if (pool_bytes) *pool_bytes = (size_t)c->pool_chunks * c->chunk_blocks * 32;
+    return 0;
+}
+
+static int configure_pools(vp8hip_ctx *c, int width, int height, int num_fb, int num_slots, size_t pool_bytes)
 {
     if (!c) return -2;
     if (width <= 0 || height <= 0 || width > 16383 || height > 16383 || num_fb < 1 || num_slots < 1)
@@ -248,9 +287,21 @@ static int configure_pools(vp8hip_ctx *c, int width, int height, int num_fb, int
     c->d2h_count = 0;
 
 
-    // IR slots: [pad][mbx][blocks][mvs], the records on 128-byte boundaries (a cache line each)
+    // IR slots: [pad][mbx][blocks][mvs], the records on 128-byte boundaries (a cache line each); with a block pool the slots
+    // have no block streams of their own
     const size_t o_mbx = 128, o_blocks = o_mbx + (size_t)c->nmb * sizeof(vp8ir_mbx);
-    c->cap_blocks = (size_t)c->nmb * VP8IR_MAX_BLOCKS_PER_MB;
+    c->cap_blocks = pool_bytes ? 0 : (size_t)c->nmb * VP8IR_MAX_BLOCKS_PER_MB;
+    if (pool_bytes) {
+        // a chunk: four macroblock rows' worst case (a lane asks for the next one when what it has left would not hold a row's)
+        c->chunk_blocks = 4u * (unsigned)c->dg.mb_cols * VP8IR_MAX_BLOCKS_PER_MB;
+        const size_t chunk_bytes = (size_t)c->chunk_blocks * 32;
+        if (pool_bytes / chunk_bytes < 2 || pool_bytes / chunk_bytes > 0xffffffffull / c->chunk_blocks)
+            return fail(c, -2, "vp8hip_configure_pooled: a pool of %zu bytes (chunks of %zu; at most 2^32 blocks)", pool_bytes, chunk_bytes);
+        c->pool_chunks = (unsigned)(pool_bytes / chunk_bytes) - 1;              // (the last chunk takes what no longer fits)
+        HIPCHK(c, hipMalloc((void **)&c->pool, ((size_t)c->pool_chunks + 1) * chunk_bytes + 8192));
+        HIPCHK(c, hipMalloc((void **)&c->d_pool_ctr, 256));
+        HIPCHK(c, hipMemsetAsync(c->d_pool_ctr, 0, 256, c->stream));
+    }
     const size_t o_mvs = align_up(o_blocks + c->cap_blocks * 32, 256);
     const size_t slotsz = align_up(o_mvs + (size_t)c->nmb * 16 * sizeof(vp8ir_mv), 256);
     HIPCHK(c, hipMalloc((void **)&c->slot_block_dev, slotsz * num_slots + 4096));   // + room for prefetches past the last macroblock
@@ -259,7 +310,7 @@ static int configure_pools(vp8hip_ctx *c, int width, int height, int num_fb, int
     for (int i = 0; i < num_slots; i++) {
         char *d = c->slot_block_dev + slotsz * i;
         Slot &s = c->slots[i];
-        s.d_mbx = (vp8ir_mbx *)(d + o_mbx); s.d_blocks = (int16_t *)(d + o_blocks); s.d_mvs = (vp8ir_mv *)(d + o_mvs);
+        s.d_mbx = (vp8ir_mbx *)(d + o_mbx); s.d_blocks = c->pool ? (int16_t *)c->pool : (int16_t *)(d + o_blocks); s.d_mvs = (vp8ir_mv *)(d + o_mvs);
         s.h_block = nullptr; s.h_hdr = nullptr; s.h_mbx = nullptr; s.h_blocks = nullptr; s.h_mvs = nullptr;
         s.h_dense = nullptr; s.h_mbs = nullptr; s.h_coef = nullptr;
         s.nblocks = 0;
@@ -294,6 +345,8 @@ extern "C" int vp8hip_geometry(const vp8hip_ctx *c, vp8ir_geom *g)
 // pinned staging of a slot (same offsets as the device block), created on first use: device-only slots cost no host memory
 static int map_staging(vp8hip_ctx *c, Slot &s)
 {
+    if (c->pool)
+        return fail(c, -2, "a context with a block pool (vp8hip_configure_pooled) takes its IR from the device's entropy decoder only");
     if (s.h_block) return 0;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipHostMalloc((void **)&s.h_block, c->slot_bytes, hipHostMallocDefault));
@@ -321,7 +374,7 @@ extern "C" int vp8hip_ir_upload_compact(vp8hip_ctx *c, int slot, size_t nblocks)
 {
     if (!c || slot < 0 || slot >= (int)c->slots.size()) return fail(c, -2, "vp8hip_ir_upload_compact: bad slot %d", slot);
     Slot &s = c->slots[slot];
-    if (!s.h_block) return fail(c, -2, "vp8hip_ir_upload_compact: slot %d was never mapped", slot);
+    if (!s.h_block || c->pool) return fail(c, -2, "vp8hip_ir_upload_compact: slot %d was never mapped", slot);
     const vp8ir_frame_hdr &h = *s.h_hdr;
     if (h.mb_cols != c->dg.mb_cols || h.mb_rows != c->dg.mb_rows)
         return fail(c, -2, "vp8hip_ir_upload_compact: header is %dx%d MBs, context configured for %dx%d", h.mb_cols, h.mb_rows,
@@ -381,7 +434,8 @@ extern "C" int vp8hip_ir_copy(vp8hip_ctx *c, int dst, int src)
     HIPCHK(c, hipSetDevice(c->device));
     d.hdr_copy = s.hdr_copy;
     d.nblocks = s.nblocks;
-    const size_t nb = s.nblocks == NBLOCKS_UNKNOWN ? c->cap_blocks : s.nblocks;
+    // (with a block pool the records say where in the pool the blocks are: the copy shares them)
+    const size_t nb = c->pool ? 0 : s.nblocks == NBLOCKS_UNKNOWN ? c->cap_blocks : s.nblocks;
     HIPCHK(c, hipMemcpyAsync(d.d_mbx, s.d_mbx, (size_t)c->nmb * sizeof(vp8ir_mbx) + nb * 32, hipMemcpyDeviceToDevice, c->stream));
     if (s.hdr_copy.frame_type != 0)
         HIPCHK(c, hipMemcpyAsync(d.d_mvs, s.d_mvs, (size_t)c->nmb * 16 * sizeof(vp8ir_mv), hipMemcpyDeviceToDevice,
@@ -471,6 +525,33 @@ extern "C" int vp8hip_ir_fetch(vp8hip_ctx *c, int slot, vp8ir_mb *mbs, int16_t *
     Slot &s = c->slots[slot];
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->pool) {
+        // the records, then row by row the piece of the pool the row's blocks are in (a row's blocks are together)
+        const int cols = c->dg.mb_cols;
+        vp8ir_mbx *x = (vp8ir_mbx *)malloc((size_t)c->nmb * sizeof(vp8ir_mbx));
+        int16_t *rowb = (int16_t *)malloc((size_t)cols * VP8IR_MAX_BLOCKS_PER_MB * 32);
+        int16_t *one = (int16_t *)malloc(VP8IR_COEF_PER_MB * sizeof(int16_t));
+        int rc = 0;
+        if (!x || !rowb || !one) rc = fail(c, -1, "vp8hip_ir_fetch: out of host memory");
+        if (!rc && hipMemcpy(x, s.d_mbx, (size_t)c->nmb * sizeof(vp8ir_mbx), hipMemcpyDeviceToHost) != hipSuccess) rc = fail(c, -1, "vp8hip_ir_fetch: copy failed");
+        const size_t pool_blocks = ((size_t)c->pool_chunks + 1) * c->chunk_blocks;
+        for (int r = 0; r < c->dg.mb_rows && !rc; r++) {
+            const uint32_t first = x[(size_t)r * cols].d.sparse_first;
+            size_t nrow = 0;
+            for (int i = r * cols; i < (r + 1) * cols; i++)
+                for (int k = 0; k < 24; k++) nrow += vp8ir_block_kind(&x[i].d, k) == 2;
+            if (first + nrow > pool_blocks) { rc = fail(c, -1, "vp8hip_ir_fetch: row %d of slot %d points outside the block pool", r, slot); break; }
+            if (nrow && hipMemcpy(rowb, c->pool + (size_t)first * 32, nrow * 32, hipMemcpyDeviceToHost) != hipSuccess) { rc = fail(c, -1, "vp8hip_ir_fetch: copy failed"); break; }
+            for (int i = r * cols; i < (r + 1) * cols; i++) {
+                vp8ir_mbx m = x[i];
+                if (m.d.sparse_first < first || m.d.sparse_first - first > nrow) { rc = fail(c, -1, "vp8hip_ir_fetch: macroblock %d of slot %d is not with its row", i, slot); break; }
+                m.d.sparse_first -= first;
+                vp8ir_expand_mb(&m, rowb, mbs ? &mbs[i] : nullptr, coef ? coef + (size_t)i * VP8IR_COEF_PER_MB : one);
+            }
+        }
+        free(x); free(rowb); free(one);
+        return rc;
+    }
     const size_t nb = s.nblocks == NBLOCKS_UNKNOWN ? c->cap_blocks : s.nblocks;
     const size_t bytes = (size_t)c->nmb * sizeof(vp8ir_mbx) + nb * 32;
     char *tmp = (char *)malloc(bytes);

@@ -79,7 +79,10 @@ struct vp8hip_ctx {
     uint8_t *fb_block; char *slot_block_dev;
     uint8_t *tile_block; size_t tile_frame;          // the tiled forms of all frame buffers (tile_frame bytes each) + the dummy tile
     DevJob *d_conv_jobs, *h_conv_jobs; int conv_cap; hipEvent_t ev_conv;    // job table of a tiled -> raster pass
-    size_t slot_bytes, o_mbx, o_blocks, o_mvs, cap_blocks;            // slot layout; cap_blocks = nmb * 24
+    size_t slot_bytes, o_mbx, o_blocks, o_mvs, cap_blocks;            // slot layout; cap_blocks = nmb * 24 (pooled: 0)
+    // vp8hip_configure_pooled: the slots have no block streams of their own; the device's entropy decoder takes the blocks' room out
+    // of this pool, chunk_blocks blocks at a time (pool_chunks chunks + one that takes what no longer fits); *d_pool_ctr = chunks taken
+    char *pool; unsigned int *d_pool_ctr; unsigned int pool_chunks, chunk_blocks;
     // job staging
     DevJob *d_jobs2[VP8HIP_NBUF]; DevJob *d_jobs; DevJob *h_jobs; int jobs_cap;   // d_jobs = d_jobs2[parity of the call]
     // launch configuration
@@ -107,7 +110,12 @@ struct vp8hip_ctx {
     uint8_t *d_mfqe, *h_mfqe; int mfqe_cap; hipEvent_t ev_mfqe;     // vp8hip_mfqe: the macroblock classes of the frame
     // vp8hip_entropy_decode: the frames' descriptions, their bytes, per-frame scratch and status on the device; the stream the
     // launch runs on (its own: beside the pixel path of other slots) and the events that order it against the main stream
-    char *d_ent_frames, *d_ent_data; unsigned int *d_ent_scratch, *d_ent_status; size_t ent_frames_cap, ent_data_cap, ent_scratch_cap;
+    // (descriptions and bytes in TWO sets: a launch's input is copied on a stream of its own, stream_h2d, while the launch before
+    // and its frames' pixel path still run -- 3 to 5 GB per launch of 24,576 1080p frames; ev_ent_in[k]: set k's copies have landed,
+    // ev_ent_out[k]: the kernel that read set k is done)
+    char *d_ent_frames2[2], *d_ent_data2[2]; size_t ent_frames_cap2[2], ent_data_cap2[2]; int ent_set;
+    hipStream_t stream_h2d; hipEvent_t ev_ent_in[2], ev_ent_out[2];
+    unsigned int *d_ent_scratch, *d_ent_status; size_t ent_status_cap, ent_scratch_cap; int ent_last_count;
     bool ent_tables_loaded, ent_parts_off; int ent_lpw;
     int ent_resident[3];           // waves of vp8_entropy_kernel the device holds at once with 64 / 32 / 16 lanes carrying a frame (LDS)
     unsigned int *d_sched;         // vp8_keyframe_kernel's role / work counters

@@ -1,4 +1,4 @@
-/* batch_md5 [--threads T] [--batch B] [--loop N] [--host-md5] [--device-entropy [--entropy-batch E] [--no-download]] [--gpus G] <in.ivf> <out.md5>
+/* batch_md5 [--threads T] [--batch B] [--loop N] [--host-md5] [--device-entropy [--entropy-batch E [--pool-mb M]] [--no-download]] [--gpus G] <in.ivf> <out.md5>
  * batch_md5 --streams S [--threads T] [--gpus G] <in.ivf> [<in2.ivf> ...] <out.md5>
  *
  * decode_to_md5 for streams of independently decodable frames (all key frames), at the rate the host can feed the
@@ -18,10 +18,13 @@
  * frame per lane (vp8hip_entropy_decode), straight into the IR slots the pixel path reads.  A lane takes about a second for a
  * large 1080p key frame whatever the batch, so this mode wants batches of thousands (one set of IR slots, two sets of frame
  * buffers).  --no-download: with the MD5s computed on the device the frames themselves stay there.  --entropy-batch E (a
- * multiple of B): the entropy decoder takes E frames per launch, into E IR slots, and the pixel path decodes them B at a time --
- * more frames in flight (frames in flight over the time of the largest is what the entropy decoder's rate is) for the memory of
- * the slots alone: tiles and frame buffers are only needed for B frames at a time.  Frames the device reports as cut short
- * (vp8hip_entropy_status) are counted and named on stderr, as the host feeder's *corrupt would.
+ * multiple of B): the entropy decoder takes E frames per launch and the pixel path decodes them B at a time -- more frames in
+ * flight (frames in flight over the time of the largest is what the entropy decoder's rate is; 24,576 is what the device holds
+ * at once, vp8hip_entropy.hip).  The E slots hold records and vectors only and the blocks of a launch come out of ONE pool
+ * (vp8hip_configure_pooled; --pool-mb M sets its size, by default what the largest launch is expected to need): a frame in
+ * flight costs what it needs, not the worst case.  With --no-download the launch's frames are hashed in one go (E frame buffers,
+ * as tiles), beside the next launch of the entropy decoder.  Frames the device reports as cut short (vp8hip_entropy_status) are
+ * counted and named on stderr, as the host feeder's *corrupt would.
  *
  * --streams S: S streams of ANY frame types decoded side by side, position t of all of them in one launch (stream s plays input
  * s mod inputs; all inputs of one frame size; the shortest sets the length): only the frame headers are read on the host, a
@@ -131,6 +134,7 @@ static long *g_order;                               /* --device-entropy: which f
 static vp8hip_entropy_frame *g_ent[2];              /* per set: the frames' descriptions for vp8hip_entropy_decode (pinned) */
 static uint8_t *g_ent_data[2];                      /* ... and their bytes, one after the other */
 static size_t g_ent_cap;
+static size_t g_pool_bytes;                         /* --entropy-batch: the block pool of the context */
 
 typedef struct batch_ref { int b, n; long first; } batch_ref;     /* batch number, frames in it, index of its first frame */
 /* The pipeline, batch by batch (three slot / frame-buffer sets, two pinned host sets):
@@ -209,10 +213,15 @@ static void take_digests(const batch_ref *br)
 /* the status words of an entropy launch (set `set`, n frames from run position `first` on), once its copy has landed */
 static void take_status(int set, long first, int n)
 {
-    for (int i = 0; i < n; i++)
+    for (int i = 0; i < n; i++) {
+        if (g_ent_status[set][i] & 2u) {
+            fprintf(stderr, "frame %ld found the block pool (%zu MB) empty: raise --pool-mb or lower --entropy-batch\n", run_index(first + i) + 1, g_pool_bytes >> 20);
+            exit(EXIT_FAILURE);
+        }
         if (g_ent_status[set][i] & 1u) {
             if (g_corrupt++ < 8) fprintf(stderr, "frame %ld: a partition ended early (corrupt)\n", run_index(first + i) + 1);
         }
+    }
 }
 
 static double now_s(void)
@@ -462,6 +471,7 @@ static int run_streams(int S_total, int threads, int gpus, int argc, char **argv
 int main(int argc, char **argv)
 {
     int threads = 0, loop = 1, a = 1, host_md5 = 0, no_download = 0, streams = 0, gpus = 1;
+    long pool_mb = 0;
     g_batch = 128;
     for (; a < argc && argv[a][0] == '-' && argv[a][1] == '-'; a++) {
         if (!strcmp(argv[a], "--threads") && a + 1 < argc) threads = atoi(argv[++a]);
@@ -470,11 +480,12 @@ int main(int argc, char **argv)
         else if (!strcmp(argv[a], "--no-download")) no_download = 1;
         else if (!strcmp(argv[a], "--entropy-batch") && a + 1 < argc) g_ebatch = atoi(argv[++a]);
         else if (!strcmp(argv[a], "--entropy-dense")) ;                 /* (what --entropy-batch does anyway since the slots hold the compact form) */
+        else if (!strcmp(argv[a], "--pool-mb") && a + 1 < argc) pool_mb = atol(argv[++a]);
         else if (!strcmp(argv[a], "--streams") && a + 1 < argc) streams = atoi(argv[++a]);
         else if (!strcmp(argv[a], "--gpus") && a + 1 < argc) gpus = atoi(argv[++a]);
         else if (!strcmp(argv[a], "--batch") && a + 1 < argc) g_batch = atoi(argv[++a]);
         else if (!strcmp(argv[a], "--loop") && a + 1 < argc) loop = atoi(argv[++a]);
-        else DIE("Usage: %s [--threads T] [--batch B] [--loop N] [--host-md5] [--device-entropy [--entropy-batch E] [--no-download]] <in.ivf> <out.md5>", argv[0]);
+        else DIE("Usage: %s [--threads T] [--batch B] [--loop N] [--host-md5] [--device-entropy [--entropy-batch E [--pool-mb M]] [--no-download]] <in.ivf> <out.md5>", argv[0]);
     }
     if (threads < 1) {
         long n = sysconf(_SC_NPROCESSORS_ONLN);
@@ -484,7 +495,7 @@ int main(int argc, char **argv)
     if (gpus < 1) gpus = 1;
     if (streams > 0) return run_streams(streams, threads, gpus, argc, argv, a);
     if (argc - a != 2 || g_batch < 1 || loop < 1)
-        DIE("Usage: %s [--threads T] [--batch B] [--loop N] [--host-md5] [--device-entropy [--entropy-batch E] [--no-download]] [--gpus G] <in.ivf> <out.md5>\n"
+        DIE("Usage: %s [--threads T] [--batch B] [--loop N] [--host-md5] [--device-entropy [--entropy-batch E [--pool-mb M]] [--no-download]] [--gpus G] <in.ivf> <out.md5>\n"
             "       %s --streams S [--threads T] [--gpus G] <in.ivf> [<in2.ivf> ...] <out.md5>", argv[0], argv[0]);
 
     /* ---- read the whole stream; every frame must be a key frame of one size */
@@ -528,8 +539,10 @@ int main(int argc, char **argv)
     /* slots and frame buffers: three sets for the host feeder (parsed / on the GPU / coming back); with the entropy decoder on
        the device the IR is written and read on one stream, one set does, and the frame buffers alternate between two */
     const int slot_sets = g_dev_entropy ? 1 : 3, fb_sets = g_dev_entropy ? 2 : 3;
-    HIP(vp8hip_configure(g_hip, g_width, g_height, fb_sets * g_batch, g_ebatch ? g_ebatch : slot_sets * g_batch));
-    HIP(vp8hip_geometry(g_hip, &g_geom));
+    if (!g_ebatch) {
+        HIP(vp8hip_configure(g_hip, g_width, g_height, fb_sets * g_batch, slot_sets * g_batch));
+        HIP(vp8hip_geometry(g_hip, &g_geom));
+    }
     if (g_dev_entropy) {
         {   /* a batch's bytes at most: the frames are taken in order of size within windows of SORT_WINDOW batches */
             g_order = (long *)malloc(sizeof(long) * (size_t)total);
@@ -545,6 +558,30 @@ int main(int argc, char **argv)
                 if (run > g_ent_cap) g_ent_cap = run;
             }
         }
+        if (g_ebatch) {
+            /* E frames per entropy launch: E slots without block streams of their own and ONE pool for the blocks of a launch
+               (vp8hip_configure_pooled) -- a frame in flight costs what it needs (records 192 bytes a macroblock + its blocks), not
+               the worst case (960), and frames in flight are what the entropy decoder's rate is made of.  The pool: what the
+               launch that needs most is expected to need -- a frame's blocks are 6 to 13 times its compressed bytes in the
+               fixtures: 14 times, capped by the worst case, + a chunk and a half per frame for the chunks' ends. */
+            const size_t nmb = (size_t)((g_width + 15) / 16) * (size_t)((g_height + 15) / 16);
+            const size_t worst = nmb * 24 * 32, chunk = (size_t)4 * ((g_width + 15) / 16) * 24 * 32;
+            size_t pool = 0;
+            for (long k0 = 0; k0 < total; k0 += unit) {
+                size_t need = 0;
+                for (long k = k0; k < k0 + unit && k < total; k++) {
+                    const size_t est = 14 * FRAME_AT(g_order[k])->size;
+                    need += (est < worst ? est : worst) + chunk + chunk / 2;
+                }
+                if (need > pool) pool = need;
+            }
+            pool += 4 * chunk;
+            if (pool_mb > 0) pool = (size_t)pool_mb << 20;
+            g_pool_bytes = pool;
+            /* frames that stay on the device are hashed a launch at a time (E frame buffers, tiles only); downloads go B at a time */
+            HIP(vp8hip_configure_pooled(g_hip, g_width, g_height, no_download ? g_ebatch : 2 * g_batch, g_ebatch, pool));
+            HIP(vp8hip_geometry(g_hip, &g_geom));
+        }
         for (int k = 0; k < 2; k++) {
             if (!(g_ent[k] = (vp8hip_entropy_frame *)vp8hip_host_alloc(g_hip, (size_t)unit * sizeof(vp8hip_entropy_frame))) ||
                 !(g_ent_data[k] = (uint8_t *)vp8hip_host_alloc(g_hip, g_ent_cap + 16)) ||
@@ -558,7 +595,7 @@ int main(int argc, char **argv)
     g_stride = vp8hip_frame_stride(g_hip);
     for (int k = 0; k < 2; k++) {
         if (!no_download && !(g_host[k] = (uint8_t *)vp8hip_host_alloc(g_hip, (size_t)g_batch * g_stride))) DIE("vp8hip_host_alloc: %s", vp8hip_last_error(g_hip));
-        if (!(g_dig[k] = (uint8_t *)vp8hip_host_alloc(g_hip, (size_t)g_batch * 16))) DIE("vp8hip_host_alloc: %s", vp8hip_last_error(g_hip));
+        if (!(g_dig[k] = (uint8_t *)vp8hip_host_alloc(g_hip, (size_t)(g_ebatch && no_download ? g_ebatch : g_batch) * 16))) DIE("vp8hip_host_alloc: %s", vp8hip_last_error(g_hip));
     }
     g_digest = calloc((size_t)total, 16);
     g_parsers = calloc((size_t)threads, sizeof *g_parsers);
@@ -584,22 +621,25 @@ int main(int argc, char **argv)
         LAUNCH_FRAMES(0, cur.n);
         size_t bytes = place_frames(&cur);
         task_start(&parse_t, 0, export_one, &cur, cur.n);
+        batch_ref prev_launch_ref = { -1, 0, 0 };
         for (long done = 0; done < total; L++) {
             task_wait(&parse_t, 0);
             if (g_failed) DIE("a frame of launch %ld failed to parse", L);
             const batch_ref now = cur;
             done += now.n;
+            HIP(vp8hip_pool_reset(g_hip));               /* (on the stream: behind the pixel path of the launch before) */
             HIP(vp8hip_entropy_decode(g_hip, 0, now.n, g_ent[now.b & 1], g_ent_data[now.b & 1], bytes));
             HIP(vp8hip_entropy_status_async(g_hip, now.n, g_ent_status[now.b & 1]));
             pend[now.b & 1].valid = 1; pend[now.b & 1].n = now.n; pend[now.b & 1].first = now.first; pend[now.b & 1].launch = L;
             for (int at = 0; at < now.n; at += g_batch, part_no++) {
                 const batch_ref part = { (int)(part_no & 0x3fffffff), now.n - at < g_batch ? now.n - at : g_batch, now.first + at };
-                const int fb0 = (part.b & 1) * g_batch;
+                const int fb0 = no_download ? at : (part.b & 1) * g_batch;
                 for (int i = 0; i < part.n; i++) {
                     jobs[i].ir_slot = at + i; jobs[i].dst_fb = fb0 + i;
                     jobs[i].ref_fb[0] = jobs[i].ref_fb[1] = jobs[i].ref_fb[2] = jobs[i].ref_fb[3] = -1;
                 }
                 HIP(vp8hip_decode(g_hip, jobs, part.n, VP8HIP_STAGE_ALL));
+                if (no_download) continue;
                 if (prev.b >= 0) {
                     HIP(vp8hip_download_wait(g_hip));
                     take_digests(&prev);
@@ -614,8 +654,28 @@ int main(int argc, char **argv)
                     bytes = place_frames(&cur);
                     task_start(&parse_t, 0, export_one, &cur, cur.n);
                 }
-                HIP(vp8hip_frames_fetch_async(g_hip, fb0, part.n, no_download ? NULL : g_host[part.b & 1], g_dig[part.b & 1]));
+                HIP(vp8hip_frames_fetch_async(g_hip, fb0, part.n, g_host[part.b & 1], g_dig[part.b & 1]));
                 prev = part; prev_launch = L;
+            }
+            if (no_download) {
+                /* the frames stay: ONE hash launch over the launch's frames, on the download stream -- beside the entropy decoder's
+                   next launch, which is most of the time.  The launch before has come back by now: its page-locked set is free
+                   for the headers of the next one */
+                if (prev_launch_ref.b >= 0) {
+                    HIP(vp8hip_download_wait(g_hip));
+                    take_digests(&prev_launch_ref);
+                    prev_launch = L - 1;
+                    TAKE_PENDING();
+                }
+                if (done < total) {
+                    const long first = cur.first + cur.n;
+                    cur.b = cur.b + 1; cur.first = first;
+                    LAUNCH_FRAMES(first, cur.n);
+                    bytes = place_frames(&cur);
+                    task_start(&parse_t, 0, export_one, &cur, cur.n);
+                }
+                HIP(vp8hip_frames_fetch_async(g_hip, 0, now.n, NULL, g_dig[now.b & 1]));
+                prev_launch_ref = now; prev = now; prev_launch = L;
             }
         }
         HIP(vp8hip_download_wait(g_hip));

@@ -198,3 +198,11 @@ def test_written_inter_streams_through_the_tools(tmp_path):
         r = subprocess.run([os.path.join(BIN, "batch_md5"), "--streams", "3", str(ivf), str(out)], capture_output=True, text=True)
         assert r.returncode == 0, r.stderr
         assert [ln.split()[0] for ln in open(out)] == gold * 3, (n, "batch_md5 --streams")
+
+
+def test_batch_md5_block_pool_too_small(tmp_path):
+    """--entropy-batch: the blocks of a launch come out of one pool (vp8hip_configure_pooled); a pool that cannot hold them is reported
+    by the frames that found it empty, and the tool stops instead of hashing frames decoded from half an IR."""
+    r = subprocess.run([os.path.join(BIN, "batch_md5"), "--device-entropy", "--batch", "4", "--entropy-batch", "12", "--pool-mb", "1", "--loop", "3",
+                        ivf_path("kf_1920x1080"), str(tmp_path / "o.md5")], capture_output=True, text=True)
+    assert r.returncode != 0 and "found the block pool (1 MB) empty" in r.stderr, r.stderr

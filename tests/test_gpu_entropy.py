@@ -186,12 +186,16 @@ def test_inter_frames(name):
     assert _one_slot_stream(P, w, h, frames[:24], golden_md5(name), name) > 0
 
 
-def _one_slot_stream(P, w, h, frames, gold, name):
-    """-> inter frames seen"""
+def _one_slot_stream(P, w, h, frames, gold, name, pooled=False):
+    """-> inter frames seen.  pooled: the slot's blocks out of a block pool (vp8hip_configure_pooled), emptied before every frame"""
     ph, pd = P.Parser(), P.Parser()
     pd.set_device_segmap(True)
     ctx = P.Vp8Hip()
-    ctx.configure(w, h, 4, 1)
+    if pooled:
+        nmb = ((w + 15) // 16) * ((h + 15) // 16)
+        ctx.configure_pooled(w, h, 4, 1, nmb * 24 * 32 + 3 * 4 * ((w + 15) // 16) * 24 * 32)
+    else:
+        ctx.configure(w, h, 4, 1)
     shown = 0
     n_inter = 0
     for i, data in enumerate(frames):
@@ -200,6 +204,8 @@ def _one_slot_stream(P, w, h, frames, gold, name):
         h2, _ = pd.begin(data)
         ef = pd.export_entropy()
         assert ef is not None
+        if pooled:
+            ctx.pool_reset()
         assert not ctx.entropy_decode(0, [ef], [data]).any()
         dm, dc = ctx.ir_fetch(0)
         bad = np.nonzero((dm != mbs).any(axis=1))[0]
@@ -249,7 +255,56 @@ def test_written_inter_streams():
     P = load_package()
     for w, h, seed, plan, lp, big in INTER_CASES:
         frames, _ = inter_sequence(w, h, seed, plan, lp, big=big)
-        assert _one_slot_stream(P, w, h, frames, oracle_listing(P, w, h, frames), (w, h, seed)) == len(plan)
+        gold = oracle_listing(P, w, h, frames)
+        assert _one_slot_stream(P, w, h, frames, gold, (w, h, seed)) == len(plan)
+        assert _one_slot_stream(P, w, h, frames, gold, (w, h, seed, "pooled"), pooled=True) == len(plan)
+
+
+@pytest.mark.parametrize("name", ["kf_odd_67x45", "kf_640x360", "kf_1920x1080", "kf_8part_1920x1080", "kf_3840x2160"])
+def test_block_pool(name):
+    """vp8hip_configure_pooled: the slots' block streams out of one pool, a chunk (four macroblock rows' worst case) at a time.
+    Same IR as the host feeder's (vp8hip_ir_fetch follows the records into the pool), same frames (the reference's MD5s); the pool
+    holds what the frames need, not their worst case; emptied, it serves the next launch; vp8hip_ir_copy'd slots share their
+    source's blocks; a pool too small flags the frames it could not serve (status bit 1) and serves the others; the host-side
+    producers are refused."""
+    P = load_package()
+    w, h, frames = P.read_ivf(ivf_path(name))
+    host = _host_ir(P, frames)
+    efs = _export(P, frames)
+    n = len(frames)
+    cols, nmb = (w + 15) // 16, ((w + 15) // 16) * ((h + 15) // 16)
+    chunk = 4 * cols * 24 * 32
+    worst = n * nmb * 24 * 32
+    ctx = P.Vp8Hip()
+    ctx.configure_pooled(w, h, n + 1, n + 1, worst + (n + 2) * chunk)
+    for rnd in range(2):                                   # (second round: the pool emptied, the frames the other way round)
+        order = list(range(n)) if rnd == 0 else list(range(n - 1, -1, -1))
+        ctx.pool_reset()
+        assert not ctx.entropy_decode(0, [efs[i] for i in order], [frames[i] for i in order]).any()
+        used, size = ctx.pool_usage()
+        assert 0 < used <= size and used % chunk == 0
+        if nmb > 1000:
+            assert used < worst                            # (what the frames need, not their worst case)
+        for k, i in enumerate(order):
+            _compare(ctx, k, host[i][1], host[i][2], (name, rnd, i))
+        ctx.ir_copy(n, 0)
+        _compare(ctx, n, host[order[0]][1], host[order[0]][2], (name, rnd, "copy"))
+        ctx.decode([(k, k, (-1, -1, -1)) for k in range(n + 1)], P.STAGE_ALL)
+        got = [P.planes_md5(*ctx.download_planes(k)) for k in range(n + 1)]
+        assert got == [golden_md5(name)[i] for i in order + [order[0]]]
+    with pytest.raises(RuntimeError, match="block pool"):
+        ctx.ir_map_compact(0)
+    # a pool of two chunks (+ the one behind them): the frames that find it empty say so, the others are whole
+    ctx.configure_pooled(w, h, 1, n, 3 * chunk)
+    st = ctx.entropy_decode(0, efs, frames)
+    if nmb > 1000:
+        assert (st & 2).any()
+    for i in range(n):
+        if not st[i] & 2:
+            _compare(ctx, i, host[i][1], host[i][2], (name, "small pool", i))
+    used, size = ctx.pool_usage()
+    assert size == 2 * chunk and (used > size) == bool((st & 2).any())
+    ctx.close()
 
 
 @pytest.mark.parametrize("name,mode", [("p_lowrate_640x360", "device"), ("p_arf_176x144", "device"), ("p_lowrate_640x360", "host")])
