@@ -81,7 +81,7 @@ static void free_pools(vp8hip_ctx *c)
 static void destroy_events(vp8hip_ctx *c)
 {
     for (int r = 0; r < VP8HIP_STATS_RING; r++) for (int i = 0; i < 6; i++) if (c->evr[r][i]) (void)hipEventDestroy(c->evr[r][i]);
-    if (c->ev_jobs) (void)hipEventDestroy(c->ev_jobs);
+    for (int k = 0; k < VP8HIP_NBUF; k++) if (c->ev_jobs2[k]) (void)hipEventDestroy(c->ev_jobs2[k]);
     if (c->ev_conv) (void)hipEventDestroy(c->ev_conv);
 }
 
@@ -114,7 +114,7 @@ extern "C" int vp8hip_create(int device, vp8hip_ctx **out)
     read_knobs(c->knobs);
     c->tile_block = nullptr; c->tile_frame = 0;
     c->d_jobs = nullptr; c->h_jobs = nullptr; c->jobs_cap = 0;
-    for (int k = 0; k < VP8HIP_NBUF; k++) c->d_jobs2[k] = nullptr;
+    for (int k = 0; k < VP8HIP_NBUF; k++) { c->d_jobs2[k] = nullptr; c->h_jobs2[k] = nullptr; c->ev_jobs2[k] = nullptr; }
     c->parity = 0;
     c->d_md5 = nullptr; c->md5_cap = 0;
     c->width = c->height = 0;
@@ -130,11 +130,11 @@ extern "C" int vp8hip_create(int device, vp8hip_ctx **out)
     c->stream_d2h = nullptr; c->ev_d2h_from = c->ev_d2h_done = nullptr; c->d2h_first = c->d2h_count = 0; c->fb_stride = 0;
     // events: every creation is checked; on failure whatever exists is destroyed again (null handles are skipped)
     for (int r = 0; r < VP8HIP_STATS_RING; r++) for (int i = 0; i < 6; i++) c->evr[r][i] = nullptr;
-    c->ev_jobs = c->ev_conv = nullptr;
+    c->ev_conv = nullptr;
     e = hipSuccess;
     for (int r = 0; r < VP8HIP_STATS_RING && e == hipSuccess; r++)
         for (int i = 0; i < 6 && e == hipSuccess; i++) e = hipEventCreate(&c->evr[r][i]);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_jobs, hipEventDisableTiming);
+    for (int k = 0; k < VP8HIP_NBUF && e == hipSuccess; k++) e = hipEventCreateWithFlags(&c->ev_jobs2[k], hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_conv, hipEventDisableTiming);
     const char *what = "hipEventCreate";
     const void *big_lds[6] = { (const void *)vp8_recon_kernel, (const void *)vp8_recon_xcu_kernel,
@@ -165,7 +165,7 @@ extern "C" void vp8hip_destroy(vp8hip_ctx *c)
     if (c->d_conv_jobs) (void)hipFree(c->d_conv_jobs);
     if (c->h_conv_jobs) (void)hipHostFree(c->h_conv_jobs);
     for (int k = 0; k < VP8HIP_NBUF; k++) if (c->d_jobs2[k]) (void)hipFree(c->d_jobs2[k]);
-    if (c->h_jobs) (void)hipHostFree(c->h_jobs);
+    for (int k = 0; k < VP8HIP_NBUF; k++) if (c->h_jobs2[k]) (void)hipHostFree(c->h_jobs2[k]);
     if (c->h_status) (void)hipHostFree(c->h_status);
     if (c->d_sched) (void)hipFree(c->d_sched);
     // the post-processing tables outlive reconfigurations: the caller's noise state does too (vp8/common/postproc.c keeps

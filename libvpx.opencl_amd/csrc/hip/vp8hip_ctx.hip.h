@@ -15,7 +15,7 @@
 #include "vp8_common.hip.h"
 
 #define VP8HIP_STATS_RING 32
-#define VP8HIP_NBUF 3          // device job tables in rotation (a launch's table may still be read while the next one is staged)
+#define VP8HIP_NBUF 4          // device job tables in rotation (a launch's table may still be read while the next one is staged)
 #ifdef VP8_STAMPS
 #define VP8HIP_SCHED_WORDS (16 + 16384 + 4 * 4096)     // + the diagnostic builds' log: four words per wave
 #else
@@ -61,7 +61,7 @@ struct vp8hip_ctx {
     hipEvent_t evr[VP8HIP_STATS_RING][6];
     bool evr_tiled[VP8HIP_STATS_RING]; vp8hip_stats evr_stats[VP8HIP_STATS_RING];
     long ncalls;
-    hipEvent_t ev_jobs;            // job table of the previous call has been copied
+    hipEvent_t ev_jobs2[VP8HIP_NBUF];   // the job table staged in h_jobs2[k] has been copied
     int parity;                    // job table used by the next launch
     char err[256];
     // geometry
@@ -84,7 +84,9 @@ struct vp8hip_ctx {
     // of this pool, chunk_blocks blocks at a time (pool_chunks chunks + one that takes what no longer fits); *d_pool_ctr = chunks taken
     char *pool; unsigned int *d_pool_ctr; unsigned int pool_chunks, chunk_blocks;
     // job staging
-    DevJob *d_jobs2[VP8HIP_NBUF]; DevJob *d_jobs; DevJob *h_jobs; int jobs_cap;   // d_jobs = d_jobs2[parity of the call]
+    // (device tables and page-locked stagings in rotation: a caller may queue VP8HIP_NBUF launches before it has to wait for the
+    // device to have taken the first one's table -- behind an entropy launch of a quarter of a second, say)
+    DevJob *d_jobs2[VP8HIP_NBUF]; DevJob *h_jobs2[VP8HIP_NBUF]; DevJob *d_jobs; DevJob *h_jobs; int jobs_cap;   // d_jobs / h_jobs = those of the call
     // launch configuration
     int num_cu, max_lds;
     int recon_nw, lf_nw;

@@ -115,14 +115,19 @@ extern "C" int vp8hip_decode(vp8hip_ctx *c, const vp8hip_job *jobs, int njobs, i
     if (njobs > c->jobs_cap) {
         // the staging arrays are reused by in-flight launches: drain before growing
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        for (int k = 0; k < VP8HIP_NBUF; k++) if (c->d_jobs2[k]) (void)hipFree(c->d_jobs2[k]);
-        if (c->h_jobs) (void)hipHostFree(c->h_jobs);
+        for (int k = 0; k < VP8HIP_NBUF; k++) {
+            if (c->d_jobs2[k]) (void)hipFree(c->d_jobs2[k]);
+            if (c->h_jobs2[k]) (void)hipHostFree(c->h_jobs2[k]);
+            c->d_jobs2[k] = nullptr; c->h_jobs2[k] = nullptr;
+        }
         c->jobs_cap = njobs < 64 ? 64 : njobs;
-        for (int k = 0; k < VP8HIP_NBUF; k++) HIPCHK(c, hipMalloc((void **)&c->d_jobs2[k], sizeof(DevJob) * c->jobs_cap));
-        HIPCHK(c, hipHostMalloc((void **)&c->h_jobs, sizeof(DevJob) * c->jobs_cap, hipHostMallocDefault));
+        for (int k = 0; k < VP8HIP_NBUF; k++) {
+            HIPCHK(c, hipMalloc((void **)&c->d_jobs2[k], sizeof(DevJob) * c->jobs_cap));
+            HIPCHK(c, hipHostMalloc((void **)&c->h_jobs2[k], sizeof(DevJob) * c->jobs_cap, hipHostMallocDefault));
+        }
     } else {
-        // h_jobs is read by an async copy of the previous call; wait for that copy only
-        HIPCHK(c, hipEventSynchronize(c->ev_jobs));
+        // this call's staging was read by the copy of the call VP8HIP_NBUF calls ago; wait for that copy only
+        HIPCHK(c, hipEventSynchronize(c->ev_jobs2[c->parity]));
     }
     const int nfb = (int)c->fb.size(), nsl = (int)c->slots.size();
     bool any_lf = false;
@@ -163,7 +168,7 @@ extern "C" int vp8hip_decode(vp8hip_ctx *c, const vp8hip_job *jobs, int njobs, i
         if (pool && vp8hip_raster_pool(c)) return -1;
         if (!need.empty() && vp8hip_need_raster_list(c, need.data(), (int)need.size())) return -1;
     }
-    c->d_jobs = c->d_jobs2[par];
+    c->d_jobs = c->d_jobs2[par]; c->h_jobs = c->h_jobs2[par];
     for (int i = 0; i < njobs; i++) {
         const vp8hip_job &j = jobs[i];
         const Slot &s = c->slots[j.ir_slot];
@@ -190,7 +195,7 @@ extern "C" int vp8hip_decode(vp8hip_ctx *c, const vp8hip_job *jobs, int njobs, i
         if (hit) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_d2h_done, 0));
     }
     HIPCHK(c, hipMemcpyAsync(c->d_jobs, c->h_jobs, sizeof(DevJob) * njobs, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipEventRecord(c->ev_jobs, c->stream));
+    HIPCHK(c, hipEventRecord(c->ev_jobs2[par], c->stream));
 
     const int wg_per_cu = K.wg_per_cu >= 1 && K.wg_per_cu <= 8 ? K.wg_per_cu : 1;
     const int grid = njobs < c->num_cu * wg_per_cu ? njobs : c->num_cu * wg_per_cu;

@@ -547,7 +547,9 @@ int main(int argc, char **argv)
         {   /* a batch's bytes at most: the frames are taken in order of size within windows of SORT_WINDOW batches */
             g_order = (long *)malloc(sizeof(long) * (size_t)total);
             for (long k = 0; k < total; k++) g_order[k] = k;
-            const long window = (long)SORT_WINDOW * g_batch > 4L * unit ? (long)SORT_WINDOW * g_batch : 4L * unit;
+            /* (whole launches: a launch that straddles two windows would get the smallest frames of one and the largest of the next) */
+            long window = ((long)SORT_WINDOW * g_batch + unit - 1) / unit * unit;
+            if (window < 4L * unit) window = 4L * unit;
             for (long w0 = 0; w0 < total; w0 += window) {
                 const long wn = total - w0 < window ? total - w0 : window;
                 qsort(g_order + w0, (size_t)wn, sizeof(long), by_size_desc);
@@ -622,8 +624,11 @@ int main(int argc, char **argv)
         size_t bytes = place_frames(&cur);
         task_start(&parse_t, 0, export_one, &cur, cur.n);
         batch_ref prev_launch_ref = { -1, 0, 0 };
+        const int trace = getenv("VP8BATCH_TRACE") != NULL;          /* where the main thread's time goes, launch by launch */
         for (long done = 0; done < total; L++) {
+            const double tw0 = now_s();
             task_wait(&parse_t, 0);
+            if (trace) fprintf(stderr, "launch %ld: at %.3f s, waited %.3f s for the headers\n", L, tw0 - t0, now_s() - tw0);
             if (g_failed) DIE("a frame of launch %ld failed to parse", L);
             const batch_ref now = cur;
             done += now.n;
@@ -662,7 +667,9 @@ int main(int argc, char **argv)
                    next launch, which is most of the time.  The launch before has come back by now: its page-locked set is free
                    for the headers of the next one */
                 if (prev_launch_ref.b >= 0) {
+                    const double tw1 = now_s();
                     HIP(vp8hip_download_wait(g_hip));
+                    if (trace) fprintf(stderr, "launch %ld: queued at %.3f s, waited %.3f s for the digests of the launch before\n", L, tw1 - t0, now_s() - tw1);
                     take_digests(&prev_launch_ref);
                     prev_launch = L - 1;
                     TAKE_PENDING();
