@@ -41,6 +41,7 @@ struct Slot {
 //   VP8HIP_SIMT_LGG=1..6       lane-per-row kernels: lanes per strand (log2); VP8HIP_SIMT_WAVES=n  at most n waves per launch
 //   VP8HIP_WG_PER_CU, VP8HIP_XCU, VP8HIP_XCU_S, VP8HIP_XCU_NW, VP8HIP_RECON_NW, VP8HIP_LF_NW   wave-per-row family shapes
 //   VP8HIP_EAGER_RASTER=1      large launches produce the raster form of their frames at once (default: when something asks for it)
+//   VP8HIP_D2H_STREAMS=1..4    a batch download goes in that many pieces on streams of their own (default 2)
 //   VP8HIP_DIRECT_DOWNLOAD=0   batch downloads of tiled frames go through the raster form in HBM and a copy (default: the tiled ->
 //                              raster pass writes the page-locked destination itself); VP8HIP_DOWNLOAD_BLOCKS=n  its workgroups
 //   VP8HIP_INTER_SPLIT=N       launches of up to N frames with inter frames among them run vp8_inter_mb_kernel first (default 384; 0:
@@ -48,7 +49,7 @@ struct Slot {
 //                              ms; 128: 1.56 -> 1.45) and costs throughput in launches that fill the chip anyway (512: 3.82 -> 4.03)
 struct Knobs {
     int recon_force;       // 0 automatic, 1 lane-per-row, 2 wave-per-row
-    int inter_split, eager_raster, direct_download, download_blocks, d2h_prio;
+    int inter_split, eager_raster, direct_download, download_blocks, d2h_prio, d2h_streams;
     int lgG, simt_waves, wg_per_cu, xcu, xcu_S, xcu_NW, recon_nw, lf_nw;
 };
 
@@ -101,6 +102,7 @@ struct vp8hip_ctx {
     // batch download of whole frame buffers on a stream of its own (vp8hip_frames_download_async): PCIe is full duplex, the next
     // batch's uploads run beside it
     hipStream_t stream_d2h;
+    hipStream_t stream_d2h_more[3]; hipEvent_t ev_d2h_more[3];      // a batch download in up to four pieces on streams of their own (a copy engine each)
     hipEvent_t ev_d2h_from, ev_d2h_done;
     int d2h_first, d2h_count;      // frame buffers of the copy in flight (count 0: none)
     uint8_t *d_md5; int md5_cap;   // vp8hip_frames_fetch_async: the batch's digests on the device
