@@ -224,18 +224,29 @@ def batch_md5_probe(fixture, device, loops=205, extra=()):
 
 
 def streams_probe(device, streams=4096, fixture="p_1920x1080"):
-    """Inter-frame streams side by side with the entropy decoder on the device (tools/streams_probe.py): `streams` copies of the
-    fixture (a key frame and nine P frames), a launch per position, only the frame headers read on the host; every shown frame of
-    every stream hashed on the device and compared with the reference decoder's listing."""
+    """Inter-frame streams side by side with the entropy decoder on the device (bin/batch_md5 --streams): `streams` copies of the
+    fixture (a key frame and nine P frames), a launch per position, only the frame headers read on the host, a stream's frames
+    through one IR slot and four frame buffers; every shown frame of every stream hashed on the device and compared with the
+    reference decoder's listing."""
     import re
+    import tempfile
+    tool = os.path.join(ROOT, "libvpx.opencl_amd", "bin", "batch_md5")
+    ivf = os.path.join(ROOT, "tests", "golden", fixture + ".ivf")
+    gold = [l.split()[0] for l in open(os.path.join(ROOT, "tests", "golden", fixture + ".md5")).read().splitlines()]
     env = dict(os.environ, VP8HIP_DEVICE=str(device))
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "streams_probe.py"), str(streams), fixture, "device"], capture_output=True,
-                       text=True, env=env, timeout=300)
-    m = re.search(r"(\d+) frames each, entropy decode on the device: ([0-9.]+) s = (\d+) frames/s = ([0-9.]+) Gpix/s.*differing from the reference's: (\d+)", r.stdout)
-    if r.returncode or not m:
-        return {"error": (r.stderr or r.stdout)[-300:]}
-    return {"tool": "tools/streams_probe.py %d %s device" % (streams, fixture), "streams": streams, "frames_per_stream": int(m.group(1)),
-            "seconds": float(m.group(2)), "frames_per_s": int(m.group(3)), "Mpix_s": round(float(m.group(4)) * 1e3, 1), "md5_mismatches": int(m.group(5))}
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "o.md5")
+        r = subprocess.run([tool, "--streams", str(streams), ivf, out], capture_output=True, text=True, env=env, timeout=300)
+        if r.returncode:
+            return {"error": r.stderr[-300:]}
+        got = [l.split()[0] for l in open(out).read().splitlines()]
+    bad = sum(1 for i, g in enumerate(got) if g != gold[i % len(gold)]) + abs(len(got) - streams * len(gold))
+    m = re.search(r"(\d+) frames in ([0-9.]+) s: ([0-9.]+) frames/s, ([0-9.]+) Mpix/s \((\d+) streams of (\d+) frames side by side.*; (\d+) corrupt\)", r.stderr)
+    if not m:
+        return {"error": "unparsed: " + r.stderr[-200:]}
+    return {"tool": "bin/batch_md5 --streams %d %s.ivf" % (streams, fixture), "streams": int(m.group(5)), "frames_per_stream": int(m.group(6)),
+            "seconds": float(m.group(2)), "frames_per_s": float(m.group(3)), "Mpix_s": float(m.group(4)), "md5_mismatches": bad,
+            "corrupt_frames": int(m.group(7))}
 
 
 def load_stream(P, ctx, fixture, F, lo):
@@ -346,7 +357,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--frames", type=int, default=0,
-                    help="frames per GPU per step (default: 8192 for 1080p, 2048 for 4k: IR, tiled scratch and frame buffers "
+                    help="frames per GPU per step (default: 8192 for 1080p, 4096 for 4k: IR, tiled scratch and frame buffers "
                          "resident in HBM; the lane-per-row kernels want several frames per wave on each of the chip's 1024 SIMDs)")
     ap.add_argument("--workload", default="1080p", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -385,7 +396,7 @@ def main():
     P = load_package()
     from libvpx_opencl_amd import sharding
     fixture, W, H = WORKLOADS[args.workload]
-    F = args.frames or {"1080p": 8192, "4k": 2048}[args.workload]
+    F = args.frames or {"1080p": 8192, "4k": 4096}[args.workload]
     gold = golden_md5(fixture)
 
     # ---- the stream: world * F frames, frame i = source frame i mod nsrc; rank r decodes the contiguous block
@@ -650,7 +661,7 @@ def main():
             # BASELINE configs[4]'s stream on one GPU: 3840x2160 all-key-frame, same path, measured the same way
             try:
                 fx4, W4, H4 = WORKLOADS["4k"]
-                F4 = 2048
+                F4 = 4096            # (two frames per strand at 32 lanes a strand: 270 macroblock rows, 8.4 rounds; 2048 frames: 4.2 rounds, five run)
                 c4 = P.Vp8Hip(local_rank)
                 c4.configure(W4, H4, F4, F4)
                 ns4, _ = load_stream(P, c4, fx4, F4, 0)
@@ -661,7 +672,8 @@ def main():
                         j4[i].ref_fb[k] = -1
                 g4 = golden_md5(fx4)
                 c4.decode_array(j4, F4, P.STAGE_ALL); c4.sync()
-                ok4 = all(P.planes_md5(*c4.download_planes(i)) == g4[i % ns4] for i in (0, 1, 2, 777, F4 // 2, F4 - 1))
+                # (hashed as the launch left them, as tiles: the raster pool of 4096 4K frame buffers -- 53 GB -- is never allocated)
+                ok4 = all(c4.frames_md5(i, 1)[0] == g4[i % ns4] for i in (0, 1, 2, 777, F4 // 2, F4 - 1))
 
                 def b4():
                     torch.cuda.synchronize()
