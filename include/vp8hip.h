@@ -93,6 +93,10 @@ int  vp8hip_configure(vp8hip_ctx *ctx, int width, int height, int num_fb, int nu
 int  vp8hip_configure_pooled(vp8hip_ctx *ctx, int width, int height, int num_fb, int num_slots, size_t pool_bytes);
 int  vp8hip_pool_reset(vp8hip_ctx *ctx);
 int  vp8hip_pool_usage(vp8hip_ctx *ctx, size_t *used_bytes, size_t *pool_bytes);
+/* The two forms' pools are allocated when a launch or a reader first needs them (the tiled forms with the first large launch, the
+ * raster forms with the first small launch, inter frame, download or filter); vp8hip_reserve allocates them now -- beside a first
+ * launch of the entropy decoder, for instance: tens of GB take the allocator a second or two. */
+int  vp8hip_reserve(vp8hip_ctx *ctx, int tiled_form, int raster_form);
 int  vp8hip_geometry(const vp8hip_ctx *ctx, vp8ir_geom *g);
 
 /* Pinned host staging of a slot in the device form, for a feeder to write into directly (vp8_parser_decode_mbs_compact): mbx[nmb],

@@ -664,7 +664,7 @@ extern "C" int vp8hip_frames_fetch_async(vp8hip_ctx *c, int first_fb, int count,
         HIPCHK(c, hipMemcpyAsync(digests, c->d_md5, 16 * (size_t)count, hipMemcpyDeviceToHost, c->stream_d2h));
     }
     HIPCHK(c, hipEventRecord(c->ev_d2h_done, c->stream_d2h));
-    c->d2h_first = first_fb; c->d2h_count = count;
+    c->d2h_first = first_fb; c->d2h_count = count; c->d2h_listed = false;
     return 0;
 }
 
@@ -733,8 +733,11 @@ extern "C" int vp8hip_frames_md5_list_async(vp8hip_ctx *c, const int *fbs, int n
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(digests, c->d_md5, 16 * (size_t)n, hipMemcpyDeviceToHost, c->stream_d2h));
     HIPCHK(c, hipEventRecord(c->ev_d2h_done, c->stream_d2h));
-    // (a launch that writes ANY frame buffer waits for this fetch: the list may name any of them)
+    // (a launch that writes one of the listed frame buffers waits for this fetch)
     c->d2h_first = 0; c->d2h_count = (int)c->fb.size();
+    c->d2h_mask.assign(c->fb.size(), (uint8_t)0);
+    for (int i = 0; i < n; i++) c->d2h_mask[(size_t)fbs[i]] = 1;
+    c->d2h_listed = true;
     return 0;
 }
 

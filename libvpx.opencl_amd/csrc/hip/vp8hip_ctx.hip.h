@@ -105,6 +105,7 @@ struct vp8hip_ctx {
     hipStream_t stream_d2h_more[3]; hipEvent_t ev_d2h_more[3];      // a batch download in up to four pieces on streams of their own (a copy engine each)
     hipEvent_t ev_d2h_from, ev_d2h_done;
     int d2h_first, d2h_count;      // frame buffers of the copy in flight (count 0: none)
+    std::vector<uint8_t> d2h_mask; bool d2h_listed;     // ... of a fetch by list (vp8hip_frames_md5_list_async): a flag per frame buffer
     uint8_t *d_md5; int md5_cap;   // vp8hip_frames_fetch_async: the batch's digests on the device
     int *d_md5_idx, *h_md5_idx; int md5_idx_cap;    // vp8hip_frames_md5_list_async: which frame buffers
     size_t fb_stride;

@@ -107,6 +107,34 @@ static Regime launch_regime(const vp8hip_ctx *c, int njobs, int stages, bool all
     return !lane ? WAVE_PER_ROW : all_key ? LANE_KEY : LANE_INTER;
 }
 
+// the tiled forms of all frame buffers, with the first large launch: tile_frame bytes each (one tile per macroblock and one more
+// per macroblock row, 32 bytes of unfiltered line per tile behind them: vp8_keyframe_simt.hip), + 8 KB: the dummy tile idle lanes
+// write, and room for the kernels' prefetches past the last tile
+static int tile_pool(vp8hip_ctx *c)
+{
+    if (c->tile_block) return 0;
+    const int nfb = (int)c->fb.size();
+    if (hipMalloc((void **)&c->tile_block, c->tile_frame * (size_t)nfb + 8192) != hipSuccess) {
+        (void)hipGetLastError();
+        c->tile_block = nullptr;
+        return fail(c, -1, "no device memory for the tiled form of %d frame buffers (%zu MB)", nfb, c->tile_frame * (size_t)nfb >> 20);
+    }
+    c->fb_tiles.resize((size_t)nfb);
+    for (int i = 0; i < nfb; i++) c->fb_tiles[(size_t)i] = c->tile_block + c->tile_frame * (size_t)i;
+    return 0;
+}
+
+// (include/vp8hip.h) the pools a pipeline is going to need, now -- while a first launch that needs neither is running, say: tens of
+// GB take the allocator a second or two
+extern "C" int vp8hip_reserve(vp8hip_ctx *c, int tiled_form, int raster_form)
+{
+    if (!c || !c->width) return fail(c, -2, "vp8hip_reserve: context not configured");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (tiled_form && tile_pool(c)) return -1;
+    if (raster_form && vp8hip_raster_pool(c)) return -1;
+    return 0;
+}
+
 extern "C" int vp8hip_decode(vp8hip_ctx *c, const vp8hip_job *jobs, int njobs, int stages)
 {
     if (!c || !jobs || njobs <= 0) return fail(c, -2, "vp8hip_decode: bad arguments");
@@ -142,14 +170,7 @@ extern "C" int vp8hip_decode(vp8hip_ctx *c, const vp8hip_job *jobs, int njobs, i
     for (int i = 0; i < njobs; i++)
         if (jobs[i].ir_slot < 0 || jobs[i].ir_slot >= nsl || jobs[i].dst_fb < 0 || jobs[i].dst_fb >= nfb)
             return fail(c, -2, "vp8hip_decode: job %d has slot %d / fb %d out of range", i, jobs[i].ir_slot, jobs[i].dst_fb);
-    if (tiled && !c->tile_block) {
-        // the tiled forms of all frame buffers, with the first large launch: tile_frame bytes each (one tile per macroblock and
-        // one more per macroblock row, 32 bytes of unfiltered line per tile behind them: vp8_keyframe_simt.hip), + 8 KB: the dummy
-        // tile idle lanes write, and room for the kernels' prefetches past the last tile
-        HIPCHK(c, hipMalloc((void **)&c->tile_block, c->tile_frame * (size_t)nfb + 8192));
-        c->fb_tiles.resize((size_t)nfb);
-        for (int i = 0; i < nfb; i++) c->fb_tiles[(size_t)i] = c->tile_block + c->tile_frame * (size_t)i;
-    }
+    if (tiled && tile_pool(c)) return -1;
     {
         // what this launch reads as raster: its reference frames (inter prediction reads the raster form, borders included), and
         // -- a wave-per-row launch of the loop filter alone -- the frames it filters in place
@@ -191,7 +212,8 @@ extern "C" int vp8hip_decode(vp8hip_ctx *c, const vp8hip_job *jobs, int njobs, i
     }
     if (c->d2h_count) {      // a batch download still in flight: a launch that writes one of its frame buffers waits for it
         bool hit = false;
-        for (int i = 0; i < njobs && !hit; i++) hit = jobs[i].dst_fb >= c->d2h_first && jobs[i].dst_fb < c->d2h_first + c->d2h_count;
+        for (int i = 0; i < njobs && !hit; i++)
+            hit = c->d2h_listed ? c->d2h_mask[(size_t)jobs[i].dst_fb] != 0 : jobs[i].dst_fb >= c->d2h_first && jobs[i].dst_fb < c->d2h_first + c->d2h_count;
         if (hit) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_d2h_done, 0));
     }
     HIPCHK(c, hipMemcpyAsync(c->d_jobs, c->h_jobs, sizeof(DevJob) * njobs, hipMemcpyHostToDevice, c->stream));

@@ -419,6 +419,7 @@ static int run_streams(int S_total, int threads, int gpus, int argc, char **argv
         task_wait(&parse_t, 0);
         if (g_failed) DIE("a frame header of position %d failed to parse", t + 1);
         HIP(vp8hip_entropy_decode(g_hip, 0, S, st.ent[t & 1], st.arena[t & 1], bytes));
+        if (t == 0) HIP(vp8hip_reserve(g_hip, S > 512, 1));       /* (the frame buffers' pools, while the first launch -- key frames: the long one -- runs) */
         /* (status and digests of position t - 1 are taken below, before their page-locked sets come round again at t + 1) */
         for (int s = 0; s < S; s++) {
             const vp8_refs *r = &st.refs[s];
@@ -635,6 +636,7 @@ int main(int argc, char **argv)
             HIP(vp8hip_pool_reset(g_hip));               /* (on the stream: behind the pixel path of the launch before) */
             HIP(vp8hip_entropy_decode(g_hip, 0, now.n, g_ent[now.b & 1], g_ent_data[now.b & 1], bytes));
             HIP(vp8hip_entropy_status_async(g_hip, now.n, g_ent_status[now.b & 1]));
+            if (L == 0) HIP(vp8hip_reserve(g_hip, 1, !no_download));     /* (the frame buffers' pools, while the first launch runs) */
             pend[now.b & 1].valid = 1; pend[now.b & 1].n = now.n; pend[now.b & 1].first = now.first; pend[now.b & 1].launch = L;
             for (int at = 0; at < now.n; at += g_batch, part_no++) {
                 const batch_ref part = { (int)(part_no & 0x3fffffff), now.n - at < g_batch ? now.n - at : g_batch, now.first + at };
