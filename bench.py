@@ -357,7 +357,8 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--frames", type=int, default=0,
-                    help="frames per GPU per step (default: 8192 for 1080p, 4096 for 4k: IR, tiled scratch and frame buffers "
+                    help="frames per GPU per step (default: 16384 for 1080p, 4096 for 4k -- two frames per strand of the lane-per-row "
+                         "launch: 136 macroblock rows are 17 whole rounds of 8 lanes, 270 are 8.4 of 32; IR, tiled scratch and frame buffers "
                          "resident in HBM; the lane-per-row kernels want several frames per wave on each of the chip's 1024 SIMDs)")
     ap.add_argument("--workload", default="1080p", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -396,7 +397,7 @@ def main():
     P = load_package()
     from libvpx_opencl_amd import sharding
     fixture, W, H = WORKLOADS[args.workload]
-    F = args.frames or {"1080p": 8192, "4k": 4096}[args.workload]
+    F = args.frames or {"1080p": 16384, "4k": 4096}[args.workload]
     gold = golden_md5(fixture)
 
     # ---- the stream: world * F frames, frame i = source frame i mod nsrc; rank r decodes the contiguous block
