@@ -118,12 +118,13 @@ def cpu_baseline(fixture, budget_s=12.0):
 
 
 
-def inter_frame_probe(P, device, n=4096, name="p_dense_1920x1080", k=2):
+def inter_frame_probe(P, device, n=8192, name="p_dense_1920x1080", k=2):
     """BASELINE configs[2] beside the headline: six-tap motion compensation + IDCT + loop filter on REAL inter frames.
     The stream is decoded the normal way up to frame k-1; then n jobs decode frame k, every one from its OWN copy of the
     IR (vp8hip_ir_copy) and its OWN copies of the three reference buffers (vp8hip_frame_copy) into its own frame buffer
     -- n independent streams in lock step, nothing shared in cache -- and one of them is compared with the reference MD5.
-    Roofline by SURVEY 8(d): 2407 B/MB for the full inter path (833 residual + 768 prediction + 770 loop filter + 36)."""
+    Roofline by SURVEY 8(d): 2407 B/MB for the full inter path (833 residual + 768 prediction + 770 loop filter + 36).
+    8192 jobs: a frame per strand of 8 lanes (68 macroblock rows: 8.5 rounds, nine run; 4096 jobs: 16 lanes, 4.25 rounds, five run)."""
     from vp8_testlib import ivf_path, golden_md5
     w, h, frames = P.read_ivf(ivf_path(name))
     gold = golden_md5(name)
@@ -234,19 +235,27 @@ def streams_probe(device, streams=4096, fixture="p_1920x1080"):
     ivf = os.path.join(ROOT, "tests", "golden", fixture + ".ivf")
     gold = [l.split()[0] for l in open(os.path.join(ROOT, "tests", "golden", fixture + ".md5")).read().splitlines()]
     env = dict(os.environ, VP8HIP_DEVICE=str(device))
+    pat = (r"(\d+) frames in ([0-9.]+) s: ([0-9.]+) frames/s, ([0-9.]+) Mpix/s \((\d+) streams of (\d+) frames side by side.*; (\d+) corrupt\)")
+    first = None
     with tempfile.TemporaryDirectory() as d:
         out = os.path.join(d, "o.md5")
-        r = subprocess.run([tool, "--streams", str(streams), ivf, out], capture_output=True, text=True, env=env, timeout=300)
-        if r.returncode:
-            return {"error": r.stderr[-300:]}
+        # (the streams are ten frames long: a run is two seconds, of which the allocator takes one to three tenths on a device that
+        # has just done the same and up to three seconds on a cold one -- both runs are reported, the second is the figure)
+        for attempt in range(2):
+            r = subprocess.run([tool, "--streams", str(streams), ivf, out], capture_output=True, text=True, env=env, timeout=300)
+            if r.returncode:
+                return {"error": r.stderr[-300:]}
+            if attempt == 0:
+                m0 = re.search(pat, r.stderr)
+                first = float(m0.group(3)) if m0 else None
         got = [l.split()[0] for l in open(out).read().splitlines()]
     bad = sum(1 for i, g in enumerate(got) if g != gold[i % len(gold)]) + abs(len(got) - streams * len(gold))
-    m = re.search(r"(\d+) frames in ([0-9.]+) s: ([0-9.]+) frames/s, ([0-9.]+) Mpix/s \((\d+) streams of (\d+) frames side by side.*; (\d+) corrupt\)", r.stderr)
+    m = re.search(pat, r.stderr)
     if not m:
         return {"error": "unparsed: " + r.stderr[-200:]}
     return {"tool": "bin/batch_md5 --streams %d %s.ivf" % (streams, fixture), "streams": int(m.group(5)), "frames_per_stream": int(m.group(6)),
             "seconds": float(m.group(2)), "frames_per_s": float(m.group(3)), "Mpix_s": float(m.group(4)), "md5_mismatches": bad,
-            "corrupt_frames": int(m.group(7))}
+            "corrupt_frames": int(m.group(7)), "frames_per_s_of_the_run_before_on_a_cold_device": first}
 
 
 def load_stream(P, ctx, fixture, F, lo):

@@ -1,7 +1,8 @@
 #!/bin/bash
 # The profile set of a round (run on the GPU box: gpurun -- 'bash tools/profile_round.sh r04_a'), written to gpurun_out/<tag>/ with
 # the summaries that are to be judged copied to gpurun_out/<tag>/for_profiles/ (copy those into profiles/ and commit them):
-#   1. kernel-trace stats of the bench command (short form) and of bin/batch_md5 --device-entropy
+#   1. kernel-trace stats of the bench command (short form) and of bin/batch_md5 --device-entropy --entropy-batch 24576 (and of
+#      bin/batch_md5 --streams 4096)
 #   2. TCC traffic passes (FETCH_SIZE, WRITE_SIZE: separate runs) of ONE launch at the benchmark's occupancy (tools/pmc_one.py),
 #      of the launch followed by the raster form of its frames, and of the inter-frame launch; -> traffic_per_mb.json, which
 #      bench.py reads (profiles/traffic_per_mb.json)
@@ -14,11 +15,12 @@ cd /tmp; export TMPDIR=/tmp
 B="--steps 10 --warmup 2 --no-inter-probe --no-4k-probe --no-end-to-end --no-cpu-baseline"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_bench -- python3 $R/bench.py $B > $O/kt_bench.json 2> $O/kt_bench.err; echo "kt_bench rc=$?" >> $O/summary.txt
 timeout 600 python3 $R/bench.py $B > $O/unprofiled_bench.json 2> $O/unprofiled.err; echo "unprofiled rc=$?" >> $O/summary.txt
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_batch_md5 -- $R/libvpx.opencl_amd/bin/batch_md5 --device-entropy --no-download --batch 8192 --loop 4096 $R/tests/golden/kf_1920x1080.ivf /tmp/o.md5 > $O/kt_batch_md5.log 2>&1; echo "kt_batch_md5 rc=$?" >> $O/summary.txt
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_batch_md5 -- $R/libvpx.opencl_amd/bin/batch_md5 --device-entropy --no-download --batch 8192 --entropy-batch 24576 --loop 12288 $R/tests/golden/kf_1920x1080.ivf /tmp/o.md5 > $O/kt_batch_md5.log 2>&1; echo "kt_batch_md5 rc=$?" >> $O/summary.txt
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_inter -- python3 $R/bench.py --steps 2 --warmup 1 --no-4k-probe --no-end-to-end --no-cpu-baseline > $O/kt_inter.json 2> $O/kt_inter.err; echo "kt_inter rc=$?" >> $O/summary.txt
-for n in kt_bench kt_batch_md5 kt_inter; do f=$(find $O/$n -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/for_profiles/${TAG}_${n}_kernel_stats.csv; done
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_streams -- $R/libvpx.opencl_amd/bin/batch_md5 --streams 4096 $R/tests/golden/p_1920x1080.ivf /tmp/o.md5 > $O/kt_streams.log 2>&1; echo "kt_streams rc=$?" >> $O/summary.txt
+for n in kt_bench kt_batch_md5 kt_inter kt_streams; do f=$(find $O/$n -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/for_profiles/${TAG}_${n}_kernel_stats.csv; done
 cp $O/kt_bench.json $O/for_profiles/${TAG}_kt_bench.json; cp $O/unprofiled_bench.json $O/for_profiles/${TAG}_unprofiled_bench.json
-cp $O/kt_batch_md5.log $O/for_profiles/${TAG}_kt_batch_md5.log; cp $O/kt_inter.json $O/for_profiles/${TAG}_kt_inter.json
+grep -v "rocprofv3\|^[EWI]2" $O/kt_batch_md5.log > $O/for_profiles/${TAG}_kt_batch_md5.log; grep -v "rocprofv3\|^[EWI]2" $O/kt_streams.log > $O/for_profiles/${TAG}_kt_streams.log; cp $O/kt_inter.json $O/for_profiles/${TAG}_kt_inter.json
 pmc() {  # name frames lgg extra-args counters...
     local name=$1 nf=$2 lgg=$3 extra=$4; shift; shift; shift; shift
     VP8HIP_SIMT_LGG=$lgg timeout 300 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $O/$name -- python3 $R/tools/pmc_one.py 7 $nf kf_1920x1080 $extra > $O/$name.log 2>&1
