@@ -42,6 +42,15 @@ def _export(P, frames):
     return out
 
 
+def _configure(ctx, w, h, nfb, nslots, pooled):
+    """pooled: slots without block streams of their own + a pool that holds every slot's worst case (vp8hip_configure_pooled)"""
+    if pooled:
+        cols, nmb = (w + 15) // 16, ((w + 15) // 16) * ((h + 15) // 16)
+        ctx.configure_pooled(w, h, nfb, nslots, nslots * nmb * 24 * 32 + (nslots + 3) * 4 * cols * 24 * 32)
+    else:
+        ctx.configure(w, h, nfb, nslots)
+
+
 def _compare(ctx, slot, mbs, coef, what):
     dm, dc = ctx.ir_fetch(slot)
     bad = np.nonzero((dm != mbs).any(axis=1))[0]
@@ -129,8 +138,8 @@ def test_written_streams():
         ctx.close()
 
 
-@pytest.mark.parametrize("name", ["kf_640x360", "kf_8part_1920x1080"])
-def test_frames_cut_short(name):
+@pytest.mark.parametrize("name,pooled", [("kf_640x360", False), ("kf_8part_1920x1080", False), ("kf_640x360", True), ("kf_8part_1920x1080", True)])
+def test_frames_cut_short(name, pooled):
     """A frame that ends early -- in the last token partition, in an earlier one, in the first partition -- gives the IR and the
     corrupt flag the host feeder gives (zeros are read past the end, as the reference does: dboolhuff.c:44-60; no tokens once a
     partition has run out: decodframe.c:119-130), next to whole frames in the same launch; a frame whose header does not fit is
@@ -161,7 +170,7 @@ def test_frames_cut_short(name):
         ph.close(); pd.close()
     assert len(kept) >= 4           # (with several partitions only cuts inside the last one pass the partition table)
     ctx = P.Vp8Hip()
-    ctx.configure(w, h, 1, len(kept))
+    _configure(ctx, w, h, 1, len(kept), pooled)
     st = ctx.entropy_decode(0, efs, kept)
     assert [int(s) & 1 for s in st] == [int(bool(c)) for _, _, c in host]
     assert st[0] == 0 and st[-1] == 0 and st.any()
@@ -318,8 +327,9 @@ def test_streams_side_by_side(name, mode):
     assert "digests differing from the reference's: 0" in r.stdout, r.stdout
 
 
-@pytest.mark.parametrize("name,index", [("kf_640x360", 1), ("p_lowrate_640x360", 3), ("p_split_352x288", 5)])
-def test_damaged_payloads(name, index):
+@pytest.mark.parametrize("name,index,pooled", [("kf_640x360", 1, False), ("p_lowrate_640x360", 3, False), ("p_split_352x288", 5, False),
+                                               ("kf_640x360", 1, True), ("p_lowrate_640x360", 3, True)])
+def test_damaged_payloads(name, index, pooled):
     """Random damage behind the frame header (bytes overwritten, bytes flipped, the tail cut): whatever the bits then say -- modes,
     vectors, runs of large coefficients, partitions that end early -- the device reads what the host feeder reads: same IR, same
     vectors, same corrupt flag, all frames of the launch side by side."""
@@ -368,7 +378,7 @@ def test_damaged_payloads(name, index):
             ph.close(); pd.close()
     assert len(kept) >= 12
     ctx = P.Vp8Hip()
-    ctx.configure(w, h, 1, len(kept))
+    _configure(ctx, w, h, 1, len(kept), pooled)
     st = ctx.entropy_decode(0, efs, kept)
     assert [int(s) & 1 for s in st] == [int(bool(c)) for *_, c in host]
     for i, (hh, mbs, coef, mvs, _) in enumerate(host):

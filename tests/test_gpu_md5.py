@@ -96,3 +96,39 @@ def test_message_tails(pkg, w, h):
         assert ctx.frames_md5(0, 2) == want
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("pieces", ["1", "2", "4"])
+def test_batch_download_in_pieces(pkg, pieces, monkeypatch):
+    """A batch download of 64 frames or more goes in VP8HIP_D2H_STREAMS pieces, each on a stream of its own (default 2): the same
+    bytes land, and the wait covers all of them.  vp8hip_reserve allocates both frame-buffer pools ahead; nothing else changes."""
+    import ctypes
+    monkeypatch.setenv("VP8HIP_D2H_STREAMS", pieces)
+    P = pkg
+    ctx = P.Vp8Hip(0)
+    try:
+        w, h, frames = P.read_ivf(ivf_path("kf_640x360"))
+        n = 13 * len(frames)
+        ctx.configure(w, h, n, len(frames))
+        L = ctx.L
+        L.vp8hip_reserve.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+        ctx._chk(L.vp8hip_reserve(ctx.h, 1, 1), "vp8hip_reserve")
+        parser = P.Parser()
+        for i, data in enumerate(frames):
+            hdr = ctx.parse_into_slot(parser, data, i)
+            parser.swap(hdr)
+            ctx.upload(i)
+        parser.close()
+        ctx.decode([(i % len(frames), i, None) for i in range(n)], P.STAGE_ALL)
+        L.vp8hip_frame_stride.restype = ctypes.c_size_t
+        L.vp8hip_frame_stride.argtypes = [ctypes.c_void_p]
+        L.vp8hip_frames_fetch_async.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+        L.vp8hip_download_wait.argtypes = [ctypes.c_void_p]
+        stride = L.vp8hip_frame_stride(ctx.h)
+        got = np.zeros((n, stride), np.uint8)
+        ctx._chk(L.vp8hip_frames_fetch_async(ctx.h, 0, n, got.ctypes.data, None), "fetch")
+        ctx._chk(L.vp8hip_download_wait(ctx.h), "wait")
+        gold = golden_md5("kf_640x360")
+        assert [P.frame_md5(got[i], ctx.g, w, h) for i in range(n)] == [gold[i % len(frames)] for i in range(n)]
+    finally:
+        ctx.close()
