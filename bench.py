@@ -722,7 +722,7 @@ def main():
             probe("c_host", lambda: batch_md5_probe(fixture, local_rank))
             # ... and with the macroblocks' modes and tokens decoded on the GPU, a frame per lane (vp8hip_entropy_decode): the host
             # reads the frame headers only
-            probe("device_entropy", lambda: batch_md5_probe(fixture, local_rank, 12288, ("--device-entropy", "--batch", "4096", "--entropy-batch", "24576")))
+            probe("device_entropy", lambda: batch_md5_probe(fixture, local_rank, 24576, ("--device-entropy", "--batch", "8192", "--entropy-batch", "24576")))
             # (24,576 frames per entropy launch: what the device holds at once, 32 lanes a wave and three waves a CU; their blocks out
             # of one pool, vp8hip_configure_pooled; 737,280 frames: thirty launches, the start-up's allocations -- 1 to 4 s -- included)
             probe("device_entropy_frames_stay", lambda: batch_md5_probe(
