@@ -231,6 +231,14 @@ int  vp8hip_download_wait(vp8hip_ctx *ctx);
  * kernel reads block by block, from whichever form the frames are in; other widths are hashed from the raster form by a kernel
  * whose blocks straddle rows (correct, slower: the conformance streams' odd sizes, not the throughput path). */
 int  vp8hip_frames_fetch_async(vp8hip_ctx *ctx, int first_fb, int count, uint8_t *dst, uint8_t *digests);
+/* The same with the frames delivered as PACKED I420: d_w x d_h luma, then the two (d_w / 2) x ((d_h + 1) / 2) chroma planes, back to
+ * back, no borders, no strides -- what `vpxdec --i420` writes (vpxdec.c:1080-1101) and what the digests are taken over --,
+ * vp8hip_i420_bytes() per frame, frame i at dst + i * vp8hip_i420_bytes().  A pass on the device packs the frames from whichever
+ * form they are in (tiles as they are; no raster form is needed), the copy engines take them out: a tenth less over the link than
+ * whole frame buffers (1080p: 3.11 MB a frame instead of 3.43), which is what a pipeline that downloads every frame is bound by.
+ * Display widths that are not a multiple of 8 are refused with -3. */
+size_t vp8hip_i420_bytes(const vp8hip_ctx *ctx);
+int  vp8hip_frames_fetch_i420_async(vp8hip_ctx *ctx, int first_fb, int count, uint8_t *dst, uint8_t *digests);
 /* The digests alone, of ANY n frame buffers (fbs[i]; not necessarily neighbours: the shown frames of many streams decoded side by
  * side, bin/batch_md5 --streams): digests[16 * i].  Same stream and same wait as vp8hip_frames_fetch_async. */
 int  vp8hip_frames_md5_list_async(vp8hip_ctx *ctx, const int *fbs, int n, uint8_t *digests);

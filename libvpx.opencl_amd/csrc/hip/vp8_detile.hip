@@ -93,3 +93,80 @@ vp8_detile_run_kernel(const uint8_t *__restrict__ tiles, size_t tstride, uint8_t
         dbase = (GLOBAL_AS unsigned char *)(dst + dstride * (size_t)j);
     });
 }
+
+// ---- frames that leave as PACKED I420 (vp8hip_frames_fetch_i420_async): w x h luma, then the two (w / 2) x ((h + 1) / 2) chroma
+// planes, back to back, no borders -- what `vpxdec --i420` writes and what the MD5s are taken over.  Whole frame buffers carry 10 %
+// of border over the link (1080p: 3.43 MB for 3.11 MB of picture), and the link is what a pipeline that downloads every frame is
+// bound by.  w a multiple of 8: every piece below is whole dwords.
+// From tiles: the thread arrangement of detile_body; a piece is stored dword by dword where it lies inside the picture.
+extern "C" __global__ void __launch_bounds__(256)
+vp8_pack_i420_tiles_kernel(const uint8_t *__restrict__ tiles, size_t tstride, uint8_t *__restrict__ dst, size_t dstride, int count, DevGeom g,
+                           int w, int h)
+{
+    const int cols = g.mb_cols, rows = g.mb_rows;
+    const int t = threadIdx.x;
+    const int tile = t & 7;
+    const int wv = __builtin_amdgcn_readfirstlane(t >> 6);          // waves 0, 1: luma; 2: U; 3: V
+    const bool luma = wv < 2;
+    const int pl = wv - 2;
+    const int row = luma ? t >> 3 : ((t - 128) >> 3) & 7;           // pixel row inside the macroblock
+    const bool window = luma ? row < 12 : row < 4;
+    const int src = luma ? (window ? 16 * row : 192 + 16 * (row - 12)) : (window ? 256 + 32 * pl + 8 * row : 320 + 32 * pl + 8 * (row - 4));
+    const int cw = w >> 1, ch = (h + 1) >> 1;
+    const int pw = luma ? w : cw, ph = luma ? h : ch;               // the plane's picture
+    const long poff = luma ? 0 : (long)w * h + (pl ? (long)cw * ch : 0);
+    const unsigned soff = (unsigned)(tile * VP8_TILE_BYTES + src);
+    const int ntiles = (window ? cols + 1 : cols) - tile;
+    const int x_first = tile * (luma ? 16 : 8) - (window ? 4 : 0);
+#pragma unroll 1
+    for (int unit = blockIdx.x; unit < count * rows; unit += gridDim.x) {
+        const int j = unit / rows, r = unit - j * rows;
+        const GLOBAL_AS unsigned char *sbase = (const GLOBAL_AS unsigned char *)(tiles + tstride * (size_t)j) + (long)r * (cols + 1) * VP8_TILE_BYTES;
+        const int y = r * (luma ? 16 : 8) + row;
+        if (y >= ph) continue;
+        GLOBAL_AS unsigned char *drow = (GLOBAL_AS unsigned char *)(dst + dstride * (size_t)j) + poff + (long)y * pw;
+        unsigned so = soff;
+        int x = x_first;
+        if (luma) {
+#pragma unroll 1
+            for (int left = ntiles; left > 0; left -= 8, so += 8 * VP8_TILE_BYTES, x += 128) {
+                const u32x4_t v = *(const GLOBAL_AS u32x4_t *)(sbase + so);
+                if (x >= 0 && x + 16 <= pw) *(GLOBAL_AS u32x4_u4 *)(drow + x) = v;
+                else {
+                    if (x >= 0 && x + 4 <= pw) *(GLOBAL_AS unsigned int *)(drow + x) = v.x;
+                    if (x + 4 >= 0 && x + 8 <= pw) *(GLOBAL_AS unsigned int *)(drow + x + 4) = v.y;
+                    if (x + 8 >= 0 && x + 12 <= pw) *(GLOBAL_AS unsigned int *)(drow + x + 8) = v.z;
+                    if (x + 12 >= 0 && x + 16 <= pw) *(GLOBAL_AS unsigned int *)(drow + x + 12) = v.w;
+                }
+            }
+        } else {
+#pragma unroll 1
+            for (int left = ntiles; left > 0; left -= 8, so += 8 * VP8_TILE_BYTES, x += 64) {
+                const u32x2_t v = *(const GLOBAL_AS u32x2_t *)(sbase + so);
+                if (x >= 0 && x + 4 <= pw) *(GLOBAL_AS unsigned int *)(drow + x) = v.x;
+                if (x + 4 >= 0 && x + 8 <= pw) *(GLOBAL_AS unsigned int *)(drow + x + 4) = v.y;
+            }
+        }
+    }
+}
+
+// From the raster form: a workgroup per plane row, dword by dword.  frames: frame buffer 0 of the pool, fstride apart; first: the first one of the run.
+extern "C" __global__ void __launch_bounds__(256)
+vp8_pack_i420_raster_kernel(const uint8_t *__restrict__ frames, size_t fstride, int first, uint8_t *__restrict__ dst, size_t dstride, int count,
+                            DevGeom g, int w, int h)
+{
+    const int cw = w >> 1, ch = (h + 1) >> 1;
+    const int per_frame = h + 2 * ch;
+#pragma unroll 1
+    for (long unit = blockIdx.x; unit < (long)count * per_frame; unit += gridDim.x) {
+        const int j = (int)(unit / per_frame);
+        int y = (int)(unit - (long)j * per_frame);
+        const int pl = y < h ? 0 : y < h + ch ? 1 : 2;
+        if (pl) y -= h + (pl - 1) * ch;
+        const int pw = pl ? cw : w;
+        const GLOBAL_AS unsigned int *s = (const GLOBAL_AS unsigned int *)(frames + fstride * (size_t)(first + j) + (pl == 0 ? g.y_off : pl == 1 ? g.u_off : g.v_off) +
+                                                                           (long)y * (pl ? g.uv_stride : g.y_stride));
+        GLOBAL_AS unsigned int *d = (GLOBAL_AS unsigned int *)(dst + dstride * (size_t)j + (pl == 0 ? 0 : (long)w * h + (pl == 2 ? (long)cw * ch : 0)) + (long)y * pw);
+        for (int i = threadIdx.x; i < pw / 4; i += 256) d[i] = s[i];
+    }
+}

@@ -20,6 +20,9 @@ extern "C" __global__ void vp8_md5_any_kernel(const uint8_t *frames, size_t fstr
 extern "C" __global__ void vp8_md5_tiles_kernel(const uint8_t *tiles, size_t tstride, const int *index, int first, int count, DevGeom g, int w,
                                                 int h, uint8_t *out);
 extern "C" __global__ void vp8_detile_run_kernel(const uint8_t *tiles, size_t tstride, uint8_t *dst, size_t dstride, int count, DevGeom g);
+extern "C" __global__ void vp8_pack_i420_tiles_kernel(const uint8_t *tiles, size_t tstride, uint8_t *dst, size_t dstride, int count, DevGeom g, int w, int h);
+extern "C" __global__ void vp8_pack_i420_raster_kernel(const uint8_t *frames, size_t fstride, int first, uint8_t *dst, size_t dstride, int count, DevGeom g,
+                                                       int w, int h);
 
 static char g_create_error[256] = "";
 
@@ -185,6 +188,8 @@ extern "C" void vp8hip_destroy(vp8hip_ctx *c)
         if (c->ev_ent_out[k]) (void)hipEventDestroy(c->ev_ent_out[k]);
     }
     if (c->stream_h2d) (void)hipStreamDestroy(c->stream_h2d);
+    if (c->d_i420) (void)hipFree(c->d_i420);
+    if (c->ev_pack) (void)hipEventDestroy(c->ev_pack);
     for (int k = 0; k < 3; k++) {
         if (c->stream_d2h_more[k]) (void)hipStreamDestroy(c->stream_d2h_more[k]);
         if (c->ev_d2h_more[k]) (void)hipEventDestroy(c->ev_d2h_more[k]);
@@ -582,7 +587,24 @@ extern "C" int vp8hip_ir_fetch(vp8hip_ctx *c, int slot, vp8ir_mb *mbs, int16_t *
 
 extern "C" size_t vp8hip_frame_stride(const vp8hip_ctx *c) { return c ? c->fb_stride : 0; }
 
+extern "C" size_t vp8hip_i420_bytes(const vp8hip_ctx *c)
+{
+    return c && c->width ? (size_t)c->width * c->height + 2 * (size_t)((c->width + 1) / 2) * ((c->height + 1) / 2) : 0;
+}
+
+static int fetch_impl(vp8hip_ctx *c, int first_fb, int count, uint8_t *dst, uint8_t *digests, bool packed);
 extern "C" int vp8hip_frames_fetch_async(vp8hip_ctx *c, int first_fb, int count, uint8_t *dst, uint8_t *digests)
+{
+    return fetch_impl(c, first_fb, count, dst, digests, false);
+}
+extern "C" int vp8hip_frames_fetch_i420_async(vp8hip_ctx *c, int first_fb, int count, uint8_t *dst, uint8_t *digests)
+{
+    if (c && (c->width & 7))
+        return fail(c, -3, "vp8hip_frames_fetch_i420_async: packed frames need a display width that is a multiple of 8 (%d)", c->width);
+    return fetch_impl(c, first_fb, count, dst, digests, dst != nullptr);
+}
+
+static int fetch_impl(vp8hip_ctx *c, int first_fb, int count, uint8_t *dst, uint8_t *digests, bool packed)
 {
     if (!c || first_fb < 0 || count < 1 || first_fb + count > (int)c->fb.size() || (!dst && !digests))
         return fail(c, -2, "vp8hip_frames_fetch_async: bad arguments");
@@ -597,8 +619,8 @@ extern "C" int vp8hip_frames_fetch_async(vp8hip_ctx *c, int first_fb, int count,
     const bool whole_blocks = (c->width & 127) == 0;        // a row is whole MD5 blocks (vp8_md5.hip); other widths: raster form, vp8_md5_any_kernel
     bool tiled = c->tile_block != nullptr && (whole_blocks || !digests);
     for (int i = 0; i < count && tiled; i++) tiled = c->fb_state[(size_t)(first_fb + i)] == FB_TILES;
-    if (tiled && dst && !c->knobs.direct_download) tiled = false;
-    if (tiled && dst) {
+    if (tiled && dst && !packed && !c->knobs.direct_download) tiled = false;
+    if (tiled && dst && !packed) {
         hipPointerAttribute_t at;
         if (hipPointerGetAttributes(&at, dst) != hipSuccess) { (void)hipGetLastError(); tiled = false; }
         else tiled = at.type == hipMemoryTypeHost;
@@ -616,7 +638,49 @@ extern "C" int vp8hip_frames_fetch_async(vp8hip_ctx *c, int first_fb, int count,
     if (c->d2h_count) HIPCHK(c, hipEventSynchronize(c->ev_d2h_done));  // one copy in flight at a time
     HIPCHK(c, hipEventRecord(c->ev_d2h_from, c->stream));             // everything queued so far: the frames' kernels
     HIPCHK(c, hipStreamWaitEvent(c->stream_d2h, c->ev_d2h_from, 0));
-    if (dst) {
+    if (dst && packed) {
+        // packed I420: a pass from whichever form the frames are in into a staging buffer on the device, then the copy engines, in
+        // pieces on streams of their own -- a tenth less over the link than whole frame buffers
+        const size_t fbytes = vp8hip_i420_bytes(c);
+        if (fbytes * (size_t)count > c->i420_cap) {
+            HIPCHK(c, hipStreamSynchronize(c->stream_d2h));
+            if (c->d_i420) (void)hipFree(c->d_i420);
+            c->d_i420 = nullptr; c->i420_cap = 0;
+            if (hipMalloc((void **)&c->d_i420, fbytes * (size_t)count + 256) != hipSuccess) {
+                (void)hipGetLastError();
+                return fail(c, -1, "no device memory for %d packed frames (%zu MB)", count, fbytes * (size_t)count >> 20);
+            }
+            c->i420_cap = fbytes * (size_t)count;
+        }
+        long units = (long)count * (tiled ? c->dg.mb_rows : c->height + 2 * ((c->height + 1) / 2));
+        if (units > 16L * c->num_cu) units = 16L * c->num_cu;
+        if (tiled)
+            hipLaunchKernelGGL(vp8_pack_i420_tiles_kernel, dim3((unsigned)units), dim3(256), 0, c->stream_d2h, (const uint8_t *)c->fb_tiles[(size_t)first_fb],
+                               c->tile_frame, c->d_i420, fbytes, count, c->dg, c->width, c->height);
+        else
+            hipLaunchKernelGGL(vp8_pack_i420_raster_kernel, dim3((unsigned)units), dim3(256), 0, c->stream_d2h, (const uint8_t *)c->fb_block, c->fb_stride,
+                               first_fb, c->d_i420, fbytes, count, c->dg, c->width, c->height);
+        HIPCHK(c, hipGetLastError());
+        const int pieces = count >= 64 ? c->knobs.d2h_streams : 1;
+        const int per = (count + pieces - 1) / pieces;
+        if (pieces > 1) {
+            if (!c->ev_pack) HIPCHK(c, hipEventCreateWithFlags(&c->ev_pack, hipEventDisableTiming));
+            HIPCHK(c, hipEventRecord(c->ev_pack, c->stream_d2h));
+        }
+        for (int k = 1; k < pieces; k++) {
+            if (!c->stream_d2h_more[k - 1]) {
+                HIPCHK(c, hipStreamCreateWithFlags(&c->stream_d2h_more[k - 1], hipStreamNonBlocking));
+                HIPCHK(c, hipEventCreateWithFlags(&c->ev_d2h_more[k - 1], hipEventDisableTiming));
+            }
+            const int at = k * per, n = count - at < per ? count - at : per;
+            if (n < 1) break;
+            HIPCHK(c, hipStreamWaitEvent(c->stream_d2h_more[k - 1], c->ev_pack, 0));
+            HIPCHK(c, hipMemcpyAsync(dst + fbytes * (size_t)at, c->d_i420 + fbytes * (size_t)at, fbytes * (size_t)n, hipMemcpyDeviceToHost, c->stream_d2h_more[k - 1]));
+            HIPCHK(c, hipEventRecord(c->ev_d2h_more[k - 1], c->stream_d2h_more[k - 1]));
+        }
+        HIPCHK(c, hipMemcpyAsync(dst, c->d_i420, fbytes * (size_t)(per < count ? per : count), hipMemcpyDeviceToHost, c->stream_d2h));
+        for (int k = 1; k < pieces && k * per < count; k++) HIPCHK(c, hipStreamWaitEvent(c->stream_d2h, c->ev_d2h_more[k - 1], 0));
+    } else if (dst) {
         if (tiled) {
             // (the pass is bound by PCIe, not by the device: a workgroup per CU keeps the link full and leaves the SIMDs to the
             // launches that run beside it)

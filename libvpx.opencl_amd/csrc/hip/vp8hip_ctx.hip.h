@@ -102,6 +102,7 @@ struct vp8hip_ctx {
     // batch download of whole frame buffers on a stream of its own (vp8hip_frames_download_async): PCIe is full duplex, the next
     // batch's uploads run beside it
     hipStream_t stream_d2h;
+    uint8_t *d_i420; size_t i420_cap; hipEvent_t ev_pack;     // vp8hip_frames_fetch_i420_async: the batch as packed I420, before it leaves
     hipStream_t stream_d2h_more[3]; hipEvent_t ev_d2h_more[3];      // a batch download in up to four pieces on streams of their own (a copy engine each)
     hipEvent_t ev_d2h_from, ev_d2h_done;
     int d2h_first, d2h_count;      // frame buffers of the copy in flight (count 0: none)

@@ -117,6 +117,9 @@ static vp8ir_geom g_geom;
 static struct { vp8ir_frame_hdr *hdr; vp8ir_mbx *mbx; int16_t *blocks; size_t cap, nblocks; vp8ir_mv *mvs; } *g_maps;
 static uint8_t *g_host[2];                          /* 2 x batch pinned frame buffers: one being filled by the GPU, one being hashed */
 static size_t g_stride;                             /* bytes from one frame buffer to the next */
+static int g_packed;                                /* downloads as packed I420 (vp8hip_frames_fetch_i420_async: a tenth less over the link than
+                                                       whole frame buffers) -- whenever the digests come from the device and nobody here
+                                                       reads the frames by their strides */
 static unsigned char (*g_digest)[16];               /* one per frame of the whole run */
 static uint8_t *g_dig[2];                           /* the digests of a batch as the device computed them (pinned), beside g_host[] */
 static int g_dev_md5;                               /* hash on the device (vp8hip_frames_fetch_async: widths that are multiples of 128),
@@ -596,6 +599,8 @@ int main(int argc, char **argv)
             HIP(vp8hip_ir_map_compact(g_hip, s, &g_maps[s].hdr, &g_maps[s].mbx, &g_maps[s].blocks, &g_maps[s].cap, &g_maps[s].mvs));
     }
     g_stride = vp8hip_frame_stride(g_hip);
+    g_packed = g_dev_md5 && !no_download && g_width % 8 == 0 && !getenv("VP8BATCH_WHOLE_BUFFERS");
+    if (g_packed) g_stride = vp8hip_i420_bytes(g_hip);
     for (int k = 0; k < 2; k++) {
         if (!no_download && !(g_host[k] = (uint8_t *)vp8hip_host_alloc(g_hip, (size_t)g_batch * g_stride))) DIE("vp8hip_host_alloc: %s", vp8hip_last_error(g_hip));
         if (!(g_dig[k] = (uint8_t *)vp8hip_host_alloc(g_hip, (size_t)(g_ebatch && no_download ? g_ebatch : g_batch) * 16))) DIE("vp8hip_host_alloc: %s", vp8hip_last_error(g_hip));
@@ -636,7 +641,7 @@ int main(int argc, char **argv)
             HIP(vp8hip_pool_reset(g_hip));               /* (on the stream: behind the pixel path of the launch before) */
             HIP(vp8hip_entropy_decode(g_hip, 0, now.n, g_ent[now.b & 1], g_ent_data[now.b & 1], bytes));
             HIP(vp8hip_entropy_status_async(g_hip, now.n, g_ent_status[now.b & 1]));
-            if (L == 0) HIP(vp8hip_reserve(g_hip, 1, !no_download));     /* (the frame buffers' pools, while the first launch runs) */
+            if (L == 0) HIP(vp8hip_reserve(g_hip, 1, !no_download && !g_packed));     /* (the frame buffers' pools, while the first launch runs) */
             pend[now.b & 1].valid = 1; pend[now.b & 1].n = now.n; pend[now.b & 1].first = now.first; pend[now.b & 1].launch = L;
             for (int at = 0; at < now.n; at += g_batch, part_no++) {
                 const batch_ref part = { (int)(part_no & 0x3fffffff), now.n - at < g_batch ? now.n - at : g_batch, now.first + at };
@@ -661,7 +666,7 @@ int main(int argc, char **argv)
                     bytes = place_frames(&cur);
                     task_start(&parse_t, 0, export_one, &cur, cur.n);
                 }
-                HIP(vp8hip_frames_fetch_async(g_hip, fb0, part.n, g_host[part.b & 1], g_dig[part.b & 1]));
+                HIP((g_packed ? vp8hip_frames_fetch_i420_async : vp8hip_frames_fetch_async)(g_hip, fb0, part.n, g_host[part.b & 1], g_dig[part.b & 1]));
                 prev = part; prev_launch = L;
             }
             if (no_download) {
@@ -763,7 +768,8 @@ int main(int argc, char **argv)
             ent_bytes = place_frames(&cur);
             task_start(&parse_t, 0, feed, &cur, cur.n);
         }
-        HIP(vp8hip_frames_fetch_async(g_hip, fb0, now.n, no_download ? NULL : g_host[now.b & 1], g_dev_md5 ? g_dig[now.b & 1] : NULL));
+        HIP((g_packed ? vp8hip_frames_fetch_i420_async : vp8hip_frames_fetch_async)(g_hip, fb0, now.n, no_download ? NULL : g_host[now.b & 1],
+                                                                                     g_dev_md5 ? g_dig[now.b & 1] : NULL));
         prev = now;
     }
     HIP(vp8hip_download_wait(g_hip));

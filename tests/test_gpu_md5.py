@@ -132,3 +132,36 @@ def test_batch_download_in_pieces(pkg, pieces, monkeypatch):
         assert [P.frame_md5(got[i], ctx.g, w, h) for i in range(n)] == [gold[i % len(frames)] for i in range(n)]
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("name,copies", [("kf_640x360", 1), ("kf_640x360", 60), ("kf_1920x1080", 1), ("kf_q0_176x144", 70)])
+def test_frames_as_packed_i420(pkg, name, copies):
+    """vp8hip_frames_fetch_i420_async: the frames as `vpxdec --i420` writes them -- luma, then the two chroma planes, no borders, no
+    strides --, packed on the device from whichever form the launch left (copies = 1: a small launch, raster; 60 / 70 copies: more
+    than 512 frames, tiles; 176x144: a picture narrower than a tile row's eight tiles, an odd number of chroma rows is covered by
+    1080: 540), the digests beside them: MD5 of a delivered frame = the digest = the reference's."""
+    import ctypes
+    import hashlib
+    P = pkg
+    ctx = P.Vp8Hip(0)
+    try:
+        n = _decode_all(P, ctx, name, copies)
+        N = copies * n
+        L = ctx.L
+        L.vp8hip_i420_bytes.restype = ctypes.c_size_t
+        L.vp8hip_i420_bytes.argtypes = [ctypes.c_void_p]
+        L.vp8hip_frames_fetch_i420_async.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+        L.vp8hip_download_wait.argtypes = [ctypes.c_void_p]
+        fb = L.vp8hip_i420_bytes(ctx.h)
+        w, h = ctx.width, ctx.height
+        assert fb == w * h + 2 * ((w + 1) // 2) * ((h + 1) // 2)
+        got = np.full((N, fb), 0xAA, np.uint8)
+        dig = np.zeros(16 * N, np.uint8)
+        ctx._chk(L.vp8hip_frames_fetch_i420_async(ctx.h, 0, N, got.ctypes.data, dig.ctypes.data), "fetch_i420")
+        ctx._chk(L.vp8hip_download_wait(ctx.h), "wait")
+        gold = golden_md5(name)
+        for i in range(N):
+            assert hashlib.md5(got[i].tobytes()).hexdigest() == gold[i % n], i
+            assert dig[16 * i: 16 * i + 16].tobytes().hex() == gold[i % n], i
+    finally:
+        ctx.close()
