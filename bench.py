@@ -724,9 +724,9 @@ def main():
             # reads the frame headers only
             probe("device_entropy", lambda: batch_md5_probe(fixture, local_rank, 24576, ("--device-entropy", "--batch", "8192", "--entropy-batch", "24576")))
             # (24,576 frames per entropy launch: what the device holds at once, 32 lanes a wave and three waves a CU; their blocks out
-            # of one pool, vp8hip_configure_pooled; 737,280 frames: thirty launches, the start-up's allocations -- 1 to 4 s -- included)
+            # of one pool, vp8hip_configure_pooled; 1,474,560 frames: sixty launches, the start-up's allocations -- 1 to 4 s -- included)
             probe("device_entropy_frames_stay", lambda: batch_md5_probe(
-                fixture, local_rank, 73728, ("--device-entropy", "--no-download", "--batch", "8192", "--entropy-batch", "24576")))
+                fixture, local_rank, 147456, ("--device-entropy", "--no-download", "--batch", "8192", "--entropy-batch", "24576")))
             probe("inter_streams_device_entropy", lambda: streams_probe(local_rank))
         if not args.no_cpu_baseline and world == 1:      # the contract: rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(fixture)

@@ -127,15 +127,17 @@ static int g_dev_md5;                               /* hash on the device (vp8hi
 static volatile int g_failed;
 static int g_dev_entropy;                           /* --device-entropy */
 static int g_ebatch;                                /* --entropy-batch: frames per entropy launch (0: = g_batch, dense) */
-static uint32_t *g_ent_status[2];                   /* per set: the device's status words of the launch (pinned) */
+static uint32_t *g_ent_status[3];                   /* per set: the device's status words of the launch (pinned) */
 static long g_corrupt;                              /* frames whose partitions ended early */
 static long *g_order;                               /* --device-entropy: which frame of the run the k-th processed one is.  A lane of the
                                                        entropy kernel is busy for as long as its frame is large and a launch lasts as long
                                                        as its longest lane, so the frames of SORT_WINDOW batches at a time are taken
                                                        largest first: the frames of a launch are of a size */
 #define SORT_WINDOW 16
-static vp8hip_entropy_frame *g_ent[2];              /* per set: the frames' descriptions for vp8hip_entropy_decode (pinned) */
-static uint8_t *g_ent_data[2];                      /* ... and their bytes, one after the other */
+#define ESET(b) ((b) % 3)                           /* three page-locked sets of a launch's input: the headers of launch L + 1 are read while
+                                                       launch L is being queued and launch L - 1 is still on the device */
+static vp8hip_entropy_frame *g_ent[3];              /* per set: the frames' descriptions for vp8hip_entropy_decode (pinned) */
+static uint8_t *g_ent_data[3];                      /* ... and their bytes, one after the other */
 static size_t g_ent_cap;
 static size_t g_pool_bytes;                         /* --entropy-batch: the block pool of the context */
 
@@ -173,7 +175,7 @@ static void export_one(void *arg, int i, int worker)
 {
     const batch_ref *br = (const batch_ref *)arg;
     const frame *f = FRAME_AT(run_index(br->first + i));
-    vp8hip_entropy_frame *e = &g_ent[br->b & 1][i];
+    vp8hip_entropy_frame *e = &g_ent[ESET(br->b)][i];
     const uint64_t off = e->data_off;
     vp8ir_frame_hdr hdr;
     int rc = vp8_parser_begin_frame(g_parsers[worker], f->data, f->size, &hdr);
@@ -181,14 +183,14 @@ static void export_one(void *arg, int i, int worker)
     if (!rc) rc = vp8_parser_export_entropy(g_parsers[worker], e);
     if (rc) { g_failed = 1; return; }
     e->data_off = off;
-    memcpy(g_ent_data[br->b & 1] + off, f->data, f->size);
+    memcpy(g_ent_data[ESET(br->b)] + off, f->data, f->size);
 }
 /* where the frames of a batch go in the set's data buffer; returns the bytes in all */
 static size_t place_frames(const batch_ref *br)
 {
     size_t off = 0;
     for (int i = 0; i < br->n; i++) {
-        g_ent[br->b & 1][i].data_off = off;
+        g_ent[ESET(br->b)][i].data_off = off;
         off += FRAME_AT(run_index(br->first + i))->size;
     }
     return off;
@@ -588,7 +590,7 @@ int main(int argc, char **argv)
             HIP(vp8hip_configure_pooled(g_hip, g_width, g_height, no_download ? g_ebatch : 2 * g_batch, g_ebatch, pool));
             HIP(vp8hip_geometry(g_hip, &g_geom));
         }
-        for (int k = 0; k < 2; k++) {
+        for (int k = 0; k < 3; k++) {
             if (!(g_ent[k] = (vp8hip_entropy_frame *)vp8hip_host_alloc(g_hip, (size_t)unit * sizeof(vp8hip_entropy_frame))) ||
                 !(g_ent_data[k] = (uint8_t *)vp8hip_host_alloc(g_hip, g_ent_cap + 16)) ||
                 !(g_ent_status[k] = (uint32_t *)vp8hip_host_alloc(g_hip, (size_t)unit * sizeof(uint32_t)))) DIE("vp8hip_host_alloc: %s", vp8hip_last_error(g_hip));
@@ -622,12 +624,12 @@ int main(int argc, char **argv)
         batch_ref cur = { 0, 0, 0 }, prev = { -1, 0, 0 };
         long part_no = 0, L = 0, prev_launch = -1;
         /* the status words of a launch are good once a fetch queued behind their copy has come back: any part of that launch */
-        struct { int valid, n; long first, launch; } pend[2] = { { 0, 0, 0, 0 }, { 0, 0, 0, 0 } };
-#define TAKE_PENDING() do { for (int k_ = 0; k_ < 2; k_++) if (pend[k_].valid && pend[k_].launch <= prev_launch) {          \
+        struct { int valid, n; long first, launch; } pend[3] = { { 0, 0, 0, 0 }, { 0, 0, 0, 0 }, { 0, 0, 0, 0 } };
+#define TAKE_PENDING() do { for (int k_ = 0; k_ < 3; k_++) if (pend[k_].valid && pend[k_].launch <= prev_launch) {          \
                                 take_status(k_, pend[k_].first, pend[k_].n); pend[k_].valid = 0; } } while (0)
         const double t0 = now_s();
         LAUNCH_FRAMES(0, cur.n);
-        size_t bytes = place_frames(&cur);
+        size_t bytes = place_frames(&cur), next_bytes = 0;
         task_start(&parse_t, 0, export_one, &cur, cur.n);
         batch_ref prev_launch_ref = { -1, 0, 0 };
         const int trace = getenv("VP8BATCH_TRACE") != NULL;          /* where the main thread's time goes, launch by launch */
@@ -638,11 +640,23 @@ int main(int argc, char **argv)
             if (g_failed) DIE("a frame of launch %ld failed to parse", L);
             const batch_ref now = cur;
             done += now.n;
+            if (done < total) {
+                /* the headers of the next launch, at once: its page-locked set (one of three) belonged to launch L - 2, whose digests
+                   came back an iteration ago -- the feeder threads work while this thread queues launch L and the device runs it */
+                const long first = cur.first + cur.n;
+                cur.b = cur.b + 1; cur.first = first;
+                LAUNCH_FRAMES(first, cur.n);
+                next_bytes = place_frames(&cur);
+                task_start(&parse_t, 0, export_one, &cur, cur.n);
+            }
             HIP(vp8hip_pool_reset(g_hip));               /* (on the stream: behind the pixel path of the launch before) */
-            HIP(vp8hip_entropy_decode(g_hip, 0, now.n, g_ent[now.b & 1], g_ent_data[now.b & 1], bytes));
-            HIP(vp8hip_entropy_status_async(g_hip, now.n, g_ent_status[now.b & 1]));
+            const double te0 = now_s();
+            HIP(vp8hip_entropy_decode(g_hip, 0, now.n, g_ent[ESET(now.b)], g_ent_data[ESET(now.b)], bytes));
+            if (trace) fprintf(stderr, "launch %ld: vp8hip_entropy_decode of %.2f GB took the host %.3f s\n", L, bytes / 1e9, now_s() - te0);
+            bytes = next_bytes;
+            HIP(vp8hip_entropy_status_async(g_hip, now.n, g_ent_status[ESET(now.b)]));
             if (L == 0) HIP(vp8hip_reserve(g_hip, 1, !no_download && !g_packed));     /* (the frame buffers' pools, while the first launch runs) */
-            pend[now.b & 1].valid = 1; pend[now.b & 1].n = now.n; pend[now.b & 1].first = now.first; pend[now.b & 1].launch = L;
+            pend[ESET(now.b)].valid = 1; pend[ESET(now.b)].n = now.n; pend[ESET(now.b)].first = now.first; pend[ESET(now.b)].launch = L;
             for (int at = 0; at < now.n; at += g_batch, part_no++) {
                 const batch_ref part = { (int)(part_no & 0x3fffffff), now.n - at < g_batch ? now.n - at : g_batch, now.first + at };
                 const int fb0 = no_download ? at : (part.b & 1) * g_batch;
@@ -650,21 +664,14 @@ int main(int argc, char **argv)
                     jobs[i].ir_slot = at + i; jobs[i].dst_fb = fb0 + i;
                     jobs[i].ref_fb[0] = jobs[i].ref_fb[1] = jobs[i].ref_fb[2] = jobs[i].ref_fb[3] = -1;
                 }
+                const double td0 = now_s();
                 HIP(vp8hip_decode(g_hip, jobs, part.n, VP8HIP_STAGE_ALL));
+                if (trace) fprintf(stderr, "launch %ld: vp8hip_decode of part %d took the host %.3f s\n", L, at / g_batch, now_s() - td0);
                 if (no_download) continue;
                 if (prev.b >= 0) {
                     HIP(vp8hip_download_wait(g_hip));
                     take_digests(&prev);
                     TAKE_PENDING();
-                }
-                if (at == 0 && done < total) {
-                    /* (the page-locked set the next launch's frames are written to belonged to launch L - 1, whose last digests have
-                       just come back: its copies are done) */
-                    const long first = cur.first + cur.n;
-                    cur.b = cur.b + 1; cur.first = first;
-                    LAUNCH_FRAMES(first, cur.n);
-                    bytes = place_frames(&cur);
-                    task_start(&parse_t, 0, export_one, &cur, cur.n);
                 }
                 HIP((g_packed ? vp8hip_frames_fetch_i420_async : vp8hip_frames_fetch_async)(g_hip, fb0, part.n, g_host[part.b & 1], g_dig[part.b & 1]));
                 prev = part; prev_launch = L;
@@ -680,13 +687,6 @@ int main(int argc, char **argv)
                     take_digests(&prev_launch_ref);
                     prev_launch = L - 1;
                     TAKE_PENDING();
-                }
-                if (done < total) {
-                    const long first = cur.first + cur.n;
-                    cur.b = cur.b + 1; cur.first = first;
-                    LAUNCH_FRAMES(first, cur.n);
-                    bytes = place_frames(&cur);
-                    task_start(&parse_t, 0, export_one, &cur, cur.n);
                 }
                 HIP(vp8hip_frames_fetch_async(g_hip, 0, now.n, NULL, g_dig[now.b & 1]));
                 prev_launch_ref = now; prev = now; prev_launch = L;
@@ -739,8 +739,8 @@ int main(int argc, char **argv)
         }
         const int fb0 = g_dev_entropy ? (now.b & 1) * g_batch : (now.b % 3) * g_batch;
         if (g_dev_entropy) {
-            HIP(vp8hip_entropy_decode(g_hip, 0, now.n, g_ent[now.b & 1], g_ent_data[now.b & 1], ent_bytes));
-            HIP(vp8hip_entropy_status_async(g_hip, now.n, g_ent_status[now.b & 1]));
+            HIP(vp8hip_entropy_decode(g_hip, 0, now.n, g_ent[ESET(now.b)], g_ent_data[ESET(now.b)], ent_bytes));
+            HIP(vp8hip_entropy_status_async(g_hip, now.n, g_ent_status[ESET(now.b)]));
         }
         for (int i = 0; i < now.n; i++) {
             const int s = g_dev_entropy ? i : (now.b % 3) * g_batch + i;
@@ -751,7 +751,7 @@ int main(int argc, char **argv)
         HIP(vp8hip_decode(g_hip, jobs, now.n, VP8HIP_STAGE_ALL));
         if (prev.b >= 0) {
             HIP(vp8hip_download_wait(g_hip));                               /* batch b-1 is in host set (b-1)&1 */
-            if (g_dev_entropy) take_status(prev.b & 1, prev.first, prev.n); /* (its status copy was queued in front of its fetch) */
+            if (g_dev_entropy) take_status(ESET(prev.b), prev.first, prev.n); /* (its status copy was queued in front of its fetch) */
             if (g_dev_md5) take_digests(&prev);
             else {
                 if (hashing.b >= 0) task_wait(&hash_t, 1);                  /* batch b-2 hashed: host set b&1 is free again */
@@ -773,7 +773,7 @@ int main(int argc, char **argv)
         prev = now;
     }
     HIP(vp8hip_download_wait(g_hip));
-    if (g_dev_entropy) take_status(prev.b & 1, prev.first, prev.n);
+    if (g_dev_entropy) take_status(ESET(prev.b), prev.first, prev.n);
     if (g_dev_md5) take_digests(&prev);
     else {
         if (hashing.b >= 0) task_wait(&hash_t, 1);
