@@ -204,6 +204,10 @@ typedef struct vp8hip_entropy_frame {
  * vp8hip_sync).  Asynchronous on the context's stream. */
 int  vp8hip_entropy_decode(vp8hip_ctx *ctx, int first_slot, int count, const vp8hip_entropy_frame *frames, const uint8_t *data,
                            size_t data_bytes);
+/* The same in two steps, for a pipeline that wants the NEXT launch's input on its way while it still queues and waits on behalf of
+ * the current one: vp8hip_entropy_stage checks the frames and sends them to the device (its own copy stream, one of two buffers),
+ * vp8hip_entropy_decode(ctx, first_slot, count, NULL, NULL, 0) launches the kernel over what was staged.  One staged input at a time. */
+int  vp8hip_entropy_stage(vp8hip_ctx *ctx, int count, const vp8hip_entropy_frame *frames, const uint8_t *data, size_t data_bytes);
 /* What became of the frames of the last vp8hip_entropy_decode, a word each: bit 1 = the block pool was empty (vp8hip_configure_pooled:
  * the frame's slot is not to be decoded); bit 0 = a partition of the frame ended early, the
  * frame is corrupt (what vp8_parser_decode_mbs reports through *corrupt).  Synchronous.  _async: the copy is queued on the

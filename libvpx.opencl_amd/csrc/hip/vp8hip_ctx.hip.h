@@ -122,6 +122,7 @@ struct vp8hip_ctx {
     char *d_ent_frames2[2], *d_ent_data2[2]; size_t ent_frames_cap2[2], ent_data_cap2[2]; int ent_set;
     hipStream_t stream_h2d; hipEvent_t ev_ent_in[2], ev_ent_out[2];
     unsigned int *d_ent_scratch, *d_ent_status; size_t ent_status_cap, ent_scratch_cap; int ent_last_count;
+    struct { int count, set, np; const vp8hip_entropy_frame *frames; size_t data_bytes; } ent_staged;    // input sent, kernel not yet launched (count 0: none)
     bool ent_tables_loaded, ent_parts_off; int ent_lpw;
     int ent_resident[3];           // waves of vp8_entropy_kernel the device holds at once with 64 / 32 / 16 lanes carrying a frame (LDS)
     unsigned int *d_sched;         // vp8_keyframe_kernel's role / work counters

@@ -11,12 +11,60 @@ extern "C" __global__ void vp8_entropy_parts_kernel(const vp8hip_entropy_frame *
                                                     size_t data_bytes, char *slot_base, size_t slot_bytes, size_t o_mbx, size_t o_blocks,
                                                     int first_slot, unsigned int *scratch, unsigned int *status);
 
+// A launch in two steps: its input -- checked, and on its way to the device on the copy stream -- and the kernel.
+// vp8hip_entropy_decode is both; vp8hip_entropy_stage + vp8hip_entropy_decode(..., NULL, NULL, 0) lets a caller send the input of
+// the NEXT launch while it still has things to queue and wait for on behalf of the current one.
+static int entropy_stage(vp8hip_ctx *c, int count, const vp8hip_entropy_frame *frames, const uint8_t *data, size_t data_bytes);
+static int entropy_launch(vp8hip_ctx *c, int first_slot, int count, int set, int np, size_t data_bytes);
+
+extern "C" int vp8hip_entropy_stage(vp8hip_ctx *c, int count, const vp8hip_entropy_frame *frames, const uint8_t *data, size_t data_bytes)
+{
+    if (!c || !frames || !data || count < 1) return fail(c, -2, "vp8hip_entropy_stage: bad arguments");
+    if (c->ent_staged.count) return fail(c, -2, "vp8hip_entropy_stage: the input staged before has not been launched");
+    return entropy_stage(c, count, frames, data, data_bytes);
+}
+
 extern "C" int vp8hip_entropy_decode(vp8hip_ctx *c, int first_slot, int count, const vp8hip_entropy_frame *frames, const uint8_t *data,
                                      size_t data_bytes)
 {
-    bool any_inter = false;
-    if (!c || !frames || !data || count < 1 || first_slot < 0 || first_slot + count > (int)c->slots.size())
+    if (!c || count < 1 || first_slot < 0 || first_slot + count > (int)c->slots.size() || (!frames) != (!data))
         return fail(c, -2, "vp8hip_entropy_decode: bad arguments");
+    if (frames) {
+        if (c->ent_staged.count) return fail(c, -2, "vp8hip_entropy_decode: input was staged (vp8hip_entropy_stage): launch that first");
+        if (entropy_stage(c, count, frames, data, data_bytes)) return -1;
+    } else if (c->ent_staged.count != count)
+        return fail(c, -2, "vp8hip_entropy_decode: %d frames asked for, %d staged", count, c->ent_staged.count);
+    const int set = c->ent_staged.set, np = c->ent_staged.np;
+    frames = c->ent_staged.frames; data_bytes = c->ent_staged.data_bytes;
+    c->ent_staged.count = 0;
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t swords = np > 1 ? (size_t)count * ((size_t)c->dg.mb_cols + 3 * (size_t)c->nmb) : (size_t)count * (8 * (size_t)c->dg.mb_cols + 64);
+    if ((size_t)count > c->ent_status_cap) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (c->d_ent_status) (void)hipFree(c->d_ent_status);
+        c->d_ent_status = nullptr; c->ent_status_cap = 0;
+        HIPCHK(c, hipMalloc((void **)&c->d_ent_status, (size_t)count * 4));
+        c->ent_status_cap = (size_t)count;
+    }
+    if (swords > c->ent_scratch_cap) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (c->d_ent_scratch) (void)hipFree(c->d_ent_scratch);
+        c->d_ent_scratch = nullptr; c->ent_scratch_cap = 0;
+        HIPCHK(c, hipMalloc((void **)&c->d_ent_scratch, swords * 4));
+        c->ent_scratch_cap = swords;
+    }
+    HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_ent_in[set], 0));
+    for (int i = 0; i < count; i++) {
+        Slot &s = c->slots[first_slot + i];
+        s.hdr_copy = frames[i].hdr;
+        s.nblocks = NBLOCKS_UNKNOWN;           // (the host never sees how many blocks the device wrote)
+    }
+    return entropy_launch(c, first_slot, count, set, np, data_bytes);
+}
+
+static int entropy_stage(vp8hip_ctx *c, int count, const vp8hip_entropy_frame *frames, const uint8_t *data, size_t data_bytes)
+{
+    bool any_inter = false;
     for (int i = 0; i < count; i++) {
         const vp8hip_entropy_frame &f = frames[i];
         const vp8ir_frame_hdr &h = f.hdr;
@@ -48,7 +96,6 @@ extern "C" int vp8hip_entropy_decode(vp8hip_ctx *c, int first_slot, int count, c
     }
     if (c->dg.mb_cols < np || c->dg.mb_cols > 256 || c->dg.mb_cols * (64 / np) > 4096 || c->ent_parts_off || any_inter) np = 1;
     if (c->pool) np = 1;           // (the partition-per-lane kernel gives every partition a worst-case region of the slot's own stream)
-    const size_t swords = np > 1 ? (size_t)count * ((size_t)c->dg.mb_cols + 3 * (size_t)c->nmb) : (size_t)count * (8 * (size_t)c->dg.mb_cols + 64);
     if (!c->stream_h2d) {
         HIPCHK(c, hipStreamCreateWithFlags(&c->stream_h2d, hipStreamNonBlocking));
         for (int k = 0; k < 2; k++) {
@@ -65,13 +112,6 @@ extern "C" int vp8hip_entropy_decode(vp8hip_ctx *c, int first_slot, int count, c
         HIPCHK(c, hipMalloc((void **)&c->d_ent_frames2[set], fbytes));
         c->ent_frames_cap2[set] = fbytes;
     }
-    if ((size_t)count > c->ent_status_cap) {
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        if (c->d_ent_status) (void)hipFree(c->d_ent_status);
-        c->d_ent_status = nullptr; c->ent_status_cap = 0;
-        HIPCHK(c, hipMalloc((void **)&c->d_ent_status, (size_t)count * 4));
-        c->ent_status_cap = (size_t)count;
-    }
     if (data_bytes + 16 > c->ent_data_cap2[set]) {
         HIPCHK(c, hipEventSynchronize(c->ev_ent_out[set]));
         if (c->d_ent_data2[set]) (void)hipFree(c->d_ent_data2[set]);
@@ -80,13 +120,6 @@ extern "C" int vp8hip_entropy_decode(vp8hip_ctx *c, int first_slot, int count, c
         HIPCHK(c, hipMalloc((void **)&c->d_ent_data2[set], cap));
         c->ent_data_cap2[set] = cap;
     }
-    if (swords > c->ent_scratch_cap) {
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        if (c->d_ent_scratch) (void)hipFree(c->d_ent_scratch);
-        c->d_ent_scratch = nullptr; c->ent_scratch_cap = 0;
-        HIPCHK(c, hipMalloc((void **)&c->d_ent_scratch, swords * 4));
-        c->ent_scratch_cap = swords;
-    }
     // the launch's input: on the copy stream, as soon as the kernel that last read this set is done -- beside whatever the context's
     // stream still has to do before this launch
     hipStream_t cs = c->stream_h2d;        // (24,576 1080p frames per launch: 15 ms of every 380 against copies on the context's stream; the kernel beside a copy is 8 % slower)
@@ -94,12 +127,12 @@ extern "C" int vp8hip_entropy_decode(vp8hip_ctx *c, int first_slot, int count, c
     HIPCHK(c, hipMemcpyAsync(c->d_ent_frames2[set], frames, fbytes, hipMemcpyHostToDevice, cs));
     HIPCHK(c, hipMemcpyAsync(c->d_ent_data2[set], data, data_bytes, hipMemcpyHostToDevice, cs));
     HIPCHK(c, hipEventRecord(c->ev_ent_in[set], cs));
-    HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_ent_in[set], 0));
-    for (int i = 0; i < count; i++) {
-        Slot &s = c->slots[first_slot + i];
-        s.hdr_copy = frames[i].hdr;
-        s.nblocks = NBLOCKS_UNKNOWN;           // (the host never sees how many blocks the device wrote)
-    }
+    c->ent_staged.count = count; c->ent_staged.set = set; c->ent_staged.np = np; c->ent_staged.frames = frames; c->ent_staged.data_bytes = data_bytes;
+    return 0;
+}
+
+static int entropy_launch(vp8hip_ctx *c, int first_slot, int count, int set, int np, size_t data_bytes)
+{
     // Lanes per wave.  A launch lasts as long as its largest frame IF all its waves are on the device at once, and what bounds
     // that is LDS -- 1.4 KB a lane (the frame's coefficient probabilities: 1152 bytes), so a CU holds one wave of 64 lanes, three
     // of 32, seven of 16: 16,384 / 24,576 / 28,672 frames on the 256 CUs; a launch with more waves than fit runs in rounds, each

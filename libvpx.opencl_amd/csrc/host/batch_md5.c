@@ -632,15 +632,19 @@ int main(int argc, char **argv)
         size_t bytes = place_frames(&cur), next_bytes = 0;
         task_start(&parse_t, 0, export_one, &cur, cur.n);
         batch_ref prev_launch_ref = { -1, 0, 0 };
+        const int late_stage = getenv("VP8BATCH_LATE_STAGE") != NULL;      /* (experiments: a launch's input is sent when the launch is queued) */
         const int trace = getenv("VP8BATCH_TRACE") != NULL;          /* where the main thread's time goes, launch by launch */
         for (long done = 0; done < total; L++) {
-            const double tw0 = now_s();
-            task_wait(&parse_t, 0);
-            if (trace) fprintf(stderr, "launch %ld: at %.3f s, waited %.3f s for the headers\n", L, tw0 - t0, now_s() - tw0);
-            if (g_failed) DIE("a frame of launch %ld failed to parse", L);
+            if (L == 0 || late_stage) {           /* (every later launch's input was sent while the launch before it was being queued: below) */
+                task_wait(&parse_t, 0);
+                if (g_failed) DIE("a frame of launch %ld failed to parse", L);
+                HIP(vp8hip_entropy_stage(g_hip, cur.n, g_ent[ESET(cur.b)], g_ent_data[ESET(cur.b)], L == 0 ? bytes : next_bytes));
+            }
+            if (trace) fprintf(stderr, "launch %ld: at %.3f s\n", L, now_s() - t0);
             const batch_ref now = cur;
             done += now.n;
-            if (done < total) {
+            const int have_next = done < total;
+            if (have_next) {
                 /* the headers of the next launch, at once: its page-locked set (one of three) belonged to launch L - 2, whose digests
                    came back an iteration ago -- the feeder threads work while this thread queues launch L and the device runs it */
                 const long first = cur.first + cur.n;
@@ -650,10 +654,7 @@ int main(int argc, char **argv)
                 task_start(&parse_t, 0, export_one, &cur, cur.n);
             }
             HIP(vp8hip_pool_reset(g_hip));               /* (on the stream: behind the pixel path of the launch before) */
-            const double te0 = now_s();
-            HIP(vp8hip_entropy_decode(g_hip, 0, now.n, g_ent[ESET(now.b)], g_ent_data[ESET(now.b)], bytes));
-            if (trace) fprintf(stderr, "launch %ld: vp8hip_entropy_decode of %.2f GB took the host %.3f s\n", L, bytes / 1e9, now_s() - te0);
-            bytes = next_bytes;
+            HIP(vp8hip_entropy_decode(g_hip, 0, now.n, NULL, NULL, 0));      /* (the kernel over the input staged before) */
             HIP(vp8hip_entropy_status_async(g_hip, now.n, g_ent_status[ESET(now.b)]));
             if (L == 0) HIP(vp8hip_reserve(g_hip, 1, !no_download && !g_packed));     /* (the frame buffers' pools, while the first launch runs) */
             pend[ESET(now.b)].valid = 1; pend[ESET(now.b)].n = now.n; pend[ESET(now.b)].first = now.first; pend[ESET(now.b)].launch = L;
@@ -675,6 +676,15 @@ int main(int argc, char **argv)
                 }
                 HIP((g_packed ? vp8hip_frames_fetch_i420_async : vp8hip_frames_fetch_async)(g_hip, fb0, part.n, g_host[part.b & 1], g_dig[part.b & 1]));
                 prev = part; prev_launch = L;
+            }
+            if (have_next && !late_stage) {
+                /* the next launch's input on its way now -- checked, and copied on the entropy decoder's copy stream while the
+                   device is busy with this launch; its kernel is launched at the top of the next iteration */
+                const double tw0 = now_s();
+                task_wait(&parse_t, 0);
+                if (g_failed) DIE("a frame of launch %ld failed to parse", L + 1);
+                HIP(vp8hip_entropy_stage(g_hip, cur.n, g_ent[ESET(cur.b)], g_ent_data[ESET(cur.b)], next_bytes));
+                if (trace) fprintf(stderr, "launch %ld: waited %.3f s for the next launch's headers, %.2f GB staged\n", L, now_s() - tw0, next_bytes / 1e9);
             }
             if (no_download) {
                 /* the frames stay: ONE hash launch over the launch's frames, on the download stream -- beside the entropy decoder's
