@@ -386,3 +386,37 @@ def test_damaged_payloads(name, index, pooled):
         if hh.frame_type:
             assert (ctx.mvs_fetch(i) == mvs.reshape(-1, 2)).all(), (name, i)
     ctx.close()
+
+
+def test_input_staged_ahead_of_the_launch():
+    """vp8hip_entropy_stage + vp8hip_entropy_decode(..., NULL, NULL, 0): the launch in two steps gives the IR of the launch in one;
+    a second stage before the launch, a launch of another count and a one-step launch over staged input are refused."""
+    import ctypes
+    P = load_package()
+    w, h, frames = P.read_ivf(ivf_path("kf_640x360"))
+    host = _host_ir(P, frames)
+    efs = _export(P, frames)
+    n = len(frames)
+    arr = (P.EntropyFrame * n)()
+    off = 0
+    for i, (f, d) in enumerate(zip(efs, frames)):
+        ctypes.memmove(ctypes.byref(arr[i]), ctypes.byref(f), ctypes.sizeof(P.EntropyFrame))
+        arr[i].data_off = off
+        off += len(d)
+    blob = b"".join(frames)
+    ctx = P.Vp8Hip()
+    ctx.configure(w, h, 1, n)
+    L = ctx.L
+    L.vp8hip_entropy_stage.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t]
+    ctx._chk(L.vp8hip_entropy_stage(ctx.h, n, ctypes.byref(arr), blob, len(blob)), "stage")
+    assert L.vp8hip_entropy_stage(ctx.h, n, ctypes.byref(arr), blob, len(blob)) != 0            # one staged input at a time
+    assert L.vp8hip_entropy_decode(ctx.h, 0, n - 1, None, None, 0) != 0                         # ... of n frames
+    assert L.vp8hip_entropy_decode(ctx.h, 0, n, ctypes.byref(arr), blob, len(blob)) != 0        # ... which is to be launched first
+    ctx._chk(L.vp8hip_entropy_decode(ctx.h, 0, n, None, None, 0), "launch")
+    st = np.zeros(n, np.uint32)
+    ctx._chk(L.vp8hip_entropy_status(ctx.h, n, st.ctypes.data), "status")
+    assert not st.any()
+    for i, (_, mbs, coef) in enumerate(host):
+        _compare(ctx, i, mbs, coef, ("staged", i))
+    assert L.vp8hip_entropy_decode(ctx.h, 0, n, None, None, 0) != 0                             # nothing staged any more
+    ctx.close()
