@@ -420,3 +420,17 @@ def test_input_staged_ahead_of_the_launch():
         _compare(ctx, i, mbs, coef, ("staged", i))
     assert L.vp8hip_entropy_decode(ctx.h, 0, n, None, None, 0) != 0                             # nothing staged any more
     ctx.close()
+
+
+def test_fuzzed_inter_streams():
+    """Twenty-four seeded inter sequences of odd small sizes (tests/test_writer_cpu.py: fuzz_case -- random plans of coded / kept /
+    re-dataed segment maps and segmentation switched off, 1..8 partitions, coefficients up to +-2047), each through ONE slot with the
+    device's entropy decoder: the IR the host feeder reads, the frames feeder + oracle decode (which the CPU suite pins to the
+    reference decoder on the same seeds)."""
+    from test_writer_cpu import FUZZ_SEEDS, fuzz_case, inter_sequence
+    P = load_package()
+    for seed in FUZZ_SEEDS:
+        w, h, _, plan, lp, big = fuzz_case(seed)
+        frames, _ = inter_sequence(w, h, seed, plan, lp, big=big)
+        gold = oracle_listing(P, w, h, frames)
+        assert _one_slot_stream(P, w, h, frames, gold, ("fuzz", seed), pooled=bool(seed & 1)) == len(plan)

@@ -182,3 +182,26 @@ def test_reference_decodes_written_inter_streams_like_the_oracle(pkg, case, tmp_
         if hdr.show_frame:
             mine.append(pkg.frame_md5(bufs[show], g, w, h))
     assert mine == ref
+
+
+def fuzz_case(seed):
+    """a small inter sequence from a seed: size, plan, partitions, coefficient range"""
+    rng = np.random.default_rng(seed)
+    w, h = int(rng.integers(1, 14)) * 16 + int(rng.integers(-15, 1)), int(rng.integers(1, 11)) * 16 + int(rng.integers(-15, 1))
+    w, h = max(w, 2), max(h, 2)
+    plan = tuple(rng.choice(["keep", "data", "map", "both", "off"], size=int(rng.integers(2, 7))))
+    return w, h, seed, plan, int(rng.integers(0, 4)), bool(rng.integers(0, 2))
+
+
+FUZZ_SEEDS = list(range(100, 124))
+
+
+@pytest.mark.skipif(not os.path.exists(REF_MD5), reason="oracle/_ref not built (needs /root/reference)")
+@pytest.mark.parametrize("seed", FUZZ_SEEDS)
+def test_reference_decodes_fuzzed_inter_streams_like_the_oracle(pkg, seed, tmp_path):
+    test_reference_decodes_written_inter_streams_like_the_oracle(pkg, fuzz_case(seed), tmp_path)
+
+
+@pytest.mark.parametrize("seed", FUZZ_SEEDS[:8])
+def test_feeder_reads_back_fuzzed_inter_frames(pkg, seed):
+    test_feeder_reads_back_inter_frames(pkg, fuzz_case(seed))
