@@ -262,6 +262,7 @@ static int configure_pools(vp8hip_ctx *c, int width, int height, int num_fb, int
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     free_pools(c);
+    c->ent_staged.count = 0;                 // (input staged for the geometry before: dropped)
     read_knobs(c->knobs);
     c->width = width; c->height = height;
     vp8ir_geom_init(&c->geom, width, height);
