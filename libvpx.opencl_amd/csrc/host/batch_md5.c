@@ -584,6 +584,10 @@ int main(int argc, char **argv)
                 if (need > pool) pool = need;
             }
             pool += 4 * chunk;
+            {   /* (a pool counts its blocks in 32 bits: 137 GB at most) */
+                const size_t most = ((size_t)0xffffffffu / (chunk / 32) - 1) * chunk;
+                if (pool > most) pool = most;
+            }
             if (pool_mb > 0) pool = (size_t)pool_mb << 20;
             g_pool_bytes = pool;
             /* frames that stay on the device are hashed a launch at a time (E frame buffers, tiles only); downloads go B at a time */
