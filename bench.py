@@ -32,6 +32,7 @@ Prints ONE JSON line on rank 0 (see README / DESIGN.md for the field definitions
              this host on the same stream, 1 core; falls back to the repo's C restatement ("port")
 """
 import argparse
+import hashlib
 import ctypes
 import json
 import os
@@ -411,16 +412,36 @@ def main():
 
     # ---- the stream: world * F frames, frame i = source frame i mod nsrc; rank r decodes the contiguous block
     # shard_range(world * F, world, r) -- entropy-decoded once on the host, outside the timed region
-    lo, hi = sharding.shard_range(world * F, world, rank)
-    assert hi - lo == F
-    ctx = P.Vp8Hip(local_rank)
-    ctx.configure(W, H, F, F)
-    nsrc, feed_s = load_stream(P, ctx, fixture, F, lo)
-    jobs = (P.Job * F)()
-    for i in range(F):
-        jobs[i].ir_slot, jobs[i].dst_fb = i, i
-        for k in range(4):
-            jobs[i].ref_fb[k] = -1
+    # (the default launch keeps 16,384 1080p frames resident: 128 GB of IR slots and 56 GB of tiles.  A device that cannot give that --
+    # somebody else's memory on it -- gets half as many frames per step rather than no bench line; --frames is taken as given)
+    while True:
+        lo, hi = sharding.shard_range(world * F, world, rank)
+        assert hi - lo == F
+        ctx = P.Vp8Hip(local_rank)
+        fits = 1
+        try:
+            ctx.configure(W, H, F, F)
+            nsrc, feed_s = load_stream(P, ctx, fixture, F, lo)
+            jobs = (P.Job * F)()
+            for i in range(F):
+                jobs[i].ir_slot, jobs[i].dst_fb = i, i
+                for k in range(4):
+                    jobs[i].ref_fb[k] = -1
+            ctx.decode_array(jobs, F, P.STAGE_ALL)           # (the first large launch allocates the tiled forms)
+            ctx.sync()
+        except RuntimeError as ex:
+            fits = 0
+            sys.stderr.write(f"[bench] rank {rank}: {F} frames per step do not fit: {ex}\n")
+        if dist is not None:
+            t = torch.tensor([fits], device=coll_dev, dtype=torch.int32)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            fits = int(t.item())
+        if fits:
+            break
+        ctx.close()
+        if args.frames or F <= 2048:
+            raise SystemExit("the device has no room for the benchmark's frames")
+        F //= 2
     nmb = ctx.nmb
 
     # ---- correctness gate 1 (multi-GPU): a 16-frames-per-rank prefix stream decoded the sharded way -- every rank its block,
@@ -455,7 +476,9 @@ def main():
     sample = [i for i in sample if 0 <= i < F]
     ok = 1
     for i in sample:
-        if P.planes_md5(*ctx.download_planes(i)) != gold[(lo + i) % nsrc]:
+        # (hashed on the HOST: the frame packed on the device from the tiles the launch left, vp8hip_frames_fetch_i420_async -- the
+        # raster pool of all F frame buffers, 56 GB at 16,384 1080p frames, is not allocated for the sake of 75 of them)
+        if (hashlib.md5(ctx.frames_i420(i, 1)[0].tobytes()).hexdigest() if W % 8 == 0 else P.planes_md5(*ctx.download_planes(i))) != gold[(lo + i) % nsrc]:
             ok = 0
             sys.stderr.write(f"[bench] rank {rank}: frame {lo + i} MD5 mismatch\n")
     if listing_ok is False:

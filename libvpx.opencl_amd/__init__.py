@@ -563,6 +563,18 @@ class Vp8Hip:
         self._chk(self.L.vp8hip_download_wait(self.h), "vp8hip_download_wait")
         return [out[16 * i: 16 * i + 16].tobytes().hex() for i in range(count)]
 
+    def frames_i420(self, first_fb, count):
+        """`count` consecutive frame buffers as packed I420 (vp8hip_frames_fetch_i420_async: packed on the device from whichever form
+        they are in -- tiles as they are --, no raster pool needed): uint8 array [count, w * h + 2 * (w / 2) * ((h + 1) / 2)]."""
+        self.L.vp8hip_i420_bytes.restype = ctypes.c_size_t
+        self.L.vp8hip_i420_bytes.argtypes = [ctypes.c_void_p]
+        self.L.vp8hip_frames_fetch_i420_async.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+        self.L.vp8hip_download_wait.argtypes = [ctypes.c_void_p]
+        out = np.zeros((count, self.L.vp8hip_i420_bytes(self.h)), np.uint8)
+        self._chk(self.L.vp8hip_frames_fetch_i420_async(self.h, first_fb, count, out.ctypes.data, None), "vp8hip_frames_fetch_i420_async")
+        self._chk(self.L.vp8hip_download_wait(self.h), "vp8hip_download_wait")
+        return out
+
     def frames_to_raster(self, first_fb, count):
         """Ask for the raster form of frame buffers a large launch left as tiles (vp8hip_frames_to_raster; asynchronous)."""
         self._chk(self.L.vp8hip_frames_to_raster(self.h, first_fb, count), "vp8hip_frames_to_raster")
