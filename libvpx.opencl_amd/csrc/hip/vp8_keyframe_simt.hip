@@ -147,6 +147,13 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
     const int lane = threadIdx.x;
     const int G = 1 << lgG;
     const int pos = lane & (G - 1);
+    // (a strand's first lane reads its context back from the hand-over tile: issued at the top of the step where the registers are
+    // there for it -- key-frame launches: -1.4 % --, right in front of the wait in launches with inter frames, whose kernel spills with it)
+#ifdef KF_READBACK_LATE
+    constexpr bool RB_EARLY = false;
+#else
+    constexpr bool RB_EARLY = !INTER;
+#endif
     const int spw = 64 >> lgG;
     const int strand = wave * spw + (lane >> lgG);
     const int cols = g.mb_cols, rows = g.mb_rows;
@@ -409,6 +416,31 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
         }
         const bool act = c >= 0 && c < cols && V < Vmax;
         const bool late = act && !p_more;        // first macroblock of a row: nothing was prepared a step ahead
+        // A strand's first lane takes its context from the hand-over tile the strand's last lane wrote a round ago: the loads are issued
+        // HERE, at the top of the step (a row's first macroblock: below, once the row's pointers are known) -- agent-scope: served by the L2,
+        // see load_l2; six wide ones instead of 21 dwords -- and waited for where the context is needed
+        u32x4 rb_a = { 0, 0, 0, 0 }, rb_0 = { 0, 0, 0, 0 }, rb_1 = { 0, 0, 0, 0 }, rb_2 = { 0, 0, 0, 0 }, rb_3 = { 0, 0, 0, 0 };
+        u32 rb_r = 0;
+        auto readback_issue = [&](const unsigned char *ha, const unsigned char *pa) {
+            if constexpr (LUMA)
+                asm volatile("global_load_dwordx4 %0, %6, off sc1\n\t"
+                             "global_load_dword %5, %6, off offset:32 sc1\n\t"
+                             "global_load_dwordx4 %1, %7, off offset:192 sc1\n\t"
+                             "global_load_dwordx4 %2, %7, off offset:208 sc1\n\t"
+                             "global_load_dwordx4 %3, %7, off offset:224 sc1\n\t"
+                             "global_load_dwordx4 %4, %7, off offset:240 sc1"
+                             : "=&v"(rb_a), "=&v"(rb_0), "=&v"(rb_1), "=&v"(rb_2), "=&v"(rb_3), "=&v"(rb_r) : "v"(ha), "v"(pa) : "memory");
+            else
+                asm volatile("global_load_dwordx4 %0, %5, off offset:16 sc1\n\t"
+                             "global_load_dwordx4 %1, %6, off offset:320 sc1\n\t"
+                             "global_load_dwordx4 %2, %6, off offset:336 sc1\n\t"
+                             "global_load_dwordx4 %3, %6, off offset:352 sc1\n\t"
+                             "global_load_dwordx4 %4, %6, off offset:368 sc1"
+                             : "=&v"(rb_a), "=&v"(rb_0), "=&v"(rb_1), "=&v"(rb_2), "=&v"(rb_3) : "v"(ha), "v"(pa) : "memory");
+        };
+        if constexpr (RB_EARLY)
+            if (act && !late && pos == 0 && r != 0)
+                readback_issue((const unsigned char *)hp + (long)c * KH_BYTES - hrow, (const unsigned char *)tp + (long)c * VP8_TILE_BYTES - rowbytes);
         u32 jm = nx_jm, dc_given = nx_dcg, cur_dq = nx_dq;
         u32 cur_w0 = nx_w0, cur_w1 = nx_w1;
         u32x4 bm = nx_bm;
@@ -471,6 +503,7 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
         const bool hand = act && pos == G - 1 && !last_row;
         const g_u8p tpc = tp + (long)(act ? c : 0) * VP8_TILE_BYTES;                 // this macroblock's tile
         const g_u8p hpc = hp + (long)(act ? c : 0) * KH_BYTES;                       // ... and unfiltered line
+        if constexpr (RB_EARLY) { if (readback && late) readback_issue((const unsigned char *)hpc - hrow, (const unsigned char *)tpc - rowbytes); }
         // ---- macroblock descriptor; loop-filter parameters (vp8_loop_filter_frame, loopfilter.c:245-299)
         const int y_mode = cur_w0 & 0xff, uv_mode = (cur_w0 >> 8) & 0xff;
         const bool bpred = y_mode == VP8IR_B_PRED;
@@ -509,38 +542,20 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
             arY = nAR;
         }
         if (readback) {
-            const unsigned char *pa = (const unsigned char *)tpc - rowbytes, *ha = (const unsigned char *)hpc - hrow;
+            if constexpr (!RB_EARLY) readback_issue((const unsigned char *)hpc - hrow, (const unsigned char *)tpc - rowbytes);
+            static_assert(KH_Y == 0 && KH_BYTES == 32 && KT_Y_BOT == 192 && KH_U == 16 && KH_V == 24 && KT_U_BOT == 320, "offsets in the loads above");
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(rb_a), "+v"(rb_0), "+v"(rb_1), "+v"(rb_2), "+v"(rb_3), "+v"(rb_r) :: "memory");
             if constexpr (LUMA) {
-                // (agent-scope loads -- served by the L2, see load_l2 --, six wide ones instead of 21 dwords)
-                u32x4 va, v0, v1, v2, v3;
-                u32 vr;
-                asm volatile("global_load_dwordx4 %0, %6, off sc1\n\t"
-                             "global_load_dword %5, %6, off offset:32 sc1\n\t"
-                             "global_load_dwordx4 %1, %7, off offset:192 sc1\n\t"
-                             "global_load_dwordx4 %2, %7, off offset:208 sc1\n\t"
-                             "global_load_dwordx4 %3, %7, off offset:224 sc1\n\t"
-                             "global_load_dwordx4 %4, %7, off offset:240 sc1\n\t"
-                             "s_waitcnt vmcnt(0)"
-                             : "=&v"(va), "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3), "=&v"(vr) : "v"(ha), "v"(pa) : "memory");
-                static_assert(KH_Y == 0 && KH_BYTES == 32 && KT_Y_BOT == 192, "offsets in the asm above");
-                aA[0] = va.x; aA[1] = va.y; aA[2] = va.z; aA[3] = va.w;
-                arY = vr;
-                const u32x4 vv[4] = { v0, v1, v2, v3 };
+                aA[0] = rb_a.x; aA[1] = rb_a.y; aA[2] = rb_a.z; aA[3] = rb_a.w;
+                arY = rb_r;
+                const u32x4 vv[4] = { rb_0, rb_1, rb_2, rb_3 };
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     tF[j][0] = vv[j].x ^ VP8_LF_BIAS; tF[j][1] = vv[j].y ^ VP8_LF_BIAS;
                     tF[j][2] = vv[j].z ^ VP8_LF_BIAS; tF[j][3] = vv[j].w ^ VP8_LF_BIAS;
                 }
             } else {
-                u32x4 va, u0, u1, w0, w1;            // U rows (4,5) (6,7), V rows (4,5) (6,7): 64 contiguous bytes
-                asm volatile("global_load_dwordx4 %0, %5, off offset:16 sc1\n\t"
-                             "global_load_dwordx4 %1, %6, off offset:320 sc1\n\t"
-                             "global_load_dwordx4 %2, %6, off offset:336 sc1\n\t"
-                             "global_load_dwordx4 %3, %6, off offset:352 sc1\n\t"
-                             "global_load_dwordx4 %4, %6, off offset:368 sc1\n\t"
-                             "s_waitcnt vmcnt(0)"
-                             : "=&v"(va), "=&v"(u0), "=&v"(u1), "=&v"(w0), "=&v"(w1) : "v"(ha), "v"(pa) : "memory");
-                static_assert(KH_U == 16 && KH_V == 24 && KT_U_BOT == 320, "offsets in the asm above");
+                const u32x4 va = rb_a, u0 = rb_0, u1 = rb_1, w0 = rb_2, w1 = rb_3;
                 aA[0] = va.x; aA[1] = va.y; aA[2] = va.z; aA[3] = va.w;
                 tF[0][0] = u0.x ^ VP8_LF_BIAS; tF[0][1] = u0.y ^ VP8_LF_BIAS; tF[1][0] = u0.z ^ VP8_LF_BIAS; tF[1][1] = u0.w ^ VP8_LF_BIAS;
                 tF[2][0] = u1.x ^ VP8_LF_BIAS; tF[2][1] = u1.y ^ VP8_LF_BIAS; tF[3][0] = u1.z ^ VP8_LF_BIAS; tF[3][1] = u1.w ^ VP8_LF_BIAS;
