@@ -283,18 +283,23 @@ extern "C" int vp8hip_decode(vp8hip_ctx *c, const vp8hip_job *jobs, int njobs, i
     }
     hipEvent_t *ev = c->evr[c->ncalls % VP8HIP_STATS_RING];
     HIPCHK(c, hipEventRecord(ev[0], c->stream));
-    // "one MB row per lane" kernels: G lanes per strand of frames, row period P >= max(cols, 2G+2).  G is at most
-    // the largest value that costs no idle steps (cols >= 2G+2), and otherwise as small as it can be while every
-    // strand of a full launch (4 waves per CU) still gets a frame: a small G means few pipeline-fill steps and a
-    // better fit of the frame's rows into whole row periods.
+    // "one MB row per lane" kernels: G lanes per strand of frames, row period P = max(cols, 2G + 2).  A strand's frames follow each
+    // other row after row, G rows at a time, so a launch takes ceil(frames per strand x rows / G) rounds of P steps + 2 (G - 1) to
+    // fill and drain -- 8192 1080p frames on 8 lanes each: 68 rows = 8.5 rounds, nine run; 16,384: two frames per strand, 17 whole
+    // rounds -- and every strand's first lane goes through the hand-over tile (a little more per step the more strands a wave has:
+    // 16,384 frames at G = 4, 8, 16: 58.1, 57.5, 58.2 ms).  G = the one that costs the fewest steps by that count.
     int lgG = 1;
     {
-        const int cols = c->dg.mb_cols;
-        int lgmax = 1;
-        while (lgmax < 6 && 2 * (2 << lgmax) + 2 <= cols) lgmax++;
-        const long lanes = (long)c->num_cu * 4 * 64;                      // one wave per SIMD
-        while (lgG < 6 && (lanes >> lgG) > njobs) lgG++;                  // strands of a full launch <= frames
-        if (lgG > lgmax && ((long)njobs << lgmax) >= lanes) lgG = lgmax;   // no idle steps, if that still fills every SIMD
+        const int cols = c->dg.mb_cols, rows = c->dg.mb_rows;
+        const long lanes = (long)c->num_cu * 4 * 64;                      // one luma wave per SIMD
+        double best = 0;
+        for (int k = 1; k <= 6; k++) {
+            const long G = 1L << k, strands = lanes >> k;
+            const long per = (njobs + strands - 1) / strands;             // frames per strand (strands without a frame idle)
+            const long P = cols > 2 * G + 2 ? cols : 2 * G + 2;
+            const double steps = (double)((per * rows + G - 1) / G * P + 2 * (G - 1)) * (1.0 + 0.09 / (double)G);
+            if (k == 1 || steps < best) { best = steps; lgG = k; }
+        }
         if (K.lgG >= 1 && K.lgG <= 6) lgG = K.lgG;
     }
     const int simtG = 1 << lgG, spw = 64 >> lgG;
