@@ -97,6 +97,12 @@ int  vp8hip_pool_usage(vp8hip_ctx *ctx, size_t *used_bytes, size_t *pool_bytes);
  * raster forms with the first small launch, inter frame, download or filter); vp8hip_reserve allocates them now -- beside a first
  * launch of the entropy decoder, for instance: tens of GB take the allocator a second or two. */
 int  vp8hip_reserve(vp8hip_ctx *ctx, int tiled_form, int raster_form);
+/* What the context holds on the device right now, in bytes: the raster forms' pool, the tiled forms' pool, the IR slots, the block
+ * pool (vp8hip_configure_pooled), the entropy decoder's input buffers, the staging of packed downloads. */
+typedef struct vp8hip_memory {
+    size_t raster_pool, tile_pool, slots, block_pool, entropy_input, packed_staging;
+} vp8hip_memory;
+int  vp8hip_memory_usage(const vp8hip_ctx *ctx, vp8hip_memory *out);
 int  vp8hip_geometry(const vp8hip_ctx *ctx, vp8ir_geom *g);
 
 /* Pinned host staging of a slot in the device form, for a feeder to write into directly (vp8_parser_decode_mbs_compact): mbx[nmb],

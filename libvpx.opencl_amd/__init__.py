@@ -437,6 +437,14 @@ class Vp8Hip:
         self.nmb = (self.g.aligned_w // 16) * (self.g.aligned_h // 16)
         self.num_fb, self.num_slots = num_fb, num_slots
 
+    def memory_usage(self):
+        """vp8hip_memory_usage -> dict of bytes the context holds on the device: raster_pool, tile_pool, slots, block_pool,
+        entropy_input, packed_staging"""
+        out = (ctypes.c_size_t * 6)()
+        self.L.vp8hip_memory_usage.argtypes = [c_void_p, c_void_p]
+        self._chk(self.L.vp8hip_memory_usage(self.h, out), "vp8hip_memory_usage")
+        return dict(zip(("raster_pool", "tile_pool", "slots", "block_pool", "entropy_input", "packed_staging"), [int(v) for v in out]))
+
     def pool_reset(self):
         self.L.vp8hip_pool_reset.argtypes = [c_void_p]
         self._chk(self.L.vp8hip_pool_reset(self.h), "vp8hip_pool_reset")

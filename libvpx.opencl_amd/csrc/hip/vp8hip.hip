@@ -347,6 +347,18 @@ int vp8hip_raster_pool(vp8hip_ctx *c)
     return 0;
 }
 
+extern "C" int vp8hip_memory_usage(const vp8hip_ctx *c, vp8hip_memory *out)
+{
+    if (!c || !out) return -2;
+    out->raster_pool = c->fb_block ? c->fb_stride * c->fb.size() : 0;
+    out->tile_pool = c->tile_block ? c->tile_frame * c->fb.size() + 8192 : 0;
+    out->slots = c->slot_block_dev ? c->slot_bytes * c->slots.size() + 4096 : 0;
+    out->block_pool = c->pool ? ((size_t)c->pool_chunks + 1) * c->chunk_blocks * 32 + 8192 : 0;
+    out->entropy_input = c->ent_frames_cap2[0] + c->ent_frames_cap2[1] + c->ent_data_cap2[0] + c->ent_data_cap2[1];
+    out->packed_staging = c->i420_cap;
+    return 0;
+}
+
 extern "C" int vp8hip_geometry(const vp8hip_ctx *c, vp8ir_geom *g)
 {
     if (!c || !g || !c->width) return -2;

@@ -135,3 +135,43 @@ def test_eager_raster_knob(pkg, monkeypatch):
         assert ctx.frames_md5(0, 10) == [gold[i % nsrc] for i in range(10)]
     finally:
         ctx.close()
+
+
+def test_the_pools_come_with_their_first_user(pkg):
+    """vp8hip_memory_usage: a context holds its IR slots from vp8hip_configure on; the tiled forms come with the first large launch,
+    the raster forms with the first reader that needs one -- hashing the frames and taking them out as packed I420 do not (both read
+    tiles), vp8hip_frame_download does --, and a small launch of key frames in a context that has only ever held tiles stays with
+    the kernels that write tiles."""
+    P = pkg
+    w, h, frames = P.read_ivf(ivf_path("kf_640x360"))
+    n = 600
+    ctx = P.Vp8Hip(0)
+    try:
+        ctx.configure(w, h, n, len(frames))
+        m = ctx.memory_usage()
+        assert m["slots"] > 0 and m["raster_pool"] == 0 and m["tile_pool"] == 0 and m["block_pool"] == 0
+        parser = P.Parser()
+        for i, data in enumerate(frames):
+            hdr = ctx.parse_into_slot(parser, data, i)
+            parser.swap(hdr)
+            ctx.upload(i)
+        parser.close()
+        gold = golden_md5("kf_640x360")
+        ctx.decode([(i % len(frames), i, None) for i in range(n)], P.STAGE_ALL)          # a large launch: tiles
+        m = ctx.memory_usage()
+        assert m["tile_pool"] > 0 and m["raster_pool"] == 0
+        assert ctx.frames_md5(0, n) == [gold[i % len(frames)] for i in range(n)]         # hashed as tiles
+        import hashlib
+        assert [hashlib.md5(f.tobytes()).hexdigest() for f in ctx.frames_i420(0, 70)] == [gold[i % len(frames)] for i in range(70)]
+        m = ctx.memory_usage()
+        assert m["raster_pool"] == 0 and m["packed_staging"] > 0
+        ctx.decode([(i, i, None) for i in range(3)], P.STAGE_ALL)                        # a small launch: stays tiled here
+        assert ctx.memory_usage()["raster_pool"] == 0
+        assert ctx.frames_md5(0, 3) == gold[:3]
+        assert P.planes_md5(*ctx.download_planes(1)) == gold[1]                          # a reader of the raster form
+        m = ctx.memory_usage()
+        assert m["raster_pool"] >= n * ctx.g.frame_size
+        ctx.decode([(i, i, None) for i in range(3)], P.STAGE_ALL)                        # small launches write raster from now on
+        assert [P.planes_md5(*ctx.download_planes(i)) for i in range(3)] == gold[:3]
+    finally:
+        ctx.close()
