@@ -498,6 +498,7 @@ def main():
         ctx.sync()
 
     elapsed_local, ms, st = timed_steps(P, ctx, jobs, F, args.steps, args.warmup, barrier)
+    mem_gb = {k: round(v / 1e9, 2) for k, v in ctx.memory_usage().items() if v}      # (what the timed step had resident on this rank)
     elapsed = elapsed_local
     per_rank = [elapsed_local]
     rank_cpus = [f"{len(my_cpus)} CPUs from {my_cpus[0]}" if my_cpus else None]
@@ -649,6 +650,7 @@ def main():
                             f"tiled form a large launch writes, read as such by the MD5 kernel and the batch download "
                             f"(config.consumers); MD5-checked vs the reference",
                 "frames_per_gpu_per_step": F,
+                "device_memory_GB": mem_gb,
                 "macroblocks_per_frame": nmb,
                 "parallelism": f"one stream of {world * F} frames sharded in contiguous blocks over {world} GPU(s) (rank r: frames "
                                f"[r*{F}, (r+1)*{F})), no pixel exchange; RCCL carries barriers, times and the MD5 listing",
