@@ -67,6 +67,9 @@ typedef struct vp8hip_stats {      /* filled by vp8hip_get_stats; times from HIP
     int   fused;                        /* 1: the lane-per-row kernels -- vp8_keyframe_kernel, or vp8_inter_pred_kernel +
                                            vp8_interframe_kernel -- reconstructed AND filtered the launch; recon_ms covers it,
                                            lf_ms is 0 */
+    int   pred_tiles;                   /* 1: the launch predicted its inter macroblocks from reference frames read as TILES
+                                           (vp8_inter_pred_tiles_kernel: what the launch before left, no tiled -> raster pass in
+                                           between); 0: from their border-extended raster form */
 } vp8hip_stats;
 
 /* device < 0: use the current HIP device.  Returns 0 or a negative error. */
@@ -261,9 +264,15 @@ int  vp8hip_frames_md5_list_async(vp8hip_ctx *ctx, const int *fbs, int n, uint8_
  * the context's stream; a no-op for frames that have it).  vp8hip_set_direct_download(ctx, 1): a batch download of tiled frames
  * into page-locked memory IS the tiled -> raster pass, a kernel writing the host buffer (the frames' raster form never exists in
  * HBM; what lands in the destination's border bytes is then undefined) -- faster than the copy engines on an otherwise idle
- * device, slower beside other kernels, hence off by default (VP8HIP_DIRECT_DOWNLOAD=1 sets the default). */
+ * device, slower beside other kernels, hence off by default (VP8HIP_DIRECT_DOWNLOAD=1 sets the default).
+ * INTER PREDICTION reads a reference frame in either form (round 5): a large launch whose references are all there as tiles and
+ * not all as raster frames -- streams decoded in lock step: every launch predicts from what the launch before left -- reads the
+ * tiles (vp8_inter_pred_tiles_kernel; borders are address clamps) and no conversion runs; any other launch reads the raster form,
+ * converting the references that lack it first.  vp8hip_set_pred_tiles(ctx, mode): 1 that rule (the default; VP8HIP_PRED_TILES
+ * sets it), 2 tiles whenever every reference has them, 0 never -- the three give the same frames, bit for bit. */
 int  vp8hip_frames_to_raster(vp8hip_ctx *ctx, int first_fb, int count);
 int  vp8hip_set_direct_download(vp8hip_ctx *ctx, int on);
+int  vp8hip_set_pred_tiles(vp8hip_ctx *ctx, int mode);
 /* Upload a whole frame buffer (frame_size bytes) -- tests and VP8_SET_REFERENCE. */
 int  vp8hip_frame_upload(vp8hip_ctx *ctx, int fb, const uint8_t *buf);
 int  vp8hip_frame_copy(vp8hip_ctx *ctx, int dst_fb, int src_fb);

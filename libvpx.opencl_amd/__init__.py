@@ -108,7 +108,7 @@ class Job(ctypes.Structure):
 class Stats(ctypes.Structure):
     _fields_ = [("recon_ms", ctypes.c_float), ("lf_ms", ctypes.c_float), ("extend_ms", ctypes.c_float),
                 ("recon_waves", c_int), ("lf_waves", c_int), ("workgroups", c_int), ("detile_pass", c_int),
-                ("lf_kernels", c_int), ("fused", c_int)]
+                ("lf_kernels", c_int), ("fused", c_int), ("pred_tiles", c_int)]
 
 
 # ------------------------------------------------------------------------------------------
@@ -384,6 +384,7 @@ def load_hip():
         L.vp8hip_frame_copy.argtypes = [c_void_p, c_int, c_int]
         L.vp8hip_frames_to_raster.argtypes = [c_void_p, c_int, c_int]
         L.vp8hip_set_direct_download.argtypes = [c_void_p, c_int]
+        L.vp8hip_set_pred_tiles.argtypes = [c_void_p, c_int]
         L.vp8hip_sync.argtypes = [c_void_p]
         L.vp8hip_join.argtypes = [c_void_p]
         L.vp8hip_get_stats_at.argtypes = [c_void_p, c_int, ctypes.POINTER(Stats)]

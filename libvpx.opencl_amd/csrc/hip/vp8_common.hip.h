@@ -13,7 +13,7 @@ struct DevJob {
     uint8_t        *dst;
     const uint8_t  *ref[4];       // [1..3] = last / golden / alt-ref frame buffers (inter frames); [0] unused
     uint8_t        *tile;         // lane-per-row (key-frame) pipeline: the job's macroblock-tiled scratch frame (VP8_TILE_BYTES per macroblock)
-    uint64_t        rsv[3];
+    const uint8_t  *ref_tile[3];  // the TILED forms of ref[1..3] (null where a reference has none): vp8_inter_pred_tiles_kernel
     // 64 + 8*8 + 4*8 = 160 B
 };
 static_assert(sizeof(DevJob) == 160, "DevJob layout");

@@ -26,7 +26,9 @@ typedef GLOBAL_AS u32x2_t *g_x2p;
 typedef u32x4_t u32x4_u4 __attribute__((aligned(4)));
 typedef u32x2_t u32x2_u4 __attribute__((aligned(4)));
 // `unit_of(unit, sbase, dbase)`: where macroblock row r of frame j (unit = j * rows + r) has its tiles and where the frame's raster form is
-template <class F>
+// RETILE: the other way round -- the tiles of a frame that only exists in raster form (with its borders: the first window's four
+// pixels left of the frame and the last window's right of it are border pixels, which no reader of tiles looks at)
+template <bool RETILE = false, class F>
 __device__ __forceinline__ void detile_body(int nunits, DevGeom g, F unit_of)
 {
     const int cols = g.mb_cols;
@@ -46,7 +48,7 @@ __device__ __forceinline__ void detile_body(int nunits, DevGeom g, F unit_of)
     // a workgroup takes macroblock rows blockIdx.x, blockIdx.x + gridDim.x, ... of the launch
 #pragma unroll 1
     for (int unit = blockIdx.x; unit < nunits; unit += gridDim.x) {
-        const GLOBAL_AS unsigned char *sbase;
+        GLOBAL_AS unsigned char *sbase;
         GLOBAL_AS unsigned char *dbase;
         int r;
         unit_of(unit, sbase, dbase, r);
@@ -55,12 +57,16 @@ __device__ __forceinline__ void detile_body(int nunits, DevGeom g, F unit_of)
         unsigned so = soff, dO = doff;
         if (luma) {
 #pragma unroll 1
-            for (int left = ntiles; left > 0; left -= 8, so += 8 * VP8_TILE_BYTES, dO += 128)
-                *(GLOBAL_AS u32x4_u4 *)(dbase + dO) = *(const GLOBAL_AS u32x4_t *)(sbase + so);
+            for (int left = ntiles; left > 0; left -= 8, so += 8 * VP8_TILE_BYTES, dO += 128) {
+                if constexpr (RETILE) *(GLOBAL_AS u32x4_t *)(sbase + so) = *(const GLOBAL_AS u32x4_u4 *)(dbase + dO);
+                else *(GLOBAL_AS u32x4_u4 *)(dbase + dO) = *(const GLOBAL_AS u32x4_t *)(sbase + so);
+            }
         } else {
 #pragma unroll 1
-            for (int left = ntiles; left > 0; left -= 8, so += 8 * VP8_TILE_BYTES, dO += 64)
-                *(GLOBAL_AS u32x2_u4 *)(dbase + dO) = *(const GLOBAL_AS u32x2_t *)(sbase + so);
+            for (int left = ntiles; left > 0; left -= 8, so += 8 * VP8_TILE_BYTES, dO += 64) {
+                if constexpr (RETILE) *(GLOBAL_AS u32x2_t *)(sbase + so) = *(const GLOBAL_AS u32x2_u4 *)(dbase + dO);
+                else *(GLOBAL_AS u32x2_u4 *)(dbase + dO) = *(const GLOBAL_AS u32x2_t *)(sbase + so);
+            }
         }
     }
 }
@@ -69,10 +75,24 @@ extern "C" __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_vgpr
 vp8_detile_kf_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g)
 {
     const int rows = g.mb_rows;
-    detile_body(njobs * rows, g, [&](int unit, const GLOBAL_AS unsigned char *&sbase, GLOBAL_AS unsigned char *&dbase, int &r) {
+    detile_body(njobs * rows, g, [&](int unit, GLOBAL_AS unsigned char *&sbase, GLOBAL_AS unsigned char *&dbase, int &r) {
         const int j = unit / rows;
         r = unit - j * rows;
-        sbase = (const GLOBAL_AS unsigned char *)jobs[j].tile;
+        sbase = (GLOBAL_AS unsigned char *)jobs[j].tile;
+        dbase = (GLOBAL_AS unsigned char *)jobs[j].dst;
+    });
+}
+
+// Raster frame buffer -> macroblock-window tiles: a reference frame that only exists in raster form -- decoded by a small launch,
+// uploaded (VP8_SET_REFERENCE) -- for a launch that reads its other references as tiles (vp8_inter_pred_tiles_kernel)
+extern "C" __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(16)))
+vp8_retile_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g)
+{
+    const int rows = g.mb_rows;
+    detile_body<true>(njobs * rows, g, [&](int unit, GLOBAL_AS unsigned char *&sbase, GLOBAL_AS unsigned char *&dbase, int &r) {
+        const int j = unit / rows;
+        r = unit - j * rows;
+        sbase = (GLOBAL_AS unsigned char *)jobs[j].tile;
         dbase = (GLOBAL_AS unsigned char *)jobs[j].dst;
     });
 }
@@ -86,10 +106,10 @@ extern "C" __global__ void __launch_bounds__(256)
 vp8_detile_run_kernel(const uint8_t *__restrict__ tiles, size_t tstride, uint8_t *__restrict__ dst, size_t dstride, int count, DevGeom g)
 {
     const int rows = g.mb_rows;
-    detile_body(count * rows, g, [&](int unit, const GLOBAL_AS unsigned char *&sbase, GLOBAL_AS unsigned char *&dbase, int &r) {
+    detile_body(count * rows, g, [&](int unit, GLOBAL_AS unsigned char *&sbase, GLOBAL_AS unsigned char *&dbase, int &r) {
         const int j = unit / rows;
         r = unit - j * rows;
-        sbase = (const GLOBAL_AS unsigned char *)(tiles + tstride * (size_t)j);
+        sbase = (GLOBAL_AS unsigned char *)(tiles + tstride * (size_t)j);
         dbase = (GLOBAL_AS unsigned char *)(dst + dstride * (size_t)j);
     });
 }

@@ -28,11 +28,19 @@
 // vp8_interframe_kernel, which reads a block row's prediction right before it writes finished pixels into the same tile, never
 // overwrites what it has not read yet.  Integer only; no MFMA by design.
 #include "vp8_block_prims.hip.h"
+#include <type_traits>
 #ifndef IP_AHEAD
 #define IP_AHEAD 6
 #endif
 #ifndef IP_WAVES
 #define IP_WAVES 4        // (five or six waves per SIMD only fit with spills: 9.9 / 10.0 ms against 9.1-9.6)
+#endif
+#ifndef IP_TILE_ALIGNED
+#define IP_TILE_ALIGNED 1 // the tile reader's loads start at a row piece (16 / 8 bytes aligned) and the dwords are picked by selects; 0: they start at
+                          // the first dword needed (4-byte aligned) and fewer selects put the pieces together
+#endif
+#ifndef IP_WAVES_TILES
+#define IP_WAVES_TILES 3  // (the tile reader's rows in flight are two loads each, and a strip carries its two column arrangements)
 #endif
 
 namespace {
@@ -44,6 +52,7 @@ typedef u32 u32x2 __attribute__((ext_vector_type(2)));
 typedef u32 u32x4 __attribute__((ext_vector_type(4)));
 typedef u32x4 u32x4_u __attribute__((aligned(4)));          // sixteen bytes at a four-byte boundary
 typedef GLOBAL_AS const u32x4_u *g_cu32x4up;
+typedef GLOBAL_AS const u32x4 *g_cu32x4p;
 
 // filter taps as (t, t) pairs of 16-bit lanes: [0] six-tap (filter.c:27-39), [1] bilinear (filter.c:16-26) on the six-tap grid
 #define T2_(a) (((u32)(unsigned short)(a)) * 0x10001u)
@@ -104,25 +113,191 @@ __device__ __forceinline__ u32 v_pass(const Row4 &h0, const Row4 &h1, const Row4
     return perm(__builtin_bit_cast(u32, finish2(a23)), __builtin_bit_cast(u32, finish2(a01)), 0x06040200u);
 }
 
-// A column strip of NOUT rows: src = the pixel two left of and two above the strip's first one in the reference plane,
-// dst / dstride = where output row y goes (rows 4.. of an 8-row strip at dst + dhalf + dstride * (y - 4): the chroma layout)
-template <int NOUT>
-__device__ __forceinline__ void strip(g_cu8p src, int stride, const Taps &tx, const Taps &ty, g_u8p dst, int dstride, int dhalf)
-{
-    const u32 sh = (u32)(unsigned long)src & 3u;
-    g_cu8p rp = src - sh;
-    // the source rows are requested AHEAD rows before they are filtered (the compiler would not move a load above the store of
-    // the output row before it -- for all it knows they alias -- and one row in flight at a time is a latency chain)
-    constexpr int NIN = NOUT + 5, AHEAD = NIN < 8 ? NIN : 8;
-    u32x3 q[AHEAD];
+// ---------------------------------------------------------------------------------------------------------------------
+// Where a strip's source rows come from.  A strip asks its source for row i twice: issue(i) requests it -- AHEAD rows before it
+// is filtered (the compiler would not move a load above the store of the output row before it -- for all it knows they alias --
+// and one row in flight at a time is a latency chain) -- and finish(raw, i) hands out the aligned dwords that hold the row's
+// pixels from byte `sh` of the first one on.
+//
+// RASTER: the reference's own frame buffer (yv12config.c:55-112) with its borders extended (extend.c, onyxd_if.c:607): a row is
+// one load.  What vp8_build_inter_predictors_mb reads (xd->pre, reconinter.c:393-441).
+template <int NDW> struct VecOf;
+template <> struct VecOf<4> { typedef u32x4 T; typedef u32x4_u TU; };
+template <> struct VecOf<3> { typedef u32x3 T; typedef u32x3 TU; };
+template <int NDW>
+struct RasterSrc {
+    typedef typename VecOf<NDW>::T Vec;
+    typedef typename VecOf<NDW>::TU Raw;
+    static constexpr bool PIN = false;
+    g_cu8p rp; int stride; u32 sh;
+    // src = the pixel two left of and two above the strip's first one in the reference plane
+    __device__ __forceinline__ RasterSrc(g_cu8p src, int stride_) : stride(stride_) { sh = (u32)(unsigned long)src & 3u; rp = src - sh; }
+    __device__ __forceinline__ Raw issue(int i) const { return *(GLOBAL_AS const Raw *)(rp + (long)i * stride); }
+    __device__ __forceinline__ Vec finish(const Raw &r, int) const { return r; }
+};
+
+// TILES: the reference frame as a large launch left it (macroblock-window tiles, vp8_keyframe_simt.hip KT_*; round 5) -- n streams
+// decoded in lock step predict every launch from what the launch before wrote, and the tiled -> raster pass + the border kernel in
+// front of every launch were 15 of its 67 ms.  A tile row piece is 16 (chroma: 8) bytes of ONE pixel row, the tile of the next
+// macroblock 384 bytes on; rows 0..11 (chroma 0..3) of a macroblock row stand in the macroblocks' WINDOWS, four pixels to the left
+// (pixel x at byte (x + 4) & 15 of tile (x + 4) >> 4), rows 12..15 (4..7) macroblock-aligned.  So a row of a strip -- 13 or 9
+// pixels from any x -- is two loads, the tail of one tile's piece and the head of the next tile's (chroma strips eight wide: three
+// pieces), put together by selects, and which of the two column arrangements applies is decided row by row.  There are no
+// borders: rows and columns beyond the frame are the frame's last (vp8_extend_mb_row / vp8_yv12_extend_frame_borders replicate,
+// extend.c:160-185, yv12extend.c:24-90) -- a clamped row index, and for the few strips that reach past the left or right
+// edge a fix-up of the loaded bytes (`edge`, taken by a wave only when one of its lanes needs it).  Motion vectors that point
+// further out than any border (no conforming stream has them: reconinter.c:348-382 clamps) read replicated pixels where the raster
+// kernel reads whatever the clamped address holds: both are memory-safe, neither is specified.
+template <bool CHROMA, int NDW>
+struct TileSrc {
+    typedef typename VecOf<NDW>::T Vec;
+    static constexpr int NPX = NDW == 4 ? 13 : 9;               // pixels a row needs
+    static constexpr int LGR = CHROMA ? 3 : 4, RMASK = (1 << LGR) - 1, BOT0 = CHROMA ? 4 : 12;     // pixel rows per tile row; first macroblock-aligned one
+    struct Raw { u32 e[CHROMA ? 5 : (IP_TILE_ALIGNED ? 8 : 2 * NDW)]; int jsel; };
+    // (the strip keeps the scheduler from moving a row's requests: with two loads and nine registers a row in flight it sinks them down to
+    // their use to save registers, and every row then waits for its own loads)
+#ifdef IP_NOPIN
+    static constexpr bool PIN = false;
+#else
+    static constexpr bool PIN = true;
+#endif
+    g_cu8p rowp;            // TWO tiles before the plane's first row piece in the first tile of the tile row the strip begins in
+    int yy0, tlo, thi;      // the strip's first row within its tile row; rows above the plane's first / below its last count as those
+    u32 rowbytes;           // bytes per tile row
+    u32 colW, colB; int jW, jB;     // window rows / bottom rows: byte offset of the first load from rowp, the first dword wanted within the piece
+    u32 sh;
+    bool any_edge, edge;    // a lane of the wave / this lane reaches past the left or right edge
+    u32 em[NDW], eselA, eselB;      // bytes to replace (per dword); v_perm selectors that splat the edge pixel out of dwords (0, 1) / (2, 3)
+    // tiles: the frame's tiles + the plane's offset in a tile (0, 256 U, 288 V); W, H: the plane's size; (x0, y0): the strip's first pixel
+    __device__ __forceinline__ TileSrc(g_cu8p tiles, int cols, int W, int H, int x0, int y0)
+    {
+        rowbytes = (u32)(cols + 1) * VP8_TILE_BYTES;
+        const int yc = max(0, min(y0, H - 1));
+        const int ybase = yc & ~RMASK;
+        yy0 = y0 - ybase; tlo = -ybase; thi = H - 1 - ybase;     // row i is row clamp(yy0 + i, tlo, thi) counted from the tile row's first
+        rowp = tiles + (long)(yc >> LGR) * rowbytes - 2 * VP8_TILE_BYTES;
+        x0 = max(-64, min(x0, W + 64));
+        const int xl = max(min(x0, W - 1), 1 - NPX);            // what is loaded: NPX bytes from xl on, at least one of them inside
+        sh = (u32)xl & 3u;
+        constexpr int PW = CHROMA ? 8 : 16, LG = CHROMA ? 3 : 4;
+        const int xs = xl + 4;
+        // (+ 2 tiles: rowp stands two tiles early, so that the offsets are never negative -- a strip that begins twelve pixels left of
+        // the frame has its first chroma piece in tile -2, and the loads are in bounds: VP8HIP_TILE_FRONT bytes lie in front of the pool)
+        jW = (xs & (PW - 1)) >> 2; colW = (u32)(((xs >> LG) + 2) * VP8_TILE_BYTES + 4 * jW);
+        jB = (xl & (PW - 1)) >> 2; colB = (u32)(((xl >> LG) + 2) * VP8_TILE_BYTES + 4 * jB + (CHROMA ? 32 : 0));     // (chroma rows 4..7: 288 + 8 yy)
+        if (CHROMA || IP_TILE_ALIGNED) { colW -= 4 * jW; colB -= 4 * jB; }  // (from the piece's first dword)
+        edge = x0 < 0 || x0 + NPX > W;
+        any_edge = __builtin_amdgcn_ballot_w64(edge) != 0;
+        eselA = eselB = 0x0c0c0c0cu;
 #pragma unroll
-    for (int i = 0; i < AHEAD; i++) q[i] = *(g_cu32x3p)(rp + (long)i * stride);
+        for (int k = 0; k < NDW; k++) em[k] = 0;
+        if (any_edge) {
+            // byte t of the loaded dwords is pixel x0 + t - sh (xl + t - sh where that differs, all of them replaced then)
+            const bool left = x0 < 0;
+            const int n = left ? min(16, (int)sh - x0) : max(0, W - x0 + (int)sh);      // left: bytes [0, n) replaced; right: [n, 16)
+            const int ed = (left ? -xl : W - 1 - xl) + (int)sh;                            // where pixel 0 / W - 1 lies
+            // (a v_perm selector byte 0x0c gives 0: the splat comes out of one pair of dwords, zeros out of the other)
+            const u32 spl = (u32)(ed & 7) * 0x01010101u;
+            eselA = ed < 8 ? spl : 0x0c0c0c0cu; eselB = ed < 8 ? 0x0c0c0c0cu : spl;
+#pragma unroll
+            for (int k = 0; k < NDW; k++) {
+                const int nk = max(0, min(4, n - 4 * k));
+                const u32 low = nk >= 4 ? 0xffffffffu : (1u << (8 * nk)) - 1u;
+                em[k] = edge ? (left ? low : ~low) : 0u;
+            }
+        }
+    }
+    __device__ __forceinline__ Raw issue(int i) const
+    {
+        const int t = max(tlo, min(yy0 + i, thi));              // row i: t >> LGR tile rows on, row t & RMASK of it
+        const u32 yy = (u32)t & RMASK;
+        const bool bot = yy >= BOT0;
+        const u32 off = __umul24((u32)t >> LGR, rowbytes) + (bot ? colB : colW) + (yy << LGR);
+        g_cu8p p = rowp + off;
+        Raw r;
+        r.jsel = bot ? jB : jW;
+        if constexpr (!CHROMA) {
+            if constexpr (IP_TILE_ALIGNED) {
+                // this tile's row piece and what can be wanted of the next one's: dwords 0 .. jsel + NDW - 1 <= NDW + 2 of the eight.
+                // (Not a dword more: a component of a load's result that nothing reads is a register the allocator hands out again
+                // while the load is in flight, and the compiler then waits for the load -- for ALL loads -- right behind it.)
+                const u32x4 a = *(g_cu32x4p)p;
+#pragma unroll
+                for (int k = 0; k < 4; k++) r.e[k] = a[k];
+                if constexpr (NDW == 4) {
+                    const u32x3 b = *(GLOBAL_AS const u32x3 *)(p + VP8_TILE_BYTES);
+                    r.e[4] = b.x; r.e[5] = b.y; r.e[6] = b.z; r.e[7] = 0;
+                } else {
+                    const u32x2 b = *(GLOBAL_AS const u32x2 *)(p + VP8_TILE_BYTES);
+                    r.e[4] = b.x; r.e[5] = b.y; r.e[6] = r.e[7] = 0;
+                }
+            } else {
+                typedef typename VecOf<NDW>::TU VU;
+                const Vec a = *(GLOBAL_AS const VU *)p, b = *(GLOBAL_AS const VU *)(p + VP8_TILE_BYTES - 16);
+#pragma unroll
+                for (int k = 0; k < NDW; k++) { r.e[k] = a[k]; r.e[NDW + k] = b[k]; }
+            }
+        } else {
+            // the piece, the next tile's piece, and for the wide strip the first dword of the third
+            typedef GLOBAL_AS const u32x2 *g_cu32x2p;
+            const u32x2 a = *(g_cu32x2p)p, b = *(g_cu32x2p)(p + VP8_TILE_BYTES);
+            r.e[0] = a.x; r.e[1] = a.y; r.e[2] = b.x; r.e[3] = b.y;
+            r.e[4] = NDW == 4 ? *(GLOBAL_AS const u32 *)(p + 2 * VP8_TILE_BYTES) : 0u;
+        }
+        return r;
+    }
+    __device__ __forceinline__ Vec finish(const Raw &r, int) const
+    {
+        Vec d;
+        if constexpr (!CHROMA) {
+            if constexpr (IP_TILE_ALIGNED) {
+                // dwords jsel .. jsel + NDW - 1 of the eight: a shifter of two stages, as bit selects under masks (written as
+                // `jsel & 2 ? e[k + 2] : e[k]` the compiler sees e[jsel + k] and puts the eight dwords in scratch to index them)
+                const u32 m2 = (u32)__builtin_amdgcn_sbfe((int)r.jsel, 1, 1), m1 = (u32)__builtin_amdgcn_sbfe((int)r.jsel, 0, 1);
+                u32 f[NDW + 1];
+#pragma unroll
+                for (int k = 0; k < NDW + 1; k++) f[k] = (r.e[k + 2] & m2) | (r.e[k] & ~m2);
+#pragma unroll
+                for (int k = 0; k < NDW; k++) d[k] = (f[k + 1] & m1) | (f[k] & ~m1);
+            } else {
+                // dword k comes from the first piece while k + jsel < 4 (its load began at dword jsel), then from the next tile's (that
+                // load began 16 bytes before the piece: its dword k is the piece's dword k + jsel - 4)
+#pragma unroll
+                for (int k = 0; k < NDW; k++) d[k] = k + r.jsel < 4 ? r.e[k] : r.e[NDW + k];
+            }
+        } else {
+            // dwords jsel .. of the five (jsel: 0 or 1)
+            const u32 m1 = (u32)-(int)r.jsel;
+#pragma unroll
+            for (int k = 0; k < NDW; k++) d[k] = (r.e[k + 1] & m1) | (r.e[k] & ~m1);
+        }
+        // the edge pixel out of whichever dword holds it, four times, into the bytes beyond the edge.  Unconditional -- the masks of
+        // a lane that reaches past no edge are empty --: a branch in the row loop, even a wave-uniform one without a load in it,
+        // makes the compiler wait for EVERY load in flight at each row (s_waitcnt vmcnt(0)), and the strip is a latency chain
+        // (14.7 ms per 4096 frames against 9.4 for the raster reader, whatever the instruction count)
+        const u32 ev = perm(d[1], d[0], eselA) | perm(NDW == 4 ? d[3] : 0u, d[2], eselB);
+#pragma unroll
+        for (int k = 0; k < NDW; k++) d[k] = (d[k] & ~em[k]) | (ev & em[k]);
+        return d;
+    }
+};
+
+// A column strip of NOUT rows, four pixels wide: dst / dstride = where output row y goes (rows 4.. of an 8-row strip at
+// dst + dhalf + dstride * (y - 4): the chroma layout)
+template <int NOUT, class SRC>
+__device__ __forceinline__ void strip(const SRC &src, const Taps &tx, const Taps &ty, g_u8p dst, int dstride, int dhalf)
+{
+    constexpr int NIN = NOUT + 5, AHEAD = NIN < 8 ? NIN : 8;
+    typename SRC::Raw q[AHEAD];
+#pragma unroll
+    for (int i = 0; i < AHEAD; i++) q[i] = src.issue(i);
     Row4 H[6];
 #pragma unroll
     for (int i = 0; i < NIN; i++) {
-        const u32x3 d = q[i % AHEAD];
-        if (i + AHEAD < NIN) q[i % AHEAD] = *(g_cu32x3p)(rp + (long)(i + AHEAD) * stride);
-        H[i % 6] = h_pass(d, sh, tx);
+        const u32x3 d = src.finish(q[i % AHEAD], i);
+        if (i + AHEAD < NIN) q[i % AHEAD] = src.issue(i + AHEAD);
+        if constexpr (SRC::PIN) __builtin_amdgcn_sched_barrier(0);
+        H[i % 6] = h_pass(d, src.sh, tx);
         if (i >= 5) {
             const int y = i - 5;
             const u32 o = v_pass(H[(i + 1) % 6], H[(i + 2) % 6], H[(i + 3) % 6], H[(i + 4) % 6], H[(i + 5) % 6], H[i % 6], ty);
@@ -150,26 +325,25 @@ __device__ __forceinline__ Row8 h_pass8(u32x4 d, u32 sh, const Taps &tx)
     for (int k = 0; k < 6; k++) { a01 += P[k] * tx.t[k]; a23 += P[k + 2] * tx.t[k]; a45 += P[k + 4] * tx.t[k]; a67 += P[k + 6] * tx.t[k]; }
     return { { finish2(a01), finish2(a23) }, { finish2(a45), finish2(a67) } };
 }
-template <int NOUT>
-__device__ __forceinline__ void strip8(g_cu8p src, int stride, const Taps &tx, const Taps &ty, g_u8p dst, int s)
+template <int NOUT, class SRC>
+__device__ __forceinline__ void strip8(const SRC &src, const Taps &tx, const Taps &ty, g_u8p dst, int s)
 {
     // Output in 16-byte stores (8-byte ones -- 19 write requests per macroblock at the L2 instead of 6 -- cost this kernel 39 % of
     // its time).  NOUT == 16, luma: dst = the macroblock's tile, lanes s = 0 / 1 hold the left / right half of its rows; after
     // every second row they swap a half row (DPP), lane 0 stores the whole row y - 1 and lane 1 the whole row y.  NOUT == 8,
     // chroma: dst = the plane's rows 0..3 (rows 4..7 64 bytes on), a lane has whole rows: two of them are one store.
     u32x2 prev = { 0, 0 };
-    const u32 sh = (u32)(unsigned long)src & 3u;
-    g_cu8p rp = src - sh;
     constexpr int NIN = NOUT + 5, AHEAD = IP_AHEAD < NIN ? IP_AHEAD : NIN;
-    u32x4_u q[AHEAD];
+    typename SRC::Raw q[AHEAD];
 #pragma unroll
-    for (int i = 0; i < AHEAD; i++) q[i] = *(g_cu32x4up)(rp + (long)i * stride);
+    for (int i = 0; i < AHEAD; i++) q[i] = src.issue(i);
     Row8 H[6];
 #pragma unroll
     for (int i = 0; i < NIN; i++) {
-        const u32x4 d = q[i % AHEAD];
-        if (i + AHEAD < NIN) q[i % AHEAD] = *(g_cu32x4up)(rp + (long)(i + AHEAD) * stride);
-        H[i % 6] = h_pass8(d, sh, tx);
+        const u32x4 d = src.finish(q[i % AHEAD], i);
+        if (i + AHEAD < NIN) q[i % AHEAD] = src.issue(i + AHEAD);
+        if constexpr (SRC::PIN) __builtin_amdgcn_sched_barrier(0);
+        H[i % 6] = h_pass8(d, src.sh, tx);
         if (i >= 5) {
             const int y = i - 5;
             const Row8 &h0 = H[(i + 1) % 6], &h1 = H[(i + 2) % 6], &h2 = H[(i + 3) % 6], &h3 = H[(i + 4) % 6], &h4 = H[(i + 5) % 6], &h5 = H[i % 6];
@@ -209,9 +383,10 @@ __device__ __forceinline__ void clamp_chroma_mv(int &row, int &col, int e_left, 
 
 } // namespace
 
-// grid: any number of blocks of four waves (a wave takes units unit, unit + waves, ...); upf = units (64 macroblocks) per frame
-extern "C" __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(IP_WAVES, 8)))
-vp8_inter_pred_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g, int upf)
+// grid: any number of blocks of four waves (a wave takes units unit, unit + waves, ...); upf = units (64 macroblocks) per frame.
+// TILES: the reference frames are read as tiles (DevJob::ref_tile), else as border-extended raster frames (DevJob::ref).
+template <bool TILES>
+__device__ __forceinline__ void inter_pred(const DevJob *__restrict__ jobs, int njobs, DevGeom g, int upf)
 {
     __shared__ u32 s_w0a[4][64];
     __shared__ unsigned char s_plaina[4][64], s_splita[4][64];
@@ -250,12 +425,33 @@ vp8_inter_pred_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g, int
             m.e_left = -((m.c * 16) << 3); m.e_right = ((cols - 1 - m.c) * 16) << 3;
             m.e_top = -((m.r * 16) << 3); m.e_bottom = ((rows - 1 - m.r) * 16) << 3;
             const int rf = (m.w0 >> 16) & 3;
-            m.ref = (g_cu8p)(rf == 1 ? job.ref[1] : rf == 2 ? job.ref[2] : job.ref[3]);
+            if constexpr (TILES) m.ref = (g_cu8p)(rf == 1 ? job.ref_tile[0] : rf == 2 ? job.ref_tile[1] : job.ref_tile[2]);
+            else m.ref = (g_cu8p)(rf == 1 ? job.ref[1] : rf == 2 ? job.ref[2] : job.ref[3]);
             m.tile = tiles + ((long)m.r * (cols + 1) + m.c) * VP8_TILE_BYTES;
             return m;
         };
+        // a strip's source: NDW dwords a row (4: thirteen pixels, 3: nine) from (x, y) of the plane (0 Y, 1 U, 2 V) on
+        auto luma_src = [&](auto ndw, const Mb &m, int x, int y) {
+            constexpr int NDW = decltype(ndw)::value;
+            if constexpr (TILES) return TileSrc<false, NDW>(m.ref, cols, g.aligned_w, g.aligned_h, x, y);
+            else {
+                // memory safety only (a conforming stream never triggers these): every tap inside the plane and its border
+                const int sx = max(-32, min(x, g.aligned_w + 32 - 4 * NDW)), sy = max(-32, min(y, g.aligned_h + 32 - (NDW == 4 ? 21 : 9)));
+                return RasterSrc<NDW>(m.ref + g.y_off + (long)sy * g.y_stride + sx, g.y_stride);
+            }
+        };
+        auto chroma_src = [&](auto ndw, const Mb &m, int pl, int x, int y) {
+            constexpr int NDW = decltype(ndw)::value;
+            if constexpr (TILES) return TileSrc<true, NDW>(m.ref + 256 + 32 * pl, cols, g.aligned_w / 2, g.aligned_h / 2, x, y);
+            else {
+                const int sx = max(-16, min(x, g.aligned_w / 2 + 16 - 4 * NDW)), sy = max(-16, min(y, g.aligned_h / 2 + 16 - (NDW == 4 ? 13 : 9)));
+                return RasterSrc<NDW>(m.ref + (pl ? g.v_off : g.u_off) + (long)sy * g.uv_stride + sx, g.uv_stride);
+            }
+        };
+        typedef std::integral_constant<int, 4> W8;      // strips eight pixels wide
+        typedef std::integral_constant<int, 3> W4;      // 4x4 blocks
 
-        // ---- one motion vector: vp8_build_inter16x16_predictors_mb.  Luma: 16 macroblocks x 4 strips
+        // ---- one motion vector: vp8_build_inter16x16_predictors_mb.  Luma: 32 macroblocks x 2 strips
         for (int i0 = 0; i0 < nP; i0 += 32) {
             const int mi = i0 + (lane >> 1), s = lane & 1;
             if (mi < nP) {
@@ -263,11 +459,8 @@ vp8_inter_pred_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g, int
                 const u32 mvw = mvs[m.idx * 16];
                 int mrow = sext16(mvw), mcol = hi16(mvw);
                 if ((m.w0 >> 24) & VP8IR_MB_CLAMP) clamp_luma_mv(mrow, mcol, m.e_left, m.e_right, m.e_top, m.e_bottom);
-                // memory safety only (a conforming stream never triggers these): every tap inside the plane and its border
-                const int sx = max(-32 + 2, min(m.c * 16 + (mcol >> 3), g.aligned_w + 32 - 22));
-                const int sy = max(-32 + 2, min(m.r * 16 + (mrow >> 3), g.aligned_h + 32 - 19));
                 const Taps tx = load_taps(bil, mcol & 7), ty = load_taps(bil, mrow & 7);
-                strip8<16>(m.ref + g.y_off + (long)(sy - 2) * g.y_stride + (sx - 2 + 8 * s), g.y_stride, tx, ty, m.tile, s);
+                strip8<16>(luma_src(W8(), m, m.c * 16 + (mcol >> 3) - 2 + 8 * s, m.r * 16 + (mrow >> 3) - 2), tx, ty, m.tile, s);
             }
         }
         // chroma: 32 macroblocks x 2 planes; the MV from the CLAMPED luma MV (reconinter.c:419-424)
@@ -282,11 +475,8 @@ vp8_inter_pred_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g, int
                 mcol = (short)(mcol + (1 | (mcol >> 31)));
                 mrow /= 2; mcol /= 2;
                 if (fullpix) { mrow &= ~7; mcol &= ~7; }
-                const int sx = max(-16 + 2, min(m.c * 8 + (mcol >> 3), g.aligned_w / 2 + 16 - 14));
-                const int sy = max(-16 + 2, min(m.r * 8 + (mrow >> 3), g.aligned_h / 2 + 16 - 11));
                 const Taps tx = load_taps(bil, mcol & 7), ty = load_taps(bil, mrow & 7);
-                strip8<8>(m.ref + (pl ? g.v_off : g.u_off) + (long)(sy - 2) * g.uv_stride + (sx - 2), g.uv_stride, tx, ty,
-                          m.tile + 256 + 32 * pl, 0);
+                strip8<8>(chroma_src(W8(), m, pl, m.c * 8 + (mcol >> 3) - 2, m.r * 8 + (mrow >> 3) - 2), tx, ty, m.tile + 256 + 32 * pl, 0);
             }
         }
         // ---- SPLITMV: build_inter4x4_predictors_mb, a 4x4 block per lane (partitions of 8x8 / 16x8 / 8x16 carry their MV in every
@@ -298,10 +488,8 @@ vp8_inter_pred_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g, int
                 const u32 mvw = mvs[m.idx * 16 + b];
                 int mrow = sext16(mvw), mcol = hi16(mvw);
                 if ((m.w0 >> 24) & VP8IR_MB_CLAMP) clamp_luma_mv(mrow, mcol, m.e_left, m.e_right, m.e_top, m.e_bottom);
-                const int sx = max(-32 + 2, min(m.c * 16 + 4 * (b & 3) + (mcol >> 3), g.aligned_w + 32 - 10));
-                const int sy = max(-32 + 2, min(m.r * 16 + 4 * (b >> 2) + (mrow >> 3), g.aligned_h + 32 - 7));
                 const Taps tx = load_taps(bil, mcol & 7), ty = load_taps(bil, mrow & 7);
-                strip<4>(m.ref + g.y_off + (long)(sy - 2) * g.y_stride + (sx - 2), g.y_stride, tx, ty,
+                strip<4>(luma_src(W4(), m, m.c * 16 + 4 * (b & 3) + (mcol >> 3) - 2, m.r * 16 + 4 * (b >> 2) + (mrow >> 3) - 2), tx, ty,
                          m.tile + 64 * (b >> 2) + 4 * (b & 3), 16, 0);
             }
         }
@@ -321,12 +509,22 @@ vp8_inter_pred_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g, int
                 mrow /= 8; mcol /= 8;
                 if (fullpix) { mrow &= ~7; mcol &= ~7; }
                 if ((m.w0 >> 24) & VP8IR_MB_CLAMP) clamp_chroma_mv(mrow, mcol, m.e_left, m.e_right, m.e_top, m.e_bottom);
-                const int sx = max(-16 + 2, min(m.c * 8 + 4 * (blk & 1) + (mcol >> 3), g.aligned_w / 2 + 16 - 10));
-                const int sy = max(-16 + 2, min(m.r * 8 + 4 * (blk >> 1) + (mrow >> 3), g.aligned_h / 2 + 16 - 7));
                 const Taps tx = load_taps(bil, mcol & 7), ty = load_taps(bil, mrow & 7);
-                strip<4>(m.ref + (pl ? g.v_off : g.u_off) + (long)(sy - 2) * g.uv_stride + (sx - 2), g.uv_stride, tx, ty,
+                strip<4>(chroma_src(W4(), m, pl, m.c * 8 + 4 * (blk & 1) + (mcol >> 3) - 2, m.r * 8 + 4 * (blk >> 1) + (mrow >> 3) - 2), tx, ty,
                          m.tile + 256 + 32 * pl + 64 * (blk >> 1) + 4 * (blk & 1), 8, 0);
             }
         }
     }
+}
+
+extern "C" __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(IP_WAVES, 8)))
+vp8_inter_pred_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g, int upf)
+{
+    inter_pred<false>(jobs, njobs, g, upf);
+}
+// ... from reference frames that are there as tiles (the frames a large launch left: DevJob::ref_tile)
+extern "C" __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(IP_WAVES_TILES, 8)))
+vp8_inter_pred_tiles_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g, int upf)
+{
+    inter_pred<true>(jobs, njobs, g, upf);
 }

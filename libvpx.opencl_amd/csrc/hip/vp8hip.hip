@@ -31,6 +31,7 @@ static void read_knobs(Knobs &k)
 {
     const char *e = getenv("VP8HIP_RECON");
     k.recon_force = !e ? 0 : !strcmp(e, "simt") ? 1 : !strcmp(e, "wave") ? 2 : 0;
+    k.pred_tiles = env_int("VP8HIP_PRED_TILES", 1);
     k.lgG = env_int("VP8HIP_SIMT_LGG", 0);
     k.simt_waves = env_int("VP8HIP_SIMT_WAVES", 0);
     k.wg_per_cu = env_int("VP8HIP_WG_PER_CU", 1);
@@ -64,8 +65,8 @@ extern "C" const char *vp8hip_last_error(const vp8hip_ctx *ctx) { return ctx ? c
 static void free_pools(vp8hip_ctx *c)
 {
     if (c->fb_block) (void)hipFree(c->fb_block);
-    if (c->tile_block) (void)hipFree(c->tile_block);
-    c->tile_block = nullptr;
+    if (c->tile_alloc) (void)hipFree(c->tile_alloc);
+    c->tile_block = c->tile_alloc = nullptr;
     if (c->slot_block_dev) (void)hipFree(c->slot_block_dev);
     if (c->pool) (void)hipFree(c->pool);
     if (c->d_pool_ctr) (void)hipFree(c->d_pool_ctr);
@@ -117,7 +118,7 @@ extern "C" int vp8hip_create(int device, vp8hip_ctx **out)
     c->max_lds = 160 * 1024;
     c->fb_block = nullptr; c->slot_block_dev = nullptr;
     read_knobs(c->knobs);
-    c->tile_block = nullptr; c->tile_frame = 0;
+    c->tile_block = c->tile_alloc = nullptr; c->tile_frame = 0;
     c->d_jobs = nullptr; c->h_jobs = nullptr; c->jobs_cap = 0;
     for (int k = 0; k < VP8HIP_NBUF; k++) { c->d_jobs2[k] = nullptr; c->h_jobs2[k] = nullptr; c->ev_jobs2[k] = nullptr; }
     c->parity = 0;
@@ -351,7 +352,7 @@ extern "C" int vp8hip_memory_usage(const vp8hip_ctx *c, vp8hip_memory *out)
 {
     if (!c || !out) return -2;
     out->raster_pool = c->fb_block ? c->fb_stride * c->fb.size() : 0;
-    out->tile_pool = c->tile_block ? c->tile_frame * c->fb.size() + 8192 : 0;
+    out->tile_pool = c->tile_block ? c->tile_frame * c->fb.size() + 8192 + VP8HIP_TILE_FRONT : 0;
     out->slots = c->slot_block_dev ? c->slot_bytes * c->slots.size() + 4096 : 0;
     out->block_pool = c->pool ? ((size_t)c->pool_chunks + 1) * c->chunk_blocks * 32 + 8192 : 0;
     out->entropy_input = c->ent_frames_cap2[0] + c->ent_frames_cap2[1] + c->ent_data_cap2[0] + c->ent_data_cap2[1];
@@ -759,6 +760,12 @@ static int fetch_impl(vp8hip_ctx *c, int first_fb, int count, uint8_t *dst, uint
     return 0;
 }
 
+extern "C" int vp8hip_set_pred_tiles(vp8hip_ctx *c, int mode)
+{
+    if (!c || mode < 0 || mode > 2) return fail(c, -2, "vp8hip_set_pred_tiles: bad arguments");
+    c->knobs.pred_tiles = mode;
+    return 0;
+}
 extern "C" int vp8hip_set_direct_download(vp8hip_ctx *c, int on)
 {
     if (!c) return -2;

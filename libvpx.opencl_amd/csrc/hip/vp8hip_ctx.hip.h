@@ -47,8 +47,11 @@ struct Slot {
 //   VP8HIP_INTER_SPLIT=N       launches of up to N frames with inter frames among them run vp8_inter_mb_kernel first (default 384; 0:
 //                              never).  It shortens a frame's critical path (1080p P frames, 1..16 per launch: recon 0.91 -> 0.46-0.56
 //                              ms; 128: 1.56 -> 1.45) and costs throughput in launches that fill the chip anyway (512: 3.82 -> 4.03)
+#define VP8HIP_TILE_FRONT 4096
 struct Knobs {
     int recon_force;       // 0 automatic, 1 lane-per-row, 2 wave-per-row
+    int pred_tiles;        // VP8HIP_PRED_TILES: 1 (default) a large launch whose references are all there as tiles, and not all as raster frames,
+                           // predicts from the tiles; 2: whenever all are there as tiles; 0: never (the raster form is made first)
     int inter_split, eager_raster, direct_download, download_blocks, d2h_prio, d2h_streams;
     int lgG, simt_waves, wg_per_cu, xcu, xcu_S, xcu_NW, recon_nw, lf_nw;
 };
@@ -79,6 +82,7 @@ struct vp8hip_ctx {
     std::vector<Slot> slots;
     uint8_t *fb_block; char *slot_block_dev;
     uint8_t *tile_block; size_t tile_frame;          // the tiled forms of all frame buffers (tile_frame bytes each) + the dummy tile
+    uint8_t *tile_alloc;                             // ... as allocated: VP8HIP_TILE_FRONT bytes in front of tile_block (the tile-reading predictor's loads left of a tile row)
     DevJob *d_conv_jobs, *h_conv_jobs; int conv_cap; hipEvent_t ev_conv;    // job table of a tiled -> raster pass
     size_t slot_bytes, o_mbx, o_blocks, o_mvs, cap_blocks;            // slot layout; cap_blocks = nmb * 24 (pooled: 0)
     // vp8hip_configure_pooled: the slots have no block streams of their own; the device's entropy decoder takes the blocks' room out

@@ -36,18 +36,24 @@ extern "C" __global__ void vp8_keyframe_kernel(const DevJob *jobs, int njobs, De
 extern "C" __global__ void vp8_interframe_kernel(const DevJob *jobs, int njobs, DevGeom g, int lgG, int P, int nstrands, uint8_t *dummy,
                                                unsigned int *sched, int nwaves);
 extern "C" __global__ void vp8_inter_pred_kernel(const DevJob *jobs, int njobs, DevGeom g, int upf);
+extern "C" __global__ void vp8_inter_pred_tiles_kernel(const DevJob *jobs, int njobs, DevGeom g, int upf);
 extern "C" __global__ void vp8_loopfilter_kernel(const DevJob *jobs, int njobs, DevGeom g);
 extern "C" __global__ void vp8_extend_kernel(const DevJob *jobs, int njobs, DevGeom g);
 extern "C" __global__ void vp8_detile_kf_kernel(const DevJob *jobs, int njobs, DevGeom g);
+extern "C" __global__ void vp8_retile_kernel(const DevJob *jobs, int njobs, DevGeom g);
 
 // The raster form of the frame buffers fbs[0..n-1], for those that only exist as tiles: the tiled -> raster pass and the borders
 // (vp8_yv12_extend_frame_borders, onyxd_if.c:607), on the context's stream.
-int vp8hip_need_raster_list(vp8hip_ctx *c, const int *fbs, int n)
+static int tile_pool(vp8hip_ctx *c);
+// to_tiles: the other direction -- the tiled form of frame buffers that only exist in raster form (vp8_retile_kernel), for a launch
+// that reads its references as tiles
+static int convert_list(vp8hip_ctx *c, const int *fbs, int n, bool to_tiles)
 {
+    const uint8_t lacks = to_tiles ? FB_RASTER : FB_TILES;        // the state of a frame that has only the other form
     int m = 0;
-    for (int i = 0; i < n; i++) m += c->fb_state[(size_t)fbs[i]] == FB_TILES;
+    for (int i = 0; i < n; i++) m += c->fb_state[(size_t)fbs[i]] == lacks;
     if (!m) return 0;
-    if (vp8hip_raster_pool(c)) return -1;
+    if (to_tiles ? tile_pool(c) : vp8hip_raster_pool(c)) return -1;
     if (m > c->conv_cap) {
         HIPCHK(c, hipStreamSynchronize(c->stream));
         if (c->d_conv_jobs) (void)hipFree(c->d_conv_jobs);
@@ -62,7 +68,7 @@ int vp8hip_need_raster_list(vp8hip_ctx *c, const int *fbs, int n)
     m = 0;
     for (int i = 0; i < n; i++) {
         const int f = fbs[i];
-        if (c->fb_state[(size_t)f] != FB_TILES) continue;
+        if (c->fb_state[(size_t)f] != lacks) continue;
         DevJob &d = c->h_conv_jobs[m++];
         memset(&d, 0, sizeof d);
         d.dst = c->fb[(size_t)f]; d.tile = c->fb_tiles[(size_t)f];
@@ -72,6 +78,11 @@ int vp8hip_need_raster_list(vp8hip_ctx *c, const int *fbs, int n)
     HIPCHK(c, hipEventRecord(c->ev_conv, c->stream));
     long units = (long)c->dg.mb_rows * m;
     if (units > 8L * c->num_cu) units = 8L * c->num_cu;
+    if (to_tiles) {
+        hipLaunchKernelGGL(vp8_retile_kernel, dim3((unsigned)units), dim3(256), 0, c->stream, (const DevJob *)c->d_conv_jobs, m, c->dg);
+        HIPCHK(c, hipGetLastError());
+        return 0;
+    }
     hipLaunchKernelGGL(vp8_detile_kf_kernel, dim3((unsigned)units), dim3(256), 0, c->stream, (const DevJob *)c->d_conv_jobs, m, c->dg);
     int bx = (c->geom.aligned_h + 64) / 4;
     if (bx < 1) bx = 1;
@@ -80,6 +91,7 @@ int vp8hip_need_raster_list(vp8hip_ctx *c, const int *fbs, int n)
     HIPCHK(c, hipGetLastError());
     return 0;
 }
+int vp8hip_need_raster_list(vp8hip_ctx *c, const int *fbs, int n) { return convert_list(c, fbs, n, false); }
 int vp8hip_need_raster(vp8hip_ctx *c, int first, int count)
 {
     bool any = false;
@@ -109,16 +121,18 @@ static Regime launch_regime(const vp8hip_ctx *c, int njobs, int stages, bool all
 
 // the tiled forms of all frame buffers, with the first large launch: tile_frame bytes each (one tile per macroblock and one more
 // per macroblock row, 32 bytes of unfiltered line per tile behind them: vp8_keyframe_simt.hip), + 8 KB: the dummy tile idle lanes
-// write, and room for the kernels' prefetches past the last tile
+// write, and room for the kernels' prefetches past the last tile; VP8HIP_TILE_FRONT bytes in front: a strip of
+// vp8_inter_pred_tiles_kernel that begins left of the frame loads from the tile before the row's first
 static int tile_pool(vp8hip_ctx *c)
 {
     if (c->tile_block) return 0;
     const int nfb = (int)c->fb.size();
-    if (hipMalloc((void **)&c->tile_block, c->tile_frame * (size_t)nfb + 8192) != hipSuccess) {
+    if (hipMalloc((void **)&c->tile_alloc, c->tile_frame * (size_t)nfb + 8192 + VP8HIP_TILE_FRONT) != hipSuccess) {
         (void)hipGetLastError();
-        c->tile_block = nullptr;
+        c->tile_alloc = nullptr;
         return fail(c, -1, "no device memory for the tiled form of %d frame buffers (%zu MB)", nfb, c->tile_frame * (size_t)nfb >> 20);
     }
+    c->tile_block = c->tile_alloc + VP8HIP_TILE_FRONT;
     c->fb_tiles.resize((size_t)nfb);
     for (int i = 0; i < nfb; i++) c->fb_tiles[(size_t)i] = c->tile_block + c->tile_frame * (size_t)i;
     return 0;
@@ -171,21 +185,38 @@ extern "C" int vp8hip_decode(vp8hip_ctx *c, const vp8hip_job *jobs, int njobs, i
         if (jobs[i].ir_slot < 0 || jobs[i].ir_slot >= nsl || jobs[i].dst_fb < 0 || jobs[i].dst_fb >= nfb)
             return fail(c, -2, "vp8hip_decode: job %d has slot %d / fb %d out of range", i, jobs[i].ir_slot, jobs[i].dst_fb);
     if (tiled && tile_pool(c)) return -1;
+    // Inter prediction reads its reference frames in the form they are in: a large launch whose references all have a raster form
+    // reads that (vp8_inter_pred_kernel: a row is one load); one whose references are all there as tiles -- streams decoded in
+    // lock step: what the launch before left -- reads the tiles (vp8_inter_pred_tiles_kernel) and no tiled -> raster pass runs;
+    // a launch with both kinds, or a small one, gets the raster form of the references that lack it first.
+    bool pred_tiles = false;
     {
-        // what this launch reads as raster: its reference frames (inter prediction reads the raster form, borders included), and
-        // -- a wave-per-row launch of the loop filter alone -- the frames it filters in place
+        // what this launch reads as raster: its reference frames (borders included), and -- a wave-per-row launch of the loop filter
+        // alone -- the frames it filters in place
         std::vector<int> need;
         bool pool = !tiled || K.eager_raster;               // (a large launch of key frames writes tiles only)
+        std::vector<int> lack_tiles;                         // references that only exist in raster form
+        bool may_tiles = inter_fused && K.pred_tiles && c->tile_block;
         for (int i = 0; i < njobs; i++) {
             if (c->slots[jobs[i].ir_slot].hdr_copy.frame_type != 0) {
-                pool = true;
                 for (int k = 1; k < 4; k++) {
                     const int f = jobs[i].ref_fb[k];
-                    if (f >= 0 && f < nfb && c->fb_state[(size_t)f] == FB_TILES) need.push_back(f);
+                    if (f < 0 || f >= nfb) continue;
+                    if (c->fb_state[(size_t)f] == FB_RASTER) lack_tiles.push_back(f);
+                    if (c->fb_state[(size_t)f] == FB_TILES) need.push_back(f);
                 }
             }
             if (!tiled && !(stages & VP8HIP_STAGE_RECON) && c->fb_state[(size_t)jobs[i].dst_fb] == FB_TILES) need.push_back(jobs[i].dst_fb);
         }
+        // tiles where a reference would have to be converted to raster first (or: always, VP8HIP_PRED_TILES=2); the references that
+        // have no tiled form -- a golden frame a small launch decoded long ago, an uploaded one -- get one (vp8_retile_kernel: once
+        // per such frame, they keep both forms)
+        pred_tiles = !all_key && may_tiles && (!need.empty() || K.pred_tiles == 2);
+        if (pred_tiles) {
+            need.clear();
+            if (!c->fb_block) lack_tiles.clear();           // (no raster form has ever been made: such a reference was never decoded at all)
+            if (!lack_tiles.empty() && convert_list(c, lack_tiles.data(), (int)lack_tiles.size(), true)) return -1;
+        } else if (!all_key) pool = true;
         if (pool && vp8hip_raster_pool(c)) return -1;
         if (!need.empty() && vp8hip_need_raster_list(c, need.data(), (int)need.size())) return -1;
     }
@@ -200,13 +231,14 @@ extern "C" int vp8hip_decode(vp8hip_ctx *c, const vp8hip_job *jobs, int njobs, i
         d.ref[0] = nullptr;
         d.tile = tiled ? c->fb_tiles[(size_t)j.dst_fb] : nullptr;
         for (int k = 1; k < 4; k++) {
-            d.ref[k] = nullptr;
+            d.ref[k] = nullptr; d.ref_tile[k - 1] = nullptr;
             if (s.hdr_copy.frame_type == 0) continue;          // key frames read no reference
             int f = j.ref_fb[k];
             if (f >= nfb) return fail(c, -2, "vp8hip_decode: job %d ref %d out of range", i, f);
             if (f < 0) return fail(c, -2, "vp8hip_decode: inter frame job %d lacks reference %d", i, k);
             if (f == j.dst_fb) return fail(c, -2, "vp8hip_decode: job %d decodes into its own reference", i);
-            d.ref[k] = c->fb[f];
+            d.ref[k] = c->fb.empty() || !c->fb_block ? nullptr : c->fb[f];
+            d.ref_tile[k - 1] = c->fb_tiles.empty() ? nullptr : c->fb_tiles[(size_t)f];
         }
         any_lf |= s.hdr_copy.filter_level != 0;
     }
@@ -312,6 +344,7 @@ extern "C" int vp8hip_decode(vp8hip_ctx *c, const vp8hip_job *jobs, int njobs, i
     }
     if (tiled) { c->stats.workgroups = simt_waves; c->stats.recon_waves = 1; c->stats.lf_waves = 1; }
     c->stats.detile_pass = tiled && K.eager_raster;
+    c->stats.pred_tiles = pred_tiles;
 
     if (stages & VP8HIP_STAGE_RECON) {
         if (tiled) {
@@ -326,8 +359,8 @@ extern "C" int vp8hip_decode(vp8hip_ctx *c, const vp8hip_job *jobs, int njobs, i
                 const int upf = (c->nmb + 63) / 64;
                 long pgrid = ((long)njobs * upf + 3) / 4;
                 if (pgrid > (long)c->num_cu * 8) pgrid = (long)c->num_cu * 8;
-                hipLaunchKernelGGL(vp8_inter_pred_kernel, dim3((unsigned)pgrid), dim3(256), 0, c->stream, (const DevJob *)c->d_jobs, njobs,
-                                   c->dg, upf);
+                hipLaunchKernelGGL(pred_tiles ? vp8_inter_pred_tiles_kernel : vp8_inter_pred_kernel, dim3((unsigned)pgrid), dim3(256), 0, c->stream,
+                                   (const DevJob *)c->d_jobs, njobs, c->dg, upf);
                 hipLaunchKernelGGL(vp8_interframe_kernel, dim3(2 * simt_waves), dim3(64), 0, c->stream, (const DevJob *)c->d_jobs, njobs,
                                    c->dg, lgG, simtP, simt_waves * spw, c->tile_block + c->tile_frame * (size_t)nfb + 4096,
                                    c->d_sched, simt_waves);
