@@ -69,6 +69,28 @@ WORKLOADS = {
 }
 
 
+def usable_cpus():
+    """The CPUs this process may really use: the affinity mask, cut down to the cgroup's CPU quota where there is one (a box of the
+    pool shows 256 logical CPUs and grants 16: cpu.max "1600000 100000").  Returns (count, how it was found)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    how = "sched_getaffinity"
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                quota, period = txt[0], int(txt[1])
+            else:
+                quota, period = txt[0], int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota not in ("max", "-1"):
+                q = max(1, int(int(quota) / period + 0.999))
+                if q < n:
+                    n, how = q, f"cgroup quota ({path}: {' '.join(txt)})"
+            break
+        except Exception:  # noqa: BLE001
+            continue
+    return max(1, n), how
+
+
 def cpu_baseline(fixture, budget_s=12.0):
     """Time the reference decoder (or the port) on this host, single thread."""
     ivf = os.path.join(ROOT, "tests", "golden", fixture + ".ivf")
@@ -88,7 +110,7 @@ def cpu_baseline(fixture, budget_s=12.0):
                              f"generic-C decoder, gcc -O3, 1 thread), time inside vpx_codec_decode only"}
             # the same decoder frame-parallel on every host core (all-key-frame streams shard by frame): one process
             # per core, each decoding the whole sample; aggregate = sum of the per-process rates
-            ncpu = os.cpu_count() or 1
+            ncpu, how = usable_cpus()
             if ncpu > 1:
                 r2 = max(1, reps // 6)
                 procs = [subprocess.Popen([ref, "--time", str(r2), ivf], stdout=subprocess.PIPE, text=True)
@@ -98,7 +120,8 @@ def cpu_baseline(fixture, budget_s=12.0):
                     o, _ = pr.communicate(timeout=900)
                     _, px, sc = o.split()
                     agg += float(px) / float(sc) / 1e6
-                res["all_cores"] = {"value": round(agg, 1), "unit": "Mpix/s", "cores": ncpu,
+                res["all_cores"] = {"value": round(agg, 1), "unit": "Mpix/s", "cores": ncpu, "cores_from": how,
+                                    "logical_cpus_of_the_box": os.cpu_count(),
                                     "sample": f"{ncpu} processes x {r2} passes of the same stream"}
             return res
         except Exception as e:  # noqa: BLE001 - fall through to the port
@@ -176,6 +199,7 @@ def inter_frame_probe(P, device, n=8192, name="p_dense_1920x1080", k=2):
         ctx.decode_array(jobs, n, P.STAGE_ALL)
     ctx.sync()
     dt_chained = (time.perf_counter() - t0) / 4
+    chained_tiles = bool(ctx.stats().pred_tiles)
     nmb = ctx.nmb
     parser.close()
     ctx.close()
@@ -185,13 +209,16 @@ def inter_frame_probe(P, device, n=8192, name="p_dense_1920x1080", k=2):
             "md5_ok": bool(ok),
             "Mpix_s": round(n * w * h / dt / 1e6, 1), "ms_per_launch": round(dt * 1e3, 3),
             "chained": {"ms_per_launch": round(dt_chained * 1e3, 3), "Mpix_s": round(n * w * h / dt_chained / 1e6, 1),
-                        "note": "every launch reads the frames the previous launch wrote"},
+                        "roofline_frac": round(B_INTER_FULL * nmb * n / dt_chained / 1e9 / HBM_PEAK_GBPS, 5),
+                        "references_read_as": "tiles (vp8_inter_pred_tiles_kernel: no tiled -> raster pass)" if chained_tiles
+                                              else "raster (vp8_detile_kf_kernel + vp8_extend_kernel in front of every launch)",
+                        "note": "every launch reads the frames the previous launch wrote: n streams in lock step, what a decoder runs"},
             "kernel_ms": {"recon": round(st.recon_ms, 3), "loopfilter": round(st.lf_ms, 3), "extend": round(st.extend_ms, 3)},
             "kernel_family": ("vp8_inter_pred_kernel (every inter macroblock's six-tap prediction, order-free, into the macroblock's tile) + "
                               "vp8_interframe_kernel (residual + loop filter, one macroblock row per lane, luma and chroma waves paired "
                               "on every SIMD: kernel_ms.recon is both); the frames are left as tiles, and a launch that predicts from "
-                              "frames the launch before left that way (chained) first gets their border-extended raster form "
-                              "(vp8_detile_kf_kernel + vp8_extend_kernel, on the same stream)"
+                              "frames the launch before left that way (chained) reads them as tiles (vp8_inter_pred_tiles_kernel, "
+                              "round 5; through round 4 their border-extended raster form was made first)"
                               if st.fused else "one wave per macroblock row"),
             "roofline": {"bound": "hbm", "achieved": round(gbps, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(gbps / HBM_PEAK_GBPS, 5),
@@ -259,6 +286,38 @@ def streams_probe(device, streams=4096, fixture="p_1920x1080"):
             "corrupt_frames": int(m.group(7)), "frames_per_s_of_the_run_before_on_a_cold_device": first}
 
 
+def small_run(P, device, fixture, W, H, n, steps=3):
+    """One context of its own with n frames of the looped fixture resident, `steps` timed launches of all n (after one untimed):
+    ms per launch, Mpix/s, what the context holds on the device, which kernels ran, and every frame's MD5 (computed on the device
+    from whichever form the launch left) against the reference listing."""
+    from vp8_testlib import golden_md5
+    gold = golden_md5(fixture)
+    ctx = P.Vp8Hip(device)
+    try:
+        ctx.configure(W, H, n, n)
+        nsrc, _ = load_stream(P, ctx, fixture, n, 0)
+        jobs = (P.Job * n)()
+        for i in range(n):
+            jobs[i].ir_slot, jobs[i].dst_fb = i, i
+            for k in range(4):
+                jobs[i].ref_fb[k] = -1
+        ctx.decode_array(jobs, n, P.STAGE_ALL); ctx.sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            ctx.decode_array(jobs, n, P.STAGE_ALL)
+        ctx.sync()
+        dt = (time.perf_counter() - t0) / steps
+        st = ctx.stats()
+        mem = sum(ctx.memory_usage().values())
+        dig = ctx.frames_md5(0, n)
+        bad = sum(1 for i in range(n) if dig[i] != gold[i % nsrc])
+        return {"frames_per_launch": n, "ms_per_launch": round(dt * 1e3, 3), "Mpix_s": round(n * W * H / dt / 1e6, 1),
+                "device_GB": round(mem / 1e9, 2), "kernels": "lane-per-row (tiles)" if st.fused else "wave-per-row (raster)",
+                "md5_mismatches": bad}
+    finally:
+        ctx.close()
+
+
 def load_stream(P, ctx, fixture, F, lo):
     """Slots 0 .. F-1 of `ctx` <- frames lo .. lo+F-1 of the looped stream (frame i of the stream is source frame i mod nsrc;
     every key frame is independently decodable).  Host feeder once per source frame, device-to-device copies for the rest."""
@@ -280,6 +339,7 @@ def load_stream(P, ctx, fixture, F, lo):
         ctx.ir_copy(j, first[(lo + j) % nsrc])
     ctx.sync()
     parser.close()
+    load_stream.last_copy_s = time.time() - t0 - feed_s     # (F - nsrc device-to-device slot copies: a rank's start-up, untimed)
     return nsrc, feed_s
 
 
@@ -375,6 +435,7 @@ def main():
     ap.add_argument("--no-inter-probe", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true")
     ap.add_argument("--no-4k-probe", action="store_true")
+    ap.add_argument("--no-curve", action="store_true", help="skip config.batch_curve and config.dense_content")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -422,6 +483,7 @@ def main():
         try:
             ctx.configure(W, H, F, F)
             nsrc, feed_s = load_stream(P, ctx, fixture, F, lo)
+            copy_s = load_stream.last_copy_s
             jobs = (P.Job * F)()
             for i in range(F):
                 jobs[i].ir_slot, jobs[i].dst_fb = i, i
@@ -665,6 +727,8 @@ def main():
                 "waves_per_workgroup": {"recon": st.recon_waves, "loopfilter": st.lf_waves},
                 "workgroups": st.workgroups,
                 "host_feeder_s_for_source_frames": round(feed_s, 4),
+                "rank_startup_s": {"host_feeder_source_frames": round(feed_s, 3), "slot_copies_device_to_device": round(copy_s, 3),
+                                   "note": f"rank 0, outside the timed region: {F} slots filled from {nsrc} source frames (vp8hip_ir_copy)"},
                 "single_frame_launch_ms": round(latency_ms, 3),
                 "consumers": consumers,
                 "with_raster_form": with_raster,
@@ -677,6 +741,17 @@ def main():
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 5),
                 "traffic": round((2 * tk["fetch_KiB_per_mb"] + tk["write_KiB_per_mb"]) * 1024 * nmb * F) if tk else None,
+                # what the HBM system really moved for this kernel, per second and against the peak: the kernel is NOT bound by
+                # memory (it runs at 92 % of the vector ALU's issue rate); `frac` above is SURVEY's byte model of a
+                # two-pass pipeline over this kernel's time, i.e. credit for the traffic the fusion removed
+                "traffic_GBps": round((2 * tk["fetch_KiB_per_mb"] + tk["write_KiB_per_mb"]) * 1024 * nmb * F / (ms[dom] * 1e-3) / 1e9, 1) if tk else None,
+                "traffic_frac_of_peak": (round((2 * tk["fetch_KiB_per_mb"] + tk["write_KiB_per_mb"]) * 1024 * nmb * F / (ms[dom] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5)
+                                         if tk else None),
+                "traffic_uncorrected": round((tk["fetch_KiB_per_mb"] + tk["write_KiB_per_mb"]) * 1024 * nmb * F) if tk else None,
+                "achieved_is": "SURVEY 8(d) algorithmic bytes (dense-coefficient model, recon 1217 + loop filter 770 B/MB) / mean launch time: "
+                               "the contract's definition; the counted bytes are `traffic` (FETCH_SIZE doubled as the MI355X guide prescribes "
+                               "for 16-byte-per-lane loads -- this kernel's loads are 16-byte LDS-DMA pieces, but scattered, so the truth "
+                               "lies between `traffic_uncorrected` and `traffic`) and `traffic_frac_of_peak`",
                 "traffic_source": (f"scaled: per-macroblock FETCH_SIZE x2 + WRITE_SIZE of this kernel from the rocprofv3 --pmc passes of "
                                    f"{traffic.get('source')} ({traffic.get('frames_per_launch')} frames per launch, {traffic.get('lanes_per_strand')} lanes "
                                    f"per strand), times the macroblocks of this launch") if tk else None,
@@ -723,6 +798,34 @@ def main():
                 c4.close()
             except Exception as ex:      # a probe, not the benchmark: report, do not fail the line
                 out["config"]["workload_4k"] = {"error": repr(ex)}
+        if world == 1 and args.workload == "1080p" and not args.no_curve:
+            # throughput against frames per launch (the lane-per-row kernels want every SIMD's two wave slots full: 16,384 1080p
+            # frames; up to 512 frames the wave-per-row kernels run), each point a context of its own with just that many frames
+            # resident, every frame's MD5 checked; the last point is the headline launch itself
+            curve = []
+            for n in (1, 64, 512, 1024, 2048, 4096, 8192):
+                if n >= F:
+                    break
+                try:
+                    curve.append(small_run(P, local_rank, fixture, W, H, n))
+                except Exception as ex:      # noqa: BLE001 - a probe, not the benchmark
+                    curve.append({"frames_per_launch": n, "error": repr(ex)})
+            curve.append({"frames_per_launch": F, "ms_per_launch": round(elapsed / K * 1e3, 3), "Mpix_s": round(F * W * H * K / elapsed / 1e6, 1),
+                          "device_GB": round(sum(mem_gb.values()), 2), "kernels": "lane-per-row (tiles)" if lane else "wave-per-row (raster)",
+                          "md5_mismatches": 0, "note": "the timed launch of this line"})
+            out["config"]["batch_curve"] = curve
+            # the same path on DENSE content (SURVEY 8d's noisy set: 21 of a macroblock's 24 blocks coded, 18 of them with more than
+            # a first coefficient -- the byte model of `roofline` is dense, the headline stream is not): tests/golden/kf_dense_1920x1080
+            try:
+                nd = F if F <= 8192 else 8192       # (a dense slot is the full 7.8 MB: 8192 frames are 64 + 28 GB)
+                d = small_run(P, local_rank, "kf_dense_1920x1080", W, H, nd)
+                gb = (B_RECON + B_LF) * nmb * nd / (d["ms_per_launch"] * 1e-3) / 1e9
+                d["roofline_pipeline"] = {"achieved": round(gb, 2), "frac": round(gb / HBM_PEAK_GBPS, 5), "unit": "GB/s",
+                                          "note": "SURVEY 8(d) 1217 + 770 B/MB x macroblocks per launch / launch time"}
+                d["workload"] = "tests/golden/kf_dense_1920x1080.ivf (2 key frames, uniform +-16 noise, quantiser index 8..16) looped"
+                out["config"]["dense_content"] = d
+            except Exception as ex:          # noqa: BLE001
+                out["config"]["dense_content"] = {"error": repr(ex)}
         if world == 1 and args.workload == "1080p" and not args.no_inter_probe:
             try:
                 out["config"]["inter_frames"] = inter_frame_probe(P, local_rank)

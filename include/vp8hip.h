@@ -89,7 +89,10 @@ int  vp8hip_configure(vp8hip_ctx *ctx, int width, int height, int num_fb, int nu
  * it goes, a chunk (four macroblock rows' worst case) at a time: a row's blocks stay together, the records' sparse_first count
  * from the pool's start, and vp8hip_decode reads the slots as ever.  vp8hip_pool_reset (on the context's stream: after the launches
  * queued so far) empties the pool -- when the frames decoded out of it have been through vp8hip_decode; the caller says when.  A
- * frame that finds the pool empty gets bit 1 of its status word (vp8hip_entropy_status) and is not to be decoded.  The host-side
+ * frame that finds the pool empty gets bit 1 of its status word (vp8hip_entropy_status) and is not to be decoded for its pixels: the
+ * blocks it could not place went into the spare chunk behind the pool's last (all such frames share it), so its records'
+ * sparse_first still point INSIDE the pool's allocation -- a vp8hip_decode over such a slot, queued before the status has come back,
+ * reads and writes nothing out of bounds; what it leaves in the frame buffer is garbage (tests/test_gpu_entropy.py).  The host-side
  * producers (vp8hip_ir_map*, vp8hip_ir_upload*) are refused on such a context; vp8hip_ir_copy copies the records, which then share
  * the blocks; frames with several token partitions are decoded a frame per lane.  vp8hip_pool_usage (synchronises): bytes taken
  * since the last reset (more than *pool_bytes: that much was asked for) and the pool's size. */

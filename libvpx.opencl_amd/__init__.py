@@ -579,9 +579,21 @@ class Vp8Hip:
         self.L.vp8hip_i420_bytes.argtypes = [ctypes.c_void_p]
         self.L.vp8hip_frames_fetch_i420_async.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
         self.L.vp8hip_download_wait.argtypes = [ctypes.c_void_p]
-        out = np.zeros((count, self.L.vp8hip_i420_bytes(self.h)), np.uint8)
-        self._chk(self.L.vp8hip_frames_fetch_i420_async(self.h, first_fb, count, out.ctypes.data, None), "vp8hip_frames_fetch_i420_async")
-        self._chk(self.L.vp8hip_download_wait(self.h), "vp8hip_download_wait")
+        nb = self.L.vp8hip_i420_bytes(self.h)
+        # (the destination of a batch fetch is page-locked memory, include/vp8hip.h: into pageable memory the asynchronous copies of
+        # the fetch's streams would be staged by the runtime one after the other)
+        self.L.vp8hip_host_alloc.restype = ctypes.c_void_p
+        self.L.vp8hip_host_alloc.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+        self.L.vp8hip_host_free.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        host = self.L.vp8hip_host_alloc(self.h, nb * count)
+        if not host:
+            raise RuntimeError("vp8hip_host_alloc: " + self.L.vp8hip_last_error(self.h).decode())
+        try:
+            self._chk(self.L.vp8hip_frames_fetch_i420_async(self.h, first_fb, count, host, None), "vp8hip_frames_fetch_i420_async")
+            self._chk(self.L.vp8hip_download_wait(self.h), "vp8hip_download_wait")
+            out = np.ctypeslib.as_array(ctypes.cast(host, ctypes.POINTER(ctypes.c_uint8)), shape=(count, nb)).copy()
+        finally:
+            self.L.vp8hip_host_free(self.h, host)
         return out
 
     def frames_to_raster(self, first_fb, count):

@@ -571,7 +571,9 @@ int main(int argc, char **argv)
                (vp8hip_configure_pooled) -- a frame in flight costs what it needs (records 192 bytes a macroblock + its blocks), not
                the worst case (960), and frames in flight are what the entropy decoder's rate is made of.  The pool: what the
                launch that needs most is expected to need -- a frame's blocks are 6 to 13 times its compressed bytes in the
-               fixtures: 14 times, capped by the worst case, + a chunk and a half per frame for the chunks' ends. */
+               fixtures: 14 times, capped by the worst case; / 0.75, because the kernel leaves a chunk as soon as what is left of it
+               would not hold a macroblock row's WORST case (a quarter of a chunk; real rows take a third of that), + two chunks per
+               frame for the chunks a frame begins and ends in. */
             const size_t nmb = (size_t)((g_width + 15) / 16) * (size_t)((g_height + 15) / 16);
             const size_t worst = nmb * 24 * 32, chunk = (size_t)4 * ((g_width + 15) / 16) * 24 * 32;
             size_t pool = 0;
@@ -579,7 +581,7 @@ int main(int argc, char **argv)
                 size_t need = 0;
                 for (long k = k0; k < k0 + unit && k < total; k++) {
                     const size_t est = 14 * FRAME_AT(g_order[k])->size;
-                    need += (est < worst ? est : worst) + chunk + chunk / 2;
+                    need += (est < worst ? est : worst) * 4 / 3 + 2 * chunk;
                 }
                 if (need > pool) pool = need;
             }

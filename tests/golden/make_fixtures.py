@@ -91,6 +91,11 @@ FIXTURES = {
     # (2) headline stream: 1920x1080, 10 key frames, profile 0, loop filter on
     "kf_1920x1080": (1920, 1080, 10, 7, 6, ALLKEY + ["--good", "--cpu-used=5", "--end-usage=cq", "--cq-level=20",
                                                       "--target-bitrate=20000"]),
+    # (2b) SURVEY 8(d)'s "noisy" set: uniform +-16 noise at a quantiser where nearly every block keeps coefficients behind its first
+    # (the byte model of the roofline is a DENSE-coefficient model; the headline stream codes 13.7 of a macroblock's 25 blocks):
+    # two key frames, loop filter on -- bench.py's config.dense_content
+    "kf_dense_1920x1080": (1920, 1080, 2, 13, 16, ALLKEY + ["--good", "--cpu-used=5", "--end-usage=cq", "--cq-level=10",
+                                                            "--min-q=8", "--max-q=16", "--target-bitrate=400000"]),
     # (3) loop filter OFF (q=0 -> filter_level 0) and very dense coefficients
     "kf_q0_176x144": (176, 144, 4, 3, 12, ALLKEY + ["--good", "--cpu-used=2", "--min-q=0", "--max-q=0",
                                                      "--target-bitrate=40000"]),

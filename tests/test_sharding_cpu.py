@@ -1,5 +1,5 @@
-"""CPU, world_size 2, gloo: the multi-GPU path's sharding + digest gather reproduce the 1-rank
-decode_to_md5 listing.  The decode itself is done by the oracle here (there is no GPU); on the GPU
+"""CPU, world_size 2 and 8, gloo: the multi-GPU path's sharding + digest gather reproduce the 1-rank
+decode_to_md5 listing, also where the frames do not divide by the ranks and where ranks are left without a frame.  The decode itself is done by the oracle here (there is no GPU); on the GPU
 box the same helpers run over RCCL in bench.py / tests marked gpu."""
 import os
 import socket
@@ -53,14 +53,16 @@ def test_shard_ranges(pkg):
             assert max(b - a for a, b in got) - min(b - a for a, b in got) <= 1
 
 
-def test_two_rank_gloo_listing_equals_single_rank(pkg):
-    name = "kf_640x360"
+@pytest.mark.parametrize("world,name", [(2, "kf_640x360"),          # ten frames, five a rank
+                                        (8, "kf_640x360"),          # ten frames over the eight ranks of a node: two ranks take two, six take one
+                                        (8, "kf_odd_67x45")])       # three frames over eight ranks: five ranks have nothing to decode
+def test_gloo_listing_equals_single_rank(pkg, world, name):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, name, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, name, q)) for r in range(world)]
     for p in procs:
         p.start()
     full = q.get(timeout=180)
