@@ -11,6 +11,13 @@
 // walk over planes, rows and blocks is wave-uniform (scalar); only the frame's base address is per lane.  The blocks are
 // requested AHEAD blocks before they are hashed (each lane reads its own 64 bytes: nothing coalesces, only latency matters;
 // round 5: by loads of ONE shape outside any branch -- the round-4 kernel's ring drained at every block, see md5_run).
+// What a batch costs (1080p, tiles): up to 4096 frames 37-38 ms -- the chain: 48.6 k blocks x 320 dependent-ish instructions of a lone
+// wave --, 8192 frames 43.6, 12,288 59, 16,384 80.6 ms (round 4: 67 ms for 8192, 86 for 16,384).  The climb is the memory system, not the
+// chain (loads compiled out: 36.8 ms for 16,384): a row piece is 16 bytes of a 128-byte line that holds eight rows of a tile, the line
+// comes back for each of them, and between two rows of a frame all the other frames' lines go by -- 16,384 frames x 121 tiles x 128 B =
+// 254 MB of lines in use, the size of the Infinity Cache.  A variant in which the WAVE fetched (one global_load_lds_dwordx4 for the
+// next chunk of three frames' row, lanes hashing out of LDS regions) was built, bit-exact, and no faster: the same lines, the same
+// wall, and 40 % more instructions beside the chain (50 ms for any batch up to 8192 frames; 82 for 16,384) -- not kept.
 // Where rows are whole blocks -- display width a multiple of 128 -- there are two readers: the raster form of a frame buffer
 // (vp8_md5_kernel), and the TILED form a large launch leaves (vp8_md5_tiles_kernel: macroblock-window tiles,
 // vp8_keyframe_simt.hip) -- the hash is the consumer that proves a frame, and it takes the frame as the decoder left it, without
