@@ -29,6 +29,7 @@
 // overwrites what it has not read yet.  Integer only; no MFMA by design.
 #include "vp8_block_prims.hip.h"
 #include <type_traits>
+#include <utility>
 #ifndef IP_AHEAD
 #define IP_AHEAD 6
 #endif
@@ -38,6 +39,9 @@
 #ifndef IP_TILE_ALIGNED
 #define IP_TILE_ALIGNED 1 // the tile reader's loads start at a row piece (16 / 8 bytes aligned) and the dwords are picked by selects; 0: they start at
                           // the first dword needed (4-byte aligned) and fewer selects put the pieces together
+#endif
+#ifndef IP_TILE_PAIRS
+#define IP_TILE_PAIRS 1   // the tile reader's chroma strips fetch two rows a load (TileSrc::PAIRED)
 #endif
 #ifndef IP_WAVES_TILES
 #define IP_WAVES_TILES 3  // (the tile reader's rows in flight are two loads each, and a strip carries its two column arrangements)
@@ -121,6 +125,11 @@ __device__ __forceinline__ u32 v_pass(const Row4 &h0, const Row4 &h1, const Row4
 //
 // RASTER: the reference's own frame buffer (yv12config.c:55-112) with its borders extended (extend.c, onyxd_if.c:607): a row is
 // one load.  What vp8_build_inter_predictors_mb reads (xd->pre, reconinter.c:393-441).
+template <int N, int I = 0, class F>
+__device__ __forceinline__ void static_for(F &&f)          // f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>)
+{
+    if constexpr (I < N) { f(std::integral_constant<int, I>()); static_for<N, I + 1>(f); }
+}
 template <int NDW> struct VecOf;
 template <> struct VecOf<4> { typedef u32x4 T; typedef u32x4_u TU; };
 template <> struct VecOf<3> { typedef u32x3 T; typedef u32x3 TU; };
@@ -128,7 +137,7 @@ template <int NDW>
 struct RasterSrc {
     typedef typename VecOf<NDW>::T Vec;
     typedef typename VecOf<NDW>::TU Raw;
-    static constexpr bool PIN = false;
+    static constexpr bool PIN = false, PAIRED = false;
     g_cu8p rp; int stride; u32 sh;
     // src = the pixel two left of and two above the strip's first one in the reference plane
     __device__ __forceinline__ RasterSrc(g_cu8p src, int stride_) : stride(stride_) { sh = (u32)(unsigned long)src & 3u; rp = src - sh; }
@@ -166,6 +175,12 @@ struct TileSrc {
     u32 rowbytes;           // bytes per tile row
     u32 colW, colB; int jW, jB;     // window rows / bottom rows: byte offset of the first load from rowp, the first dword wanted within the piece
     u32 sh;
+    // Chroma strips eight wide fetch their rows in PAIRS where no lane of the wave has a row above or below the plane (y_edge): rows
+    // 2 k, 2 k + 1 of a tile are 16 adjacent bytes, so one 16-byte load a piece serves two rows -- 21 loads a strip instead of 39, and
+    // the loads (the lines they touch) are what bounds this kernel
+    static constexpr bool PAIRED = CHROMA && NDW == 4 && IP_TILE_PAIRS;
+    struct PairRaw { u32 e[11]; int jsel; };
+    bool y_edge, odd;       // a lane of the wave clamps a row; this lane's first row is the second of its pair
     bool any_edge, edge;    // a lane of the wave / this lane reaches past the left or right edge
     u32 em[NDW], eselA, eselB;      // bytes to replace (per dword); v_perm selectors that splat the edge pixel out of dwords (0, 1) / (2, 3)
     // tiles: the frame's tiles + the plane's offset in a tile (0, 256 U, 288 V); W, H: the plane's size; (x0, y0): the strip's first pixel
@@ -176,6 +191,8 @@ struct TileSrc {
         const int ybase = yc & ~RMASK;
         yy0 = y0 - ybase; tlo = -ybase; thi = H - 1 - ybase;     // row i is row clamp(yy0 + i, tlo, thi) counted from the tile row's first
         rowp = tiles + (long)(yc >> LGR) * rowbytes - 2 * VP8_TILE_BYTES;
+        y_edge = __builtin_amdgcn_ballot_w64(y0 < 0 || y0 + (NDW == 4 ? (CHROMA ? 13 : 21) : 9) > H) != 0;
+        odd = (yy0 & 1) != 0;
         x0 = max(-64, min(x0, W + 64));
         const int xl = max(min(x0, W - 1), 1 - NPX);            // what is loaded: NPX bytes from xl on, at least one of them inside
         sh = (u32)xl & 3u;
@@ -246,6 +263,46 @@ struct TileSrc {
         }
         return r;
     }
+    // rows 2 k - odd, 2 k + 1 - odd of the strip (PAIRED; no lane clamps a row): the pair's three pieces, both rows of each
+    __device__ __forceinline__ PairRaw issue_pair(int k) const
+    {
+        const int t = yy0 - (odd ? 1 : 0) + 2 * k;
+        const u32 yy = (u32)t & RMASK;
+        const bool bot = yy >= BOT0;
+        const u32 off = __umul24((u32)t >> LGR, rowbytes) + (bot ? colB : colW) + (yy << LGR);
+        g_cu8p p = rowp + off;
+        PairRaw r;
+        r.jsel = bot ? jB : jW;
+        const u32x4 a = *(g_cu32x4p)p, b = *(g_cu32x4p)(p + VP8_TILE_BYTES);
+        const u32x3 c = *(GLOBAL_AS const u32x3 *)(p + 2 * VP8_TILE_BYTES);
+#pragma unroll
+        for (int j = 0; j < 4; j++) { r.e[j] = a[j]; r.e[4 + j] = b[j]; }
+        r.e[8] = c.x; r.e[9] = c.y; r.e[10] = c.z;
+        return r;
+    }
+    // row i of the strip out of the pairs that can hold it: A = pair (i + 1) / 2 when the lane's first row is the second of its
+    // pair, B = pair i / 2 when it is the first -- for an even i the same pair, other half
+    __device__ __forceinline__ Vec finish_pair(const PairRaw &A, const PairRaw &B, int i) const
+    {
+        // (lo half: the pair's first row, dwords 0, 1 of every piece; hi half: dwords 2, 3)
+        const int ha = (i + 1) & 1, hb = i & 1;           // which half of A (odd lanes) / of B (even lanes) row i is
+        u32 sA[5] = { A.e[2 * ha], A.e[2 * ha + 1], A.e[4 + 2 * ha], A.e[5 + 2 * ha], A.e[8 + 2 * ha] };
+        u32 sB[5] = { B.e[2 * hb], B.e[2 * hb + 1], B.e[4 + 2 * hb], B.e[5 + 2 * hb], B.e[8 + 2 * hb] };
+        const u32 mo = odd ? 0xffffffffu : 0u;
+        u32 sv[5];
+#pragma unroll
+        for (int k = 0; k < 5; k++) sv[k] = (sA[k] & mo) | (sB[k] & ~mo);
+        const u32 m1 = (u32)-(int)(odd ? A.jsel : B.jsel);
+        Vec d;
+#pragma unroll
+        for (int k = 0; k < NDW; k++) d[k] = (sv[k + 1] & m1) | (sv[k] & ~m1);
+        const u32 ev = perm(d[1], d[0], eselA) | perm(d[3], d[2], eselB);
+#pragma unroll
+        for (int k = 0; k < NDW; k++) d[k] = (d[k] & ~em[k]) | (ev & em[k]);
+        return d;
+    }
+    // (the middle dword of a pair's third piece is never read: keeps it from looking dead while the load is in flight, see issue())
+    __device__ __forceinline__ void retire_pair(const PairRaw &r) const { asm volatile("" :: "v"(r.e[9])); }
     __device__ __forceinline__ Vec finish(const Raw &r, int) const
     {
         Vec d;
@@ -334,24 +391,19 @@ __device__ __forceinline__ void strip8(const SRC &src, const Taps &tx, const Tap
     // chroma: dst = the plane's rows 0..3 (rows 4..7 64 bytes on), a lane has whole rows: two of them are one store.
     u32x2 prev = { 0, 0 };
     constexpr int NIN = NOUT + 5, AHEAD = IP_AHEAD < NIN ? IP_AHEAD : NIN;
-    typename SRC::Raw q[AHEAD];
-#pragma unroll
-    for (int i = 0; i < AHEAD; i++) q[i] = src.issue(i);
     Row8 H[6];
-#pragma unroll
-    for (int i = 0; i < NIN; i++) {
-        const u32x4 d = src.finish(q[i % AHEAD], i);
-        if (i + AHEAD < NIN) q[i % AHEAD] = src.issue(i + AHEAD);
-        if constexpr (SRC::PIN) __builtin_amdgcn_sched_barrier(0);
+    // source row i, its pixels in d: the horizontal pass, and from the sixth row on an output row
+    auto row = [&](auto ic, const u32x4 d) {
+        constexpr int i = decltype(ic)::value;
         H[i % 6] = h_pass8(d, src.sh, tx);
-        if (i >= 5) {
-            const int y = i - 5;
+        if constexpr (i >= 5) {
+            constexpr int y = i - 5;
             const Row8 &h0 = H[(i + 1) % 6], &h1 = H[(i + 2) % 6], &h2 = H[(i + 3) % 6], &h3 = H[(i + 4) % 6], &h4 = H[(i + 5) % 6], &h5 = H[i % 6];
             u32x2 o;
             o.x = v_pass(h0.l, h1.l, h2.l, h3.l, h4.l, h5.l, ty);
             o.y = v_pass(h0.r, h1.r, h2.r, h3.r, h4.r, h5.r, ty);
-            if (!(y & 1)) prev = o;
-            else if (NOUT == 16) {
+            if constexpr (!(y & 1)) prev = o;
+            else if constexpr (NOUT == 16) {
                 const u32x2 give = s ? prev : o;
                 const u32 tx_ = dpp_xor1(give.x), ty_ = dpp_xor1(give.y);
                 const u32x4 v = s ? (u32x4){ tx_, ty_, o.x, o.y } : (u32x4){ prev.x, prev.y, tx_, ty_ };
@@ -361,7 +413,44 @@ __device__ __forceinline__ void strip8(const SRC &src, const Taps &tx, const Tap
                 *(GLOBAL_AS u32x4 *)qd = (u32x4){ prev.x, prev.y, o.x, o.y };
             }
         }
+    };
+    auto rows_one_by_one = [&]() {
+        typename SRC::Raw q[AHEAD];
+#pragma unroll
+        for (int i = 0; i < AHEAD; i++) q[i] = src.issue(i);
+        static_for<NIN>([&](auto ic) {
+            constexpr int I = decltype(ic)::value;
+            const u32x4 d = src.finish(q[I % AHEAD], I);
+            if constexpr (I + AHEAD < NIN) q[I % AHEAD] = src.issue(I + AHEAD);
+            if constexpr (SRC::PIN) __builtin_amdgcn_sched_barrier(0);
+            row(ic, d);
+        });
+    };
+    if constexpr (SRC::PAIRED) {
+        if (!src.y_edge) {
+            // rows in pairs (TileSrc::PAIRED): pair k holds rows 2 k, 2 k + 1 for a lane whose first row is the first of its pair,
+            // rows 2 k - 1, 2 k for the others: row i wants pair i / 2 resp. (i + 1) / 2; four pairs in flight
+            constexpr int NP = (NIN + 1) / 2 + 1, PA = 4;
+            typename SRC::PairRaw q[PA];
+#pragma unroll
+            for (int k = 0; k < PA; k++) q[k] = src.issue_pair(k);
+            static_for<NIN>([&](auto ic) {
+                constexpr int I = decltype(ic)::value;
+                const u32x4 d = src.finish_pair(q[((I + 1) / 2) % PA], q[(I / 2) % PA], I);
+                // (behind an odd row pair (I - 1) / 2 is done with: its slot takes the pair four on)
+                if constexpr ((I & 1) && (I - 1) / 2 + PA < NP) {
+                    src.retire_pair(q[((I - 1) / 2) % PA]);
+                    q[((I - 1) / 2) % PA] = src.issue_pair((I - 1) / 2 + PA);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                row(ic, d);
+            });
+#pragma unroll
+            for (int k = 0; k < PA; k++) src.retire_pair(q[k]);
+            return;
+        }
     }
+    rows_one_by_one();
 }
 
 // clamp_mv_to_umv_border (reconinter.c:348-368)
