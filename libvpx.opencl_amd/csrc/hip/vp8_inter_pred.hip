@@ -242,6 +242,9 @@ struct TileSrc {
 #pragma unroll
                 for (int k = 0; k < 4; k++) r.e[k] = a[k];
                 if constexpr (NDW == 4) {
+                    // (requested also where the strip begins in its piece's first dword and has all thirteen pixels in it: skipping
+                    // it there -- a quarter of the lanes -- puts a branch with a load into the row loop, the waits behind it drain every
+                    // load in flight again, and the launch is 2 % slower)
                     const u32x3 b = *(GLOBAL_AS const u32x3 *)(p + VP8_TILE_BYTES);
                     r.e[4] = b.x; r.e[5] = b.y; r.e[6] = b.z; r.e[7] = 0;
                 } else {
