@@ -32,6 +32,7 @@ static void read_knobs(Knobs &k)
     const char *e = getenv("VP8HIP_RECON");
     k.recon_force = !e ? 0 : !strcmp(e, "simt") ? 1 : !strcmp(e, "wave") ? 2 : 0;
     k.pred_tiles = env_int("VP8HIP_PRED_TILES", 1);
+    k.md5_pack_from = env_int("VP8HIP_MD5_PACK_FROM", 12288);
     k.lgG = env_int("VP8HIP_SIMT_LGG", 0);
     k.simt_waves = env_int("VP8HIP_SIMT_WAVES", 0);
     k.wg_per_cu = env_int("VP8HIP_WG_PER_CU", 1);
@@ -677,10 +678,9 @@ static int fetch_impl(vp8hip_ctx *c, int first_fb, int count, uint8_t *dst, uint
         HIPCHK(c, hipGetLastError());
         const int pieces = count >= 64 ? c->knobs.d2h_streams : 1;
         const int per = (count + pieces - 1) / pieces;
-        if (pieces > 1) {
-            if (!c->ev_pack) HIPCHK(c, hipEventCreateWithFlags(&c->ev_pack, hipEventDisableTiming));
-            HIPCHK(c, hipEventRecord(c->ev_pack, c->stream_d2h));
-        }
+        // (the packed copy is there: the copies' other streams, and the hash, wait for this)
+        if (!c->ev_pack) HIPCHK(c, hipEventCreateWithFlags(&c->ev_pack, hipEventDisableTiming));
+        HIPCHK(c, hipEventRecord(c->ev_pack, c->stream_d2h));
         for (int k = 1; k < pieces; k++) {
             if (!c->stream_d2h_more[k - 1]) {
                 HIPCHK(c, hipStreamCreateWithFlags(&c->stream_d2h_more[k - 1], hipStreamNonBlocking));
@@ -742,7 +742,39 @@ static int fetch_impl(vp8hip_ctx *c, int first_fb, int count, uint8_t *dst, uint
             ms = c->stream_d2h_more[2];
             HIPCHK(c, hipStreamWaitEvent(ms, c->ev_d2h_from, 0));
         }
-        if (tiled)
+        // Batches beyond what the Infinity Cache holds of tiles (vp8_md5.hip: a 16-byte row piece costs its 128-byte line, eight times
+        // over -- 254 MB of lines in use at 16,384 1080p frames) are hashed from a PACKED copy: vp8_pack_i420_tiles_kernel reads every
+        // line once, and the hash then streams its frame front to back (the raster reader over a geometry without borders).  Where the
+        // frames were packed for the download anyway the copy is there; else it is made if the device has the room (3.1 MB a frame).
+        bool from_packed = tiled && whole_blocks && dst && packed;
+        if (tiled && whole_blocks && !dst && count >= c->knobs.md5_pack_from) {
+            const size_t fbytes = vp8hip_i420_bytes(c);
+            if (fbytes * (size_t)count > c->i420_cap) {
+                HIPCHK(c, hipStreamSynchronize(c->stream_d2h));
+                if (c->d_i420) (void)hipFree(c->d_i420);
+                c->d_i420 = nullptr; c->i420_cap = 0;
+                if (hipMalloc((void **)&c->d_i420, fbytes * (size_t)count + 256) == hipSuccess) c->i420_cap = fbytes * (size_t)count;
+                else { (void)hipGetLastError(); c->d_i420 = nullptr; }
+            }
+            if (c->d_i420 && fbytes * (size_t)count <= c->i420_cap) {
+                long units = (long)count * c->dg.mb_rows;
+                if (units > 16L * c->num_cu) units = 16L * c->num_cu;
+                hipLaunchKernelGGL(vp8_pack_i420_tiles_kernel, dim3((unsigned)units), dim3(256), 0, ms, (const uint8_t *)c->fb_tiles[(size_t)first_fb],
+                                   c->tile_frame, c->d_i420, fbytes, count, c->dg, c->width, c->height);
+                HIPCHK(c, hipGetLastError());
+                from_packed = true;
+            }
+        }
+        if (from_packed) {
+            // (the hash kernel of a packed batch download runs on a stream of its own: behind the pack pass)
+            if (dst) HIPCHK(c, hipStreamWaitEvent(ms, c->ev_pack, 0));
+            DevGeom pg = c->dg;
+            const int cw = c->width / 2, ch = (c->height + 1) / 2;
+            pg.y_off = 0; pg.y_stride = c->width; pg.uv_stride = cw;
+            pg.u_off = c->width * c->height; pg.v_off = pg.u_off + cw * ch;
+            hipLaunchKernelGGL(vp8_md5_kernel, dim3((unsigned)((count + 63) / 64)), dim3(64), 0, ms, (const uint8_t *)c->d_i420, vp8hip_i420_bytes(c),
+                               (const int *)nullptr, 0, count, pg, c->width, c->height, c->d_md5);
+        } else if (tiled)
             hipLaunchKernelGGL(vp8_md5_tiles_kernel, dim3((unsigned)((count + 63) / 64)), dim3(64), 0, ms,
                                (const uint8_t *)c->tile_block, c->tile_frame, (const int *)nullptr, first_fb, count, c->dg, c->width, c->height, c->d_md5);
         else

@@ -50,6 +50,7 @@ struct Slot {
 #define VP8HIP_TILE_FRONT 4096
 struct Knobs {
     int recon_force;       // 0 automatic, 1 lane-per-row, 2 wave-per-row
+    int md5_pack_from;     // VP8HIP_MD5_PACK_FROM: batches of this many tiled frames and more are hashed from a packed copy (vp8hip.hip: fetch_impl)
     int pred_tiles;        // VP8HIP_PRED_TILES: 1 (default) a large launch whose references are all there as tiles, and not all as raster frames,
                            // predicts from the tiles; 2: whenever all are there as tiles; 0: never (the raster form is made first)
     int inter_split, eager_raster, direct_download, download_blocks, d2h_prio, d2h_streams;
