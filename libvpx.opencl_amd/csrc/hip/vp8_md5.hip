@@ -15,7 +15,8 @@
 // wave --, 8192 frames 43.6, 12,288 59, 16,384 80.6 ms (round 4: 67 ms for 8192, 86 for 16,384).  The climb is the memory system, not the
 // chain (loads compiled out: 36.8 ms for 16,384): a row piece is 16 bytes of a 128-byte line that holds eight rows of a tile, the line
 // comes back for each of them, and between two rows of a frame all the other frames' lines go by -- 16,384 frames x 121 tiles x 128 B =
-// 254 MB of lines in use, the size of the Infinity Cache.  A variant in which the WAVE fetched (one global_load_lds_dwordx4 for the
+// 254 MB of lines in use, the size of the Infinity Cache; which is why fetch_impl (vp8hip.hip) hashes batches of 12,288 tiled frames and
+// more from a packed I420 copy with vp8_md5_kernel (pack 25 ms + hash 40 ms = 65.6 ms for 16,384 frames).  A variant in which the WAVE fetched (one global_load_lds_dwordx4 for the
 // next chunk of three frames' row, lanes hashing out of LDS regions) was built, bit-exact, and no faster: the same lines, the same
 // wall, and 40 % more instructions beside the chain (50 ms for any batch up to 8192 frames; 82 for 16,384) -- not kept.
 // Where rows are whole blocks -- display width a multiple of 128 -- there are two readers: the raster form of a frame buffer
