@@ -142,7 +142,7 @@ __device__ __forceinline__ void frame_levels_inter(const vp8ir_frame_hdr &h, u32
 template <bool LUMA, bool INTER>
 __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njobs, DevGeom g, int lgG, int P, int nstrands, uint8_t *dummy,
                                         const int wave, u32 *s_stage, unsigned short *s_queue, u32 *s_tab,
-                                        u32 *s_y2dc, u32 *s_desc, u32 *s_sf)
+                                        u32 *s_y2dc, u32 *s_desc, u32 *s_sf, const u32 *s_psel)
 {
     const int lane = threadIdx.x;
     const int G = 1 << lgG;
@@ -578,6 +578,16 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
                             + (lf ? sad4(l0[0]) + sad4(l0[1]) + sad4(l0[2]) + sad4(l0[3]) : 0);
                 dcY = (s + (1 << (shift - 1))) >> shift;
             }
+            // the branch-free predictor's per-macroblock inputs (pred4x4_net): which table entry a block takes -- a B_PRED macroblock's
+            // sub-block modes; any other: 0 (the dword C below: DC_PRED's value or, V_PRED, the line above) or PSEL_MB_H --, TM apart
+            const bool tm_mb = !bpred && y_mode == VP8IR_TM_PRED;
+            {
+                const u32 emb = y_mode == VP8IR_H_PRED ? (u32)PSEL_MB_H * 0x01010101u : 0u;
+                if (!(bpred && act)) bm = (u32x4){ emb, emb, emb, emb };
+            }
+            const u32 dcs = perm((u32)dcY, (u32)dcY, 0u);
+            const bool v_mb = y_mode == VP8IR_V_PRED;
+            const u32 Cmb[4] = { v_mb ? aA[0] : dcs, v_mb ? aA[1] : dcs, v_mb ? aA[2] : dcs, v_mb ? aA[3] : dcs };
             u32 abv[4] = { aA[0], aA[1], aA[2], aA[3] };      // line above the current block row (B_PRED chain)
             int tlrow = tlY;                                   // top-left of the block row's first block
             u32 nl[4] = { 0, 0, 0, 0 };                        // right column of this macroblock = left of the next
@@ -636,15 +646,34 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     u32 p[4];
-                    if (INTER && is_inter) {
-#pragma unroll
-                        for (int jj = 0; jj < 4; jj++) p[jj] = k == 0 ? pr[jj].x : k == 1 ? pr[jj].y : k == 2 ? pr[jj].z : pr[jj].w;
-                    } else if (bpred) {
+                    {
                         // decodframe.c:200-236; above-right of the right-hand block column is the macroblock's own
                         // above-right for every block row (reconintra4x4.c:305-317)
-                        bpred4x4((bmw >> (8 * k)) & 0xff, abv[k], k < 3 ? abv[k + 1] : arY, left, tl, p);
-                    } else {
-                        mb_mode_pred(y_mode, aA[k], lcur, tlY, dcY, p);
+                        const u32 em = (bmw >> (8 * k)) & 0xff;
+                        const u32 a0 = abv[k], a1 = k < 3 ? abv[k + 1] : arY;
+                        const u32 bdc = __builtin_amdgcn_sad_u8(left, 0u, __builtin_amdgcn_sad_u8(a0, 0u, 4u)) >> 3;      // B_DC_PRED
+                        pred4x4_net((const u32x4 *)(s_psel + em * PSEL_WORDS), a0, a1, left, tl, em == 0, bpred ? perm(bdc, bdc, 0u) : Cmb[k],
+                                    !bpred, lcur, p);
+                        // TM_PRED of the macroblock (above = the macroblock's line above, left = its left column) and B_TM_PRED of a
+                        // block (the running context): one formula
+                        const bool tm = bpred ? em == VP8IR_B_TM_PRED : tm_mb;
+                        if (__builtin_amdgcn_ballot_w64(tm) != 0) {
+                            const u32 at = bpred ? a0 : aA[k], lt = bpred ? left : lcur;
+                            const int tt = bpred ? tl : tlY;
+                            const v2s a01 = as_v2s(perm(at, at, 0x0c010c00u)), a23 = as_v2s(perm(at, at, 0x0c030c02u));
+#pragma unroll
+                            for (int jj = 0; jj < 4; jj++) {
+                                const u32 t = tm_row(a01, a23, (int)((lt >> (8 * jj)) & 0xff) - tt);
+                                p[jj] = tm ? t : p[jj];
+                            }
+                        }
+                        if constexpr (INTER) {
+#pragma unroll
+                            for (int jj = 0; jj < 4; jj++) {
+                                const u32 q = k == 0 ? pr[jj].x : k == 1 ? pr[jj].y : k == 2 ? pr[jj].z : pr[jj].w;
+                                p[jj] = is_inter ? q : p[jj];
+                            }
+                        }
                     }
                     u32 o[4] = { p[0], p[1], p[2], p[3] };
                     const bool hasr = (rmg >> k) & 1;
@@ -911,6 +940,8 @@ __device__ __forceinline__ void kf_kernel(const DevJob *__restrict__ jobs, int n
     __shared__ __attribute__((aligned(16))) u32 s_y2dc[64 * 8];
     __shared__ __attribute__((aligned(16))) u32 s_desc[5 * 64 * 4];
     __shared__ u32 s_sf[12 * 64];
+    __shared__ __attribute__((aligned(16))) u32 s_psel[PSEL_MODES * PSEL_WORDS];
+    for (int i = threadIdx.x; i < PSEL_MODES * PSEL_WORDS; i += 64) s_psel[i] = k_pred_sel[i];
     int role = 0, item = 0;
     if (threadIdx.x == 0) {
         const u32 hw = __builtin_amdgcn_s_getreg((31 << 11) | 4 /* HW_REG_HW_ID */);
@@ -940,8 +971,8 @@ __device__ __forceinline__ void kf_kernel(const DevJob *__restrict__ jobs, int n
 #define KF_LUMA_PRIO 3
 #endif
     if (role == 0) __builtin_amdgcn_s_setprio(KF_LUMA_PRIO);
-    if (role == 0) kf_body<true, INTER>(jobs, njobs, g, lgG, P, nstrands, dummy, item, s_stage, s_queue, s_tab, s_y2dc, s_desc, s_sf);
-    else kf_body<false, INTER>(jobs, njobs, g, lgG, P, nstrands, dummy + 1024, item, s_stage, s_queue, s_tab, s_y2dc, s_desc, s_sf);
+    if (role == 0) kf_body<true, INTER>(jobs, njobs, g, lgG, P, nstrands, dummy, item, s_stage, s_queue, s_tab, s_y2dc, s_desc, s_sf, s_psel);
+    else kf_body<false, INTER>(jobs, njobs, g, lgG, P, nstrands, dummy + 1024, item, s_stage, s_queue, s_tab, s_y2dc, s_desc, s_sf, s_psel);
 #ifdef VP8_STAMPS       // ... and for how long (units of 1024 cycles, above the work item's ten bits)
     if (threadIdx.x == 0) sched[16 + 16384 + 4 * blockIdx.x + 3] = (u32)item | ((u32)((__builtin_amdgcn_s_memtime() - t_begin) >> 10) << 10);
 #endif

@@ -156,6 +156,39 @@ __device__ __forceinline__ void bpred4x4(int mode, u32 a0, u32 a1, u32 left, int
     }
 }
 
+// The same predictors without a branch (vp8_keyframe_simt.hip, luma).  A wave's lanes hold macroblocks of every kind, so the
+// switch above runs ALL its cases, each behind an exec-mask save / branch / restore: 145 of the 339 instructions a block's
+// prediction + add took were scalar bookkeeping, and to a wave that is alone in keeping its SIMD's issue port (the luma wave:
+// the kernel's time is its time) a scalar instruction costs what a vector one does.  Here a predicted row is three v_perm_b32
+// over the lane's POOL of filtered edge values, OR-ed, the selectors looked up by mode in an LDS table (tools/gen_pred_sel.py
+// has the layout and writes vp8_pred_sel.inc; k_pred_sel is copied to LDS at kernel entry).  Entry 0 serves B_DC_PRED and the
+// 16x16 modes DC_PRED / V_PRED (the row is the dword C), entry 10 the 16x16 H_PRED (rows = bytes of `hcol`); TM is arithmetic
+// and stays with the caller.
+enum { PSEL_MB_H = 10, PSEL_MODES = 11, PSEL_WORDS = 12 };
+__device__ const u32 k_pred_sel[PSEL_MODES * PSEL_WORDS] = {
+#include "vp8_pred_sel.inc"
+};
+// sel: the mode's entry in LDS (three 16-byte reads); use_c: the mode is 0 (take C for F[0..3]); mb: a 16x16 mode (take hcol for G[0..3])
+__device__ __forceinline__ void pred4x4_net(const u32x4 *sel, u32 a0, u32 a1, u32 left, int tl, bool use_c, u32 C, bool mb, u32 hcol, u32 p[4])
+{
+    const u32x4 sa = sel[0], sb = sel[1], sc = sel[2];
+    const u32 E0 = perm(left, left, 0x01020303u);                       // L3 L3 L2 L1
+    const u32 E1 = perm(a0, left, 0x05040c00u) | ((u32)tl << 8);        // L0 TL A0 A1
+    const u32 E2 = alignb(a1, a0, 2);                                   // A2 A3 A4 A5
+    const u32 E3 = perm(a1, a1, 0x03030302u);                           // A6 A7 A7 A7
+    const u32 N0 = alignb(E1, E0, 1), N1 = alignb(E2, E1, 1), N2 = alignb(E3, E2, 1), N3 = E3 >> 8;
+    const u32 M0 = E0 << 8, M1 = alignb(E1, E0, 3), M2 = alignb(E2, E1, 3), M3 = alignb(E3, E2, 3);
+    const u32 one = 0x01010101u;
+    const u32 F0 = lerp(lerp(M0, N0, 0), E0, one), F1 = lerp(lerp(M1, N1, 0), E1, one);
+    const u32 F2 = lerp(lerp(M2, N2, 0), E2, one), F3 = lerp(lerp(M3, N3, 0), E3, one);
+    const u32 G0 = lerp(E0, N0, one), G1 = lerp(E1, N1, one), G2 = lerp(E2, N2, one);
+    const u32 lo0 = use_c ? C : F0, hi1 = perm(G2, F3, 0x05040100u), lo2 = mb ? hcol : G0;      // hi1 = F12 F13 G8 G9
+    p[0] = perm(F1, lo0, sa.x) | perm(hi1, F2, sa.y) | perm(G1, lo2, sa.z);
+    p[1] = perm(F1, lo0, sa.w) | perm(hi1, F2, sb.x) | perm(G1, lo2, sb.y);
+    p[2] = perm(F1, lo0, sb.z) | perm(hi1, F2, sb.w) | perm(G1, lo2, sc.x);
+    p[3] = perm(F1, lo0, sc.y) | perm(hi1, F2, sc.z) | perm(G1, lo2, sc.w);
+}
+
 __device__ __forceinline__ int sext16(u32 v) { return (int)(short)(v & 0xffff); }
 __device__ __forceinline__ int hi16(u32 v) { return (int)v >> 16; }
 
