@@ -170,7 +170,7 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
 
     // ---- per-lane row state; the pointers are valid addresses at all times
     g_cu32p mbp = (g_cu32p)jobs[0].mbx;         // record of the current macroblock (vp8ir_mbx: VP8IR_MBX_WORDS dwords)
-    g_cs16p bp = (g_cs16p)jobs[0].blocks;       // its first block in the slot's block stream (the blocks of a row follow each other)
+    g_cs16p bp = (g_cs16p)jobs[0].blocks;                 // its first block in the slot's block stream (the blocks of a row follow each other)
     g_u8p tp = (g_u8p)dummy, hp = (g_u8p)dummy; // first tile / first unfiltered line of its macroblock row
     int r = 0;
     u32 dqs[4][2];                              // luma: y1, y2 quantisers per segment (dc | ac << 16); chroma: uv in [s][0]
@@ -579,10 +579,9 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
                 dcY = (s + (1 << (shift - 1))) >> shift;
             }
             // the branch-free predictor's per-macroblock inputs (pred4x4_net): which table entry a block takes -- a B_PRED macroblock's
-            // sub-block modes; any other: 0 (the dword C below: DC_PRED's value or, V_PRED, the line above) or PSEL_MB_H --, TM apart
-            const bool tm_mb = !bpred && y_mode == VP8IR_TM_PRED;
+            // sub-block modes; any other: 0 (the dword C below: DC_PRED's value or, V_PRED, the line above), PSEL_MB_H, or B_TM_PRED's for TM_PRED
             {
-                const u32 emb = y_mode == VP8IR_H_PRED ? (u32)PSEL_MB_H * 0x01010101u : 0u;
+                const u32 emb = y_mode == VP8IR_H_PRED ? (u32)PSEL_MB_H * 0x01010101u : (y_mode == VP8IR_TM_PRED ? (u32)VP8IR_B_TM_PRED * 0x01010101u : 0u);
                 if (!(bpred && act)) bm = (u32x4){ emb, emb, emb, emb };
             }
             const u32 dcs = perm((u32)dcY, (u32)dcY, 0u);
@@ -656,7 +655,8 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
                                     !bpred, lcur, p);
                         // TM_PRED of the macroblock (above = the macroblock's line above, left = its left column) and B_TM_PRED of a
                         // block (the running context): one formula
-                        const bool tm = bpred ? em == VP8IR_B_TM_PRED : tm_mb;
+                        const bool tm = em == VP8IR_B_TM_PRED;
+
                         if (__builtin_amdgcn_ballot_w64(tm) != 0) {
                             const u32 at = bpred ? a0 : aA[k], lt = bpred ? left : lcur;
                             const int tt = bpred ? tl : tlY;
@@ -688,8 +688,7 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
                                 const u32 a1 = (u32)((dc + 4) >> 3) & 0xffffu, a2 = a1 | (a1 << 16);
                                 ra = rb = (u32x4){ a2, a2, a2, a2 };
                             }
-                            o[0] = add_clamp_pack(p[0], ra.x, ra.y); o[1] = add_clamp_pack(p[1], ra.z, ra.w);
-                            o[2] = add_clamp_pack(p[2], rb.x, rb.y); o[3] = add_clamp_pack(p[3], rb.z, rb.w);
+                            add_clamp_rows(p, ra, rb, o);
                         }
                     }
 #pragma unroll
@@ -805,17 +804,19 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
                     const int s = (up ? sad4(aC0) + sad4(aC1) : 0) + (lf ? sad4(lC0) + sad4(lC1) : 0);
                     dcC = (s + (1 << (shift - 1))) >> shift;
                 }
+                const u32 dcsC = perm((u32)dcC, (u32)dcC, 0u);
                 u32 bot[2] = { 0, 0 }, rc[2] = { 0, 0 };
                 u32 o0[4][2], o1[4][2];
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     const int bx = k & 1, byc = k >> 1;
                     u32 p[4];
-                    if (INTER && is_inter) {
+                    mb_mode_pred_sel(uv_mode, bx ? aC1 : aC0, byc ? lC1 : lC0, tlA, dcsC, p);
+                    if constexpr (INTER) {
                         const u32x4 ra = byc ? pr[2] : pr[0], rb = byc ? pr[3] : pr[1];
-                        p[0] = bx ? ra.y : ra.x; p[1] = bx ? ra.w : ra.z; p[2] = bx ? rb.y : rb.x; p[3] = bx ? rb.w : rb.z;
-                    } else
-                        mb_mode_pred(uv_mode, bx ? aC1 : aC0, byc ? lC1 : lC0, tlA, dcC, p);
+                        p[0] = is_inter ? (bx ? ra.y : ra.x) : p[0]; p[1] = is_inter ? (bx ? ra.w : ra.z) : p[1];
+                        p[2] = is_inter ? (bx ? rb.y : rb.x) : p[2]; p[3] = is_inter ? (bx ? rb.w : rb.z) : p[3];
+                    }
                     u32 o[4] = { p[0], p[1], p[2], p[3] };
                     const bool hasr = (rmg >> k) & 1;
                     if (__builtin_amdgcn_ballot_w64(hasr) != 0) {
@@ -827,8 +828,7 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
                                 const u32 a1 = (u32)((dc + 4) >> 3) & 0xffffu, a2 = a1 | (a1 << 16);
                                 ra = rb = (u32x4){ a2, a2, a2, a2 };
                             }
-                            o[0] = add_clamp_pack(p[0], ra.x, ra.y); o[1] = add_clamp_pack(p[1], ra.z, ra.w);
-                            o[2] = add_clamp_pack(p[2], rb.x, rb.y); o[3] = add_clamp_pack(p[3], rb.z, rb.w);
+                            add_clamp_rows(p, ra, rb, o);
                         }
                     }
 #pragma unroll

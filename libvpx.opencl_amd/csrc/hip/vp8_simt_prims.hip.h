@@ -60,6 +60,22 @@ __device__ __forceinline__ u32 add_clamp_pack(u32 pred, u32 r01, u32 r23)
     return clamp_pack4(as_v2s(perm(pred, pred, 0x0c010c00u)) + as_v2s(r01), as_v2s(perm(pred, pred, 0x0c030c02u)) + as_v2s(r23));
 }
 
+// ... for the four rows of a block at once, stage by stage: the rows are independent, and gfx950 wants a wait state between a
+// packed operation and its consumer -- row after row the compiler fills it with s_nop
+__device__ __forceinline__ void add_clamp_rows(const u32 (&p)[4], const u32x4 ra, const u32x4 rb, u32 (&o)[4])
+{
+    const u32 r[8] = { ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w };
+    u32 w[8], t[8];
+#pragma unroll
+    for (int j = 0; j < 4; j++) { w[2 * j] = perm(p[j], p[j], 0x0c010c00u); w[2 * j + 1] = perm(p[j], p[j], 0x0c030c02u); }
+#pragma unroll
+    for (int i = 0; i < 8; i++) w[i] = as_u32(as_v2s(w[i]) + as_v2s(r[i]));
+#pragma unroll
+    for (int i = 0; i < 8; i++) t[i] = sat_pk_u8(as_v2s(w[i]));
+#pragma unroll
+    for (int j = 0; j < 4; j++) o[j] = perm(t[2 * j + 1], t[2 * j], 0x05040100u);
+}
+
 // TM prediction of a row of four pixels: clamp(above[i] + left - top_left), above given as two packed pairs
 __device__ __forceinline__ u32 tm_row(v2s a01, v2s a23, int l_minus_tl)
 {
@@ -86,6 +102,24 @@ __device__ __forceinline__ void mb_mode_pred(int mode, u32 above, u32 left, int 
         const v2s a01 = as_v2s(perm(above, above, 0x0c010c00u)), a23 = as_v2s(perm(above, above, 0x0c030c02u));
 #pragma unroll
         for (int j = 0; j < 4; j++) p[j] = tm_row(a01, a23, (int)((left >> (8 * j)) & 0xff) - tl);
+    }
+}
+
+// ... the same without a branch per mode (the chroma planes of vp8_keyframe_simt.hip; see pred4x4_net below for why): selects, and
+// TM behind one wave-uniform test.  dcs: the DC value on all four bytes.
+__device__ __forceinline__ void mb_mode_pred_sel(int mode, u32 above, u32 left, int tl, u32 dcs, u32 p[4])
+{
+    const bool v = mode == VP8IR_V_PRED, h = mode == VP8IR_H_PRED, tm = mode == VP8IR_TM_PRED;
+    const u32 c = v ? above : dcs;
+    p[0] = h ? perm(left, left, 0x00000000u) : c; p[1] = h ? perm(left, left, 0x01010101u) : c;
+    p[2] = h ? perm(left, left, 0x02020202u) : c; p[3] = h ? perm(left, left, 0x03030303u) : c;
+    if (__builtin_amdgcn_ballot_w64(tm) != 0) {
+        const v2s a01 = as_v2s(perm(above, above, 0x0c010c00u)), a23 = as_v2s(perm(above, above, 0x0c030c02u));
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const u32 t = tm_row(a01, a23, (int)((left >> (8 * j)) & 0xff) - tl);
+            p[j] = tm ? t : p[j];
+        }
     }
 }
 
