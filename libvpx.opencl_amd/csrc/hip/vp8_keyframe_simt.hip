@@ -509,6 +509,8 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
         const bool bpred = y_mode == VP8IR_B_PRED;
         const int ref_frame = INTER ? (int)((cur_w0 >> 16) & 3) : 0;
         const bool is_inter = INTER && act && ref_frame != VP8IR_INTRA_FRAME;
+        // (launches with inter frames: most waves hold nothing but inter macroblocks, and skip the intra predictors)
+        const bool any_intra = !INTER || __builtin_amdgcn_ballot_w64(act && !is_inter) != 0;
         int level;
         if constexpr (INTER) {
             // vp8_loop_filter_frame_init (loopfilter.c:117-201) for this macroblock's segment, reference frame and mode class
@@ -644,8 +646,8 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
                 u32 orow[4][4];                               // [row][block]
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
-                    u32 p[4];
-                    {
+                    u32 p[4] = { 0, 0, 0, 0 };
+                    if (any_intra) {
                         // decodframe.c:200-236; above-right of the right-hand block column is the macroblock's own
                         // above-right for every block row (reconintra4x4.c:305-317)
                         const u32 em = (bmw >> (8 * k)) & 0xff;
@@ -667,12 +669,12 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
                                 p[jj] = tm ? t : p[jj];
                             }
                         }
-                        if constexpr (INTER) {
+                    }
+                    if constexpr (INTER) {
 #pragma unroll
-                            for (int jj = 0; jj < 4; jj++) {
-                                const u32 q = k == 0 ? pr[jj].x : k == 1 ? pr[jj].y : k == 2 ? pr[jj].z : pr[jj].w;
-                                p[jj] = is_inter ? q : p[jj];
-                            }
+                        for (int jj = 0; jj < 4; jj++) {
+                            const u32 q = k == 0 ? pr[jj].x : k == 1 ? pr[jj].y : k == 2 ? pr[jj].z : pr[jj].w;
+                            p[jj] = is_inter ? q : p[jj];
                         }
                     }
                     u32 o[4] = { p[0], p[1], p[2], p[3] };
@@ -684,7 +686,7 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
                                 // a lone DC: (short)(q[0] * dq[0]) (idct_blk.c:34), or the Y2 block's; a1 = (dc + 4) >> 3 on every pixel
                                 const u32 y2w = k < 2 ? y2w0 : y2w1;
                                 const int raw = (short)(y2w >> (16 * (k & 1)));
-                                const int dc = (dc_given & 1) ? raw : (short)(raw * (short)(cur_dq & 0xffff));
+                                const int dc = (dc_given & 1) ? raw : (short)__mul24(raw, (int)(cur_dq & 0xffff));
                                 const u32 a1 = (u32)((dc + 4) >> 3) & 0xffffu, a2 = a1 | (a1 << 16);
                                 ra = rb = (u32x4){ a2, a2, a2, a2 };
                             }
@@ -810,8 +812,8 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     const int bx = k & 1, byc = k >> 1;
-                    u32 p[4];
-                    mb_mode_pred_sel(uv_mode, bx ? aC1 : aC0, byc ? lC1 : lC0, tlA, dcsC, p);
+                    u32 p[4] = { 0, 0, 0, 0 };
+                    if (any_intra) mb_mode_pred_sel(uv_mode, bx ? aC1 : aC0, byc ? lC1 : lC0, tlA, dcsC, p);
                     if constexpr (INTER) {
                         const u32x4 ra = byc ? pr[2] : pr[0], rb = byc ? pr[3] : pr[1];
                         p[0] = is_inter ? (bx ? ra.y : ra.x) : p[0]; p[1] = is_inter ? (bx ? ra.w : ra.z) : p[1];
@@ -824,7 +826,7 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
                             u32x4 ra = rr[2 * k], rb = rr[2 * k + 1];
                             if (!((rmf >> k) & 1)) {          // a lone DC
                                 const u32 cw = k < 2 ? cdc0 : cdc1;
-                                const int dc = (short)((short)(cw >> (16 * (k & 1))) * (short)(cur_dq & 0xffff));
+                                const int dc = (short)__mul24((int)(short)(cw >> (16 * (k & 1))), (int)(cur_dq & 0xffff));
                                 const u32 a1 = (u32)((dc + 4) >> 3) & 0xffffu, a2 = a1 | (a1 << 16);
                                 ra = rb = (u32x4){ a2, a2, a2, a2 };
                             }
