@@ -333,11 +333,24 @@ __device__ __forceinline__ void masks(const v2u p[8], v2u lim, v2u elim, v2u thr
 {
     const v2u d10 = adu(p[2], p[3]), dq = adu(p[5], p[4]);
     const v2u dh = umax(d10, dq);
+#ifdef LF_MASKS_ABS
     v2u m = umax(umax(adu(p[0], p[1]), adu(p[1], p[2])), dh);
     m = umax(m, umax(adu(p[6], p[5]), adu(p[7], p[6])));
     const v2u a = adu(p[3], p[4]);
     const v2u e = uadds(uadds(a, a), (adu(p[2], p[5]) >> 1) & mku(0xff00));      // 2|p0-q0| + |p1-q1|/2, saturating
     const v2u over = usubs(m, lim) | usubs(e, elim);                              // non-zero: leave the edge alone
+#else
+    // The four outer differences are only ever compared with the limit, so their sign need not be taken off: with
+    // u = clamp(a - b) as a signed 16-bit number, |a - b| <= lim  <=>  (u + lim) mod 2^16 <= 2 lim as UNSIGNED numbers (lim <= 63 << 8:
+    // a negative u + lim wraps to >= 32768 + 256, a saturated difference is beyond the limit on either side) -- subtract, add,
+    // max instead of max, min, subtract, max.
+    const v2u t0 = pix(subs(sgn(p[0]), sgn(p[1]))) + lim, t1 = pix(subs(sgn(p[1]), sgn(p[2]))) + lim;
+    const v2u t2 = pix(subs(sgn(p[6]), sgn(p[5]))) + lim, t3 = pix(subs(sgn(p[7]), sgn(p[6]))) + lim;
+    const v2u tm = umax(umax(t0, t1), umax(t2, t3));
+    const v2u a = adu(p[3], p[4]);
+    const v2u e = uadds(uadds(a, a), (adu(p[2], p[5]) >> 1) & mku(0xff00));      // 2|p0-q0| + |p1-q1|/2, saturating
+    const v2u over = usubs(tm, lim + lim) | usubs(dh, lim) | usubs(e, elim);      // non-zero: leave the edge alone
+#endif
     mask = nz_clear(over, one) & gate;
     hev = nz_set(usubs(dh, thr), one);
 }
