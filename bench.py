@@ -610,8 +610,10 @@ def main():
             got = np.ctypeslib.as_array(ctypes.cast(dig, ctypes.POINTER(ctypes.c_uint8)), shape=(F, 16))
             bad = sum(1 for i in range(F) if got[i].tobytes().hex() != gold[(lo + i) % nsrc])
             consumers["device_md5"] = {"ms_per_step": round(t_md5, 3), "Mpix_s": round(F * W * H / t_md5 / 1e3, 1), "md5_mismatches": bad,
-                                       "what": f"decode {F} frames, then vp8_md5_tiles_kernel hashes every one of them from the tiles (a frame per "
-                                               f"lane) and the {F} digests come back: decode_to_md5's output for the step"}
+                                       "what": f"decode {F} frames, then every one of them is hashed on the device, a frame per lane (batches of 12,288 "
+                                               f"frames and more from a packed copy, vp8_pack_i420_tiles_kernel + vp8_md5_kernel; smaller ones "
+                                               f"straight from the tiles, vp8_md5_tiles_kernel) and the {F} digests come back: decode_to_md5's "
+                                               f"output for the step"}
         except Exception as ex:      # noqa: BLE001 - a probe, not the benchmark
             consumers["device_md5"] = {"error": repr(ex)}
         try:
