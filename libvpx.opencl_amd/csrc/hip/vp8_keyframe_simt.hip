@@ -531,7 +531,7 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
         // the simple filter leaves chroma alone (loopfilter.c:283-299)
         const bool any_normal = __builtin_amdgcn_ballot_w64(on && !simple) != 0;
         const bool any_simple = LUMA && __builtin_amdgcn_ballot_w64(on && simple) != 0;
-        auto gate = [](bool b) { return mku(b ? 0xffff : 0); };
+        auto gate = [](bool b) { return lf_gate(b); };
         const Gates gv = { gate(mbv && !simple), gate(inner && !simple), gate(LUMA && mbv && simple), gate(LUMA && inner && simple), any_normal, any_simple };
         const Gates gh = { gate(mbh && !simple), gate(inner && !simple), gate(LUMA && mbh && simple), gate(LUMA && inner && simple), any_normal, any_simple };
         // ---- unfiltered line above (127 above the frame; vp8_setup_intra_recon)

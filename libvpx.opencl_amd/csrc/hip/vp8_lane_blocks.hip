@@ -27,7 +27,7 @@ lane_lf_kernel(const unsigned char *__restrict__ in, unsigned char *__restrict__
     const Lim L = { mku(pp[0] << 8), mku(pp[1] << 8), mku(pp[2] << 8), mku(pp[3] << 8), one };
     const bool simple = pp[7] != 0, mbv = live && pp[4], inner = live && pp[5], mbh = live && pp[6];
     const bool any_normal = __builtin_amdgcn_ballot_w64(live && !simple) != 0, any_simple = __builtin_amdgcn_ballot_w64(live && simple) != 0;
-    auto gate = [](bool b) { return mku(b ? 0xffff : 0); };
+    auto gate = [](bool b) { return lf_gate(b); };
     const Gates gv = { gate(mbv && !simple), gate(inner && !simple), gate(mbv && simple), gate(inner && simple), any_normal, any_simple };
     const Gates gh = { gate(mbh && !simple), gate(inner && !simple), gate(mbh && simple), gate(inner && simple), any_normal, any_simple };
     auto px = [&](int y, int x) { return (u32)src[(y + 4) * 20 + (x + 4)]; };

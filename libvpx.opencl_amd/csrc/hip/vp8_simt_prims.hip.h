@@ -311,7 +311,8 @@ __device__ __forceinline__ v2u usubs(v2u a, v2u b) { return __builtin_elementwis
 __device__ __forceinline__ v2u uadds(v2u a, v2u b) { return __builtin_elementwise_add_sat(a, b); }
 __device__ __forceinline__ v2s adds(v2s a, v2s b) { return __builtin_elementwise_add_sat(a, b); }     // signed-char clamp
 __device__ __forceinline__ v2s subs(v2s a, v2s b) { return __builtin_elementwise_sub_sat(a, b); }
-// x != 0 ? 0 : 0xffff (nz_clear) and x != 0 ? 0xffff : 0 (nz_set) per half, from max(1 - x, 0) by saturating subtraction.
+// (Through round 4: x != 0 ? 0 : 0xffff (nz_clear) and x != 0 ? 0xffff : 0 (nz_set) per half, from max(1 - x, 0) by saturating
+// subtraction; masks() now keeps the 1 / 0 form and multiplies.)
 // `one` is the constant 1 | 1 << 16 made opaque to LLVM (one empty asm at kernel entry, see Lim::one): with a visible
 // constant the expression is canonicalised into a compare-and-select, which gfx950 can only do one half at a time.
 __device__ __forceinline__ v2u nz_clear(v2u x, v2u one) { return mku(0) - usubs(one, x); }
@@ -323,23 +324,16 @@ __device__ __forceinline__ v2s hib(v2s v) { return as_v2s(as_u32(v) & 0xff00ff00
 
 struct Lim { v2u mblim, blim, lim, thr, one; };     // the limits, << 8; the opaque constant 1 of nz_clear / nz_set
 
-// The filters are branch-free: `gate` (0xffff / 0 per lane) switches an edge off by clearing its filter mask,
+// The filters are branch-free: `gate` (lf_gate: 0 / 0xffff per lane) switches an edge off by clearing its filter mask,
 // which makes every update the identity.  Straight-line code lets the scheduler interleave the independent
 // pixel-line pairs, which is what hides the wait state gfx950 wants between dependent packed-math ops.
 
 // vp8_filter_mask + vp8_hevmask (loopfilter_filters.c:27-49) for p[0..7] = p3 p2 p1 p0 q0 q1 q2 q3:
-// mask = 0xffff where the edge is filtered, hev = 0xffff where the high-edge-variance rule applies
+// mask = 1 where the edge is filtered (see below), hev = 0xffff where the high-edge-variance rule applies
 __device__ __forceinline__ void masks(const v2u p[8], v2u lim, v2u elim, v2u thr, v2u one, v2u gate, v2u &mask, v2u &hev)
 {
     const v2u d10 = adu(p[2], p[3]), dq = adu(p[5], p[4]);
     const v2u dh = umax(d10, dq);
-#ifdef LF_MASKS_ABS
-    v2u m = umax(umax(adu(p[0], p[1]), adu(p[1], p[2])), dh);
-    m = umax(m, umax(adu(p[6], p[5]), adu(p[7], p[6])));
-    const v2u a = adu(p[3], p[4]);
-    const v2u e = uadds(uadds(a, a), (adu(p[2], p[5]) >> 1) & mku(0xff00));      // 2|p0-q0| + |p1-q1|/2, saturating
-    const v2u over = usubs(m, lim) | usubs(e, elim);                              // non-zero: leave the edge alone
-#else
     // The four outer differences are only ever compared with the limit, so their sign need not be taken off: with
     // u = clamp(a - b) as a signed 16-bit number, |a - b| <= lim  <=>  (u + lim) mod 2^16 <= 2 lim as UNSIGNED numbers (lim <= 63 << 8:
     // a negative u + lim wraps to >= 32768 + 256, a saturated difference is beyond the limit on either side) -- subtract, add,
@@ -350,9 +344,21 @@ __device__ __forceinline__ void masks(const v2u p[8], v2u lim, v2u elim, v2u thr
     const v2u a = adu(p[3], p[4]);
     const v2u e = uadds(uadds(a, a), (adu(p[2], p[5]) >> 1) & mku(0xff00));      // 2|p0-q0| + |p1-q1|/2, saturating
     const v2u over = usubs(tm, lim + lim) | usubs(dh, lim) | usubs(e, elim);      // non-zero: leave the edge alone
-#endif
-    mask = nz_clear(over, one) & gate;
-    hev = nz_set(usubs(dh, thr), one);
+    // `mask` is 1 / 0 per half here and is applied by a multiplication (lf_keep): one saturating subtraction makes it, where the
+    // all-ones form takes two; the gate (lf_gate: 0 = open) is one more reason to leave the edge alone.
+    // hev only matters where the edge is filtered, and there dh <= lim < 2^15: (thr - dh) >> 15, sign and all, is the mask.
+    mask = usubs(one, over | gate);
+    hev = as_v2u(as_u32(as_v2s(as_u32(thr - dh)) >> 15));
+}
+// a lane's switch for an edge: see masks
+__device__ __forceinline__ v2u lf_gate(bool on)
+{
+    return mku(on ? 0 : 0xffff);
+}
+// the filter value of the lines `mask` lets through, 0 for the others
+__device__ __forceinline__ v2s lf_keep(v2s f, v2u mask)
+{
+    return as_v2s(as_u32(as_v2u(as_u32(f)) * mask));
 }
 
 // filter_value = clamp(filter_value + 3 * (qs0 - ps0)) (loopfilter_filters.c:66, 176): three saturating adds of
@@ -370,7 +376,7 @@ __device__ __forceinline__ void lf_inner(v2u p[8], const Lim &L, v2u gate)
     masks(p, L.lim, L.blim, L.thr, L.one, gate, mask, hev);
     v2s ps1 = sgn(p[2]), ps0 = sgn(p[3]), qs0 = sgn(p[4]), qs1 = sgn(p[5]);
     v2s f = as_v2s(as_u32(subs(ps1, qs1)) & as_u32(hev));
-    f = as_v2s(as_u32(add3w(f, qs0, ps0)) & as_u32(mask));
+    f = lf_keep(add3w(f, qs0, ps0), mask);
     const v2s f1 = hib(adds(f, mks(0x0400)) >> 3), f2 = hib(adds(f, mks(0x0300)) >> 3);
     qs0 = subs(qs0, f1); ps0 = adds(ps0, f2);
     f = as_v2s(as_u32((f1 + mks(0x0100)) >> 1) & (~as_u32(hev) & 0xff00ff00u));
@@ -384,7 +390,7 @@ __device__ __forceinline__ void lf_mbedge(v2u p[8], const Lim &L, v2u gate)
     v2u mask, hev;
     masks(p, L.lim, L.mblim, L.thr, L.one, gate, mask, hev);
     v2s ps2 = sgn(p[1]), ps1 = sgn(p[2]), ps0 = sgn(p[3]), qs0 = sgn(p[4]), qs1 = sgn(p[5]), qs2 = sgn(p[6]);
-    v2s f = as_v2s(as_u32(add3w(subs(ps1, qs1), qs0, ps0)) & as_u32(mask));
+    v2s f = lf_keep(add3w(subs(ps1, qs1), qs0, ps0), mask);
     v2s f2 = as_v2s(as_u32(f) & as_u32(hev));
     const v2s f1 = hib(adds(f2, mks(0x0400)) >> 3);
     f2 = hib(adds(f2, mks(0x0300)) >> 3);
@@ -406,9 +412,9 @@ __device__ __forceinline__ void lf_simple(v2u p[8], v2u elim, v2u one, v2u gate)
 {
     const v2u a = adu(p[3], p[4]);
     const v2u e = uadds(uadds(a, a), (adu(p[2], p[5]) >> 1) & mku(0xff00));
-    const v2u mask = nz_clear(usubs(e, elim), one) & gate;
+    const v2u mask = usubs(one, usubs(e, elim) | gate);
     v2s ps1 = sgn(p[2]), ps0 = sgn(p[3]), qs0 = sgn(p[4]), qs1 = sgn(p[5]);
-    const v2s f = as_v2s(as_u32(add3w(subs(ps1, qs1), qs0, ps0)) & as_u32(mask));
+    const v2s f = lf_keep(add3w(subs(ps1, qs1), qs0, ps0), mask);
     const v2s f1 = hib(adds(f, mks(0x0400)) >> 3), f2 = hib(adds(f, mks(0x0300)) >> 3);
     p[4] = pix(subs(qs0, f1)); p[3] = pix(adds(ps0, f2));
 }
