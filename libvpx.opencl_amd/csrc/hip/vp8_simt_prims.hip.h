@@ -328,6 +328,12 @@ struct Lim { v2u mblim, blim, lim, thr, one; };     // the limits, << 8; the opa
 // which makes every update the identity.  Straight-line code lets the scheduler interleave the independent
 // pixel-line pairs, which is what hides the wait state gfx950 wants between dependent packed-math ops.
 
+// |w| of a signed 16-bit pair as an unsigned one (-32768 -> 32768)
+__device__ __forceinline__ v2u sabs(v2s w)
+{
+    return pix(__builtin_elementwise_max(w, sgn(mku(0) - pix(w))));
+}
+
 // vp8_filter_mask + vp8_hevmask (loopfilter_filters.c:27-49) for p[0..7] = p3 p2 p1 p0 q0 q1 q2 q3:
 // mask = 1 where the edge is filtered (see below), hev = 0xffff where the high-edge-variance rule applies
 __device__ __forceinline__ void masks(const v2u p[8], v2u lim, v2u elim, v2u thr, v2u one, v2u gate, v2u &mask, v2u &hev)
@@ -341,8 +347,10 @@ __device__ __forceinline__ void masks(const v2u p[8], v2u lim, v2u elim, v2u thr
     const v2u t0 = pix(subs(sgn(p[0]), sgn(p[1]))) + lim, t1 = pix(subs(sgn(p[1]), sgn(p[2]))) + lim;
     const v2u t2 = pix(subs(sgn(p[6]), sgn(p[5]))) + lim, t3 = pix(subs(sgn(p[7]), sgn(p[6]))) + lim;
     const v2u tm = umax(umax(t0, t1), umax(t2, t3));
-    const v2u a = adu(p[3], p[4]);
-    const v2u e = uadds(uadds(a, a), (adu(p[2], p[5]) >> 1) & mku(0xff00));      // 2|p0-q0| + |p1-q1|/2, saturating
+    // |p0 - q0| from the SATURATED difference the filters need anyway (max(w, -w): two instructions, not three): beyond +-32767 twice
+    // of it is larger than any limit (elim <= 193 << 8) either way.  |p1 - q1| is halved and has to be exact.
+    const v2u a = sabs(subs(sgn(p[4]), sgn(p[3]))), b = adu(p[2], p[5]);
+    const v2u e = uadds(uadds(a, a), (b >> 1) & mku(0xff00));                     // 2|p0-q0| + |p1-q1|/2, saturating
     const v2u over = usubs(tm, lim + lim) | usubs(dh, lim) | usubs(e, elim);      // non-zero: leave the edge alone
     // `mask` is 1 / 0 per half here and is applied by a multiplication (lf_keep): one saturating subtraction makes it, where the
     // all-ones form takes two; the gate (lf_gate: 0 = open) is one more reason to leave the edge alone.
@@ -394,12 +402,12 @@ __device__ __forceinline__ void lf_mbedge(v2u p[8], const Lim &L, v2u gate)
     v2s f2 = as_v2s(as_u32(f) & as_u32(hev));
     const v2s f1 = hib(adds(f2, mks(0x0400)) >> 3);
     f2 = hib(adds(f2, mks(0x0300)) >> 3);
-    qs0 = subs(qs0, f1); ps0 = adds(ps0, f2);
     const v2s F = as_v2s(as_u32(f) & ~as_u32(hev)) >> 8;             // plain signed value, -128 .. 127
     // ((F * 27 + 63) >> 7) << 8 == (F * 54 + 126) with the low byte cleared (|F * 54 + 126| < 2^15): one multiply-add
     // and one AND instead of multiply-add, shift, shift
     v2s u = hib(F * 54 + 126);
-    qs0 = subs(qs0, u); ps0 = adds(ps0, u);
+    // (a line takes the hev branch's f1 / f2 or the 27-tap u, never both -- the other is zero: one update of p0 / q0, not two)
+    qs0 = subs(qs0, as_v2s(as_u32(f1) | as_u32(u))); ps0 = adds(ps0, as_v2s(as_u32(f2) | as_u32(u)));
     u = hib(F * 36 + 126);
     qs1 = subs(qs1, u); ps1 = adds(ps1, u);
     u = hib(F * 18 + 126);
@@ -410,8 +418,8 @@ __device__ __forceinline__ void lf_mbedge(v2u p[8], const Lim &L, v2u gate)
 // vp8_loop_filter_simple_horizontal/vertical_edge_c (loopfilter_filters.c:292-355): modifies p0 q0
 __device__ __forceinline__ void lf_simple(v2u p[8], v2u elim, v2u one, v2u gate)
 {
-    const v2u a = adu(p[3], p[4]);
-    const v2u e = uadds(uadds(a, a), (adu(p[2], p[5]) >> 1) & mku(0xff00));
+    const v2u a = sabs(subs(sgn(p[4]), sgn(p[3]))), b = adu(p[2], p[5]);
+    const v2u e = uadds(uadds(a, a), (b >> 1) & mku(0xff00));
     const v2u mask = usubs(one, usubs(e, elim) | gate);
     v2s ps1 = sgn(p[2]), ps0 = sgn(p[3]), qs0 = sgn(p[4]), qs1 = sgn(p[5]);
     const v2s f = lf_keep(add3w(subs(ps1, qs1), qs0, ps0), mask);
