@@ -709,6 +709,17 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
                 if (by == 3) { sb[0] = sB[0]; sb[1] = sB[1]; sb[2] = sB[2]; sb[3] = sB[3]; }
                 lf_block_row<4>(orow, sb, tF, by == 0, gv, gh, L, d);
                 STAMP(5)
+                // (launches with inter frames: the next part of the prediction is asked for IN FRONT of the row stores -- it lies in other
+                // bytes of the tile than they write --, so that the four youngest memory operations the drain below leaves in flight are
+                // always the stores: behind them, the wait for the coefficients was a wait for the stores to be acknowledged as well)
+                if constexpr (INTER) {
+                    const bool nx_inter = more && ((nx_w0 >> 16) & 3) != VP8IR_INTRA_FRAME;        // (by == 3: nx_w0 is the next macroblock's)
+                    if (by < 3 ? is_inter : nx_inter) {
+                        const g_u8p pp = by < 3 ? tpc + 64 * (by + 1) : tpc + VP8_TILE_BYTES;
+#pragma unroll
+                        for (int j = 0; j < 4; j++) pr[j] = *(g_cu32x4p)(pp + 16 * j);
+                    }
+                }
                 const bool first = by == 0;
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
@@ -720,14 +731,6 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
                 for (int j = 0; j < 4; j++) { if (act && !first) sF[(4 * by - 4 + j) * 64] = d[j][3]; sfix[j] = sb[j]; }
                 prow = KF_ACT(act) ? (first ? tpc + KT_Y_WIN : prow + 64) : (g_u8p)dummy;
                 pstride = KF_ACT(act) ? 16 : 0;
-                if constexpr (INTER) {
-                    const bool nx_inter = more && ((nx_w0 >> 16) & 3) != VP8IR_INTRA_FRAME;        // (by == 3: nx_w0 is the next macroblock's)
-                    if (by < 3 ? is_inter : nx_inter) {
-                        const g_u8p pp = by < 3 ? tpc + 64 * (by + 1) : tpc + VP8_TILE_BYTES;
-#pragma unroll
-                        for (int j = 0; j < 4; j++) pr[j] = *(g_cu32x4p)(pp + 16 * j);
-                    }
-                }
                 STAMP(10)
                 // ---- the next phase's residuals (its coefficients have landed: the four row stores above are younger)
                 drain(by < 3 ? 4 * by + 4 : 0, 0, 4);
@@ -840,6 +843,15 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
                 }
                 bA[0] = bot[0]; bA[1] = bot[1]; l0[0] = rc[0]; l0[1] = rc[1];
                 STAMP(4)
+                // (the other plane's prediction, or the next macroblock's: in front of this plane's stores, see the luma role)
+                if constexpr (INTER) {
+                    const bool nx_inter = more && ((nx_w0 >> 16) & 3) != VP8IR_INTRA_FRAME;        // (pl == 1: nx_w0 is the next macroblock's)
+                    if (pl == 0 ? is_inter : nx_inter) {
+                        const g_u8p pp = pl == 0 ? tpc + 288 : tpc + VP8_TILE_BYTES + 256;
+                        pr[0] = *(g_cu32x4p)pp; pr[1] = *(g_cu32x4p)(pp + 16);
+                        pr[2] = *(g_cu32x4p)(pp + 64); pr[3] = *(g_cu32x4p)(pp + 80);
+                    }
+                }
                 // ---- loop filter of the plane, block row by block row
                 const int poff = 32 * pl;
                 if (hand) *(g_u32x2p)(hpc + KH_U + 8 * pl) = (u32x2){ bot[0], bot[1] };        // unfiltered bottom line: hand-over
@@ -887,14 +899,6 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
 #pragma unroll
                             for (int j = 0; j < 4; j += 2) *(g_u32x4p)(tpc + KT_U_BOT + poff + j * 8) = (u32x4){ e[j][0], e[j][1], e[j + 1][0], e[j + 1][1] } ^ VP8_LF_BIAS;
                         }
-                    }
-                }
-                if constexpr (INTER) {
-                    const bool nx_inter = more && ((nx_w0 >> 16) & 3) != VP8IR_INTRA_FRAME;        // (pl == 1: nx_w0 is the next macroblock's)
-                    if (pl == 0 ? is_inter : nx_inter) {
-                        const g_u8p pp = pl == 0 ? tpc + 288 : tpc + VP8_TILE_BYTES + 256;
-                        pr[0] = *(g_cu32x4p)pp; pr[1] = *(g_cu32x4p)(pp + 16);
-                        pr[2] = *(g_cu32x4p)(pp + 64); pr[3] = *(g_cu32x4p)(pp + 80);
                     }
                 }
                 // ---- the other plane's residuals (or the next macroblock's first): the four row stores above are younger
