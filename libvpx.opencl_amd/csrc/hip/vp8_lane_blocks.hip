@@ -56,12 +56,28 @@ lane_lf_kernel(const unsigned char *__restrict__ in, unsigned char *__restrict__
 __global__ void __launch_bounds__(64)
 lane_bpred_kernel(const unsigned char *__restrict__ mode, const unsigned char *__restrict__ ctx, unsigned char *__restrict__ out, int n)
 {
+    // the key-frame kernels' predictor (vp8_keyframe_simt.hip, luma): the selector table in LDS, the pool + three v_perm_b32 a row,
+    // B_DC_PRED through the dword C, TM by arithmetic and a select
+    __shared__ __attribute__((aligned(16))) u32 s_psel[PSEL_MODES * PSEL_WORDS];
+    for (int k = threadIdx.x; k < PSEL_MODES * PSEL_WORDS; k += 64) s_psel[k] = k_pred_sel[k];
+    __syncthreads();
     const int i = blockIdx.x * 64 + threadIdx.x;
-    if (i >= n) return;
-    const u32 *c = (const u32 *)(ctx + (size_t)i * 16);
+    const bool live = i < n;
+    const u32 *c = (const u32 *)(ctx + (size_t)(live ? i : 0) * 16);
+    const u32 em = live ? mode[i] : 0u, a0 = c[0], a1 = c[1], left = c[2];
+    const int tl = (int)(c[3] & 0xff);
+    const u32 bdc = __builtin_amdgcn_sad_u8(left, 0u, __builtin_amdgcn_sad_u8(a0, 0u, 4u)) >> 3;
     u32 p[4];
-    bpred4x4(mode[i], c[0], c[1], c[2], (int)(c[3] & 0xff), p);
-    for (int j = 0; j < 4; j++) ((u32 *)(out + (size_t)i * 16))[j] = p[j];
+    pred4x4_net((const u32x4 *)(s_psel + em * PSEL_WORDS), a0, a1, left, tl, em == 0, perm(bdc, bdc, 0u), false, 0u, p);
+    const bool tm = em == VP8IR_B_TM_PRED;
+    if (__builtin_amdgcn_ballot_w64(tm) != 0) {
+        const v2s a01 = as_v2s(perm(a0, a0, 0x0c010c00u)), a23 = as_v2s(perm(a0, a0, 0x0c030c02u));
+        for (int j = 0; j < 4; j++) {
+            const u32 t = tm_row(a01, a23, (int)((left >> (8 * j)) & 0xff) - tl);
+            p[j] = tm ? t : p[j];
+        }
+    }
+    if (live) for (int j = 0; j < 4; j++) ((u32 *)(out + (size_t)i * 16))[j] = p[j];
 }
 
 // coef: 16 shorts per block in IR order (column-major, include/vp8_ir.h); dq: dc, ac per block; pred / out: 16 bytes per block

@@ -89,24 +89,10 @@ __device__ __forceinline__ u32 right_column(const u32 o[4])
     return perm(perm(o[3], o[2], 0x0c0c0703u), perm(o[1], o[0], 0x0c0c0703u), 0x05040100u);
 }
 
-// Whole-block predictors DC / V / H / TM (reconintra.c:139-241, 403-521) for one 4x4 block:
-// above = the 4 pixels above the block's columns, left = the 4 pixels left of its rows (top in byte 0).
-__device__ __forceinline__ void mb_mode_pred(int mode, u32 above, u32 left, int tl, int dc, u32 p[4])
-{
-    if (mode == VP8IR_DC_PRED) { p[0] = p[1] = p[2] = p[3] = splat(dc); }
-    else if (mode == VP8IR_V_PRED) { p[0] = p[1] = p[2] = p[3] = above; }
-    else if (mode == VP8IR_H_PRED) {
-        p[0] = perm(left, left, 0x00000000u); p[1] = perm(left, left, 0x01010101u);
-        p[2] = perm(left, left, 0x02020202u); p[3] = perm(left, left, 0x03030303u);
-    } else {
-        const v2s a01 = as_v2s(perm(above, above, 0x0c010c00u)), a23 = as_v2s(perm(above, above, 0x0c030c02u));
-#pragma unroll
-        for (int j = 0; j < 4; j++) p[j] = tm_row(a01, a23, (int)((left >> (8 * j)) & 0xff) - tl);
-    }
-}
-
-// ... the same without a branch per mode (the chroma planes of vp8_keyframe_simt.hip; see pred4x4_net below for why): selects, and
-// TM behind one wave-uniform test.  dcs: the DC value on all four bytes.
+// Whole-block predictors DC / V / H / TM (reconintra.c:139-241, 403-521) for one 4x4 block of a chroma plane (vp8_keyframe_simt.hip):
+// above = the 4 pixels above the block's columns, left = the 4 pixels left of its rows (top in byte 0), dcs = the DC value on all
+// four bytes.  No branch per mode (see pred4x4_net below for why; through round 4 this was an if-chain): selects, and
+// TM behind one wave-uniform test.
 __device__ __forceinline__ void mb_mode_pred_sel(int mode, u32 above, u32 left, int tl, u32 dcs, u32 p[4])
 {
     const bool v = mode == VP8IR_V_PRED, h = mode == VP8IR_H_PRED, tm = mode == VP8IR_TM_PRED;
@@ -125,73 +111,11 @@ __device__ __forceinline__ void mb_mode_pred_sel(int mode, u32 above, u32 left, 
 
 // vp8_intra4x4_predict (reconintra4x4.c:16-303) for one block.  a0 = above 4 pixels, a1 = the next 4
 // (above-right), left = left 4 pixels (top in byte 0), tl = top-left.  Edge vector as in the oracle:
-// P[0..14] = { L3, L3, L2, L1, L0, TL, A0..A7, A7 }; F[k] = (P[k-1]+2P[k]+P[k+1]+2)>>2,
+// P[0..15] = { L3, L3, L2, L1, L0, TL, A0..A7, A7, A7 }; F[k] = (P[k-1]+2P[k]+P[k+1]+2)>>2,
 // G[k] = (P[k]+P[k+1]+1)>>1, both computed four pixels per instruction with v_lerp_u8:
-// (a+2b+c+2)>>2 == (((a+c)>>1) + b + 1)>>1 exactly.
-__device__ __forceinline__ void bpred4x4(int mode, u32 a0, u32 a1, u32 left, int tl, u32 p[4])
-{
-    if (mode == VP8IR_B_DC_PRED) {
-        p[0] = p[1] = p[2] = p[3] = splat((sad4(a0) + sad4(left) + 4) >> 3);
-        return;
-    }
-    if (mode == VP8IR_B_TM_PRED) {
-        const v2s a01 = as_v2s(perm(a0, a0, 0x0c010c00u)), a23 = as_v2s(perm(a0, a0, 0x0c030c02u));
-#pragma unroll
-        for (int j = 0; j < 4; j++) p[j] = tm_row(a01, a23, (int)((left >> (8 * j)) & 0xff) - tl);
-        return;
-    }
-    const u32 E0 = perm(left, left, 0x01020303u);                       // L3 L3 L2 L1
-    const u32 E1 = perm(a0, left, 0x05040c00u) | ((u32)tl << 8);        // L0 TL A0 A1
-    const u32 E2 = alignb(a1, a0, 2);                                   // A2 A3 A4 A5
-    const u32 E3 = perm(a1, a1, 0x03030302u);                           // A6 A7 A7 A7
-    // neighbours: M_w[j] = P[4w+j-1], N_w[j] = P[4w+j+1]
-    const u32 N0 = alignb(E1, E0, 1), N1 = alignb(E2, E1, 1), N2 = alignb(E3, E2, 1), N3 = E3 >> 8;
-    const u32 M0 = E0 << 8, M1 = alignb(E1, E0, 3), M2 = alignb(E2, E1, 3), M3 = alignb(E3, E2, 3);
-    const u32 one = 0x01010101u;
-    const u32 F0 = lerp(lerp(M0, N0, 0), E0, one), F1 = lerp(lerp(M1, N1, 0), E1, one);
-    const u32 F2 = lerp(lerp(M2, N2, 0), E2, one), F3 = lerp(lerp(M3, N3, 0), E3, one);
-    const u32 G0 = lerp(E0, N0, one), G1 = lerp(E1, N1, one), G2 = lerp(E2, N2, one);
-    switch (mode) {
-    case VP8IR_B_VE_PRED: p[0] = p[1] = p[2] = p[3] = alignb(F2, F1, 2); break;          // F6..F9
-    case VP8IR_B_HE_PRED:                                                                  // F4, F3, F2, F1
-        p[0] = perm(F1, F0, 0x04040404u); p[1] = perm(F1, F0, 0x03030303u);
-        p[2] = perm(F1, F0, 0x02020202u); p[3] = perm(F1, F0, 0x01010101u);
-        break;
-    case VP8IR_B_LD_PRED:                                                                  // F[7+r ..]
-        p[0] = alignb(F2, F1, 3); p[1] = F2; p[2] = alignb(F3, F2, 1); p[3] = alignb(F3, F2, 2);
-        break;
-    case VP8IR_B_RD_PRED:                                                                  // F[5-r ..]
-        p[0] = alignb(F2, F1, 1); p[1] = F1; p[2] = alignb(F1, F0, 3); p[3] = alignb(F1, F0, 2);
-        break;
-    case VP8IR_B_VR_PRED:
-        p[0] = alignb(G2, G1, 1);                 // G5 G6 G7 G8
-        p[1] = alignb(F2, F1, 1);                 // F5 F6 F7 F8
-        p[2] = perm(G1, F1, 0x07060500u);         // F4 G5 G6 G7
-        p[3] = perm(F1, F0, 0x07060503u);         // F3 F5 F6 F7
-        break;
-    case VP8IR_B_VL_PRED:
-        p[0] = alignb(G2, G1, 2);                 // G6 G7 G8 G9
-        p[1] = alignb(F2, F1, 3);                 // F7 F8 F9 F10
-        p[2] = perm(F2, alignb(G2, G1, 3), 0x07020100u);   // G7 G8 G9 F11
-        p[3] = perm(F3, F2, 0x04020100u);         // F8 F9 F10 F12
-        break;
-    case VP8IR_B_HD_PRED:
-        p[0] = perm(F1, G1, 0x07060500u);                             // G4 F5 F6 F7
-        p[1] = perm(perm(F1, G1, 0x0500040cu), G0, 0x07060503u);      // G3 F4 G4 F5
-        p[2] = perm(F1, perm(F0, G0, 0x0c030702u), 0x04020100u);      // G2 F3 G3 F4
-        p[3] = perm(F0, G0, 0x07020601u);                             // G1 F2 G2 F3
-        break;
-    default: /* VP8IR_B_HU_PRED */
-        p[0] = perm(F0, G0, 0x06020703u);                             // G3 F3 G2 F2
-        p[1] = perm(F0, G0, 0x05010602u);                             // G2 F2 G1 F1
-        p[2] = perm(E0, perm(F0, G0, 0x0c0c0501u), 0x05050100u);      // G1 F1 L3 L3
-        p[3] = perm(E0, E0, 0x01010101u);                             // L3 x4
-        break;
-    }
-}
-
-// The same predictors without a branch (vp8_keyframe_simt.hip, luma).  A wave's lanes hold macroblocks of every kind, so the
-// switch above runs ALL its cases, each behind an exec-mask save / branch / restore: 145 of the 339 instructions a block's
+// (a+2b+c+2)>>2 == (((a+c)>>1) + b + 1)>>1 exactly.  Which F / G a pixel of a mode is: tools/gen_pred_sel.py.
+// Through round 4 this was a switch over the ten modes.  A wave's lanes hold macroblocks of every kind, so the switch ran ALL
+// its cases, each behind an exec-mask save / branch / restore: 145 of the 339 instructions a block's
 // prediction + add took were scalar bookkeeping, and to a wave that is alone in keeping its SIMD's issue port (the luma wave:
 // the kernel's time is its time) a scalar instruction costs what a vector one does.  Here a predicted row is three v_perm_b32
 // over the lane's POOL of filtered edge values, OR-ed, the selectors looked up by mode in an LDS table (tools/gen_pred_sel.py
