@@ -175,3 +175,25 @@ def test_the_pools_come_with_their_first_user(pkg):
         assert [P.planes_md5(*ctx.download_planes(i)) for i in range(3)] == gold[:3]
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("n,pack_from", [(200, 100), (129, 65), (64, 64), (333, 70)])
+def test_large_batches_are_hashed_from_a_packed_copy(pkg, monkeypatch, n, pack_from):
+    """A digest-only batch of VP8HIP_MD5_PACK_FROM tiled frames and more (default 12,288: where the tiles' lines no longer fit the
+    Infinity Cache) is hashed from a packed I420 copy (vp8_pack_i420_tiles_kernel + vp8_md5_kernel over a geometry without borders),
+    smaller ones and sub-ranges below the threshold straight from the tiles: every digest is the reference decoder's either way
+    (tests/test_gpu_bench_shapes.py has the 16,384-frame case with the default threshold)."""
+    P = pkg
+    monkeypatch.setenv("VP8HIP_MD5_PACK_FROM", str(pack_from))
+    ctx = P.Vp8Hip(0)
+    try:
+        nsrc, gold = _setup(P, ctx, "kf_640x360", n, monkeypatch)
+        ctx.decode([(i, i, None) for i in range(n)], P.STAGE_ALL)
+        assert ctx.stats().fused == 1
+        want = [gold[i % nsrc] for i in range(n)]
+        for rep in range(2):
+            assert ctx.frames_md5(0, n) == want
+        assert ctx.frames_md5(5, n - 5) == want[5:]
+        assert ctx.memory_usage()["raster_pool"] == 0
+    finally:
+        ctx.close()
