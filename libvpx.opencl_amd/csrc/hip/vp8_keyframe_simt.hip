@@ -129,7 +129,7 @@ __device__ __forceinline__ void frame_levels_inter(const vp8ir_frame_hdr &h, u32
 // coefficients are requested into the same buffer (they are then on their way during the owner's prediction + filtering of
 // the current phase).  The macroblock descriptors of the next step come by LDS-DMA too (a 16-byte slot per lane and piece),
 // not through registers held for a step.
-// LDS of a wave, whichever role it plays (19 KB: eight waves per CU, two per SIMD):
+// LDS of a wave, whichever role it plays (19.3 KB: eight waves per CU, two per SIMD):
 //   s_stage  [block of the phase][half][lane] 16 B: the owner's coefficients in, residuals out     8192 B
 //   s_queue  owner lane | block in phase << 6 | DC given << 8                 512 B
 //   s_tab    per owner: quantiser (dc | ac << 16)                             256 B
@@ -139,6 +139,8 @@ __device__ __forceinline__ void frame_levels_inter(const vp8ir_frame_hdr &h, u32
 //   s_sf     [row][lane]: the last four pixels (filtered, biased) of pixel rows of the macroblock to the left -- luma rows 0..11,
 //            chroma U rows 0..3, V rows 0..3 (the bottom four rows' are in registers: they double as the lane below's context).
 //            Per-lane state read and written once per step and indexed by the block row: in LDS it costs no registers    3072 B
+//   s_psel   (round 5) the v_perm_b32 selectors of the branch-free 4x4 predictor, 48 bytes per mode (pred4x4_net,
+//            vp8_simt_prims.hip.h; the table is k_pred_sel, copied in at kernel entry)                                        528 B
 template <bool LUMA, bool INTER>
 __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njobs, DevGeom g, int lgG, int P, int nstrands, uint8_t *dummy,
                                         const int wave, u32 *s_stage, unsigned short *s_queue, u32 *s_tab,
