@@ -181,9 +181,10 @@ __device__ __forceinline__ void dequant_idct(const u32x4 ca, const u32x4 cb, int
 #pragma unroll
     for (int row = 0; row < 4; row++) {
         int o0, o1, o2, o3;
-        idct1d(t[row * 4], t[row * 4 + 1], t[row * 4 + 2], t[row * 4 + 3], o0, o1, o2, o3);
-        res[row * 4 + 0] = (o0 + 4) >> 3; res[row * 4 + 1] = (o1 + 4) >> 3;
-        res[row * 4 + 2] = (o2 + 4) >> 3; res[row * 4 + 3] = (o3 + 4) >> 3;
+        // (the rounding 4 of all four outputs rides in on the first input: a1 = i0 + i2 and b1 = i0 - i2 both carry it)
+        idct1d(t[row * 4] + 4, t[row * 4 + 1], t[row * 4 + 2], t[row * 4 + 3], o0, o1, o2, o3);
+        res[row * 4 + 0] = o0 >> 3; res[row * 4 + 1] = o1 >> 3;
+        res[row * 4 + 2] = o2 >> 3; res[row * 4 + 3] = o3 >> 3;
     }
 }
 
