@@ -30,7 +30,7 @@ def L(pkg):
     return lib
 
 
-@pytest.mark.parametrize("seed,noise", [(1, 3), (2, 12), (3, 40), (4, 255)])
+@pytest.mark.parametrize("seed,noise", [(1, 3), (2, 12), (3, 40), (4, 255), (5, 255)])
 def test_loop_filter_macroblocks(L, seed, noise):
     """64-lane steps of the streamed loop filter (lf_block_row: lf_mbedge / lf_inner / lf_simple on packed pairs, the
     row <-> column-pair shuffles, the left-context fix-up) on random macroblocks with random limits and edge gates."""
@@ -41,6 +41,8 @@ def test_loop_filter_macroblocks(L, seed, noise):
     grad = rng.integers(-3, 4, size=(n, 1, 1)) * np.arange(20).reshape(1, 20, 1) + rng.integers(-3, 4, size=(n, 1, 1)) * np.arange(20).reshape(1, 1, 20)
     step = (np.arange(20).reshape(1, 1, 20) >= rng.integers(0, 20, size=(n, 1, 1))) * rng.integers(-30, 31, size=(n, 1, 1))
     src = np.clip(base + grad + step + rng.integers(-noise, noise + 1, size=(n, 20, 20)), 0, 255).astype(np.uint8)
+    if seed == 5:                           # black and white only: every difference is 0 or 255 (the masks' saturated differences)
+        src = np.where(src > 127, 255, 0).astype(np.uint8)
     par = np.zeros((n, 8), np.uint8)
     lfi = OraLfi()
     for i in range(n):
@@ -69,7 +71,7 @@ def test_loop_filter_macroblocks(L, seed, noise):
             if inner: O.vp8o_loop_filter_bh(y, du, du, ci(20), ci(24), ctypes.byref(lf))
     bad = np.nonzero((got != want).reshape(n, -1).any(axis=1))[0]
     assert bad.size == 0, (bad[:8], par[bad[:4]])
-    assert (want != src).any()              # the filters did something
+    assert seed == 5 or (want != src).any()              # the filters did something
 
 
 def test_intra4x4_predictors(L):
