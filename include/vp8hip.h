@@ -109,6 +109,12 @@ typedef struct vp8hip_memory {
     size_t raster_pool, tile_pool, slots, block_pool, entropy_input, packed_staging;
 } vp8hip_memory;
 int  vp8hip_memory_usage(const vp8hip_ctx *ctx, vp8hip_memory *out);
+/* packed_staging: the batch as packed I420 -- what vp8hip_frames_fetch_i420_async sends, and what a digest-only fetch of
+ * VP8HIP_MD5_PACK_FROM (12,288) tiled frames and more is hashed from: 3.1 MB per 1080p frame, 51 GB at 16,384, allocated when first
+ * needed (a fetch that finds no room for it hashes the tiles) and KEPT for the next batch.  It is a cache: the library frees it by
+ * itself when one of the two pools cannot be allocated beside it, and vp8hip_release_staging frees it now (waits for fetches in
+ * flight). */
+int  vp8hip_release_staging(vp8hip_ctx *ctx);
 int  vp8hip_geometry(const vp8hip_ctx *ctx, vp8ir_geom *g);
 
 /* Pinned host staging of a slot in the device form, for a feeder to write into directly (vp8_parser_decode_mbs_compact): mbx[nmb],
@@ -268,11 +274,14 @@ int  vp8hip_frames_md5_list_async(vp8hip_ctx *ctx, const int *fbs, int n, uint8_
  * into page-locked memory IS the tiled -> raster pass, a kernel writing the host buffer (the frames' raster form never exists in
  * HBM; what lands in the destination's border bytes is then undefined) -- faster than the copy engines on an otherwise idle
  * device, slower beside other kernels, hence off by default (VP8HIP_DIRECT_DOWNLOAD=1 sets the default).
- * INTER PREDICTION reads a reference frame in either form (round 5): a large launch whose references are all there as tiles and
- * not all as raster frames -- streams decoded in lock step: every launch predicts from what the launch before left -- reads the
- * tiles (vp8_inter_pred_tiles_kernel; borders are address clamps) and no conversion runs; any other launch reads the raster form,
- * converting the references that lack it first.  vp8hip_set_pred_tiles(ctx, mode): 1 that rule (the default; VP8HIP_PRED_TILES
- * sets it), 2 tiles whenever every reference has them, 0 never -- the three give the same frames, bit for bit. */
+ * INTER PREDICTION reads a reference frame in either form (round 5).  A large launch ONE of whose references exists only as tiles
+ * -- streams decoded in lock step: every launch predicts from what the launch before left -- reads all its references as tiles
+ * (vp8_inter_pred_tiles_kernel; borders are address clamps): no tiled -> raster pass runs, and a reference that exists only in
+ * raster form (a golden frame a small launch decoded, an uploaded one) is given its tiled form once (vp8_retile_kernel) and keeps
+ * both.  Any other launch -- every reference has a raster form already, or the launch is a small one -- reads the raster form.
+ * vp8hip_set_pred_tiles(ctx, mode): 1 that rule (the default; VP8HIP_PRED_TILES sets it), 2 large launches always read tiles
+ * (references without them are retiled), 0 never -- the three give the same frames, bit for bit.  Frames 16 pixels wide are always
+ * read in raster form (a strip of the tile reader replicates one horizontal edge, and theirs reach past both). */
 int  vp8hip_frames_to_raster(vp8hip_ctx *ctx, int first_fb, int count);
 int  vp8hip_set_direct_download(vp8hip_ctx *ctx, int on);
 int  vp8hip_set_pred_tiles(vp8hip_ctx *ctx, int mode);

@@ -432,8 +432,11 @@ __device__ __forceinline__ void strip8(const SRC &src, const Taps &tx, const Tap
     if constexpr (SRC::PAIRED) {
         if (!src.y_edge) {
             // rows in pairs (TileSrc::PAIRED): pair k holds rows 2 k, 2 k + 1 for a lane whose first row is the first of its pair,
-            // rows 2 k - 1, 2 k for the others: row i wants pair i / 2 resp. (i + 1) / 2; four pairs in flight
-            constexpr int NP = (NIN + 1) / 2 + 1, PA = 4;
+            // rows 2 k - 1, 2 k for the others: row i wants pair i / 2 resp. (i + 1) / 2 -- pairs 0 .. NIN / 2, (NIN + 1) / 2 of them
+            // (a pair begins at an even row of its tile and so never leaves the tile row: the last one stays inside the plane as
+            // its first row does); four pairs in flight
+            constexpr int NP = (NIN + 1) / 2, PA = 4;
+            static_assert((NIN & 1) && (NIN - 1 + 1) / 2 == NP - 1, "the last row's pair is the last pair");
             typename SRC::PairRaw q[PA];
 #pragma unroll
             for (int k = 0; k < PA; k++) q[k] = src.issue_pair(k);

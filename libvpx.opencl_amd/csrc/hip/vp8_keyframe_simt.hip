@@ -938,6 +938,10 @@ __device__ __forceinline__ void kf_body(const DevJob *__restrict__ jobs, int njo
 // from one counter per role (if its role has run out of work it takes the other).  grid = 2 * nwaves.
 //   sched[0], sched[1]: next luma / chroma work item (zeroed before every launch); sched[16 + simd]: waves seen (never reset:
 //   only the parity matters).
+// Who is on a SIMD right now: luma waves in bits 15:0, chroma waves in bits 31:16, one word per SIMD of the device, for ALL launches
+// of the process (every context, every stream: kernels of two contexts run side by side, and each must see the other's waves).
+__device__ unsigned int vp8_simd_roles[16384];
+
 template <bool INTER>
 __device__ __forceinline__ void kf_kernel(const DevJob *__restrict__ jobs, int njobs, DevGeom g, int lgG, int P, int nstrands, uint8_t *dummy,
                                           unsigned int *sched, int nwaves)
@@ -951,15 +955,26 @@ __device__ __forceinline__ void kf_kernel(const DevJob *__restrict__ jobs, int n
     __shared__ __attribute__((aligned(16))) u32 s_psel[PSEL_MODES * PSEL_WORDS];
     for (int i = threadIdx.x; i < PSEL_MODES * PSEL_WORDS; i += 64) s_psel[i] = k_pred_sel[i];
     int role = 0, item = 0;
-    if (threadIdx.x == 0) {
-        const u32 hw = __builtin_amdgcn_s_getreg((31 << 11) | 4 /* HW_REG_HW_ID */);
-        const u32 xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20 /* HW_REG_XCC_ID */);
+    // (the SIMD's word is looked up again when the wave leaves: a wave stays where it is, and the kernel has no register to carry it in)
+    auto simd_word = [](u32 &hw, u32 &xcc) {
+        hw = __builtin_amdgcn_s_getreg((31 << 11) | 4 /* HW_REG_HW_ID */);
+        xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20 /* HW_REG_XCC_ID */);
         // SIMD_ID [5:4], CU_ID [11:8], SH_ID [12], SE_ID [15:13]; the pipe / queue fields in between differ from stream to stream
-        const u32 simd = ((hw >> 4) & 3) | (((hw >> 8) & 0xff) << 2) | ((xcc & 15) << 10);
-        const u32 seen = __hip_atomic_fetch_add(&sched[16 + simd], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        role = seen & 1;
+        return vp8_simd_roles + (((hw >> 4) & 3) | (((hw >> 8) & 0xff) << 2) | ((xcc & 15) << 10));
+    };
+    if (threadIdx.x == 0) {
+        u32 hw, xcc;
+        unsigned int *const here = simd_word(hw, xcc);
+        // the wave joins its SIMD as the role the SIMD holds fewer of (an empty SIMD: luma) ...
+        unsigned int seen = __hip_atomic_load(here, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        do role = (seen & 0xffffu) <= (seen >> 16) ? 0 : 1;
+        while (!__hip_atomic_compare_exchange_strong(here, &seen, seen + (role ? 0x10000u : 1u), __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
         item = (int)__hip_atomic_fetch_add(&sched[role], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (item >= nwaves) { role ^= 1; item = (int)__hip_atomic_fetch_add(&sched[role], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+        if (item >= nwaves) {       // ... unless that role has run out of work in this launch
+            (void)__hip_atomic_fetch_add(here, role ? 1u - 0x10000u : 0x10000u - 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            role ^= 1;
+            item = (int)__hip_atomic_fetch_add(&sched[role], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
 #ifdef VP8_STAMPS       // diagnostic builds: where every wave ran and as what
         sched[16 + 16384 + 4 * blockIdx.x] = hw; sched[16 + 16384 + 4 * blockIdx.x + 1] = xcc;
         sched[16 + 16384 + 4 * blockIdx.x + 2] = (u32)role | (seen << 8); sched[16 + 16384 + 4 * blockIdx.x + 3] = (u32)item;
@@ -967,7 +982,12 @@ __device__ __forceinline__ void kf_kernel(const DevJob *__restrict__ jobs, int n
     }
     role = __builtin_amdgcn_readfirstlane(role);
     item = __builtin_amdgcn_readfirstlane(item);
-    if (item >= nwaves) return;         // (cannot happen with grid = 2 * nwaves)
+    // (leaving: the SIMD's count of this role goes down again)
+    auto leave = [&]() {
+        u32 hw, xcc;
+        if (threadIdx.x == 0) (void)__hip_atomic_fetch_add(simd_word(hw, xcc), role ? 0u - 0x10000u : 0u - 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    if (item >= nwaves) { leave(); return; }         // (cannot happen with grid = 2 * nwaves)
 #ifdef VP8_STAMPS
     const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
 #endif
@@ -981,6 +1001,7 @@ __device__ __forceinline__ void kf_kernel(const DevJob *__restrict__ jobs, int n
     if (role == 0) __builtin_amdgcn_s_setprio(KF_LUMA_PRIO);
     if (role == 0) kf_body<true, INTER>(jobs, njobs, g, lgG, P, nstrands, dummy, item, s_stage, s_queue, s_tab, s_y2dc, s_desc, s_sf, s_psel);
     else kf_body<false, INTER>(jobs, njobs, g, lgG, P, nstrands, dummy + 1024, item, s_stage, s_queue, s_tab, s_y2dc, s_desc, s_sf, s_psel);
+    leave();
 #ifdef VP8_STAMPS       // ... and for how long (units of 1024 cycles, above the work item's ten bits)
     if (threadIdx.x == 0) sched[16 + 16384 + 4 * blockIdx.x + 3] = (u32)item | ((u32)((__builtin_amdgcn_s_memtime() - t_begin) >> 10) << 10);
 #endif

@@ -334,12 +334,32 @@ static int configure_pools(vp8hip_ctx *c, int width, int height, int num_fb, int
     return 0;
 }
 
+// The staging of packed downloads -- which a digest-only fetch of a large batch also allocates and keeps, 3.1 MB per 1080p frame
+// (fetch_impl) -- is a cache: given back when a pool that the context cannot do without finds no room.
+int vp8hip_drop_staging(vp8hip_ctx *c)
+{
+    if (!c->d_i420) return 0;
+    if (c->stream_d2h) HIPCHK(c, hipStreamSynchronize(c->stream_d2h));
+    for (int k = 0; k < 3; k++) if (c->stream_d2h_more[k]) HIPCHK(c, hipStreamSynchronize(c->stream_d2h_more[k]));
+    (void)hipFree(c->d_i420);
+    c->d_i420 = nullptr; c->i420_cap = 0;
+    return 1;
+}
+extern "C" int vp8hip_release_staging(vp8hip_ctx *c)
+{
+    if (!c) return -2;
+    HIPCHK(c, hipSetDevice(c->device));
+    return vp8hip_drop_staging(c) < 0 ? -1 : 0;
+}
+
 int vp8hip_raster_pool(vp8hip_ctx *c)
 {
     if (c->fb_block || c->fb.empty()) return 0;
     HIPCHK(c, hipSetDevice(c->device));
     const size_t n = c->fb.size();
-    if (hipMalloc((void **)&c->fb_block, c->fb_stride * n) != hipSuccess) {
+    hipError_t e = hipMalloc((void **)&c->fb_block, c->fb_stride * n);
+    if (e != hipSuccess && vp8hip_drop_staging(c) == 1) { (void)hipGetLastError(); e = hipMalloc((void **)&c->fb_block, c->fb_stride * n); }
+    if (e != hipSuccess) {
         (void)hipGetLastError();
         c->fb_block = nullptr;
         return fail(c, -1, "no device memory for the raster form of %zu frame buffers (%zu MB)", n, c->fb_stride * n >> 20);

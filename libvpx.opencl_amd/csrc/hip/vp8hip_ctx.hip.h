@@ -151,6 +151,7 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 // pipeline whose frames are written as tiles, hashed as tiles and never read by coordinate never pays for it -- at 1080p 3.2 MB
 // per frame buffer, a quarter of what a frame in flight costs.
 int vp8hip_raster_pool(vp8hip_ctx *c);
+int vp8hip_drop_staging(vp8hip_ctx *c);       // vp8hip.hip: frees the packed staging (1: freed, 0: there was none)
 int vp8hip_need_raster(vp8hip_ctx *c, int first, int count);
 int vp8hip_need_raster_list(vp8hip_ctx *c, const int *fbs, int n);
 // vp8hip.hip

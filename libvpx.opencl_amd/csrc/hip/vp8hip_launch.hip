@@ -127,7 +127,12 @@ static int tile_pool(vp8hip_ctx *c)
 {
     if (c->tile_block) return 0;
     const int nfb = (int)c->fb.size();
-    if (hipMalloc((void **)&c->tile_alloc, c->tile_frame * (size_t)nfb + 8192 + VP8HIP_TILE_FRONT) != hipSuccess) {
+    hipError_t e = hipMalloc((void **)&c->tile_alloc, c->tile_frame * (size_t)nfb + 8192 + VP8HIP_TILE_FRONT);
+    if (e != hipSuccess && vp8hip_drop_staging(c) == 1) {       // (the packed staging is a cache: vp8hip.hip)
+        (void)hipGetLastError();
+        e = hipMalloc((void **)&c->tile_alloc, c->tile_frame * (size_t)nfb + 8192 + VP8HIP_TILE_FRONT);
+    }
+    if (e != hipSuccess) {
         (void)hipGetLastError();
         c->tile_alloc = nullptr;
         return fail(c, -1, "no device memory for the tiled form of %d frame buffers (%zu MB)", nfb, c->tile_frame * (size_t)nfb >> 20);
@@ -186,9 +191,10 @@ extern "C" int vp8hip_decode(vp8hip_ctx *c, const vp8hip_job *jobs, int njobs, i
             return fail(c, -2, "vp8hip_decode: job %d has slot %d / fb %d out of range", i, jobs[i].ir_slot, jobs[i].dst_fb);
     if (tiled && tile_pool(c)) return -1;
     // Inter prediction reads its reference frames in the form they are in: a large launch whose references all have a raster form
-    // reads that (vp8_inter_pred_kernel: a row is one load); one whose references are all there as tiles -- streams decoded in
-    // lock step: what the launch before left -- reads the tiles (vp8_inter_pred_tiles_kernel) and no tiled -> raster pass runs;
-    // a launch with both kinds, or a small one, gets the raster form of the references that lack it first.
+    // reads that (vp8_inter_pred_kernel: a row is one load); one with a reference that exists only as tiles -- streams decoded in
+    // lock step: what the launch before left -- reads ALL its references as tiles (vp8_inter_pred_tiles_kernel), no tiled ->
+    // raster pass runs, and those of its references that exist only in raster form are retiled once (they keep both forms); a
+    // small launch gets the raster form of the references that lack it first.
     bool pred_tiles = false;
     {
         // what this launch reads as raster: its reference frames (borders included), and -- a wave-per-row launch of the loop filter
@@ -196,7 +202,8 @@ extern "C" int vp8hip_decode(vp8hip_ctx *c, const vp8hip_job *jobs, int njobs, i
         std::vector<int> need;
         bool pool = !tiled || K.eager_raster;               // (a large launch of key frames writes tiles only)
         std::vector<int> lack_tiles;                         // references that only exist in raster form
-        bool may_tiles = inter_fused && K.pred_tiles && c->tile_block;
+        // (frames one macroblock wide: a chroma strip reaches past BOTH vertical edges, and TileSrc replicates one)
+        bool may_tiles = inter_fused && K.pred_tiles && c->tile_block && c->geom.aligned_w >= 32;
         for (int i = 0; i < njobs; i++) {
             if (c->slots[jobs[i].ir_slot].hdr_copy.frame_type != 0) {
                 for (int k = 1; k < 4; k++) {

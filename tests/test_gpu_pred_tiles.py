@@ -51,7 +51,8 @@ def test_random_inter_ir_from_tiled_references(pkg, monkeypatch, w, h, version, 
             ctx._chk(ctx.L.vp8hip_set_pred_tiles(ctx.h, 1), "vp8hip_set_pred_tiles")
             ctx.decode([(0, 0, (1, 2, 3))], 7)
             st = ctx.stats()
-            assert st.fused == 1 and st.pred_tiles == 1, (st.fused, st.pred_tiles)
+            # (frames one macroblock wide stay with the raster reader: a chroma strip reaches past both vertical edges there)
+            assert st.fused == 1 and st.pred_tiles == (1 if w > 16 else 0), (st.fused, st.pred_tiles)
             got = ctx.download_full(0)
             d = bordered_area_equal(got, o, g)
             assert not d, (seed, "tiles", d)
@@ -61,6 +62,45 @@ def test_random_inter_ir_from_tiled_references(pkg, monkeypatch, w, h, version, 
             st = ctx.stats()
             assert st.fused == 1 and st.pred_tiles == 0
             assert np.array_equal(ctx.download_full(4), got), seed
+    finally:
+        ctx.close()
+
+
+@pytest.mark.parametrize("w,h", [(176, 144), (640, 368)])
+@pytest.mark.parametrize("mode", [1, 2])
+def test_references_in_mixed_forms(pkg, monkeypatch, w, h, mode):
+    """A launch whose `last` frame exists only as tiles while its golden frame was UPLOADED (raster form only: VP8_SET_REFERENCE, or
+    a frame a small launch decoded): the tile reader runs, the uploaded frame is given its tiled form once (vp8_retile_kernel) and
+    keeps its raster bytes; both modes that read tiles, against the oracle and against the raster reader."""
+    P = pkg
+    monkeypatch.setenv("VP8HIP_RECON", "simt")
+    ctx = P.Vp8Hip(0)
+    try:
+        ctx.configure(w, h, 6, 4)
+        g = ctx.g
+        refs = _tile_only_refs(P, ctx, w, h, 4)
+        # the golden frame comes from outside: its own pixels, borders extended as vp8_yv12_extend_frame_borders leaves them
+        hdr_g, mbs_g, coef_g, mvs_g = synth_ir(w, h, 4242, inter=False, dense=0.5)
+        gold = np.zeros(g.frame_size, np.uint8)
+        oracle_decode(hdr_g, mbs_g, coef_g, mvs_g, gold, (None, None, None), 7)
+        ctx.upload_frame(2, gold)
+        refs[1] = gold
+        hdr, mbs, coef, mvs = synth_ir(w, h, 77 + w, inter=True, dense=0.4, big=True)
+        o = np.zeros(g.frame_size, np.uint8)
+        oracle_decode(hdr, mbs, coef, mvs, o, tuple(refs), 7)
+        ctx.fill_slot(0, hdr, mbs, coef, mvs)
+        ctx._chk(ctx.L.vp8hip_set_pred_tiles(ctx.h, mode), "vp8hip_set_pred_tiles")
+        for rep in range(2):            # (the second launch finds the golden frame in both forms)
+            ctx.decode([(0, 4 + rep, (1, 2, 3))], 7)
+            st = ctx.stats()
+            assert st.fused == 1 and st.pred_tiles == 1, (st.fused, st.pred_tiles)
+            d = bordered_area_equal(ctx.download_full(4 + rep), o, g)
+            assert not d, (rep, d)
+        assert np.array_equal(ctx.download_full(2), gold)          # the raster form was kept
+        ctx._chk(ctx.L.vp8hip_set_pred_tiles(ctx.h, 0), "vp8hip_set_pred_tiles")
+        ctx.decode([(0, 0, (1, 2, 3))], 7)
+        assert ctx.stats().pred_tiles == 0
+        assert np.array_equal(ctx.download_full(0), ctx.download_full(4))
     finally:
         ctx.close()
 
