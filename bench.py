@@ -142,87 +142,146 @@ def cpu_baseline(fixture, budget_s=12.0):
 
 
 
-def inter_frame_probe(P, device, n=8192, name="p_dense_1920x1080", k=2):
-    """BASELINE configs[2] beside the headline: six-tap motion compensation + IDCT + loop filter on REAL inter frames.
-    The stream is decoded the normal way up to frame k-1; then n jobs decode frame k, every one from its OWN copy of the
-    IR (vp8hip_ir_copy) and its OWN copies of the three reference buffers (vp8hip_frame_copy) into its own frame buffer
-    -- n independent streams in lock step, nothing shared in cache -- and one of them is compared with the reference MD5.
-    Roofline by SURVEY 8(d): 2407 B/MB for the full inter path (833 residual + 768 prediction + 770 loop filter + 36).
-    8192 jobs: a frame per strand of 8 lanes (68 macroblock rows: 8.5 rounds, nine run; 4096 jobs: 16 lanes, 4.25 rounds, five run)."""
+def inter_frame_probe(P, device, n=8192, name="p_dense_1920x1080", k=2, reps=3):
+    """BASELINE configs[2] beside the headline: six-tap motion compensation + IDCT + loop filter on REAL inter frames, n jobs a launch.
+      * `ms_per_launch`: the stream is decoded the normal way up to frame k-1; then n jobs decode frame k, every one from its OWN copy
+        of the IR (vp8hip_ir_copy) and its OWN copy of the reference frame (vp8hip_frame_copy: raster form) into its own frame buffer
+        -- nothing shared in cache, nothing chained: the launches are repeated over the same references;
+      * `chained`: n copies of the stream decoded in LOCK STEP, every stream with its own IR slots and its own four frame buffers (the
+        frame lifecycle of vp8dx_receive_compressed_data, onyxd_if.c:318-706, for n decoders side by side), a launch per position up
+        to frame k-1; then frames k and k+1 one after the other -- launch k+1 predicts from the frames launch k just wrote, as a
+        decoder's launches do, read as the tiles they were left as --, the streams taken back to frame k-1 (untimed) and the pair
+        repeated.
+    EVERY job's frame is hashed on the device after the timed launches and compared with the reference decoder's listing.  Roofline by
+    SURVEY 8(d): 2407 B/MB for the full inter path (833 residual + 768 prediction + 770 loop filter + 36), a model of dense content.
+    8192 jobs: a frame per strand of 8 lanes (68 macroblock rows: 8.5 rounds, nine run)."""
     from vp8_testlib import ivf_path, golden_md5
     w, h, frames = P.read_ivf(ivf_path(name))
     gold = golden_md5(name)
+    assert k + 1 < len(frames)
+    # ---------------- frame k alone, from private raster references
     ctx = P.Vp8Hip(device)
-    ctx.configure(w, h, 4 + 2 * n, 2 + n)          # 4 decoder buffers, then per job: one reference copy, one destination
+    ctx.configure(w, h, 4 + 2 * n, 2 + n)          # 4 decoder buffers, then n reference copies, then n destinations
     parser = P.Parser()
+    shown_k = 0
     for data in frames[:k]:
         hdr = ctx.parse_into_slot(parser, data, 0)
         ctx.upload(0)
         r = parser.refs
         ctx.decode([(0, r.new_idx, (r.lst_idx, r.gld_idx, r.alt_idx) if hdr.frame_type else None)], P.STAGE_ALL)
         ctx.sync()
+        shown_k += 1 if hdr.show_frame else 0
         parser.swap(hdr)
     hdr = ctx.parse_into_slot(parser, frames[k], 1)
-    assert hdr.frame_type == 1
+    assert hdr.frame_type == 1 and hdr.show_frame
     ctx.upload(1)
     r = parser.refs
     distinct = len({r.lst_idx, r.gld_idx, r.alt_idx})
     jobs = (P.Job * n)()
     for i in range(n):
         ctx.ir_copy(2 + i, 1)
-        # (the fixture's golden and alt-ref are the key frame and never referenced by frame k's macroblocks: one private
-        # copy of `last` per job is every byte the job reads; the other two indices still point at valid buffers)
-        ctx.L.vp8hip_frame_copy(ctx.h, 4 + 2 * i, r.lst_idx)
-        jobs[i].ir_slot, jobs[i].dst_fb = 2 + i, 5 + 2 * i
-        jobs[i].ref_fb[1], jobs[i].ref_fb[2], jobs[i].ref_fb[3] = 4 + 2 * i, r.gld_idx, r.alt_idx
+        # (the fixtures' golden and alt-ref are the key frame and not referenced by frame k's macroblocks: one private copy of `last`
+        # per job is every byte the job reads; the other two indices still point at valid buffers)
+        ctx.L.vp8hip_frame_copy(ctx.h, 4 + i, r.lst_idx)
+        jobs[i].ir_slot, jobs[i].dst_fb = 2 + i, 4 + n + i
+        jobs[i].ref_fb[1], jobs[i].ref_fb[2], jobs[i].ref_fb[3] = 4 + i, r.gld_idx, r.alt_idx
     for _ in range(2):              # (the first launch allocates the tiled forms)
         ctx.decode_array(jobs, n, P.STAGE_ALL)
     ctx.sync()
-    ok = P.planes_md5(*ctx.download_planes(5 + 2 * (n // 2))) == gold[k]
-    reps = 5
     t0 = time.perf_counter()
-    for _ in range(reps):
+    for _ in range(5):
         ctx.decode_array(jobs, n, P.STAGE_ALL)
     ctx.sync()
-    dt = (time.perf_counter() - t0) / reps
+    dt = (time.perf_counter() - t0) / 5
     st = ctx.stats()
-    # the same launches CHAINED: every launch predicts from the frames the launch before it wrote (n streams in lock step, as a
-    # decoder runs them): the reference frames' raster form is produced at the start of every launch
-    back = (P.Job * n)()
-    for i in range(n):
-        back[i].ir_slot, back[i].dst_fb = 2 + i, 4 + 2 * i
-        back[i].ref_fb[1], back[i].ref_fb[2], back[i].ref_fb[3] = 5 + 2 * i, r.gld_idx, r.alt_idx
-    ctx.decode_array(back, n, P.STAGE_ALL); ctx.decode_array(jobs, n, P.STAGE_ALL); ctx.sync()
-    t0 = time.perf_counter()
-    for _ in range(2):
-        ctx.decode_array(back, n, P.STAGE_ALL)
-        ctx.decode_array(jobs, n, P.STAGE_ALL)
-    ctx.sync()
-    dt_chained = (time.perf_counter() - t0) / 4
-    chained_tiles = bool(ctx.stats().pred_tiles)
+    unchained_tiles = bool(st.pred_tiles)
+    bad = sum(1 for v in ctx.frames_md5(4 + n, n) if v != gold[shown_k])
     nmb = ctx.nmb
     parser.close()
+    ctx.close()
+    # ---------------- frames k, k+1 chained: n streams in lock step.  Frame buffer b of stream i: b * n + i; slots: set A = 0 .. n-1,
+    # set B = n .. 2n-1, then one master per frame 0 .. k+1
+    ctx = P.Vp8Hip(device)
+    ctx.configure(w, h, 4 * n, 2 * n + k + 2)
+    parser = P.Parser()
+    M = 2 * n
+    info = []                   # per frame: (frame_type, new, last, golden, alt-ref, shown index or -1)
+    shown = 0
+    for f in range(k + 2):
+        hdr = ctx.parse_into_slot(parser, frames[f], M + f)
+        ctx.upload(M + f)
+        r = parser.refs
+        info.append((hdr.frame_type, r.new_idx, r.lst_idx, r.gld_idx, r.alt_idx, shown if hdr.show_frame else -1))
+        shown += 1 if hdr.show_frame else 0
+        parser.swap(hdr)
+    parser.close()
+    assert info[0][0] == 0 and info[k][0] == 1 and info[k + 1][0] == 1 and info[k][5] >= 0 and info[k + 1][5] >= 0
+
+    def fill(base, f):          # slot set <- frame f's IR (device-to-device copies of the master)
+        for i in range(n):
+            ctx.ir_copy(base + i, M + f)
+
+    def jobs_of(base, f):
+        ft, new, lst, gld, alt, _ = info[f]
+        jj = (P.Job * n)()
+        for i in range(n):
+            jj[i].ir_slot, jj[i].dst_fb = base + i, new * n + i
+            for q, ref in enumerate((lst, gld, alt)):
+                jj[i].ref_fb[1 + q] = ref * n + i if ft else -1
+        return jj
+
+    def mismatches(f):
+        return sum(1 for v in ctx.frames_md5(info[f][1] * n, n) if v != gold[info[f][5]])
+
+    for f in range(k):          # the streams up to frame k-1
+        fill(0, f)
+        ctx.decode_array(jobs_of(0, f), n, P.STAGE_ALL)
+    fill(0, k); fill(n, k + 1)
+    jk, jk1 = jobs_of(0, k), jobs_of(n, k + 1)
+    # the pair can be repeated when the key frame's buffer outlives it (the streams are then decoded again from frame 1)
+    if any(info[f][1] == info[0][1] for f in range(1, k + 2)):
+        reps = 1
+    t_chain, bad_chain, chained_tiles = 0.0, 0, False
+    for rep in range(reps):
+        if rep:
+            for f in range(1, k):
+                fill(0, f)
+                ctx.decode_array(jobs_of(0, f), n, P.STAGE_ALL)
+            fill(0, k)
+        ctx.sync()
+        t0 = time.perf_counter()
+        ctx.decode_array(jk, n, P.STAGE_ALL)
+        ctx.decode_array(jk1, n, P.STAGE_ALL)
+        ctx.sync()
+        t_chain += time.perf_counter() - t0
+        chained_tiles = bool(ctx.stats().pred_tiles)
+        bad_chain += mismatches(k) + mismatches(k + 1)
+    dt_chained = t_chain / (2 * reps)
+    raster_pool = ctx.memory_usage()["raster_pool"]
     ctx.close()
     gbps = B_INTER_FULL * nmb * n / dt / 1e9
     return {"workload": f"{name}.ivf frame {k} (inter: {distinct} distinct references, six-tap, normal loop filter) x {n} jobs per "
                         f"launch, each with its own IR slot, reference buffer and destination",
-            "md5_ok": bool(ok),
+            "md5_ok": bad == 0, "md5_checked": n, "md5_mismatches": bad,
             "Mpix_s": round(n * w * h / dt / 1e6, 1), "ms_per_launch": round(dt * 1e3, 3),
+            "references_read_as": "tiles" if unchained_tiles else "raster (private copies, borders extended)",
             "chained": {"ms_per_launch": round(dt_chained * 1e3, 3), "Mpix_s": round(n * w * h / dt_chained / 1e6, 1),
                         "roofline_frac": round(B_INTER_FULL * nmb * n / dt_chained / 1e9 / HBM_PEAK_GBPS, 5),
+                        "launches": f"{n} copies of the stream in lock step (own IR slots, own four frame buffers) up to frame {k - 1}; timed: "
+                                    f"frames {k} and {k + 1} of every stream, {reps} time(s) (the streams decoded again from frame 1 in between, untimed)",
+                        "md5_checked": 2 * n * reps, "md5_mismatches": bad_chain, "md5_ok": bad_chain == 0,
                         "references_read_as": "tiles (vp8_inter_pred_tiles_kernel: no tiled -> raster pass)" if chained_tiles
                                               else "raster (vp8_detile_kf_kernel + vp8_extend_kernel in front of every launch)",
-                        "note": "every launch reads the frames the previous launch wrote: n streams in lock step, what a decoder runs"},
+                        "raster_pool_bytes": raster_pool,
+                        "note": "every launch reads the frames the launch before it wrote: n streams in lock step, what a decoder runs"},
             "kernel_ms": {"recon": round(st.recon_ms, 3), "loopfilter": round(st.lf_ms, 3), "extend": round(st.extend_ms, 3)},
-            "kernel_family": ("vp8_inter_pred_kernel (every inter macroblock's six-tap prediction, order-free, into the macroblock's tile) + "
-                              "vp8_interframe_kernel (residual + loop filter, one macroblock row per lane, luma and chroma waves paired "
-                              "on every SIMD: kernel_ms.recon is both); the frames are left as tiles, and a launch that predicts from "
-                              "frames the launch before left that way (chained) reads them as tiles (vp8_inter_pred_tiles_kernel, "
-                              "round 5; through round 4 their border-extended raster form was made first)"
+            "kernel_family": ("vp8_inter_pred_kernel / vp8_inter_pred_tiles_kernel (every inter macroblock's six-tap prediction, order-free, "
+                              "into the macroblock's tile) + vp8_interframe_kernel (residual + loop filter, one macroblock row per lane, luma "
+                              "and chroma waves paired on every SIMD: kernel_ms.recon is both); the frames are left as tiles"
                               if st.fused else "one wave per macroblock row"),
             "roofline": {"bound": "hbm", "achieved": round(gbps, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(gbps / HBM_PEAK_GBPS, 5),
-                         "note": "SURVEY 8(d) full inter path 2407 B/MB x macroblocks per launch / wall time per launch"}}
+                         "note": "SURVEY 8(d) full inter path 2407 B/MB (a model of dense content) x macroblocks per launch / wall time per launch"}}
 
 
 def batch_md5_probe(fixture, device, loops=205, extra=()):
@@ -818,21 +877,29 @@ def main():
             out["config"]["batch_curve"] = curve
             # the same path on DENSE content (SURVEY 8d's noisy set: 21 of a macroblock's 24 blocks coded, 18 of them with more than
             # a first coefficient -- the byte model of `roofline` is dense, the headline stream is not): tests/golden/kf_dense_1920x1080
-            try:
-                nd = F if F <= 8192 else 8192       # (a dense slot is the full 7.8 MB: 8192 frames are 64 + 28 GB)
-                d = small_run(P, local_rank, "kf_dense_1920x1080", W, H, nd)
-                gb = (B_RECON + B_LF) * nmb * nd / (d["ms_per_launch"] * 1e-3) / 1e9
-                d["roofline_pipeline"] = {"achieved": round(gb, 2), "frac": round(gb / HBM_PEAK_GBPS, 5), "unit": "GB/s",
-                                          "note": "SURVEY 8(d) 1217 + 770 B/MB x macroblocks per launch / launch time"}
-                d["workload"] = "tests/golden/kf_dense_1920x1080.ivf (2 key frames, uniform +-16 noise, quantiser index 8..16) looped"
-                out["config"]["dense_content"] = d
-            except Exception as ex:          # noqa: BLE001
-                out["config"]["dense_content"] = {"error": repr(ex)}
+            # at the headline's launch size (a dense slot is the full 7.8 MB: 16,384 frames are 128 + 56 GB) and, as through round 5, at 8192
+            for key, nd in (("dense_content", F), ("dense_content_8192", 8192)):
+                if key != "dense_content" and nd >= F:
+                    continue
+                try:
+                    d = small_run(P, local_rank, "kf_dense_1920x1080", W, H, nd)
+                    gb = (B_RECON + B_LF) * nmb * nd / (d["ms_per_launch"] * 1e-3) / 1e9
+                    d["roofline_pipeline"] = {"achieved": round(gb, 2), "frac": round(gb / HBM_PEAK_GBPS, 5), "unit": "GB/s",
+                                              "note": "SURVEY 8(d) 1217 + 770 B/MB x macroblocks per launch / launch time"}
+                    d["workload"] = "tests/golden/kf_dense_1920x1080.ivf (2 key frames, uniform +-16 noise, quantiser index 8..16) looped"
+                    out["config"][key] = d
+                except Exception as ex:          # noqa: BLE001
+                    out["config"][key] = {"error": repr(ex)}
         if world == 1 and args.workload == "1080p" and not args.no_inter_probe:
             try:
                 out["config"]["inter_frames"] = inter_frame_probe(P, local_rank)
             except Exception as ex:      # a probe, not the benchmark: report, do not fail the line
                 out["config"]["inter_frames"] = {"error": repr(ex)}
+            # SURVEY 8(d)'s own config-3 input: the 10-frame K+P fixture (93-99 % of its P frames' macroblocks skipped, sub-pixel vectors)
+            try:
+                out["config"]["inter_frames_typical"] = inter_frame_probe(P, local_rank, name="p_1920x1080", k=5)
+            except Exception as ex:      # noqa: BLE001
+                out["config"]["inter_frames_typical"] = {"error": repr(ex)}
         if world == 1 and args.workload == "1080p" and not args.no_end_to_end:
             # host-inclusive rates (never `value`): compressed frames in host memory -> per-frame MD5.  Every probe on its own: one
             # that fails reports its error and leaves the others' results alone

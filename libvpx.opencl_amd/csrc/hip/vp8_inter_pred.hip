@@ -385,23 +385,40 @@ __device__ __forceinline__ Row8 h_pass8(u32x4 d, u32 sh, const Taps &tx)
     for (int k = 0; k < 6; k++) { a01 += P[k] * tx.t[k]; a23 += P[k + 2] * tx.t[k]; a45 += P[k + 4] * tx.t[k]; a67 += P[k + 6] * tx.t[k]; }
     return { { finish2(a01), finish2(a23) }, { finish2(a45), finish2(a67) } };
 }
-template <int NOUT, class SRC>
-__device__ __forceinline__ void strip8(const SRC &src, const Taps &tx, const Taps &ty, g_u8p dst, int s)
+// ... the same from dwords whose first byte IS the row's first pixel (the LDS-fed strips: WinGeo below normalises the rows)
+__device__ __forceinline__ Row8 h_pass8n(u32x4 d, const Taps &tx)
 {
-    // Output in 16-byte stores (8-byte ones -- 19 write requests per macroblock at the L2 instead of 6 -- cost this kernel 39 % of
-    // its time).  NOUT == 16, luma: dst = the macroblock's tile, lanes s = 0 / 1 hold the left / right half of its rows; after
-    // every second row they swap a half row (DPP), lane 0 stores the whole row y - 1 and lane 1 the whole row y.  NOUT == 8,
-    // chroma: dst = the plane's rows 0..3 (rows 4..7 64 bytes on), a lane has whole rows: two of them are one store.
-    u32x2 prev = { 0, 0 };
-    constexpr int NIN = NOUT + 5, AHEAD = IP_AHEAD < NIN ? IP_AHEAD : NIN;
+    auto asv = [](u32 v) { return __builtin_bit_cast(v2u16, v); };
+    const u32 w0 = d.x, w1 = d.y, w2 = d.z, w3 = d.w;
+    const v2u16 P[12] = { asv(perm(w0, w0, 0x0c010c00u)), asv(perm(w0, w0, 0x0c020c01u)), asv(perm(w0, w0, 0x0c030c02u)),
+                          asv(perm(w1, w0, 0x0c040c03u)), asv(perm(w1, w1, 0x0c010c00u)), asv(perm(w1, w1, 0x0c020c01u)),
+                          asv(perm(w1, w1, 0x0c030c02u)), asv(perm(w2, w1, 0x0c040c03u)), asv(perm(w2, w2, 0x0c010c00u)),
+                          asv(perm(w2, w2, 0x0c020c01u)), asv(perm(w2, w2, 0x0c030c02u)), asv(perm(w3, w2, 0x0c040c03u)) };
+    const v2u16 bias = { 64 + 8192, 64 + 8192 };
+    v2u16 a01 = bias, a23 = bias, a45 = bias, a67 = bias;
+#pragma unroll
+    for (int k = 0; k < 6; k++) { a01 += P[k] * tx.t[k]; a23 += P[k + 2] * tx.t[k]; a45 += P[k + 4] * tx.t[k]; a67 += P[k + 6] * tx.t[k]; }
+    return { { finish2(a01), finish2(a23) }, { finish2(a45), finish2(a67) } };
+}
+// What a strip eight pixels wide does with its filtered source rows, one after the other: the ring of the last six, from the sixth
+// on an output row, and the stores.  Output in 16-byte stores (8-byte ones -- 19 write requests per macroblock at the L2 instead of
+// 6 -- cost the kernel 39 % of its time).  NOUT == 16, luma: dst = the macroblock's tile, lanes s = 0 / 1 hold the left / right half of
+// its rows; after every second row they swap a half row (DPP), lane 0 stores the whole row y - 1 and lane 1 the whole row y.
+// NOUT == 8, chroma: dst = the plane's rows 0..3 (rows 4..7 64 bytes on), a lane has whole rows: two of them are one store.
+template <int NOUT>
+struct Strip8Rows {
     Row8 H[6];
-    // source row i, its pixels in d: the horizontal pass, and from the sixth row on an output row
-    auto row = [&](auto ic, const u32x4 d) {
-        constexpr int i = decltype(ic)::value;
-        H[i % 6] = h_pass8(d, src.sh, tx);
-        if constexpr (i >= 5) {
-            constexpr int y = i - 5;
-            const Row8 &h0 = H[(i + 1) % 6], &h1 = H[(i + 2) % 6], &h2 = H[(i + 3) % 6], &h3 = H[(i + 4) % 6], &h4 = H[(i + 5) % 6], &h5 = H[i % 6];
+    u32x2 prev;
+    g_u8p dst; int s;
+    __device__ __forceinline__ Strip8Rows(g_u8p dst_, int s_) : dst(dst_), s(s_) { prev = (u32x2){ 0, 0 }; }
+    // source row I, filtered horizontally
+    template <int I>
+    __device__ __forceinline__ void feed(const Row8 &h, const Taps &ty)
+    {
+        H[I % 6] = h;
+        if constexpr (I >= 5) {
+            constexpr int y = I - 5;
+            const Row8 &h0 = H[(I + 1) % 6], &h1 = H[(I + 2) % 6], &h2 = H[(I + 3) % 6], &h3 = H[(I + 4) % 6], &h4 = H[(I + 5) % 6], &h5 = H[I % 6];
             u32x2 o;
             o.x = v_pass(h0.l, h1.l, h2.l, h3.l, h4.l, h5.l, ty);
             o.y = v_pass(h0.r, h1.r, h2.r, h3.r, h4.r, h5.r, ty);
@@ -416,6 +433,17 @@ __device__ __forceinline__ void strip8(const SRC &src, const Taps &tx, const Tap
                 *(GLOBAL_AS u32x4 *)qd = (u32x4){ prev.x, prev.y, o.x, o.y };
             }
         }
+    }
+};
+template <int NOUT, class SRC>
+__device__ __forceinline__ void strip8(const SRC &src, const Taps &tx, const Taps &ty, g_u8p dst, int s)
+{
+    constexpr int NIN = NOUT + 5, AHEAD = IP_AHEAD < NIN ? IP_AHEAD : NIN;
+    Strip8Rows<NOUT> out(dst, s);
+    // source row i, its pixels in d: the horizontal pass, and from the sixth row on an output row
+    auto row = [&](auto ic, const u32x4 d) {
+        constexpr int i = decltype(ic)::value;
+        out.template feed<i>(h_pass8(d, src.sh, tx), ty);
     };
     auto rows_one_by_one = [&]() {
         typename SRC::Raw q[AHEAD];
@@ -459,6 +487,112 @@ __device__ __forceinline__ void strip8(const SRC &src, const Taps &tx, const Tap
     rows_one_by_one();
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 6: the tile reader's macroblocks with ONE motion vector fetch their source rows TOGETHER, through LDS.
+//
+// What bounded the tile reader was the number of cache lines its loads touch (TA_BUSY 85 % of the kernel, 110 vector-cache accesses
+// per macroblock against the raster reader's 54): a lane of a strip asks for 16 bytes of ONE pixel row, and the next row's 16 bytes
+// -- the same 64-byte sector of the same tile -- with the next instruction.  Here four neighbouring lanes ask for the four rows of a
+// sector with one instruction (luma: a macroblock's 21 x 21 source window is 6 sector rows x 3 tile pieces = 18 accesses where the
+// strips made 48; chroma: a sector holds four rows of BOTH planes, 12 accesses for 42), and because the lane that loads a row is
+// not the lane that filters it the rows go through LDS -- NORMALISED on the way: the loading lane picks the window's dwords out of
+// the pieces (the two-stage shifter the strips ran per row and lane), shifts them to the window's first pixel (v_alignbyte: the
+// strips' horizontal pass then needs none), replaces what lies beyond the frame's left or right edge by the edge pixel, and writes
+// 24 (chroma 16) bytes a row.  A strip's row is then one aligned LDS read at 8 s.  Rows above and below the plane are clamped row
+// indices of the loading lane, as before.  Three sector rows of 32 macroblocks x 4 rows x 32 bytes are resident per wave (12 KB:
+// three waves per SIMD still fit); the lanes of a wave are up to three rows apart in their sector rows (the windows' first rows
+// differ mod 4), so a slot is rewritten when the lanes that began earliest are done with it, and the loads for it are issued four
+// rows before that.
+//
+// The source window of ONE macroblock plane as the lane that loads it sees it: NB bytes a row from pixel X0 on, rows from y0 on.
+template <bool CHROMA>
+struct WinGeo {
+    static constexpr int LGR = CHROMA ? 3 : 4, RMASK = (1 << LGR) - 1, BOT0 = CHROMA ? 4 : 12;      // as TileSrc
+    static constexpr int PW = CHROMA ? 8 : 16, LG = CHROMA ? 3 : 4;                                    // bytes of a tile's row piece
+    static constexpr int NB = CHROMA ? 16 : 24, NDW = NB / 4;                                          // the normalised row
+    static constexpr int NPX = CHROMA ? 13 : 21;                                                       // ... and how many of its pixels the strips read
+    static constexpr int NE = CHROMA ? 6 : 9;                                                          // dwords loaded a row
+    g_cu8p rowp;            // two tiles before the first tile of the tile row the window begins in (+ 256: chroma)
+    int base4, tlo, thi;    // the window's first row floored to a multiple of four, and the plane's first / last row, all relative to that tile row
+    u32 rowbytes, colW, colB;
+    u32 a_sh;               // dword shift for window rows | for bottom rows << 2 | byte shift << 4
+    bool edge;
+    u32 edge_info;          // bytes to replace (left: the first n, right: from the n-th on) | where the edge pixel lies << 8 | left << 16
+    __device__ __forceinline__ WinGeo(g_cu8p tiles, int cols, int W, int H, int X0, int y0)
+    {
+        rowbytes = (u32)(cols + 1) * VP8_TILE_BYTES;
+        const int yc = max(0, min(y0, H - 1));
+        const int ybase = yc & ~RMASK;
+        base4 = (y0 - ybase) & ~3; tlo = -ybase; thi = H - 1 - ybase;
+        rowp = tiles + (long)(yc >> LGR) * rowbytes - 2 * VP8_TILE_BYTES;
+        // what is loaded: from xl on, at least one of the first NPX pixels inside the plane (the edge pixel has to be among the bytes
+        // the shifter delivers whole: with the vector clamps of reconinter.c:348-382 a window begins up to 21 pixels left of the frame)
+        const int xl = max(min(X0, W - 1), 1 - NPX);
+        const int xs = xl + 4;
+        colW = (u32)(((xs >> LG) + 2) * VP8_TILE_BYTES);
+        colB = (u32)(((xl >> LG) + 2) * VP8_TILE_BYTES + (CHROMA ? 64 : 0));
+        a_sh = (u32)((xs & (PW - 1)) >> 2) | ((u32)((xl & (PW - 1)) >> 2) << 2) | (((u32)xl & 3u) << 4);
+        // byte t of the normalised row is pixel X0 + t (where xl differs from X0 every byte is beyond one edge)
+        edge = X0 < 0 || X0 + NB > W;
+        const bool left = X0 < 0;
+        const int n = left ? min(NB, -X0) : max(0, W - X0);        // left: bytes [0, n) replaced; right: [n, NB)
+        const int ed = left ? -xl : W - 1 - xl;                     // where pixel 0 / W - 1 lies
+        edge_info = (u32)n | ((u32)ed << 8) | ((u32)left << 16);
+    }
+    // where row `v` (relative to the tile row, any value) lies -- the row piece of the window's first tile --, and whether it is one of
+    // the macroblock-aligned rows.  Rows above / below the plane are its first / last (vp8_extend_mb_row, vp8_yv12_extend_frame_borders).
+    // Chroma: the PAIR of rows (v, v + 1), v even -- 16 adjacent bytes; of a pair beyond the plane both rows are the plane's first
+    // (the pair's first row) resp. last (its second): first_twice / second_twice
+    __device__ __forceinline__ g_cu8p row_ptr(int v, bool &bot, bool &first_twice, bool &second_twice) const
+    {
+        int t = max(tlo, min(v, thi));
+        first_twice = CHROMA && v + 1 < tlo; second_twice = CHROMA && v > thi;
+        if constexpr (CHROMA) t &= ~1;            // (tlo is even, thi odd)
+        const u32 yy = (u32)t & RMASK;
+        bot = yy >= BOT0;
+        return rowp + (__umul24((u32)t >> LGR, rowbytes) + (bot ? colB : colW) + (CHROMA ? (yy & 3u) << 3 : yy << 4));
+    }
+    // E[0 .. NE-1]: the row's loaded dwords (luma: two pieces and the first dword of the third; chroma: three pieces) -> N: the
+    // normalised row.  any_edge: a lane of the wave has an edge in its window
+    __device__ __forceinline__ void normalise(const u32 (&E)[NE], bool bot, bool any_edge, u32 (&N)[NDW]) const
+    {
+        const u32 a = bot ? (a_sh >> 2) & 3u : a_sh & 3u, sh = a_sh >> 4;
+        u32 D[NDW + 1];
+        if constexpr (!CHROMA) {
+            // dwords a .. a + 5 of the nine (a + 6 only feeds bytes past the 21st pixel): a shifter of two stages under masks
+            const u32 m2 = (u32)__builtin_amdgcn_sbfe((int)a, 1, 1), m1 = (u32)__builtin_amdgcn_sbfe((int)a, 0, 1);
+            u32 F[NDW + 1];
+#pragma unroll
+            for (int k = 0; k < NDW + 1; k++) F[k] = (E[k + 2] & m2) | (E[k] & ~m2);
+#pragma unroll
+            for (int k = 0; k < NDW; k++) D[k] = (F[k + 1] & m1) | (F[k] & ~m1);
+            D[NDW] = 0;
+        } else {
+            const u32 m1 = (u32)-(int)a;                // (a: 0 or 1)
+#pragma unroll
+            for (int k = 0; k < NDW + 1; k++) D[k] = (E[k + 1] & m1) | (E[k] & ~m1);
+        }
+#pragma unroll
+        for (int k = 0; k < NDW; k++) N[k] = __builtin_amdgcn_alignbyte(D[k + 1], D[k], sh);
+        if (any_edge) {
+            // (the masks are made here, by the few waves that have a window at an edge, rather than kept in registers by all)
+            const int n = (int)(edge_info & 0xff), ed = (int)((edge_info >> 8) & 0xff);
+            const bool left = (edge_info >> 16) & 1;
+            const u32 spl = (u32)(ed & 7) * 0x01010101u;
+            u32 ev = 0;
+#pragma unroll
+            for (int k = 0; k < NDW / 2; k++) ev |= perm(N[2 * k + 1], N[2 * k], (ed >> 3) == k ? spl : 0x0c0c0c0cu);
+#pragma unroll
+            for (int k = 0; k < NDW; k++) {
+                const int nk = max(0, min(4, n - 4 * k));
+                const u32 low = nk >= 4 ? 0xffffffffu : (1u << (8 * nk)) - 1u;
+                const u32 em = edge ? (left ? low : ~low) : 0u;
+                N[k] = (N[k] & ~em) | (ev & em);
+            }
+        }
+    }
+};
+
 // clamp_mv_to_umv_border (reconinter.c:348-368)
 __device__ __forceinline__ void clamp_luma_mv(int &row, int &col, int e_left, int e_right, int e_top, int e_bottom)
 {
@@ -485,7 +619,9 @@ __device__ __forceinline__ void inter_pred(const DevJob *__restrict__ jobs, int 
 {
     __shared__ u32 s_w0a[4][64];
     __shared__ unsigned char s_plaina[4][64], s_splita[4][64];
+    __shared__ __attribute__((aligned(16))) u32 s_ringa[TILES ? 4 : 1][TILES ? 3072 : 4];      // (the tile reader's rows on their way from loading to filtering lanes)
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    u32 *const ring = s_ringa[TILES ? wv : 0];
     u32 *const s_w0 = s_w0a[wv];
     unsigned char *const s_plain = s_plaina[wv], *const s_split = s_splita[wv];
     const int cols = g.mb_cols, rows = g.mb_rows, nmb = cols * rows;
@@ -546,7 +682,161 @@ __device__ __forceinline__ void inter_pred(const DevJob *__restrict__ jobs, int 
         typedef std::integral_constant<int, 4> W8;      // strips eight pixels wide
         typedef std::integral_constant<int, 3> W4;      // 4x4 blocks
 
-        // ---- one motion vector: vp8_build_inter16x16_predictors_mb.  Luma: 32 macroblocks x 2 strips
+        // ---- one motion vector: vp8_build_inter16x16_predictors_mb
+        if constexpr (TILES) {
+            // the motion vector of macroblock `li` of the plain list as its luma / chroma predictor uses it
+            auto luma_mv = [&](const Mb &m, int &mrow, int &mcol) {
+                const u32 mvw = mvs[m.idx * 16];
+                mrow = sext16(mvw); mcol = hi16(mvw);
+                if ((m.w0 >> 24) & VP8IR_MB_CLAMP) clamp_luma_mv(mrow, mcol, m.e_left, m.e_right, m.e_top, m.e_bottom);
+            };
+            auto chroma_mv = [&](const Mb &m, int &mrow, int &mcol) {         // from the CLAMPED luma vector (reconinter.c:419-424)
+                luma_mv(m, mrow, mcol);
+                mrow = (short)(mrow + (1 | (mrow >> 31)));
+                mcol = (short)(mcol + (1 | (mcol >> 31)));
+                mrow /= 2; mcol /= 2;
+                if (fullpix) { mrow &= ~7; mcol &= ~7; }
+            };
+            // Luma: 32 macroblocks a pass; as a FILTERING lane: macroblock lane >> 1, strip lane & 1; as a LOADING lane, twice a sector
+            // row: macroblocks lane >> 2 and 16 + (lane >> 2), row lane & 3 of the sector.  Positions behind the list's end work on its
+            // last macroblock once more (the same bytes to the same places): no lane is ever masked.
+            // LDS (dwords): ring[slot 3][macroblock 32][row 4][8]
+            for (int i0 = 0; i0 < nP; i0 += 32) {
+                wave_lds_sync();                                // the pass before has read its last rows
+                const int s = lane & 1;
+                const Mb m = mb_of(s_plain[min(i0 + (lane >> 1), nP - 1)]);
+                int mrow, mcol;
+                luma_mv(m, mrow, mcol);
+                const Taps tx = load_taps(bil, mcol & 7), ty = load_taps(bil, mrow & 7);
+                const u32 m4 = (u32)(m.r * 16 + (mrow >> 3) - 2) & 3u;                    // the window's first row within its sector
+                const bool c1 = m4 >= 1, c2 = m4 >= 2, c3 = m4 >= 3;
+                const u32 kq[4] = { m4 * 8, ((m4 + 1) & 3) * 8, ((m4 + 2) & 3) * 8, ((m4 + 3) & 3) * 8 };
+                const u32 *const mine = ring + (lane >> 1) * 32 + 2 * s;
+                typedef WinGeo<false> Geo;
+                auto geo_of = [&](int hf) {
+                    const Mb ml = mb_of(s_plain[min(i0 + 16 * hf + (lane >> 2), nP - 1)]);
+                    int r_, c_;
+                    luma_mv(ml, r_, c_);
+                    return Geo(ml.ref, cols, g.aligned_w, g.aligned_h, ml.c * 16 + (c_ >> 3) - 2, ml.r * 16 + (r_ >> 3) - 2);
+                };
+                const Geo g0 = geo_of(0), g1 = geo_of(1);
+                const bool any_edge = __builtin_amdgcn_ballot_w64(g0.edge || g1.edge) != 0;
+                struct Raw { u32x4 a, b; u32 c; bool bot; };
+                auto issue = [&](const Geo &ge, int sr) {
+                    bool ft, st;
+                    Raw r;
+                    g_cu8p p = ge.row_ptr(ge.base4 + 4 * sr + (lane & 3), r.bot, ft, st);
+                    r.a = *(g_cu32x4p)p; r.b = *(g_cu32x4p)(p + VP8_TILE_BYTES); r.c = *(GLOBAL_AS const u32 *)(p + 2 * VP8_TILE_BYTES);
+                    return r;
+                };
+                auto land = [&](const Geo &ge, const Raw &r, int sr, int hf) {
+                    const u32 E[9] = { r.a.x, r.a.y, r.a.z, r.a.w, r.b.x, r.b.y, r.b.z, r.b.w, r.c };
+                    u32 N[6];
+                    ge.normalise(E, r.bot, any_edge, N);
+                    u32 *q = ring + (sr % 3) * 1024 + (16 * hf + (lane >> 2)) * 32 + (lane & 3) * 8;
+                    *(u32x4 *)q = (u32x4){ N[0], N[1], N[2], N[3] };
+                    *(u32x2 *)(q + 4) = (u32x2){ N[4], N[5] };
+                };
+                Raw n0, n1;
+                {   // sector rows 0..2 into the three slots (two sector rows' loads in flight at a time)
+                    Raw a0 = issue(g0, 0), a1 = issue(g1, 0), b0 = issue(g0, 1), b1 = issue(g1, 1);
+                    land(g0, a0, 0, 0); land(g1, a1, 0, 1);
+                    a0 = issue(g0, 2); a1 = issue(g1, 2);
+                    land(g0, b0, 1, 0); land(g1, b1, 1, 1);
+                    n0 = issue(g0, 3); n1 = issue(g1, 3);
+                    land(g0, a0, 2, 0); land(g1, a1, 2, 1);
+                }
+                wave_lds_sync();
+                Strip8Rows<16> out(m.tile, s);
+                static_for<21>([&](auto ic) {
+                    constexpr int I = decltype(ic)::value;
+                    if constexpr (I == 4 || I == 8 || I == 12) {
+                        // every lane is done with sector row I / 4 - 1: its slot takes sector row I / 4 + 2, whose loads were issued four
+                        // rows ago; the next one's go out
+                        wave_lds_sync();
+                        land(g0, n0, I / 4 + 2, 0); land(g1, n1, I / 4 + 2, 1);
+                        if constexpr (I < 12) { n0 = issue(g0, I / 4 + 3); n1 = issue(g1, I / 4 + 3); }
+                        wave_lds_sync();
+                    }
+                    // row I of the window: sector row (m4 + I) >> 2, row (m4 + I) & 3 of it
+                    constexpr int G = I >> 2, R = I & 3;
+                    const bool carry = R == 0 ? false : R == 1 ? c3 : R == 2 ? c2 : c1;
+                    const u32 off = carry ? ((G + 1) % 3) * 1024u : (G % 3) * 1024u;
+                    const u32 *q = mine + off + kq[R];
+                    const u32x2 lo = *(const u32x2 *)q, hi = *(const u32x2 *)(q + 2);
+                    out.template feed<I>(h_pass8n((u32x4){ lo.x, lo.y, hi.x, hi.y }, tx), ty);
+                });
+            }
+            // Chroma: 32 macroblocks a pass; filtering lane: macroblock lane >> 1, plane lane & 1; loading lane: macroblocks lane >> 2 and
+            // 16 + (lane >> 2), plane (lane >> 1) & 1, row pair lane & 1 of the sector (a sector: four rows of U, four rows of V).
+            // LDS (dwords): ring[slot 3][macroblock 32][plane 2][row 4][4]
+            for (int i0 = 0; i0 < nP; i0 += 32) {
+                wave_lds_sync();
+                const int pl = lane & 1;
+                const Mb m = mb_of(s_plain[min(i0 + (lane >> 1), nP - 1)]);
+                int mrow, mcol;
+                chroma_mv(m, mrow, mcol);
+                const Taps tx = load_taps(bil, mcol & 7), ty = load_taps(bil, mrow & 7);
+                const u32 m4 = (u32)(m.r * 8 + (mrow >> 3) - 2) & 3u;
+                const bool c1 = m4 >= 1, c2 = m4 >= 2, c3 = m4 >= 3;
+                const u32 kq[4] = { m4 * 4, ((m4 + 1) & 3) * 4, ((m4 + 2) & 3) * 4, ((m4 + 3) & 3) * 4 };
+                const u32 *const mine = ring + (lane >> 1) * 32 + pl * 16;
+                typedef WinGeo<true> Geo;
+                const int lpl = (lane >> 1) & 1, lrp = lane & 1;
+                auto geo_of = [&](int hf) {
+                    const Mb ml = mb_of(s_plain[min(i0 + 16 * hf + (lane >> 2), nP - 1)]);
+                    int r_, c_;
+                    chroma_mv(ml, r_, c_);
+                    return Geo(ml.ref + 256 + 32 * lpl, cols, g.aligned_w / 2, g.aligned_h / 2, ml.c * 8 + (c_ >> 3) - 2, ml.r * 8 + (r_ >> 3) - 2);
+                };
+                const Geo g0 = geo_of(0), g1 = geo_of(1);
+                const bool any_edge = __builtin_amdgcn_ballot_w64(g0.edge || g1.edge) != 0;
+                struct Raw { u32x4 a, b, c; bool bot, ft, st; };
+                auto issue = [&](const Geo &ge, int sr) {
+                    Raw r;
+                    g_cu8p p = ge.row_ptr(ge.base4 + 4 * sr + 2 * lrp, r.bot, r.ft, r.st);
+                    r.a = *(g_cu32x4p)p; r.b = *(g_cu32x4p)(p + VP8_TILE_BYTES); r.c = *(g_cu32x4p)(p + 2 * VP8_TILE_BYTES);
+                    return r;
+                };
+                auto land = [&](const Geo &ge, const Raw &r, int sr, int hf) {
+                    // the pair's two rows: (x, y) of every piece the first, (z, w) the second -- both the same one beyond the plane
+                    const bool hiA = r.st, loB = r.ft;
+                    const u32 EA[6] = { hiA ? r.a.z : r.a.x, hiA ? r.a.w : r.a.y, hiA ? r.b.z : r.b.x, hiA ? r.b.w : r.b.y, hiA ? r.c.z : r.c.x, hiA ? r.c.w : r.c.y };
+                    const u32 EB[6] = { loB ? r.a.x : r.a.z, loB ? r.a.y : r.a.w, loB ? r.b.x : r.b.z, loB ? r.b.y : r.b.w, loB ? r.c.x : r.c.z, loB ? r.c.y : r.c.w };
+                    u32 NA[4], NB_[4];
+                    ge.normalise(EA, r.bot, any_edge, NA);
+                    ge.normalise(EB, r.bot, any_edge, NB_);
+                    u32 *q = ring + (sr % 3) * 1024 + (16 * hf + (lane >> 2)) * 32 + lpl * 16 + lrp * 8;
+                    *(u32x4 *)q = (u32x4){ NA[0], NA[1], NA[2], NA[3] };
+                    *(u32x4 *)(q + 4) = (u32x4){ NB_[0], NB_[1], NB_[2], NB_[3] };
+                };
+                Raw n0, n1;
+                {
+                    Raw a0 = issue(g0, 0), a1 = issue(g1, 0), b0 = issue(g0, 1), b1 = issue(g1, 1);
+                    land(g0, a0, 0, 0); land(g1, a1, 0, 1);
+                    a0 = issue(g0, 2); a1 = issue(g1, 2);
+                    land(g0, b0, 1, 0); land(g1, b1, 1, 1);
+                    n0 = issue(g0, 3); n1 = issue(g1, 3);
+                    land(g0, a0, 2, 0); land(g1, a1, 2, 1);
+                }
+                wave_lds_sync();
+                Strip8Rows<8> out(m.tile + 256 + 32 * pl, 0);
+                static_for<13>([&](auto ic) {
+                    constexpr int I = decltype(ic)::value;
+                    if constexpr (I == 4) {
+                        wave_lds_sync();
+                        land(g0, n0, 3, 0); land(g1, n1, 3, 1);
+                        wave_lds_sync();
+                    }
+                    constexpr int G = I >> 2, R = I & 3;
+                    const bool carry = R == 0 ? false : R == 1 ? c3 : R == 2 ? c2 : c1;
+                    const u32 off = carry ? ((G + 1) % 3) * 1024u : (G % 3) * 1024u;
+                    const u32x4 d = *(const u32x4 *)(mine + off + kq[R]);
+                    out.template feed<I>(h_pass8n(d, tx), ty);
+                });
+            }
+        } else {
+        // Luma: 32 macroblocks x 2 strips
         for (int i0 = 0; i0 < nP; i0 += 32) {
             const int mi = i0 + (lane >> 1), s = lane & 1;
             if (mi < nP) {
@@ -574,8 +864,10 @@ __device__ __forceinline__ void inter_pred(const DevJob *__restrict__ jobs, int 
                 strip8<8>(chroma_src(W8(), m, pl, m.c * 8 + (mcol >> 3) - 2, m.r * 8 + (mrow >> 3) - 2), tx, ty, m.tile + 256 + 32 * pl, 0);
             }
         }
+        }
         // ---- SPLITMV: build_inter4x4_predictors_mb, a 4x4 block per lane (partitions of 8x8 / 16x8 / 8x16 carry their MV in every
         // block they cover: the filters are the same per pixel).  Luma: 4 macroblocks x 16 blocks
+#ifndef IP_NOSPLIT        // (diagnostic builds: what the kernels need without the SPLITMV paths)
         for (int i0 = 0; i0 < nS; i0 += 4) {
             const int mi = i0 + (lane >> 4), b = lane & 15;
             if (mi < nS) {
@@ -609,6 +901,7 @@ __device__ __forceinline__ void inter_pred(const DevJob *__restrict__ jobs, int 
                          m.tile + 256 + 32 * pl + 64 * (blk >> 1) + 4 * (blk & 1), 8, 0);
             }
         }
+#endif
     }
 }
 
