@@ -417,24 +417,49 @@ struct Strip8Rows {
     {
         H[I % 6] = h;
         if constexpr (I >= 5) {
-            constexpr int y = I - 5;
             const Row8 &h0 = H[(I + 1) % 6], &h1 = H[(I + 2) % 6], &h2 = H[(I + 3) % 6], &h3 = H[(I + 4) % 6], &h4 = H[(I + 5) % 6], &h5 = H[I % 6];
             u32x2 o;
             o.x = v_pass(h0.l, h1.l, h2.l, h3.l, h4.l, h5.l, ty);
             o.y = v_pass(h0.r, h1.r, h2.r, h3.r, h4.r, h5.r, ty);
-            if constexpr (!(y & 1)) prev = o;
-            else if constexpr (NOUT == 16) {
-                const u32x2 give = s ? prev : o;
-                const u32 tx_ = dpp_xor1(give.x), ty_ = dpp_xor1(give.y);
-                const u32x4 v = s ? (u32x4){ tx_, ty_, o.x, o.y } : (u32x4){ prev.x, prev.y, tx_, ty_ };
-                *(GLOBAL_AS u32x4 *)(dst + 16 * (y - 1 + s)) = v;
-            } else {
-                g_u8p qd = y - 1 >= 4 ? dst + 64 + 8 * (y - 1 - 4) : dst + 8 * (y - 1);
-                *(GLOBAL_AS u32x4 *)qd = (u32x4){ prev.x, prev.y, o.x, o.y };
-            }
+            emit<I - 5>(o);
+        }
+    }
+    // output row y of the strip, eight pixels
+    template <int y>
+    __device__ __forceinline__ void emit(const u32x2 o)
+    {
+        if constexpr (!(y & 1)) prev = o;
+        else if constexpr (NOUT == 16) {
+            const u32x2 give = s ? prev : o;
+            const u32 tx_ = dpp_xor1(give.x), ty_ = dpp_xor1(give.y);
+            const u32x4 v = s ? (u32x4){ tx_, ty_, o.x, o.y } : (u32x4){ prev.x, prev.y, tx_, ty_ };
+            *(GLOBAL_AS u32x4 *)(dst + 16 * (y - 1 + s)) = v;
+        } else {
+            g_u8p qd = y - 1 >= 4 ? dst + 64 + 8 * (y - 1 - 4) : dst + 8 * (y - 1);
+            *(GLOBAL_AS u32x4 *)qd = (u32x4){ prev.x, prev.y, o.x, o.y };
         }
     }
 };
+// A strip of a macroblock whose motion vector has no fraction: the reference copies (vp8_copy_mem16x16 / vp8_copy_mem8x8,
+// reconinter.c:22-110, chosen at :402-417 by `mv.as_int & 0x00070007`) where its filters would multiply by {0, 0, 128, 0, 0, 0} --
+// sixteen (eight) rows in, no halo, no arithmetic.  src = the strip's first pixel in a raster plane.
+template <int NOUT>
+__device__ __forceinline__ void copy_strip8(g_cu8p src, int stride, g_u8p dst, int s)
+{
+    const u32 sh = (u32)(unsigned long)src & 3u;
+    g_cu8p rp = src - sh;
+    constexpr int AHEAD = 8;
+    u32x3 q[AHEAD];
+#pragma unroll
+    for (int y = 0; y < AHEAD; y++) q[y] = *(GLOBAL_AS const u32x3 *)(rp + (long)y * stride);
+    Strip8Rows<NOUT> out(dst, s);
+    static_for<NOUT>([&](auto ic) {
+        constexpr int y = decltype(ic)::value;
+        const u32x3 d = q[y % AHEAD];
+        if constexpr (y + AHEAD < NOUT) q[y % AHEAD] = *(GLOBAL_AS const u32x3 *)(rp + (long)(y + AHEAD) * stride);
+        out.template emit<y>((u32x2){ __builtin_amdgcn_alignbyte(d.y, d.x, sh), __builtin_amdgcn_alignbyte(d.z, d.y, sh) });
+    });
+}
 template <int NOUT, class SRC>
 __device__ __forceinline__ void strip8(const SRC &src, const Taps &tx, const Taps &ty, g_u8p dst, int s)
 {
@@ -617,13 +642,16 @@ __device__ __forceinline__ void clamp_chroma_mv(int &row, int &col, int e_left, 
 template <bool TILES>
 __device__ __forceinline__ void inter_pred(const DevJob *__restrict__ jobs, int njobs, DevGeom g, int upf)
 {
-    __shared__ u32 s_w0a[4][64];
-    __shared__ unsigned char s_plaina[4][64], s_splita[4][64];
+    __shared__ u32 s_w0a[4][64], s_rca[4][64], s_mva[4][64], s_cmva[4][64];
+    __shared__ unsigned char s_lista[4][5][64];
     __shared__ __attribute__((aligned(16))) u32 s_ringa[TILES ? 4 : 1][TILES ? 3072 : 4];      // (the tile reader's rows on their way from loading to filtering lanes)
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     u32 *const ring = s_ringa[TILES ? wv : 0];
-    u32 *const s_w0 = s_w0a[wv];
-    unsigned char *const s_plain = s_plaina[wv], *const s_split = s_splita[wv];
+    u32 *const s_w0 = s_w0a[wv], *const s_rc = s_rca[wv], *const s_mv = s_mva[wv], *const s_cmv = s_cmva[wv];
+    // the unit's macroblocks by what their prediction takes: one vector with a fraction / without one (luma), the same for the chroma
+    // vector derived from it, SPLITMV
+    unsigned char *const s_plain = s_lista[wv][0], *const s_whole = s_lista[wv][1], *const s_cplain = s_lista[wv][2],
+                  *const s_cwhole = s_lista[wv][3], *const s_split = s_lista[wv][4];
     const int cols = g.mb_cols, rows = g.mb_rows, nmb = cols * rows;
     const long nunits = (long)njobs * upf;
     for (long unit = (long)blockIdx.x * 4 + wv; unit < nunits; unit += (long)gridDim.x * 4) {
@@ -638,21 +666,63 @@ __device__ __forceinline__ void inter_pred(const DevJob *__restrict__ jobs, int 
         const u32 w0_l = mb_l < nmb ? mbs[(long)mb_l * VP8IR_MBX_WORDS] : 0u;
         const bool inter_l = ((w0_l >> 16) & 0xff) != VP8IR_INTRA_FRAME;
         const bool split_l = inter_l && (w0_l & 0xff) == VP8IR_SPLITMV;
-        const unsigned long long balP = __builtin_amdgcn_ballot_w64(inter_l && !split_l), balS = __builtin_amdgcn_ballot_w64(split_l);
-        const int nP = __builtin_popcountll(balP), nS = __builtin_popcountll(balS);
+        const bool one_l = inter_l && !split_l;
+        // Per macroblock of the unit, ONCE (the passes below look a macroblock up several times, the tile reader as filtering and as
+        // loading lane): its row and column (a division), and -- one motion vector -- that vector as the luma predictor uses it
+        // (clamp_mv_to_umv_border, reconinter.c:348-368, where the macroblock is flagged) and as the chroma predictor does
+        // (reconinter.c:419-424: from the CLAMPED luma vector, rounded away from zero, halved; whole pixels in version 3)
+        const int r_l = mb_l / cols, c_l = mb_l - r_l * cols;
+        u32 mv_l = 0, cmv_l = 0;
+        bool whole_l = false, cwhole_l = false;
+        if (one_l) {
+            const u32 mvw = mvs[(long)mb_l * 16];
+            int mrow = sext16(mvw), mcol = hi16(mvw);
+            if ((w0_l >> 24) & VP8IR_MB_CLAMP)
+                clamp_luma_mv(mrow, mcol, -((c_l * 16) << 3), ((cols - 1 - c_l) * 16) << 3, -((r_l * 16) << 3), ((rows - 1 - r_l) * 16) << 3);
+            mv_l = ((u32)mrow & 0xffffu) | ((u32)mcol << 16);
+#ifndef IP_NOCOPY         // (diagnostic builds: every macroblock through the filters, as through round 5)
+            whole_l = ((mrow | mcol) & 7) == 0;                 // vp8_build_inter16x16_predictors_mb: `mv.as_int & 0x00070007`
+#endif
+            mrow = (short)(mrow + (1 | (mrow >> 31)));
+            mcol = (short)(mcol + (1 | (mcol >> 31)));
+            mrow /= 2; mcol /= 2;
+            if (fullpix) { mrow &= ~7; mcol &= ~7; }
+            cmv_l = ((u32)mrow & 0xffffu) | ((u32)mcol << 16);
+#ifndef IP_NOCOPY
+            cwhole_l = ((mrow | mcol) & 7) == 0;
+#endif
+        }
+        const bool is_l[5] = { one_l && !whole_l, one_l && whole_l, one_l && !cwhole_l, one_l && cwhole_l, split_l };
+        unsigned long long bal[5];
+        int cnt[5];
+#pragma unroll
+        for (int k = 0; k < 5; k++) { bal[k] = __builtin_amdgcn_ballot_w64(is_l[k]); cnt[k] = __builtin_popcountll(bal[k]); }
         wave_lds_sync();                                    // the previous unit's readers are done
         s_w0[lane] = w0_l;
-        if (inter_l && !split_l) s_plain[__builtin_amdgcn_mbcnt_hi((u32)(balP >> 32), __builtin_amdgcn_mbcnt_lo((u32)balP, 0u))] = (unsigned char)lane;
-        if (split_l) s_split[__builtin_amdgcn_mbcnt_hi((u32)(balS >> 32), __builtin_amdgcn_mbcnt_lo((u32)balS, 0u))] = (unsigned char)lane;
+        s_rc[lane] = ((u32)r_l << 16) | (u32)c_l;
+        s_mv[lane] = mv_l; s_cmv[lane] = cmv_l;
+#pragma unroll
+        for (int k = 0; k < 5; k++)
+            if (is_l[k]) s_lista[wv][k][__builtin_amdgcn_mbcnt_hi((u32)(bal[k] >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal[k], 0u))] = (unsigned char)lane;
+        wave_lds_sync();
+        // What is left of the whole-pixel lists behind their last full pass of 32 fills the free places of the filtered lists' last pass
+        // -- taps {0, 0, 128, 0, 0, 0} give the same pixels, as the reference's C filters would (filter.c:95-128; through round 5 every
+        // macroblock went that way) -- and only what does not fit there makes a (short, cheap) copy pass of its own.
+        const int mvW = min(cnt[1] & 31, -cnt[0] & 31), mvC = min(cnt[3] & 31, -cnt[2] & 31);
+        const int nW = cnt[1] - mvW, nCW = cnt[3] - mvC, nP = cnt[0] + mvW, nCP = cnt[2] + mvC, nS = cnt[4];
+        if (lane < mvW) s_plain[cnt[0] + lane] = s_whole[nW + lane];
+        if (lane < mvC) s_cplain[cnt[2] + lane] = s_cwhole[nCW + lane];
         wave_lds_sync();
 
-        // what a lane needs to know about macroblock `li` of the unit
-        struct Mb { int r, c; u32 w0; long idx; int e_left, e_right, e_top, e_bottom; g_cu8p ref; g_u8p tile; };
+        // what a lane needs to know about macroblock `li` of the unit (mrow / mcol, crow / ccol: its one vector, luma / chroma form)
+        struct Mb { int r, c; u32 w0; int mrow, mcol, crow, ccol; long idx; int e_left, e_right, e_top, e_bottom; g_cu8p ref; g_u8p tile; };
         auto mb_of = [&](int li) {
             Mb m;
             m.idx = (long)u * 64 + li;
-            m.r = (int)(m.idx / cols); m.c = (int)(m.idx - (long)m.r * cols);
+            const u32 rc = s_rc[li], mv = s_mv[li], cmv = s_cmv[li];
+            m.r = (int)(rc >> 16); m.c = (int)(rc & 0xffffu);
             m.w0 = s_w0[li];
+            m.mrow = sext16(mv); m.mcol = hi16(mv); m.crow = sext16(cmv); m.ccol = hi16(cmv);
             m.e_left = -((m.c * 16) << 3); m.e_right = ((cols - 1 - m.c) * 16) << 3;
             m.e_top = -((m.r * 16) << 3); m.e_bottom = ((rows - 1 - m.r) * 16) << 3;
             const int rf = (m.w0 >> 16) & 3;
@@ -684,186 +754,189 @@ __device__ __forceinline__ void inter_pred(const DevJob *__restrict__ jobs, int 
 
         // ---- one motion vector: vp8_build_inter16x16_predictors_mb
         if constexpr (TILES) {
-            // the motion vector of macroblock `li` of the plain list as its luma / chroma predictor uses it
-            auto luma_mv = [&](const Mb &m, int &mrow, int &mcol) {
-                const u32 mvw = mvs[m.idx * 16];
-                mrow = sext16(mvw); mcol = hi16(mvw);
-                if ((m.w0 >> 24) & VP8IR_MB_CLAMP) clamp_luma_mv(mrow, mcol, m.e_left, m.e_right, m.e_top, m.e_bottom);
-            };
-            auto chroma_mv = [&](const Mb &m, int &mrow, int &mcol) {         // from the CLAMPED luma vector (reconinter.c:419-424)
-                luma_mv(m, mrow, mcol);
-                mrow = (short)(mrow + (1 | (mrow >> 31)));
-                mcol = (short)(mcol + (1 | (mcol >> 31)));
-                mrow /= 2; mcol /= 2;
-                if (fullpix) { mrow &= ~7; mcol &= ~7; }
-            };
             // Luma: 32 macroblocks a pass; as a FILTERING lane: macroblock lane >> 1, strip lane & 1; as a LOADING lane, twice a sector
             // row: macroblocks lane >> 2 and 16 + (lane >> 2), row lane & 3 of the sector.  Positions behind the list's end work on its
             // last macroblock once more (the same bytes to the same places): no lane is ever masked.
             // LDS (dwords): ring[slot 3][macroblock 32][row 4][8]
-            for (int i0 = 0; i0 < nP; i0 += 32) {
-                wave_lds_sync();                                // the pass before has read its last rows
-                const int s = lane & 1;
-                const Mb m = mb_of(s_plain[min(i0 + (lane >> 1), nP - 1)]);
-                int mrow, mcol;
-                luma_mv(m, mrow, mcol);
-                const Taps tx = load_taps(bil, mcol & 7), ty = load_taps(bil, mrow & 7);
-                const u32 m4 = (u32)(m.r * 16 + (mrow >> 3) - 2) & 3u;                    // the window's first row within its sector
-                const bool c1 = m4 >= 1, c2 = m4 >= 2, c3 = m4 >= 3;
-                const u32 kq[4] = { m4 * 8, ((m4 + 1) & 3) * 8, ((m4 + 2) & 3) * 8, ((m4 + 3) & 3) * 8 };
-                const u32 *const mine = ring + (lane >> 1) * 32 + 2 * s;
-                typedef WinGeo<false> Geo;
-                auto geo_of = [&](int hf) {
-                    const Mb ml = mb_of(s_plain[min(i0 + 16 * hf + (lane >> 2), nP - 1)]);
-                    int r_, c_;
-                    luma_mv(ml, r_, c_);
-                    return Geo(ml.ref, cols, g.aligned_w, g.aligned_h, ml.c * 16 + (c_ >> 3) - 2, ml.r * 16 + (r_ >> 3) - 2);
-                };
-                const Geo g0 = geo_of(0), g1 = geo_of(1);
-                const bool any_edge = __builtin_amdgcn_ballot_w64(g0.edge || g1.edge) != 0;
-                struct Raw { u32x4 a, b; u32 c; bool bot; };
-                auto issue = [&](const Geo &ge, int sr) {
-                    bool ft, st;
-                    Raw r;
-                    g_cu8p p = ge.row_ptr(ge.base4 + 4 * sr + (lane & 3), r.bot, ft, st);
-                    r.a = *(g_cu32x4p)p; r.b = *(g_cu32x4p)(p + VP8_TILE_BYTES); r.c = *(GLOBAL_AS const u32 *)(p + 2 * VP8_TILE_BYTES);
-                    return r;
-                };
-                auto land = [&](const Geo &ge, const Raw &r, int sr, int hf) {
-                    const u32 E[9] = { r.a.x, r.a.y, r.a.z, r.a.w, r.b.x, r.b.y, r.b.z, r.b.w, r.c };
-                    u32 N[6];
-                    ge.normalise(E, r.bot, any_edge, N);
-                    u32 *q = ring + (sr % 3) * 1024 + (16 * hf + (lane >> 2)) * 32 + (lane & 3) * 8;
-                    *(u32x4 *)q = (u32x4){ N[0], N[1], N[2], N[3] };
-                    *(u32x2 *)(q + 4) = (u32x2){ N[4], N[5] };
-                };
-                Raw n0, n1;
-                {   // sector rows 0..2 into the three slots (two sector rows' loads in flight at a time)
-                    Raw a0 = issue(g0, 0), a1 = issue(g1, 0), b0 = issue(g0, 1), b1 = issue(g1, 1);
-                    land(g0, a0, 0, 0); land(g1, a1, 0, 1);
-                    a0 = issue(g0, 2); a1 = issue(g1, 2);
-                    land(g0, b0, 1, 0); land(g1, b1, 1, 1);
-                    n0 = issue(g0, 3); n1 = issue(g1, 3);
-                    land(g0, a0, 2, 0); land(g1, a1, 2, 1);
-                }
-                wave_lds_sync();
-                Strip8Rows<16> out(m.tile, s);
-                static_for<21>([&](auto ic) {
-                    constexpr int I = decltype(ic)::value;
-                    if constexpr (I == 4 || I == 8 || I == 12) {
-                        // every lane is done with sector row I / 4 - 1: its slot takes sector row I / 4 + 2, whose loads were issued four
-                        // rows ago; the next one's go out
-                        wave_lds_sync();
-                        land(g0, n0, I / 4 + 2, 0); land(g1, n1, I / 4 + 2, 1);
-                        if constexpr (I < 12) { n0 = issue(g0, I / 4 + 3); n1 = issue(g1, I / 4 + 3); }
-                        wave_lds_sync();
+            // COPY: the list of the vectors without a fraction -- the same windows (their halo rows and columns loaded for nothing: the
+            // loader is one code path), but a filtering lane takes rows 2..17 from byte 2 on as they are.
+            auto luma_pass = [&](const unsigned char *list, const int n, const bool COPY /* wave-uniform: ONE body -- the kernel has to stay inside the instruction cache */) {
+                for (int i0 = 0; i0 < n; i0 += 32) {
+                    wave_lds_sync();                                // the pass before has read its last rows
+                    const int s = lane & 1;
+                    const Mb m = mb_of(list[min(i0 + (lane >> 1), n - 1)]);
+                    const Taps tx = load_taps(bil, COPY ? 0 : m.mcol & 7), ty = load_taps(bil, COPY ? 0 : m.mrow & 7);
+                    const u32 m4 = (u32)(m.r * 16 + (m.mrow >> 3) - 2) & 3u;                    // the window's first row within its sector
+                    const bool c1 = m4 >= 1, c2 = m4 >= 2, c3 = m4 >= 3;
+                    const u32 kq[4] = { m4 * 8, ((m4 + 1) & 3) * 8, ((m4 + 2) & 3) * 8, ((m4 + 3) & 3) * 8 };
+                    const u32 *const mine = ring + (lane >> 1) * 32 + 2 * s;
+                    typedef WinGeo<false> Geo;
+                    auto geo_of = [&](int hf) {
+                        const Mb ml = mb_of(list[min(i0 + 16 * hf + (lane >> 2), n - 1)]);
+                        return Geo(ml.ref, cols, g.aligned_w, g.aligned_h, ml.c * 16 + (ml.mcol >> 3) - 2, ml.r * 16 + (ml.mrow >> 3) - 2);
+                    };
+                    const Geo g0 = geo_of(0), g1 = geo_of(1);
+                    const bool any_edge = __builtin_amdgcn_ballot_w64(g0.edge || g1.edge) != 0;
+                    struct Raw { u32x4 a, b; u32 c; bool bot; };
+                    auto issue = [&](const Geo &ge, int sr) {
+                        bool ft, st;
+                        Raw r;
+                        g_cu8p p = ge.row_ptr(ge.base4 + 4 * sr + (lane & 3), r.bot, ft, st);
+                        r.a = *(g_cu32x4p)p; r.b = *(g_cu32x4p)(p + VP8_TILE_BYTES); r.c = *(GLOBAL_AS const u32 *)(p + 2 * VP8_TILE_BYTES);
+                        return r;
+                    };
+                    auto land = [&](const Geo &ge, const Raw &r, int sr, int hf) {
+                        const u32 E[9] = { r.a.x, r.a.y, r.a.z, r.a.w, r.b.x, r.b.y, r.b.z, r.b.w, r.c };
+                        u32 N[6];
+                        ge.normalise(E, r.bot, any_edge, N);
+                        u32 *q = ring + (sr % 3) * 1024 + (16 * hf + (lane >> 2)) * 32 + (lane & 3) * 8;
+                        *(u32x4 *)q = (u32x4){ N[0], N[1], N[2], N[3] };
+                        *(u32x2 *)(q + 4) = (u32x2){ N[4], N[5] };
+                    };
+                    Raw n0, n1;
+                    {   // sector rows 0..2 into the three slots (two sector rows' loads in flight at a time)
+                        Raw a0 = issue(g0, 0), a1 = issue(g1, 0), b0 = issue(g0, 1), b1 = issue(g1, 1);
+                        land(g0, a0, 0, 0); land(g1, a1, 0, 1);
+                        a0 = issue(g0, 2); a1 = issue(g1, 2);
+                        land(g0, b0, 1, 0); land(g1, b1, 1, 1);
+                        n0 = issue(g0, 3); n1 = issue(g1, 3);
+                        land(g0, a0, 2, 0); land(g1, a1, 2, 1);
                     }
-                    // row I of the window: sector row (m4 + I) >> 2, row (m4 + I) & 3 of it
-                    constexpr int G = I >> 2, R = I & 3;
-                    const bool carry = R == 0 ? false : R == 1 ? c3 : R == 2 ? c2 : c1;
-                    const u32 off = carry ? ((G + 1) % 3) * 1024u : (G % 3) * 1024u;
-                    const u32 *q = mine + off + kq[R];
-                    const u32x2 lo = *(const u32x2 *)q, hi = *(const u32x2 *)(q + 2);
-                    out.template feed<I>(h_pass8n((u32x4){ lo.x, lo.y, hi.x, hi.y }, tx), ty);
-                });
-            }
+                    wave_lds_sync();
+                    Strip8Rows<16> out(m.tile, s);
+                    static_for<21>([&](auto ic) {
+                        constexpr int I = decltype(ic)::value;
+                        if constexpr (I == 4 || I == 8 || I == 12) {
+                            // every lane is done with sector row I / 4 - 1: its slot takes sector row I / 4 + 2, whose loads were issued four
+                            // rows ago; the next one's go out
+                            wave_lds_sync();
+                            land(g0, n0, I / 4 + 2, 0); land(g1, n1, I / 4 + 2, 1);
+                            if constexpr (I < 12) { n0 = issue(g0, I / 4 + 3); n1 = issue(g1, I / 4 + 3); }
+                            wave_lds_sync();
+                        }
+                        // row I of the window: sector row (m4 + I) >> 2, row (m4 + I) & 3 of it
+                        constexpr int G = I >> 2, R = I & 3;
+                        const bool carry = R == 0 ? false : R == 1 ? c3 : R == 2 ? c2 : c1;
+                        const u32 off = carry ? ((G + 1) % 3) * 1024u : (G % 3) * 1024u;
+                        const u32 *q = mine + off + kq[R];
+                        const u32x2 lo = *(const u32x2 *)q, hi = *(const u32x2 *)(q + 2);
+                        if (!COPY) out.template feed<I>(h_pass8n((u32x4){ lo.x, lo.y, hi.x, hi.y }, tx), ty);
+                        else if constexpr (I >= 2 && I < 18)
+                            out.template emit<I - 2>((u32x2){ __builtin_amdgcn_alignbyte(lo.y, lo.x, 2), __builtin_amdgcn_alignbyte(hi.x, lo.y, 2) });
+                    });
+                }
+            };
             // Chroma: 32 macroblocks a pass; filtering lane: macroblock lane >> 1, plane lane & 1; loading lane: macroblocks lane >> 2 and
             // 16 + (lane >> 2), plane (lane >> 1) & 1, row pair lane & 1 of the sector (a sector: four rows of U, four rows of V).
             // LDS (dwords): ring[slot 3][macroblock 32][plane 2][row 4][4]
-            for (int i0 = 0; i0 < nP; i0 += 32) {
-                wave_lds_sync();
-                const int pl = lane & 1;
-                const Mb m = mb_of(s_plain[min(i0 + (lane >> 1), nP - 1)]);
-                int mrow, mcol;
-                chroma_mv(m, mrow, mcol);
-                const Taps tx = load_taps(bil, mcol & 7), ty = load_taps(bil, mrow & 7);
-                const u32 m4 = (u32)(m.r * 8 + (mrow >> 3) - 2) & 3u;
-                const bool c1 = m4 >= 1, c2 = m4 >= 2, c3 = m4 >= 3;
-                const u32 kq[4] = { m4 * 4, ((m4 + 1) & 3) * 4, ((m4 + 2) & 3) * 4, ((m4 + 3) & 3) * 4 };
-                const u32 *const mine = ring + (lane >> 1) * 32 + pl * 16;
-                typedef WinGeo<true> Geo;
-                const int lpl = (lane >> 1) & 1, lrp = lane & 1;
-                auto geo_of = [&](int hf) {
-                    const Mb ml = mb_of(s_plain[min(i0 + 16 * hf + (lane >> 2), nP - 1)]);
-                    int r_, c_;
-                    chroma_mv(ml, r_, c_);
-                    return Geo(ml.ref + 256 + 32 * lpl, cols, g.aligned_w / 2, g.aligned_h / 2, ml.c * 8 + (c_ >> 3) - 2, ml.r * 8 + (r_ >> 3) - 2);
-                };
-                const Geo g0 = geo_of(0), g1 = geo_of(1);
-                const bool any_edge = __builtin_amdgcn_ballot_w64(g0.edge || g1.edge) != 0;
-                struct Raw { u32x4 a, b, c; bool bot, ft, st; };
-                auto issue = [&](const Geo &ge, int sr) {
-                    Raw r;
-                    g_cu8p p = ge.row_ptr(ge.base4 + 4 * sr + 2 * lrp, r.bot, r.ft, r.st);
-                    r.a = *(g_cu32x4p)p; r.b = *(g_cu32x4p)(p + VP8_TILE_BYTES); r.c = *(g_cu32x4p)(p + 2 * VP8_TILE_BYTES);
-                    return r;
-                };
-                auto land = [&](const Geo &ge, const Raw &r, int sr, int hf) {
-                    // the pair's two rows: (x, y) of every piece the first, (z, w) the second -- both the same one beyond the plane
-                    const bool hiA = r.st, loB = r.ft;
-                    const u32 EA[6] = { hiA ? r.a.z : r.a.x, hiA ? r.a.w : r.a.y, hiA ? r.b.z : r.b.x, hiA ? r.b.w : r.b.y, hiA ? r.c.z : r.c.x, hiA ? r.c.w : r.c.y };
-                    const u32 EB[6] = { loB ? r.a.x : r.a.z, loB ? r.a.y : r.a.w, loB ? r.b.x : r.b.z, loB ? r.b.y : r.b.w, loB ? r.c.x : r.c.z, loB ? r.c.y : r.c.w };
-                    u32 NA[4], NB_[4];
-                    ge.normalise(EA, r.bot, any_edge, NA);
-                    ge.normalise(EB, r.bot, any_edge, NB_);
-                    u32 *q = ring + (sr % 3) * 1024 + (16 * hf + (lane >> 2)) * 32 + lpl * 16 + lrp * 8;
-                    *(u32x4 *)q = (u32x4){ NA[0], NA[1], NA[2], NA[3] };
-                    *(u32x4 *)(q + 4) = (u32x4){ NB_[0], NB_[1], NB_[2], NB_[3] };
-                };
-                Raw n0, n1;
-                {
-                    Raw a0 = issue(g0, 0), a1 = issue(g1, 0), b0 = issue(g0, 1), b1 = issue(g1, 1);
-                    land(g0, a0, 0, 0); land(g1, a1, 0, 1);
-                    a0 = issue(g0, 2); a1 = issue(g1, 2);
-                    land(g0, b0, 1, 0); land(g1, b1, 1, 1);
-                    n0 = issue(g0, 3); n1 = issue(g1, 3);
-                    land(g0, a0, 2, 0); land(g1, a1, 2, 1);
-                }
-                wave_lds_sync();
-                Strip8Rows<8> out(m.tile + 256 + 32 * pl, 0);
-                static_for<13>([&](auto ic) {
-                    constexpr int I = decltype(ic)::value;
-                    if constexpr (I == 4) {
-                        wave_lds_sync();
-                        land(g0, n0, 3, 0); land(g1, n1, 3, 1);
-                        wave_lds_sync();
+            auto chroma_pass = [&](const unsigned char *list, const int n, const bool COPY) {
+                for (int i0 = 0; i0 < n; i0 += 32) {
+                    wave_lds_sync();
+                    const int pl = lane & 1;
+                    const Mb m = mb_of(list[min(i0 + (lane >> 1), n - 1)]);
+                    const Taps tx = load_taps(bil, COPY ? 0 : m.ccol & 7), ty = load_taps(bil, COPY ? 0 : m.crow & 7);
+                    const u32 m4 = (u32)(m.r * 8 + (m.crow >> 3) - 2) & 3u;
+                    const bool c1 = m4 >= 1, c2 = m4 >= 2, c3 = m4 >= 3;
+                    const u32 kq[4] = { m4 * 4, ((m4 + 1) & 3) * 4, ((m4 + 2) & 3) * 4, ((m4 + 3) & 3) * 4 };
+                    const u32 *const mine = ring + (lane >> 1) * 32 + pl * 16;
+                    typedef WinGeo<true> Geo;
+                    const int lpl = (lane >> 1) & 1, lrp = lane & 1;
+                    auto geo_of = [&](int hf) {
+                        const Mb ml = mb_of(list[min(i0 + 16 * hf + (lane >> 2), n - 1)]);
+                        return Geo(ml.ref + 256 + 32 * lpl, cols, g.aligned_w / 2, g.aligned_h / 2, ml.c * 8 + (ml.ccol >> 3) - 2, ml.r * 8 + (ml.crow >> 3) - 2);
+                    };
+                    const Geo g0 = geo_of(0), g1 = geo_of(1);
+                    const bool any_edge = __builtin_amdgcn_ballot_w64(g0.edge || g1.edge) != 0;
+                    // (a lane of the wave loads rows above or below the plane: only then are a pair's rows anything but its two halves)
+                    const bool any_yedge = __builtin_amdgcn_ballot_w64(g0.base4 < g0.tlo || g0.base4 + 15 > g0.thi || g1.base4 < g1.tlo || g1.base4 + 15 > g1.thi) != 0;
+                    struct Raw { u32x4 a, b, c; bool bot, ft, st; };
+                    auto issue = [&](const Geo &ge, int sr) {
+                        Raw r;
+                        g_cu8p p = ge.row_ptr(ge.base4 + 4 * sr + 2 * lrp, r.bot, r.ft, r.st);
+                        r.a = *(g_cu32x4p)p; r.b = *(g_cu32x4p)(p + VP8_TILE_BYTES); r.c = *(g_cu32x4p)(p + 2 * VP8_TILE_BYTES);
+                        return r;
+                    };
+                    auto land = [&](const Geo &ge, const Raw &r, int sr, int hf) {
+                        // the pair's two rows: (x, y) of every piece the first, (z, w) the second -- both the same one beyond the plane
+                        u32 EA[6] = { r.a.x, r.a.y, r.b.x, r.b.y, r.c.x, r.c.y }, EB[6] = { r.a.z, r.a.w, r.b.z, r.b.w, r.c.z, r.c.w };
+                        if (any_yedge) {
+#pragma unroll
+                            for (int k = 0; k < 6; k++) { const u32 lo = EA[k], hi = EB[k]; EA[k] = r.st ? hi : lo; EB[k] = r.ft ? lo : hi; }
+                        }
+                        u32 NA[4], NB_[4];
+                        ge.normalise(EA, r.bot, any_edge, NA);
+                        ge.normalise(EB, r.bot, any_edge, NB_);
+                        u32 *q = ring + (sr % 3) * 1024 + (16 * hf + (lane >> 2)) * 32 + lpl * 16 + lrp * 8;
+                        *(u32x4 *)q = (u32x4){ NA[0], NA[1], NA[2], NA[3] };
+                        *(u32x4 *)(q + 4) = (u32x4){ NB_[0], NB_[1], NB_[2], NB_[3] };
+                    };
+                    Raw n0, n1;
+                    {
+                        Raw a0 = issue(g0, 0), a1 = issue(g1, 0), b0 = issue(g0, 1), b1 = issue(g1, 1);
+                        land(g0, a0, 0, 0); land(g1, a1, 0, 1);
+                        a0 = issue(g0, 2); a1 = issue(g1, 2);
+                        land(g0, b0, 1, 0); land(g1, b1, 1, 1);
+                        n0 = issue(g0, 3); n1 = issue(g1, 3);
+                        land(g0, a0, 2, 0); land(g1, a1, 2, 1);
                     }
-                    constexpr int G = I >> 2, R = I & 3;
-                    const bool carry = R == 0 ? false : R == 1 ? c3 : R == 2 ? c2 : c1;
-                    const u32 off = carry ? ((G + 1) % 3) * 1024u : (G % 3) * 1024u;
-                    const u32x4 d = *(const u32x4 *)(mine + off + kq[R]);
-                    out.template feed<I>(h_pass8n(d, tx), ty);
-                });
-            }
+                    wave_lds_sync();
+                    Strip8Rows<8> out(m.tile + 256 + 32 * pl, 0);
+                    static_for<13>([&](auto ic) {
+                        constexpr int I = decltype(ic)::value;
+                        if constexpr (I == 4) {
+                            wave_lds_sync();
+                            land(g0, n0, 3, 0); land(g1, n1, 3, 1);
+                            wave_lds_sync();
+                        }
+                        constexpr int G = I >> 2, R = I & 3;
+                        const bool carry = R == 0 ? false : R == 1 ? c3 : R == 2 ? c2 : c1;
+                        const u32 off = carry ? ((G + 1) % 3) * 1024u : (G % 3) * 1024u;
+                        const u32x4 d = *(const u32x4 *)(mine + off + kq[R]);
+                        if (!COPY) out.template feed<I>(h_pass8n(d, tx), ty);
+                        else if constexpr (I >= 2 && I < 10)
+                            out.template emit<I - 2>((u32x2){ __builtin_amdgcn_alignbyte(d.y, d.x, 2), __builtin_amdgcn_alignbyte(d.z, d.y, 2) });
+                    });
+                }
+            };
+            // (one loop over both lists: one copy of the pass's code)
+            for (int k = 0; k < 2; k++) luma_pass(k ? s_whole : s_plain, k ? nW : nP, k != 0);
+            for (int k = 0; k < 2; k++) chroma_pass(k ? s_cwhole : s_cplain, k ? nCW : nCP, k != 0);
         } else {
-        // Luma: 32 macroblocks x 2 strips
-        for (int i0 = 0; i0 < nP; i0 += 32) {
-            const int mi = i0 + (lane >> 1), s = lane & 1;
-            if (mi < nP) {
-                const Mb m = mb_of(s_plain[mi]);
-                const u32 mvw = mvs[m.idx * 16];
-                int mrow = sext16(mvw), mcol = hi16(mvw);
-                if ((m.w0 >> 24) & VP8IR_MB_CLAMP) clamp_luma_mv(mrow, mcol, m.e_left, m.e_right, m.e_top, m.e_bottom);
-                const Taps tx = load_taps(bil, mcol & 7), ty = load_taps(bil, mrow & 7);
-                strip8<16>(luma_src(W8(), m, m.c * 16 + (mcol >> 3) - 2 + 8 * s, m.r * 16 + (mrow >> 3) - 2), tx, ty, m.tile, s);
+            // Luma: 32 macroblocks x 2 strips
+            for (int i0 = 0; i0 < nP; i0 += 32) {
+                const int mi = i0 + (lane >> 1), s = lane & 1;
+                if (mi < nP) {
+                    const Mb m = mb_of(s_plain[mi]);
+                    const Taps tx = load_taps(bil, m.mcol & 7), ty = load_taps(bil, m.mrow & 7);
+                    strip8<16>(luma_src(W8(), m, m.c * 16 + (m.mcol >> 3) - 2 + 8 * s, m.r * 16 + (m.mrow >> 3) - 2), tx, ty, m.tile, s);
+                }
             }
-        }
-        // chroma: 32 macroblocks x 2 planes; the MV from the CLAMPED luma MV (reconinter.c:419-424)
-        for (int i0 = 0; i0 < nP; i0 += 32) {
-            const int mi = i0 + (lane >> 1), pl = lane & 1;
-            if (mi < nP) {
-                const Mb m = mb_of(s_plain[mi]);
-                const u32 mvw = mvs[m.idx * 16];
-                int mrow = sext16(mvw), mcol = hi16(mvw);
-                if ((m.w0 >> 24) & VP8IR_MB_CLAMP) clamp_luma_mv(mrow, mcol, m.e_left, m.e_right, m.e_top, m.e_bottom);
-                mrow = (short)(mrow + (1 | (mrow >> 31)));
-                mcol = (short)(mcol + (1 | (mcol >> 31)));
-                mrow /= 2; mcol /= 2;
-                if (fullpix) { mrow &= ~7; mcol &= ~7; }
-                const Taps tx = load_taps(bil, mcol & 7), ty = load_taps(bil, mrow & 7);
-                strip8<8>(chroma_src(W8(), m, pl, m.c * 8 + (mcol >> 3) - 2, m.r * 8 + (mrow >> 3) - 2), tx, ty, m.tile + 256 + 32 * pl, 0);
+            // ... whose vector has no fraction: copied (memory safety as in luma_src: twelve bytes a row inside the plane and its border)
+            for (int i0 = 0; i0 < nW; i0 += 32) {
+                const int mi = i0 + (lane >> 1), s = lane & 1;
+                if (mi < nW) {
+                    const Mb m = mb_of(s_whole[mi]);
+                    const int x = max(-32, min(m.c * 16 + (m.mcol >> 3) + 8 * s, g.aligned_w + 32 - 12)), y = max(-32, min(m.r * 16 + (m.mrow >> 3), g.aligned_h + 32 - 16));
+                    copy_strip8<16>(m.ref + g.y_off + (long)y * g.y_stride + x, g.y_stride, m.tile, s);
+                }
             }
-        }
+            // chroma: 32 macroblocks x 2 planes
+            for (int i0 = 0; i0 < nCP; i0 += 32) {
+                const int mi = i0 + (lane >> 1), pl = lane & 1;
+                if (mi < nCP) {
+                    const Mb m = mb_of(s_cplain[mi]);
+                    const Taps tx = load_taps(bil, m.ccol & 7), ty = load_taps(bil, m.crow & 7);
+                    strip8<8>(chroma_src(W8(), m, pl, m.c * 8 + (m.ccol >> 3) - 2, m.r * 8 + (m.crow >> 3) - 2), tx, ty, m.tile + 256 + 32 * pl, 0);
+                }
+            }
+            for (int i0 = 0; i0 < nCW; i0 += 32) {
+                const int mi = i0 + (lane >> 1), pl = lane & 1;
+                if (mi < nCW) {
+                    const Mb m = mb_of(s_cwhole[mi]);
+                    const int x = max(-16, min(m.c * 8 + (m.ccol >> 3), g.aligned_w / 2 + 16 - 12)), y = max(-16, min(m.r * 8 + (m.crow >> 3), g.aligned_h / 2 + 16 - 8));
+                    copy_strip8<8>(m.ref + (pl ? g.v_off : g.u_off) + (long)y * g.uv_stride + x, g.uv_stride, m.tile + 256 + 32 * pl, 0);
+                }
+            }
         }
         // ---- SPLITMV: build_inter4x4_predictors_mb, a 4x4 block per lane (partitions of 8x8 / 16x8 / 8x16 carry their MV in every
         // block they cover: the filters are the same per pixel).  Luma: 4 macroblocks x 16 blocks

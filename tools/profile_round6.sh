@@ -4,6 +4,7 @@
 #   tools/profile_round6.sh TAG sq [jobs]           SQ instruction / wait counters of the same launches
 #   tools/profile_round6.sh TAG ta [jobs]           texture-addresser / vector-cache counters
 #   tools/profile_round6.sh TAG fetch|write [jobs]  HBM traffic
+#   tools/profile_round6.sh TAG whole_sq|whole_fetch [jobs]   the same counters on a stream of whole-pixel vectors (tools/whole_pixel_time.py)
 #   tools/profile_round6.sh TAG kt_bench            kernel trace of the bench command + the same command unprofiled
 #   tools/profile_round6.sh TAG kt_chain [jobs]     kernel trace of the chained launches
 cd "$GRAFT_REPO_ROOT" || exit 1
@@ -26,6 +27,8 @@ sq2)   pmc inter_sq2_$NJ $NMB $R/tools/inter_chain_time.py $NJ 1 -- SQ_INSTS_VME
 ta)    pmc inter_ta_$NJ $NMB $R/tools/inter_chain_time.py $NJ 1 -- TA_TA_BUSY_sum TA_BUSY_avr TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum ;;
 fetch) pmc inter_fetch_$NJ $NMB $R/tools/inter_chain_time.py $NJ 1 -- FETCH_SIZE ;;
 write) pmc inter_write_$NJ $NMB $R/tools/inter_chain_time.py $NJ 1 -- WRITE_SIZE ;;
+whole_sq)    pmc whole_sq1_$NJ $NMB $R/tools/whole_pixel_time.py $NJ 1 -- SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY ;;
+whole_fetch) pmc whole_fetch_$NJ $NMB $R/tools/whole_pixel_time.py $NJ 1 -- FETCH_SIZE ;;
 kt_chain)
     timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_chain -- python3 $R/tools/inter_chain_time.py $NJ 4 > $O/kt_chain.log 2>&1; echo "kt_chain rc=$?" >> $O/summary.txt
     f=$(find $O/kt_chain -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/for_profiles/${TAG}_kt_chain${NJ}_kernel_stats.csv
