@@ -347,7 +347,9 @@ struct TileSrc {
 template <int NOUT, class SRC>
 __device__ __forceinline__ void strip(const SRC &src, const Taps &tx, const Taps &ty, g_u8p dst, int dstride, int dhalf)
 {
-    constexpr int NIN = NOUT + 5, AHEAD = NIN < 8 ? NIN : 8;
+    // (the tile reader's rows are two loads and nine registers each: five of them in flight keep the kernel, whose passes for one
+    // motion vector want their registers for other things, from spilling)
+    constexpr int NIN = NOUT + 5, WANT = SRC::PIN ? 5 : 8, AHEAD = NIN < WANT ? NIN : WANT;
     typename SRC::Raw q[AHEAD];
 #pragma unroll
     for (int i = 0; i < AHEAD; i++) q[i] = src.issue(i);
@@ -642,12 +644,13 @@ __device__ __forceinline__ void clamp_chroma_mv(int &row, int &col, int e_left, 
 template <bool TILES>
 __device__ __forceinline__ void inter_pred(const DevJob *__restrict__ jobs, int njobs, DevGeom g, int upf)
 {
-    __shared__ u32 s_w0a[4][64], s_rca[4][64], s_mva[4][64], s_cmva[4][64];
+    // (the tile reader's workgroup has to stay under a third of a CU's LDS -- 54,613 bytes -- for three waves per SIMD)
+    __shared__ u32 s_rca[4][64], s_mva[4][64], s_cmva[4][64];
     __shared__ unsigned char s_lista[4][5][64];
     __shared__ __attribute__((aligned(16))) u32 s_ringa[TILES ? 4 : 1][TILES ? 3072 : 4];      // (the tile reader's rows on their way from loading to filtering lanes)
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     u32 *const ring = s_ringa[TILES ? wv : 0];
-    u32 *const s_w0 = s_w0a[wv], *const s_rc = s_rca[wv], *const s_mv = s_mva[wv], *const s_cmv = s_cmva[wv];
+    u32 *const s_rc = s_rca[wv], *const s_mv = s_mva[wv], *const s_cmv = s_cmva[wv];
     // the unit's macroblocks by what their prediction takes: one vector with a fraction / without one (luma), the same for the chroma
     // vector derived from it, SPLITMV
     unsigned char *const s_plain = s_lista[wv][0], *const s_whole = s_lista[wv][1], *const s_cplain = s_lista[wv][2],
@@ -698,8 +701,8 @@ __device__ __forceinline__ void inter_pred(const DevJob *__restrict__ jobs, int 
 #pragma unroll
         for (int k = 0; k < 5; k++) { bal[k] = __builtin_amdgcn_ballot_w64(is_l[k]); cnt[k] = __builtin_popcountll(bal[k]); }
         wave_lds_sync();                                    // the previous unit's readers are done
-        s_w0[lane] = w0_l;
-        s_rc[lane] = ((u32)r_l << 16) | (u32)c_l;
+        // row << 20 | column << 8 | vectors to be clamped << 2 | reference frame (a frame has at most 1024 x 1024 macroblocks)
+        s_rc[lane] = ((u32)r_l << 20) | ((u32)c_l << 8) | (((w0_l >> 24) & VP8IR_MB_CLAMP) ? 4u : 0u) | ((w0_l >> 16) & 3u);
         s_mv[lane] = mv_l; s_cmv[lane] = cmv_l;
 #pragma unroll
         for (int k = 0; k < 5; k++)
@@ -715,17 +718,17 @@ __device__ __forceinline__ void inter_pred(const DevJob *__restrict__ jobs, int 
         wave_lds_sync();
 
         // what a lane needs to know about macroblock `li` of the unit (mrow / mcol, crow / ccol: its one vector, luma / chroma form)
-        struct Mb { int r, c; u32 w0; int mrow, mcol, crow, ccol; long idx; int e_left, e_right, e_top, e_bottom; g_cu8p ref; g_u8p tile; };
+        struct Mb { int r, c; bool clamp; int mrow, mcol, crow, ccol; long idx; int e_left, e_right, e_top, e_bottom; g_cu8p ref; g_u8p tile; };
         auto mb_of = [&](int li) {
             Mb m;
             m.idx = (long)u * 64 + li;
             const u32 rc = s_rc[li], mv = s_mv[li], cmv = s_cmv[li];
-            m.r = (int)(rc >> 16); m.c = (int)(rc & 0xffffu);
-            m.w0 = s_w0[li];
+            m.r = (int)(rc >> 20); m.c = (int)((rc >> 8) & 0xfffu);
+            m.clamp = (rc & 4u) != 0;
             m.mrow = sext16(mv); m.mcol = hi16(mv); m.crow = sext16(cmv); m.ccol = hi16(cmv);
             m.e_left = -((m.c * 16) << 3); m.e_right = ((cols - 1 - m.c) * 16) << 3;
             m.e_top = -((m.r * 16) << 3); m.e_bottom = ((rows - 1 - m.r) * 16) << 3;
-            const int rf = (m.w0 >> 16) & 3;
+            const int rf = (int)(rc & 3u);
             if constexpr (TILES) m.ref = (g_cu8p)(rf == 1 ? job.ref_tile[0] : rf == 2 ? job.ref_tile[1] : job.ref_tile[2]);
             else m.ref = (g_cu8p)(rf == 1 ? job.ref[1] : rf == 2 ? job.ref[2] : job.ref[3]);
             m.tile = tiles + ((long)m.r * (cols + 1) + m.c) * VP8_TILE_BYTES;
@@ -947,7 +950,7 @@ __device__ __forceinline__ void inter_pred(const DevJob *__restrict__ jobs, int 
                 const Mb m = mb_of(s_split[mi]);
                 const u32 mvw = mvs[m.idx * 16 + b];
                 int mrow = sext16(mvw), mcol = hi16(mvw);
-                if ((m.w0 >> 24) & VP8IR_MB_CLAMP) clamp_luma_mv(mrow, mcol, m.e_left, m.e_right, m.e_top, m.e_bottom);
+                if (m.clamp) clamp_luma_mv(mrow, mcol, m.e_left, m.e_right, m.e_top, m.e_bottom);
                 const Taps tx = load_taps(bil, mcol & 7), ty = load_taps(bil, mrow & 7);
                 strip<4>(luma_src(W4(), m, m.c * 16 + 4 * (b & 3) + (mcol >> 3) - 2, m.r * 16 + 4 * (b >> 2) + (mrow >> 3) - 2), tx, ty,
                          m.tile + 64 * (b >> 2) + 4 * (b & 3), 16, 0);
@@ -968,7 +971,7 @@ __device__ __forceinline__ void inter_pred(const DevJob *__restrict__ jobs, int 
                 mcol += 4 + ((mcol >> 31) << 3);
                 mrow /= 8; mcol /= 8;
                 if (fullpix) { mrow &= ~7; mcol &= ~7; }
-                if ((m.w0 >> 24) & VP8IR_MB_CLAMP) clamp_chroma_mv(mrow, mcol, m.e_left, m.e_right, m.e_top, m.e_bottom);
+                if (m.clamp) clamp_chroma_mv(mrow, mcol, m.e_left, m.e_right, m.e_top, m.e_bottom);
                 const Taps tx = load_taps(bil, mcol & 7), ty = load_taps(bil, mrow & 7);
                 strip<4>(chroma_src(W4(), m, pl, m.c * 8 + 4 * (blk & 1) + (mcol >> 3) - 2, m.r * 8 + 4 * (blk >> 1) + (mrow >> 3) - 2), tx, ty,
                          m.tile + 256 + 32 * pl + 64 * (blk >> 1) + 4 * (blk & 1), 8, 0);
