@@ -21,7 +21,8 @@
  * multiple of B): the entropy decoder takes E frames per launch and the pixel path decodes them B at a time -- more frames in
  * flight (frames in flight over the time of the largest is what the entropy decoder's rate is; 24,576 is what the device holds
  * at once, vp8hip_entropy.hip).  The E slots hold records and vectors only and the blocks of a launch come out of ONE pool
- * (vp8hip_configure_pooled; --pool-mb M sets its size, by default what the largest launch is expected to need): a frame in
+ * (vp8hip_configure_pooled; --pool-mb M sets its size, by default what the largest launch is expected to need; a launch that finds
+ * the pool empty ends the attempt, and the work is run again with twice the pool, up to three times: pooled_attempts): a frame in
  * flight costs what it needs, not the worst case.  With --no-download the launch's frames are hashed in one go (E frame buffers,
  * as tiles), beside the next launch of the entropy decoder.  Frames the device reports as cut short (vp8hip_entropy_status) are
  * counted and named on stderr, as the host feeder's *corrupt would.
@@ -215,18 +216,47 @@ static void take_digests(const batch_ref *br)
 {
     for (int i = 0; i < br->n; i++) memcpy(g_digest[run_index(br->first + i)], g_dig[br->b & 1] + 16 * (size_t)i, 16);
 }
+#define EXIT_POOL_STARVED 75         /* (pooled_attempts, below) */
 /* the status words of an entropy launch (set `set`, n frames from run position `first` on), once its copy has landed */
 static void take_status(int set, long first, int n)
 {
     for (int i = 0; i < n; i++) {
         if (g_ent_status[set][i] & 2u) {
-            fprintf(stderr, "frame %ld found the block pool (%zu MB) empty: raise --pool-mb or lower --entropy-batch\n", run_index(first + i) + 1, g_pool_bytes >> 20);
-            exit(EXIT_FAILURE);
+            /* the launch's frames were decoded from half an IR: nothing of this attempt is kept -- the supervising process runs the
+               work again with twice the pool (pooled_attempts) */
+            fprintf(stderr, "frame %ld found the block pool (%zu MB) empty\n", run_index(first + i) + 1, g_pool_bytes >> 20);
+            fflush(NULL);
+            _exit(EXIT_POOL_STARVED);
         }
         if (g_ent_status[set][i] & 1u) {
             if (g_corrupt++ < 8) fprintf(stderr, "frame %ld: a partition ended early (corrupt)\n", run_index(first + i) + 1);
         }
     }
+}
+
+/* --entropy-batch: the block pool is sized from the stream (or by --pool-mb), and a launch that finds it empty has decoded some of
+   its frames from half an IR.  The work therefore runs in a CHILD process (forked before anything touches the device); a child that
+   ends with EXIT_POOL_STARVED is run again with twice the pool, up to three times.  Returns in the child, with the factor its pool
+   is to be scaled by; the parent never returns. */
+static size_t pooled_attempts(void)
+{
+    size_t scale = 1;
+    for (int attempt = 0; attempt < 4; attempt++, scale *= 2) {
+        fflush(NULL);
+        const pid_t pid = fork();
+        if (pid < 0) { fprintf(stderr, "fork failed\n"); exit(EXIT_FAILURE); }
+        if (pid == 0) return scale;
+        int st = 0;
+        if (waitpid(pid, &st, 0) < 0) { fprintf(stderr, "waitpid failed\n"); exit(EXIT_FAILURE); }
+        if (WIFEXITED(st) && WEXITSTATUS(st) == EXIT_POOL_STARVED && attempt < 3) {
+            fprintf(stderr, "the block pool was too small: decoding again with a pool %zu times the size\n", 2 * scale);
+            continue;
+        }
+        if (WIFEXITED(st) && WEXITSTATUS(st) == EXIT_POOL_STARVED)
+            fprintf(stderr, "the block pool is still too small at %zu times its size: raise --pool-mb or lower --entropy-batch\n", scale);
+        exit(WIFEXITED(st) ? WEXITSTATUS(st) : EXIT_FAILURE);
+    }
+    exit(EXIT_FAILURE);
 }
 
 static double now_s(void)
@@ -536,6 +566,7 @@ int main(int argc, char **argv)
     const int unit = g_ebatch ? g_ebatch : g_batch;            /* frames per entropy launch */
 
     /* ---- device and host state */
+    const size_t pool_scale = g_ebatch ? pooled_attempts() : 1;
     int device = -1;
     if (getenv("VP8HIP_DEVICE")) device = atoi(getenv("VP8HIP_DEVICE"));
     if (vp8hip_create(device, &g_hip)) DIE("vp8hip_create: %s (no CPU fallback)", vp8hip_last_error(NULL));
@@ -591,6 +622,11 @@ int main(int argc, char **argv)
                 if (pool > most) pool = most;
             }
             if (pool_mb > 0) pool = (size_t)pool_mb << 20;
+            pool *= pool_scale;                      /* (an attempt after one that found the pool empty: pooled_attempts) */
+            {
+                const size_t most = ((size_t)0xffffffffu / (chunk / 32) - 1) * chunk;
+                if (pool > most) pool = most;
+            }
             g_pool_bytes = pool;
             /* frames that stay on the device are hashed a launch at a time (E frame buffers, tiles only); downloads go B at a time */
             HIP(vp8hip_configure_pooled(g_hip, g_width, g_height, no_download ? g_ebatch : 2 * g_batch, g_ebatch, pool));

@@ -6,7 +6,7 @@ import subprocess
 
 import pytest
 
-from vp8_testlib import FIXTURES, GOLDEN, ROOT, ivf_path
+from vp8_testlib import FIXTURES, GOLDEN, ROOT, golden_md5, ivf_path
 
 pytestmark = pytest.mark.gpu
 BIN = os.path.join(ROOT, "libvpx.opencl_amd", "bin")
@@ -202,7 +202,22 @@ def test_written_inter_streams_through_the_tools(tmp_path):
 
 def test_batch_md5_block_pool_too_small(tmp_path):
     """--entropy-batch: the blocks of a launch come out of one pool (vp8hip_configure_pooled); a pool that cannot hold them is reported
-    by the frames that found it empty, and the tool stops instead of hashing frames decoded from half an IR."""
+    by the frames that found it empty, nothing decoded from half an IR is hashed, and the work is run again with twice the pool --
+    three times at most: a pool of 1 MB is still too small at 8 MB, and the tool gives up with an error."""
     r = subprocess.run([os.path.join(BIN, "batch_md5"), "--device-entropy", "--batch", "4", "--entropy-batch", "12", "--pool-mb", "1", "--loop", "3",
                         ivf_path("kf_1920x1080"), str(tmp_path / "o.md5")], capture_output=True, text=True)
     assert r.returncode != 0 and "found the block pool (1 MB) empty" in r.stderr, r.stderr
+    assert "found the block pool (8 MB) empty" in r.stderr and "still too small at 8 times" in r.stderr, r.stderr
+    assert not os.path.exists(tmp_path / "o.md5")
+
+
+def test_batch_md5_block_pool_doubled_until_it_holds(tmp_path):
+    """... and a pool that is too small by less than that: the first attempt's launch finds it empty, a later attempt has room, and
+    the listing is the reference decoder's (twelve 1080p key frames of the fixture need about 30 MB of blocks)."""
+    out = tmp_path / "o.md5"
+    r = subprocess.run([os.path.join(BIN, "batch_md5"), "--device-entropy", "--batch", "4", "--entropy-batch", "12", "--pool-mb", "12", "--loop", "3",
+                        ivf_path("kf_1920x1080"), str(out)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "found the block pool (12 MB) empty" in r.stderr and "decoding again with a pool" in r.stderr, r.stderr
+    gold = golden_md5("kf_1920x1080")
+    assert [ln.split()[0] for ln in open(out)] == gold * 3
