@@ -150,12 +150,17 @@ __device__ __forceinline__ void pred4x4_net(const u32x4 *sel, u32 a0, u32 a1, u3
 __device__ __forceinline__ int sext16(u32 v) { return (int)(short)(v & 0xffff); }
 __device__ __forceinline__ int hi16(u32 v) { return (int)v >> 16; }
 
-// one 1-D pass of vp8_short_idct4x4llm_c (idctllm.c:39-60 / 65-88) without the final rounding
-__device__ __forceinline__ void idct1d(int i0, int i1, int i2, int i3, int &o0, int &o1, int &o2, int &o3)
+// one 1-D pass of vp8_short_idct4x4llm_c (idctllm.c:39-60 / 65-88) without the final rounding.  The odd inputs come SHIFTED:
+// x1 = i1 << 16, x3 = i3 << 16 (a 16-bit value in the upper half of its dword -- where a packed pair holds its second element
+// anyway).  Then (i * 35468) >> 16 is the high half of the 64-bit product x * 35468, ONE v_mul_hi_i32 (floor division by 2^16, as
+// the arithmetic shift is), and i + ((i * 20091) >> 16) == (i * (65536 + 20091)) >> 16 is one more: four instructions for the two
+// rotated terms where multiply, shift, multiply, shift, add took ten (round 6: the transform is a fifth of the luma wave's time on
+// dense inter frames).
+__device__ __forceinline__ void idct1d(int i0, int x1, int i2, int x3, int &o0, int &o1, int &o2, int &o3)
 {
     const int a1 = i0 + i2, b1 = i0 - i2;
-    const int c1 = ((i1 * 35468) >> 16) - (i3 + ((i3 * 20091) >> 16));
-    const int d1 = (i1 + ((i1 * 20091) >> 16)) + ((i3 * 35468) >> 16);
+    const int c1 = __mulhi(x1, 35468) - __mulhi(x3, 65536 + 20091);
+    const int d1 = __mulhi(x1, 65536 + 20091) + __mulhi(x3, 35468);
     o0 = a1 + d1; o3 = a1 - d1; o1 = b1 + c1; o2 = b1 - c1;
 }
 
@@ -173,10 +178,13 @@ __device__ __forceinline__ void dequant_idct(const u32x4 ca, const u32x4 cb, int
         const v2s p23 = as_v2s(q[2 * col + 1]) * pk(dqac, dqac);
         int i0 = p01.x;
         if (col == 0 && dc_given) i0 = dc_in;
-        const int i1 = p01.y, i2 = p23.x, i3 = p23.y;
+        const int i2 = p23.x;
+        const int x1 = (int)(as_u32(p01) & 0xffff0000u), x3 = (int)(as_u32(p23) & 0xffff0000u);      // (the pairs' upper halves, where they are)
         int o0, o1, o2, o3;
-        idct1d(i0, i1, i2, i3, o0, o1, o2, o3);  // vertical pass: column `col`, rows 0..3
-        t[0 + col] = (short)o0; t[4 + col] = (short)o1; t[8 + col] = (short)o2; t[12 + col] = (short)o3;
+        idct1d(i0, x1, i2, x3, o0, o1, o2, o3);  // vertical pass: column `col`, rows 0..3
+        // (`short output[16]`: columns 0, 2 as sign-extended values, columns 1, 3 -- the next pass's odd inputs -- shifted up, which truncates too)
+        if (col & 1) { t[0 + col] = (int)((u32)o0 << 16); t[4 + col] = (int)((u32)o1 << 16); t[8 + col] = (int)((u32)o2 << 16); t[12 + col] = (int)((u32)o3 << 16); }
+        else { t[0 + col] = (short)o0; t[4 + col] = (short)o1; t[8 + col] = (short)o2; t[12 + col] = (short)o3; }
     }
 #pragma unroll
     for (int row = 0; row < 4; row++) {
