@@ -307,7 +307,16 @@ __device__ __forceinline__ v2s lf_keep(v2s f, v2u mask)
 __device__ __forceinline__ v2s add3w(v2s f, v2s qs0, v2s ps0)
 {
     const v2s w = subs(qs0, ps0);
+#ifdef LF_ADD3_STEPWISE      // (through round 5: three saturating adds)
     return adds(adds(adds(f, w), w), w);
+#else
+    // ONE saturation of the exact sum f + 3 w (v_pk_mad_i16 ... clamp: the multiply-add is exact, the clamp works on its result): where
+    // w itself was saturated 3 w lies beyond the range by more than any f brings back, so the result is the clamp of the exact sum
+    // either way -- which is what the reference computes (loopfilter_filters.c:66, 176)
+    u32 d;
+    asm("v_pk_mad_i16 %0, %1, %2, %3 op_sel_hi:[1,0,1] clamp" : "=v"(d) : "v"(as_u32(w)), "s"(3u), "v"(as_u32(f)));
+    return as_v2s(d);
+#endif
 }
 
 // vp8_loop_filter_c (loopfilter_filters.c:51-95): inner edges, modifies p1 p0 q0 q1
