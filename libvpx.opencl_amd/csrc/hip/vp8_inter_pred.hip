@@ -18,9 +18,14 @@
 //   * both passes always run, as in the reference's C filters (filter.c:95-128): a whole-pixel offset has the taps {0,0,128,0,0,0},
 //     which make a pass the identity, and the bilinear filters of versions 1-3 are the six-tap arithmetic with the taps
 //     {0,0,128-16f,16f,0,0} (the same sums, the same rounding; the clamp never binds) -- one code path for every profile;
-//   * a wave takes 64 consecutive macroblocks of a frame, sorts them by ballot into those with one motion vector and the
-//     SPLITMV ones (intra macroblocks drop out), and works through the two lists 32 (luma strips; then chroma strips) resp.
-//     4 / 8 macroblocks (luma / chroma 4x4 blocks) at a time, all lanes busy on the same code.
+//   * a wave takes 64 consecutive macroblocks of a frame, sorts them by ballot into those with one motion vector -- with a fraction
+//     (filtered) or without (copied: the reference's vp8_copy_mem branch, reconinter.c:402-417; round 6), luma and chroma apart -- and
+//     the SPLITMV ones (intra macroblocks drop out), and works through the lists 32 (luma strips; then chroma strips) resp. 4 / 8
+//     macroblocks (luma / chroma 4x4 blocks) at a time, all lanes busy on the same code;
+//   * the reference frames are read as border-extended raster frames (vp8_inter_pred_kernel) or as the tiles a large launch left
+//     (vp8_inter_pred_tiles_kernel): there the macroblocks with one vector fetch their source windows TOGETHER, four lanes a 64-byte
+//     sector, and hand the rows -- normalised, edges replicated -- to the filtering lanes through LDS (WinGeo; round 6), the 4x4
+//     blocks of SPLITMV macroblocks read per lane (TileSrc; round 5).
 //
 // Output: the prediction of macroblock (r, c) in ITS tile of the job's scratch frame (DevJob::tile, the key-frame kernels'
 // rows x (cols + 1) tiles of VP8_TILE_BYTES): luma rows at 16 y; chroma in the arrangement the tiles' chroma has -- U rows 0..3
@@ -36,15 +41,8 @@
 #ifndef IP_WAVES
 #define IP_WAVES 4        // (five or six waves per SIMD only fit with spills: 9.9 / 10.0 ms against 9.1-9.6)
 #endif
-#ifndef IP_TILE_ALIGNED
-#define IP_TILE_ALIGNED 1 // the tile reader's loads start at a row piece (16 / 8 bytes aligned) and the dwords are picked by selects; 0: they start at
-                          // the first dword needed (4-byte aligned) and fewer selects put the pieces together
-#endif
-#ifndef IP_TILE_PAIRS
-#define IP_TILE_PAIRS 1   // the tile reader's chroma strips fetch two rows a load (TileSrc::PAIRED)
-#endif
 #ifndef IP_WAVES_TILES
-#define IP_WAVES_TILES 3  // (the tile reader's rows in flight are two loads each, and a strip carries its two column arrangements)
+#define IP_WAVES_TILES 3  // (the tile reader: 12 KB of LDS a wave for the rows on their way from loading to filtering lanes)
 #endif
 
 namespace {
@@ -137,7 +135,7 @@ template <int NDW>
 struct RasterSrc {
     typedef typename VecOf<NDW>::T Vec;
     typedef typename VecOf<NDW>::TU Raw;
-    static constexpr bool PIN = false, PAIRED = false;
+    static constexpr bool PIN = false;
     g_cu8p rp; int stride; u32 sh;
     // src = the pixel two left of and two above the strip's first one in the reference plane
     __device__ __forceinline__ RasterSrc(g_cu8p src, int stride_) : stride(stride_) { sh = (u32)(unsigned long)src & 3u; rp = src - sh; }
@@ -145,44 +143,33 @@ struct RasterSrc {
     __device__ __forceinline__ Vec finish(const Raw &r, int) const { return r; }
 };
 
-// TILES: the reference frame as a large launch left it (macroblock-window tiles, vp8_keyframe_simt.hip KT_*; round 5) -- n streams
-// decoded in lock step predict every launch from what the launch before wrote, and the tiled -> raster pass + the border kernel in
-// front of every launch were 15 of its 67 ms.  A tile row piece is 16 (chroma: 8) bytes of ONE pixel row, the tile of the next
-// macroblock 384 bytes on; rows 0..11 (chroma 0..3) of a macroblock row stand in the macroblocks' WINDOWS, four pixels to the left
-// (pixel x at byte (x + 4) & 15 of tile (x + 4) >> 4), rows 12..15 (4..7) macroblock-aligned.  So a row of a strip -- 13 or 9
-// pixels from any x -- is two loads, the tail of one tile's piece and the head of the next tile's (chroma strips eight wide: three
-// pieces), put together by selects, and which of the two column arrangements applies is decided row by row.  There are no
-// borders: rows and columns beyond the frame are the frame's last (vp8_extend_mb_row / vp8_yv12_extend_frame_borders replicate,
-// extend.c:160-185, yv12extend.c:24-90) -- a clamped row index, and for the few strips that reach past the left or right
-// edge a fix-up of the loaded bytes (`edge`, taken by a wave only when one of its lanes needs it).  Motion vectors that point
-// further out than any border (no conforming stream has them: reconinter.c:348-382 clamps) read replicated pixels where the raster
-// kernel reads whatever the clamped address holds: both are memory-safe, neither is specified.
+// TILES, for the 4x4 blocks of SPLITMV macroblocks (macroblocks with one vector fetch their windows together: WinGeo, further down).
+// The reference frame as a large launch left it (macroblock-window tiles, vp8_keyframe_simt.hip KT_*; round 5) -- n streams
+// decoded in lock step predict every launch from what the launch before wrote.  A tile row piece is 16 (chroma: 8) bytes of ONE
+// pixel row, the tile of the next macroblock 384 bytes on; rows 0..11 (chroma 0..3) of a macroblock row stand in the macroblocks'
+// WINDOWS, four pixels to the left (pixel x at byte (x + 4) & 15 of tile (x + 4) >> 4), rows 12..15 (4..7) macroblock-aligned.  So a
+// row of a block's strip -- nine pixels from any x -- is two loads, the tail of one tile's piece and the head of the next tile's,
+// put together by selects, and which of the two column arrangements applies is decided row by row.  There are no borders: rows and
+// columns beyond the frame are the frame's last (vp8_extend_mb_row / vp8_yv12_extend_frame_borders replicate, extend.c:160-185,
+// yv12extend.c:24-90) -- a clamped row index, and for the few strips that reach past the left or right edge a fix-up of the loaded
+// bytes.  Motion vectors that point further out than any border (no conforming stream has them: reconinter.c:348-382 clamps) read
+// replicated pixels where the raster kernel reads whatever the clamped address holds: both are memory-safe, neither is specified.
 template <bool CHROMA, int NDW>
 struct TileSrc {
+    static_assert(NDW == 3, "strips eight pixels wide go through WinGeo");
     typedef typename VecOf<NDW>::T Vec;
-    static constexpr int NPX = NDW == 4 ? 13 : 9;               // pixels a row needs
+    static constexpr int NPX = 9;                               // pixels a row needs
     static constexpr int LGR = CHROMA ? 3 : 4, RMASK = (1 << LGR) - 1, BOT0 = CHROMA ? 4 : 12;     // pixel rows per tile row; first macroblock-aligned one
-    struct Raw { u32 e[CHROMA ? 5 : (IP_TILE_ALIGNED ? 8 : 2 * NDW)]; int jsel; };
+    struct Raw { u32 e[CHROMA ? 5 : 8]; int jsel; };
     // (the strip keeps the scheduler from moving a row's requests: with two loads and nine registers a row in flight it sinks them down to
     // their use to save registers, and every row then waits for its own loads)
-#ifdef IP_NOPIN
-    static constexpr bool PIN = false;
-#else
     static constexpr bool PIN = true;
-#endif
     g_cu8p rowp;            // TWO tiles before the plane's first row piece in the first tile of the tile row the strip begins in
     int yy0, tlo, thi;      // the strip's first row within its tile row; rows above the plane's first / below its last count as those
     u32 rowbytes;           // bytes per tile row
     u32 colW, colB; int jW, jB;     // window rows / bottom rows: byte offset of the first load from rowp, the first dword wanted within the piece
     u32 sh;
-    // Chroma strips eight wide fetch their rows in PAIRS where no lane of the wave has a row above or below the plane (y_edge): rows
-    // 2 k, 2 k + 1 of a tile are 16 adjacent bytes, so one 16-byte load a piece serves two rows -- 21 loads a strip instead of 39, and
-    // the loads (the lines they touch) are what bounds this kernel
-    static constexpr bool PAIRED = CHROMA && NDW == 4 && IP_TILE_PAIRS;
-    struct PairRaw { u32 e[11]; int jsel; };
-    bool y_edge, odd;       // a lane of the wave clamps a row; this lane's first row is the second of its pair
-    bool any_edge, edge;    // a lane of the wave / this lane reaches past the left or right edge
-    u32 em[NDW], eselA, eselB;      // bytes to replace (per dword); v_perm selectors that splat the edge pixel out of dwords (0, 1) / (2, 3)
+    u32 em[NDW], eselA, eselB;      // bytes to replace (per dword); v_perm selectors that splat the edge pixel out of dwords (0, 1) / (2)
     // tiles: the frame's tiles + the plane's offset in a tile (0, 256 U, 288 V); W, H: the plane's size; (x0, y0): the strip's first pixel
     __device__ __forceinline__ TileSrc(g_cu8p tiles, int cols, int W, int H, int x0, int y0)
     {
@@ -191,8 +178,6 @@ struct TileSrc {
         const int ybase = yc & ~RMASK;
         yy0 = y0 - ybase; tlo = -ybase; thi = H - 1 - ybase;     // row i is row clamp(yy0 + i, tlo, thi) counted from the tile row's first
         rowp = tiles + (long)(yc >> LGR) * rowbytes - 2 * VP8_TILE_BYTES;
-        y_edge = __builtin_amdgcn_ballot_w64(y0 < 0 || y0 + (NDW == 4 ? (CHROMA ? 13 : 21) : 9) > H) != 0;
-        odd = (yy0 & 1) != 0;
         x0 = max(-64, min(x0, W + 64));
         const int xl = max(min(x0, W - 1), 1 - NPX);            // what is loaded: NPX bytes from xl on, at least one of them inside
         sh = (u32)xl & 3u;
@@ -200,15 +185,13 @@ struct TileSrc {
         const int xs = xl + 4;
         // (+ 2 tiles: rowp stands two tiles early, so that the offsets are never negative -- a strip that begins twelve pixels left of
         // the frame has its first chroma piece in tile -2, and the loads are in bounds: VP8HIP_TILE_FRONT bytes lie in front of the pool)
-        jW = (xs & (PW - 1)) >> 2; colW = (u32)(((xs >> LG) + 2) * VP8_TILE_BYTES + 4 * jW);
-        jB = (xl & (PW - 1)) >> 2; colB = (u32)(((xl >> LG) + 2) * VP8_TILE_BYTES + 4 * jB + (CHROMA ? 32 : 0));     // (chroma rows 4..7: 288 + 8 yy)
-        if (CHROMA || IP_TILE_ALIGNED) { colW -= 4 * jW; colB -= 4 * jB; }  // (from the piece's first dword)
-        edge = x0 < 0 || x0 + NPX > W;
-        any_edge = __builtin_amdgcn_ballot_w64(edge) != 0;
+        jW = (xs & (PW - 1)) >> 2; colW = (u32)(((xs >> LG) + 2) * VP8_TILE_BYTES);
+        jB = (xl & (PW - 1)) >> 2; colB = (u32)(((xl >> LG) + 2) * VP8_TILE_BYTES + (CHROMA ? 32 : 0));     // (chroma rows 4..7: 288 + 8 yy)
+        const bool edge = x0 < 0 || x0 + NPX > W;
         eselA = eselB = 0x0c0c0c0cu;
 #pragma unroll
         for (int k = 0; k < NDW; k++) em[k] = 0;
-        if (any_edge) {
+        if (__builtin_amdgcn_ballot_w64(edge) != 0) {
             // byte t of the loaded dwords is pixel x0 + t - sh (xl + t - sh where that differs, all of them replaced then)
             const bool left = x0 < 0;
             const int n = left ? min(16, (int)sh - x0) : max(0, W - x0 + (int)sh);      // left: bytes [0, n) replaced; right: [n, 16)
@@ -234,97 +217,34 @@ struct TileSrc {
         Raw r;
         r.jsel = bot ? jB : jW;
         if constexpr (!CHROMA) {
-            if constexpr (IP_TILE_ALIGNED) {
-                // this tile's row piece and what can be wanted of the next one's: dwords 0 .. jsel + NDW - 1 <= NDW + 2 of the eight.
-                // (Not a dword more: a component of a load's result that nothing reads is a register the allocator hands out again
-                // while the load is in flight, and the compiler then waits for the load -- for ALL loads -- right behind it.)
-                const u32x4 a = *(g_cu32x4p)p;
+            // this tile's row piece and what can be wanted of the next one's: dwords 0 .. jsel + NDW - 1 <= 5 of the eight.
+            // (Not a dword more: a component of a load's result that nothing reads is a register the allocator hands out again
+            // while the load is in flight, and the compiler then waits for the load -- for ALL loads -- right behind it.)
+            const u32x4 a = *(g_cu32x4p)p;
 #pragma unroll
-                for (int k = 0; k < 4; k++) r.e[k] = a[k];
-                if constexpr (NDW == 4) {
-                    // (requested also where the strip begins in its piece's first dword and has all thirteen pixels in it: skipping
-                    // it there -- a quarter of the lanes -- puts a branch with a load into the row loop, the waits behind it drain every
-                    // load in flight again, and the launch is 2 % slower)
-                    const u32x3 b = *(GLOBAL_AS const u32x3 *)(p + VP8_TILE_BYTES);
-                    r.e[4] = b.x; r.e[5] = b.y; r.e[6] = b.z; r.e[7] = 0;
-                } else {
-                    const u32x2 b = *(GLOBAL_AS const u32x2 *)(p + VP8_TILE_BYTES);
-                    r.e[4] = b.x; r.e[5] = b.y; r.e[6] = r.e[7] = 0;
-                }
-            } else {
-                typedef typename VecOf<NDW>::TU VU;
-                const Vec a = *(GLOBAL_AS const VU *)p, b = *(GLOBAL_AS const VU *)(p + VP8_TILE_BYTES - 16);
-#pragma unroll
-                for (int k = 0; k < NDW; k++) { r.e[k] = a[k]; r.e[NDW + k] = b[k]; }
-            }
+            for (int k = 0; k < 4; k++) r.e[k] = a[k];
+            const u32x2 b = *(GLOBAL_AS const u32x2 *)(p + VP8_TILE_BYTES);
+            r.e[4] = b.x; r.e[5] = b.y; r.e[6] = r.e[7] = 0;
         } else {
-            // the piece, the next tile's piece, and for the wide strip the first dword of the third
+            // the piece and the next tile's piece
             typedef GLOBAL_AS const u32x2 *g_cu32x2p;
             const u32x2 a = *(g_cu32x2p)p, b = *(g_cu32x2p)(p + VP8_TILE_BYTES);
-            r.e[0] = a.x; r.e[1] = a.y; r.e[2] = b.x; r.e[3] = b.y;
-            r.e[4] = NDW == 4 ? *(GLOBAL_AS const u32 *)(p + 2 * VP8_TILE_BYTES) : 0u;
+            r.e[0] = a.x; r.e[1] = a.y; r.e[2] = b.x; r.e[3] = b.y; r.e[4] = 0u;
         }
         return r;
     }
-    // rows 2 k - odd, 2 k + 1 - odd of the strip (PAIRED; no lane clamps a row): the pair's three pieces, both rows of each
-    __device__ __forceinline__ PairRaw issue_pair(int k) const
-    {
-        const int t = yy0 - (odd ? 1 : 0) + 2 * k;
-        const u32 yy = (u32)t & RMASK;
-        const bool bot = yy >= BOT0;
-        const u32 off = __umul24((u32)t >> LGR, rowbytes) + (bot ? colB : colW) + (yy << LGR);
-        g_cu8p p = rowp + off;
-        PairRaw r;
-        r.jsel = bot ? jB : jW;
-        const u32x4 a = *(g_cu32x4p)p, b = *(g_cu32x4p)(p + VP8_TILE_BYTES);
-        const u32x3 c = *(GLOBAL_AS const u32x3 *)(p + 2 * VP8_TILE_BYTES);
-#pragma unroll
-        for (int j = 0; j < 4; j++) { r.e[j] = a[j]; r.e[4 + j] = b[j]; }
-        r.e[8] = c.x; r.e[9] = c.y; r.e[10] = c.z;
-        return r;
-    }
-    // row i of the strip out of the pairs that can hold it: A = pair (i + 1) / 2 when the lane's first row is the second of its
-    // pair, B = pair i / 2 when it is the first -- for an even i the same pair, other half
-    __device__ __forceinline__ Vec finish_pair(const PairRaw &A, const PairRaw &B, int i) const
-    {
-        // (lo half: the pair's first row, dwords 0, 1 of every piece; hi half: dwords 2, 3)
-        const int ha = (i + 1) & 1, hb = i & 1;           // which half of A (odd lanes) / of B (even lanes) row i is
-        u32 sA[5] = { A.e[2 * ha], A.e[2 * ha + 1], A.e[4 + 2 * ha], A.e[5 + 2 * ha], A.e[8 + 2 * ha] };
-        u32 sB[5] = { B.e[2 * hb], B.e[2 * hb + 1], B.e[4 + 2 * hb], B.e[5 + 2 * hb], B.e[8 + 2 * hb] };
-        const u32 mo = odd ? 0xffffffffu : 0u;
-        u32 sv[5];
-#pragma unroll
-        for (int k = 0; k < 5; k++) sv[k] = (sA[k] & mo) | (sB[k] & ~mo);
-        const u32 m1 = (u32)-(int)(odd ? A.jsel : B.jsel);
-        Vec d;
-#pragma unroll
-        for (int k = 0; k < NDW; k++) d[k] = (sv[k + 1] & m1) | (sv[k] & ~m1);
-        const u32 ev = perm(d[1], d[0], eselA) | perm(d[3], d[2], eselB);
-#pragma unroll
-        for (int k = 0; k < NDW; k++) d[k] = (d[k] & ~em[k]) | (ev & em[k]);
-        return d;
-    }
-    // (the middle dword of a pair's third piece is never read: keeps it from looking dead while the load is in flight, see issue())
-    __device__ __forceinline__ void retire_pair(const PairRaw &r) const { asm volatile("" :: "v"(r.e[9])); }
     __device__ __forceinline__ Vec finish(const Raw &r, int) const
     {
         Vec d;
         if constexpr (!CHROMA) {
-            if constexpr (IP_TILE_ALIGNED) {
-                // dwords jsel .. jsel + NDW - 1 of the eight: a shifter of two stages, as bit selects under masks (written as
-                // `jsel & 2 ? e[k + 2] : e[k]` the compiler sees e[jsel + k] and puts the eight dwords in scratch to index them)
-                const u32 m2 = (u32)__builtin_amdgcn_sbfe((int)r.jsel, 1, 1), m1 = (u32)__builtin_amdgcn_sbfe((int)r.jsel, 0, 1);
-                u32 f[NDW + 1];
+            // dwords jsel .. jsel + NDW - 1 of the eight: a shifter of two stages, as bit selects under masks (written as
+            // `jsel & 2 ? e[k + 2] : e[k]` the compiler sees e[jsel + k] and puts the eight dwords in scratch to index them)
+            const u32 m2 = (u32)__builtin_amdgcn_sbfe((int)r.jsel, 1, 1), m1 = (u32)__builtin_amdgcn_sbfe((int)r.jsel, 0, 1);
+            u32 f[NDW + 1];
 #pragma unroll
-                for (int k = 0; k < NDW + 1; k++) f[k] = (r.e[k + 2] & m2) | (r.e[k] & ~m2);
+            for (int k = 0; k < NDW + 1; k++) f[k] = (r.e[k + 2] & m2) | (r.e[k] & ~m2);
 #pragma unroll
-                for (int k = 0; k < NDW; k++) d[k] = (f[k + 1] & m1) | (f[k] & ~m1);
-            } else {
-                // dword k comes from the first piece while k + jsel < 4 (its load began at dword jsel), then from the next tile's (that
-                // load began 16 bytes before the piece: its dword k is the piece's dword k + jsel - 4)
-#pragma unroll
-                for (int k = 0; k < NDW; k++) d[k] = k + r.jsel < 4 ? r.e[k] : r.e[NDW + k];
-            }
+            for (int k = 0; k < NDW; k++) d[k] = (f[k + 1] & m1) | (f[k] & ~m1);
         } else {
             // dwords jsel .. of the five (jsel: 0 or 1)
             const u32 m1 = (u32)-(int)r.jsel;
@@ -334,8 +254,7 @@ struct TileSrc {
         // the edge pixel out of whichever dword holds it, four times, into the bytes beyond the edge.  Unconditional -- the masks of
         // a lane that reaches past no edge are empty --: a branch in the row loop, even a wave-uniform one without a load in it,
         // makes the compiler wait for EVERY load in flight at each row (s_waitcnt vmcnt(0)), and the strip is a latency chain
-        // (14.7 ms per 4096 frames against 9.4 for the raster reader, whatever the instruction count)
-        const u32 ev = perm(d[1], d[0], eselA) | perm(NDW == 4 ? d[3] : 0u, d[2], eselB);
+        const u32 ev = perm(d[1], d[0], eselA) | perm(0u, d[2], eselB);
 #pragma unroll
         for (int k = 0; k < NDW; k++) d[k] = (d[k] & ~em[k]) | (ev & em[k]);
         return d;
@@ -467,51 +386,16 @@ __device__ __forceinline__ void strip8(const SRC &src, const Taps &tx, const Tap
 {
     constexpr int NIN = NOUT + 5, AHEAD = IP_AHEAD < NIN ? IP_AHEAD : NIN;
     Strip8Rows<NOUT> out(dst, s);
-    // source row i, its pixels in d: the horizontal pass, and from the sixth row on an output row
-    auto row = [&](auto ic, const u32x4 d) {
-        constexpr int i = decltype(ic)::value;
-        out.template feed<i>(h_pass8(d, src.sh, tx), ty);
-    };
-    auto rows_one_by_one = [&]() {
-        typename SRC::Raw q[AHEAD];
+    typename SRC::Raw q[AHEAD];
 #pragma unroll
-        for (int i = 0; i < AHEAD; i++) q[i] = src.issue(i);
-        static_for<NIN>([&](auto ic) {
-            constexpr int I = decltype(ic)::value;
-            const u32x4 d = src.finish(q[I % AHEAD], I);
-            if constexpr (I + AHEAD < NIN) q[I % AHEAD] = src.issue(I + AHEAD);
-            if constexpr (SRC::PIN) __builtin_amdgcn_sched_barrier(0);
-            row(ic, d);
-        });
-    };
-    if constexpr (SRC::PAIRED) {
-        if (!src.y_edge) {
-            // rows in pairs (TileSrc::PAIRED): pair k holds rows 2 k, 2 k + 1 for a lane whose first row is the first of its pair,
-            // rows 2 k - 1, 2 k for the others: row i wants pair i / 2 resp. (i + 1) / 2 -- pairs 0 .. NIN / 2, (NIN + 1) / 2 of them
-            // (a pair begins at an even row of its tile and so never leaves the tile row: the last one stays inside the plane as
-            // its first row does); four pairs in flight
-            constexpr int NP = (NIN + 1) / 2, PA = 4;
-            static_assert((NIN & 1) && (NIN - 1 + 1) / 2 == NP - 1, "the last row's pair is the last pair");
-            typename SRC::PairRaw q[PA];
-#pragma unroll
-            for (int k = 0; k < PA; k++) q[k] = src.issue_pair(k);
-            static_for<NIN>([&](auto ic) {
-                constexpr int I = decltype(ic)::value;
-                const u32x4 d = src.finish_pair(q[((I + 1) / 2) % PA], q[(I / 2) % PA], I);
-                // (behind an odd row pair (I - 1) / 2 is done with: its slot takes the pair four on)
-                if constexpr ((I & 1) && (I - 1) / 2 + PA < NP) {
-                    src.retire_pair(q[((I - 1) / 2) % PA]);
-                    q[((I - 1) / 2) % PA] = src.issue_pair((I - 1) / 2 + PA);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                row(ic, d);
-            });
-#pragma unroll
-            for (int k = 0; k < PA; k++) src.retire_pair(q[k]);
-            return;
-        }
-    }
-    rows_one_by_one();
+    for (int i = 0; i < AHEAD; i++) q[i] = src.issue(i);
+    // source row I: the horizontal pass, and from the sixth row on an output row
+    static_for<NIN>([&](auto ic) {
+        constexpr int I = decltype(ic)::value;
+        const u32x4 d = src.finish(q[I % AHEAD], I);
+        if constexpr (I + AHEAD < NIN) q[I % AHEAD] = src.issue(I + AHEAD);
+        out.template feed<I>(h_pass8(d, src.sh, tx), ty);
+    });
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

@@ -32,7 +32,7 @@ def _tile_only_refs(P, ctx, w, h, seed):
     return outs
 
 
-@pytest.mark.parametrize("w,h", [(16, 16), (48, 32), (176, 144), (640, 368), (1000, 40), (33, 600)])
+@pytest.mark.parametrize("w,h", [(16, 16), (32, 48), (48, 32), (176, 144), (640, 368), (1000, 40), (33, 600)])
 @pytest.mark.parametrize("version,ftype", [(0, 0), (1, 1), (2, 0), (3, 1)])
 def test_random_inter_ir_from_tiled_references(pkg, monkeypatch, w, h, version, ftype):
     P = pkg
