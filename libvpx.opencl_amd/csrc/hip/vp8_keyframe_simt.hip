@@ -988,6 +988,9 @@ __device__ __forceinline__ void kf_kernel(const DevJob *__restrict__ jobs, int n
         if (threadIdx.x == 0) (void)__hip_atomic_fetch_add(simd_word(hw, xcc), role ? 0u - 0x10000u : 0u - 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
     if (item >= nwaves) { leave(); return; }         // (cannot happen with grid = 2 * nwaves)
+#ifdef KF_ONLY_ROLE     // (timing experiments only, the frames are wrong: one role's waves alone on their SIMDs -- DESIGN 8's issue model)
+    if (role != KF_ONLY_ROLE) { leave(); return; }
+#endif
 #ifdef VP8_STAMPS
     const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
 #endif
