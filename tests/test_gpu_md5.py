@@ -165,3 +165,30 @@ def test_frames_as_packed_i420(pkg, name, copies):
             assert dig[16 * i: 16 * i + 16].tobytes().hex() == gold[i % n], i
     finally:
         ctx.close()
+
+
+def test_packed_staging_is_a_cache(pkg, monkeypatch):
+    """A digest-only fetch of a large batch of TILED frames is hashed from a packed copy (vp8_pack_i420_tiles_kernel) whose buffer the
+    context keeps -- vp8hip_memory_usage().packed_staging -- until vp8hip_release_staging gives it back (round 6: the library frees it by
+    itself when a pool finds no room beside it); with or without it the digests are the reference's."""
+    P = pkg
+    monkeypatch.setenv("VP8HIP_RECON", "simt")            # (tiles: the packed copy is made of them)
+    monkeypatch.setenv("VP8HIP_MD5_PACK_FROM", "8")
+    ctx = P.Vp8Hip(0)
+    try:
+        name, copies = "kf_640x360", 3
+        n = _decode_all(P, ctx, name, copies)
+        gold = golden_md5(name)
+        want = [gold[i % n] for i in range(copies * n)]
+        assert ctx.memory_usage()["packed_staging"] == 0
+        assert ctx.frames_md5(0, copies * n) == want
+        held = ctx.memory_usage()["packed_staging"]
+        assert held >= copies * n * 640 * 360 * 3 // 2
+        ctx.L.vp8hip_release_staging.argtypes = [__import__("ctypes").c_void_p]
+        ctx._chk(ctx.L.vp8hip_release_staging(ctx.h), "vp8hip_release_staging")
+        assert ctx.memory_usage()["packed_staging"] == 0
+        assert ctx.frames_md5(0, copies * n) == want          # (allocated again)
+        assert ctx.memory_usage()["packed_staging"] == held
+        assert ctx.frames_md5(2, 4) == want[2:6]              # (a small batch: from the tiles)
+    finally:
+        ctx.close()
