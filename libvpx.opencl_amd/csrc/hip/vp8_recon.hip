@@ -575,7 +575,27 @@ __device__ __forceinline__ void recon_body(const DevJob *__restrict__ jobs, int 
             return gran_above + (apl == 0 ? 0 : (apl == 1 ? cols * 4 + 1 : cols * 6 + 1)) + (x >> 2);
         };
         u64 gpre = 0;
-        auto process = [&](const int c, const u32 mbw, const Coefs &q, const Mv2 &mv2) __attribute__((always_inline)) {
+        // (INTER_DONE) the pixels of macroblock c this lane would have stored, where vp8_inter_mb_kernel has left them: requested a
+        // macroblock AHEAD (round 6) -- a row of a P frame is mostly such macroblocks, and a load, a granule store and an LDS
+        // turnaround in a chain per macroblock made this kernel half a millisecond for a 1080p frame with sixteen intra macroblocks
+        struct Done { u32 y0, y1, c; };
+        auto load_done = [&](int c, u32 d) -> Done {
+            Done v = { 0u, 0u, 0u };
+            if (INTER_DONE && ((half_sel(d, 0) >> 16) & 0xff) != VP8IR_INTRA_FRAME) {
+                if (tile_out) {
+                    g_cu8p t = (g_cu8p)tile_out + ((long)r * cols + c) * VP8_TILE_BYTES;
+                    v.y0 = *(g_cu32p)(t + ly0 * 16 + lx0);
+                    v.y1 = *(g_cu32p)(t + (ly0 + 8) * 16 + lx0);
+                    v.c = *(g_cu32p)(t + 256 + cpl * 64 + cy * 8 + cx0);
+                } else {
+                    v.y0 = *(g_cu32p)(dY + (long)ly0 * g.y_stride + c * 16 + lx0);
+                    v.y1 = *(g_cu32p)(dY + (long)(ly0 + 8) * g.y_stride + c * 16 + lx0);
+                    v.c = *(g_cu32p)((cpl ? dV : dU) + (long)cy * g.uv_stride + c * 8 + cx0);
+                }
+            }
+            return v;
+        };
+        auto process = [&](const int c, const u32 mbw, const Coefs &q, const Mv2 &mv2, const Done &done) __attribute__((always_inline)) {
             unsigned char *const tY = wl->tY, *const tU = wl->tU, *const tV = wl->tV;   // lambda locals: selects between them stay in registers
             const u64 gcur = gpre;
             if (XCU && r > 0 && hl < 12 && c + 1 < cols) gpre = gran_load(above_gran(c + 1));
@@ -594,8 +614,9 @@ __device__ __forceinline__ void recon_body(const DevJob *__restrict__ jobs, int 
             // ---- wait for the row above to be two MBs ahead (or finished)
             if (!XCU && r > 0) wg_wait_ge(&prog[dep_wave], (dep_seq << 16) + min(c + 2, cols));
 
-            // ---- above line -> tile row -1 (dword copies: Y x=-4..19, U/V x=-4..7)
-            if (hl < 12) {
+            // ---- above line -> tile row -1 (dword copies: Y x=-4..19, U/V x=-4..7).  A macroblock that is finished already needs
+            // neither the line nor -- spread over several CUs -- the wait for it (an intra macroblock further on waits for its own)
+            if (hl < 12 && !(XCU && elsewhere)) {
                 const int pl = hl < 6 ? 0 : (hl < 9 ? 1 : 2), i = hl - (pl == 0 ? 0 : (pl == 1 ? 6 : 9));
                 u32 v = 0x7f7f7f7fu;                 // frame row 0: everything above is 127
                 if (r > 0) {
@@ -716,17 +737,8 @@ __device__ __forceinline__ void recon_body(const DevJob *__restrict__ jobs, int 
                     outY1 = *(const u32 *)(tY + TY_AT(ly0 + 8, lx0));
                 }
             } else if (INTER_DONE) {
-                // ---- inter MB, finished by vp8_inter_mb_kernel: what this lane would have stored
-                if (tile_out) {
-                    g_cu8p t = (g_cu8p)tile_out + ((long)r * cols + c) * VP8_TILE_BYTES;
-                    outY0 = *(g_cu32p)(t + ly0 * 16 + lx0);
-                    outY1 = *(g_cu32p)(t + (ly0 + 8) * 16 + lx0);
-                    outC = *(g_cu32p)(t + 256 + cpl * 64 + cy * 8 + cx0);
-                } else {
-                outY0 = *(g_cu32p)(dY + (long)ly0 * g.y_stride + c * 16 + lx0);
-                outY1 = *(g_cu32p)(dY + (long)(ly0 + 8) * g.y_stride + c * 16 + lx0);
-                outC = *(g_cu32p)((cpl ? dV : dU) + (long)cy * g.uv_stride + c * 8 + cx0);
-                }
+                // ---- inter MB, finished by vp8_inter_mb_kernel: what this lane would have stored (load_done, a macroblock ago)
+                outY0 = done.y0; outY1 = done.y1; outC = done.c;
             } else {
                 // ---- inter MB
                 mb_inter(g, wl, (g_cu8p)(half ? jobB.ref[ref_frame & 3] : jobA.ref[ref_frame & 3]),
@@ -780,6 +792,7 @@ __device__ __forceinline__ void recon_body(const DevJob *__restrict__ jobs, int 
         u32 dA = load_desc(0), dB = cols > 1 ? load_desc(1) : 0u;
         Coefs qA = load_coefs(0, dA, skipped(dA)), qB = qA;
         Mv2 mA = load_mv(0), mB = mA;
+        Done pA = load_done(0, dA), pB = pA;
         for (int c0 = 0; c0 < cols; c0 += 2) {
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
@@ -790,9 +803,10 @@ __device__ __forceinline__ void recon_body(const DevJob *__restrict__ jobs, int 
                     if (c + 2 < cols) { if (u) dB = load_desc(c + 2); else dA = load_desc(c + 2); }
                     if (c + 1 < cols) {
                         const bool sk = skipped(dn);
-                        if (u) { qA = load_coefs(c + 1, dn, sk); mA = load_mv(c + 1); } else { qB = load_coefs(c + 1, dn, sk); mB = load_mv(c + 1); }
+                        if (u) { qA = load_coefs(c + 1, dn, sk); mA = load_mv(c + 1); pA = load_done(c + 1, dn); }
+                        else { qB = load_coefs(c + 1, dn, sk); mB = load_mv(c + 1); pB = load_done(c + 1, dn); }
                     }
-                    process(c, d, u ? qB : qA, u ? mB : mA);
+                    process(c, d, u ? qB : qA, u ? mB : mA, u ? pB : pA);
                 }
             }
         }
