@@ -377,6 +377,42 @@ def small_run(P, device, fixture, W, H, n, steps=3):
         ctx.close()
 
 
+def single_inter_latency(P, device, name="p_1920x1080"):
+    """One INTER frame per launch -- a single stream through vpx_codec_decode: vp8_inter_mb_kernel (every inter macroblock on its own) +
+    the row-ordered kernels for the intra macroblocks and the loop filter --, launch to synchronisation, averaged over the fixture's P
+    frames; every shown frame's MD5 checked."""
+    from vp8_testlib import ivf_path, golden_md5
+    w, h, frames = P.read_ivf(ivf_path(name))
+    gold = golden_md5(name)
+    ctx = P.Vp8Hip(device)
+    try:
+        ctx.configure(w, h, 4, 1)
+        n, total, ok = 0, 0.0, True
+        for it in range(3):
+            parser = P.Parser()
+            shown = 0
+            for data in frames:
+                hdr = ctx.parse_into_slot(parser, data, 0)
+                ctx.upload(0)
+                r = parser.refs
+                ctx.sync()
+                t = time.perf_counter()
+                ctx.decode([(0, r.new_idx, (r.lst_idx, r.gld_idx, r.alt_idx) if hdr.frame_type else None)], P.STAGE_ALL)
+                ctx.sync()
+                if hdr.frame_type and it:
+                    total += time.perf_counter() - t
+                    n += 1
+                new = r.new_idx
+                parser.swap(hdr)
+                if hdr.show_frame:
+                    ok = ok and P.planes_md5(*ctx.download_planes(new)) == gold[shown]
+                    shown += 1
+            parser.close()
+        return {"ms": round(total / n * 1e3, 3), "frames": n, "md5_ok": bool(ok), "stream": name}
+    finally:
+        ctx.close()
+
+
 def load_stream(P, ctx, fixture, F, lo):
     """Slots 0 .. F-1 of `ctx` <- frames lo .. lo+F-1 of the looped stream (frame i of the stream is source frame i mod nsrc;
     every key frame is independently decodable).  Host feeder once per source frame, device-to-device copies for the rest."""
@@ -721,6 +757,12 @@ def main():
         ctx.sync()
         latency_ms = (time.perf_counter() - tl) / 20 * 1e3
     ctx.close()
+    inter_latency = None
+    if rank == 0 and world == 1 and args.workload == "1080p":
+        try:
+            inter_latency = single_inter_latency(P, local_rank)
+        except Exception as ex:      # noqa: BLE001 - a probe, not the benchmark
+            inter_latency = {"error": repr(ex)}
     if rank == 0:
         # what the HBM system delivers to a plain device-to-device copy on this box (SURVEY.md 8d asks for the probe)
         a = torch.empty(2 << 30, dtype=torch.uint8, device="cuda")
@@ -791,6 +833,7 @@ def main():
                 "rank_startup_s": {"host_feeder_source_frames": round(feed_s, 3), "slot_copies_device_to_device": round(copy_s, 3),
                                    "note": f"rank 0, outside the timed region: {F} slots filled from {nsrc} source frames (vp8hip_ir_copy)"},
                 "single_frame_launch_ms": round(latency_ms, 3),
+                "single_frame_launch_inter": inter_latency,
                 "consumers": consumers,
                 "with_raster_form": with_raster,
             },
